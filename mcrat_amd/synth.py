@@ -1,0 +1,404 @@
+"""Synthetic hydro frames and photon sets for the BASELINE.json configurations.
+
+No FLASH/PLUTO data ships with the reference, so every input is generated from a
+seed.  A *frame* is a dict holding the fields of the
+reference's ``struct hydro_dataframe`` (Src/mcrat.h:194-244) in the form its
+readers leave them (cgs units, velocities in units of c); a *photon set* is a dict
+of SoA columns named after ``struct photon`` (Src/mcrat.h:142-171).
+
+The fluid fields follow the reference's analytic outflows
+(Src/analytic_outflows.c:70-145 spherical wind, :147-236 Lundman+14 structured
+jet) and the photons follow the rules of photonInjection (Src/mclib.c:9-300:
+slab selection, n_i ~ V_i Gamma_i T_i^3, Bjorkman-Wood black-body frequencies,
+isotropic comoving directions boosted to the lab, uniform in-cell positions) with
+a fixed total and equal weights.  These are input generators, not part of the
+accelerated path; they are plain numpy.
+"""
+import numpy as np
+
+# Src/mclib.c:4-5 (verbatim values)
+A_RAD = 7.56e-15
+C_LIGHT = 2.99792458e10
+PL_CONST = 6.6260755e-27
+K_B = 1.380658e-16
+M_P = 1.6726231e-24
+THOM_X_SECT = 6.65246e-25
+M_EL = 9.1093879e-28
+
+CARTESIAN, SPHERICAL, CYLINDRICAL, POLAR = 0, 1, 2, 3
+TWO, TWO_POINT_FIVE, THREE = 0, 1, 2
+
+PHOTON_F8_FIELDS = ("p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3",
+                    "r0", "r1", "r2", "s0", "s1", "s2", "s3", "num_scatt", "weight",
+                    "time_to_scatter", "total_optical_depth")
+
+
+# --------------------------------------------------------------------------- meshes
+def _finish_frame(frame):
+    """fill r, theta as fillHydroCoordinateToSpherical does (Src/geometry.c:66-106,156-174)."""
+    dims, geom = frame["dimensions"], frame["geometry"]
+    r0, r1 = frame["r0"], frame["r1"]
+    if dims in (TWO, TWO_POINT_FIVE):
+        if geom in (CARTESIAN, CYLINDRICAL):
+            frame["r"] = np.sqrt(r0 * r0 + r1 * r1)
+            frame["theta"] = np.arctan2(r0, r1)
+        else:
+            frame["r"] = r0.copy()
+            frame["theta"] = r1.copy()
+    else:
+        r2 = frame["r2"]
+        if geom == CARTESIAN:
+            frame["r"] = np.sqrt(r0 * r0 + r1 * r1 + r2 * r2)
+            frame["theta"] = np.arccos(r2 / frame["r"])
+        elif geom == SPHERICAL:
+            frame["r"] = r0.copy()
+            frame["theta"] = r1.copy()
+        else:
+            frame["r"] = np.sqrt(r0 * r0 + r2 * r2)
+            frame["theta"] = np.arccos(r2 / frame["r"])
+    frame["num_elements"] = int(r0.size)
+    return frame
+
+
+def uniform_mesh_2d(r0_lo, r0_hi, n0, r1_lo, r1_hi, n1, geometry, domain0, domain1, fps):
+    """uniform (r0, r1) cells, r0 fastest."""
+    d0 = (r0_hi - r0_lo) / n0
+    d1 = (r1_hi - r1_lo) / n1
+    c0 = r0_lo + d0 * (np.arange(n0) + 0.5)
+    c1 = r1_lo + d1 * (np.arange(n1) + 0.5)
+    R0, R1 = np.meshgrid(c0, c1, indexing="xy")
+    frame = dict(dimensions=TWO, geometry=geometry,
+                 r0=R0.ravel().copy(), r1=R1.ravel().copy(),
+                 r0_size=np.full(n0 * n1, d0), r1_size=np.full(n0 * n1, d1),
+                 r0_domain=tuple(domain0), r1_domain=tuple(domain1), r2_domain=(0.0, 0.0), fps=float(fps))
+    return _finish_frame(frame)
+
+
+def flash_like_mesh(block_side, nxf, nxc, nzc, z_lo, domain0, domain1, fps, geometry=CYLINDRICAL):
+    """Two-level FLASH-like block mesh in (r, z): `nxf` x 2*nzc fine leaf blocks of side
+    `block_side` next to the axis and `nxc` x nzc coarse blocks of twice the side beyond;
+    every leaf block expands to 8x8 cells with x fastest and cell centres at
+    (+-1,3,5,7)/16 of the block size (Src/mclib_flash.c:69,253-264)."""
+    off = (np.arange(8) - 3.5) / 8.0
+    pieces = []
+    # fine blocks, then coarse blocks; row-major in z within each level
+    for (nx, nz, side, x_lo) in ((nxf, 2 * nzc, block_side, 0.0),
+                                 (nxc, nzc, 2.0 * block_side, nxf * block_side)):
+        bx = x_lo + side * (np.arange(nx) + 0.5)
+        bz = z_lo + side * (np.arange(nz) + 0.5)
+        BX, BZ = np.meshgrid(bx, bz, indexing="xy")          # (nz, nx)
+        BX, BZ = BX.ravel(), BZ.ravel()
+        cx = BX[:, None, None] + side * off[None, None, :]     # x fastest
+        cz = BZ[:, None, None] + side * off[None, :, None]
+        cx = np.broadcast_to(cx, (BX.size, 8, 8)).reshape(-1)
+        cz = np.broadcast_to(cz, (BX.size, 8, 8)).reshape(-1)
+        pieces.append((cx, cz, np.full(cx.size, side / 8.0)))
+    r0 = np.concatenate([p[0] for p in pieces])
+    r1 = np.concatenate([p[1] for p in pieces])
+    sz = np.concatenate([p[2] for p in pieces])
+    frame = dict(dimensions=TWO, geometry=geometry, r0=r0, r1=r1, r0_size=sz.copy(), r1_size=sz.copy(),
+                 r0_domain=tuple(domain0), r1_domain=tuple(domain1), r2_domain=(0.0, 0.0), fps=float(fps))
+    return _finish_frame(frame)
+
+
+def pluto_spherical_mesh(r_lo, r_hi, nr, th_lo, th_hi, nth, fps):
+    """PLUTO-like 2-D spherical (r, theta) grid, log-spaced in r, uniform in theta, r fastest;
+    centre = (left+right)/2, size = right-left (Src/mclib_pluto.c:951-971)."""
+    edges_r = np.exp(np.linspace(np.log(r_lo), np.log(r_hi), nr + 1))
+    edges_t = np.linspace(th_lo, th_hi, nth + 1)
+    cr, sr = 0.5 * (edges_r[1:] + edges_r[:-1]), edges_r[1:] - edges_r[:-1]
+    ct, st = 0.5 * (edges_t[1:] + edges_t[:-1]), edges_t[1:] - edges_t[:-1]
+    R, T = np.meshgrid(cr, ct, indexing="xy")
+    SR, ST = np.meshgrid(sr, st, indexing="xy")
+    frame = dict(dimensions=TWO, geometry=SPHERICAL, r0=R.ravel().copy(), r1=T.ravel().copy(),
+                 r0_size=SR.ravel().copy(), r1_size=ST.ravel().copy(),
+                 r0_domain=(r_lo, r_hi), r1_domain=(th_lo, th_hi), r2_domain=(0.0, 0.0), fps=float(fps))
+    return _finish_frame(frame)
+
+
+def uniform_mesh_3d_cartesian(lo, hi, n, fps):
+    """uniform 3-D Cartesian cells (x fastest) for the THREE/CARTESIAN code path."""
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    d = (hi - lo) / np.asarray(n)
+    cs = [lo[a] + d[a] * (np.arange(n[a]) + 0.5) for a in range(3)]
+    Z, Y, X = np.meshgrid(cs[2], cs[1], cs[0], indexing="ij")
+    m = X.size
+    frame = dict(dimensions=THREE, geometry=CARTESIAN, r0=X.ravel().copy(), r1=Y.ravel().copy(), r2=Z.ravel().copy(),
+                 r0_size=np.full(m, d[0]), r1_size=np.full(m, d[1]), r2_size=np.full(m, d[2]),
+                 r0_domain=(lo[0], hi[0]), r1_domain=(lo[1], hi[1]), r2_domain=(lo[2], hi[2]), fps=float(fps))
+    return _finish_frame(frame)
+
+
+# --------------------------------------------------------------------------- fluids
+def _radial_velocity(frame, vel):
+    dims, geom = frame["dimensions"], frame["geometry"]
+    if dims in (TWO, TWO_POINT_FIVE):
+        if geom in (CARTESIAN, CYLINDRICAL):
+            rr = np.sqrt(frame["r0"] ** 2 + frame["r1"] ** 2)
+            frame["v0"] = vel * frame["r0"] / rr
+            frame["v1"] = vel * frame["r1"] / rr
+        else:
+            frame["v0"] = vel.copy()
+            frame["v1"] = np.zeros_like(vel)
+        if dims == TWO_POINT_FIVE:
+            frame["v2"] = np.zeros_like(vel)
+    else:
+        if geom == CARTESIAN:
+            rr = np.sqrt(frame["r0"] ** 2 + frame["r1"] ** 2 + frame["r2"] ** 2)
+            frame["v0"] = vel * frame["r0"] / rr
+            frame["v1"] = vel * frame["r1"] / rr
+            frame["v2"] = vel * frame["r2"] / rr
+        elif geom == SPHERICAL:
+            frame["v0"] = vel.copy()
+            frame["v1"] = np.zeros_like(vel)
+            frame["v2"] = np.zeros_like(vel)
+        else:
+            rr = np.sqrt(frame["r0"] ** 2 + frame["r2"] ** 2)
+            frame["v0"] = vel * frame["r0"] / rr
+            frame["v1"] = np.zeros_like(vel)
+            frame["v2"] = vel * frame["r2"] / rr
+
+
+def spherical_outflow(frame, gamma_infinity=100.0, lumi=1e54, r00=1e8):
+    """formulas of sphericalPrep, Src/analytic_outflows.c:70-145."""
+    r = frame["r"]
+    coast = r >= r00 * gamma_infinity
+    gamma = np.where(coast, gamma_infinity, r / r00)
+    pres = np.where(coast,
+                    (lumi * r00 ** (2.0 / 3.0) * r ** (-8.0 / 3.0)) / (12.0 * np.pi * C_LIGHT * gamma_infinity ** (4.0 / 3.0)),
+                    (lumi * r00 ** 2.0) / (12.0 * np.pi * C_LIGHT * r ** 4.0))
+    dens = lumi / (4 * np.pi * r ** 2.0 * C_LIGHT ** 3.0 * gamma_infinity * gamma)
+    frame.update(gamma=gamma, pres=pres, dens=dens, dens_lab=dens * gamma, temp=(3 * pres / A_RAD) ** 0.25)
+    _radial_velocity(frame, np.sqrt(1 - gamma ** -2.0))
+    return frame
+
+
+def structured_fireball(frame, gamma_0=100.0, lumi=3e50, r00=1e8, theta_j=0.1, p=4.0):
+    """formulas of structuredFireballPrep (Lundman, Pe'er & Ryde 2014), Src/analytic_outflows.c:147-236,
+    with the parameters the manual quotes for its validation run (Doc/mcrat_doc.tex:553)."""
+    r, theta = frame["r"], frame["theta"]
+    T_0 = (lumi / (4 * np.pi * r00 * r00 * A_RAD * C_LIGHT)) ** 0.25
+    eta = gamma_0 / np.sqrt(1 + (theta / theta_j) ** (2 * p))
+    eta = np.where(theta >= theta_j * (gamma_0 / 2) ** (1.0 / p), 2.0, eta)
+    r_sat = eta * r00
+    coast = r >= r_sat
+    gamma = np.where(coast, eta, r / r_sat)
+    temp = np.where(coast, T_0 * (r_sat / r) ** (2.0 / 3.0) / eta, T_0)
+    vel = np.sqrt(1 - gamma ** -2.0)
+    dens = M_P * lumi / (4 * np.pi * M_P * C_LIGHT ** 3 * eta * vel * gamma * r * r)
+    frame.update(gamma=gamma, temp=temp, dens=dens, dens_lab=dens * gamma, pres=A_RAD * temp ** 4.0 / 3)
+    _radial_velocity(frame, vel)
+    return frame
+
+
+# --------------------------------------------------------------------------- geometry helpers (vectorised)
+def hydro_vector_to_cartesian(frame, idx, phi):
+    """Src/geometry.c:189-253 for arrays of cell indices and photon azimuths."""
+    dims, geom = frame["dimensions"], frame["geometry"]
+    v0, v1 = frame["v0"][idx], frame["v1"][idx]
+    v2 = frame["v2"][idx] if (dims != TWO and "v2" in frame) else np.zeros_like(v0)
+    if dims in (TWO, TWO_POINT_FIVE):
+        if geom in (CARTESIAN, CYLINDRICAL):
+            return np.stack([v0 * np.cos(phi) - v2 * np.sin(phi), v0 * np.sin(phi) + v2 * np.cos(phi), v1], axis=-1)
+        th = frame["r1"][idx]
+        return np.stack([v0 * np.sin(th) * np.cos(phi) + v1 * np.cos(th) * np.cos(phi) - v2 * np.sin(phi),
+                         v0 * np.sin(th) * np.sin(phi) + v1 * np.cos(th) * np.sin(phi) + v2 * np.cos(phi),
+                         v0 * np.cos(th) - v1 * np.sin(th)], axis=-1)
+    if geom == CARTESIAN:
+        return np.stack([v0, v1, v2], axis=-1)
+    if geom == SPHERICAL:
+        th, ph = frame["r1"][idx], frame["r2"][idx]
+        return np.stack([v0 * np.sin(th) * np.cos(ph) + v1 * np.cos(th) * np.cos(ph) - v2 * np.sin(ph),
+                         v0 * np.sin(th) * np.sin(ph) + v1 * np.cos(th) * np.sin(ph) + v2 * np.cos(ph),
+                         v0 * np.cos(th) - v1 * np.sin(th)], axis=-1)
+    ph = frame["r1"][idx]
+    return np.stack([v0 * np.cos(ph) - v1 * np.sin(ph), v0 * np.sin(ph) + v1 * np.cos(ph), v2], axis=-1)
+
+
+def lorentz_boost(beta_vec, p4):
+    """textbook boost of 4-vectors p4[...,4] into the frames moving with beta_vec[...,3]."""
+    b2 = np.sum(beta_vec * beta_vec, axis=-1)
+    gamma = 1.0 / np.sqrt(1.0 - b2)
+    bp = np.sum(beta_vec * p4[..., 1:], axis=-1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        coef = np.where(b2 > 0, (gamma - 1.0) * bp / b2, 0.0)
+    out = np.empty_like(p4)
+    out[..., 0] = gamma * (p4[..., 0] - bp)
+    out[..., 1:] = p4[..., 1:] + (coef - gamma * p4[..., 0])[..., None] * beta_vec
+    return out
+
+
+def element_volume(frame, idx):
+    """Src/geometry.c:255-296."""
+    dims, geom = frame["dimensions"], frame["geometry"]
+    r0, s0, r1, s1 = frame["r0"][idx], frame["r0_size"][idx], frame["r1"][idx], frame["r1_size"][idx]
+    a, b = r0 + 0.5 * s0, r0 - 0.5 * s0
+    if dims in (TWO, TWO_POINT_FIVE):
+        if geom in (CARTESIAN, CYLINDRICAL):
+            return np.pi * (a * a - b * b) * s1
+        return (2.0 * np.pi / 3.0) * (a ** 3 - b ** 3) * (np.cos(r1 - 0.5 * s1) - np.cos(r1 + 0.5 * s1))
+    s2 = frame["r2_size"][idx]
+    if geom == CARTESIAN:
+        return s0 * s1 * s2
+    if geom == SPHERICAL:
+        return (1.0 / 3.0) * (a ** 3 - b ** 3) * (np.cos(r1 - 0.5 * s1) - np.cos(r1 + 0.5 * s1)) * s2
+    return 0.5 * (a * a - b * b) * s1 * s2
+
+
+def _corner_spherical(frame, sign):
+    dims, geom = frame["dimensions"], frame["geometry"]
+    c0 = frame["r0"] + sign * 0.5 * frame["r0_size"]
+    c1 = frame["r1"] + sign * 0.5 * frame["r1_size"]
+    if dims in (TWO, TWO_POINT_FIVE):
+        if geom in (CARTESIAN, CYLINDRICAL):
+            return np.sqrt(c0 * c0 + c1 * c1), np.arctan2(c0, c1)
+        return c0, c1
+    c0 = np.abs(frame["r0"]) + sign * 0.5 * frame["r0_size"]
+    c1 = np.abs(frame["r1"]) + sign * 0.5 * frame["r1_size"]
+    c2 = np.abs(frame["r2"]) + sign * 0.5 * frame["r2_size"]
+    if geom == CARTESIAN:
+        rr = np.sqrt(c0 * c0 + c1 * c1 + c2 * c2)
+        return rr, np.arccos(c2 / rr)
+    if geom == SPHERICAL:
+        return c0, c1
+    rr = np.sqrt(c0 * c0 + c2 * c2)
+    return rr, np.arccos(c2 / rr)
+
+
+# --------------------------------------------------------------------------- photons
+def inject_photons(frame, n_photons, r_inj, theta_min, theta_max, seed, weight=1.0):
+    """Fixed-total, equal-weight restatement of photonInjection's rules (Src/mclib.c:9-300)."""
+    rng = np.random.default_rng(seed)
+    dims = frame["dimensions"]
+    rmin = r_inj - 0.5 * C_LIGHT / frame["fps"]
+    rmax = r_inj + 0.5 * C_LIGHT / frame["fps"]
+    r_in, th_in = _corner_spherical(frame, -1.0)
+    r_out, th_out = _corner_spherical(frame, +1.0)
+    sel = np.nonzero((rmin <= r_out) & (r_in <= rmax) & (th_out >= theta_min) & (th_in <= theta_max))[0]
+    if sel.size == 0:
+        raise ValueError("no hydro cell intersects the injection slab")
+    expect = (4.0 / 3.0) * element_volume(frame, sel) * frame["gamma"][sel] * 20.29 * frame["temp"][sel] ** 3
+    counts = rng.multinomial(n_photons, expect / expect.sum())
+    cell = np.repeat(sel, counts)                       # photons ordered by cell, like the reference's loops
+    n = cell.size
+    T = frame["temp"][cell]
+
+    # black-body frequency, Bjorkman & Wood 2001 as in mclib.c:199-213
+    u = 1.0 - rng.random((n, 5))                        # (0,1]
+    target = (np.pi ** 4 / 90.0) * u[:, 0]
+    csum = np.cumsum(1.0 / np.arange(1, 2001, dtype=np.float64) ** 4)
+    m = np.minimum(np.searchsorted(csum, target, side="left"), csum.size - 1) + 1.0
+    freq = -np.log(u[:, 1] * u[:, 2] * u[:, 3] * u[:, 4]) / m * K_B * T / PL_CONST
+
+    position_phi = rng.random(n) * 2 * np.pi if dims != THREE else np.zeros(n)
+    com_phi = rng.random(n) * 2 * np.pi
+    com_theta = np.arccos(rng.random(n) * 2 - 1)
+    e = PL_CONST * freq / C_LIGHT
+    p_comv = np.stack([e, e * np.sin(com_theta) * np.cos(com_phi), e * np.sin(com_theta) * np.sin(com_phi),
+                       e * np.cos(com_theta)], axis=-1)
+    beta = hydro_vector_to_cartesian(frame, cell, position_phi)
+    p_lab = lorentz_boost(-beta, p_comv)
+    nrm = np.sqrt(np.sum(p_lab[:, 1:] ** 2, axis=-1))
+    p_lab[:, 1:] *= (p_lab[:, 0] / nrm)[:, None]        # zeroNorm, mclib.c:409
+
+    h0 = frame["r0"][cell] + (rng.random(n) - 0.5) * frame["r0_size"][cell]
+    h1 = frame["r1"][cell] + (rng.random(n) - 0.5) * frame["r1_size"][cell]
+    geom = frame["geometry"]
+    if dims in (TWO, TWO_POINT_FIVE):
+        if geom in (CARTESIAN, CYLINDRICAL):
+            x, y, z = h0 * np.cos(position_phi), h0 * np.sin(position_phi), h1
+        else:
+            x, y, z = h0 * np.sin(h1) * np.cos(position_phi), h0 * np.sin(h1) * np.sin(position_phi), h0 * np.cos(h1)
+    else:
+        h2 = frame["r2"][cell] + (rng.random(n) - 0.5) * frame["r2_size"][cell]
+        if geom == CARTESIAN:
+            x, y, z = h0, h1, h2
+        elif geom == SPHERICAL:
+            x, y, z = h0 * np.sin(h1) * np.cos(h2), h0 * np.sin(h1) * np.sin(h2), h0 * np.cos(h1)
+        else:
+            x, y, z = h0 * np.cos(h1), h0 * np.sin(h1), h2
+
+    ph = dict(
+        type=np.full(n, b"i", dtype="S1"),
+        p0=p_lab[:, 0].copy(), p1=p_lab[:, 1].copy(), p2=p_lab[:, 2].copy(), p3=p_lab[:, 3].copy(),
+        comv_p0=p_comv[:, 0].copy(), comv_p1=p_comv[:, 1].copy(), comv_p2=p_comv[:, 2].copy(), comv_p3=p_comv[:, 3].copy(),
+        r0=np.ascontiguousarray(x), r1=np.ascontiguousarray(y), r2=np.ascontiguousarray(z),
+        s0=np.ones(n), s1=np.zeros(n), s2=np.zeros(n), s3=np.zeros(n),
+        num_scatt=np.zeros(n), weight=np.full(n, float(weight)),
+        nearest_block_index=np.zeros(n, dtype=np.int32), recalc_properties=np.ones(n, dtype=np.int32),
+        time_to_scatter=np.zeros(n), total_optical_depth=np.zeros(n),
+    )
+    return ph
+
+
+def photons_to_aos(ph, dtype):
+    """pack SoA columns into the 176-byte AoS records of struct photon."""
+    n = ph["p0"].size
+    aos = np.zeros(n, dtype=dtype)
+    for k in dtype.names:
+        aos[k] = ph[k]
+    return aos
+
+
+def photons_from_aos(aos):
+    return {k: np.ascontiguousarray(aos[k]) for k in aos.dtype.names}
+
+
+def select_slab(frame, keep):
+    """keep a subset of cells (what the readers' slab selection leaves, Src/mclib_flash.c:279-326)."""
+    out = dict(frame)
+    for k, v in frame.items():
+        if isinstance(v, np.ndarray) and v.shape == (frame["num_elements"],):
+            out[k] = np.ascontiguousarray(v[keep])
+    out["num_elements"] = int(np.count_nonzero(keep)) if keep.dtype == bool else int(len(keep))
+    return out
+
+
+# --------------------------------------------------------------------------- BASELINE.json configurations
+def config1(n_photons=10_000, seed=0, n0=64, n1=64, fps=5.0, r_inj=1e12):
+    """cfg1: analytic spherical wind on a 2-D CARTESIAN uniform mesh, Compton-only, STOKES off.
+    The mesh covers the photons' slab r in [r_inj-3c/fps, r_inj+3c/fps], theta in [0,5deg]."""
+    th = 5.0 * np.pi / 180
+    dr = 3 * C_LIGHT / fps
+    x_hi = (r_inj + dr) * np.sin(th)
+    z_lo, z_hi = (r_inj - dr) * np.cos(th), r_inj + dr
+    frame = uniform_mesh_2d(0.0, x_hi, n0, z_lo, z_hi, n1, CARTESIAN, (0.0, 2.5e13), (0.0, 2.5e13), fps)
+    spherical_outflow(frame)
+    ph = inject_photons(frame, n_photons, r_inj, 0.0, 3.0 * np.pi / 180, seed)
+    cfg = dict(dimensions=TWO, geometry=CARTESIAN, stokes=0, name="cfg1-spherical-wind-2d-cartesian")
+    return frame, ph, cfg
+
+
+def config2(n_photons=1_000_000, seed=0x4D435261, nzc=64, fps=5.0, r_inj=1e12, block_side=2.5e8, stokes=0):
+    """cfg2: FLASH-like two-level block mesh, CYLINDRICAL (r,z), Lundman structured jet, Compton+KN.
+    nzc=64 gives 16 384 leaf blocks = 1 048 576 cells; smaller nzc scales the mesh down for tests
+    (cells grow so that the mesh always covers the same slab)."""
+    scale = 64 // nzc
+    side = block_side * scale
+    nxf, nxc = nzc, 2 * nzc
+    H = 2 * nzc * side
+    z_lo = r_inj - 0.5 * H
+    frame = flash_like_mesh(side, nxf, nxc, nzc, z_lo, (0.0, 5e12), (0.0, 2.5e13), fps)
+    structured_fireball(frame)
+    ph = inject_photons(frame, n_photons, r_inj, 0.0, 3.0 * np.pi / 180, seed)
+    cfg = dict(dimensions=TWO, geometry=CYLINDRICAL, stokes=int(stokes), name="cfg2-flash-2d-cylindrical-jet")
+    return frame, ph, cfg
+
+
+def config3(n_photons=10_000_000, seed=0x4D435262, nr=2048, nth=512, fps=5.0, r_inj=1e12, stokes=1):
+    """cfg3: PLUTO-like 2-D SPHERICAL log-r grid, same jet, STOKES on."""
+    frame = pluto_spherical_mesh(1e9, 2.5e13, nr, 0.0, np.pi / 2, nth, fps)
+    structured_fireball(frame)
+    ph = inject_photons(frame, n_photons, r_inj, 0.0, 6.0 * np.pi / 180, seed)
+    cfg = dict(dimensions=TWO, geometry=SPHERICAL, stokes=int(stokes), name="cfg3-pluto-2d-spherical-jet")
+    return frame, ph, cfg
+
+
+def config_3d_cartesian(n_photons=2000, seed=7, n=(24, 24, 24), fps=5.0, r_inj=1e12):
+    """small THREE/CARTESIAN case for the 3-D code path (parity tests only)."""
+    half = 8e10
+    frame = uniform_mesh_3d_cartesian((-half, -half, r_inj - 2e10), (half, half, r_inj + 2e10), n, fps)
+    spherical_outflow(frame)
+    ph = inject_photons(frame, n_photons, r_inj, 0.0, 3.0 * np.pi / 180, seed)
+    cfg = dict(dimensions=THREE, geometry=CARTESIAN, stokes=1, name="3d-cartesian-wind")
+    return frame, ph, cfg

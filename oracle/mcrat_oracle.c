@@ -1,0 +1,805 @@
+/*
+ * mcrat_oracle.c -- plain-C restatement of MCRaT's per-timestep photon loop.
+ * TEST INFRASTRUCTURE ONLY; see mcrat_oracle.h for the rules and the
+ * "parity unpinned" statement.  Every function cites the reference lines it
+ * restates (paths relative to /root/reference/Src).
+ */
+#define _GNU_SOURCE
+#include "mcrat_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+#include <limits.h>
+
+int orc_sizeof_photon(void) { return (int)sizeof(orc_photon); }
+
+/* ------------------------------------------------------------------ */
+/* small dense helpers standing for the GSL BLAS calls of the reference */
+
+/* gsl_blas_dnrm2 == reference BLAS DNRM2 (scaled sum of squares) */
+double orc_dnrm2(const double *x, int n)
+{
+    double scale = 0.0, ssq = 1.0;
+    for (int i = 0; i < n; i++) {
+        if (x[i] != 0.0) {
+            double ax = fabs(x[i]);
+            if (scale < ax) {
+                ssq = 1.0 + ssq * (scale / ax) * (scale / ax);
+                scale = ax;
+            } else {
+                ssq += (ax / scale) * (ax / scale);
+            }
+        }
+    }
+    return scale * sqrt(ssq);
+}
+
+/* y = A x for a row-major n x n matrix, accumulation order of the reference
+ * CBLAS dgemv (temp += x[j]*A[i][j], j ascending), alpha=1, beta=0 */
+static void matvec(int n, const double *A, const double *x, double *y)
+{
+    for (int i = 0; i < n; i++) {
+        double temp = 0.0;
+        for (int j = 0; j < n; j++) temp += x[j] * A[i * n + j];
+        y[i] = temp;
+    }
+}
+
+static double dot3(const double a[3], const double b[3])
+{
+    double r = 0.0;
+    for (int i = 0; i < 3; i++) r += a[i] * b[i];
+    return r;
+}
+
+/* ------------------------------------------------------------------ */
+/* mclib.c:409-434 */
+void orc_zeroNorm(double p[4])
+{
+    double nrm = orc_dnrm2(p + 1, 3);
+    if (p[0] != nrm) {
+        p[1] = (p[1] / nrm) * p[0];
+        p[2] = (p[2] / nrm) * p[0];
+        p[3] = (p[3] / nrm) * p[0];
+    }
+}
+
+/* mclib.c:302-407: general boost into the frame moving with velocity `boost`
+ * (units of c); photons ('p') are re-normalised to a null vector afterwards */
+void orc_lorentzBoost(const double boost[3], const double p[4], double result[4], char object)
+{
+    double out[4];
+    double beta = orc_dnrm2(boost, 3);
+    if (beta > 0) {
+        double gamma = 1.0 / sqrt(1 - beta * beta);
+        double L[16];
+        memset(L, 0, sizeof L);
+        L[0] = gamma;
+        L[1] = -1 * boost[0] * gamma;
+        L[2] = -1 * boost[1] * gamma;
+        L[3] = -1 * boost[2] * gamma;
+        L[5]  = 1 + ((gamma - 1) * (boost[0] * boost[0]) / (beta * beta));
+        L[6]  = ((gamma - 1) * (boost[0] * boost[1] / (beta * beta)));
+        L[7]  = ((gamma - 1) * (boost[0] * boost[2] / (beta * beta)));
+        L[10] = 1 + ((gamma - 1) * (boost[1] * boost[1]) / (beta * beta));
+        L[11] = ((gamma - 1) * (boost[1] * boost[2]) / (beta * beta));
+        L[15] = 1 + ((gamma - 1) * (boost[2] * boost[2]) / (beta * beta));
+        L[4] = L[1]; L[8] = L[2]; L[12] = L[3];
+        L[9] = L[6]; L[13] = L[7]; L[14] = L[11];
+        matvec(4, L, p, out);
+        if (object == 'p') orc_zeroNorm(out);
+    } else {
+        memcpy(out, p, sizeof out);
+        if (object == 'p') orc_zeroNorm(out);
+    }
+    memcpy(result, out, sizeof out);
+}
+
+/* geometry.c:15-64 */
+void orc_mcratCoordinateToHydroCoordinate(const orc_config *c, double out[3], double x, double y, double z)
+{
+    double r0 = -1, r1 = -1, r2 = -1;
+    if (c->dimensions == ORC_TWO || c->dimensions == ORC_TWO_POINT_FIVE) {
+        if (c->geometry == ORC_CARTESIAN || c->geometry == ORC_CYLINDRICAL) {
+            r0 = sqrt(x * x + y * y);
+            r1 = z;
+        }
+        if (c->geometry == ORC_SPHERICAL) {
+            r0 = sqrt(x * x + y * y + z * z);
+            r1 = acos(z / r0);
+        }
+    } else {
+        if (c->geometry == ORC_CARTESIAN) { r0 = x; r1 = y; r2 = z; }
+        if (c->geometry == ORC_SPHERICAL) {
+            r0 = sqrt(x * x + y * y + z * z);
+            r1 = acos(z / r0);
+            r2 = fmod(atan2(y, x) * 180.0 / M_PI + 360.0, 360.0) * M_PI / 180;
+        }
+        if (c->geometry == ORC_POLAR) {
+            r0 = sqrt(x * x + y * y);
+            r1 = fmod(atan2(y, x) * 180.0 / M_PI + 360.0, 360.0) * M_PI / 180;
+            r2 = z;
+        }
+    }
+    out[0] = r0; out[1] = r1; out[2] = r2;
+}
+
+/* geometry.c:189-253 */
+void orc_hydroVectorToCartesian(const orc_config *c, double out[3], double v0, double v1, double v2,
+                                double x0, double x1, double x2)
+{
+    double t0 = 0, t1 = 0, t2 = 0;
+    (void)x0;
+    if (c->dimensions == ORC_TWO) {
+        if (c->geometry == ORC_CARTESIAN || c->geometry == ORC_CYLINDRICAL) {
+            t0 = v0 * cos(x2);
+            t1 = v0 * sin(x2);
+            t2 = v1;
+        }
+        if (c->geometry == ORC_SPHERICAL) {
+            v2 = 0;
+            t0 = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
+            t1 = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
+            t2 = v0 * cos(x1) - v1 * sin(x1);
+        }
+    } else if (c->dimensions == ORC_TWO_POINT_FIVE) {
+        if (c->geometry == ORC_CARTESIAN || c->geometry == ORC_CYLINDRICAL) {
+            t0 = v0 * cos(x2) - v2 * sin(x2);
+            t1 = v0 * sin(x2) + v2 * cos(x2);
+            t2 = v1;
+        }
+        if (c->geometry == ORC_SPHERICAL) {
+            t0 = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
+            t1 = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
+            t2 = v0 * cos(x1) - v1 * sin(x1);
+        }
+    } else {
+        if (c->geometry == ORC_CARTESIAN) { t0 = v0; t1 = v1; t2 = v2; }
+        if (c->geometry == ORC_SPHERICAL) {
+            t0 = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
+            t1 = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
+            t2 = v0 * cos(x1) - v1 * sin(x1);
+        }
+        if (c->geometry == ORC_POLAR) {
+            t0 = v0 * cos(x1) - v1 * sin(x1);
+            t1 = v0 * sin(x1) + v1 * cos(x1);
+            t2 = v2;
+        }
+    }
+    out[0] = t0; out[1] = t1; out[2] = t2;
+}
+
+/* the fluid velocity of cell `idx` as a Cartesian 3-vector for a photon at
+ * azimuth ph_phi: the three call shapes at mclib.c:546-555,1167-1174 and
+ * optical_depth.c:27-36 */
+static void cell_beta_cartesian(const orc_config *c, const orc_hydro *h, int idx, double ph_phi, double out[3])
+{
+    if (c->dimensions == ORC_THREE)
+        orc_hydroVectorToCartesian(c, out, h->v0[idx], h->v1[idx], h->v2[idx], h->r0[idx], h->r1[idx], h->r2[idx]);
+    else if (c->dimensions == ORC_TWO_POINT_FIVE)
+        orc_hydroVectorToCartesian(c, out, h->v0[idx], h->v1[idx], h->v2[idx], h->r0[idx], h->r1[idx], ph_phi);
+    else
+        orc_hydroVectorToCartesian(c, out, h->v0[idx], h->v1[idx], 0, h->r0[idx], h->r1[idx], ph_phi);
+}
+
+/* geometry.c:394-417 */
+int orc_checkInBlock(const orc_config *c, double a0, double a1, double a2, const orc_hydro *h, int idx)
+{
+    int in;
+    if (c->dimensions == ORC_TWO || c->dimensions == ORC_TWO_POINT_FIVE)
+        in = (2 * fabs(a0 - h->r0[idx]) - h->r0_size[idx] <= 0) && (2 * fabs(a1 - h->r1[idx]) - h->r1_size[idx] <= 0);
+    else
+        in = (2 * fabs(a0 - h->r0[idx]) - h->r0_size[idx] <= 0) && (2 * fabs(a1 - h->r1[idx]) - h->r1_size[idx] <= 0)
+             && (2 * fabs(a2 - h->r2[idx]) - h->r2_size[idx] <= 0);
+    return in ? 1 : 0;
+}
+
+/* geometry.c:350-391 (the path taken because hydro_data->grid == NULL,
+ * mcrat_io.c:1985 -> geometry.c:426-430): lowest-index containing cell or -1 */
+int orc_findContainingBlock(const orc_config *c, double a0, double a1, double a2, const orc_hydro *h)
+{
+    for (int i = 0; i < h->num_elements; i++)
+        if (orc_checkInBlock(c, a0, a1, a2, h, i)) return i;
+    return -1;
+}
+
+/* geometry.c:255-296 */
+double orc_hydroElementVolume(const orc_config *c, const orc_hydro *h, int idx)
+{
+    double V = 0;
+    double r0_max = h->r0[idx] + 0.5 * h->r0_size[idx], r0_min = h->r0[idx] - 0.5 * h->r0_size[idx];
+    double r1_max = h->r1[idx] + 0.5 * h->r1_size[idx], r1_min = h->r1[idx] - 0.5 * h->r1_size[idx];
+    if (c->dimensions == ORC_TWO || c->dimensions == ORC_TWO_POINT_FIVE) {
+        if (c->geometry == ORC_CARTESIAN || c->geometry == ORC_CYLINDRICAL)
+            V = M_PI * (r0_max * r0_max - r0_min * r0_min) * h->r1_size[idx];
+        if (c->geometry == ORC_SPHERICAL)
+            V = (2.0 * M_PI / 3.0) * (r0_max * r0_max * r0_max - r0_min * r0_min * r0_min) * (cos(r1_min) - cos(r1_max));
+    } else {
+        double r2_max = h->r2[idx] + 0.5 * h->r2_size[idx], r2_min = h->r2[idx] - 0.5 * h->r2_size[idx];
+        if (c->geometry == ORC_CARTESIAN) V = h->r0_size[idx] * h->r1_size[idx] * h->r2_size[idx];
+        if (c->geometry == ORC_SPHERICAL)
+            V = (1.0 / 3.0) * (r0_max * r0_max * r0_max - r0_min * r0_min * r0_min) * (cos(r1_min) - cos(r1_max)) * (r2_max - r2_min);
+        if (c->geometry == ORC_POLAR)
+            V = 0.5 * (r0_max * r0_max - r0_min * r0_min) * h->r1_size[idx] * h->r2_size[idx];
+    }
+    return V;
+}
+
+/* ------------------------------------------------------------------ */
+/* Stokes helpers */
+
+/* mcrat_scattering.c:10-39: Q' = Q cos2t - U sin2t, U' = Q sin2t + U cos2t */
+void orc_mullerMatrixRotation(double theta, double s[4])
+{
+    double M[16], out[4];
+    memset(M, 0, sizeof M);
+    M[0] = 1; M[15] = 1;
+    M[5] = cos(2 * theta);
+    M[10] = cos(2 * theta);
+    M[6] = -1 * sin(2 * theta);
+    M[9] = sin(2 * theta);
+    matvec(4, M, s, out);
+    memcpy(s, out, sizeof out);
+}
+
+/* mcrat_scattering.c:41-65 */
+void orc_findXY(const double v[3], const double ref[3], double x[3], double y[3])
+{
+    double norm;
+    y[0] = (v[1] * ref[2] - v[2] * ref[1]);
+    y[1] = -1 * (v[0] * ref[2] - v[2] * ref[0]);
+    y[2] = (v[0] * ref[1] - v[1] * ref[0]);
+    norm = 1.0 / sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    y[0] *= norm; y[1] *= norm; y[2] *= norm;
+
+    x[0] = y[1] * v[2] - y[2] * v[1];
+    x[1] = -1 * (y[0] * v[2] - y[2] * v[0]);
+    x[2] = y[0] * v[1] - y[1] * v[0];
+    norm = 1.0 / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    x[0] *= norm; x[1] *= norm; x[2] *= norm;
+}
+
+/* mcrat_scattering.c:67-101 */
+double orc_findPhi(const double x_old[3], const double y_old[3], const double x_new[3], const double y_new[3])
+{
+    double factor, d;
+    (void)x_new;
+    d = dot3(x_old, y_new);
+    if (d > 0) factor = 1;
+    else if (d < 0) factor = -1;
+    else factor = 0;
+    d = dot3(y_old, y_new);
+    if ((d < -1) || (d > 1)) d = round(d);
+    return -1 * factor * acos(d);
+}
+
+/* mcrat_scattering.c:103-149 */
+void orc_stokesRotation(const double v[3], const double v_ph[3], const double v_ph_boosted[3], double s[4])
+{
+    const double z_hat[3] = {0, 0, 1};
+    double x[3], y[3], x_new[3], y_new[3], phi;
+    orc_findXY(v_ph, z_hat, x, y);
+    orc_findXY(v_ph, v, x_new, y_new);
+    phi = orc_findPhi(x, y, x_new, y_new);
+    orc_mullerMatrixRotation(phi, s);
+    orc_findXY(v_ph_boosted, v, x, y);
+    orc_findXY(v_ph_boosted, z_hat, x_new, y_new);
+    phi = orc_findPhi(x, y, x_new, y_new);
+    orc_mullerMatrixRotation(phi, s);
+}
+
+/* ------------------------------------------------------------------ */
+/* mcrat_scattering.c:597-623 */
+double orc_kleinNishinaCrossSection(double e)
+{
+    if (e >= 1e-3)
+        return (3. / 4.) * (2. / (e * e) + (1. / (2. * e) - (1. + e) / (e * e * e)) * log(1. + 2. * e)
+                            + (1. + e) / ((1. + 2. * e) * (1. + 2. * e)));
+    return (1. - 2. * e);
+}
+
+/* mcrat_scattering.c:509-595 */
+int orc_kleinNishinaScatter(const orc_config *c, double *theta, double *phi, double p0, double q, double u, orc_rng *rng)
+{
+    double phi_dum = 0, cos_theta_dum = 0, f_phi_dum = 0, f_cos_theta_dum = 0, f_theta_dum = 0;
+    double phi_y_dum = 1, cos_theta_y_dum = 1, mu, phi_max, norm;
+    double energy_ratio = p0 / (ORC_M_EL * ORC_C_LIGHT);
+    double kn = orc_kleinNishinaCrossSection(energy_ratio);
+    double rand_num = orc_rng_uniform(rng);
+
+    if (!(rand_num <= kn)) return 0;
+
+    while (cos_theta_y_dum > f_cos_theta_dum) {
+        cos_theta_y_dum = orc_rng_uniform(rng) * 2;
+        cos_theta_dum = orc_rng_uniform(rng) * 2 - 1;
+        f_cos_theta_dum = pow((1 + energy_ratio * (1 - cos_theta_dum)), -2)
+                          * (energy_ratio * (1 - cos_theta_dum) + (1 / (1 + energy_ratio * (1 - cos_theta_dum)))
+                             + cos_theta_dum * cos_theta_dum);
+    }
+    *theta = acos(cos_theta_dum);
+    mu = 1 + energy_ratio * (1 - cos(*theta));
+    f_theta_dum = (pow(mu, -1.0) + pow(mu, -3.0) - pow(mu, -2.0) * sin(*theta) * sin(*theta)) * sin(*theta);
+
+    while (phi_y_dum > f_phi_dum) {
+        if (!c->stokes_switch || (u == 0 && q == 0)) {
+            phi_dum = orc_rng_uniform(rng) * 2 * M_PI;
+            phi_y_dum = -1;
+        } else {
+            phi_max = fabs(atan2(-u, q)) / 2.0;
+            norm = (f_theta_dum + pow(mu, -2.0) * sin(*theta) * sin(*theta) * sin(*theta)
+                                  * (q * cos(2 * phi_max) - u * sin(2 * phi_max)));
+            phi_y_dum = orc_rng_uniform(rng);
+            phi_dum = orc_rng_uniform(rng) * 2 * M_PI;
+            f_phi_dum = (f_theta_dum + pow(mu, -2.0) * sin(*theta) * sin(*theta) * sin(*theta)
+                                       * (q * cos(2 * phi_dum) - u * sin(2 * phi_dum))) / norm;
+        }
+    }
+    *phi = phi_dum;
+    return 1;
+}
+
+/* Modified Bessel function K_2(x), standing for gsl_sf_bessel_Kn(2, x) at
+ * electron.c:221.  Evaluated from the integral representation
+ *   K_nu(x) = int_0^inf exp(-x cosh t) cosh(nu t) dt        (DLMF 10.32.9)
+ * with the trapezoid rule, which converges geometrically for this analytic,
+ * doubly-exponentially decaying integrand.  Checked against scipy.special.kn
+ * in tests/test_oracle_kat.py (relative error < 1e-13 on [0.05, 700]). */
+double orc_bessel_K2(double x)
+{
+    double h = 0.35 / sqrt(x);
+    if (h > 0.125) h = 0.125;
+    double sum = 0.5;               /* t = 0 term: exp(0)*cosh(0), half weight */
+    for (int k = 1; k < 100000; k++) {
+        double t = k * h;
+        double sh = sinh(0.5 * t);
+        double e = -x * 2.0 * sh * sh;   /* -x (cosh t - 1) */
+        double term = exp(e) * cosh(2.0 * t);
+        sum += term;
+        if (e + 2.0 * t < -80.0) break;
+    }
+    return exp(-x) * sum * h;
+}
+
+/* electron.c:202-237 */
+double orc_sampleThermalElectron(double temp, orc_rng *rng)
+{
+    double gamma = 1, factor, x_dum = 0, y_dum = 1, f_x_dum = 0, beta_x_dum;
+    if (temp >= 1e7) {
+        factor = ORC_K_B * temp / (ORC_M_EL * ORC_C_LIGHT * ORC_C_LIGHT);
+        double k2 = orc_bessel_K2(1.0 / factor);  /* loop-invariant; the reference re-evaluates it each pass */
+        while (isnan(f_x_dum) || (y_dum > f_x_dum)) {
+            x_dum = orc_rng_uniform_pos(rng) * (1 + 100 * factor);
+            beta_x_dum = sqrt(1 - (1 / (x_dum * x_dum)));
+            y_dum = orc_rng_uniform(rng) / 2.0;
+            f_x_dum = x_dum * x_dum * (beta_x_dum / k2) * exp(-1 * x_dum / factor);
+        }
+        gamma = x_dum;
+    } else {
+        factor = sqrt(ORC_K_B * temp / ORC_M_EL);
+        double g1 = orc_rng_gaussian(rng, factor) / ORC_C_LIGHT;
+        double g2 = orc_rng_gaussian(rng, factor) / ORC_C_LIGHT;
+        double g3 = orc_rng_gaussian(rng, factor) / ORC_C_LIGHT;
+        gamma = 1.0 / sqrt(1 - (pow(g1, 2) + pow(g2, 2) + pow(g3, 2)));
+    }
+    return gamma;
+}
+
+/* electron.c:177-200 (eq. 56 of the RAIKOU paper) */
+double orc_sampleElectronTheta(double beta, orc_rng *rng)
+{
+    return acos((1 - sqrt(1 + beta * beta + 2 * beta - 4 * beta * orc_rng_uniform(rng))) / beta);
+}
+
+/* electron.c:126-175 */
+void orc_rotateElectron(double el_p[4], const double ph_p[4])
+{
+    double rot[9], tmp[3], out[3];
+    double ph_phi = atan2(ph_p[2], ph_p[3]);
+    double ph_theta = atan2(sqrt(pow(ph_p[2], 2) + pow(ph_p[3], 2)), ph_p[1]);
+
+    memset(rot, 0, sizeof rot);
+    rot[4] = 1;
+    rot[8] = cos(ph_theta);
+    rot[0] = cos(ph_theta);
+    rot[2] = -sin(ph_theta);
+    rot[6] = sin(ph_theta);
+    matvec(3, rot, el_p + 1, tmp);
+
+    memset(rot, 0, sizeof rot);
+    rot[0] = 1;
+    rot[4] = cos(-ph_phi);
+    rot[8] = cos(-ph_phi);
+    rot[5] = -sin(-ph_phi);
+    rot[7] = sin(-ph_phi);
+    matvec(3, rot, tmp, out);
+    el_p[1] = out[0]; el_p[2] = out[1]; el_p[3] = out[2];
+}
+
+/* electron.c:70-94 (generateSingleElectron, electron.c:7-13, reduces to this
+ * when NONTHERMAL_E_DIST == OFF) */
+void orc_singleThermalElectron(double el_p[4], double temp, const double ph_p[4], orc_rng *rng)
+{
+    double gamma = orc_sampleThermalElectron(temp, rng);
+    double beta = sqrt(1 - (1 / (gamma * gamma)));
+    double phi = orc_rng_uniform(rng) * 2 * M_PI;
+    double theta = orc_sampleElectronTheta(beta, rng);
+    el_p[0] = gamma * ORC_M_EL * ORC_C_LIGHT;
+    el_p[1] = gamma * ORC_M_EL * ORC_C_LIGHT * beta * cos(theta);
+    el_p[2] = gamma * ORC_M_EL * ORC_C_LIGHT * beta * sin(theta) * sin(phi);
+    el_p[3] = gamma * ORC_M_EL * ORC_C_LIGHT * beta * sin(theta) * cos(phi);
+    orc_rotateElectron(el_p, ph_p);
+}
+
+/* mcrat_scattering.c:151-485 */
+int orc_singleScatter(const orc_config *c, double el_comov[4], double ph_comov[4], double s[4], orc_rng *rng)
+{
+    const double z_axis[3] = {0, 0, 1};
+    double el_v[3], neg_el_v[3], ph_pr[4], el_pr[4], ph_orig[4];
+    double rot0[9], rot1[9], res0[3], res1[3], result[4];
+    double phi0, phi1, phi = 0, theta = 0;
+    int occurred;
+
+    el_v[0] = el_comov[1] / el_comov[0];
+    el_v[1] = el_comov[2] / el_comov[0];
+    el_v[2] = el_comov[3] / el_comov[0];
+
+    orc_lorentzBoost(el_v, el_comov, el_pr, 'e');   /* :217 */
+    orc_lorentzBoost(el_v, ph_comov, ph_pr, 'p');   /* :218 */
+
+    if (c->stokes_switch) orc_stokesRotation(el_v, ph_comov + 1, ph_pr + 1, s); /* :225 */
+
+    memcpy(ph_orig, ph_pr, sizeof ph_orig);          /* :236-239 */
+
+    phi0 = atan2(ph_pr[2], ph_pr[1]);                 /* :244 */
+    memset(rot0, 0, sizeof rot0);
+    rot0[8] = 1;
+    rot0[0] = cos(-phi0);
+    rot0[4] = cos(-phi0);
+    rot0[1] = -sin(-phi0);
+    rot0[3] = sin(-phi0);
+    matvec(3, rot0, ph_pr + 1, res0);                 /* :252 */
+    ph_pr[1] = res0[0];
+    ph_pr[2] = 0;
+    ph_pr[3] = res0[2];
+
+    phi1 = atan2(res0[2], res0[0]);                   /* :269 */
+    memset(rot1, 0, sizeof rot1);
+    rot1[4] = 1;
+    rot1[0] = cos(-phi1);
+    rot1[8] = cos(-phi1);
+    rot1[2] = -sin(-phi1);
+    rot1[6] = sin(-phi1);
+    matvec(3, rot1, ph_pr + 1, res1);                 /* :283 */
+    ph_pr[1] = ph_pr[0];                              /* :294 */
+    ph_pr[2] = res1[1];
+    ph_pr[3] = 0;
+
+    occurred = orc_kleinNishinaScatter(c, &theta, &phi, ph_pr[0], s[1], s[2], rng); /* :307 */
+
+    if (occurred == 1) {
+        result[0] = ph_pr[0] / (1 + ((ph_pr[0] * (1 - cos(theta))) / (ORC_M_EL * ORC_C_LIGHT))); /* :322 */
+        result[1] = result[0] * cos(theta);
+        result[2] = result[0] * sin(theta) * sin(phi);
+        result[3] = result[0] * sin(theta) * cos(phi);
+        /* :342-348 update the electron 4-momentum, which is never read again */
+
+        memcpy(ph_pr, result, sizeof result);         /* :356-359 */
+        memset(rot1, 0, sizeof rot1);
+        rot1[4] = 1;
+        rot1[0] = cos(-phi1);
+        rot1[8] = cos(-phi1);
+        rot1[2] = sin(-phi1);
+        rot1[6] = -sin(-phi1);
+        matvec(3, rot1, ph_pr + 1, res1);             /* :366 */
+        ph_pr[1] = res1[0]; ph_pr[2] = res1[1]; ph_pr[3] = res1[2];
+
+        memset(rot0, 0, sizeof rot0);
+        rot0[8] = 1;
+        rot0[0] = cos(-phi0);
+        rot0[4] = cos(-phi0);
+        rot0[1] = sin(-phi0);
+        rot0[3] = -sin(-phi0);
+        matvec(3, rot0, ph_pr + 1, res0);             /* :386 */
+
+        if (c->stokes_switch) {
+            double xt[3], yt[3], xn[3], yn[3], scatt[16], sres[4];
+            orc_findXY(ph_orig + 1, z_axis, xt, yt);  /* :402 */
+            orc_findXY(res0, ph_orig + 1, xn, yn);    /* :403 */
+            phi = orc_findPhi(xt, yt, xn, yn);
+            orc_mullerMatrixRotation(phi, s);
+
+            theta = acos((ph_orig[1] * res0[0] + ph_orig[2] * res0[1] + ph_orig[3] * res0[2]) / (ph_orig[0] * ph_pr[0])); /* :408 */
+
+            memset(scatt, 0, sizeof scatt);           /* :411-416, Fano's matrix */
+            scatt[0]  = 1.0 + pow(cos(theta), 2.0) + ((1 - cos(theta)) * (ph_orig[0] - result[0]) / (ORC_M_EL * ORC_C_LIGHT));
+            scatt[1]  = sin(theta) * sin(theta);
+            scatt[4]  = sin(theta) * sin(theta);
+            scatt[5]  = 1.0 + cos(theta) * cos(theta);
+            scatt[10] = 2.0 * cos(theta);
+            scatt[15] = 2.0 * cos(theta) + ((cos(theta)) * (1 - cos(theta)) * (ph_orig[0] - result[0]) / (ORC_M_EL * ORC_C_LIGHT));
+            matvec(4, scatt, s, sres);                /* :418 */
+            s[0] = sres[0] / sres[0];                 /* :430-433 */
+            s[1] = sres[1] / sres[0];
+            s[2] = sres[2] / sres[0];
+            s[3] = sres[3] / sres[0];
+
+            orc_findXY(res0, ph_orig + 1, xt, yt);    /* :438 */
+            orc_findXY(res0, z_axis, xn, yn);         /* :441 */
+            phi = orc_findPhi(xt, yt, xn, yn);
+            orc_mullerMatrixRotation(phi, s);         /* :447 */
+        }
+
+        ph_pr[1] = res0[0]; ph_pr[2] = res0[1]; ph_pr[3] = res0[2]; /* :452-454 */
+        neg_el_v[0] = -1 * el_v[0];
+        neg_el_v[1] = -1 * el_v[1];
+        neg_el_v[2] = -1 * el_v[2];
+        orc_lorentzBoost(neg_el_v, ph_pr, ph_comov, 'p');            /* :465 */
+        if (c->stokes_switch) orc_stokesRotation(neg_el_v, ph_pr + 1, ph_comov + 1, s); /* :473 */
+    }
+    return occurred;
+}
+
+/* ------------------------------------------------------------------ */
+/* optical_depth.c:7-59 with TAU_CALCULATION == DIRECT (getCrossSection = 1, :125-127) */
+void orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hydro *h)
+{
+    int idx = ph->nearest_block_index;
+    double fluid_beta[3];
+    double ph_phi = atan2(ph->r1, ph->r0);
+    cell_beta_cartesian(c, h, idx, ph_phi, fluid_beta);
+
+    double fl_v_x = fluid_beta[0], fl_v_y = fluid_beta[1], fl_v_z = fluid_beta[2];
+    double fl_v_norm = sqrt(fl_v_x * fl_v_x + fl_v_y * fl_v_y + fl_v_z * fl_v_z);
+    double ph_v_norm = sqrt(ph->p1 * ph->p1 + ph->p2 * ph->p2 + ph->p3 * ph->p3);
+    double n_cosangle = ((fl_v_x * ph->p1) + (fl_v_y * ph->p2) + (fl_v_z * ph->p3)) / (fl_v_norm * ph_v_norm);
+    double beta = sqrt(1.0 - 1.0 / (h->gamma[idx] * h->gamma[idx]));
+    double fluid_factor = (1.0 - beta * n_cosangle);
+    double thermal_n_dens_lab = h->dens_lab[idx] / ORC_M_P;
+    double norm_cross_section = 1;
+    ph->total_optical_depth = (thermal_n_dens_lab) * (ORC_THOM_X_SECT * norm_cross_section) * fluid_factor;
+}
+
+/* mclib.c:436-615 */
+int orc_findContainingHydroCell(const orc_config *c, orc_photon_list *l, const orc_hydro *h,
+                                int find_nearest_block_switch, orc_stats *st)
+{
+    int n_new = 0;
+    for (int i = 0; i < l->list_capacity; i++) {
+        orc_photon *ph = &l->photons[i];
+        int ph_block_index = (find_nearest_block_switch == 0) ? ph->nearest_block_index : 0;
+        double hc[3];
+        orc_mcratCoordinateToHydroCoordinate(c, hc, ph->r0, ph->r1, ph->r2);
+
+        int inside;
+        if (c->dimensions == ORC_TWO || c->dimensions == ORC_TWO_POINT_FIVE)
+            inside = (hc[1] < h->r1_domain[1]) && (hc[1] > h->r1_domain[0]) &&
+                     (hc[0] < h->r0_domain[1]) && (hc[0] > h->r0_domain[0]);
+        else
+            inside = (hc[2] < h->r2_domain[1]) && (hc[2] > h->r2_domain[0]) &&
+                     (hc[1] < h->r1_domain[1]) && (hc[1] > h->r1_domain[0]) &&
+                     (hc[0] < h->r0_domain[1]) && (hc[0] > h->r0_domain[0]);
+
+        if (inside && (ph->nearest_block_index != -1)) {
+            int is_in_block = orc_checkInBlock(c, hc[0], hc[1], hc[2], h, ph_block_index);
+            if (find_nearest_block_switch == 1 || !is_in_block) {
+                int min_index = orc_findContainingBlock(c, hc[0], hc[1], hc[2], h);
+                ph->nearest_block_index = min_index;
+                if (min_index != -1) {
+                    double ph_p[4] = {ph->p0, ph->p1, ph->p2, ph->p3}, ph_p_comv[4], fluid_beta[3];
+                    double ph_phi = atan2(ph->r1, ph->r0);
+                    cell_beta_cartesian(c, h, min_index, ph_phi, fluid_beta);
+                    orc_lorentzBoost(fluid_beta, ph_p, ph_p_comv, 'p');
+                    ph->comv_p0 = ph_p_comv[0];
+                    ph->comv_p1 = ph_p_comv[1];
+                    ph->comv_p2 = ph_p_comv[2];
+                    ph->comv_p3 = ph_p_comv[3];
+                    orc_calculateOpticalDepth(c, ph, h);
+                    if (ph->recalc_properties == 1) ph->recalc_properties = 0;
+                    n_new += 1;
+                } else if (st) {
+                    st->not_found += 1;
+                }
+            }
+        } else {
+            ph->nearest_block_index = -1;
+        }
+    }
+    if (find_nearest_block_switch != 0) n_new = 0;   /* mclib.c:608-611 */
+    return n_new;
+}
+
+/* argsort comparator of mclib.c:753-763 with a total order on ties */
+static int cmp_time_then_slot(const void *a, const void *b, void *ctx)
+{
+    const orc_photon *ph = (const orc_photon *)ctx;
+    int aa = *(const int *)a, bb = *(const int *)b;
+    double ta = ph[aa].time_to_scatter, tb = ph[bb].time_to_scatter;
+    if (isnan(ta)) ta = INFINITY;
+    if (isnan(tb)) tb = INFINITY;
+    if (ta < tb) return -1;
+    if (ta > tb) return 1;
+    return (aa > bb) - (aa < bb);
+}
+
+/* mclib.c:617-714 */
+void orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hydro *h, orc_rng *rng)
+{
+    const double default_mfp = 1e12;
+    for (int i = 0; i < l->list_capacity; i++) {
+        orc_photon *ph = &l->photons[i];
+        double mfp;
+        if (ph->nearest_block_index != -1) {
+            if (ph->recalc_properties == 1) {
+                orc_calculateOpticalDepth(c, ph, h);
+                ph->recalc_properties = 0;
+            }
+            double rnd = orc_rng_freepath_upos(rng, (uint32_t)i);
+            mfp = (-1.0 / ph->total_optical_depth) * log(rnd);
+        } else {
+            mfp = default_mfp;
+        }
+        ph->time_to_scatter = mfp / ORC_C_LIGHT;
+    }
+    for (int i = 0; i < l->list_capacity; i++) l->sorted_indexes[i] = i;
+    qsort_r(l->sorted_indexes, (size_t)l->list_capacity, sizeof(int), cmp_time_then_slot, l->photons);
+}
+
+/* mclib.c:1054-1100 (the two position norms computed there are unused) */
+void orc_updatePhotonPosition(orc_photon_list *l, double t)
+{
+    for (int i = 0; i < l->list_capacity; i++) {
+        orc_photon *ph = &l->photons[i];
+        if ((ph->type != ORC_CS_POOL_PHOTON) && (ph->weight != 0)) {
+            double divide_p0 = 1.0 / ph->p0;
+            ph->r0 += ph->p1 * divide_p0 * ORC_C_LIGHT * t;
+            ph->r1 += ph->p2 * divide_p0 * ORC_C_LIGHT * t;
+            ph->r2 += ph->p3 * divide_p0 * ORC_C_LIGHT * t;
+        }
+    }
+}
+
+/* mclib.c:1107-1356 */
+double orc_photonEvent(const orc_config *c, orc_photon_list *l, double dt_max, const orc_hydro *h,
+                       int *scattered_ph_index, long long *frame_scatt_cnt, orc_rng *rng, orc_stats *st)
+{
+    int i = 0, ph_index = 0, event_did_occur = 0;
+    double scatt_time = 0, old_scatt_time = 0;
+
+    while (i < l->list_capacity && event_did_occur == 0) {
+        ph_index = l->sorted_indexes[i];
+        orc_photon *ph = &l->photons[ph_index];
+        scatt_time = ph->time_to_scatter;
+
+        if (scatt_time < dt_max) {
+            orc_updatePhotonPosition(l, scatt_time - old_scatt_time);
+            int index = ph->nearest_block_index;
+            if (index != -1) {   /* documented deviation: see header */
+                double fluid_temp = h->temp[index];
+                double ph_phi = atan2(ph->r1, ph->r0);
+                double fluid_beta[3], negative_fluid_beta[3];
+                cell_beta_cartesian(c, h, index, ph_phi, fluid_beta);
+
+                double ph_p[4] = {ph->p0, ph->p1, ph->p2, ph->p3};
+                double ph_p_comov[4] = {ph->comv_p0, ph->comv_p1, ph->comv_p2, ph->comv_p3};
+                double s[4] = {ph->s0, ph->s1, ph->s2, ph->s3};
+                double el_p_comov[4];
+
+                if (c->stokes_switch) orc_stokesRotation(fluid_beta, ph_p + 1, ph_p_comov + 1, s); /* :1227 */
+
+                orc_rng_event_begin(rng, (uint32_t)ph_index);
+                orc_singleThermalElectron(el_p_comov, fluid_temp, ph_p_comov, rng);            /* :1234 */
+                event_did_occur = orc_singleScatter(c, el_p_comov, ph_p_comov, s, rng);        /* :1245 */
+                if (st) st->event_draws += (long long)rng->n_draws;
+
+                if (event_did_occur == 1) {
+                    negative_fluid_beta[0] = -1 * fluid_beta[0];
+                    negative_fluid_beta[1] = -1 * fluid_beta[1];
+                    negative_fluid_beta[2] = -1 * fluid_beta[2];
+                    orc_lorentzBoost(negative_fluid_beta, ph_p_comov, ph_p, 'p');             /* :1265 */
+                    if (c->stokes_switch) {
+                        orc_stokesRotation(negative_fluid_beta, ph_p_comov + 1, ph_p + 1, s);  /* :1280 */
+                        ph->s0 = s[0]; ph->s1 = s[1]; ph->s2 = s[2]; ph->s3 = s[3];
+                    }
+                    ph->p0 = ph_p[0]; ph->p1 = ph_p[1]; ph->p2 = ph_p[2]; ph->p3 = ph_p[3];
+                    ph->comv_p0 = ph_p_comov[0]; ph->comv_p1 = ph_p_comov[1];
+                    ph->comv_p2 = ph_p_comov[2]; ph->comv_p3 = ph_p_comov[3];
+                    ph->num_scatt += 1;
+                    *frame_scatt_cnt += 1;
+                    ph->recalc_properties = 1;
+                } else if (st) {
+                    st->kn_rejections += 1;
+                }
+            }
+        } else {
+            scatt_time = dt_max;
+            orc_updatePhotonPosition(l, scatt_time - old_scatt_time);
+            event_did_occur = 1;
+        }
+        old_scatt_time = scatt_time;
+        i++;
+    }
+    *scattered_ph_index = ph_index;
+    return scatt_time;
+}
+
+/* mclib.c:1358-1383 (CYCLOSYNCHROTRON_SWITCH OFF: no weight filter) */
+double orc_averagePhotonEnergy(const orc_photon_list *l)
+{
+    double e_sum = 0, w_sum = 0;
+    for (int i = 0; i < l->list_capacity; i++) {
+        e_sum += l->photons[i].p0 * l->photons[i].weight;
+        w_sum += l->photons[i].weight;
+    }
+    return (e_sum * ORC_C_LIGHT) / w_sum;
+}
+
+/* mclib.c:1385-1462 (CYCLOSYNCHROTRON_SWITCH OFF) */
+void orc_phScattStats(const orc_photon_list *l, int *max, int *min, double *avg, double *r_avg)
+{
+    int temp_max = 0, temp_min = INT_MAX, count = 0;
+    double sum = 0, avg_r_sum = 0;
+    for (int i = 0; i < l->list_capacity; i++) {
+        const orc_photon *ph = &l->photons[i];
+        sum += ph->num_scatt;
+        avg_r_sum += sqrt(ph->r0 * ph->r0 + ph->r1 * ph->r1 + ph->r2 * ph->r2);
+        if (ph->num_scatt > temp_max) temp_max = (int)ph->num_scatt;
+        if (ph->num_scatt < temp_min) temp_min = (int)ph->num_scatt;
+        count++;
+    }
+    *avg = sum / count;
+    *r_avg = avg_r_sum / count;
+    *max = temp_max;
+    *min = temp_min;
+}
+
+/* mclib.c:1465-1515 */
+void orc_phMinMax(const orc_photon_list *l, double *min, double *max, double *min_theta, double *max_theta)
+{
+    double r_max = 0, r_min = DBL_MAX, th_max = 0, th_min = DBL_MAX;
+    for (int i = 0; i < l->list_capacity; i++) {
+        const orc_photon *ph = &l->photons[i];
+        if (ph->weight != 0) {
+            double r = sqrt(ph->r0 * ph->r0 + ph->r1 * ph->r1 + ph->r2 * ph->r2);
+            double th = acos(ph->r2 / r);
+            if (r > r_max) r_max = r;
+            if (r < r_min) r_min = r;
+            if (th > th_max) th_max = th;
+            if (th < th_min) th_min = th;
+        }
+    }
+    *max = r_max; *min = r_min; *max_theta = th_max; *min_theta = th_min;
+}
+
+/* mcrat.c:754-851 */
+void orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro *h, orc_rng *rng,
+                     double *time_now, double *remaining_time, int *find_nearest_grid_switch,
+                     long long max_iterations, uint64_t iteration_base, orc_stats *st)
+{
+    long long it = 0;
+    double time_step = 0;
+    while (*remaining_time > 0 && (max_iterations <= 0 || it < max_iterations)) {
+        orc_rng_set_iteration(rng, iteration_base + (uint64_t)it);
+        st->num_photons_find_new_element += orc_findContainingHydroCell(c, l, h, *find_nearest_grid_switch, st);
+        orc_calcMeanFreePath(c, l, h, rng);
+        *find_nearest_grid_switch = 0;
+
+        if (l->photons[l->sorted_indexes[0]].time_to_scatter < *remaining_time) {
+            time_step = orc_photonEvent(c, l, *remaining_time, h, &st->last_scattered_index,
+                                        &st->frame_scatt_cnt, rng, st);
+            *time_now += time_step;
+            *remaining_time -= time_step;
+        } else {
+            *time_now += *remaining_time;
+            orc_updatePhotonPosition(l, *remaining_time);
+            time_step = *remaining_time;
+            *remaining_time = 0;
+        }
+        it++;
+        st->photon_steps += l->list_capacity;
+    }
+    st->iterations += it;
+    st->last_time_step = time_step;
+    st->remaining_time = *remaining_time;
+    st->time_now = *time_now;
+}

@@ -1,0 +1,164 @@
+/*
+ * mcrat_oracle.h -- CPU oracle for MCRaT's per-timestep photon loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may import, call, link or execute anything
+ * under oracle/ -- and there only as the checker or the timed CPU baseline,
+ * never as the thing shipped.  The product path (include/, mcrat_amd/) does
+ * not link this library and fails loudly when its HIP extension is missing.
+ *
+ * PARITY UNPINNED: the reference (lazzati-astro/MCRaT @ /root/reference) ships
+ * no tests, golden vectors or fixtures for this path and
+ * cannot be compiled in this image: every translation unit includes 22 GSL
+ * headers (Src/mcrat.h:91-125) and GSL is not installed; writing stand-ins for
+ * it is not allowed.  This file is therefore a plain-C restatement of the
+ * reference's algorithm, function by function with the reference file:line
+ * cited on each, pinned only by closed-form known-answer tests
+ * (tests/test_oracle_kat.py) and self-consistency properties.
+ *
+ * Deviations from the reference, all deliberate and documented in DESIGN.md:
+ *   - random source: oracle_rng.h (the reference's ranlxs0 stream is an input);
+ *   - the compile-time switches of mcrat_input.h are run-time fields of
+ *     orc_config so one library serves every configuration;
+ *   - argsort ties (qsort_r is unstable, mclib.c:723) break by lowest slot;
+ *   - a photon whose free time is the 1e12/c "never scatters" default is not
+ *     offered to the scattering routine even if dt_max were larger (the
+ *     reference would index hydro arrays with -1 there, mclib.c:1146-1148);
+ *   - fprintf logging is replaced by counters in orc_stats.
+ */
+#ifndef MCRAT_ORACLE_H
+#define MCRAT_ORACLE_H
+
+#include <stdint.h>
+#include <stdio.h>
+#include "oracle_rng.h"
+
+/* values mirror Src/mcrat.h:36-44 */
+#define ORC_CARTESIAN   0
+#define ORC_SPHERICAL   1
+#define ORC_CYLINDRICAL 2
+#define ORC_POLAR       3
+#define ORC_TWO             0
+#define ORC_TWO_POINT_FIVE  1
+#define ORC_THREE           2
+
+/* Src/mcrat.h:52-57 */
+#define ORC_INJECTED_PHOTON      'i'
+#define ORC_COMPTONIZED_PHOTON   'k'
+#define ORC_CS_POOL_PHOTON       'p'
+#define ORC_UNABSORBED_CS_PHOTON 'c'
+#define ORC_REBINNED_PHOTON      'r'
+#define ORC_NULL_PHOTON          'N'
+
+/* Src/mclib.c:4-5, verbatim values */
+#define ORC_A_RAD       7.56e-15
+#define ORC_C_LIGHT     2.99792458e10
+#define ORC_PL_CONST    6.6260755e-27
+#define ORC_K_B         1.380658e-16
+#define ORC_M_P         1.6726231e-24
+#define ORC_THOM_X_SECT 6.65246e-25
+#define ORC_M_EL        9.1093879e-28
+
+/* Src/mcrat.h:142-171, thermal-only build: 176 bytes on x86-64 */
+typedef struct orc_photon {
+    char   type;
+    double p0, p1, p2, p3;
+    double comv_p0, comv_p1, comv_p2, comv_p3;
+    double r0, r1, r2;
+    double s0, s1, s2, s3;
+    double num_scatt;
+    int    recalc_properties;
+    double weight;
+    int    nearest_block_index;
+    double time_to_scatter;
+    double total_optical_depth;
+} orc_photon;
+
+/* Src/mcrat.h:173-180 */
+typedef struct orc_photon_list {
+    orc_photon *photons;
+    int *sorted_indexes;
+    int num_photons;
+    int num_null_photons;
+    int list_capacity;
+} orc_photon_list;
+
+/* the fields of struct hydro_dataframe (Src/mcrat.h:194-244) the path reads */
+typedef struct orc_hydro {
+    int num_elements;
+    double *r0, *r1, *r2;
+    double *r0_size, *r1_size, *r2_size;
+    double *v0, *v1, *v2;
+    double *dens_lab, *temp, *gamma;
+    double r0_domain[2], r1_domain[2], r2_domain[2];
+    double fps;
+} orc_hydro;
+
+typedef struct orc_config {
+    int dimensions;     /* ORC_TWO / ORC_TWO_POINT_FIVE / ORC_THREE  (mcrat_input.h DIMENSIONS) */
+    int geometry;       /* ORC_CARTESIAN ...                          (mcrat_input.h GEOMETRY)   */
+    int stokes_switch;  /* STOKES_SWITCH                                                        */
+} orc_config;
+
+typedef struct orc_stats {
+    long long iterations;
+    long long photon_steps;          /* sum over iterations of list_capacity          */
+    long long frame_scatt_cnt;       /* mclib.c:1318                                   */
+    long long num_photons_find_new_element; /* mclib.c:579                             */
+    long long not_found;             /* "Hydro grid index not found" lines mclib.c:583 */
+    long long kn_rejections;         /* candidates that drew an electron but did not scatter */
+    long long event_draws;           /* event-stream draws consumed                    */
+    int    last_scattered_index;     /* *scattered_ph_index, mclib.c:1341              */
+    double last_time_step;
+    double remaining_time;
+    double time_now;
+} orc_stats;
+
+/* ---- L1 maths -------------------------------------------------------- */
+void   orc_lorentzBoost(const double boost[3], const double p[4], double result[4], char object); /* mclib.c:302 */
+void   orc_zeroNorm(double p[4]);                                                                /* mclib.c:409 */
+double orc_dnrm2(const double *x, int n);                                /* reference BLAS dnrm2 (gsl_blas_dnrm2) */
+void   orc_mcratCoordinateToHydroCoordinate(const orc_config *c, double out[3], double x, double y, double z); /* geometry.c:15 */
+void   orc_hydroVectorToCartesian(const orc_config *c, double out[3], double v0, double v1, double v2,
+                                  double x0, double x1, double x2);       /* geometry.c:189 */
+int    orc_checkInBlock(const orc_config *c, double a0, double a1, double a2, const orc_hydro *h, int idx); /* geometry.c:394 */
+int    orc_findContainingBlock(const orc_config *c, double a0, double a1, double a2, const orc_hydro *h);   /* geometry.c:350 */
+double orc_hydroElementVolume(const orc_config *c, const orc_hydro *h, int idx); /* geometry.c:255 */
+void   orc_mullerMatrixRotation(double theta, double s[4]);              /* mcrat_scattering.c:10 */
+void   orc_findXY(const double v_ph[3], const double ref[3], double x[3], double y[3]); /* mcrat_scattering.c:41 */
+double orc_findPhi(const double x_old[3], const double y_old[3], const double x_new[3], const double y_new[3]); /* :67 */
+void   orc_stokesRotation(const double v[3], const double v_ph[3], const double v_ph_boosted[3], double s[4]);  /* :103 */
+double orc_kleinNishinaCrossSection(double energy_ratio);                /* mcrat_scattering.c:597 */
+double orc_bessel_K2(double x);                                          /* stands for gsl_sf_bessel_Kn(2,x), electron.c:221 */
+
+/* ---- sampling -------------------------------------------------------- */
+int    orc_kleinNishinaScatter(const orc_config *c, double *theta, double *phi, double p0, double q, double u, orc_rng *rng); /* :509 */
+double orc_sampleThermalElectron(double temp, orc_rng *rng);             /* electron.c:202 */
+double orc_sampleElectronTheta(double beta, orc_rng *rng);               /* electron.c:177 */
+void   orc_rotateElectron(double el_p[4], const double ph_p[4]);         /* electron.c:126 */
+void   orc_singleThermalElectron(double el_p[4], double temp, const double ph_p[4], orc_rng *rng); /* electron.c:70 */
+int    orc_singleScatter(const orc_config *c, double el_comov[4], double ph_comov[4], double s[4], orc_rng *rng); /* mcrat_scattering.c:151 */
+
+/* ---- the loop (reference signatures minus gsl_rng*, FILE*) ------------ */
+void   orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hydro *h);       /* optical_depth.c:7 */
+int    orc_findContainingHydroCell(const orc_config *c, orc_photon_list *l, const orc_hydro *h,
+                                   int find_nearest_block_switch, orc_stats *st);                /* mclib.c:436 */
+void   orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hydro *h, orc_rng *rng); /* mclib.c:617 */
+void   orc_updatePhotonPosition(orc_photon_list *l, double t);                                   /* mclib.c:1054 */
+double orc_photonEvent(const orc_config *c, orc_photon_list *l, double dt_max, const orc_hydro *h,
+                       int *scattered_ph_index, long long *frame_scatt_cnt, orc_rng *rng, orc_stats *st); /* mclib.c:1107 */
+double orc_averagePhotonEnergy(const orc_photon_list *l);                                         /* mclib.c:1358 */
+void   orc_phScattStats(const orc_photon_list *l, int *max, int *min, double *avg, double *r_avg); /* mclib.c:1385 */
+void   orc_phMinMax(const orc_photon_list *l, double *min, double *max, double *min_theta, double *max_theta); /* mclib.c:1465 */
+
+/* while (remaining_time>0) of mcrat.c:754-851, optionally bounded by max_iterations (<=0: unbounded).
+ * iteration_base offsets the RNG iteration counter so a frame can be run in several calls.
+ * find_nearest_grid_switch is the value at entry (1 on the first call of a frame, mcrat.c:756). */
+void   orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro *h, orc_rng *rng,
+                       double *time_now, double *remaining_time, int *find_nearest_grid_switch,
+                       long long max_iterations, uint64_t iteration_base, orc_stats *st);
+
+/* helpers for ctypes */
+int    orc_sizeof_photon(void);
+
+#endif

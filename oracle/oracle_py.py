@@ -1,0 +1,199 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never from the product package mcrat_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+# struct photon of Src/mcrat.h:142-171 (thermal-only build), 176 bytes
+PHOTON_DTYPE = np.dtype(
+    [("type", "S1"),
+     ("p0", "f8"), ("p1", "f8"), ("p2", "f8"), ("p3", "f8"),
+     ("comv_p0", "f8"), ("comv_p1", "f8"), ("comv_p2", "f8"), ("comv_p3", "f8"),
+     ("r0", "f8"), ("r1", "f8"), ("r2", "f8"),
+     ("s0", "f8"), ("s1", "f8"), ("s2", "f8"), ("s3", "f8"),
+     ("num_scatt", "f8"),
+     ("recalc_properties", "i4"),
+     ("weight", "f8"),
+     ("nearest_block_index", "i4"),
+     ("time_to_scatter", "f8"),
+     ("total_optical_depth", "f8")],
+    align=True,
+)
+assert PHOTON_DTYPE.itemsize == 176
+
+CARTESIAN, SPHERICAL, CYLINDRICAL, POLAR = 0, 1, 2, 3
+TWO, TWO_POINT_FIVE, THREE = 0, 1, 2
+
+_dp = C.POINTER(C.c_double)
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("iteration", C.c_uint64), ("stream", C.c_uint32),
+                ("ev_state", C.c_uint64), ("n_draws", C.c_uint64)]
+
+
+class PhotonList(C.Structure):
+    _fields_ = [("photons", C.c_void_p), ("sorted_indexes", C.POINTER(C.c_int)),
+                ("num_photons", C.c_int), ("num_null_photons", C.c_int), ("list_capacity", C.c_int)]
+
+
+class Hydro(C.Structure):
+    _fields_ = [("num_elements", C.c_int),
+                ("r0", _dp), ("r1", _dp), ("r2", _dp),
+                ("r0_size", _dp), ("r1_size", _dp), ("r2_size", _dp),
+                ("v0", _dp), ("v1", _dp), ("v2", _dp),
+                ("dens_lab", _dp), ("temp", _dp), ("gamma", _dp),
+                ("r0_domain", C.c_double * 2), ("r1_domain", C.c_double * 2), ("r2_domain", C.c_double * 2),
+                ("fps", C.c_double)]
+
+
+class Config(C.Structure):
+    _fields_ = [("dimensions", C.c_int), ("geometry", C.c_int), ("stokes_switch", C.c_int)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("iterations", C.c_longlong), ("photon_steps", C.c_longlong),
+                ("frame_scatt_cnt", C.c_longlong), ("num_photons_find_new_element", C.c_longlong),
+                ("not_found", C.c_longlong), ("kn_rejections", C.c_longlong), ("event_draws", C.c_longlong),
+                ("last_scattered_index", C.c_int), ("last_time_step", C.c_double),
+                ("remaining_time", C.c_double), ("time_now", C.c_double)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("mcrat_oracle.c", "mcrat_oracle.h", "oracle_rng.c", "oracle_rng.h")):
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        d, i, p = C.c_double, C.c_int, C.c_void_p
+        cfgp, hp, lp, rp, sp = C.POINTER(Config), C.POINTER(Hydro), C.POINTER(PhotonList), C.POINTER(Rng), C.POINTER(Stats)
+        sig = {
+            "orc_philox4x32_10": (None, [C.POINTER(C.c_uint32)] * 3),
+            "orc_splitmix64_next": (C.c_uint64, [C.POINTER(C.c_uint64)]),
+            "orc_rng_init": (None, [rp, C.c_uint64, C.c_uint32]),
+            "orc_rng_set_iteration": (None, [rp, C.c_uint64]),
+            "orc_rng_freepath_upos": (d, [rp, C.c_uint32]),
+            "orc_rng_freepath_bits": (C.c_uint64, [rp, C.c_uint32]),
+            "orc_rng_event_begin": (None, [rp, C.c_uint32]),
+            "orc_rng_uniform": (d, [rp]),
+            "orc_rng_uniform_pos": (d, [rp]),
+            "orc_rng_gaussian": (d, [rp, d]),
+            "orc_lorentzBoost": (None, [_dp, _dp, _dp, C.c_char]),
+            "orc_zeroNorm": (None, [_dp]),
+            "orc_dnrm2": (d, [_dp, i]),
+            "orc_mcratCoordinateToHydroCoordinate": (None, [cfgp, _dp, d, d, d]),
+            "orc_hydroVectorToCartesian": (None, [cfgp, _dp, d, d, d, d, d, d]),
+            "orc_checkInBlock": (i, [cfgp, d, d, d, hp, i]),
+            "orc_findContainingBlock": (i, [cfgp, d, d, d, hp]),
+            "orc_hydroElementVolume": (d, [cfgp, hp, i]),
+            "orc_mullerMatrixRotation": (None, [d, _dp]),
+            "orc_findXY": (None, [_dp, _dp, _dp, _dp]),
+            "orc_findPhi": (d, [_dp, _dp, _dp, _dp]),
+            "orc_stokesRotation": (None, [_dp, _dp, _dp, _dp]),
+            "orc_kleinNishinaCrossSection": (d, [d]),
+            "orc_bessel_K2": (d, [d]),
+            "orc_kleinNishinaScatter": (i, [cfgp, _dp, _dp, d, d, d, rp]),
+            "orc_sampleThermalElectron": (d, [d, rp]),
+            "orc_sampleElectronTheta": (d, [d, rp]),
+            "orc_rotateElectron": (None, [_dp, _dp]),
+            "orc_singleThermalElectron": (None, [_dp, d, _dp, rp]),
+            "orc_singleScatter": (i, [cfgp, _dp, _dp, _dp, rp]),
+            "orc_calculateOpticalDepth": (None, [cfgp, p, hp]),
+            "orc_findContainingHydroCell": (i, [cfgp, lp, hp, i, sp]),
+            "orc_calcMeanFreePath": (None, [cfgp, lp, hp, rp]),
+            "orc_updatePhotonPosition": (None, [lp, d]),
+            "orc_photonEvent": (d, [cfgp, lp, d, hp, C.POINTER(i), C.POINTER(C.c_longlong), rp, sp]),
+            "orc_averagePhotonEnergy": (d, [lp]),
+            "orc_phScattStats": (None, [lp, C.POINTER(i), C.POINTER(i), _dp, _dp]),
+            "orc_phMinMax": (None, [lp, _dp, _dp, _dp, _dp]),
+            "orc_photon_loop": (None, [cfgp, lp, hp, rp, _dp, _dp, C.POINTER(i), C.c_longlong, C.c_uint64, sp]),
+            "orc_sizeof_photon": (i, []),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        assert L.orc_sizeof_photon() == PHOTON_DTYPE.itemsize
+        _lib = L
+    return _lib
+
+
+def vec(a):
+    """contiguous float64 array and its double* (keep the array alive)."""
+    arr = np.ascontiguousarray(a, dtype=np.float64)
+    return arr, arr.ctypes.data_as(_dp)
+
+
+class OracleHydro:
+    """Owns the arrays behind an orc_hydro view.  `frame` is a dict with the
+    hydro_dataframe field names (see mcrat_amd.synth)."""
+    FIELDS = ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size", "v0", "v1", "v2", "dens_lab", "temp", "gamma")
+
+    def __init__(self, frame):
+        self.n = int(frame["num_elements"])
+        self.keep = {}
+        self.c = Hydro()
+        self.c.num_elements = self.n
+        for f in self.FIELDS:
+            a = frame.get(f)
+            if a is None:
+                a = np.zeros(self.n)
+            arr, ptr = vec(a)
+            assert arr.shape == (self.n,), f
+            self.keep[f] = arr
+            setattr(self.c, f, ptr)
+        for k in ("r0_domain", "r1_domain", "r2_domain"):
+            dom = frame.get(k, (0.0, 0.0))
+            getattr(self.c, k)[0] = float(dom[0])
+            getattr(self.c, k)[1] = float(dom[1])
+        self.c.fps = float(frame.get("fps", 1.0))
+
+
+class OraclePhotons:
+    """Owns an AoS photon array (PHOTON_DTYPE) and the photonList view on it."""
+
+    def __init__(self, aos):
+        self.aos = np.ascontiguousarray(aos, dtype=PHOTON_DTYPE).copy()
+        n = len(self.aos)
+        self.sorted = np.zeros(n, dtype=np.int32)
+        self.c = PhotonList()
+        self.c.photons = self.aos.ctypes.data
+        self.c.sorted_indexes = self.sorted.ctypes.data_as(C.POINTER(C.c_int))
+        nulls = int(np.count_nonzero(self.aos["type"] == b"N"))
+        self.c.num_photons = n - nulls
+        self.c.num_null_photons = nulls
+        self.c.list_capacity = n
+
+
+def make_config(dimensions, geometry, stokes):
+    return Config(int(dimensions), int(geometry), int(bool(stokes)))
+
+
+def photon_loop(cfg, photons, hydro, seed, time_now, remaining_time, max_iterations=0,
+                iteration_base=0, find_switch=1, stream=0):
+    """Run orc_photon_loop; returns (stats, time_now, remaining, find_switch)."""
+    L = lib()
+    rng = Rng()
+    L.orc_rng_init(C.byref(rng), int(seed), int(stream))
+    st = Stats()
+    tn, rem, sw = C.c_double(time_now), C.c_double(remaining_time), C.c_int(find_switch)
+    L.orc_photon_loop(C.byref(cfg), C.byref(photons.c), C.byref(hydro.c), C.byref(rng),
+                      C.byref(tn), C.byref(rem), C.byref(sw), int(max_iterations), int(iteration_base), C.byref(st))
+    return st, tn.value, rem.value, sw.value

@@ -1,0 +1,567 @@
+"""Known-answer and closed-form tests that pin the CPU oracle.
+
+The reference ships no tests or fixtures for this path and cannot be built here
+(GSL absent), so these closed-form checks are what pins oracle/ ("parity
+unpinned" by reference-run vectors; see oracle/mcrat_oracle.h and DESIGN.md).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy import special, stats
+
+from mcrat_amd import synth
+
+M_EL, C_LIGHT, K_B, M_P, SIG_T = synth.M_EL, synth.C_LIGHT, synth.K_B, synth.M_P, synth.THOM_X_SECT
+
+
+def _same(a, b):
+    """field-wise equality of two photon AoS arrays (struct padding is not compared)."""
+    return all(np.array_equal(a[k], b[k]) for k in a.dtype.names)
+
+
+def _v(*x):
+    a = np.array(x, dtype=np.float64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ------------------------------------------------------------------ RNG
+def test_philox_known_answers(oracle):
+    """Random123 kat_vectors for philox4x32-10."""
+    L = oracle.lib()
+    cases = [
+        ([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+        ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+        ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]),
+    ]
+    for ctr, key, want in cases:
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        o = (C.c_uint32 * 4)()
+        L.orc_philox4x32_10(c, k, o)
+        assert list(o) == want
+
+
+def test_splitmix64_known_answers(oracle):
+    L = oracle.lib()
+    s = C.c_uint64(1234567)
+    got = [L.orc_splitmix64_next(C.byref(s)) for _ in range(5)]
+    assert got == [6457827717110365317, 3203168211198807973, 9817491932198370423,
+                   4593380528125082431, 16408922859458223821]
+
+
+def test_uniform_ranges_and_keying(oracle):
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 42, 0)
+    L.orc_rng_set_iteration(C.byref(r), 7)
+    u = np.array([L.orc_rng_freepath_upos(C.byref(r), i) for i in range(4096)])
+    assert (u > 0).all() and (u < 1).all()
+    assert abs(u.mean() - 0.5) < 0.02
+    # slot pairs share one Philox block: words {0,1} and {2,3}
+    b0, b1 = L.orc_rng_freepath_bits(C.byref(r), 10), L.orc_rng_freepath_bits(C.byref(r), 11)
+    ctr = (C.c_uint32 * 4)(7, 0, 5, 0)
+    key = (C.c_uint32 * 2)(42, 0)
+    o = (C.c_uint32 * 4)()
+    L.orc_philox4x32_10(ctr, key, o)
+    assert b0 == o[0] | (o[1] << 32) and b1 == o[2] | (o[3] << 32)
+    # a different iteration or seed changes the draw
+    L.orc_rng_set_iteration(C.byref(r), 8)
+    assert L.orc_rng_freepath_bits(C.byref(r), 10) != b0
+    # event stream = splitmix64 seeded by the first 64 bits of the EVENT block
+    L.orc_rng_set_iteration(C.byref(r), 7)
+    L.orc_rng_event_begin(C.byref(r), 123)
+    ctr = (C.c_uint32 * 4)(7, 0, 123, 1)
+    L.orc_philox4x32_10(ctr, key, o)
+    s = C.c_uint64(o[0] | (o[1] << 32))
+    want = (L.orc_splitmix64_next(C.byref(s)) >> 11) * 2.0 ** -53
+    assert L.orc_rng_uniform(C.byref(r)) == want
+    # extremes of the conversions
+    assert (0xFFFFFFFFFFFFFFFF >> 11) * 2.0 ** -53 < 1.0
+    assert ((0 >> 12) + 0.5) * 2.0 ** -52 > 0.0 and ((0xFFFFFFFFFFFFFFFF >> 12) + 0.5) * 2.0 ** -52 < 1.0
+
+
+def test_gaussian_moments(oracle):
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 1, 0)
+    L.orc_rng_event_begin(C.byref(r), 0)
+    g = np.array([L.orc_rng_gaussian(C.byref(r), 2.5) for _ in range(100000)])
+    assert abs(g.mean()) < 0.03 and abs(g.std() - 2.5) < 0.03
+    assert stats.kstest(g / 2.5, "norm").pvalue > 1e-3
+
+
+# ------------------------------------------------------------------ Klein-Nishina cross section
+def test_kn_cross_section_closed_forms(oracle):
+    L = oracle.lib()
+    f = L.orc_kleinNishinaCrossSection
+    assert f(0.0) == 1.0
+    assert f(1e-6) == 1.0 - 2e-6
+    # value at eps = 1 from the textbook form (Rybicki & Lightman eq. 7.5)
+    x = 1.0
+    rl = 0.75 * ((1 + x) / x ** 3 * (2 * x * (1 + x) / (1 + 2 * x) - np.log(1 + 2 * x))
+                 + np.log(1 + 2 * x) / (2 * x) - (1 + 3 * x) / (1 + 2 * x) ** 2)
+    assert abs(f(1.0) - rl) < 1e-14
+    assert abs(f(1.0) - 0.43072784) < 1e-8
+    # the two branches meet at 1e-3 with a 5e-6 step that is reference behaviour
+    assert abs(f(1e-3) - 0.99800519) < 2e-7
+    assert f(np.nextafter(1e-3, 0)) == pytest.approx(0.998, abs=1e-12)
+    for x in np.logspace(-2.9, 3, 60):
+        rl = 0.75 * ((1 + x) / x ** 3 * (2 * x * (1 + x) / (1 + 2 * x) - np.log(1 + 2 * x))
+                     + np.log(1 + 2 * x) / (2 * x) - (1 + 3 * x) / (1 + 2 * x) ** 2)
+        assert f(float(x)) == pytest.approx(rl, rel=1e-8)
+    # monotone decreasing on the exact branch
+    y = np.array([f(float(x)) for x in np.logspace(-2.9, 3, 200)])
+    assert (np.diff(y) < 0).all()
+
+
+def test_bessel_k2_against_scipy(oracle):
+    L = oracle.lib()
+    for x in np.concatenate([np.logspace(np.log10(0.05), np.log10(700), 120), [593.0, 1.0, 2.0]]):
+        got = L.orc_bessel_K2(float(x))
+        want = special.kn(2, float(x))
+        assert got == pytest.approx(want, rel=2e-13), x
+
+
+# ------------------------------------------------------------------ boosts
+def test_lorentz_boost_properties(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        beta = rng.normal(size=3)
+        beta *= rng.uniform(0, 0.99995) / np.linalg.norm(beta)
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        e = 10 ** rng.uniform(-20, -15)
+        p, pp = _v(e, *(e * n))
+        b, bp = _v(*beta)
+        out, op = _v(0, 0, 0, 0)
+        L.orc_lorentzBoost(bp, pp, op, b"p")
+        # null vector after the photon boost
+        assert out[0] == pytest.approx(np.linalg.norm(out[1:]), rel=1e-15)
+        # agrees with the textbook boost
+        want = synth.lorentz_boost(beta[None, :], p[None, :])[0]
+        assert np.allclose(out, want, rtol=1e-11, atol=0)
+        # boost back is the identity
+        nb, nbp = _v(*(-beta))
+        back, backp = _v(0, 0, 0, 0)
+        L.orc_lorentzBoost(nbp, op, backp, b"p")
+        g = 1 / np.sqrt(1 - beta @ beta)
+        assert np.allclose(back, p, rtol=1e-12 * g * g, atol=0)
+    # along z: p0' = gamma (p0 - beta p3)
+    b, bp = _v(0, 0, 0.6)
+    p, pp = _v(1.0, 0.0, 0.0, 1.0)
+    out, op = _v(0, 0, 0, 0)
+    L.orc_lorentzBoost(bp, pp, op, b"e")
+    assert np.allclose(out, [1.25 * 0.4, 0, 0, 1.25 * 0.4], rtol=1e-15)
+    # beta = 0 returns the input (electron) / the re-normalised input (photon)
+    b, bp = _v(0, 0, 0)
+    p, pp = _v(2.0, 0.0, 3.0, 4.0)
+    L.orc_lorentzBoost(bp, pp, op, b"e")
+    assert np.array_equal(out, p)
+    L.orc_lorentzBoost(bp, pp, op, b"p")
+    assert np.allclose(out, [2.0, 0.0, 1.2, 1.6], rtol=1e-15)
+
+
+def test_dnrm2(oracle):
+    L = oracle.lib()
+    a, ap = _v(3e-20, 4e-20, 12e-20)
+    assert L.orc_dnrm2(ap, 3) == pytest.approx(13e-20, rel=1e-15)
+    a, ap = _v(0, 0, 0)
+    assert L.orc_dnrm2(ap, 3) == 0.0
+
+
+# ------------------------------------------------------------------ Stokes helpers
+def test_mueller_rotation(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(5)
+    for _ in range(100):
+        q, u, v = rng.uniform(-0.5, 0.5, 3)
+        th = rng.uniform(-np.pi, np.pi)
+        s, sp = _v(1.0, q, u, v)
+        L.orc_mullerMatrixRotation(th, sp)
+        assert s[0] == 1.0 and s[3] == v
+        assert s[1] == pytest.approx(q * np.cos(2 * th) - u * np.sin(2 * th), abs=1e-15)
+        assert s[2] == pytest.approx(q * np.sin(2 * th) + u * np.cos(2 * th), abs=1e-15)
+        assert s[1] ** 2 + s[2] ** 2 == pytest.approx(q * q + u * u, rel=1e-13)
+        L.orc_mullerMatrixRotation(-th, sp)
+        assert np.allclose(s, [1.0, q, u, v], atol=1e-15)
+
+
+def test_findxy_orthonormal_and_findphi(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(6)
+    for _ in range(100):
+        v, vp = _v(*rng.normal(size=3))
+        ref, rp = _v(*rng.normal(size=3))
+        x, xp = _v(0, 0, 0)
+        y, yp = _v(0, 0, 0)
+        L.orc_findXY(vp, rp, xp, yp)
+        assert abs(x @ y) < 1e-14 and abs(x @ v) / np.linalg.norm(v) < 1e-14 and abs(y @ v) / np.linalg.norm(v) < 1e-14
+        assert abs(np.linalg.norm(x) - 1) < 1e-14 and abs(np.linalg.norm(y) - 1) < 1e-14
+        # y is along v x ref, x along y x v
+        yy = np.cross(v, ref)
+        assert np.allclose(y, yy / np.linalg.norm(yy), atol=1e-14)
+        # same frame -> phi = 0 ; rotated frame -> |phi| = rotation angle
+        assert abs(L.orc_findPhi(xp, yp, xp, yp)) < 1e-7   # acos near 1 amplifies the last ulp
+        a = rng.uniform(0.1, 3.0)
+        xn, xnp = _v(*(np.cos(a) * x + np.sin(a) * y))
+        yn, ynp = _v(*(-np.sin(a) * x + np.cos(a) * y))
+        phi = L.orc_findPhi(xp, yp, xnp, ynp)
+        assert phi == pytest.approx(a, abs=1e-7)          # -sign(x.y') acos(y.y'), x.y' = -sin a
+
+
+def test_stokes_rotation_preserves_polarisation_degree(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        v, vp = _v(*rng.normal(size=3) * 0.3)
+        k, kp = _v(*rng.normal(size=3))
+        kb, kbp = _v(*rng.normal(size=3))
+        q, u = rng.uniform(-0.6, 0.6, 2)
+        s, sp = _v(1.0, q, u, 0.1)
+        L.orc_stokesRotation(vp, kp, kbp, sp)
+        assert s[0] == 1.0 and s[3] == 0.1
+        assert np.hypot(s[1], s[2]) == pytest.approx(np.hypot(q, u), rel=1e-12)
+        s2, s2p = _v(1.0, 0.0, 0.0, 0.0)
+        L.orc_stokesRotation(vp, kp, kbp, s2p)
+        assert np.array_equal(s2, [1.0, 0.0, 0.0, 0.0])
+
+
+# ------------------------------------------------------------------ geometry
+def test_coordinate_transforms(oracle):
+    L = oracle.lib()
+    out, op = _v(0, 0, 0)
+    x, y, z = 3e10, 4e10, 12e10
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 0)
+    L.orc_mcratCoordinateToHydroCoordinate(C.byref(c), op, x, y, z)
+    assert out[0] == pytest.approx(5e10, rel=1e-15) and out[1] == z
+    c = oracle.make_config(oracle.TWO, oracle.SPHERICAL, 0)
+    L.orc_mcratCoordinateToHydroCoordinate(C.byref(c), op, x, y, z)
+    assert out[0] == pytest.approx(13e10, rel=1e-15) and out[1] == pytest.approx(np.arccos(12 / 13), rel=1e-15)
+    c = oracle.make_config(oracle.THREE, oracle.SPHERICAL, 0)
+    L.orc_mcratCoordinateToHydroCoordinate(C.byref(c), op, x, -y, z)
+    assert out[2] == pytest.approx(2 * np.pi + np.arctan2(-4, 3), rel=1e-14)
+    c = oracle.make_config(oracle.THREE, oracle.POLAR, 0)
+    L.orc_mcratCoordinateToHydroCoordinate(C.byref(c), op, x, y, z)
+    assert out[0] == pytest.approx(5e10) and out[1] == pytest.approx(np.arctan2(4, 3)) and out[2] == z
+    # vector transform: a purely radial spherical velocity maps onto the unit radius vector
+    c = oracle.make_config(oracle.TWO, oracle.SPHERICAL, 0)
+    th, ph = 0.3, 1.1
+    L.orc_hydroVectorToCartesian(C.byref(c), op, 0.9, 0.0, 5.0, 1e12, th, ph)   # v2 is forced to 0 in 2-D
+    assert np.allclose(out, 0.9 * np.array([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)]), rtol=1e-15)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 0)
+    L.orc_hydroVectorToCartesian(C.byref(c), op, 0.3, 0.8, 0.0, 1e10, 1e12, ph)
+    assert np.allclose(out, [0.3 * np.cos(ph), 0.3 * np.sin(ph), 0.8], rtol=1e-15)
+    c = oracle.make_config(oracle.TWO_POINT_FIVE, oracle.CYLINDRICAL, 0)
+    L.orc_hydroVectorToCartesian(C.byref(c), op, 0.3, 0.8, 0.1, 1e10, 1e12, ph)
+    assert np.allclose(out, [0.3 * np.cos(ph) - 0.1 * np.sin(ph), 0.3 * np.sin(ph) + 0.1 * np.cos(ph), 0.8], rtol=1e-15)
+
+
+def test_find_containing_block_lowest_index_and_closed_faces(oracle):
+    L = oracle.lib()
+    frame = synth.uniform_mesh_2d(0.0, 4.0, 4, 0.0, 4.0, 4, synth.CYLINDRICAL, (0, 10), (0, 10), 1.0)
+    for k in ("v0", "v1", "dens_lab", "temp", "gamma"):
+        frame[k] = np.ones(16)
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 0)
+    assert L.orc_findContainingBlock(C.byref(c), 0.5, 0.5, 0.0, C.byref(H.c)) == 0
+    assert L.orc_findContainingBlock(C.byref(c), 3.5, 2.5, 0.0, C.byref(H.c)) == 11
+    # a point on a shared face belongs to both cells (<=); the scan returns the lowest index
+    assert L.orc_findContainingBlock(C.byref(c), 1.0, 0.5, 0.0, C.byref(H.c)) == 0
+    assert L.orc_findContainingBlock(C.byref(c), 1.0, 1.0, 0.0, C.byref(H.c)) == 0
+    assert L.orc_findContainingBlock(C.byref(c), 2.0, 3.0, 0.0, C.byref(H.c)) == 9
+    assert L.orc_findContainingBlock(C.byref(c), 4.5, 0.5, 0.0, C.byref(H.c)) == -1
+    assert L.orc_checkInBlock(C.byref(c), 1.0, 0.5, 0.0, C.byref(H.c), 1) == 1
+    # cell volume: pi (ro^2 - ri^2) dz
+    assert L.orc_hydroElementVolume(C.byref(c), C.byref(H.c), 5) == pytest.approx(np.pi * (4 - 1) * 1.0)
+
+
+# ------------------------------------------------------------------ optical depth, free path
+def _one_cell_frame(v0, v1, gamma, dens_lab, temp, geometry=synth.CYLINDRICAL):
+    frame = synth.uniform_mesh_2d(0.0, 2e12, 1, 0.0, 2e12, 1, geometry, (0.0, 1e13), (0.0, 1e13), 5.0)
+    frame.update(v0=np.array([v0]), v1=np.array([v1]), gamma=np.array([gamma]),
+                 dens_lab=np.array([dens_lab]), temp=np.array([temp]))
+    return frame
+
+
+def _photon(oracle, p, r, **kw):
+    a = np.zeros(1, dtype=oracle.PHOTON_DTYPE)
+    a["type"] = b"i"
+    a["p0"], a["p1"], a["p2"], a["p3"] = p
+    a["comv_p0"], a["comv_p1"], a["comv_p2"], a["comv_p3"] = p
+    a["r0"], a["r1"], a["r2"] = r
+    a["s0"] = 1.0
+    a["weight"] = 1.0
+    a["recalc_properties"] = 1
+    for k, v in kw.items():
+        a[k] = v
+    return a
+
+
+def test_optical_depth_closed_form(oracle):
+    L = oracle.lib()
+    beta = 0.8
+    gamma = 1 / np.sqrt(1 - beta ** 2)
+    frame = _one_cell_frame(0.0, beta, gamma, 3e-9, 1e6)
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 0)
+    n_sig = 3e-9 / M_P * SIG_T
+    for mu in (1.0, 0.0, -1.0, 0.3):
+        e = 1e-18
+        a = _photon(oracle, (e, e * np.sqrt(1 - mu * mu), 0.0, e * mu), (1e11, 0.0, 1e12))
+        L.orc_calculateOpticalDepth(C.byref(c), a.ctypes.data, C.byref(H.c))
+        assert a["total_optical_depth"][0] == pytest.approx(n_sig * (1 - beta * mu), rel=1e-14)
+
+
+def test_free_path_distribution_and_outside_domain(oracle):
+    L = oracle.lib()
+    beta = 0.5
+    gamma = 1 / np.sqrt(1 - beta ** 2)
+    frame = _one_cell_frame(0.0, beta, gamma, 1e-9, 1e6)
+    frame["r0_domain"] = (0.0, 2e12)
+    frame["r1_domain"] = (0.0, 2e12)
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 0)
+    n = 20000
+    aos = np.repeat(_photon(oracle, (1e-18, 0.0, 0.0, 1e-18), (1e11, 0.0, 1e12)), n)
+    aos["r0"][-5:] = 3e12            # outside the hydro domain
+    P = oracle.OraclePhotons(aos)
+    st = oracle.Stats()
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), 99, 0)
+    L.orc_rng_set_iteration(C.byref(rng), 0)
+    L.orc_findContainingHydroCell(C.byref(c), C.byref(P.c), C.byref(H.c), 1, C.byref(st))
+    L.orc_calcMeanFreePath(C.byref(c), C.byref(P.c), C.byref(H.c), C.byref(rng))
+    a = P.aos
+    assert (a["nearest_block_index"][-5:] == -1).all() and (a["nearest_block_index"][:-5] == 0).all()
+    assert (a["time_to_scatter"][-5:] == 1e12 / C_LIGHT).all()
+    tau = 1e-9 / M_P * SIG_T * (1 - beta)
+    assert np.allclose(a["total_optical_depth"][:-5], tau, rtol=1e-14)
+    x = a["time_to_scatter"][:-5] * C_LIGHT * tau       # ~ Exp(1)
+    assert abs(x.mean() - 1) < 0.03
+    assert stats.kstest(x, "expon").pvalue > 1e-3
+    # argsort is ascending with ties by slot
+    t = a["time_to_scatter"][P.sorted]
+    assert (np.diff(t) >= 0).all()
+    assert list(P.sorted[-5:]) == list(range(n - 5, n))
+    # comoving 4-momentum = boost of the lab one
+    want = synth.lorentz_boost(np.array([[0, 0, beta]]), np.array([[1e-18, 0, 0, 1e-18]]))[0]
+    assert np.allclose([a["comv_p0"][0], a["comv_p1"][0], a["comv_p2"][0], a["comv_p3"][0]], want, rtol=1e-13, atol=1e-33)
+
+
+# ------------------------------------------------------------------ electron sampling
+def test_electron_theta_distribution(oracle):
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 5, 0)
+    L.orc_rng_event_begin(C.byref(r), 0)
+    beta = 0.7
+    th = np.array([L.orc_sampleElectronTheta(beta, C.byref(r)) for _ in range(40000)])
+    # pdf ~ (1 - beta cos t) sin t / 2  ->  cdf = [(1-cos t) - beta sin^2 t / 2] / 2
+    cdf = lambda t: ((1 - np.cos(t)) - beta * np.sin(t) ** 2 / 2) / 2
+    assert stats.kstest(th, cdf).pvalue > 1e-3
+
+
+def test_thermal_electron_energies(oracle):
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 6, 0)
+    L.orc_rng_event_begin(C.byref(r), 0)
+    # Maxwell-Boltzmann branch (T < 1e7 K): <gamma - 1> = 3/2 Theta to first order
+    T = 5e6
+    theta = K_B * T / (M_EL * C_LIGHT ** 2)
+    g = np.array([L.orc_sampleThermalElectron(T, C.byref(r)) for _ in range(40000)])
+    assert (g >= 1).all()
+    assert (g - 1).mean() == pytest.approx(1.5 * theta, rel=0.03)
+    # Maxwell-Juttner branch: <gamma> = 3 Theta + K1(1/Theta)/K2(1/Theta)
+    for T in (3e9, 3e10):
+        theta = K_B * T / (M_EL * C_LIGHT ** 2)
+        g = np.array([L.orc_sampleThermalElectron(T, C.byref(r)) for _ in range(30000)])
+        want = 3 * theta + special.kve(1, 1 / theta) / special.kve(2, 1 / theta)
+        assert g.mean() == pytest.approx(want, rel=0.02)
+
+
+def test_rotate_electron_aligns_x_axis_with_photon(oracle):
+    L = oracle.lib()
+    rng = np.random.default_rng(11)
+    for _ in range(50):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        ph, php = _v(1.0, *n)
+        el, elp = _v(1.0, 1.0, 0.0, 0.0)          # electron momentum along +x
+        L.orc_rotateElectron(elp, php)
+        assert np.allclose(el[1:], n, atol=1e-14)  # ... ends up along the photon direction
+
+
+# ------------------------------------------------------------------ scattering
+def test_kn_scatter_thomson_limit_angles(oracle):
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 9, 0)
+    L.orc_rng_event_begin(C.byref(r), 0)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 0)
+    th, ph = C.c_double(), C.c_double()
+    cos2, phis, acc = [], [], 0
+    n = 40000
+    for _ in range(n):
+        ok = L.orc_kleinNishinaScatter(C.byref(c), C.byref(th), C.byref(ph), 1e-8 * M_EL * C_LIGHT, 0.0, 0.0, C.byref(r))
+        acc += ok
+        cos2.append(np.cos(th.value) ** 2)
+        phis.append(ph.value)
+    assert acc == n                                  # sigma_KN/sigma_T = 1 - 2e-8
+    assert np.mean(cos2) == pytest.approx(0.4, abs=0.006)   # pdf ~ 1 + cos^2
+    assert stats.kstest(np.array(phis) / (2 * np.pi), "uniform").pvalue > 1e-3
+    # deep KN regime: acceptance probability equals sigma_KN/sigma_T
+    eps = 5.0
+    acc = sum(L.orc_kleinNishinaScatter(C.byref(c), C.byref(th), C.byref(ph), eps * M_EL * C_LIGHT, 0.0, 0.0, C.byref(r))
+              for _ in range(n))
+    assert acc / n == pytest.approx(L.orc_kleinNishinaCrossSection(eps), abs=0.01)
+
+
+def test_kn_scatter_polarised_azimuth(oracle):
+    """100 % +Q light scatters preferentially perpendicular to its polarisation plane:
+    pdf(phi) ~ F + mu^-2 sin^3(theta) q cos(2 phi) (Src/mcrat_scattering.c:568-575)."""
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 10, 0)
+    L.orc_rng_event_begin(C.byref(r), 0)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 1)
+    th, ph = C.c_double(), C.c_double()
+    num = den = 0.0
+    for _ in range(40000):
+        L.orc_kleinNishinaScatter(C.byref(c), C.byref(th), C.byref(ph), 1e-6 * M_EL * C_LIGHT, 1.0, 0.0, C.byref(r))
+        if abs(th.value - np.pi / 2) < 0.2:
+            num += np.cos(2 * ph.value)
+            den += 1
+    # at theta ~ 90 deg in the Thomson limit pdf ~ 1 + cos(2 phi)  ->  <cos 2phi> ~ 1/2
+    assert num / den == pytest.approx(0.5, abs=0.05)
+
+
+def _rest_frame_angle(el, k_in, k_out):
+    beta = el[1:] / el[0]
+    a = synth.lorentz_boost(beta[None, :], k_in[None, :])[0]
+    b = synth.lorentz_boost(beta[None, :], k_out[None, :])[0]
+    return a, b, np.arccos(np.clip(a[1:] @ b[1:] / (a[0] * b[0]), -1, 1))
+
+
+def test_single_scatter_compton_kinematics_and_polarisation(oracle):
+    """E' = E / (1 + eps (1 - cos theta)) in the electron rest frame, null 4-momentum out, and in the
+    Thomson limit unpolarised light leaves with Pi = sin^2 / (1 + cos^2) (Src/mcrat_scattering.c:411-416);
+    the polarisation degree is boost invariant."""
+    L = oracle.lib()
+    rng = np.random.default_rng(12)
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 11, 0)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 1)
+    for case in range(300):
+        L.orc_rng_set_iteration(C.byref(r), case)
+        L.orc_rng_event_begin(C.byref(r), 0)
+        gam = 1 + 10 ** rng.uniform(-3, 0.5)
+        bet = np.sqrt(1 - 1 / gam ** 2)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        el, elp = _v(gam * M_EL * C_LIGHT, *(gam * M_EL * C_LIGHT * bet * d))
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        eps = 10 ** rng.uniform(-9, -7) if case % 2 == 0 else 10 ** rng.uniform(-2, 0.3)
+        e = eps * M_EL * C_LIGHT
+        k_in = np.array([e, *(e * n)])
+        ph, php = _v(*k_in)
+        s, sp = _v(1.0, 0.0, 0.0, 0.0)
+        el0 = el.copy()
+        ok = L.orc_singleScatter(C.byref(c), elp, php, sp, C.byref(r))
+        if not ok:
+            assert np.array_equal(ph, k_in) and np.array_equal(s, [1, 0, 0, 0])
+            continue
+        assert ph[0] == pytest.approx(np.linalg.norm(ph[1:]), rel=1e-14)
+        a, b, theta = _rest_frame_angle(el0, k_in, ph)
+        assert b[0] == pytest.approx(a[0] / (1 + a[0] / (M_EL * C_LIGHT) * (1 - np.cos(theta))), rel=1e-9)
+        assert s[0] == 1.0 and s[3] == 0.0
+        pol = np.hypot(s[1], s[2])
+        e0, e1 = a[0] / (M_EL * C_LIGHT), b[0] / (M_EL * C_LIGHT)
+        want = np.sin(theta) ** 2 / (1 + np.cos(theta) ** 2 + (1 - np.cos(theta)) * (e0 - e1))
+        assert pol == pytest.approx(want, rel=1e-7, abs=1e-9)
+
+
+def test_fano_forward_scatter_leaves_stokes_unchanged():
+    """Fano's matrix at theta = 0 is 2 x identity (Src/mcrat_scattering.c:411-416)."""
+    th, de = 0.0, 0.3
+    T = np.diag([1 + np.cos(th) ** 2 + (1 - np.cos(th)) * de, 1 + np.cos(th) ** 2, 2 * np.cos(th),
+                 2 * np.cos(th) + np.cos(th) * (1 - np.cos(th)) * de])
+    T[0, 1] = T[1, 0] = np.sin(th) ** 2
+    s = np.array([1.0, 0.3, -0.2, 0.1])
+    out = T @ s
+    assert np.allclose(out / out[0], s)
+
+
+# ------------------------------------------------------------------ the loop
+def test_photon_loop_bookkeeping(oracle):
+    frame, ph, cfg = synth.config1(n_photons=400, n0=16, n1=16)
+    H = oracle.OracleHydro(frame)
+    P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    r_before = np.sqrt(P.aos["r0"] ** 2 + P.aos["r1"] ** 2 + P.aos["r2"] ** 2)
+    dt = 1e-2
+    st, tn, rem, sw = oracle.photon_loop(c, P, H, seed=7, time_now=10.0, remaining_time=dt)
+    a = P.aos
+    assert rem == 0.0 and sw == 0
+    assert tn == pytest.approx(10.0 + dt, rel=1e-14)
+    assert st.frame_scatt_cnt == a["num_scatt"].sum() > 50
+    assert st.photon_steps == st.iterations * 400
+    # every photon moved at the speed of light for dt (path length c dt, displacement <= c dt)
+    r_after = np.sqrt(a["r0"] ** 2 + a["r1"] ** 2 + a["r2"] ** 2)
+    assert (np.abs(r_after - r_before) <= C_LIGHT * dt * (1 + 1e-9)).all()
+    # photon 4-momenta stay null and Stokes untouched with STOKES off
+    assert np.allclose(a["p0"], np.sqrt(a["p1"] ** 2 + a["p2"] ** 2 + a["p3"] ** 2), rtol=1e-14)
+    assert (a["s0"] == 1).all() and (a["s1"] == 0).all() and (a["s2"] == 0).all()
+    # determinism: same seed, same result; different seed, different result
+    P2 = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    oracle.photon_loop(c, P2, H, seed=7, time_now=10.0, remaining_time=dt)
+    assert _same(P2.aos, a)
+    P3 = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    oracle.photon_loop(c, P3, H, seed=8, time_now=10.0, remaining_time=dt)
+    assert not _same(P3.aos, a)
+
+
+def test_photon_loop_split_calls_equal_one_call(oracle):
+    """running a frame as several bounded calls (iteration_base) equals one unbounded call."""
+    frame, ph, cfg = synth.config1(n_photons=300, n0=16, n1=16)
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 1)
+    P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    st, tn, rem, _ = oracle.photon_loop(c, P, H, seed=3, time_now=0.0, remaining_time=1e-3)
+    Q = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    tn2, rem2, sw, base, total = 0.0, 1e-3, 1, 0, 0
+    while rem2 > 0:
+        s2, tn2, rem2, sw = oracle.photon_loop(c, Q, H, seed=3, time_now=tn2, remaining_time=rem2,
+                                               max_iterations=37, iteration_base=base, find_switch=sw)
+        base += s2.iterations
+        total += s2.frame_scatt_cnt
+    assert base == st.iterations and total == st.frame_scatt_cnt
+    assert _same(Q.aos, P.aos)
+    assert np.hypot(P.aos["s1"], P.aos["s2"]).max() > 0       # STOKES on: scattered photons are polarised
+    assert (np.hypot(P.aos["s1"], P.aos["s2"]) <= 1 + 1e-12).all()
+
+
+def test_per_frame_reductions(oracle):
+    L = oracle.lib()
+    frame, ph, cfg = synth.config1(n_photons=500, n0=16, n1=16)
+    ph["num_scatt"] = np.arange(500) % 7 + 0.0
+    ph["weight"][::10] = 0.0
+    P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    mx, mn = C.c_int(), C.c_int()
+    avg, ravg = C.c_double(), C.c_double()
+    L.orc_phScattStats(C.byref(P.c), C.byref(mx), C.byref(mn), C.byref(avg), C.byref(ravg))
+    r = np.sqrt(ph["r0"] ** 2 + ph["r1"] ** 2 + ph["r2"] ** 2)
+    assert (mx.value, mn.value) == (6, 0)
+    assert avg.value == pytest.approx(ph["num_scatt"].mean()) and ravg.value == pytest.approx(r.mean())
+    a, b, c_, d = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    L.orc_phMinMax(C.byref(P.c), C.byref(a), C.byref(b), C.byref(c_), C.byref(d))
+    live = ph["weight"] != 0
+    th = np.arccos(ph["r2"] / r)
+    assert a.value == r[live].min() and b.value == r[live].max()
+    assert c_.value == pytest.approx(th[live].min(), rel=1e-12) and d.value == pytest.approx(th[live].max(), rel=1e-12)
+    e = L.orc_averagePhotonEnergy(C.byref(P.c))
+    assert e == pytest.approx(C_LIGHT * (ph["p0"] * ph["weight"]).sum() / ph["weight"].sum(), rel=1e-12)
