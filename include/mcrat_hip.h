@@ -1,0 +1,207 @@
+/*
+ * mcrat_hip.h -- C ABI of the MI355X photon-loop engine (libmcrat_hip.so).
+ *
+ * Drop-in boundary for ONE path of lazzati-astro/MCRaT: the per-timestep photon
+ * loop `while (remaining_time > 0)` of Src/mcrat.c:761-851 and the functions it
+ * calls (findContainingHydroCell mclib.c:436, calcMeanFreePath mclib.c:617,
+ * photonEvent mclib.c:1107, updatePhotonPosition mclib.c:1054) plus the
+ * per-frame reductions around it (phMinMax mclib.c:1465, phScattStats
+ * mclib.c:1385, averagePhotonEnergy mclib.c:1358).
+ *
+ * The reference has no plugin/FFI interface: its boundary is the set of C
+ * functions main() calls on caller-owned structs (Src/mclib.h:8-29).  This
+ * header keeps those structs' layouts (so MCRaT's own photonInjection,
+ * saveCheckpoint, printPhotons keep working on the host side) and replaces the
+ * loop by frame-granular calls, because a host<->device round trip per scatter
+ * event would cost more than the event.  INTEGRATION.md shows the edit to
+ * mcrat.c; DESIGN.md the device side.
+ *
+ * Conventions (mirroring the reference where it has any):
+ *   - plain C, plain pointers and sizes; the library never takes ownership of
+ *     caller memory and never calls exit(); every entry point returns 0 on
+ *     success or a negative MCRAT_HIP_E* code (the caller keeps the reference's
+ *     fatal behaviour, e.g. mcrat.c:904-915);
+ *   - one context per MPI rank / GPU; a context is not thread safe (the
+ *     reference runs one thread per rank);
+ *   - the "cell not found" log lines of geometry.c:382 / mclib.c:583 are
+ *     reported as counters in mcrat_hip_frame_stats;
+ *   - there is NO CPU fallback: if the device or the code object is missing
+ *     mcrat_hip_init fails with MCRAT_HIP_ENODEV.
+ */
+#ifndef MCRAT_HIP_H
+#define MCRAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCRAT_HIP_ABI_VERSION 1
+
+/* error codes */
+#define MCRAT_HIP_OK        0
+#define MCRAT_HIP_EINVAL   (-1)  /* bad argument / unsupported switch combination        */
+#define MCRAT_HIP_ENODEV   (-2)  /* no usable gfx950 device or code object                */
+#define MCRAT_HIP_ENOMEM   (-3)  /* device or host allocation failed                      */
+#define MCRAT_HIP_EHIP     (-4)  /* a HIP runtime call failed (see mcrat_hip_last_error)  */
+#define MCRAT_HIP_ESTATE   (-5)  /* call out of order (e.g. run before set_hydro)         */
+
+/* switch values: identical to Src/mcrat.h:36-44,64-65 so a -D of mcrat_input.h maps 1:1 */
+#define MCRAT_HIP_CARTESIAN        0
+#define MCRAT_HIP_SPHERICAL        1
+#define MCRAT_HIP_CYLINDRICAL      2
+#define MCRAT_HIP_POLAR            3
+#define MCRAT_HIP_TWO              0
+#define MCRAT_HIP_TWO_POINT_FIVE   1
+#define MCRAT_HIP_THREE            2
+#define MCRAT_HIP_TAU_DIRECT       1
+#define MCRAT_HIP_TAU_TABLE        2   /* not yet supported: MCRAT_HIP_EINVAL */
+
+/* the compile-time switches of Src/mcrat_input.h:49-71 that the loop depends on */
+typedef struct mcrat_hip_config {
+    int abi_version;             /* MCRAT_HIP_ABI_VERSION                                     */
+    int dimensions;              /* DIMENSIONS                                                */
+    int geometry;                /* GEOMETRY                                                  */
+    int stokes_switch;           /* STOKES_SWITCH   (0/1)                                     */
+    int tau_calculation;         /* TAU_CALCULATION (only MCRAT_HIP_TAU_DIRECT)               */
+    int cyclosynchrotron_switch; /* CYCLOSYNCHROTRON_SWITCH (only 0)                          */
+    int device;                  /* HIP device ordinal                                        */
+    void *stream;                /* hipStream_t to launch on, or NULL for a private stream    */
+    uint32_t rng_stream;         /* virtual-rank id mixed into every RNG counter (rank id)    */
+    int iterations_per_sync;     /* loop iterations queued between host status reads (0: 256) */
+    int use_graph;               /* replay the iteration batch as a hipGraph (0/1)            */
+    int profile;                 /* bracket every step-kernel launch with HIP events (0/1)    */
+} mcrat_hip_config;
+
+/* == struct photon, Src/mcrat.h:142-171 (thermal-only build): 176 bytes on x86-64,
+ * offsets type@0 p0@8 ... num_scatt@128 recalc_properties@136 weight@144
+ * nearest_block_index@152 time_to_scatter@160 total_optical_depth@168 */
+typedef struct mcrat_hip_photon {
+    char   type;
+    double p0, p1, p2, p3;
+    double comv_p0, comv_p1, comv_p2, comv_p3;
+    double r0, r1, r2;
+    double s0, s1, s2, s3;
+    double num_scatt;
+    int    recalc_properties;
+    double weight;
+    int    nearest_block_index;
+    double time_to_scatter;
+    double total_optical_depth;
+} mcrat_hip_photon;
+
+/* == struct photonList, Src/mcrat.h:173-180 */
+typedef struct mcrat_hip_photon_list {
+    mcrat_hip_photon *photons;
+    int *sorted_indexes;
+    int num_photons;
+    int num_null_photons;
+    int list_capacity;
+} mcrat_hip_photon_list;
+
+/* column form of the same record (host pointers, n entries each); any pointer may be
+ * NULL on get (column skipped).  On set, NULL comv_p, s, time_to_scatter and
+ * total_optical_depth columns mean zeros; the other columns are required. */
+typedef struct mcrat_hip_photon_soa {
+    int n;
+    char   *type;
+    double *p0, *p1, *p2, *p3;
+    double *comv_p0, *comv_p1, *comv_p2, *comv_p3;
+    double *r0, *r1, *r2;
+    double *s0, *s1, *s2, *s3;
+    double *num_scatt;
+    int    *recalc_properties;
+    double *weight;
+    int    *nearest_block_index;
+    double *time_to_scatter;
+    double *total_optical_depth;
+} mcrat_hip_photon_soa;
+
+/* the members of struct hydro_dataframe (Src/mcrat.h:194-244) the loop reads; host pointers
+ * of num_elements doubles.  r2, r2_size, v2 may be NULL in 2-D. */
+typedef struct mcrat_hip_hydro {
+    int num_elements;
+    const double *r0, *r1, *r2;
+    const double *r0_size, *r1_size, *r2_size;
+    const double *v0, *v1, *v2;
+    const double *dens_lab, *temp, *gamma;
+    double r0_domain[2], r1_domain[2], r2_domain[2];
+    double fps;
+} mcrat_hip_hydro;
+
+/* what main() logs after the loop (mcrat.c:810-817,881-892) plus throughput counters */
+typedef struct mcrat_hip_frame_stats {
+    long long iterations;                    /* passes of the while loop                         */
+    long long photon_steps;                  /* iterations x list_capacity                       */
+    long long frame_scatt_cnt;               /* mclib.c:1318                                     */
+    long long num_photons_find_new_element;  /* mclib.c:579,608-611                              */
+    long long not_found;                     /* "Hydro grid index not found" events, mclib.c:583 */
+    long long kn_rejections;                 /* candidates that drew an electron but did not scatter */
+    long long rescans;                       /* times the candidate list had to be refilled      */
+    int    last_scattered_index;             /* *scattered_ph_index, mclib.c:1341                */
+    double last_scattered_temp;              /* hydro temp of its cell, mcrat.c:813              */
+    double last_time_step;                   /* time_step, mcrat.c:781,844                       */
+    double remaining_time;
+    double time_now;
+    double step_kernel_ms;                   /* profile=1: summed duration of step-kernel launches */
+    long long step_kernel_launches;
+    double event_kernel_ms;                  /* profile=1: summed duration of event-kernel launches */
+} mcrat_hip_frame_stats;
+
+typedef struct mcrat_hip_ctx mcrat_hip_ctx;
+
+/* lifetime ------------------------------------------------------------------ */
+int  mcrat_hip_init(mcrat_hip_ctx **ctx, const mcrat_hip_config *cfg);
+void mcrat_hip_destroy(mcrat_hip_ctx *ctx);
+const char *mcrat_hip_version(void);
+const char *mcrat_hip_strerror(int code);
+const char *mcrat_hip_last_error(const mcrat_hip_ctx *ctx);   /* text of the last HIP failure */
+
+/* staging: once per hydro frame (after getHydroData, mcrat.c:721) ------------- */
+int mcrat_hip_set_hydro(mcrat_hip_ctx *ctx, const mcrat_hip_hydro *hydro);
+
+/* photons host -> device (after photonInjection mcrat.c:645 / readCheckpoint) and back
+ * (before saveCheckpoint mcrat.c:902 / printPhotons mcrat.c:907).  NULL-photon slots
+ * (type 'N', weight 0, index -1: photons.c:208) are carried through unchanged. */
+int mcrat_hip_set_photons(mcrat_hip_ctx *ctx, const mcrat_hip_photon_list *list);
+int mcrat_hip_get_photons(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list);
+int mcrat_hip_set_photons_soa(mcrat_hip_ctx *ctx, const mcrat_hip_photon_soa *soa);
+int mcrat_hip_get_photons_soa(mcrat_hip_ctx *ctx, const mcrat_hip_photon_soa *soa);
+int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *ctx);
+
+/* the loop -------------------------------------------------------------------- */
+/* replaces mcrat.c:754-851 for one hydro frame: sets find_nearest_grid_switch=1,
+ * runs until remaining_time is used up, updates *time_now, fills *stats.
+ * `seed` is the per-frame seed; the reference draws one at mcrat.c:701
+ * (gsl_rng_set(rng, gsl_rng_get(rng))) -- pass that gsl_rng_get value. */
+int mcrat_hip_propagate_frame(mcrat_hip_ctx *ctx, double *time_now, double remaining_time,
+                              uint64_t seed, mcrat_hip_frame_stats *stats);
+
+/* the same loop in pieces, for bounded runs (benchmarks, tests, progress logging):
+ * begin_frame resets the per-frame state; each run executes at most max_iterations
+ * passes (<= 0: until the frame time is used up) and is synchronous on return. */
+int mcrat_hip_begin_frame(mcrat_hip_ctx *ctx, uint64_t seed, double time_now, double remaining_time);
+int mcrat_hip_run(mcrat_hip_ctx *ctx, long long max_iterations, mcrat_hip_frame_stats *stats);
+
+/* function-granular A/B entry points (one kernel each, for parity tests against the
+ * reference functions): the findContainingHydroCell + calcMeanFreePath half of an
+ * iteration and the photonEvent half. */
+int mcrat_hip_step_locate_sample(mcrat_hip_ctx *ctx, int find_nearest_block_switch);
+int mcrat_hip_step_event(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);
+
+/* per-frame reductions on the resident photons ------------------------------- */
+int mcrat_hip_ph_minmax(mcrat_hip_ctx *ctx, double *min_r, double *max_r, double *min_theta, double *max_theta); /* mclib.c:1465 */
+int mcrat_hip_scatt_stats(mcrat_hip_ctx *ctx, int *max_scatt, int *min_scatt, double *avg_scatt, double *avg_r); /* mclib.c:1385 */
+int mcrat_hip_avg_energy(mcrat_hip_ctx *ctx, double *erg);                                                    /* mclib.c:1358 */
+
+/* introspection used by bench.py / tests -------------------------------------- */
+int mcrat_hip_synchronize(mcrat_hip_ctx *ctx);
+size_t mcrat_hip_device_bytes(const mcrat_hip_ctx *ctx);   /* HBM held by the context */
+int mcrat_hip_lookup_cell(mcrat_hip_ctx *ctx, int n, const double *a0, const double *a1, const double *a2, int *cell_out); /* device cell search == findContainingBlock geometry.c:350 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCRAT_HIP_H */

@@ -1,0 +1,53 @@
+"""Build libmcrat_hip.so (HIP kernels + C ABI) in-tree for gfx950.
+
+    python -m mcrat_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  -ffp-contract=off keeps every a*b+c as two IEEE
+roundings so that double results track the reference's plain C ("Numerics").
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmcrat_hip.so")
+SOURCES = ["kernels.hip", "engine.hip"]
+HEADERS = ["device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (ROCm is required to build libmcrat_hip.so)")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, resource_log=None):
+    if not force and not stale():
+        return LIB
+    cmd = [hipcc()] + FLAGS
+    if resource_log:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if resource_log:
+        with open(resource_log, "w") as f:
+            f.write(r.stderr)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr)
+        raise RuntimeError("hipcc failed building libmcrat_hip.so")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, resource_log=os.environ.get("MCRAT_RESOURCE_LOG")))

@@ -1,0 +1,112 @@
+// device_types.hpp -- HBM layouts shared by the kernels and the host-side engine.
+#pragma once
+#include <stdint.h>
+
+namespace mcrat {
+
+// Src/mclib.c:4-5, verbatim values
+constexpr double A_RAD = 7.56e-15;
+constexpr double C_LIGHT = 2.99792458e10;
+constexpr double PL_CONST = 6.6260755e-27;
+constexpr double K_B = 1.380658e-16;
+constexpr double M_P = 1.6726231e-24;
+constexpr double THOM_X_SECT = 6.65246e-25;
+constexpr double M_EL = 9.1093879e-28;
+
+constexpr int GEOM_CARTESIAN = 0, GEOM_SPHERICAL = 1, GEOM_CYLINDRICAL = 2, GEOM_POLAR = 3;
+constexpr int DIM_TWO = 0, DIM_TWO_POINT_FIVE = 1, DIM_THREE = 2;
+
+// per-photon flag byte (replaces the reads of type, weight and recalc_properties on the streaming path)
+constexpr unsigned FLAG_RECALC = 1u;   // recalc_properties == 1                       (mcrat.h:161)
+constexpr unsigned FLAG_MOVES = 2u;    // type != CS_POOL_PHOTON && weight != 0        (mclib.c:1070)
+constexpr unsigned FLAG_VALID = 4u;    // slot index < list_capacity (padding slots are not valid)
+
+constexpr int TOPK = 4;          // candidates kept per workgroup / per iteration before a rescan
+constexpr int MAX_SEG = 8;       // advance segments remembered per iteration (one per tried candidate)
+constexpr int STEP_BLOCK = 256;  // threads per workgroup of the step kernel; each thread owns slot pairs
+constexpr int EVENT_BLOCK = 256;    // one workgroup; only lane 0 runs the scattering physics, so leave it the whole register file
+
+// SoA photon columns in HBM.  Capacity is padded to a multiple of 2*STEP_BLOCK; every column is 256-B aligned.
+struct PhotonDev {
+    double *r0, *r1, *r2;
+    double *p0, *p1, *p2, *p3;
+    double *c0, *c1, *c2, *c3;   // comv_p
+    double *s0, *s1, *s2, *s3;
+    double *num_scatt;
+    double *weight;
+    double *tau;                 // total_optical_depth [1/cm]
+    double *tts;                 // time_to_scatter [s]
+    int *idx;                    // nearest_block_index
+    unsigned char *flags;
+    char *type;
+    int n;                       // list_capacity
+    int n_pad;
+};
+
+struct alignas(32) CellGeom {    // one 32-B sector per in-cell test (geometry.c:394-417)
+    double c0, c1, s0, s1;       // centre and full size on axes 0,1
+};
+struct alignas(16) CellGeom2 {   // third axis, 3-D only
+    double c2, s2;
+};
+struct alignas(32) CellFluid {   // gathered when tau or the comoving momentum is recomputed
+    double v0, v1, gamma, dens_lab;
+};
+
+// exact accelerator for findContainingBlock (geometry.c:350-391): uniform buckets (optionally in
+// log of the coordinate) whose member lists are ascending in cell index, so the first hit of the
+// closed-interval test is the lowest-index containing cell, i.e. what the reference's linear scan returns.
+struct GridDev {
+    const int *start;            // [nb+1]
+    const int *cells;            // [start[nb]]
+    double org[3];
+    double inv[3];
+    int dim[3];
+    int logmap[3];
+    int naxes;
+};
+
+struct HydroDev {
+    const CellGeom *geom;
+    const CellGeom2 *geom2;
+    const CellFluid *fluid;
+    const double *temp;
+    const double *v2;            // 2.5-D / 3-D
+    const double *k2e;           // exp(x) K_2(x), x = m_e c^2 / k T, for cells with T >= 1e7 K (else 0)
+    int M;
+    double dom0[2], dom1[2], dom2[2];
+    GridDev grid;
+};
+
+struct alignas(16) Cand {
+    double t;
+    int idx;
+    int pad;
+};
+
+// loop state kept in HBM between kernels (the scalars of mcrat.c:754-851)
+struct alignas(256) LoopState {
+    double remaining_time;
+    double time_now;
+    unsigned long long iteration;        // k, also the RNG counter
+    int done;                            // remaining_time <= 0
+    int nseg;                            // pending advance segments (applied by the next step kernel)
+    int skip_idx;                        // photon already advanced by the event kernel (-1: none)
+    int last_scattered_index;
+    double seg[MAX_SEG];
+    double last_time_step;
+    double last_scattered_temp;
+    long long iterations;
+    long long frame_scatt_cnt;
+    long long n_relocated;               // num_photons_find_new_element (not counted on forced passes)
+    long long not_found;
+    long long kn_rejections;
+    long long rescans;
+};
+
+struct RngKey {
+    uint64_t seed;
+    uint32_t stream;
+};
+
+}  // namespace mcrat

@@ -1,0 +1,800 @@
+// engine.hip -- host side of libmcrat_hip.so: the C ABI of include/mcrat_hip.h on top of the kernels.
+//
+// Owns the HBM residency of one rank's photon list (SoA columns) and of the current hydro frame
+// (packed cell records + the exact cell-lookup grid), and drives the per-iteration kernel pair.
+// There is no CPU compute path in this file: if HIP is unavailable every entry point fails.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mcrat_hip.h"
+#include "device_types.hpp"
+#include "launch.hpp"
+
+using namespace mcrat;
+
+static_assert(sizeof(mcrat_hip_photon) == 176, "struct photon layout (Src/mcrat.h:142-171) must be 176 bytes");
+static_assert(offsetof(mcrat_hip_photon, num_scatt) == 128 && offsetof(mcrat_hip_photon, recalc_properties) == 136 &&
+              offsetof(mcrat_hip_photon, weight) == 144 && offsetof(mcrat_hip_photon, nearest_block_index) == 152 &&
+              offsetof(mcrat_hip_photon, time_to_scatter) == 160 && offsetof(mcrat_hip_photon, total_optical_depth) == 168,
+              "struct photon field offsets");
+static_assert(sizeof(LoopState) == 256, "LoopState is one 256-B record");
+
+struct mcrat_hip_ctx {
+    mcrat_hip_config cfg;
+    KernelConfig kc;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string last_error;
+
+    // photons
+    PhotonDev ph{};
+    void *ph_buf = nullptr;
+    size_t ph_bytes = 0;
+    bool have_photons = false;
+    int step_blocks = 0;
+    Cand *partials = nullptr;
+    int partials_cap = 0;
+
+    // hydro
+    HydroDev hy{};
+    void *hy_buf = nullptr;
+    size_t hy_bytes = 0;
+    bool have_hydro = false;
+
+    // loop
+    LoopState *d_state = nullptr;
+    LoopState *h_state = nullptr;     // pinned
+    bool frame_open = false;
+    int find_switch = 1;
+    RngKey key{0, 0};
+    long long frame_photon_steps = 0;
+
+    // scratch
+    ReducePartial *d_red = nullptr;
+    ReducePartial *h_red = nullptr;   // pinned
+    static constexpr int RED_BLOCKS = 512;
+
+    // profiling
+    std::vector<hipEvent_t> ev;
+    double prof_step_ms = 0, prof_event_ms = 0;
+    long long prof_launches = 0;
+
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_batch = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->last_error = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return (e_ == hipErrorOutOfMemory) ? MCRAT_HIP_ENOMEM : MCRAT_HIP_EHIP;                \
+        }                                                                                          \
+    } while (0)
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static void drop_graph(mcrat_hip_ctx *c)
+{
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    c->graph_batch = 0;
+}
+
+extern "C" const char *mcrat_hip_version(void) { return "mcrat_hip 0.1 (gfx950, abi 1)"; }
+
+extern "C" const char *mcrat_hip_strerror(int code)
+{
+    switch (code) {
+    case MCRAT_HIP_OK: return "ok";
+    case MCRAT_HIP_EINVAL: return "invalid argument or unsupported switch combination";
+    case MCRAT_HIP_ENODEV: return "no usable HIP device";
+    case MCRAT_HIP_ENOMEM: return "out of memory";
+    case MCRAT_HIP_EHIP: return "HIP runtime error";
+    case MCRAT_HIP_ESTATE: return "call out of order";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char *mcrat_hip_last_error(const mcrat_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+static bool geometry_supported(int dims, int geom)
+{
+    if (dims == DIM_TWO || dims == DIM_TWO_POINT_FIVE)
+        return geom == GEOM_CARTESIAN || geom == GEOM_CYLINDRICAL || geom == GEOM_SPHERICAL;
+    if (dims == DIM_THREE) return geom == GEOM_CARTESIAN || geom == GEOM_SPHERICAL || geom == GEOM_POLAR;
+    return false;
+}
+
+extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
+{
+    if (!out || !cfg) return MCRAT_HIP_EINVAL;
+    *out = nullptr;
+    if (cfg->abi_version != MCRAT_HIP_ABI_VERSION) return MCRAT_HIP_EINVAL;
+    if (!geometry_supported(cfg->dimensions, cfg->geometry)) return MCRAT_HIP_EINVAL;
+    if (cfg->tau_calculation != MCRAT_HIP_TAU_DIRECT) return MCRAT_HIP_EINVAL;   // TABLE: SURVEY.md 8(f) #4
+    if (cfg->cyclosynchrotron_switch != 0) return MCRAT_HIP_EINVAL;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MCRAT_HIP_ENODEV;
+    if (hipSetDevice(cfg->device) != hipSuccess) return MCRAT_HIP_ENODEV;
+
+    mcrat_hip_ctx *c = new (std::nothrow) mcrat_hip_ctx();
+    if (!c) return MCRAT_HIP_ENOMEM;
+    c->cfg = *cfg;
+    if (c->cfg.iterations_per_sync <= 0) c->cfg.iterations_per_sync = 256;
+    c->kc.dimensions = cfg->dimensions;
+    c->kc.geometry = cfg->geometry;
+    c->kc.stokes = cfg->stokes_switch ? 1 : 0;
+    c->key.stream = cfg->rng_stream & 0xffffffu;
+
+    auto fail = [&](int code) { mcrat_hip_destroy(c); return code; };
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(MCRAT_HIP_ENODEV);
+        c->own_stream = true;
+    }
+    if (hipMalloc((void **)&c->d_state, sizeof(LoopState)) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
+    if (hipHostMalloc((void **)&c->h_state, sizeof(LoopState), hipHostMallocDefault) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
+    if (hipMalloc((void **)&c->d_red, sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
+    if (hipHostMalloc((void **)&c->h_red, sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS, hipHostMallocDefault) != hipSuccess)
+        return fail(MCRAT_HIP_ENOMEM);
+    memset(c->h_state, 0, sizeof(LoopState));
+    c->h_state->done = 1;
+    c->h_state->skip_idx = -1;
+    if (hipMemcpy(c->d_state, c->h_state, sizeof(LoopState), hipMemcpyHostToDevice) != hipSuccess) return fail(MCRAT_HIP_ENODEV);
+    *out = c;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
+{
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->ph_buf) (void)hipFree(c->ph_buf);
+    if (c->hy_buf) (void)hipFree(c->hy_buf);
+    if (c->partials) (void)hipFree(c->partials);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->d_red) (void)hipFree(c->d_red);
+    if (c->h_red) (void)hipHostFree(c->h_red);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mcrat_hip_synchronize(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" size_t mcrat_hip_device_bytes(const mcrat_hip_ctx *c)
+{
+    if (!c) return 0;
+    return c->ph_bytes + c->hy_bytes + sizeof(LoopState) + (size_t)c->partials_cap * sizeof(Cand) +
+           sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS;
+}
+
+// ---------------------------------------------------------------------------------------------- hydro staging
+namespace {
+
+struct GridHost {
+    std::vector<int> start, cells;
+    double org[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    int dim[3] = {1, 1, 1}, logmap[3] = {0, 0, 0}, naxes = 2;
+};
+
+inline int bucket_of(double x, int logmap, double org, double inv, int dim)
+{
+    double u = logmap ? std::log(x) : x;
+    double f = std::floor((u - org) * inv);
+    if (!(f == f)) return 0;
+    if (f < 0.0) return 0;
+    if (f > (double)(dim - 1)) return dim - 1;
+    return (int)f;
+}
+
+// Exact accelerator for the reference's linear findContainingBlock (geometry.c:350-391).  Every cell is
+// entered into all buckets its closed extent, widened by 1e-9 relative, touches; cells are visited in
+// ascending index so each bucket list is ascending.  The device walks the list of the bucket holding the
+// point and applies the reference's own closed-interval test, so it returns the lowest-index containing
+// cell exactly as the linear scan does.  (The reference's own buildSpatialGrid, geometry.c:526-676, is
+// disabled at HEAD and tests DIMENSIONS against the wrong constants; it is not reproduced.)
+bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
+{
+    const int M = h->num_elements;
+    const double *c[3] = {h->r0, h->r1, h->r2};
+    const double *s[3] = {h->r0_size, h->r1_size, h->r2_size};
+    g.naxes = naxes;
+    double ext_lo[3], ext_hi[3], ncell[3];
+    for (int k = 0; k < naxes; ++k) {
+        double lo = INFINITY, hi = -INFINITY, smin = INFINITY, smax = 0;
+        for (int i = 0; i < M; ++i) {
+            lo = std::min(lo, c[k][i] - 0.5 * s[k][i]);
+            hi = std::max(hi, c[k][i] + 0.5 * s[k][i]);
+            smin = std::min(smin, s[k][i]);
+            smax = std::max(smax, s[k][i]);
+        }
+        if (!(hi > lo) || !(smin > 0)) return false;
+        g.logmap[k] = (lo > 0 && smax / smin > 4.0) ? 1 : 0;
+        // typical cell width in the mapped coordinate: median over a sample
+        std::vector<double> w;
+        const int stride = std::max(1, M / 4096);
+        for (int i = 0; i < M; i += stride) {
+            const double a = c[k][i] - 0.5 * s[k][i], b = c[k][i] + 0.5 * s[k][i];
+            w.push_back(g.logmap[k] ? std::log(b) - std::log(std::max(a, 1e-300)) : b - a);
+        }
+        std::nth_element(w.begin(), w.begin() + w.size() / 2, w.end());
+        const double med = w[w.size() / 2];
+        ext_lo[k] = g.logmap[k] ? std::log(lo) : lo;
+        ext_hi[k] = g.logmap[k] ? std::log(hi) : hi;
+        ncell[k] = std::max(1.0, (ext_hi[k] - ext_lo[k]) / med);
+    }
+    double prod = 1;
+    for (int k = 0; k < naxes; ++k) prod *= ncell[k];
+    const double target = std::min(std::max((double)M, 1.0), 16777216.0);
+    double f = (prod > target) ? std::pow(target / prod, 1.0 / naxes) : 1.0;
+
+    for (int attempt = 0; attempt < 12; ++attempt, f *= 0.5) {
+        long long nb = 1;
+        for (int k = 0; k < 3; ++k) {
+            g.dim[k] = 1; g.org[k] = 0; g.inv[k] = 0;
+            if (k < naxes) {
+                g.dim[k] = (int)std::max(1.0, std::min(65536.0, std::floor(ncell[k] * f)));
+                g.org[k] = ext_lo[k];
+                g.inv[k] = g.dim[k] / (ext_hi[k] - ext_lo[k]);
+            }
+            nb *= g.dim[k];
+        }
+        std::vector<long long> count((size_t)nb + 1, 0);
+        auto range = [&](int i, int k, int &b0, int &b1) {
+            const double m = 1e-9 * (std::fabs(c[k][i]) + s[k][i]);
+            double a = c[k][i] - 0.5 * s[k][i] - m, b = c[k][i] + 0.5 * s[k][i] + m;
+            if (g.logmap[k] && a <= 0) a = 1e-300;
+            b0 = bucket_of(a, g.logmap[k], g.org[k], g.inv[k], g.dim[k]);
+            b1 = bucket_of(b, g.logmap[k], g.org[k], g.inv[k], g.dim[k]);
+        };
+        long long total = 0;
+        for (int i = 0; i < M; ++i) {
+            int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            for (int k = 0; k < naxes; ++k) range(i, k, lo[k], hi[k]);
+            for (int z = lo[2]; z <= hi[2]; ++z)
+                for (int y = lo[1]; y <= hi[1]; ++y)
+                    for (int x = lo[0]; x <= hi[0]; ++x) count[((size_t)z * g.dim[1] + y) * g.dim[0] + x + 1]++;
+            total += (long long)(hi[0] - lo[0] + 1) * (hi[1] - lo[1] + 1) * (hi[2] - lo[2] + 1);
+            if (total > 64LL * M + 1024) break;
+        }
+        if (total > 64LL * M + 1024) continue;   // too fine for this mesh: coarsen and retry
+        if (total > 2000000000LL) continue;
+        for (size_t b = 0; b < (size_t)nb; ++b) count[b + 1] += count[b];
+        g.start.resize((size_t)nb + 1);
+        for (size_t b = 0; b <= (size_t)nb; ++b) g.start[b] = (int)count[b];
+        g.cells.assign((size_t)total, -1);
+        std::vector<int> fill(g.start.begin(), g.start.end() - 1);
+        for (int i = 0; i < M; ++i) {
+            int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+            for (int k = 0; k < naxes; ++k) range(i, k, lo[k], hi[k]);
+            for (int z = lo[2]; z <= hi[2]; ++z)
+                for (int y = lo[1]; y <= hi[1]; ++y)
+                    for (int x = lo[0]; x <= hi[0]; ++x) g.cells[(size_t)fill[((size_t)z * g.dim[1] + y) * g.dim[0] + x]++] = i;
+        }
+        return true;
+    }
+    return false;
+}
+
+}  // namespace
+
+extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
+{
+    if (!c || !h || h->num_elements <= 0) return MCRAT_HIP_EINVAL;
+    const int M = h->num_elements;
+    const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
+    if (!h->r0 || !h->r1 || !h->r0_size || !h->r1_size || !h->v0 || !h->v1 || !h->dens_lab || !h->temp || !h->gamma) return MCRAT_HIP_EINVAL;
+    if (three && (!h->r2 || !h->r2_size)) return MCRAT_HIP_EINVAL;
+    if (!two && !h->v2) return MCRAT_HIP_EINVAL;
+
+    GridHost g;
+    if (!build_grid(h, three ? 3 : 2, g)) { c->last_error = "cell-lookup grid: degenerate mesh"; return MCRAT_HIP_EINVAL; }
+
+    bool any_hot = false;
+    for (int i = 0; i < M; ++i) any_hot = any_hot || (h->temp[i] >= 1e7);
+
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_geom = take(sizeof(CellGeom) * M);
+    const size_t o_geom2 = three ? take(sizeof(CellGeom2) * M) : 0;
+    const size_t o_fluid = take(sizeof(CellFluid) * M);
+    const size_t o_temp = take(sizeof(double) * M);
+    const size_t o_v2 = !two ? take(sizeof(double) * M) : 0;
+    const size_t o_k2e = any_hot ? take(sizeof(double) * M) : 0;
+    const size_t o_start = take(sizeof(int) * g.start.size());
+    const size_t o_cells = take(sizeof(int) * std::max<size_t>(g.cells.size(), 1));
+    const size_t total = off;
+
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->hy_buf && c->hy_bytes < total) { HIPCHK(c, hipFree(c->hy_buf)); c->hy_buf = nullptr; c->hy_bytes = 0; }
+    if (!c->hy_buf) { HIPCHK(c, hipMalloc(&c->hy_buf, total)); c->hy_bytes = total; }
+
+    std::vector<char> host(total, 0);
+    CellGeom *geom = reinterpret_cast<CellGeom *>(host.data() + o_geom);
+    CellFluid *fluid = reinterpret_cast<CellFluid *>(host.data() + o_fluid);
+    for (int i = 0; i < M; ++i) {
+        geom[i].c0 = h->r0[i]; geom[i].c1 = h->r1[i]; geom[i].s0 = h->r0_size[i]; geom[i].s1 = h->r1_size[i];
+        fluid[i].v0 = h->v0[i]; fluid[i].v1 = h->v1[i]; fluid[i].gamma = h->gamma[i]; fluid[i].dens_lab = h->dens_lab[i];
+    }
+    if (three) {
+        CellGeom2 *g2 = reinterpret_cast<CellGeom2 *>(host.data() + o_geom2);
+        for (int i = 0; i < M; ++i) { g2[i].c2 = h->r2[i]; g2[i].s2 = h->r2_size[i]; }
+    }
+    memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
+    if (!two) memcpy(host.data() + o_v2, h->v2, sizeof(double) * M);
+    memcpy(host.data() + o_start, g.start.data(), sizeof(int) * g.start.size());
+    if (!g.cells.empty()) memcpy(host.data() + o_cells, g.cells.data(), sizeof(int) * g.cells.size());
+    HIPCHK(c, hipMemcpy(c->hy_buf, host.data(), total, hipMemcpyHostToDevice));
+
+    char *base = static_cast<char *>(c->hy_buf);
+    HydroDev &hy = c->hy;
+    hy.geom = reinterpret_cast<const CellGeom *>(base + o_geom);
+    hy.geom2 = three ? reinterpret_cast<const CellGeom2 *>(base + o_geom2) : nullptr;
+    hy.fluid = reinterpret_cast<const CellFluid *>(base + o_fluid);
+    hy.temp = reinterpret_cast<const double *>(base + o_temp);
+    hy.v2 = !two ? reinterpret_cast<const double *>(base + o_v2) : nullptr;
+    hy.k2e = any_hot ? reinterpret_cast<const double *>(base + o_k2e) : nullptr;
+    hy.M = M;
+    hy.dom0[0] = h->r0_domain[0]; hy.dom0[1] = h->r0_domain[1];
+    hy.dom1[0] = h->r1_domain[0]; hy.dom1[1] = h->r1_domain[1];
+    hy.dom2[0] = h->r2_domain[0]; hy.dom2[1] = h->r2_domain[1];
+    hy.grid.start = reinterpret_cast<const int *>(base + o_start);
+    hy.grid.cells = reinterpret_cast<const int *>(base + o_cells);
+    for (int k = 0; k < 3; ++k) {
+        hy.grid.org[k] = g.org[k]; hy.grid.inv[k] = g.inv[k]; hy.grid.dim[k] = g.dim[k]; hy.grid.logmap[k] = g.logmap[k];
+    }
+    hy.grid.naxes = g.naxes;
+    if (any_hot) {
+        HIPCHK(c, launch_k2e(hy.temp, reinterpret_cast<double *>(base + o_k2e), M, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->have_hydro = true;
+    drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- photons
+static int alloc_photons(mcrat_hip_ctx *c, int n)
+{
+    const int n_pad = (int)align_up((size_t)std::max(n, 1), 2 * STEP_BLOCK);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t o_d[19];
+    for (int k = 0; k < 19; ++k) o_d[k] = take(sizeof(double) * n_pad);
+    const size_t o_idx = take(sizeof(int) * n_pad);
+    const size_t o_flags = take(n_pad);
+    const size_t o_type = take(n_pad);
+    const size_t total = off;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->ph_buf && c->ph_bytes < total) { HIPCHK(c, hipFree(c->ph_buf)); c->ph_buf = nullptr; c->ph_bytes = 0; }
+    if (!c->ph_buf) { HIPCHK(c, hipMalloc(&c->ph_buf, total)); c->ph_bytes = total; }
+    HIPCHK(c, hipMemsetAsync(c->ph_buf, 0, total, c->stream));
+    char *b = static_cast<char *>(c->ph_buf);
+    PhotonDev &p = c->ph;
+    double **cols[19] = {&p.r0, &p.r1, &p.r2, &p.p0, &p.p1, &p.p2, &p.p3, &p.c0, &p.c1, &p.c2, &p.c3,
+                         &p.s0, &p.s1, &p.s2, &p.s3, &p.num_scatt, &p.weight, &p.tau, &p.tts};
+    for (int k = 0; k < 19; ++k) *cols[k] = reinterpret_cast<double *>(b + o_d[k]);
+    p.idx = reinterpret_cast<int *>(b + o_idx);
+    p.flags = reinterpret_cast<unsigned char *>(b + o_flags);
+    p.type = b + o_type;
+    p.n = n;
+    p.n_pad = n_pad;
+    c->step_blocks = step_grid_blocks(n_pad);
+    const int need = c->step_blocks * TOPK;
+    if (c->partials_cap < need) {
+        if (c->partials) HIPCHK(c, hipFree(c->partials));
+        c->partials = nullptr;
+        HIPCHK(c, hipMalloc((void **)&c->partials, sizeof(Cand) * need));
+        c->partials_cap = need;
+    }
+    drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
+static inline unsigned char make_flags(char type, double weight, int recalc)
+{
+    unsigned f = FLAG_VALID;
+    if (type != 'p' && weight != 0) f |= FLAG_MOVES;      // mclib.c:1070
+    if (recalc == 1) f |= FLAG_RECALC;
+    return (unsigned char)f;
+}
+
+static int upload_columns(mcrat_hip_ctx *c, int n, const std::vector<const double *> &src, const int *idx,
+                          const unsigned char *flags, const char *type)
+{
+    PhotonDev &p = c->ph;
+    double *cols[19] = {p.r0, p.r1, p.r2, p.p0, p.p1, p.p2, p.p3, p.c0, p.c1, p.c2, p.c3,
+                        p.s0, p.s1, p.s2, p.s3, p.num_scatt, p.weight, p.tau, p.tts};
+    for (int k = 0; k < 19; ++k)
+        if (src[k]) HIPCHK(c, hipMemcpyAsync(cols[k], src[k], sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p.idx, idx, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p.flags, flags, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p.type, type, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_photons = true;
+    c->frame_open = false;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_set_photons(mcrat_hip_ctx *c, const mcrat_hip_photon_list *l)
+{
+    if (!c || !l || !l->photons || l->list_capacity <= 0) return MCRAT_HIP_EINVAL;
+    const int n = l->list_capacity;
+    int rc = alloc_photons(c, n);
+    if (rc) return rc;
+    std::vector<double> col((size_t)19 * n);
+    std::vector<int> idx(n);
+    std::vector<unsigned char> flags(n);
+    std::vector<char> type(n);
+    for (int i = 0; i < n; ++i) {
+        const mcrat_hip_photon &q = l->photons[i];
+        const double v[19] = {q.r0, q.r1, q.r2, q.p0, q.p1, q.p2, q.p3, q.comv_p0, q.comv_p1, q.comv_p2, q.comv_p3,
+                              q.s0, q.s1, q.s2, q.s3, q.num_scatt, q.weight, q.total_optical_depth, q.time_to_scatter};
+        for (int k = 0; k < 19; ++k) col[(size_t)k * n + i] = v[k];
+        idx[i] = q.nearest_block_index;
+        flags[i] = make_flags(q.type, q.weight, q.recalc_properties);
+        type[i] = q.type;
+    }
+    std::vector<const double *> src(19);
+    for (int k = 0; k < 19; ++k) src[k] = col.data() + (size_t)k * n;
+    return upload_columns(c, n, src, idx.data(), flags.data(), type.data());
+}
+
+extern "C" int mcrat_hip_set_photons_soa(mcrat_hip_ctx *c, const mcrat_hip_photon_soa *s)
+{
+    if (!c || !s || s->n <= 0) return MCRAT_HIP_EINVAL;
+    if (!s->type || !s->p0 || !s->p1 || !s->p2 || !s->p3 || !s->r0 || !s->r1 || !s->r2 || !s->num_scatt ||
+        !s->recalc_properties || !s->weight || !s->nearest_block_index)
+        return MCRAT_HIP_EINVAL;
+    const int n = s->n;
+    int rc = alloc_photons(c, n);
+    if (rc) return rc;
+    std::vector<unsigned char> flags(n);
+    for (int i = 0; i < n; ++i) flags[i] = make_flags(s->type[i], s->weight[i], s->recalc_properties[i]);
+    std::vector<const double *> src = {s->r0, s->r1, s->r2, s->p0, s->p1, s->p2, s->p3,
+                                       s->comv_p0, s->comv_p1, s->comv_p2, s->comv_p3,
+                                       s->s0, s->s1, s->s2, s->s3, s->num_scatt, s->weight,
+                                       s->total_optical_depth, s->time_to_scatter};
+    return upload_columns(c, n, src, s->nearest_block_index, flags.data(), s->type);
+}
+
+extern "C" int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *c) { return (c && c->have_photons) ? c->ph.n : 0; }
+
+static int flush_pending(mcrat_hip_ctx *c)
+{
+    HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_get_photons_soa(mcrat_hip_ctx *c, const mcrat_hip_photon_soa *s)
+{
+    if (!c || !s) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    if (s->n != c->ph.n) return MCRAT_HIP_EINVAL;
+    const int n = c->ph.n;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    PhotonDev &p = c->ph;
+    const double *cols[19] = {p.r0, p.r1, p.r2, p.p0, p.p1, p.p2, p.p3, p.c0, p.c1, p.c2, p.c3,
+                              p.s0, p.s1, p.s2, p.s3, p.num_scatt, p.weight, p.tau, p.tts};
+    double *dst[19] = {s->r0, s->r1, s->r2, s->p0, s->p1, s->p2, s->p3, s->comv_p0, s->comv_p1, s->comv_p2, s->comv_p3,
+                       s->s0, s->s1, s->s2, s->s3, s->num_scatt, s->weight, s->total_optical_depth, s->time_to_scatter};
+    for (int k = 0; k < 19; ++k)
+        if (dst[k]) HIPCHK(c, hipMemcpyAsync(dst[k], cols[k], sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    if (s->nearest_block_index) HIPCHK(c, hipMemcpyAsync(s->nearest_block_index, p.idx, sizeof(int) * n, hipMemcpyDeviceToHost, c->stream));
+    if (s->type) HIPCHK(c, hipMemcpyAsync(s->type, p.type, n, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned char> flags;
+    if (s->recalc_properties) {
+        flags.resize(n);
+        HIPCHK(c, hipMemcpyAsync(flags.data(), p.flags, n, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (s->recalc_properties)
+        for (int i = 0; i < n; ++i) s->recalc_properties[i] = (flags[i] & FLAG_RECALC) ? 1 : 0;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_get_photons(mcrat_hip_ctx *c, mcrat_hip_photon_list *l)
+{
+    if (!c || !l || !l->photons) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    if (l->list_capacity != c->ph.n) return MCRAT_HIP_EINVAL;
+    const int n = c->ph.n;
+    std::vector<double> col((size_t)19 * n);
+    std::vector<int> idx(n), recalc(n);
+    std::vector<char> type(n);
+    mcrat_hip_photon_soa s;
+    memset(&s, 0, sizeof s);
+    s.n = n;
+    double **dst[19] = {&s.r0, &s.r1, &s.r2, &s.p0, &s.p1, &s.p2, &s.p3, &s.comv_p0, &s.comv_p1, &s.comv_p2, &s.comv_p3,
+                        &s.s0, &s.s1, &s.s2, &s.s3, &s.num_scatt, &s.weight, &s.total_optical_depth, &s.time_to_scatter};
+    for (int k = 0; k < 19; ++k) *dst[k] = col.data() + (size_t)k * n;
+    s.nearest_block_index = idx.data();
+    s.recalc_properties = recalc.data();
+    s.type = type.data();
+    int rc = mcrat_hip_get_photons_soa(c, &s);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) {
+        mcrat_hip_photon &q = l->photons[i];
+        q.type = type[i];
+        q.r0 = s.r0[i]; q.r1 = s.r1[i]; q.r2 = s.r2[i];
+        q.p0 = s.p0[i]; q.p1 = s.p1[i]; q.p2 = s.p2[i]; q.p3 = s.p3[i];
+        q.comv_p0 = s.comv_p0[i]; q.comv_p1 = s.comv_p1[i]; q.comv_p2 = s.comv_p2[i]; q.comv_p3 = s.comv_p3[i];
+        q.s0 = s.s0[i]; q.s1 = s.s1[i]; q.s2 = s.s2[i]; q.s3 = s.s3[i];
+        q.num_scatt = s.num_scatt[i];
+        q.weight = s.weight[i];
+        q.total_optical_depth = s.total_optical_depth[i];
+        q.time_to_scatter = s.time_to_scatter[i];
+        q.nearest_block_index = idx[i];
+        q.recalc_properties = recalc[i];
+    }
+    return MCRAT_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- the loop
+static void fill_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
+{
+    if (!s) return;
+    const LoopState &h = *c->h_state;
+    s->iterations = h.iterations;
+    s->photon_steps = h.iterations * (long long)c->ph.n;
+    s->frame_scatt_cnt = h.frame_scatt_cnt;
+    s->num_photons_find_new_element = h.n_relocated;
+    s->not_found = h.not_found;
+    s->kn_rejections = h.kn_rejections;
+    s->rescans = h.rescans;
+    s->last_scattered_index = h.last_scattered_index;
+    s->last_scattered_temp = h.last_scattered_temp;
+    s->last_time_step = h.last_time_step;
+    s->remaining_time = h.remaining_time;
+    s->time_now = h.time_now;
+    s->step_kernel_ms = c->prof_step_ms;
+    s->step_kernel_launches = c->prof_launches;
+    s->event_kernel_ms = c->prof_event_ms;
+}
+
+extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double time_now, double remaining_time)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro || !c->have_photons) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    LoopState &h = *c->h_state;
+    memset(&h, 0, sizeof h);
+    h.remaining_time = remaining_time;
+    h.time_now = time_now;
+    h.done = !(remaining_time > 0);
+    h.skip_idx = -1;
+    h.last_scattered_index = -1;
+    HIPCHK(c, hipMemcpyAsync(c->d_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->key.seed = seed;
+    c->find_switch = 1;           // mcrat.c:756
+    c->frame_open = true;
+    c->prof_step_ms = c->prof_event_ms = 0;
+    c->prof_launches = 0;
+    return MCRAT_HIP_OK;
+}
+
+static int launch_iteration(mcrat_hip_ctx *c, bool force)
+{
+    HIPCHK(c, launch_step(c->kc, force, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->stream));
+    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks * TOPK, c->stream));
+    return MCRAT_HIP_OK;
+}
+
+static int ensure_events(mcrat_hip_ctx *c, size_t n)
+{
+    while (c->ev.size() < n) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreate(&e));
+        c->ev.push_back(e);
+    }
+    return MCRAT_HIP_OK;
+}
+
+static int ensure_graph(mcrat_hip_ctx *c, int batch)
+{
+    if (c->graph_exec && c->graph_batch == batch) return MCRAT_HIP_OK;
+    drop_graph(c);
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    int rc = MCRAT_HIP_OK;
+    for (int b = 0; b < batch && rc == MCRAT_HIP_OK; ++b) rc = launch_iteration(c, false);
+    hipError_t e = hipStreamEndCapture(c->stream, &c->graph);
+    if (rc != MCRAT_HIP_OK) return rc;
+    HIPCHK(c, e);
+    HIPCHK(c, hipGraphInstantiate(&c->graph_exec, c->graph, nullptr, nullptr, 0));
+    c->graph_batch = batch;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame_stats *stats)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->frame_open) return MCRAT_HIP_ESTATE;
+    const int per_sync = c->cfg.iterations_per_sync;
+    long long it = 0;
+    int rc;
+    while (max_iterations <= 0 || it < max_iterations) {
+        int batch = per_sync;
+        if (max_iterations > 0 && (long long)batch > max_iterations - it) batch = (int)(max_iterations - it);
+        if (c->cfg.profile) {
+            if ((rc = ensure_events(c, (size_t)3 * batch))) return rc;
+            for (int b = 0; b < batch; ++b) {
+                HIPCHK(c, hipEventRecord(c->ev[3 * b], c->stream));
+                HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->stream));
+                c->find_switch = 0;
+                HIPCHK(c, hipEventRecord(c->ev[3 * b + 1], c->stream));
+                HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks * TOPK, c->stream));
+                HIPCHK(c, hipEventRecord(c->ev[3 * b + 2], c->stream));
+            }
+        } else {
+            int b = 0;
+            if (c->find_switch) {             // the forced-relocation pass is never part of the graph
+                if ((rc = launch_iteration(c, true))) return rc;
+                c->find_switch = 0;
+                b = 1;
+            }
+            if (c->cfg.use_graph && b == 0 && batch == per_sync) {
+                if ((rc = ensure_graph(c, batch))) return rc;
+                HIPCHK(c, hipGraphLaunch(c->graph_exec, c->stream));
+            } else {
+                for (; b < batch; ++b)
+                    if ((rc = launch_iteration(c, false))) return rc;
+            }
+        }
+        it += batch;
+        HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->cfg.profile) {
+            // only launches that did work are counted: after `done` the kernels return at once
+            const long long did = c->h_state->iterations - c->prof_launches;
+            for (int b = 0; b < batch && b < did; ++b) {
+                float ms = 0;
+                HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3 * b], c->ev[3 * b + 1]));
+                c->prof_step_ms += ms;
+                HIPCHK(c, hipEventElapsedTime(&ms, c->ev[3 * b + 1], c->ev[3 * b + 2]));
+                c->prof_event_ms += ms;
+            }
+            c->prof_launches = c->h_state->iterations;
+        }
+        if (c->h_state->done) break;
+    }
+    if ((rc = flush_pending(c))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fill_stats(c, stats);
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_propagate_frame(mcrat_hip_ctx *c, double *time_now, double remaining_time, uint64_t seed,
+                                         mcrat_hip_frame_stats *stats)
+{
+    if (!c || !time_now) return MCRAT_HIP_EINVAL;
+    int rc = mcrat_hip_begin_frame(c, seed, *time_now, remaining_time);
+    if (rc) return rc;
+    mcrat_hip_frame_stats local;
+    rc = mcrat_hip_run(c, 0, &local);
+    if (rc) return rc;
+    *time_now = local.time_now;
+    if (stats) *stats = local;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_step_locate_sample(mcrat_hip_ctx *c, int find_nearest_block_switch)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->frame_open) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, launch_step(c->kc, find_nearest_block_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->stream));
+    c->find_switch = 0;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_step_event(mcrat_hip_ctx *c, mcrat_hip_frame_stats *stats)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->frame_open) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks * TOPK, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fill_stats(c, stats);
+    return MCRAT_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- reductions
+static int run_reduce(mcrat_hip_ctx *c, ReducePartial &t)
+{
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    const int blocks = std::min(mcrat_hip_ctx::RED_BLOCKS, std::max(1, (c->ph.n + 255) / 256));
+    HIPCHK(c, launch_reduce(c->ph, c->d_red, blocks, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_red, c->d_red, sizeof(ReducePartial) * blocks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    t = c->h_red[0];
+    for (int b = 1; b < blocks; ++b) {
+        const ReducePartial &p = c->h_red[b];
+        t.r_min = std::min(t.r_min, p.r_min); t.r_max = std::max(t.r_max, p.r_max);
+        t.th_min = std::min(t.th_min, p.th_min); t.th_max = std::max(t.th_max, p.th_max);
+        t.sum_scatt += p.sum_scatt; t.sum_r += p.sum_r; t.e_sum += p.e_sum; t.w_sum += p.w_sum;
+        t.max_scatt = std::max(t.max_scatt, p.max_scatt); t.min_scatt = std::min(t.min_scatt, p.min_scatt);
+        t.count += p.count;
+    }
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_ph_minmax(mcrat_hip_ctx *c, double *min_r, double *max_r, double *min_theta, double *max_theta)
+{
+    if (!c || !min_r || !max_r || !min_theta || !max_theta) return MCRAT_HIP_EINVAL;
+    ReducePartial t;
+    int rc = run_reduce(c, t);
+    if (rc) return rc;
+    *min_r = t.r_min; *max_r = t.r_max; *min_theta = t.th_min; *max_theta = t.th_max;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_scatt_stats(mcrat_hip_ctx *c, int *max_scatt, int *min_scatt, double *avg_scatt, double *avg_r)
+{
+    if (!c || !max_scatt || !min_scatt || !avg_scatt || !avg_r) return MCRAT_HIP_EINVAL;
+    ReducePartial t;
+    int rc = run_reduce(c, t);
+    if (rc) return rc;
+    *max_scatt = (int)t.max_scatt; *min_scatt = (int)t.min_scatt;
+    *avg_scatt = t.sum_scatt / (double)t.count; *avg_r = t.sum_r / (double)t.count;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_avg_energy(mcrat_hip_ctx *c, double *erg)
+{
+    if (!c || !erg) return MCRAT_HIP_EINVAL;
+    ReducePartial t;
+    int rc = run_reduce(c, t);
+    if (rc) return rc;
+    *erg = (t.e_sum * C_LIGHT) / t.w_sum;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_lookup_cell(mcrat_hip_ctx *c, int n, const double *a0, const double *a1, const double *a2, int *out)
+{
+    if (!c || n <= 0 || !a0 || !a1 || !out) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro) return MCRAT_HIP_ESTATE;
+    double *d = nullptr;
+    int *dout = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, sizeof(double) * 3 * (size_t)n));
+    if (hipMalloc((void **)&dout, sizeof(int) * (size_t)n) != hipSuccess) { (void)hipFree(d); return MCRAT_HIP_ENOMEM; }
+    int rc = MCRAT_HIP_OK;
+    std::vector<double> zeros;
+    if (!a2) { zeros.assign(n, 0.0); a2 = zeros.data(); }
+    if (hipMemcpy(d, a0, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n, a1, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + 2 * (size_t)n, a2, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess ||
+        launch_lookup(c->kc, c->hy, n, d, d + n, d + 2 * (size_t)n, dout, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(out, dout, sizeof(int) * n, hipMemcpyDeviceToHost) != hipSuccess) {
+        c->last_error = "lookup_cell failed";
+        rc = MCRAT_HIP_EHIP;
+    }
+    (void)hipFree(d);
+    (void)hipFree(dout);
+    return rc;
+}

@@ -1,0 +1,36 @@
+// launch.hpp -- host-callable launchers of the kernels in kernels.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+
+namespace mcrat {
+
+struct KernelConfig {
+    int dimensions;
+    int geometry;
+    int stokes;
+};
+
+struct ReducePartial {      // one per workgroup of the reduction kernels
+    double r_min, r_max, th_min, th_max;       // phMinMax (weight != 0)
+    double sum_scatt, sum_r, e_sum, w_sum;     // phScattStats / averagePhotonEnergy
+    double max_scatt, min_scatt;
+    long long count;
+};
+
+int step_grid_blocks(int n_pad);   // workgroups of the step kernel for this capacity
+
+// findContainingHydroCell + calcMeanFreePath (+ the pending updatePhotonPosition) over all slots
+hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy,
+                       LoopState *st, RngKey key, Cand *partials, int blocks, hipStream_t stream);
+// candidate selection + photonEvent + loop bookkeeping
+hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
+                        const Cand *partials, int n_partials, hipStream_t stream);
+// apply the pending advance (end of run / before photons are read back) and clear it
+hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
+hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);
+hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream);
+hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, const double *a0, const double *a1,
+                         const double *a2, int *out, hipStream_t stream);
+
+}  // namespace mcrat

@@ -1,0 +1,452 @@
+// physics.hpp -- per-photon physics of the photon loop as HIP device functions (IEEE double,
+// compiled with -ffp-contract=off so that sums and products round like the reference's C).
+// Each function names the reference lines (under /root/reference/Src) whose arithmetic it follows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "device_types.hpp"
+#include "rng.hpp"
+
+namespace mcrat {
+namespace phys {
+
+constexpr int REJECTION_CAP = 1 << 22;   // every rejection loop is bounded so that a wave always finishes
+
+// ---------------------------------------------------------------- geometry
+// geometry.c:15-64
+template <int DIMS, int GEOM>
+__device__ __forceinline__ void hydro_coords(double x, double y, double z, double &a0, double &a1, double &a2)
+{
+    a0 = -1; a1 = -1; a2 = -1;
+    if constexpr (DIMS == DIM_TWO || DIMS == DIM_TWO_POINT_FIVE) {
+        if constexpr (GEOM == GEOM_CARTESIAN || GEOM == GEOM_CYLINDRICAL) {
+            a0 = sqrt(x * x + y * y);
+            a1 = z;
+        } else if constexpr (GEOM == GEOM_SPHERICAL) {
+            a0 = sqrt(x * x + y * y + z * z);
+            a1 = acos(z / a0);
+        }
+    } else {
+        if constexpr (GEOM == GEOM_CARTESIAN) {
+            a0 = x; a1 = y; a2 = z;
+        } else if constexpr (GEOM == GEOM_SPHERICAL) {
+            a0 = sqrt(x * x + y * y + z * z);
+            a1 = acos(z / a0);
+            a2 = fmod(atan2(y, x) * 180.0 / M_PI + 360.0, 360.0) * M_PI / 180;
+        } else if constexpr (GEOM == GEOM_POLAR) {
+            a0 = sqrt(x * x + y * y);
+            a1 = fmod(atan2(y, x) * 180.0 / M_PI + 360.0, 360.0) * M_PI / 180;
+            a2 = z;
+        }
+    }
+}
+
+// strict domain test of mclib.c:492-504
+template <int DIMS>
+__device__ __forceinline__ bool in_domain(const HydroDev &h, double a0, double a1, double a2)
+{
+    bool in = (a1 < h.dom1[1]) && (a1 > h.dom1[0]) && (a0 < h.dom0[1]) && (a0 > h.dom0[0]);
+    if constexpr (DIMS == DIM_THREE) in = (a2 < h.dom2[1]) && (a2 > h.dom2[0]) && in;
+    return in;
+}
+
+// geometry.c:394-417, closed intervals
+template <int DIMS>
+__device__ __forceinline__ bool check_in_block(const HydroDev &h, int cell, double a0, double a1, double a2)
+{
+    const CellGeom g = h.geom[cell];
+    bool in = (2 * fabs(a0 - g.c0) - g.s0 <= 0) && (2 * fabs(a1 - g.c1) - g.s1 <= 0);
+    if constexpr (DIMS == DIM_THREE) {
+        const CellGeom2 g2 = h.geom2[cell];
+        in = in && (2 * fabs(a2 - g2.c2) - g2.s2 <= 0);
+    }
+    return in;
+}
+
+// findContainingBlock, geometry.c:350-391: lowest-index cell whose closed extent holds the point, or -1.
+// The bucket lists are ascending in cell index and hold every cell whose (slightly widened) extent
+// touches the bucket, so the first hit equals the reference's linear first match.
+template <int DIMS>
+__device__ __forceinline__ int find_containing_block(const HydroDev &h, double a0, double a1, double a2)
+{
+    const GridDev &g = h.grid;
+    const double a[3] = {a0, a1, a2};
+    int b[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        if (k < g.naxes) {
+            double u = g.logmap[k] ? log(a[k]) : a[k];
+            double f = floor((u - g.org[k]) * g.inv[k]);
+            if (!(f == f)) return -1;
+            int bi = (f < 0.0) ? 0 : ((f > (double)(g.dim[k] - 1)) ? g.dim[k] - 1 : (int)f);
+            b[k] = bi;
+        }
+    }
+    const int bucket = (b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0];
+    const int e1 = g.start[bucket + 1];
+    for (int e = g.start[bucket]; e < e1; ++e) {
+        const int c = g.cells[e];
+        if (check_in_block<DIMS>(h, c, a0, a1, a2)) return c;
+    }
+    return -1;
+}
+
+// geometry.c:189-253: fluid velocity of a cell (hydro basis) -> Cartesian, for a photon at azimuth phi
+template <int DIMS, int GEOM>
+__device__ __forceinline__ void cell_beta(const HydroDev &h, int cell, double ph_phi, double out[3])
+{
+    const CellFluid f = h.fluid[cell];
+    const CellGeom g = h.geom[cell];
+    double v0 = f.v0, v1 = f.v1, v2 = 0.0;
+    if constexpr (DIMS != DIM_TWO) v2 = h.v2[cell];
+    if constexpr (DIMS == DIM_TWO) {
+        if constexpr (GEOM == GEOM_CARTESIAN || GEOM == GEOM_CYLINDRICAL) {
+            out[0] = v0 * cos(ph_phi);
+            out[1] = v0 * sin(ph_phi);
+            out[2] = v1;
+        } else {
+            const double x1 = g.c1, x2 = ph_phi;
+            v2 = 0;
+            out[0] = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
+            out[1] = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
+            out[2] = v0 * cos(x1) - v1 * sin(x1);
+        }
+    } else if constexpr (DIMS == DIM_TWO_POINT_FIVE) {
+        if constexpr (GEOM == GEOM_CARTESIAN || GEOM == GEOM_CYLINDRICAL) {
+            out[0] = v0 * cos(ph_phi) - v2 * sin(ph_phi);
+            out[1] = v0 * sin(ph_phi) + v2 * cos(ph_phi);
+            out[2] = v1;
+        } else {
+            const double x1 = g.c1, x2 = ph_phi;
+            out[0] = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
+            out[1] = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
+            out[2] = v0 * cos(x1) - v1 * sin(x1);
+        }
+    } else {
+        if constexpr (GEOM == GEOM_CARTESIAN) {
+            out[0] = v0; out[1] = v1; out[2] = v2;
+        } else if constexpr (GEOM == GEOM_SPHERICAL) {
+            const double x1 = g.c1, x2 = h.geom2[cell].c2;
+            out[0] = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
+            out[1] = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
+            out[2] = v0 * cos(x1) - v1 * sin(x1);
+        } else {
+            const double x1 = g.c1;
+            out[0] = v0 * cos(x1) - v1 * sin(x1);
+            out[1] = v0 * sin(x1) + v1 * cos(x1);
+            out[2] = v2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- boosts
+// mclib.c:409-434
+__device__ __forceinline__ void zero_norm(double p[4])
+{
+    const double nrm = sqrt(p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    if (p[0] != nrm) {
+        p[1] = (p[1] / nrm) * p[0];
+        p[2] = (p[2] / nrm) * p[0];
+        p[3] = (p[3] / nrm) * p[0];
+    }
+}
+
+// mclib.c:302-407
+__device__ __forceinline__ void lorentz_boost(const double b[3], const double p[4], double out[4], bool photon)
+{
+    const double beta = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+    double r[4];
+    if (beta > 0) {
+        const double gamma = 1.0 / sqrt(1 - beta * beta);
+        const double b2 = beta * beta, g1 = gamma - 1;
+        const double L01 = -1 * b[0] * gamma, L02 = -1 * b[1] * gamma, L03 = -1 * b[2] * gamma;
+        const double L11 = 1 + ((g1 * (b[0] * b[0])) / b2);
+        const double L12 = g1 * (b[0] * b[1] / b2);
+        const double L13 = g1 * (b[0] * b[2] / b2);
+        const double L22 = 1 + ((g1 * (b[1] * b[1])) / b2);
+        const double L23 = (g1 * (b[1] * b[2])) / b2;
+        const double L33 = 1 + ((g1 * (b[2] * b[2])) / b2);
+        r[0] = ((p[0] * gamma + p[1] * L01) + p[2] * L02) + p[3] * L03;
+        r[1] = ((p[0] * L01 + p[1] * L11) + p[2] * L12) + p[3] * L13;
+        r[2] = ((p[0] * L02 + p[1] * L12) + p[2] * L22) + p[3] * L23;
+        r[3] = ((p[0] * L03 + p[1] * L13) + p[2] * L23) + p[3] * L33;
+    } else {
+        r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
+    }
+    if (photon) zero_norm(r);
+    out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
+}
+
+// ---------------------------------------------------------------- optical depth
+// optical_depth.c:7-59 (TAU_CALCULATION == DIRECT): tau' = n_lab sigma_T (1 - beta cos(angle to the flow)) [1/cm]
+__device__ __forceinline__ double optical_depth_direct(const double fluid_beta[3], double gamma_cell, double dens_lab,
+                                                       double p1, double p2, double p3)
+{
+    const double fl_v_norm = sqrt(fluid_beta[0] * fluid_beta[0] + fluid_beta[1] * fluid_beta[1] + fluid_beta[2] * fluid_beta[2]);
+    const double ph_v_norm = sqrt(p1 * p1 + p2 * p2 + p3 * p3);
+    const double n_cosangle = ((fluid_beta[0] * p1) + (fluid_beta[1] * p2) + (fluid_beta[2] * p3)) / (fl_v_norm * ph_v_norm);
+    const double beta = sqrt(1.0 - 1.0 / (gamma_cell * gamma_cell));
+    const double fluid_factor = (1.0 - beta * n_cosangle);
+    const double thermal_n_dens_lab = dens_lab / M_P;
+    return (thermal_n_dens_lab) * (THOM_X_SECT * 1.0) * fluid_factor;
+}
+
+// ---------------------------------------------------------------- Stokes helpers
+// mcrat_scattering.c:10-39
+__device__ __forceinline__ void mueller_rotation(double theta, double s[4])
+{
+    const double c = cos(2 * theta), sn = sin(2 * theta);
+    const double q = s[1] * c + s[2] * (-1 * sn);
+    const double u = s[1] * sn + s[2] * c;
+    s[1] = q;
+    s[2] = u;
+}
+
+// mcrat_scattering.c:41-65
+__device__ __forceinline__ void find_xy(const double v[3], const double ref[3], double x[3], double y[3])
+{
+    y[0] = (v[1] * ref[2] - v[2] * ref[1]);
+    y[1] = -1 * (v[0] * ref[2] - v[2] * ref[0]);
+    y[2] = (v[0] * ref[1] - v[1] * ref[0]);
+    double norm = 1.0 / sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    y[0] *= norm; y[1] *= norm; y[2] *= norm;
+    x[0] = y[1] * v[2] - y[2] * v[1];
+    x[1] = -1 * (y[0] * v[2] - y[2] * v[0]);
+    x[2] = y[0] * v[1] - y[1] * v[0];
+    norm = 1.0 / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    x[0] *= norm; x[1] *= norm; x[2] *= norm;
+}
+
+// mcrat_scattering.c:67-101
+__device__ __forceinline__ double find_phi(const double x_old[3], const double y_old[3], const double y_new[3])
+{
+    double d = (x_old[0] * y_new[0] + x_old[1] * y_new[1]) + x_old[2] * y_new[2];
+    const double factor = (d > 0) ? 1.0 : ((d < 0) ? -1.0 : 0.0);
+    d = (y_old[0] * y_new[0] + y_old[1] * y_new[1]) + y_old[2] * y_new[2];
+    if ((d < -1) || (d > 1)) d = round(d);
+    return -1 * factor * acos(d);
+}
+
+// mcrat_scattering.c:103-149
+__device__ __forceinline__ void stokes_rotation(const double v[3], const double v_ph[3], const double v_ph_boosted[3], double s[4])
+{
+    const double z_hat[3] = {0, 0, 1};
+    double x[3], y[3], xn[3], yn[3];
+    find_xy(v_ph, z_hat, x, y);
+    find_xy(v_ph, v, xn, yn);
+    mueller_rotation(find_phi(x, y, yn), s);
+    find_xy(v_ph_boosted, v, x, y);
+    find_xy(v_ph_boosted, z_hat, xn, yn);
+    mueller_rotation(find_phi(x, y, yn), s);
+}
+
+// ---------------------------------------------------------------- Klein-Nishina
+// mcrat_scattering.c:597-623
+__device__ __forceinline__ double kn_cross_section(double e)
+{
+    if (e >= 1e-3)
+        return (3. / 4.) * (2. / (e * e) + (1. / (2. * e) - (1. + e) / (e * e * e)) * log(1. + 2. * e)
+                            + (1. + e) / ((1. + 2. * e) * (1. + 2. * e)));
+    return (1. - 2. * e);
+}
+
+// mcrat_scattering.c:509-595
+template <bool STOKES>
+__device__ __forceinline__ bool kn_scatter(double &theta, double &phi, double p0, double q, double u, EventStream &rng)
+{
+    const double energy_ratio = p0 / (M_EL * C_LIGHT);
+    const double kn = kn_cross_section(energy_ratio);
+    const double rand_num = rng.uniform();
+    if (!(rand_num <= kn)) return false;
+
+    double cos_theta_dum = 0, f_cos = 0, y_cos = 1;
+    for (int it = 0; it < REJECTION_CAP && (y_cos > f_cos); ++it) {
+        y_cos = rng.uniform() * 2;
+        cos_theta_dum = rng.uniform() * 2 - 1;
+        const double a = (1 + energy_ratio * (1 - cos_theta_dum));
+        f_cos = (1.0 / (a * a)) * (energy_ratio * (1 - cos_theta_dum) + (1 / a) + cos_theta_dum * cos_theta_dum);
+    }
+    theta = acos(cos_theta_dum);
+    const double mu = 1 + energy_ratio * (1 - cos(theta));
+    const double st = sin(theta);
+    const double f_theta = (1.0 / mu + 1.0 / (mu * mu * mu) - (1.0 / (mu * mu)) * st * st) * st;
+
+    double phi_dum = 0;
+    bool uniform_phi = true;
+    if constexpr (STOKES) uniform_phi = (u == 0 && q == 0);
+    if (uniform_phi) {
+        phi_dum = rng.uniform() * 2 * M_PI;
+    } else {
+        const double phi_max = fabs(atan2(-u, q)) / 2.0;
+        const double pol = (1.0 / (mu * mu)) * st * st * st;
+        const double norm = (f_theta + pol * (q * cos(2 * phi_max) - u * sin(2 * phi_max)));
+        double y_phi = 1, f_phi = 0;
+        for (int it = 0; it < REJECTION_CAP && (y_phi > f_phi); ++it) {
+            y_phi = rng.uniform();
+            phi_dum = rng.uniform() * 2 * M_PI;
+            f_phi = (f_theta + pol * (q * cos(2 * phi_dum) - u * sin(2 * phi_dum))) / norm;
+        }
+    }
+    phi = phi_dum;
+    return true;
+}
+
+// ---------------------------------------------------------------- electron
+// Marsaglia polar method, one value per call (the published algorithm of gsl_ran_gaussian)
+__device__ __forceinline__ double gaussian(EventStream &rng, double sigma)
+{
+    double x = 0, y = 0, r2 = 2;
+    for (int it = 0; it < REJECTION_CAP && (r2 > 1.0 || r2 == 0.0); ++it) {
+        x = -1.0 + 2.0 * rng.uniform_pos();
+        y = -1.0 + 2.0 * rng.uniform_pos();
+        r2 = x * x + y * y;
+    }
+    return sigma * y * sqrt(-2.0 * log(r2) / r2);
+}
+
+// electron.c:202-237.  k2e = exp(1/Theta) K_2(1/Theta) of the cell (HydroDev::k2e): the reference's
+// x^2 beta exp(-x/Theta) / K_2(1/Theta) is evaluated as x^2 beta exp(-(x-1)/Theta) / k2e, the same number
+// without the e^-600 intermediate.
+__device__ __forceinline__ double sample_thermal_electron(double temp, double k2e, EventStream &rng)
+{
+    double gamma = 1;
+    if (temp >= 1e7) {
+        const double factor = K_B * temp / (M_EL * C_LIGHT * C_LIGHT);
+        double x_dum = 1, y_dum = 1, f_x_dum = 0;
+        for (int it = 0; it < REJECTION_CAP && ((f_x_dum != f_x_dum) || (y_dum > f_x_dum)); ++it) {
+            x_dum = rng.uniform_pos() * (1 + 100 * factor);
+            const double beta_x_dum = sqrt(1 - (1 / (x_dum * x_dum)));
+            y_dum = rng.uniform() / 2.0;
+            f_x_dum = x_dum * x_dum * (beta_x_dum / k2e) * exp(-1 * (x_dum - 1.0) / factor);
+        }
+        gamma = x_dum;
+    } else {
+        const double factor = sqrt(K_B * temp / M_EL);
+        const double g1 = gaussian(rng, factor) / C_LIGHT;
+        const double g2 = gaussian(rng, factor) / C_LIGHT;
+        const double g3 = gaussian(rng, factor) / C_LIGHT;
+        gamma = 1.0 / sqrt(1 - ((g1 * g1 + g2 * g2) + g3 * g3));
+    }
+    return gamma;
+}
+
+// electron.c:70-94 with sampleElectronTheta (:177-200) and rotateElectron (:126-175) in line
+__device__ __forceinline__ void single_thermal_electron(double el_p[4], double temp, double k2e, const double ph_p[4], EventStream &rng)
+{
+    const double gamma = sample_thermal_electron(temp, k2e, rng);
+    const double beta = sqrt(1 - (1 / (gamma * gamma)));
+    const double phi = rng.uniform() * 2 * M_PI;
+    const double theta = acos((1 - sqrt(1 + beta * beta + 2 * beta - 4 * beta * rng.uniform())) / beta);
+    const double mc = gamma * (M_EL) * (C_LIGHT);
+    el_p[0] = mc;
+    const double e1 = mc * beta * cos(theta);
+    const double e2 = mc * beta * sin(theta) * sin(phi);
+    const double e3 = mc * beta * sin(theta) * cos(phi);
+
+    const double ph_phi = atan2(ph_p[2], ph_p[3]);
+    const double ph_theta = atan2(sqrt(ph_p[2] * ph_p[2] + ph_p[3] * ph_p[3]), ph_p[1]);
+    const double ct = cos(ph_theta), sth = sin(ph_theta);
+    // R_y: rows (ct, 0, -st), (0,1,0), (st, 0, ct)
+    const double w0 = (e1 * ct + e2 * 0.0) + e3 * (-sth);
+    const double w1 = e2;
+    const double w2 = (e1 * sth + e2 * 0.0) + e3 * ct;
+    // R_x(-phi): rows (1,0,0), (0, cos(-phi), -sin(-phi)), (0, sin(-phi), cos(-phi))
+    const double cp = cos(-ph_phi), sp = sin(-ph_phi);
+    el_p[1] = w0;
+    el_p[2] = (w0 * 0.0 + w1 * cp) + w2 * (-sp);
+    el_p[3] = (w0 * 0.0 + w1 * sp) + w2 * cp;
+}
+
+// ---------------------------------------------------------------- the scattering itself
+// mcrat_scattering.c:151-485.  ph_comov and s are updated only when the scattering happens.
+template <bool STOKES>
+__device__ __forceinline__ bool single_scatter(const double el_comov[4], double ph_comov[4], double s[4], EventStream &rng)
+{
+    const double z_axis[3] = {0, 0, 1};
+    double el_v[3] = {el_comov[1] / el_comov[0], el_comov[2] / el_comov[0], el_comov[3] / el_comov[0]};
+    double ph_pr[4];
+    lorentz_boost(el_v, ph_comov, ph_pr, true);                                   // :218
+    if constexpr (STOKES) stokes_rotation(el_v, ph_comov + 1, ph_pr + 1, s);      // :225
+    const double ph_orig[4] = {ph_pr[0], ph_pr[1], ph_pr[2], ph_pr[3]};
+
+    const double phi0 = atan2(ph_pr[2], ph_pr[1]);                                // :244
+    const double c0 = cos(-phi0), s0 = sin(-phi0);
+    // rot0 rows (c0, -s0, 0), (s0, c0, 0), (0,0,1)
+    const double r00 = (ph_pr[1] * c0 + ph_pr[2] * (-s0)) + ph_pr[3] * 0.0;
+    const double r02 = (ph_pr[1] * 0.0 + ph_pr[2] * 0.0) + ph_pr[3] * 1.0;
+    const double phi1 = atan2(r02, r00);                                          // :269
+    const double c1 = cos(-phi1), s1 = sin(-phi1);
+    // after the two alignment rotations the photon is (p0, p0, 0, 0) by construction (:294-296)
+
+    double theta = 0, phi = 0;
+    const bool occurred = kn_scatter<STOKES>(theta, phi, ph_pr[0], s[1], s[2], rng);   // :307
+    if (!occurred) return false;
+
+    double result[4];
+    result[0] = ph_pr[0] / (1 + ((ph_pr[0] * (1 - cos(theta))) / (M_EL * C_LIGHT)));  // :322
+    result[1] = result[0] * cos(theta);
+    result[2] = result[0] * sin(theta) * sin(phi);
+    result[3] = result[0] * sin(theta) * cos(phi);
+
+    // undo rot1: rows (c1, 0, s1), (0,1,0), (-s1, 0, c1)                                :360-366
+    const double u0 = (result[1] * c1 + result[2] * 0.0) + result[3] * s1;
+    const double u1 = (result[1] * 0.0 + result[2] * 1.0) + result[3] * 0.0;
+    const double u2 = (result[1] * (-s1) + result[2] * 0.0) + result[3] * c1;
+    // undo rot0: rows (c0, s0, 0), (-s0, c0, 0), (0,0,1)                                :380-386
+    double res0[3];
+    res0[0] = (u0 * c0 + u1 * s0) + u2 * 0.0;
+    res0[1] = (u0 * (-s0) + u1 * c0) + u2 * 0.0;
+    res0[2] = (u0 * 0.0 + u1 * 0.0) + u2 * 1.0;
+
+    if constexpr (STOKES) {
+        double xt[3], yt[3], xn[3], yn[3];
+        find_xy(ph_orig + 1, z_axis, xt, yt);                                     // :402
+        find_xy(res0, ph_orig + 1, xn, yn);                                       // :403
+        mueller_rotation(find_phi(xt, yt, yn), s);
+        theta = acos(((ph_orig[1] * res0[0] + ph_orig[2] * res0[1]) + ph_orig[3] * res0[2]) / (ph_orig[0] * result[0]));  // :408
+        const double ct = cos(theta), sth = sin(theta);
+        const double de = (ph_orig[0] - result[0]) / (M_EL * C_LIGHT);
+        // Fano's matrix :411-416
+        const double t00 = 1.0 + ct * ct + ((1 - ct) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
+        const double t01 = sth * sth;
+        const double t11 = 1.0 + ct * ct;
+        const double t22 = 2.0 * ct;
+        const double t33 = 2.0 * ct + ((ct) * (1 - ct) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
+        (void)de;
+        const double o0 = ((s[0] * t00 + s[1] * t01) + s[2] * 0.0) + s[3] * 0.0;
+        const double o1 = ((s[0] * t01 + s[1] * t11) + s[2] * 0.0) + s[3] * 0.0;
+        const double o2 = ((s[0] * 0.0 + s[1] * 0.0) + s[2] * t22) + s[3] * 0.0;
+        const double o3 = ((s[0] * 0.0 + s[1] * 0.0) + s[2] * 0.0) + s[3] * t33;
+        s[0] = o0 / o0; s[1] = o1 / o0; s[2] = o2 / o0; s[3] = o3 / o0;          // :430-433
+        find_xy(res0, ph_orig + 1, xt, yt);                                       // :438
+        find_xy(res0, z_axis, xn, yn);                                            // :441
+        mueller_rotation(find_phi(xt, yt, yn), s);                                // :447
+    }
+
+    double ph_out[4] = {result[0], res0[0], res0[1], res0[2]};                    // :452-454
+    const double neg_el_v[3] = {-1 * el_v[0], -1 * el_v[1], -1 * el_v[2]};
+    double back[4];
+    lorentz_boost(neg_el_v, ph_out, back, true);                                  // :465
+    if constexpr (STOKES) stokes_rotation(neg_el_v, ph_out + 1, back + 1, s);     // :473
+    ph_comov[0] = back[0]; ph_comov[1] = back[1]; ph_comov[2] = back[2]; ph_comov[3] = back[3];
+    return true;
+}
+
+// exp(x) K_2(x) from K_nu(x) = int_0^inf exp(-x cosh t) cosh(nu t) dt (DLMF 10.32.9), trapezoid rule;
+// stands for gsl_sf_bessel_Kn(2, x) at electron.c:221 (scaled by e^x).
+__device__ __forceinline__ double bessel_k2_scaled(double x)
+{
+    double h = 0.35 / sqrt(x);
+    if (h > 0.125) h = 0.125;
+    double sum = 0.5;
+    for (int k = 1; k < 100000; ++k) {
+        const double t = k * h;
+        const double sh = sinh(0.5 * t);
+        const double e = -x * 2.0 * sh * sh;
+        sum += exp(e) * cosh(2.0 * t);
+        if (e + 2.0 * t < -80.0) break;
+    }
+    return sum * h;
+}
+
+}  // namespace phys
+}  // namespace mcrat

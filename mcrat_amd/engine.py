@@ -1,0 +1,300 @@
+"""ctypes binding of libmcrat_hip.so (include/mcrat_hip.h) -- the product path.
+
+There is no CPU fallback here: if the shared library is missing or no MI355X is
+visible, construction raises.  Nothing under oracle/ is imported by this package.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmcrat_hip.so")
+
+ABI_VERSION = 1
+CARTESIAN, SPHERICAL, CYLINDRICAL, POLAR = 0, 1, 2, 3
+TWO, TWO_POINT_FIVE, THREE = 0, 1, 2
+TAU_DIRECT = 1
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+# struct photon of Src/mcrat.h:142-171 (thermal-only build), 176 bytes
+PHOTON_DTYPE = np.dtype(
+    [("type", "S1"),
+     ("p0", "f8"), ("p1", "f8"), ("p2", "f8"), ("p3", "f8"),
+     ("comv_p0", "f8"), ("comv_p1", "f8"), ("comv_p2", "f8"), ("comv_p3", "f8"),
+     ("r0", "f8"), ("r1", "f8"), ("r2", "f8"),
+     ("s0", "f8"), ("s1", "f8"), ("s2", "f8"), ("s3", "f8"),
+     ("num_scatt", "f8"),
+     ("recalc_properties", "i4"),
+     ("weight", "f8"),
+     ("nearest_block_index", "i4"),
+     ("time_to_scatter", "f8"),
+     ("total_optical_depth", "f8")],
+    align=True,
+)
+assert PHOTON_DTYPE.itemsize == 176
+
+F8_COLUMNS = ("p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3", "r0", "r1", "r2",
+              "s0", "s1", "s2", "s3", "num_scatt", "weight", "time_to_scatter", "total_optical_depth")
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_int), ("dimensions", C.c_int), ("geometry", C.c_int),
+                ("stokes_switch", C.c_int), ("tau_calculation", C.c_int), ("cyclosynchrotron_switch", C.c_int),
+                ("device", C.c_int), ("stream", C.c_void_p), ("rng_stream", C.c_uint32),
+                ("iterations_per_sync", C.c_int), ("use_graph", C.c_int), ("profile", C.c_int)]
+
+
+class PhotonList(C.Structure):
+    _fields_ = [("photons", C.c_void_p), ("sorted_indexes", _ip),
+                ("num_photons", C.c_int), ("num_null_photons", C.c_int), ("list_capacity", C.c_int)]
+
+
+class PhotonSoA(C.Structure):
+    _fields_ = [("n", C.c_int), ("type", C.c_char_p),
+                ("p0", _dp), ("p1", _dp), ("p2", _dp), ("p3", _dp),
+                ("comv_p0", _dp), ("comv_p1", _dp), ("comv_p2", _dp), ("comv_p3", _dp),
+                ("r0", _dp), ("r1", _dp), ("r2", _dp),
+                ("s0", _dp), ("s1", _dp), ("s2", _dp), ("s3", _dp),
+                ("num_scatt", _dp), ("recalc_properties", _ip), ("weight", _dp),
+                ("nearest_block_index", _ip), ("time_to_scatter", _dp), ("total_optical_depth", _dp)]
+
+
+class Hydro(C.Structure):
+    _fields_ = [("num_elements", C.c_int),
+                ("r0", _dp), ("r1", _dp), ("r2", _dp),
+                ("r0_size", _dp), ("r1_size", _dp), ("r2_size", _dp),
+                ("v0", _dp), ("v1", _dp), ("v2", _dp),
+                ("dens_lab", _dp), ("temp", _dp), ("gamma", _dp),
+                ("r0_domain", C.c_double * 2), ("r1_domain", C.c_double * 2), ("r2_domain", C.c_double * 2),
+                ("fps", C.c_double)]
+
+
+class FrameStats(C.Structure):
+    _fields_ = [("iterations", C.c_longlong), ("photon_steps", C.c_longlong), ("frame_scatt_cnt", C.c_longlong),
+                ("num_photons_find_new_element", C.c_longlong), ("not_found", C.c_longlong),
+                ("kn_rejections", C.c_longlong), ("rescans", C.c_longlong),
+                ("last_scattered_index", C.c_int), ("last_scattered_temp", C.c_double),
+                ("last_time_step", C.c_double), ("remaining_time", C.c_double), ("time_now", C.c_double),
+                ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_longlong), ("event_kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/mcrat_hip.h declares: (restype, argtypes)
+_ctx = C.c_void_p
+SYMBOLS = {
+    "mcrat_hip_init": (C.c_int, [C.POINTER(_ctx), C.POINTER(Config)]),
+    "mcrat_hip_destroy": (None, [_ctx]),
+    "mcrat_hip_version": (C.c_char_p, []),
+    "mcrat_hip_strerror": (C.c_char_p, [C.c_int]),
+    "mcrat_hip_last_error": (C.c_char_p, [_ctx]),
+    "mcrat_hip_set_hydro": (C.c_int, [_ctx, C.POINTER(Hydro)]),
+    "mcrat_hip_set_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
+    "mcrat_hip_get_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
+    "mcrat_hip_set_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
+    "mcrat_hip_get_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
+    "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
+    "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
+    "mcrat_hip_begin_frame": (C.c_int, [_ctx, C.c_uint64, C.c_double, C.c_double]),
+    "mcrat_hip_run": (C.c_int, [_ctx, C.c_longlong, C.POINTER(FrameStats)]),
+    "mcrat_hip_step_locate_sample": (C.c_int, [_ctx, C.c_int]),
+    "mcrat_hip_step_event": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
+    "mcrat_hip_ph_minmax": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
+    "mcrat_hip_scatt_stats": (C.c_int, [_ctx, _ip, _ip, _dp, _dp]),
+    "mcrat_hip_avg_energy": (C.c_int, [_ctx, _dp]),
+    "mcrat_hip_synchronize": (C.c_int, [_ctx]),
+    "mcrat_hip_device_bytes": (C.c_size_t, [_ctx]),
+    "mcrat_hip_lookup_cell": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _ip]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmcrat_hip.so and bind every symbol; raises if the library was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmcrat_hip.so is missing (%s): build it with `python -m mcrat_amd.build`; "
+                "there is no CPU fallback for the photon loop" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(lib, name)
+            f.restype, f.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+class McratHipError(RuntimeError):
+    pass
+
+
+def _f8(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Engine:
+    """One context of the HIP photon-loop engine (one per rank / GPU)."""
+
+    def __init__(self, dimensions, geometry, stokes=0, device=0, stream=None, rng_stream=0,
+                 iterations_per_sync=0, use_graph=False, profile=False):
+        self.lib = load_library()
+        self.cfg = Config(ABI_VERSION, int(dimensions), int(geometry), int(bool(stokes)), TAU_DIRECT, 0,
+                          int(device), C.c_void_p(stream) if stream else None, int(rng_stream),
+                          int(iterations_per_sync), int(bool(use_graph)), int(bool(profile)))
+        self.ctx = _ctx()
+        rc = self.lib.mcrat_hip_init(C.byref(self.ctx), C.byref(self.cfg))
+        if rc != 0:
+            self.ctx = _ctx()
+            raise McratHipError("mcrat_hip_init: %s" % self.lib.mcrat_hip_strerror(rc).decode())
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.mcrat_hip_destroy(self.ctx)
+            self.ctx = _ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise McratHipError("%s: %s (%s)" % (what, self.lib.mcrat_hip_strerror(rc).decode(),
+                                                 self.lib.mcrat_hip_last_error(self.ctx).decode()))
+
+    # ---- staging
+    def set_hydro(self, frame):
+        n = int(frame["num_elements"])
+        keep, h = [], Hydro()
+        h.num_elements = n
+        for f in ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size", "v0", "v1", "v2", "dens_lab", "temp", "gamma"):
+            a = frame.get(f)
+            if a is None:
+                setattr(h, f, None)
+                continue
+            a = _f8(a)
+            assert a.shape == (n,), f
+            keep.append(a)
+            setattr(h, f, a.ctypes.data_as(_dp))
+        for k in ("r0_domain", "r1_domain", "r2_domain"):
+            dom = frame.get(k, (0.0, 0.0))
+            getattr(h, k)[0], getattr(h, k)[1] = float(dom[0]), float(dom[1])
+        h.fps = float(frame.get("fps", 1.0))
+        self._check(self.lib.mcrat_hip_set_hydro(self.ctx, C.byref(h)), "set_hydro")
+
+    def set_photons(self, ph):
+        """ph: dict of SoA columns (mcrat_amd.synth layout)."""
+        n = int(len(ph["p0"]))
+        keep, s = [], PhotonSoA()
+        s.n = n
+        for f in F8_COLUMNS:
+            a = ph.get(f)
+            if a is None:
+                setattr(s, f, None)
+                continue
+            a = _f8(a)
+            assert a.shape == (n,), f
+            keep.append(a)
+            setattr(s, f, a.ctypes.data_as(_dp))
+        t = np.ascontiguousarray(ph["type"], dtype="S1")
+        idx = np.ascontiguousarray(ph["nearest_block_index"], dtype=np.int32)
+        rc_ = np.ascontiguousarray(ph["recalc_properties"], dtype=np.int32)
+        keep += [t, idx, rc_]
+        s.type = t.ctypes.data_as(C.c_char_p)
+        s.nearest_block_index = idx.ctypes.data_as(_ip)
+        s.recalc_properties = rc_.ctypes.data_as(_ip)
+        self._check(self.lib.mcrat_hip_set_photons_soa(self.ctx, C.byref(s)), "set_photons_soa")
+        self.n = n
+
+    def get_photons(self):
+        n = self.n
+        out, s = {}, PhotonSoA()
+        s.n = n
+        for f in F8_COLUMNS:
+            out[f] = np.empty(n, dtype=np.float64)
+            setattr(s, f, out[f].ctypes.data_as(_dp))
+        out["type"] = np.empty(n, dtype="S1")
+        out["nearest_block_index"] = np.empty(n, dtype=np.int32)
+        out["recalc_properties"] = np.empty(n, dtype=np.int32)
+        s.type = out["type"].ctypes.data_as(C.c_char_p)
+        s.nearest_block_index = out["nearest_block_index"].ctypes.data_as(_ip)
+        s.recalc_properties = out["recalc_properties"].ctypes.data_as(_ip)
+        self._check(self.lib.mcrat_hip_get_photons_soa(self.ctx, C.byref(s)), "get_photons_soa")
+        return out
+
+    def set_photons_aos(self, aos):
+        """aos: numpy array of PHOTON_DTYPE (the reference's struct photon records)."""
+        a = np.ascontiguousarray(aos, dtype=PHOTON_DTYPE)
+        l = PhotonList(a.ctypes.data, None, len(a) - int(np.count_nonzero(a["type"] == b"N")),
+                       int(np.count_nonzero(a["type"] == b"N")), len(a))
+        self._check(self.lib.mcrat_hip_set_photons(self.ctx, C.byref(l)), "set_photons")
+        self.n = len(a)
+
+    def get_photons_aos(self):
+        a = np.zeros(self.n, dtype=PHOTON_DTYPE)
+        l = PhotonList(a.ctypes.data, None, self.n, 0, self.n)
+        self._check(self.lib.mcrat_hip_get_photons(self.ctx, C.byref(l)), "get_photons")
+        return a
+
+    # ---- the loop
+    def begin_frame(self, seed, time_now, remaining_time):
+        self._check(self.lib.mcrat_hip_begin_frame(self.ctx, int(seed), float(time_now), float(remaining_time)), "begin_frame")
+
+    def run(self, max_iterations=0):
+        st = FrameStats()
+        self._check(self.lib.mcrat_hip_run(self.ctx, int(max_iterations), C.byref(st)), "run")
+        return st
+
+    def propagate_frame(self, time_now, remaining_time, seed):
+        st = FrameStats()
+        tn = C.c_double(time_now)
+        self._check(self.lib.mcrat_hip_propagate_frame(self.ctx, C.byref(tn), float(remaining_time), int(seed), C.byref(st)),
+                    "propagate_frame")
+        return tn.value, st
+
+    def step_locate_sample(self, find_nearest_block_switch):
+        self._check(self.lib.mcrat_hip_step_locate_sample(self.ctx, int(find_nearest_block_switch)), "step_locate_sample")
+
+    def step_event(self):
+        st = FrameStats()
+        self._check(self.lib.mcrat_hip_step_event(self.ctx, C.byref(st)), "step_event")
+        return st
+
+    # ---- reductions
+    def ph_minmax(self):
+        v = [C.c_double() for _ in range(4)]
+        self._check(self.lib.mcrat_hip_ph_minmax(self.ctx, *[C.byref(x) for x in v]), "ph_minmax")
+        return tuple(x.value for x in v)          # min_r, max_r, min_theta, max_theta
+
+    def scatt_stats(self):
+        mx, mn, avg, ravg = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        self._check(self.lib.mcrat_hip_scatt_stats(self.ctx, C.byref(mx), C.byref(mn), C.byref(avg), C.byref(ravg)), "scatt_stats")
+        return mx.value, mn.value, avg.value, ravg.value
+
+    def avg_energy(self):
+        e = C.c_double()
+        self._check(self.lib.mcrat_hip_avg_energy(self.ctx, C.byref(e)), "avg_energy")
+        return e.value
+
+    def synchronize(self):
+        self._check(self.lib.mcrat_hip_synchronize(self.ctx), "synchronize")
+
+    def device_bytes(self):
+        return int(self.lib.mcrat_hip_device_bytes(self.ctx))
+
+    def lookup_cell(self, a0, a1, a2=None):
+        a0, a1 = _f8(a0), _f8(a1)
+        a2p = _f8(a2) if a2 is not None else None
+        out = np.empty(len(a0), dtype=np.int32)
+        self._check(self.lib.mcrat_hip_lookup_cell(self.ctx, len(a0), a0.ctypes.data_as(_dp), a1.ctypes.data_as(_dp),
+                                                   a2p.ctypes.data_as(_dp) if a2p is not None else None,
+                                                   out.ctypes.data_as(_ip)), "lookup_cell")
+        return out

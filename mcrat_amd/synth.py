@@ -182,7 +182,9 @@ def structured_fireball(frame, gamma_0=100.0, lumi=3e50, r00=1e8, theta_j=0.1, p
     eta = np.where(theta >= theta_j * (gamma_0 / 2) ** (1.0 / p), 2.0, eta)
     r_sat = eta * r00
     coast = r >= r_sat
-    gamma = np.where(coast, eta, r / r_sat)
+    # below saturation the reference sets gamma = r / r_sat, which is < 1 (NaN velocity) inside r00; no
+    # photon is ever injected there ("it shouldn't matter", analytic_outflows.c:181), so keep the frame finite
+    gamma = np.where(coast, eta, np.maximum(r / r_sat, 1.0 + 1e-6))
     temp = np.where(coast, T_0 * (r_sat / r) ** (2.0 / 3.0) / eta, T_0)
     vel = np.sqrt(1 - gamma ** -2.0)
     dens = M_P * lumi / (4 * np.pi * M_P * C_LIGHT ** 3 * eta * vel * gamma * r * r)
@@ -369,7 +371,7 @@ def config1(n_photons=10_000, seed=0, n0=64, n1=64, fps=5.0, r_inj=1e12):
     return frame, ph, cfg
 
 
-def config2(n_photons=1_000_000, seed=0x4D435261, nzc=64, fps=5.0, r_inj=1e12, block_side=2.5e8, stokes=0):
+def config2(n_photons=1_000_000, seed=0x4D435261, nzc=64, fps=5.0, r_inj=1e12, block_side=2.5e8, stokes=0, lumi=3e50):
     """cfg2: FLASH-like two-level block mesh, CYLINDRICAL (r,z), Lundman structured jet, Compton+KN.
     nzc=64 gives 16 384 leaf blocks = 1 048 576 cells; smaller nzc scales the mesh down for tests
     (cells grow so that the mesh always covers the same slab)."""
@@ -379,16 +381,16 @@ def config2(n_photons=1_000_000, seed=0x4D435261, nzc=64, fps=5.0, r_inj=1e12, b
     H = 2 * nzc * side
     z_lo = r_inj - 0.5 * H
     frame = flash_like_mesh(side, nxf, nxc, nzc, z_lo, (0.0, 5e12), (0.0, 2.5e13), fps)
-    structured_fireball(frame)
+    structured_fireball(frame, lumi=lumi)
     ph = inject_photons(frame, n_photons, r_inj, 0.0, 3.0 * np.pi / 180, seed)
     cfg = dict(dimensions=TWO, geometry=CYLINDRICAL, stokes=int(stokes), name="cfg2-flash-2d-cylindrical-jet")
     return frame, ph, cfg
 
 
-def config3(n_photons=10_000_000, seed=0x4D435262, nr=2048, nth=512, fps=5.0, r_inj=1e12, stokes=1):
+def config3(n_photons=10_000_000, seed=0x4D435262, nr=2048, nth=512, fps=5.0, r_inj=1e12, stokes=1, lumi=3e50):
     """cfg3: PLUTO-like 2-D SPHERICAL log-r grid, same jet, STOKES on."""
     frame = pluto_spherical_mesh(1e9, 2.5e13, nr, 0.0, np.pi / 2, nth, fps)
-    structured_fireball(frame)
+    structured_fireball(frame, lumi=lumi)
     ph = inject_photons(frame, n_photons, r_inj, 0.0, 6.0 * np.pi / 180, seed)
     cfg = dict(dimensions=TWO, geometry=SPHERICAL, stokes=int(stokes), name="cfg3-pluto-2d-spherical-jet")
     return frame, ph, cfg
