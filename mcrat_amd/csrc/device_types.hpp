@@ -21,9 +21,10 @@ constexpr unsigned FLAG_RECALC = 1u;   // recalc_properties == 1                
 constexpr unsigned FLAG_MOVES = 2u;    // type != CS_POOL_PHOTON && weight != 0        (mclib.c:1070)
 constexpr unsigned FLAG_VALID = 4u;    // slot index < list_capacity (padding slots are not valid)
 
-constexpr int TOPK = 4;          // candidates kept per workgroup / per iteration before a rescan
+constexpr int TOPK = 4;          // candidates fetched per rescan of time_to_scatter in the event kernel
 constexpr int MAX_SEG = 8;       // advance segments remembered per iteration (one per tried candidate)
-constexpr int STEP_BLOCK = 256;  // threads per workgroup of the step kernel; each thread owns slot pairs
+constexpr int STEP_BLOCK = 256;  // threads per workgroup of the step kernels; each thread owns slot pairs
+constexpr int SHORTLIST_CAP = 256;   // early candidates (free time below LoopState::t_cut) collected per iteration
 constexpr int EVENT_BLOCK = 256;    // one workgroup; only lane 0 runs the scattering physics, so leave it the whole register file
 
 // SoA photon columns in HBM.  Capacity is padded to a multiple of 2*STEP_BLOCK; every column is 256-B aligned.
@@ -50,7 +51,8 @@ struct alignas(16) CellGeom2 {   // third axis, 3-D only
     double c2, s2;
 };
 struct alignas(32) CellFluid {   // gathered when tau or the comoving momentum is recomputed
-    double v0, v1, gamma, dens_lab;
+    double a, b;                 // velocity with the per-cell part of geometry.c:189-253 applied (physics.hpp, cell_beta)
+    double gamma, dens_lab;
 };
 
 // exact accelerator for findContainingBlock (geometry.c:350-391): uniform buckets (optionally in
@@ -71,7 +73,7 @@ struct HydroDev {
     const CellGeom2 *geom2;
     const CellFluid *fluid;
     const double *temp;
-    const double *v2;            // 2.5-D / 3-D
+    const double *fluid_c;       // third velocity component (2.5-D: v2; 3-D: Cartesian z), absent in 2-D
     const double *k2e;           // exp(x) K_2(x), x = m_e c^2 / k T, for cells with T >= 1e7 K (else 0)
     int M;
     double dom0[2], dom1[2], dom2[2];
@@ -102,6 +104,18 @@ struct alignas(256) LoopState {
     long long not_found;
     long long kn_rejections;
     long long rescans;
+    double t_cut;                        // free times below this go on the shortlist (speed only, never results)
+    double t_est;                        // running estimate of the smallest free time per iteration
+};
+
+// Candidates of one iteration.  Every slot whose free time is below LoopState::t_cut is appended here
+// (a handful per iteration), so the list holds the COMPLETE sorted prefix of the reference's argsort
+// (mclib.c:702-712) up to t_cut; the per-workgroup minima cover the case of an empty list.  If the walk of
+// photonEvent needs candidates beyond the list, the event kernel rescans time_to_scatter.
+struct alignas(16) Shortlist {
+    int count;                   // may exceed SHORTLIST_CAP: then the list is incomplete and ignored
+    int pad[3];
+    Cand items[SHORTLIST_CAP];
 };
 
 struct RngKey {

@@ -41,6 +41,7 @@ struct mcrat_hip_ctx {
     int step_blocks = 0;
     Cand *partials = nullptr;
     int partials_cap = 0;
+    Shortlist *shortlist = nullptr;
 
     // hydro
     HydroDev hy{};
@@ -166,6 +167,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->ph_buf) (void)hipFree(c->ph_buf);
     if (c->hy_buf) (void)hipFree(c->hy_buf);
     if (c->partials) (void)hipFree(c->partials);
+    if (c->shortlist) (void)hipFree(c->shortlist);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->d_red) (void)hipFree(c->d_red);
@@ -184,7 +186,7 @@ extern "C" int mcrat_hip_synchronize(mcrat_hip_ctx *c)
 extern "C" size_t mcrat_hip_device_bytes(const mcrat_hip_ctx *c)
 {
     if (!c) return 0;
-    return c->ph_bytes + c->hy_bytes + sizeof(LoopState) + (size_t)c->partials_cap * sizeof(Cand) +
+    return c->ph_bytes + c->hy_bytes + sizeof(Shortlist) + sizeof(LoopState) + (size_t)c->partials_cap * sizeof(Cand) +
            sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS;
 }
 
@@ -319,7 +321,7 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     const size_t o_geom2 = three ? take(sizeof(CellGeom2) * M) : 0;
     const size_t o_fluid = take(sizeof(CellFluid) * M);
     const size_t o_temp = take(sizeof(double) * M);
-    const size_t o_v2 = !two ? take(sizeof(double) * M) : 0;
+    const size_t o_fc = !two ? take(sizeof(double) * M) : 0;
     const size_t o_k2e = any_hot ? take(sizeof(double) * M) : 0;
     const size_t o_start = take(sizeof(int) * g.start.size());
     const size_t o_cells = take(sizeof(int) * std::max<size_t>(g.cells.size(), 1));
@@ -332,16 +334,43 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     std::vector<char> host(total, 0);
     CellGeom *geom = reinterpret_cast<CellGeom *>(host.data() + o_geom);
     CellFluid *fluid = reinterpret_cast<CellFluid *>(host.data() + o_fluid);
+    // the per-cell part of hydroVectorToCartesian (geometry.c:189-253) is applied here, once per frame, in
+    // host double arithmetic; the device adds the photon-azimuth part (physics.hpp, cell_beta)
+    double *fc = !two ? reinterpret_cast<double *>(host.data() + o_fc) : nullptr;
+    const int geomv = c->kc.geometry;
     for (int i = 0; i < M; ++i) {
         geom[i].c0 = h->r0[i]; geom[i].c1 = h->r1[i]; geom[i].s0 = h->r0_size[i]; geom[i].s1 = h->r1_size[i];
-        fluid[i].v0 = h->v0[i]; fluid[i].v1 = h->v1[i]; fluid[i].gamma = h->gamma[i]; fluid[i].dens_lab = h->dens_lab[i];
+        fluid[i].gamma = h->gamma[i]; fluid[i].dens_lab = h->dens_lab[i];
+        const double v0 = h->v0[i], v1 = h->v1[i], v2 = two ? 0.0 : h->v2[i];
+        if (!three) {
+            if (geomv == GEOM_SPHERICAL) {
+                const double th = h->r1[i];
+                fluid[i].a = v0 * std::sin(th) + v1 * std::cos(th);
+                fluid[i].b = v0 * std::cos(th) - v1 * std::sin(th);
+            } else {
+                fluid[i].a = v0;
+                fluid[i].b = v1;
+            }
+            if (fc) fc[i] = v2;
+        } else if (geomv == GEOM_CARTESIAN) {
+            fluid[i].a = v0; fluid[i].b = v1; fc[i] = v2;
+        } else if (geomv == GEOM_SPHERICAL) {
+            const double x1 = h->r1[i], x2 = h->r2[i];
+            fluid[i].a = v0 * std::sin(x1) * std::cos(x2) + v1 * std::cos(x1) * std::cos(x2) - v2 * std::sin(x2);
+            fluid[i].b = v0 * std::sin(x1) * std::sin(x2) + v1 * std::cos(x1) * std::sin(x2) + v2 * std::cos(x2);
+            fc[i] = v0 * std::cos(x1) - v1 * std::sin(x1);
+        } else {   // POLAR
+            const double x1 = h->r1[i];
+            fluid[i].a = v0 * std::cos(x1) - v1 * std::sin(x1);
+            fluid[i].b = v0 * std::sin(x1) + v1 * std::cos(x1);
+            fc[i] = v2;
+        }
     }
     if (three) {
         CellGeom2 *g2 = reinterpret_cast<CellGeom2 *>(host.data() + o_geom2);
         for (int i = 0; i < M; ++i) { g2[i].c2 = h->r2[i]; g2[i].s2 = h->r2_size[i]; }
     }
     memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
-    if (!two) memcpy(host.data() + o_v2, h->v2, sizeof(double) * M);
     memcpy(host.data() + o_start, g.start.data(), sizeof(int) * g.start.size());
     if (!g.cells.empty()) memcpy(host.data() + o_cells, g.cells.data(), sizeof(int) * g.cells.size());
     HIPCHK(c, hipMemcpy(c->hy_buf, host.data(), total, hipMemcpyHostToDevice));
@@ -352,7 +381,7 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     hy.geom2 = three ? reinterpret_cast<const CellGeom2 *>(base + o_geom2) : nullptr;
     hy.fluid = reinterpret_cast<const CellFluid *>(base + o_fluid);
     hy.temp = reinterpret_cast<const double *>(base + o_temp);
-    hy.v2 = !two ? reinterpret_cast<const double *>(base + o_v2) : nullptr;
+    hy.fluid_c = !two ? reinterpret_cast<const double *>(base + o_fc) : nullptr;
     hy.k2e = any_hot ? reinterpret_cast<const double *>(base + o_k2e) : nullptr;
     hy.M = M;
     hy.dom0[0] = h->r0_domain[0]; hy.dom0[1] = h->r0_domain[1];
@@ -400,13 +429,15 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     p.n = n;
     p.n_pad = n_pad;
     c->step_blocks = step_grid_blocks(n_pad);
-    const int need = c->step_blocks * TOPK;
+    const int need = c->step_blocks;
     if (c->partials_cap < need) {
         if (c->partials) HIPCHK(c, hipFree(c->partials));
         c->partials = nullptr;
         HIPCHK(c, hipMalloc((void **)&c->partials, sizeof(Cand) * need));
         c->partials_cap = need;
     }
+    if (!c->shortlist) HIPCHK(c, hipMalloc((void **)&c->shortlist, sizeof(Shortlist)));
+    HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     drop_graph(c);
     return MCRAT_HIP_OK;
 }
@@ -586,6 +617,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     h.skip_idx = -1;
     h.last_scattered_index = -1;
     HIPCHK(c, hipMemcpyAsync(c->d_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->key.seed = seed;
     c->find_switch = 1;           // mcrat.c:756
@@ -597,8 +629,8 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
 
 static int launch_iteration(mcrat_hip_ctx *c, bool force)
 {
-    HIPCHK(c, launch_step(c->kc, force, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->stream));
-    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks * TOPK, c->stream));
+    HIPCHK(c, launch_step(c->kc, force, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
     return MCRAT_HIP_OK;
 }
 
@@ -641,10 +673,10 @@ extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_h
             if ((rc = ensure_events(c, (size_t)3 * batch))) return rc;
             for (int b = 0; b < batch; ++b) {
                 HIPCHK(c, hipEventRecord(c->ev[3 * b], c->stream));
-                HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->stream));
+                HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
                 c->find_switch = 0;
                 HIPCHK(c, hipEventRecord(c->ev[3 * b + 1], c->stream));
-                HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks * TOPK, c->stream));
+                HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
                 HIPCHK(c, hipEventRecord(c->ev[3 * b + 2], c->stream));
             }
         } else {
@@ -704,7 +736,7 @@ extern "C" int mcrat_hip_step_locate_sample(mcrat_hip_ctx *c, int find_nearest_b
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->frame_open) return MCRAT_HIP_ESTATE;
-    HIPCHK(c, launch_step(c->kc, find_nearest_block_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->stream));
+    HIPCHK(c, launch_step(c->kc, find_nearest_block_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
     c->find_switch = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCRAT_HIP_OK;
@@ -714,7 +746,7 @@ extern "C" int mcrat_hip_step_event(mcrat_hip_ctx *c, mcrat_hip_frame_stats *sta
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->frame_open) return MCRAT_HIP_ESTATE;
-    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks * TOPK, c->stream));
+    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fill_stats(c, stats);

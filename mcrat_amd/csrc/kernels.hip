@@ -1,15 +1,18 @@
 // kernels.hip -- HIP kernels of the photon loop for gfx950 (wave64).
 //
-//   step_kernel   one lane per photon-slot pair, coalesced 16-B SoA loads:
-//                 pending updatePhotonPosition (mclib.c:1054) -> findContainingHydroCell (mclib.c:436)
-//                 -> calcMeanFreePath (mclib.c:617) fused in ONE pass over the photons, with the argsort
-//                 of mclib.c:702-712 replaced by a top-K selection (only the prefix of the sorted list
-//                 is ever consumed, mclib.c:1128-1133).  HBM-bound; this is the kernel priced against
-//                 the roofline.
-//   event_kernel  one workgroup: merges the per-workgroup candidates, walks them in sorted order as
-//                 photonEvent does (mclib.c:1107-1356), scatters at most one photon and does the time
-//                 bookkeeping of mcrat.c:777-846.
-//   flush_kernel  applies the advance still pending when a run stops.
+//   step_kernel    one lane per photon-slot pair, coalesced 16-B SoA loads: pending updatePhotonPosition
+//                  (mclib.c:1054) -> domain + in-cell test of findContainingHydroCell (mclib.c:485-507) ->
+//                  free-time draw of calcMeanFreePath (mclib.c:675-687), fused in ONE pass over the photons.
+//                  Slots that left their cell or need tau recomputed (about 1 % per iteration) are
+//                  ballot-compacted into an LDS queue and finished by the same workgroup with dense lanes
+//                  (cell search, comoving 4-momentum, optical depth: mclib.c:528-586, optical_depth.c:7-59).
+//                  The argsort of mclib.c:702-712 is replaced by min-selection: only the prefix of the sorted
+//                  list is ever consumed (mclib.c:1128-1133).  HBM-bound; this is the kernel priced against
+//                  the roofline.
+//   event_kernel   one workgroup: sorts the iteration's shortlist of early candidates, walks it as
+//                  photonEvent does (mclib.c:1107-1356), scatters at most one photon and does the time
+//                  bookkeeping of mcrat.c:777-846.
+//   flush_kernel   applies the advance still pending when a run stops.
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <math.h>
@@ -66,6 +69,36 @@ __device__ __forceinline__ void wave_min_pair(double &t, int &i)
     }
 }
 
+// wave64 lexicographic min of (t, i) on the VALU's DPP path (no LDS traffic): prefix-min inside each row of
+// 16 lanes (row_shr 1,2,4,8), then across rows (row_bcast 15, 31); lane 63 ends with the wave minimum,
+// which is broadcast through readlane.  Lanes without a DPP source keep their own value, harmless for a min.
+template <int CTRL>
+__device__ __forceinline__ void dpp_min_step(double &t, int &i)
+{
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+    const int lo = (int)(unsigned)(tb & 0xffffffffu), hi = (int)(unsigned)(tb >> 32);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    const int oi = __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false);
+    const double ot = __longlong_as_double((long long)(((unsigned long long)(unsigned)ohi << 32) | (unsigned)olo));
+    if (cand_less(ot, oi, t, i)) { t = ot; i = oi; }
+}
+
+__device__ __forceinline__ void wave_min_pair_dpp(double &t, int &i)
+{
+    dpp_min_step<0x111>(t, i);   // row_shr:1
+    dpp_min_step<0x112>(t, i);   // row_shr:2
+    dpp_min_step<0x114>(t, i);   // row_shr:4
+    dpp_min_step<0x118>(t, i);   // row_shr:8
+    dpp_min_step<0x142>(t, i);   // row_bcast:15
+    dpp_min_step<0x143>(t, i);   // row_bcast:31
+    const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tb & 0xffffffffu), 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(tb >> 32), 63);
+    t = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    i = __builtin_amdgcn_readlane(i, 63);
+}
+
 // the K smallest of all lanes' lists -> out[0..K) (ascending).  NW = waves in the workgroup, NW*TOPK <= 64.
 template <int NW>
 __device__ __forceinline__ void block_topk(TopK &mine, Cand (*s_w)[TOPK], Cand *out)
@@ -98,107 +131,159 @@ __device__ __forceinline__ void block_topk(TopK &mine, Cand (*s_w)[TOPK], Cand *
 }
 
 // ------------------------------------------------------------------ step kernel
-struct StepCounters {
-    int relocated;
-    int not_found;
+// free time of a photon in a known cell: mclib.c:675-687
+__device__ __forceinline__ double sample_free_time(double tau, uint64_t bits)
+{
+    const double rnd = bits_to_uniform_pos(bits);
+    const double mfp = (-1.0 / tau) * log(rnd);
+    return mfp / C_LIGHT;
+}
+
+// blocks b and b+8 share an XCD (and its L2): give every XCD one contiguous eighth of the photon chunks so
+// that the cell records a workgroup gathers are shared with its L2 neighbours (placement is a speed matter only)
+__device__ __forceinline__ int xcd_contiguous_chunk(int b, int G)
+{
+    const int x = b & 7, q = G >> 3, rem = G & 7;
+    return x * q + (x < rem ? x : rem) + (b >> 3);
+}
+
+struct MinCand {
+    double t;
+    int i;
+    __device__ __forceinline__ void init() { t = INFINITY; i = INT_MAX; }
+    __device__ __forceinline__ void offer(double tt, int ii)
+    {
+        if (tt != tt) tt = INFINITY;   // a NaN free time (cell at rest, optical_depth.c:46) never wins
+        if (cand_less(tt, ii, t, i)) { t = tt; i = ii; }
+    }
 };
 
-// one photon slot through the iteration's first half.  Returns time_to_scatter.
-template <int DIMS, int GEOM, bool FORCE>
-__device__ __forceinline__ double step_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned fl, int cell,
-                                           double r0, double r1, double r2, double p0, double p1, double p2, double p3,
-                                           double tau, uint64_t bits, StepCounters &cnt)
+__device__ __forceinline__ void shortlist_push(Shortlist *sl, double t, int i)
 {
-    if (!(fl & FLAG_VALID)) return INFINITY;
+    const int pos = atomicAdd(&sl->count, 1);
+    if (pos < SHORTLIST_CAP) { sl->items[pos].t = t; sl->items[pos].idx = i; sl->items[pos].pad = 0; }
+}
 
+// streaming half of an iteration for one slot.  Returns the free time, or sets `queue` when the slot must
+// go through the slow path (then the returned time is a placeholder the slow path overwrites).
+template <int DIMS, int GEOM, bool FORCE>
+__device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned fl, int cell,
+                                           double r0, double r1, double r2, double tau, uint64_t bits, bool &queue)
+{
+    queue = false;
+    if (!(fl & FLAG_VALID)) return INFINITY;
     double a0, a1, a2;
     phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
-    bool recalc = (fl & FLAG_RECALC) != 0;
-    bool need_tau = false;
-
-    if (phys::in_domain<DIMS>(hy, a0, a1, a2) && (cell != -1)) {          // mclib.c:492-505
-        bool relocate = FORCE;
-        if constexpr (!FORCE) relocate = !phys::check_in_block<DIMS>(hy, cell, a0, a1, a2);   // mclib.c:507,528
-        if (relocate) {
-            const int found = phys::find_containing_block<DIMS>(hy, a0, a1, a2);             // mclib.c:534
-            cell = found;
-            ph.idx[i] = found;                                                               // mclib.c:536
-            if (found != -1) {
-                // comoving 4-momentum in the new cell, mclib.c:541-563
-                const double ph_phi = atan2(r1, r0);
-                double beta[3];
-                phys::cell_beta<DIMS, GEOM>(hy, found, ph_phi, beta);
-                const double lab[4] = {p0, p1, p2, p3};
-                double comv[4];
-                phys::lorentz_boost(beta, lab, comv, true);
-                ph.c0[i] = comv[0]; ph.c1[i] = comv[1]; ph.c2[i] = comv[2]; ph.c3[i] = comv[3];
-                need_tau = true;                                                             // mclib.c:570
-                if constexpr (!FORCE) cnt.relocated += 1;                                    // mclib.c:579,608-611
-            } else {
-                cnt.not_found += 1;                                                          // mclib.c:583
-            }
+    if (phys::in_domain<DIMS>(hy, a0, a1, a2) && (cell != -1)) {               // mclib.c:492-505
+        if constexpr (FORCE) {
+            queue = true;                                                        // mclib.c:528, find_nearest_block_switch == 1
+        } else {
+            queue = !phys::check_in_block<DIMS>(hy, cell, a0, a1, a2) || (fl & FLAG_RECALC);   // mclib.c:507,528 / :668
         }
-    } else if (cell != -1) {
-        cell = -1;                                                                           // mclib.c:592
-        ph.idx[i] = -1;
+        if (queue) return INFINITY;
+        return sample_free_time(tau, bits);
     }
+    if (cell != -1) ph.idx[i] = -1;                                              // mclib.c:592
+    return 1e12 / C_LIGHT;                                                       // mclib.c:620,684
+}
 
-    double tts;
-    if (cell != -1) {                                                                        // mclib.c:657
-        if (need_tau || recalc) {                                                            // mclib.c:668-673 / :570-576
-            const double ph_phi = atan2(r1, r0);
-            double beta[3];
-            phys::cell_beta<DIMS, GEOM>(hy, cell, ph_phi, beta);
+// slow path of one queued slot: mclib.c:528-586 (re-location, comoving momentum, optical depth) and the
+// recalc_properties branch of calcMeanFreePath (mclib.c:668-673), then its free-time draw
+template <int DIMS, int GEOM, bool FORCE>
+__device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned long long iter,
+                                           const RngKey &key, int &relocated, int &not_found)
+{
+    const double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
+    const double p0 = ph.p0[i], p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
+    const unsigned fl = ph.flags[i];
+    int cell = ph.idx[i];
+    double a0, a1, a2;
+    phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
+    bool relocate = FORCE;
+    if constexpr (!FORCE) relocate = !phys::check_in_block<DIMS>(hy, cell, a0, a1, a2);
+    double cphi, sphi;
+    phys::cos_sin_of_atan2(r1, r0, cphi, sphi);                                  // photon azimuth, mclib.c:549-552
+    double beta[3] = {0, 0, 0};
+    bool need_tau = (fl & FLAG_RECALC) != 0;
+    if (relocate) {
+        cell = phys::find_containing_block<DIMS>(hy, a0, a1, a2);                // mclib.c:534
+        ph.idx[i] = cell;                                                        // mclib.c:536
+        if (cell != -1) {
+            phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);
+            const double lab[4] = {p0, p1, p2, p3};
+            double comv[4];
+            phys::lorentz_boost(beta, lab, comv, true);                          // mclib.c:558
+            ph.c0[i] = comv[0]; ph.c1[i] = comv[1]; ph.c2[i] = comv[2]; ph.c3[i] = comv[3];
+            need_tau = true;                                                     // mclib.c:570
+            if constexpr (!FORCE) relocated += 1;                                // mclib.c:579,608-611
+        } else {
+            not_found += 1;                                                      // mclib.c:583
+        }
+    } else {
+        phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);
+    }
+    double t;
+    if (cell != -1) {
+        double tau;
+        if (need_tau) {
             const CellFluid f = hy.fluid[cell];
             tau = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p1, p2, p3);
             ph.tau[i] = tau;
-            if (recalc) ph.flags[i] = (unsigned char)(fl & ~FLAG_RECALC);
+            if (fl & FLAG_RECALC) ph.flags[i] = (unsigned char)(fl & ~FLAG_RECALC);   // mclib.c:571-576,672
+        } else {
+            tau = ph.tau[i];
         }
-        const double rnd = bits_to_uniform_pos(bits);                                        // mclib.c:675
-        const double mfp = (-1.0 / tau) * log(rnd);                                          // mclib.c:680
-        tts = mfp / C_LIGHT;                                                                 // mclib.c:687
+        const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)(i >> 1), RNG_FREEPATH, key.stream);
+        const uint64_t bits = (i & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
+                                      : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
+        t = sample_free_time(tau, bits);
     } else {
-        tts = 1e12 / C_LIGHT;                                                                // mclib.c:620,684
+        t = 1e12 / C_LIGHT;
     }
-    return tts;
+    ph.tts[i] = t;
+    return t;
 }
 
 template <int DIMS, int GEOM, bool FORCE>
 __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
-                                                          Cand *__restrict__ partials)
+                                                          Cand *__restrict__ block_min, Shortlist *sl)
 {
-    __shared__ Cand s_w[STEP_BLOCK / 64][TOPK];
+    __shared__ int s_qn;
+    __shared__ int s_q[2 * STEP_BLOCK];
+    __shared__ double s_wt[STEP_BLOCK / 64];
+    __shared__ int s_wi[STEP_BLOCK / 64];
     if (st->done) return;
     const int nseg = st->nseg;
     const int skip = st->skip_idx;
     const unsigned long long iter = st->iteration;
+    const double t_cut = st->t_cut;
+    const int G = gridDim.x;
+    const int lane = threadIdx.x & 63;
 
-    TopK best;
+    MinCand best;
     best.init();
-    StepCounters cnt = {0, 0};
-    const int npairs = ph.n_pad >> 1;
+    int relocated = 0, not_found = 0;
+    const int nchunks = ph.n_pad / (2 * STEP_BLOCK);
+    if (threadIdx.x == 0) s_qn = 0;
+    __syncthreads();
 
-    for (int pair = blockIdx.x * STEP_BLOCK + threadIdx.x; pair < npairs; pair += gridDim.x * STEP_BLOCK) {
+    for (int chunk = xcd_contiguous_chunk(blockIdx.x, G); chunk < nchunks; chunk += G) {
+        const int pair = chunk * STEP_BLOCK + threadIdx.x;
         const int i0 = pair << 1;
         double2 R0 = *reinterpret_cast<const double2 *>(ph.r0 + i0);
         double2 R1 = *reinterpret_cast<const double2 *>(ph.r1 + i0);
         double2 R2 = *reinterpret_cast<const double2 *>(ph.r2 + i0);
-        const double2 P0 = *reinterpret_cast<const double2 *>(ph.p0 + i0);
-        const double2 P1 = *reinterpret_cast<const double2 *>(ph.p1 + i0);
-        const double2 P2 = *reinterpret_cast<const double2 *>(ph.p2 + i0);
-        const double2 P3 = *reinterpret_cast<const double2 *>(ph.p3 + i0);
         const double2 TAU = *reinterpret_cast<const double2 *>(ph.tau + i0);
         const int2 ID = *reinterpret_cast<const int2 *>(ph.idx + i0);
         const uchar2 FL = *reinterpret_cast<const uchar2 *>(ph.flags + i0);
 
-        // one Philox block serves both slots of the pair
-        const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)pair, RNG_FREEPATH, key.stream);
-        const uint64_t bits0 = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
-        const uint64_t bits1 = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
-
         // pending updatePhotonPosition of the previous iteration, mclib.c:1067-1095: one segment per
         // candidate that photonEvent walked (mclib.c:1138,1332)
         if (nseg > 0) {
+            const double2 P0 = *reinterpret_cast<const double2 *>(ph.p0 + i0);
+            const double2 P1 = *reinterpret_cast<const double2 *>(ph.p1 + i0);
+            const double2 P2 = *reinterpret_cast<const double2 *>(ph.p2 + i0);
+            const double2 P3 = *reinterpret_cast<const double2 *>(ph.p3 + i0);
             const double d0 = 1.0 / P0.x, d1 = 1.0 / P0.y;
             const bool m0 = (FL.x & FLAG_MOVES) && (i0 != skip);
             const bool m1 = (FL.y & FLAG_MOVES) && (i0 + 1 != skip);
@@ -223,143 +308,221 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev
             *reinterpret_cast<double2 *>(ph.r2 + i0) = R2;
         }
 
+        // one Philox block serves both slots of the pair
+        const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)pair, RNG_FREEPATH, key.stream);
+        const uint64_t bits0 = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
+        const uint64_t bits1 = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
+
+        bool q0, q1;
         double2 T;
-        T.x = step_one<DIMS, GEOM, FORCE>(ph, hy, i0, FL.x, ID.x, R0.x, R1.x, R2.x, P0.x, P1.x, P2.x, P3.x, TAU.x, bits0, cnt);
-        T.y = step_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, FL.y, ID.y, R0.y, R1.y, R2.y, P0.y, P1.y, P2.y, P3.y, TAU.y, bits1, cnt);
+        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, FL.x, ID.x, R0.x, R1.x, R2.x, TAU.x, bits0, q0);
+        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, FL.y, ID.y, R0.y, R1.y, R2.y, TAU.y, bits1, q1);
         *reinterpret_cast<double2 *>(ph.tts + i0) = T;
-        if (FL.x & FLAG_VALID) best.insert(T.x, i0);
-        if (FL.y & FLAG_VALID) best.insert(T.y, i0 + 1);
+        if ((FL.x & FLAG_VALID) && !q0) { best.offer(T.x, i0); if (T.x < t_cut) shortlist_push(sl, T.x, i0); }
+        if ((FL.y & FLAG_VALID) && !q1) { best.offer(T.y, i0 + 1); if (T.y < t_cut) shortlist_push(sl, T.y, i0 + 1); }
+
+        // ballot-compact the slots that need the slow path into the workgroup's LDS queue: one LDS atomic per wave
+        const unsigned long long m0 = __ballot(q0), m1 = __ballot(q1);
+        if (m0 | m1) {
+            const int c0 = __popcll(m0), c1 = __popcll(m1);
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_qn, c0 + c1);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if (q0) s_q[base + __popcll(m0 & below)] = i0;
+            if (q1) s_q[base + c0 + __popcll(m1 & below)] = i0 + 1;
+        }
+        __syncthreads();
+        const int qn = s_qn;
+        for (int e = threadIdx.x; e < qn; e += STEP_BLOCK) {
+            const int i = s_q[e];
+            const double t = slow_one<DIMS, GEOM, FORCE>(ph, hy, i, iter, key, relocated, not_found);
+            best.offer(t, i);
+            if (t < t_cut) shortlist_push(sl, t, i);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_qn = 0;
+        __syncthreads();
     }
 
-    block_topk<STEP_BLOCK / 64>(best, s_w, partials + (size_t)blockIdx.x * TOPK);
-
-    if (cnt.relocated) atomicAdd(reinterpret_cast<unsigned long long *>(&st->n_relocated), (unsigned long long)cnt.relocated);
-    if (cnt.not_found) atomicAdd(reinterpret_cast<unsigned long long *>(&st->not_found), (unsigned long long)cnt.not_found);
+    // workgroup minimum -> block_min[blockIdx.x]
+    wave_min_pair_dpp(best.t, best.i);
+    if (lane == 0) { s_wt[threadIdx.x >> 6] = best.t; s_wi[threadIdx.x >> 6] = best.i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinCand m;
+        m.init();
+#pragma unroll
+        for (int w = 0; w < STEP_BLOCK / 64; ++w) m.offer(s_wt[w], s_wi[w]);
+        Cand c;
+        c.t = m.t; c.idx = m.i; c.pad = 0;
+        block_min[blockIdx.x] = c;
+    }
+    if (relocated) atomicAdd(reinterpret_cast<unsigned long long *>(&st->n_relocated), (unsigned long long)relocated);
+    if (not_found) atomicAdd(reinterpret_cast<unsigned long long *>(&st->not_found), (unsigned long long)not_found);
 }
 
 // ------------------------------------------------------------------ event kernel
 enum { EV_RUNNING = 0, EV_DONE = 1, EV_NEED_MORE = 2 };
 
+// thread 0's state while it walks the sorted candidates, photonEvent mclib.c:1128-1339
+struct EventWalk {
+    double dt_max, old_scatt_time, dt;
+    double *seg;          // [MAX_SEG] in LDS (runtime-indexed: keep it out of scratch)
+    int nseg, skip, last_idx;
+    long long rej;
+    bool first;           // the next candidate is the head of the sorted list
+};
+
+// one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
+template <int DIMS, int GEOM, bool STOKES>
+__device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
+                                             unsigned long long iter, EventWalk &w, double scatt_time, int i)
+{
+    // *scattered_ph_index (mclib.c:1341) is the last candidate photonEvent looked at; main() does not call
+    // photonEvent at all when even the first free time exceeds the frame (mcrat.c:777,834)
+    const bool in_frame = scatt_time < w.dt_max;
+    if (!(w.first && !in_frame)) w.last_idx = i;
+    w.first = false;
+    if (!in_frame) {                                       // mclib.c:1327-1335
+        const double this_seg = w.dt_max - w.old_scatt_time;
+        if (w.nseg < MAX_SEG) w.seg[w.nseg++] = this_seg;
+        else w.seg[MAX_SEG - 1] += this_seg;
+        w.dt = w.dt_max;
+        return EV_DONE;
+    }
+    const double this_seg = scatt_time - w.old_scatt_time;  // mclib.c:1138
+    if (w.nseg < MAX_SEG) w.seg[w.nseg++] = this_seg;
+    else w.seg[MAX_SEG - 1] += this_seg;
+    w.old_scatt_time = scatt_time;
+    const int cell = ph.idx[i];
+    if (cell == -1) return EV_RUNNING;                     // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
+
+    double p[4] = {ph.p0[i], ph.p1[i], ph.p2[i], ph.p3[i]};
+    double r[3] = {ph.r0[i], ph.r1[i], ph.r2[i]};
+    if (ph.flags[i] & FLAG_MOVES) {                        // the candidate's own position after mclib.c:1138
+        const double d = 1.0 / p[0];
+        for (int s = 0; s < w.nseg; ++s) {
+            r[0] += p[1] * d * C_LIGHT * w.seg[s];
+            r[1] += p[2] * d * C_LIGHT * w.seg[s];
+            r[2] += p[3] * d * C_LIGHT * w.seg[s];
+        }
+    }
+    const double fluid_temp = hy.temp[cell];               // mclib.c:1148
+    double cphi, sphi;
+    phys::cos_sin_of_atan2(r[1], r[0], cphi, sphi);        // ph_phi, mclib.c:1151
+    double beta[3];
+    phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);     // mclib.c:1167-1174
+    double pc[4] = {ph.c0[i], ph.c1[i], ph.c2[i], ph.c3[i]};
+    double s[4] = {1, 0, 0, 0};
+    if constexpr (STOKES) {
+        s[0] = ph.s0[i]; s[1] = ph.s1[i]; s[2] = ph.s2[i]; s[3] = ph.s3[i];
+        phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
+    }
+    EventStream rng = event_stream(key.seed, iter, (uint32_t)i, key.stream);
+    const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
+    double el[4];
+    phys::single_thermal_electron(el, fluid_temp, k2e, pc, rng);       // mclib.c:1234
+    if (!phys::single_scatter<STOKES>(el, pc, s, rng)) {               // mclib.c:1245
+        w.rej += 1;
+        return EV_RUNNING;
+    }
+    const double nb[3] = {-1 * beta[0], -1 * beta[1], -1 * beta[2]};
+    phys::lorentz_boost(nb, pc, p, true);                              // mclib.c:1265
+    if constexpr (STOKES) {
+        phys::stokes_rotation(nb, pc + 1, p + 1, s);                   // mclib.c:1280
+        ph.s0[i] = s[0]; ph.s1[i] = s[1]; ph.s2[i] = s[2]; ph.s3[i] = s[3];
+    }
+    ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
+    ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
+    ph.r0[i] = r[0]; ph.r1[i] = r[1]; ph.r2[i] = r[2];              // already advanced: the next step kernel skips it
+    ph.num_scatt[i] += 1;                                              // mclib.c:1317
+    ph.flags[i] |= (unsigned char)FLAG_RECALC;                         // mclib.c:1322
+    st->frame_scatt_cnt += 1;                                          // mclib.c:1318
+    st->last_scattered_temp = fluid_temp;
+    w.skip = i;
+    w.dt = scatt_time;
+    return EV_DONE;
+}
+
 template <int DIMS, int GEOM, bool STOKES>
 __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
-                                                            const Cand *__restrict__ partials, int n_partials)
+                                                            const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl)
 {
+    static_assert(EVENT_BLOCK == SHORTLIST_CAP, "one thread per shortlist entry");
     __shared__ Cand s_w[EVENT_BLOCK / 64][TOPK];
     __shared__ Cand s_c[TOPK];
+    __shared__ Cand s_raw[SHORTLIST_CAP];
+    __shared__ Cand s_list[SHORTLIST_CAP];
+    __shared__ double s_wt[EVENT_BLOCK / 64];
+    __shared__ int s_wi[EVENT_BLOCK / 64];
     __shared__ int s_status;
     __shared__ double s_last_t;
     __shared__ int s_last_i;
+    __shared__ double s_seg[MAX_SEG];
     if (st->done) return;
-
     const int tid = threadIdx.x;
+
+    // ---- the iteration's candidates in sorted order: the shortlist if it is complete, else the global minimum
+    int n_list = sl->count;
+    if (n_list > SHORTLIST_CAP) n_list = 0;                // overflowed: incomplete, ignore it
+    if (tid < n_list) s_raw[tid] = sl->items[tid];
     {
-        TopK best;
-        best.init();
-        for (int e = tid; e < n_partials; e += EVENT_BLOCK) {
-            const Cand c = partials[e];
-            if (c.idx != INT_MAX) best.insert(c.t, c.idx);
-        }
-        block_topk<EVENT_BLOCK / 64>(best, s_w, s_c);
+        MinCand m;
+        m.init();
+        for (int e = tid; e < n_blocks; e += EVENT_BLOCK) m.offer(block_min[e].t, block_min[e].idx);
+        wave_min_pair_dpp(m.t, m.i);
+        if ((tid & 63) == 0) { s_wt[tid >> 6] = m.t; s_wi[tid >> 6] = m.i; }
     }
-
-    // thread 0's walk through the sorted candidates, photonEvent mclib.c:1128-1339
-    const double dt_max = st->remaining_time;
-    const unsigned long long iter = st->iteration;
-    double old_scatt_time = 0, dt = 0;
-    double seg[MAX_SEG];
-    int nseg = 0, skip = -1;
-    long long rej = 0, rescans = 0;
-    int last_idx = st->last_scattered_index;
-    if (tid == 0) s_status = EV_RUNNING;
     __syncthreads();
+    if (tid < n_list) {                                    // rank sort (times with equal (t, idx) cannot occur)
+        const Cand me = s_raw[tid];
+        int rank = 0;
+        for (int j = 0; j < n_list; ++j) rank += cand_less(s_raw[j].t, s_raw[j].idx, me.t, me.idx) ? 1 : 0;
+        s_list[rank] = me;
+    }
+    if (n_list == 0 && tid == 0) {
+        MinCand g;
+        g.init();
+#pragma unroll
+        for (int w = 0; w < EVENT_BLOCK / 64; ++w) g.offer(s_wt[w], s_wi[w]);
+        s_list[0].t = g.t; s_list[0].idx = g.i; s_list[0].pad = 0;
+    }
+    __syncthreads();
+    if (n_list == 0 && s_list[0].idx != INT_MAX) n_list = 1;
 
-    const int max_rounds = ph.n / TOPK + 2;
+    const unsigned long long iter = st->iteration;
+    EventWalk w;
+    w.dt_max = st->remaining_time;
+    w.seg = s_seg;
+    w.old_scatt_time = 0; w.dt = 0; w.nseg = 0; w.skip = -1; w.rej = 0; w.first = true;
+    w.last_idx = st->last_scattered_index;
+    long long rescans = 0;
+    const double t_first = (n_list > 0) ? s_list[0].t : INFINITY;
+
+    // ---- walk the list (thread 0); refill it TOPK at a time from time_to_scatter if it runs out
+    const Cand *list = s_list;
+    const int max_rounds = ph.n / TOPK + 3;
     for (int round = 0; round < max_rounds; ++round) {
         if (tid == 0) {
             int status = EV_NEED_MORE;
-            for (int c = 0; c < TOPK; ++c) {
-                const double scatt_time = s_c[c].t;
-                const int i = s_c[c].idx;
-                if (i == INT_MAX) {                       // every slot was tried: mclib.c:1128 loop ends
-                    dt = old_scatt_time;
+            if (n_list == 0) {                             // every slot was tried (or there is none): mclib.c:1128 loop ends
+                w.dt = (round == 0) ? w.dt_max : w.old_scatt_time;
+                status = EV_DONE;
+            }
+            for (int c = 0; c < n_list && status == EV_NEED_MORE; ++c) {
+                if (try_candidate<DIMS, GEOM, STOKES>(ph, hy, st, key, iter, w, list[c].t, list[c].idx) == EV_DONE)
                     status = EV_DONE;
-                    break;
-                }
-                // *scattered_ph_index (mclib.c:1341) is the last candidate photonEvent looked at; main() does not
-                // call photonEvent at all when even the first free time exceeds the frame (mcrat.c:777,834)
-                if (!(round == 0 && c == 0 && !(scatt_time < dt_max))) last_idx = i;
-                if (scatt_time < dt_max) {                // mclib.c:1136
-                    const double this_seg = scatt_time - old_scatt_time;
-                    if (nseg < MAX_SEG) seg[nseg++] = this_seg;
-                    else seg[MAX_SEG - 1] += this_seg;
-                    old_scatt_time = scatt_time;
-                    const int cell = ph.idx[i];
-                    if (cell != -1) {
-                        double p[4] = {ph.p0[i], ph.p1[i], ph.p2[i], ph.p3[i]};
-                        double r[3] = {ph.r0[i], ph.r1[i], ph.r2[i]};
-                        if (ph.flags[i] & FLAG_MOVES) {   // the candidate's own position after mclib.c:1138
-                            const double d = 1.0 / p[0];
-                            for (int s = 0; s < nseg; ++s) {
-                                r[0] += p[1] * d * C_LIGHT * seg[s];
-                                r[1] += p[2] * d * C_LIGHT * seg[s];
-                                r[2] += p[3] * d * C_LIGHT * seg[s];
-                            }
-                        }
-                        const double fluid_temp = hy.temp[cell];                       // mclib.c:1148
-                        const double ph_phi = atan2(r[1], r[0]);                       // mclib.c:1151
-                        double beta[3];
-                        phys::cell_beta<DIMS, GEOM>(hy, cell, ph_phi, beta);           // mclib.c:1167-1174
-                        double pc[4] = {ph.c0[i], ph.c1[i], ph.c2[i], ph.c3[i]};
-                        double s[4] = {1, 0, 0, 0};
-                        if constexpr (STOKES) {
-                            s[0] = ph.s0[i]; s[1] = ph.s1[i]; s[2] = ph.s2[i]; s[3] = ph.s3[i];
-                            phys::stokes_rotation(beta, p + 1, pc + 1, s);             // mclib.c:1227
-                        }
-                        EventStream rng = event_stream(key.seed, iter, (uint32_t)i, key.stream);
-                        const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
-                        double el[4];
-                        phys::single_thermal_electron(el, fluid_temp, k2e, pc, rng);   // mclib.c:1234
-                        if (phys::single_scatter<STOKES>(el, pc, s, rng)) {            // mclib.c:1245
-                            const double nb[3] = {-1 * beta[0], -1 * beta[1], -1 * beta[2]};
-                            phys::lorentz_boost(nb, pc, p, true);                      // mclib.c:1265
-                            if constexpr (STOKES) {
-                                phys::stokes_rotation(nb, pc + 1, p + 1, s);           // mclib.c:1280
-                                ph.s0[i] = s[0]; ph.s1[i] = s[1]; ph.s2[i] = s[2]; ph.s3[i] = s[3];
-                            }
-                            ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
-                            ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
-                            ph.r0[i] = r[0]; ph.r1[i] = r[1]; ph.r2[i] = r[2];      // already advanced: the next step kernel skips it
-                            ph.num_scatt[i] += 1;                                      // mclib.c:1317
-                            ph.flags[i] |= (unsigned char)FLAG_RECALC;                 // mclib.c:1322
-                            st->frame_scatt_cnt += 1;                                  // mclib.c:1318
-                            st->last_scattered_temp = fluid_temp;
-                            skip = i;
-                            dt = scatt_time;
-                            status = EV_DONE;
-                            break;
-                        }
-                        rej += 1;
-                    }
-                } else {                                   // mclib.c:1327-1335
-                    const double this_seg = dt_max - old_scatt_time;
-                    if (nseg < MAX_SEG) seg[nseg++] = this_seg;
-                    else seg[MAX_SEG - 1] += this_seg;
-                    dt = dt_max;
-                    status = EV_DONE;
-                    break;
-                }
             }
             if (status == EV_NEED_MORE) {
-                s_last_t = s_c[TOPK - 1].t;
-                s_last_i = s_c[TOPK - 1].idx;
+                s_last_t = list[n_list - 1].t;
+                s_last_i = list[n_list - 1].idx;
                 rescans += 1;
             }
             s_status = status;
         }
         __syncthreads();
         if (s_status != EV_NEED_MORE) break;
-
-        // all TOPK candidates were Klein-Nishina rejected: fetch the next TOPK in sorted order
         {
             const double lt = s_last_t;
             const int li = s_last_i;
@@ -372,22 +535,32 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
             }
             block_topk<EVENT_BLOCK / 64>(more, s_w, s_c);
         }
+        list = s_c;
+        n_list = 0;
+        for (int c = 0; c < TOPK; ++c) n_list += (s_c[c].idx != INT_MAX) ? 1 : 0;
     }
 
     if (tid == 0) {                                        // mcrat.c:782-784 / 837-845
-        st->time_now += dt;
-        const double rem = dt_max - dt;
+        st->time_now += w.dt;
+        const double rem = w.dt_max - w.dt;
         st->remaining_time = rem;
-        st->last_time_step = dt;
+        st->last_time_step = w.dt;
         st->iteration = iter + 1;
         st->iterations += 1;
         st->done = !(rem > 0);
-        st->nseg = nseg;
-        for (int s = 0; s < MAX_SEG; ++s) st->seg[s] = (s < nseg) ? seg[s] : 0.0;
-        st->skip_idx = skip;
-        st->last_scattered_index = last_idx;
-        st->kn_rejections += rej;
+        st->nseg = w.nseg;
+        for (int s = 0; s < MAX_SEG; ++s) st->seg[s] = (s < w.nseg) ? w.seg[s] : 0.0;
+        st->skip_idx = w.skip;
+        st->last_scattered_index = w.last_idx;
+        st->kn_rejections += w.rej;
         st->rescans += rescans;
+        // shortlist threshold for the next iteration: ~8 expected entries (speed only)
+        if (t_first < INFINITY) {
+            const double est = (st->t_est > 0) ? 0.875 * st->t_est + 0.125 * t_first : t_first;
+            st->t_est = est;
+            st->t_cut = 8.0 * est;
+        }
+        sl->count = 0;
     }
 }
 
@@ -540,26 +713,26 @@ static hipError_t dispatch(const KernelConfig &kc, F &&f)
 }
 
 hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy,
-                       LoopState *st, RngKey key, Cand *partials, int blocks, hipStream_t stream)
+                       LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream)
 {
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
         if (force_relocate)
-            step_kernel<DV, GV, true><<<dim3(blocks), dim3(STEP_BLOCK), 0, stream>>>(ph, hy, st, key, partials);
+            step_kernel<DV, GV, true><<<dim3(blocks), dim3(STEP_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, sl);
         else
-            step_kernel<DV, GV, false><<<dim3(blocks), dim3(STEP_BLOCK), 0, stream>>>(ph, hy, st, key, partials);
+            step_kernel<DV, GV, false><<<dim3(blocks), dim3(STEP_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, sl);
     });
 }
 
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
-                        const Cand *partials, int n_partials, hipStream_t stream)
+                        const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream)
 {
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
         if (kc.stokes)
-            event_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, partials, n_partials);
+            event_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl);
         else
-            event_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, partials, n_partials);
+            event_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl);
     });
 }
 

@@ -22,10 +22,10 @@ int step_grid_blocks(int n_pad);   // workgroups of the step kernel for this cap
 
 // findContainingHydroCell + calcMeanFreePath (+ the pending updatePhotonPosition) over all slots
 hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy,
-                       LoopState *st, RngKey key, Cand *partials, int blocks, hipStream_t stream);
+                       LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
 // candidate selection + photonEvent + loop bookkeeping
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
-                        const Cand *partials, int n_partials, hipStream_t stream);
+                        const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 // apply the pending advance (end of run / before photons are read back) and clear it
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);

@@ -1,6 +1,12 @@
 // physics.hpp -- per-photon physics of the photon loop as HIP device functions (IEEE double,
 // compiled with -ffp-contract=off so that sums and products round like the reference's C).
 // Each function names the reference lines (under /root/reference/Src) whose arithmetic it follows.
+//
+// Angles the reference only ever feeds back into sin/cos are never materialised: cos(atan2(y,x)) is
+// x/hypot, cos(acos(c)) is c, sin(acos(c)) is sqrt(1-c^2), cos/sin(2 acos(d)) are 2d^2-1 / 2d sqrt(1-d^2).
+// These are the same real numbers as the reference's expressions (they differ in the last ulp, inside the
+// stated parity tolerance) and take the ~25 f64 libm calls per scattering event, which are pure serial
+// latency on the one lane that runs the event, down to two sincos.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
@@ -90,51 +96,37 @@ __device__ __forceinline__ int find_containing_block(const HydroDev &h, double a
     return -1;
 }
 
-// geometry.c:189-253: fluid velocity of a cell (hydro basis) -> Cartesian, for a photon at azimuth phi
-template <int DIMS, int GEOM>
-__device__ __forceinline__ void cell_beta(const HydroDev &h, int cell, double ph_phi, double out[3])
+// cos and sin of atan2(y, x) without the angle (atan2(0,0) = 0 -> (1,0))
+__device__ __forceinline__ void cos_sin_of_atan2(double y, double x, double &c, double &s)
+{
+    const double h = sqrt(x * x + y * y);
+    if (h > 0) { c = x / h; s = y / h; }
+    else { c = (x < 0 || (x == 0 && signbit(x))) ? -1.0 : 1.0; s = 0.0; }
+}
+
+// geometry.c:189-253: fluid velocity of a cell (hydro basis) -> Cartesian, for a photon at azimuth
+// phi = atan2(r1, r0) given as (cos phi, sin phi).  The per-cell part of the transform is folded into the
+// staged record (engine.hip, pack_fluid): axisymmetric runs store (a, b[, c]) with
+//   beta = (a cos(phi) - c sin(phi), a sin(phi) + c cos(phi), b)
+// (a = v0, b = v1 in CARTESIAN/CYLINDRICAL; a = v0 sin(th)+v1 cos(th), b = v0 cos(th)-v1 sin(th) in SPHERICAL;
+// c = v2 in 2.5-D, absent in 2-D) and 3-D runs store the Cartesian vector itself.
+template <int DIMS>
+__device__ __forceinline__ void cell_beta(const HydroDev &h, int cell, double cphi, double sphi, double out[3])
 {
     const CellFluid f = h.fluid[cell];
-    const CellGeom g = h.geom[cell];
-    double v0 = f.v0, v1 = f.v1, v2 = 0.0;
-    if constexpr (DIMS != DIM_TWO) v2 = h.v2[cell];
     if constexpr (DIMS == DIM_TWO) {
-        if constexpr (GEOM == GEOM_CARTESIAN || GEOM == GEOM_CYLINDRICAL) {
-            out[0] = v0 * cos(ph_phi);
-            out[1] = v0 * sin(ph_phi);
-            out[2] = v1;
-        } else {
-            const double x1 = g.c1, x2 = ph_phi;
-            v2 = 0;
-            out[0] = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
-            out[1] = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
-            out[2] = v0 * cos(x1) - v1 * sin(x1);
-        }
+        out[0] = f.a * cphi;
+        out[1] = f.a * sphi;
+        out[2] = f.b;
     } else if constexpr (DIMS == DIM_TWO_POINT_FIVE) {
-        if constexpr (GEOM == GEOM_CARTESIAN || GEOM == GEOM_CYLINDRICAL) {
-            out[0] = v0 * cos(ph_phi) - v2 * sin(ph_phi);
-            out[1] = v0 * sin(ph_phi) + v2 * cos(ph_phi);
-            out[2] = v1;
-        } else {
-            const double x1 = g.c1, x2 = ph_phi;
-            out[0] = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
-            out[1] = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
-            out[2] = v0 * cos(x1) - v1 * sin(x1);
-        }
+        const double c = h.fluid_c[cell];
+        out[0] = f.a * cphi - c * sphi;
+        out[1] = f.a * sphi + c * cphi;
+        out[2] = f.b;
     } else {
-        if constexpr (GEOM == GEOM_CARTESIAN) {
-            out[0] = v0; out[1] = v1; out[2] = v2;
-        } else if constexpr (GEOM == GEOM_SPHERICAL) {
-            const double x1 = g.c1, x2 = h.geom2[cell].c2;
-            out[0] = v0 * sin(x1) * cos(x2) + v1 * cos(x1) * cos(x2) - v2 * sin(x2);
-            out[1] = v0 * sin(x1) * sin(x2) + v1 * cos(x1) * sin(x2) + v2 * cos(x2);
-            out[2] = v0 * cos(x1) - v1 * sin(x1);
-        } else {
-            const double x1 = g.c1;
-            out[0] = v0 * cos(x1) - v1 * sin(x1);
-            out[1] = v0 * sin(x1) + v1 * cos(x1);
-            out[2] = v2;
-        }
+        out[0] = f.a;
+        out[1] = f.b;
+        out[2] = h.fluid_c[cell];
     }
 }
 
@@ -191,16 +183,6 @@ __device__ __forceinline__ double optical_depth_direct(const double fluid_beta[3
 }
 
 // ---------------------------------------------------------------- Stokes helpers
-// mcrat_scattering.c:10-39
-__device__ __forceinline__ void mueller_rotation(double theta, double s[4])
-{
-    const double c = cos(2 * theta), sn = sin(2 * theta);
-    const double q = s[1] * c + s[2] * (-1 * sn);
-    const double u = s[1] * sn + s[2] * c;
-    s[1] = q;
-    s[2] = u;
-}
-
 // mcrat_scattering.c:41-65
 __device__ __forceinline__ void find_xy(const double v[3], const double ref[3], double x[3], double y[3])
 {
@@ -216,14 +198,21 @@ __device__ __forceinline__ void find_xy(const double v[3], const double ref[3], 
     x[0] *= norm; x[1] *= norm; x[2] *= norm;
 }
 
-// mcrat_scattering.c:67-101
-__device__ __forceinline__ double find_phi(const double x_old[3], const double y_old[3], const double y_new[3])
+// findPhi (mcrat_scattering.c:67-101) followed by mullerMatrixRotation (:10-39):
+// phi = -sign(x.y') acos(d), d = y.y' (rounded to +-1 if it strays outside [-1,1]); the Mueller matrix needs
+// cos(2 phi) = 2 d^2 - 1 and sin(2 phi) = -sign(x.y') 2 d sqrt(1 - d^2).
+__device__ __forceinline__ void rotate_stokes_between(const double x_old[3], const double y_old[3], const double y_new[3], double s[4])
 {
     double d = (x_old[0] * y_new[0] + x_old[1] * y_new[1]) + x_old[2] * y_new[2];
     const double factor = (d > 0) ? 1.0 : ((d < 0) ? -1.0 : 0.0);
     d = (y_old[0] * y_new[0] + y_old[1] * y_new[1]) + y_old[2] * y_new[2];
     if ((d < -1) || (d > 1)) d = round(d);
-    return -1 * factor * acos(d);
+    const double c2 = 2 * d * d - 1;
+    const double s2 = -1 * factor * 2 * d * sqrt(1 - d * d);
+    const double q = s[1] * c2 + s[2] * (-1 * s2);
+    const double u = s[1] * s2 + s[2] * c2;
+    s[1] = q;
+    s[2] = u;
 }
 
 // mcrat_scattering.c:103-149
@@ -233,10 +222,10 @@ __device__ __forceinline__ void stokes_rotation(const double v[3], const double 
     double x[3], y[3], xn[3], yn[3];
     find_xy(v_ph, z_hat, x, y);
     find_xy(v_ph, v, xn, yn);
-    mueller_rotation(find_phi(x, y, yn), s);
+    rotate_stokes_between(x, y, yn, s);
     find_xy(v_ph_boosted, v, x, y);
     find_xy(v_ph_boosted, z_hat, xn, yn);
-    mueller_rotation(find_phi(x, y, yn), s);
+    rotate_stokes_between(x, y, yn, s);
 }
 
 // ---------------------------------------------------------------- Klein-Nishina
@@ -249,9 +238,10 @@ __device__ __forceinline__ double kn_cross_section(double e)
     return (1. - 2. * e);
 }
 
-// mcrat_scattering.c:509-595
+// mcrat_scattering.c:509-595.  Returns cos(theta) and (cos phi, sin phi) of the scattered direction.
 template <bool STOKES>
-__device__ __forceinline__ bool kn_scatter(double &theta, double &phi, double p0, double q, double u, EventStream &rng)
+__device__ __forceinline__ bool kn_scatter(double &cos_theta, double &cos_phi, double &sin_phi, double p0, double q, double u,
+                                           EventStream &rng)
 {
     const double energy_ratio = p0 / (M_EL * C_LIGHT);
     const double kn = kn_cross_section(energy_ratio);
@@ -265,28 +255,30 @@ __device__ __forceinline__ bool kn_scatter(double &theta, double &phi, double p0
         const double a = (1 + energy_ratio * (1 - cos_theta_dum));
         f_cos = (1.0 / (a * a)) * (energy_ratio * (1 - cos_theta_dum) + (1 / a) + cos_theta_dum * cos_theta_dum);
     }
-    theta = acos(cos_theta_dum);
-    const double mu = 1 + energy_ratio * (1 - cos(theta));
-    const double st = sin(theta);
-    const double f_theta = (1.0 / mu + 1.0 / (mu * mu * mu) - (1.0 / (mu * mu)) * st * st) * st;
-
+    cos_theta = cos_theta_dum;
     double phi_dum = 0;
     bool uniform_phi = true;
     if constexpr (STOKES) uniform_phi = (u == 0 && q == 0);
     if (uniform_phi) {
         phi_dum = rng.uniform() * 2 * M_PI;
     } else {
-        const double phi_max = fabs(atan2(-u, q)) / 2.0;
+        const double mu = 1 + energy_ratio * (1 - cos_theta_dum);
+        const double st = sqrt(1 - cos_theta_dum * cos_theta_dum);
+        const double f_theta = (1.0 / mu + 1.0 / (mu * mu * mu) - (1.0 / (mu * mu)) * st * st) * st;
+        // phi_max = |atan2(-u, q)| / 2  ->  cos(2 phi_max) = q / h, sin(2 phi_max) = |u| / h
+        const double h = sqrt(q * q + u * u);
         const double pol = (1.0 / (mu * mu)) * st * st * st;
-        const double norm = (f_theta + pol * (q * cos(2 * phi_max) - u * sin(2 * phi_max)));
+        const double norm = (f_theta + pol * (q * (q / h) - u * (fabs(u) / h)));
         double y_phi = 1, f_phi = 0;
         for (int it = 0; it < REJECTION_CAP && (y_phi > f_phi); ++it) {
             y_phi = rng.uniform();
             phi_dum = rng.uniform() * 2 * M_PI;
-            f_phi = (f_theta + pol * (q * cos(2 * phi_dum) - u * sin(2 * phi_dum))) / norm;
+            double s2, c2;
+            sincos(2 * phi_dum, &s2, &c2);
+            f_phi = (f_theta + pol * (q * c2 - u * s2)) / norm;
         }
     }
-    phi = phi_dum;
+    sincos(phi_dum, &sin_phi, &cos_phi);
     return true;
 }
 
@@ -335,22 +327,28 @@ __device__ __forceinline__ void single_thermal_electron(double el_p[4], double t
     const double gamma = sample_thermal_electron(temp, k2e, rng);
     const double beta = sqrt(1 - (1 / (gamma * gamma)));
     const double phi = rng.uniform() * 2 * M_PI;
-    const double theta = acos((1 - sqrt(1 + beta * beta + 2 * beta - 4 * beta * rng.uniform())) / beta);
+    // theta = acos(ct): only cos(theta) = ct and sin(theta) = sqrt(1 - ct^2) are used
+    const double ct_e = (1 - sqrt(1 + beta * beta + 2 * beta - 4 * beta * rng.uniform())) / beta;
+    const double st_e = sqrt(1 - ct_e * ct_e);
+    double sphi, cphi;
+    sincos(phi, &sphi, &cphi);
     const double mc = gamma * (M_EL) * (C_LIGHT);
     el_p[0] = mc;
-    const double e1 = mc * beta * cos(theta);
-    const double e2 = mc * beta * sin(theta) * sin(phi);
-    const double e3 = mc * beta * sin(theta) * cos(phi);
+    const double e1 = mc * beta * ct_e;
+    const double e2 = mc * beta * st_e * sphi;
+    const double e3 = mc * beta * st_e * cphi;
 
-    const double ph_phi = atan2(ph_p[2], ph_p[3]);
-    const double ph_theta = atan2(sqrt(ph_p[2] * ph_p[2] + ph_p[3] * ph_p[3]), ph_p[1]);
-    const double ct = cos(ph_theta), sth = sin(ph_theta);
+    // ph_phi = atan2(p2, p3), ph_theta = atan2(sqrt(p2^2 + p3^2), p1)
+    const double rho = sqrt(ph_p[2] * ph_p[2] + ph_p[3] * ph_p[3]);
+    double ct, sth, cp, spp;
+    cos_sin_of_atan2(rho, ph_p[1], ct, sth);
+    cos_sin_of_atan2(ph_p[2], ph_p[3], cp, spp);
+    const double sp = -spp;                       // sin(-ph_phi); cos(-ph_phi) = cp
     // R_y: rows (ct, 0, -st), (0,1,0), (st, 0, ct)
     const double w0 = (e1 * ct + e2 * 0.0) + e3 * (-sth);
     const double w1 = e2;
     const double w2 = (e1 * sth + e2 * 0.0) + e3 * ct;
     // R_x(-phi): rows (1,0,0), (0, cos(-phi), -sin(-phi)), (0, sin(-phi), cos(-phi))
-    const double cp = cos(-ph_phi), sp = sin(-ph_phi);
     el_p[1] = w0;
     el_p[2] = (w0 * 0.0 + w1 * cp) + w2 * (-sp);
     el_p[3] = (w0 * 0.0 + w1 * sp) + w2 * cp;
@@ -368,24 +366,29 @@ __device__ __forceinline__ bool single_scatter(const double el_comov[4], double 
     if constexpr (STOKES) stokes_rotation(el_v, ph_comov + 1, ph_pr + 1, s);      // :225
     const double ph_orig[4] = {ph_pr[0], ph_pr[1], ph_pr[2], ph_pr[3]};
 
-    const double phi0 = atan2(ph_pr[2], ph_pr[1]);                                // :244
-    const double c0 = cos(-phi0), s0 = sin(-phi0);
+    // phi0 = atan2(py, px) (:244): c0 = cos(-phi0), s0 = sin(-phi0)
+    double c0, sp0;
+    cos_sin_of_atan2(ph_pr[2], ph_pr[1], c0, sp0);
+    const double s0 = -sp0;
     // rot0 rows (c0, -s0, 0), (s0, c0, 0), (0,0,1)
     const double r00 = (ph_pr[1] * c0 + ph_pr[2] * (-s0)) + ph_pr[3] * 0.0;
     const double r02 = (ph_pr[1] * 0.0 + ph_pr[2] * 0.0) + ph_pr[3] * 1.0;
-    const double phi1 = atan2(r02, r00);                                          // :269
-    const double c1 = cos(-phi1), s1 = sin(-phi1);
+    // phi1 = atan2(r02, r00) (:269): c1 = cos(-phi1), s1 = sin(-phi1)
+    double c1, sp1;
+    cos_sin_of_atan2(r02, r00, c1, sp1);
+    const double s1 = -sp1;
     // after the two alignment rotations the photon is (p0, p0, 0, 0) by construction (:294-296)
 
-    double theta = 0, phi = 0;
-    const bool occurred = kn_scatter<STOKES>(theta, phi, ph_pr[0], s[1], s[2], rng);   // :307
+    double ct = 0, cphi = 1, sphi = 0;
+    const bool occurred = kn_scatter<STOKES>(ct, cphi, sphi, ph_pr[0], s[1], s[2], rng);   // :307
     if (!occurred) return false;
+    const double sth = sqrt(1 - ct * ct);
 
     double result[4];
-    result[0] = ph_pr[0] / (1 + ((ph_pr[0] * (1 - cos(theta))) / (M_EL * C_LIGHT)));  // :322
-    result[1] = result[0] * cos(theta);
-    result[2] = result[0] * sin(theta) * sin(phi);
-    result[3] = result[0] * sin(theta) * cos(phi);
+    result[0] = ph_pr[0] / (1 + ((ph_pr[0] * (1 - ct)) / (M_EL * C_LIGHT)));     // :322
+    result[1] = result[0] * ct;
+    result[2] = result[0] * sth * sphi;
+    result[3] = result[0] * sth * cphi;
 
     // undo rot1: rows (c1, 0, s1), (0,1,0), (-s1, 0, c1)                                :360-366
     const double u0 = (result[1] * c1 + result[2] * 0.0) + result[3] * s1;
@@ -401,17 +404,16 @@ __device__ __forceinline__ bool single_scatter(const double el_comov[4], double 
         double xt[3], yt[3], xn[3], yn[3];
         find_xy(ph_orig + 1, z_axis, xt, yt);                                     // :402
         find_xy(res0, ph_orig + 1, xn, yn);                                       // :403
-        mueller_rotation(find_phi(xt, yt, yn), s);
-        theta = acos(((ph_orig[1] * res0[0] + ph_orig[2] * res0[1]) + ph_orig[3] * res0[2]) / (ph_orig[0] * result[0]));  // :408
-        const double ct = cos(theta), sth = sin(theta);
-        const double de = (ph_orig[0] - result[0]) / (M_EL * C_LIGHT);
+        rotate_stokes_between(xt, yt, yn, s);                                     // :404-405
+        // theta between incoming and scattered photon (:408): only its cosine and sine are used
+        const double cth = ((ph_orig[1] * res0[0] + ph_orig[2] * res0[1]) + ph_orig[3] * res0[2]) / (ph_orig[0] * result[0]);
+        const double sn2 = 1 - cth * cth;                                         // sin^2
         // Fano's matrix :411-416
-        const double t00 = 1.0 + ct * ct + ((1 - ct) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
-        const double t01 = sth * sth;
-        const double t11 = 1.0 + ct * ct;
-        const double t22 = 2.0 * ct;
-        const double t33 = 2.0 * ct + ((ct) * (1 - ct) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
-        (void)de;
+        const double t00 = 1.0 + cth * cth + ((1 - cth) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
+        const double t01 = sn2;
+        const double t11 = 1.0 + cth * cth;
+        const double t22 = 2.0 * cth;
+        const double t33 = 2.0 * cth + ((cth) * (1 - cth) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
         const double o0 = ((s[0] * t00 + s[1] * t01) + s[2] * 0.0) + s[3] * 0.0;
         const double o1 = ((s[0] * t01 + s[1] * t11) + s[2] * 0.0) + s[3] * 0.0;
         const double o2 = ((s[0] * 0.0 + s[1] * 0.0) + s[2] * t22) + s[3] * 0.0;
@@ -419,7 +421,7 @@ __device__ __forceinline__ bool single_scatter(const double el_comov[4], double 
         s[0] = o0 / o0; s[1] = o1 / o0; s[2] = o2 / o0; s[3] = o3 / o0;          // :430-433
         find_xy(res0, ph_orig + 1, xt, yt);                                       // :438
         find_xy(res0, z_axis, xn, yn);                                            // :441
-        mueller_rotation(find_phi(xt, yt, yn), s);                                // :447
+        rotate_stokes_between(xt, yt, yn, s);                                     // :444-447
     }
 
     double ph_out[4] = {result[0], res0[0], res0[1], res0[2]};                    // :452-454

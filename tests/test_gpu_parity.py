@@ -63,8 +63,8 @@ def _compare(gpu, ref, rtol=RTOL):
             scale = np.maximum(np.abs(ref["comv_p0"]), 1e-300)
         if k in ("r0", "r1", "r2"):
             scale = np.maximum(scale, 1e9)
-        if k in ("s1", "s2", "s3"):
-            scale = np.maximum(scale, 1e-3)
+        if k in ("s0", "s1", "s2", "s3"):
+            scale = np.ones_like(b)                   # Stokes parameters are fractions of I = 1: absolute error
         err = np.abs(a - b) / scale
         assert np.all(err <= rtol), (k, float(err.max()), int(err.argmax()))
 
