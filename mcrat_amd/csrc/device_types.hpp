@@ -23,7 +23,8 @@ constexpr unsigned FLAG_VALID = 4u;    // slot index < list_capacity (padding sl
 
 constexpr int TOPK = 4;          // candidates fetched per rescan of time_to_scatter in the event kernel
 constexpr int MAX_SEG = 8;       // advance segments remembered per iteration (one per tried candidate)
-constexpr int STEP_BLOCK = 256;  // threads per workgroup of the step kernels; each thread owns slot pairs
+constexpr int STEP_BLOCK = 256;  // threads per workgroup of the step kernel; each thread owns slot pairs
+constexpr int STEP_QCAP = 1024;  // LDS queue of slots awaiting the slow path, per workgroup
 constexpr int SHORTLIST_CAP = 256;   // early candidates (free time below LoopState::t_cut) collected per iteration
 constexpr int EVENT_BLOCK = 256;    // one workgroup; only lane 0 runs the scattering physics, so leave it the whole register file
 
@@ -37,6 +38,9 @@ struct PhotonDev {
     double *weight;
     double *tau;                 // total_optical_depth [1/cm]
     double *tts;                 // time_to_scatter [s]
+    // derived columns, maintained wherever p or tau change, so that the streaming pass needs no division:
+    double *u0, *u1, *u2;        // (p_k * (1/p0)) * C_LIGHT: the velocity factor of mclib.c:1076-1080, rounded as there
+    double *ntau;                // -1.0 / total_optical_depth, the factor of mclib.c:680
     int *idx;                    // nearest_block_index
     unsigned char *flags;
     char *type;

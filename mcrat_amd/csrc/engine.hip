@@ -408,8 +408,8 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     const int n_pad = (int)align_up((size_t)std::max(n, 1), 2 * STEP_BLOCK);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    size_t o_d[19];
-    for (int k = 0; k < 19; ++k) o_d[k] = take(sizeof(double) * n_pad);
+    size_t o_d[23];
+    for (int k = 0; k < 23; ++k) o_d[k] = take(sizeof(double) * n_pad);
     const size_t o_idx = take(sizeof(int) * n_pad);
     const size_t o_flags = take(n_pad);
     const size_t o_type = take(n_pad);
@@ -423,13 +423,17 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     double **cols[19] = {&p.r0, &p.r1, &p.r2, &p.p0, &p.p1, &p.p2, &p.p3, &p.c0, &p.c1, &p.c2, &p.c3,
                          &p.s0, &p.s1, &p.s2, &p.s3, &p.num_scatt, &p.weight, &p.tau, &p.tts};
     for (int k = 0; k < 19; ++k) *cols[k] = reinterpret_cast<double *>(b + o_d[k]);
+    p.u0 = reinterpret_cast<double *>(b + o_d[19]);
+    p.u1 = reinterpret_cast<double *>(b + o_d[20]);
+    p.u2 = reinterpret_cast<double *>(b + o_d[21]);
+    p.ntau = reinterpret_cast<double *>(b + o_d[22]);
     p.idx = reinterpret_cast<int *>(b + o_idx);
     p.flags = reinterpret_cast<unsigned char *>(b + o_flags);
     p.type = b + o_type;
     p.n = n;
     p.n_pad = n_pad;
     c->step_blocks = step_grid_blocks(n_pad);
-    const int need = c->step_blocks;
+    const int need = c->step_blocks;                          // one candidate per workgroup of the step kernel
     if (c->partials_cap < need) {
         if (c->partials) HIPCHK(c, hipFree(c->partials));
         c->partials = nullptr;
@@ -458,6 +462,23 @@ static int upload_columns(mcrat_hip_ctx *c, int n, const std::vector<const doubl
                         p.s0, p.s1, p.s2, p.s3, p.num_scatt, p.weight, p.tau, p.tts};
     for (int k = 0; k < 19; ++k)
         if (src[k]) HIPCHK(c, hipMemcpyAsync(cols[k], src[k], sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    // derived columns (device_types.hpp): same operations, in the same order, as mclib.c:1074-1080 and :680
+    std::vector<double> der((size_t)4 * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const double p0 = src[3][i];
+        if (p0 != 0) {
+            const double d = 1.0 / p0;
+            der[i] = src[4][i] * d * C_LIGHT;
+            der[(size_t)n + i] = src[5][i] * d * C_LIGHT;
+            der[(size_t)2 * n + i] = src[6][i] * d * C_LIGHT;
+        }
+        const double tau = src[17] ? src[17][i] : 0.0;
+        der[(size_t)3 * n + i] = -1.0 / tau;
+    }
+    HIPCHK(c, hipMemcpyAsync(p.u0, der.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p.u1, der.data() + n, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p.u2, der.data() + (size_t)2 * n, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p.ntau, der.data() + (size_t)3 * n, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(p.idx, idx, sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(p.flags, flags, n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(p.type, type, n, hipMemcpyHostToDevice, c->stream));

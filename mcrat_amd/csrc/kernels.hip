@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "device_types.hpp"
 #include "launch.hpp"
@@ -23,6 +24,16 @@
 #include "rng.hpp"
 
 namespace mcrat {
+
+// Diagnostic build only (-DMCRAT_DIAG, tools/diag_build.sh): g_diag bits knock out parts of the step kernel so that
+// their cost can be read off the kernel trace.  Results are wrong with any bit set; the product build has no such code.
+#ifdef MCRAT_DIAG
+__device__ int g_diag = 0;
+#define MC_DIAG(bit) (g_diag & (bit))
+#else
+#define MC_DIAG(bit) 0
+#endif
+enum { DIAG_SKIP_SLOW = 1, DIAG_SKIP_INCELL = 2, DIAG_SKIP_SAMPLE = 4, DIAG_SKIP_ADVANCE = 8, DIAG_SKIP_MIN = 16 };
 
 // ------------------------------------------------------------------ top-K of (time, slot), ascending, ties by slot
 __device__ __forceinline__ bool cand_less(double ta, int ia, double tb, int ib)
@@ -132,10 +143,10 @@ __device__ __forceinline__ void block_topk(TopK &mine, Cand (*s_w)[TOPK], Cand *
 
 // ------------------------------------------------------------------ step kernel
 // free time of a photon in a known cell: mclib.c:675-687
-__device__ __forceinline__ double sample_free_time(double tau, uint64_t bits)
+__device__ __forceinline__ double sample_free_time(double ntau /* -1.0 / tau */, uint64_t bits)
 {
     const double rnd = bits_to_uniform_pos(bits);
-    const double mfp = (-1.0 / tau) * log(rnd);
+    const double mfp = ntau * log(rnd);
     return mfp / C_LIGHT;
 }
 
@@ -164,79 +175,88 @@ __device__ __forceinline__ void shortlist_push(Shortlist *sl, double t, int i)
     if (pos < SHORTLIST_CAP) { sl->items[pos].t = t; sl->items[pos].idx = i; sl->items[pos].pad = 0; }
 }
 
-// streaming half of an iteration for one slot.  Returns the free time, or sets `queue` when the slot must
-// go through the slow path (then the returned time is a placeholder the slow path overwrites).
+constexpr int Q_RECALC_ONLY = (int)0x80000000;   // queue entry flag: the slot is still in its cell, only tau is stale
+
+// streaming half of an iteration for one slot.  Returns the free time, or sets `queue` (0: no, 1: re-locate,
+// 2: recalc tau only) when the slot must go through the slow path; the time returned then is a placeholder.
 template <int DIMS, int GEOM, bool FORCE>
 __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned fl, int cell,
-                                           double r0, double r1, double r2, double tau, uint64_t bits, bool &queue)
+                                           double r0, double r1, double r2, double ntau, uint64_t bits, int &queue)
 {
-    queue = false;
+    queue = 0;
     if (!(fl & FLAG_VALID)) return INFINITY;
     double a0, a1, a2;
     phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
     if (phys::in_domain<DIMS>(hy, a0, a1, a2) && (cell != -1)) {               // mclib.c:492-505
         if constexpr (FORCE) {
-            queue = true;                                                        // mclib.c:528, find_nearest_block_switch == 1
+            queue = 1;                                                           // mclib.c:528, find_nearest_block_switch == 1
         } else {
-            queue = !phys::check_in_block<DIMS>(hy, cell, a0, a1, a2) || (fl & FLAG_RECALC);   // mclib.c:507,528 / :668
+            if (MC_DIAG(DIAG_SKIP_INCELL)) queue = 0;
+            else if (!phys::check_in_block<DIMS>(hy, cell, a0, a1, a2)) queue = 1;    // mclib.c:507,528
+            else if (fl & FLAG_RECALC) queue = 2;                                // mclib.c:668
         }
         if (queue) return INFINITY;
-        return sample_free_time(tau, bits);
+        if (MC_DIAG(DIAG_SKIP_SAMPLE)) return ntau * (double)(bits >> 40);
+        return sample_free_time(ntau, bits);
     }
     if (cell != -1) ph.idx[i] = -1;                                              // mclib.c:592
     return 1e12 / C_LIGHT;                                                       // mclib.c:620,684
 }
 
-// slow path of one queued slot: mclib.c:528-586 (re-location, comoving momentum, optical depth) and the
+// slow path of one queued slot: mclib.c:528-586 (re-location, comoving momentum, optical depth) or the
 // recalc_properties branch of calcMeanFreePath (mclib.c:668-673), then its free-time draw
-template <int DIMS, int GEOM, bool FORCE>
-__device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned long long iter,
-                                           const RngKey &key, int &relocated, int &not_found)
+template <int DIMS, int GEOM>
+__device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, bool relocate, bool count_it,
+                                           unsigned long long iter, const RngKey &key, int &relocated, int &not_found)
 {
     const double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
     const double p0 = ph.p0[i], p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
     const unsigned fl = ph.flags[i];
-    int cell = ph.idx[i];
-    double a0, a1, a2;
-    phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
-    bool relocate = FORCE;
-    if constexpr (!FORCE) relocate = !phys::check_in_block<DIMS>(hy, cell, a0, a1, a2);
-    double cphi, sphi;
-    phys::cos_sin_of_atan2(r1, r0, cphi, sphi);                                  // photon azimuth, mclib.c:549-552
-    double beta[3] = {0, 0, 0};
+    int cell;
     bool need_tau = (fl & FLAG_RECALC) != 0;
+    bool new_cell = false;
     if (relocate) {
+        double a0, a1, a2;
+        phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
         cell = phys::find_containing_block<DIMS>(hy, a0, a1, a2);                // mclib.c:534
         ph.idx[i] = cell;                                                        // mclib.c:536
         if (cell != -1) {
-            phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);
-            const double lab[4] = {p0, p1, p2, p3};
-            double comv[4];
-            phys::lorentz_boost(beta, lab, comv, true);                          // mclib.c:558
-            ph.c0[i] = comv[0]; ph.c1[i] = comv[1]; ph.c2[i] = comv[2]; ph.c3[i] = comv[3];
+            new_cell = true;
             need_tau = true;                                                     // mclib.c:570
-            if constexpr (!FORCE) relocated += 1;                                // mclib.c:579,608-611
+            if (count_it) relocated += 1;                                        // mclib.c:579,608-611
         } else {
             not_found += 1;                                                      // mclib.c:583
         }
     } else {
-        phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);
+        cell = ph.idx[i];
     }
     double t;
     if (cell != -1) {
-        double tau;
+        double ntau;
         if (need_tau) {
+            double cphi, sphi;
+            phys::cos_sin_of_atan2(r1, r0, cphi, sphi);                          // photon azimuth, mclib.c:549-552
+            double beta[3];
+            phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);
+            if (new_cell) {
+                const double lab[4] = {p0, p1, p2, p3};
+                double comv[4];
+                phys::lorentz_boost(beta, lab, comv, true);                      // mclib.c:558
+                ph.c0[i] = comv[0]; ph.c1[i] = comv[1]; ph.c2[i] = comv[2]; ph.c3[i] = comv[3];
+            }
             const CellFluid f = hy.fluid[cell];
-            tau = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p1, p2, p3);
+            const double tau = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p1, p2, p3);
+            ntau = -1.0 / tau;
             ph.tau[i] = tau;
+            ph.ntau[i] = ntau;
             if (fl & FLAG_RECALC) ph.flags[i] = (unsigned char)(fl & ~FLAG_RECALC);   // mclib.c:571-576,672
         } else {
-            tau = ph.tau[i];
+            ntau = ph.ntau[i];
         }
         const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)(i >> 1), RNG_FREEPATH, key.stream);
         const uint64_t bits = (i & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
                                       : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
-        t = sample_free_time(tau, bits);
+        t = sample_free_time(ntau, bits);
     } else {
         t = 1e12 / C_LIGHT;
     }
@@ -244,12 +264,41 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
     return t;
 }
 
+// the streaming loads of one slot pair
+struct PairIn {
+    double2 R0, R1, R2, U0, U1, U2, NTAU;
+    int2 ID;
+    uchar2 FL;
+};
+
+__device__ __forceinline__ PairIn load_pair(const PhotonDev &ph, int i0, bool need_u)
+{
+    PairIn in;
+    in.R0 = *reinterpret_cast<const double2 *>(ph.r0 + i0);
+    in.R1 = *reinterpret_cast<const double2 *>(ph.r1 + i0);
+    in.R2 = *reinterpret_cast<const double2 *>(ph.r2 + i0);
+    in.NTAU = *reinterpret_cast<const double2 *>(ph.ntau + i0);
+    in.ID = *reinterpret_cast<const int2 *>(ph.idx + i0);
+    in.FL = *reinterpret_cast<const uchar2 *>(ph.flags + i0);
+    if (need_u) {
+        in.U0 = *reinterpret_cast<const double2 *>(ph.u0 + i0);
+        in.U1 = *reinterpret_cast<const double2 *>(ph.u1 + i0);
+        in.U2 = *reinterpret_cast<const double2 *>(ph.u2 + i0);
+    } else {
+        in.U0 = in.U1 = in.U2 = make_double2(0, 0);
+    }
+    return in;
+}
+
+// One workgroup streams its chunks of 512 slots (phase 1, two chunks in flight per thread), collecting in an
+// LDS queue the few slots that need the slow path, then finishes those with dense lanes (phase 2) and
+// publishes its minimum.  On the forced pass of a new frame every slot takes the slow path, in line.
 template <int DIMS, int GEOM, bool FORCE>
 __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
                                                           Cand *__restrict__ block_min, Shortlist *sl)
 {
     __shared__ int s_qn;
-    __shared__ int s_q[2 * STEP_BLOCK];
+    __shared__ int s_q[STEP_QCAP];
     __shared__ double s_wt[STEP_BLOCK / 64];
     __shared__ int s_wi[STEP_BLOCK / 64];
     if (st->done) return;
@@ -265,84 +314,81 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev
     int relocated = 0, not_found = 0;
     const int nchunks = ph.n_pad / (2 * STEP_BLOCK);
     if (threadIdx.x == 0) s_qn = 0;
+    for (int e = threadIdx.x; e < STEP_QCAP; e += STEP_BLOCK) s_q[e] = -1;   // -1: hole left by a wave that overflowed
     __syncthreads();
 
-    for (int chunk = xcd_contiguous_chunk(blockIdx.x, G); chunk < nchunks; chunk += G) {
-        const int pair = chunk * STEP_BLOCK + threadIdx.x;
+    auto process = [&](PairIn &in, int pair) {
         const int i0 = pair << 1;
-        double2 R0 = *reinterpret_cast<const double2 *>(ph.r0 + i0);
-        double2 R1 = *reinterpret_cast<const double2 *>(ph.r1 + i0);
-        double2 R2 = *reinterpret_cast<const double2 *>(ph.r2 + i0);
-        const double2 TAU = *reinterpret_cast<const double2 *>(ph.tau + i0);
-        const int2 ID = *reinterpret_cast<const int2 *>(ph.idx + i0);
-        const uchar2 FL = *reinterpret_cast<const uchar2 *>(ph.flags + i0);
-
         // pending updatePhotonPosition of the previous iteration, mclib.c:1067-1095: one segment per
-        // candidate that photonEvent walked (mclib.c:1138,1332)
-        if (nseg > 0) {
-            const double2 P0 = *reinterpret_cast<const double2 *>(ph.p0 + i0);
-            const double2 P1 = *reinterpret_cast<const double2 *>(ph.p1 + i0);
-            const double2 P2 = *reinterpret_cast<const double2 *>(ph.p2 + i0);
-            const double2 P3 = *reinterpret_cast<const double2 *>(ph.p3 + i0);
-            const double d0 = 1.0 / P0.x, d1 = 1.0 / P0.y;
-            const bool m0 = (FL.x & FLAG_MOVES) && (i0 != skip);
-            const bool m1 = (FL.y & FLAG_MOVES) && (i0 + 1 != skip);
-#pragma unroll
-            for (int s = 0; s < MAX_SEG; ++s) {
-                if (s < nseg) {
-                    const double t = st->seg[s];
-                    if (m0) {
-                        R0.x += P1.x * d0 * C_LIGHT * t;
-                        R1.x += P2.x * d0 * C_LIGHT * t;
-                        R2.x += P3.x * d0 * C_LIGHT * t;
-                    }
-                    if (m1) {
-                        R0.y += P1.y * d1 * C_LIGHT * t;
-                        R1.y += P2.y * d1 * C_LIGHT * t;
-                        R2.y += P3.y * d1 * C_LIGHT * t;
-                    }
-                }
+        // candidate that photonEvent walked (mclib.c:1138,1332); u = (p * (1/p0)) * C_LIGHT is stored
+        if (nseg > 0 && !MC_DIAG(DIAG_SKIP_ADVANCE)) {
+            const bool m0 = (in.FL.x & FLAG_MOVES) && (i0 != skip);
+            const bool m1 = (in.FL.y & FLAG_MOVES) && (i0 + 1 != skip);
+            for (int s = 0; s < nseg; ++s) {
+                const double t = st->seg[s];
+                if (m0) { in.R0.x += in.U0.x * t; in.R1.x += in.U1.x * t; in.R2.x += in.U2.x * t; }
+                if (m1) { in.R0.y += in.U0.y * t; in.R1.y += in.U1.y * t; in.R2.y += in.U2.y * t; }
             }
-            *reinterpret_cast<double2 *>(ph.r0 + i0) = R0;
-            *reinterpret_cast<double2 *>(ph.r1 + i0) = R1;
-            *reinterpret_cast<double2 *>(ph.r2 + i0) = R2;
+            *reinterpret_cast<double2 *>(ph.r0 + i0) = in.R0;
+            *reinterpret_cast<double2 *>(ph.r1 + i0) = in.R1;
+            *reinterpret_cast<double2 *>(ph.r2 + i0) = in.R2;
         }
-
         // one Philox block serves both slots of the pair
         const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)pair, RNG_FREEPATH, key.stream);
         const uint64_t bits0 = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
         const uint64_t bits1 = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
 
-        bool q0, q1;
+        int q0, q1;
         double2 T;
-        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, FL.x, ID.x, R0.x, R1.x, R2.x, TAU.x, bits0, q0);
-        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, FL.y, ID.y, R0.y, R1.y, R2.y, TAU.y, bits1, q1);
-        *reinterpret_cast<double2 *>(ph.tts + i0) = T;
-        if ((FL.x & FLAG_VALID) && !q0) { best.offer(T.x, i0); if (T.x < t_cut) shortlist_push(sl, T.x, i0); }
-        if ((FL.y & FLAG_VALID) && !q1) { best.offer(T.y, i0 + 1); if (T.y < t_cut) shortlist_push(sl, T.y, i0 + 1); }
-
-        // ballot-compact the slots that need the slow path into the workgroup's LDS queue: one LDS atomic per wave
-        const unsigned long long m0 = __ballot(q0), m1 = __ballot(q1);
-        if (m0 | m1) {
-            const int c0 = __popcll(m0), c1 = __popcll(m1);
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&s_qn, c0 + c1);
-            base = __builtin_amdgcn_readfirstlane(base);
-            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            if (q0) s_q[base + __popcll(m0 & below)] = i0;
-            if (q1) s_q[base + c0 + __popcll(m1 & below)] = i0 + 1;
+        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0);
+        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1);
+        if constexpr (FORCE) {
+            if (q0) T.x = slow_one<DIMS, GEOM>(ph, hy, i0, true, false, iter, key, relocated, not_found);
+            if (q1) T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, true, false, iter, key, relocated, not_found);
+            q0 = q1 = 0;
+        } else {
+            // ballot-compact the slots that need the slow path into the workgroup's LDS queue (one LDS atomic
+            // per wave); if the queue is full the wave finishes its own slots in line
+            const unsigned long long m0 = __ballot(q0 != 0), m1 = __ballot(q1 != 0);
+            if (m0 | m1) {
+                const int c0 = __popcll(m0), c1 = __popcll(m1);
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_qn, c0 + c1);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base + c0 + c1 <= STEP_QCAP) {
+                    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+                    if (q0) s_q[base + __popcll(m0 & below)] = i0 | (q0 == 2 ? Q_RECALC_ONLY : 0);
+                    if (q1) s_q[base + c0 + __popcll(m1 & below)] = (i0 + 1) | (q1 == 2 ? Q_RECALC_ONLY : 0);
+                } else {
+                    if (q0) { T.x = slow_one<DIMS, GEOM>(ph, hy, i0, q0 == 1, true, iter, key, relocated, not_found); q0 = 0; }
+                    if (q1) { T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, q1 == 1, true, iter, key, relocated, not_found); q1 = 0; }
+                }
+            }
         }
+        *reinterpret_cast<double2 *>(ph.tts + i0) = T;      // queued slots: placeholder, rewritten in phase 2
+        if ((in.FL.x & FLAG_VALID) && !q0) { best.offer(T.x, i0); if (T.x < t_cut) shortlist_push(sl, T.x, i0); }
+        if ((in.FL.y & FLAG_VALID) && !q1) { best.offer(T.y, i0 + 1); if (T.y < t_cut) shortlist_push(sl, T.y, i0 + 1); }
+    };
+
+    for (int chunk = xcd_contiguous_chunk(blockIdx.x, G); chunk < nchunks; chunk += G) {
+        const int pa = chunk * STEP_BLOCK + threadIdx.x;
+        PairIn A = load_pair(ph, pa << 1, nseg > 0);
+        process(A, pa);
+    }
+
+    if constexpr (!FORCE) {
         __syncthreads();
-        const int qn = s_qn;
+        int qn = s_qn;
+        if (qn > STEP_QCAP) qn = STEP_QCAP;                  // the surplus was finished in line
+        if (MC_DIAG(DIAG_SKIP_SLOW)) qn = 0;
         for (int e = threadIdx.x; e < qn; e += STEP_BLOCK) {
-            const int i = s_q[e];
-            const double t = slow_one<DIMS, GEOM, FORCE>(ph, hy, i, iter, key, relocated, not_found);
+            const int entry = s_q[e];
+            if (entry == -1) continue;
+            const int i = entry & ~Q_RECALC_ONLY;
+            const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(entry & Q_RECALC_ONLY), true, iter, key, relocated, not_found);
             best.offer(t, i);
             if (t < t_cut) shortlist_push(sl, t, i);
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_qn = 0;
-        __syncthreads();
     }
 
     // workgroup minimum -> block_min[blockIdx.x]
@@ -401,11 +447,11 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     double p[4] = {ph.p0[i], ph.p1[i], ph.p2[i], ph.p3[i]};
     double r[3] = {ph.r0[i], ph.r1[i], ph.r2[i]};
     if (ph.flags[i] & FLAG_MOVES) {                        // the candidate's own position after mclib.c:1138
-        const double d = 1.0 / p[0];
+        const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
         for (int s = 0; s < w.nseg; ++s) {
-            r[0] += p[1] * d * C_LIGHT * w.seg[s];
-            r[1] += p[2] * d * C_LIGHT * w.seg[s];
-            r[2] += p[3] * d * C_LIGHT * w.seg[s];
+            r[0] += u0 * w.seg[s];
+            r[1] += u1 * w.seg[s];
+            r[2] += u2 * w.seg[s];
         }
     }
     const double fluid_temp = hy.temp[cell];               // mclib.c:1148
@@ -434,6 +480,10 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
         ph.s0[i] = s[0]; ph.s1[i] = s[1]; ph.s2[i] = s[2]; ph.s3[i] = s[3];
     }
     ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
+    {
+        const double d = 1.0 / p[0];                                   // mclib.c:1074-1080 factors of the new momentum
+        ph.u0[i] = p[1] * d * C_LIGHT; ph.u1[i] = p[2] * d * C_LIGHT; ph.u2[i] = p[3] * d * C_LIGHT;
+    }
     ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
     ph.r0[i] = r[0]; ph.r1[i] = r[1]; ph.r2[i] = r[2];              // already advanced: the next step kernel skips it
     ph.num_scatt[i] += 1;                                              // mclib.c:1317
@@ -572,14 +622,13 @@ __global__ __launch_bounds__(STEP_BLOCK) void flush_kernel(PhotonDev ph, const L
     const int skip = st->skip_idx;
     for (int i = blockIdx.x * STEP_BLOCK + threadIdx.x; i < ph.n; i += gridDim.x * STEP_BLOCK) {
         if ((ph.flags[i] & FLAG_MOVES) && i != skip) {
-            const double d = 1.0 / ph.p0[i];
-            const double p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
+            const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
             double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
             for (int s = 0; s < nseg; ++s) {
                 const double t = st->seg[s];
-                r0 += p1 * d * C_LIGHT * t;
-                r1 += p2 * d * C_LIGHT * t;
-                r2 += p3 * d * C_LIGHT * t;
+                r0 += u0 * t;
+                r1 += u1 * t;
+                r2 += u2 * t;
             }
             ph.r0[i] = r0; ph.r1[i] = r1; ph.r2[i] = r2;
         }
@@ -686,7 +735,14 @@ int step_grid_blocks(int n_pad)
 {
     const int pairs = n_pad / 2;
     int blocks = (pairs + STEP_BLOCK - 1) / STEP_BLOCK;
-    if (blocks > 2048) blocks = 2048;      // 256 CUs x 8 workgroups; grid-stride the rest
+    // all workgroups resident at once: every workgroup streams its chunks back to back and pays the
+    // latency-bound slow path once.  MCRAT_HIP_STEP_BLOCKS overrides the cap (tuning).
+    int cap = 768;                        // 3 workgroups per CU, all resident at the kernel's register budget
+    if (const char *e = getenv("MCRAT_HIP_STEP_BLOCKS")) { const int v = atoi(e); if (v > 0) cap = v; }
+    if (blocks > cap) {                   // balance: every workgroup gets the same number of chunks
+        const int per_block = (blocks + cap - 1) / cap;
+        blocks = (blocks + per_block - 1) / per_block;
+    }
     if (blocks < 1) blocks = 1;
     return blocks;
 }
@@ -735,6 +791,13 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
             event_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl);
     });
 }
+
+#ifdef MCRAT_DIAG
+extern "C" int mcrat_hip_diag_set(int bits)
+{
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &bits, sizeof(int)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream)
 {

@@ -71,6 +71,17 @@ __device__ __forceinline__ bool check_in_block(const HydroDev &h, int cell, doub
 // findContainingBlock, geometry.c:350-391: lowest-index cell whose closed extent holds the point, or -1.
 // The bucket lists are ascending in cell index and hold every cell whose (slightly widened) extent
 // touches the bucket, so the first hit equals the reference's linear first match.
+// Latency matters here, not bandwidth (a handful of lanes per wave walk this path): the first four list
+// entries and their cell records are fetched as two batches of independent loads instead of a
+// load -> test -> load chain.
+template <int DIMS>
+__device__ __forceinline__ bool in_cell_rec(const CellGeom &g, const CellGeom2 &g2, double a0, double a1, double a2)
+{
+    bool in = (2 * fabs(a0 - g.c0) - g.s0 <= 0) && (2 * fabs(a1 - g.c1) - g.s1 <= 0);
+    if constexpr (DIMS == DIM_THREE) in = in && (2 * fabs(a2 - g2.c2) - g2.s2 <= 0);
+    return in;
+}
+
 template <int DIMS>
 __device__ __forceinline__ int find_containing_block(const HydroDev &h, double a0, double a1, double a2)
 {
@@ -88,10 +99,30 @@ __device__ __forceinline__ int find_containing_block(const HydroDev &h, double a
         }
     }
     const int bucket = (b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0];
+    const int e0 = g.start[bucket];
     const int e1 = g.start[bucket + 1];
-    for (int e = g.start[bucket]; e < e1; ++e) {
-        const int c = g.cells[e];
-        if (check_in_block<DIMS>(h, c, a0, a1, a2)) return c;
+    const int n = e1 - e0;
+    constexpr int BATCH = 4;
+    int c[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) c[k] = (k < n) ? g.cells[e0 + k] : -1;
+    CellGeom gg[BATCH];
+    CellGeom2 gg2[BATCH];
+#pragma unroll
+    for (int k = 0; k < BATCH; ++k) {
+        const int ck = c[k] < 0 ? 0 : c[k];
+        gg[k] = h.geom[ck];
+        if constexpr (DIMS == DIM_THREE) gg2[k] = h.geom2[ck];
+        else { gg2[k].c2 = 0; gg2[k].s2 = 0; }
+    }
+    int found = -1;
+#pragma unroll
+    for (int k = BATCH - 1; k >= 0; --k)
+        if (c[k] >= 0 && in_cell_rec<DIMS>(gg[k], gg2[k], a0, a1, a2)) found = c[k];
+    if (found >= 0 || n <= BATCH) return found;
+    for (int e = e0 + BATCH; e < e1; ++e) {
+        const int cc = g.cells[e];
+        if (check_in_block<DIMS>(h, cc, a0, a1, a2)) return cc;
     }
     return -1;
 }

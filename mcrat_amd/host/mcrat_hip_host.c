@@ -1,0 +1,135 @@
+/* mcrat_hip_host.c -- see mcrat_hip_host.h.  Plain C99, no photon physics on the CPU. */
+#include "mcrat_hip_host.h"
+
+#include <ctype.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* next line that carries values: skips blank lines and "[Block]" headers, cuts the trailing "# comment" */
+static int next_value_line(FILE *f, char *buf, size_t n)
+{
+    while (fgets(buf, (int)n, f)) {
+        char *hash = strchr(buf, '#');
+        if (hash) *hash = '\0';
+        char *p = buf;
+        while (*p && isspace((unsigned char)*p)) p++;
+        if (*p == '\0' || *p == '[') continue;
+        memmove(buf, p, strlen(p) + 1);
+        return 1;
+    }
+    return 0;
+}
+
+static int parse_doubles(char *line, double *out, int n)
+{
+    char *save = NULL;
+    int k = 0;
+    for (char *tok = strtok_r(line, " \t\r\n", &save); tok && k < n; tok = strtok_r(NULL, " \t\r\n", &save)) {
+        char *end;
+        out[k] = strtod(tok, &end);
+        if (end == tok) return k;
+        k++;
+    }
+    return k;
+}
+
+int mcrat_host_read_mcpar(const char *path, mcrat_host_mcpar *out)
+{
+    char buf[2000];
+    double v[64];
+    if (!path || !out) return -2;
+    memset(out, 0, sizeof *out);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int rc = -2;
+    do {
+        /* [Hydro/MHD Simulation Block]  mcrat_io.c:1151-1166 */
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, 1) != 1) break;
+        out->fps = v[0];
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, 1) != 1) break;
+        out->last_frame = (int)v[0];
+        double *dom[3] = {out->r0_domain, out->r1_domain, out->r2_domain};
+        int ok = 1;
+        for (int a = 0; a < 3 && ok; a++) {
+            ok = next_value_line(f, buf, sizeof buf) && parse_doubles(buf, v, 2) == 2;
+            if (ok) { dom[a][0] = v[0]; dom[a][1] = v[1]; }
+        }
+        if (!ok) break;
+        /* [MCRaT Injection Angles Block]  :1168-1216 */
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, 1) != 1) break;
+        out->theta_jmin = v[0];
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, 1) != 1) break;
+        out->theta_j = v[0];
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, 1) != 1) break;
+        out->n_theta_j = (int)v[0];
+        const int nb = out->n_theta_j;
+        if (nb < 1 || nb > 64) break;
+        out->frm0 = (int *)malloc(sizeof(int) * nb);
+        out->frm2 = (int *)malloc(sizeof(int) * nb);
+        out->inj_radius = (double *)malloc(sizeof(double) * nb);
+        if (!out->frm0 || !out->frm2 || !out->inj_radius) break;
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, nb) != nb) break;
+        for (int i = 0; i < nb; i++) out->frm0[i] = (int)v[i];
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, nb) != nb) break;
+        for (int i = 0; i < nb; i++) out->frm2[i] = (int)v[i] + out->frm0[i];     /* number of frames -> last frame, :1201 */
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, nb) != nb) break;
+        for (int i = 0; i < nb; i++) out->inj_radius[i] = (double)(float)v[i];    /* strtof in the reference, :1211 */
+        /* [MCRaT Photon Block]  :1218-1227 */
+        if (!next_value_line(f, buf, sizeof buf)) break;
+        out->spect = buf[0];
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, 1) != 1) break;
+        out->min_photons = (int)v[0];
+        if (!next_value_line(f, buf, sizeof buf) || parse_doubles(buf, v, 1) != 1) break;
+        out->max_photons = (int)v[0];
+        /* [Initialization/Continuation Block]  :1229-1233 */
+        if (!next_value_line(f, buf, sizeof buf)) break;
+        out->restart = buf[0];
+        if ((out->spect != 'b' && out->spect != 'w') || (out->restart != 'i' && out->restart != 'c')) break;
+        rc = 0;
+    } while (0);
+    fclose(f);
+    if (rc != 0) mcrat_host_free_mcpar(out);
+    return rc;
+}
+
+void mcrat_host_free_mcpar(mcrat_host_mcpar *p)
+{
+    if (!p) return;
+    free(p->frm0); free(p->frm2); free(p->inj_radius);
+    p->frm0 = p->frm2 = NULL;
+    p->inj_radius = NULL;
+}
+
+int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, const mcrat_hip_hydro *hydro,
+                             double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
+                             uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats)
+{
+    mcrat_hip_frame_stats st;
+    int rc, max_scatt = 0, min_scatt = 0;
+    double avg_scatt = 0, avg_r = 0;
+    if (!ctx || !list || !hydro || !time_now || !(fps > 0)) return MCRAT_HIP_EINVAL;
+
+    if ((rc = mcrat_hip_set_hydro(ctx, hydro)) != 0) return rc;          /* after getHydroData, mcrat.c:721 */
+    if ((rc = mcrat_hip_set_photons(ctx, list)) != 0) return rc;
+
+    /* mcrat.c:758: time left in this hydro frame */
+    const double remaining_time = ((scatt_frame + increment_scatt_frame) / fps) - *time_now;
+    if ((rc = mcrat_hip_propagate_frame(ctx, time_now, remaining_time, seed, &st)) != 0) return rc;   /* mcrat.c:761-851 */
+
+    if ((rc = mcrat_hip_scatt_stats(ctx, &max_scatt, &min_scatt, &avg_scatt, &avg_r)) != 0) return rc;  /* mcrat.c:881 */
+    if ((rc = mcrat_hip_get_photons(ctx, list)) != 0) return rc;          /* before saveCheckpoint/printPhotons, mcrat.c:902-907 */
+
+    if (fPtr) {                                                           /* mcrat.c:883-890, same wording */
+        fprintf(fPtr, "The number of scatterings in this frame is: %d\n", (int)st.frame_scatt_cnt);
+        fprintf(fPtr, "The last time step was: %e.\nThe time now is: %e\n", st.last_time_step, *time_now);
+        fprintf(fPtr, "MCRaT had to refind the position of photons %d times in this frame.\n", (int)st.num_photons_find_new_element);
+        fprintf(fPtr, "The maximum number of scatterings for a photon is: %d\nThe minimum number of scatterings for a photon is: %d\n",
+                max_scatt, min_scatt);
+        fprintf(fPtr, "The average number of scatterings thus far is: %lf\nThe average position of photons is %e\n", avg_scatt, avg_r);
+        for (long long k = 0; k < st.not_found; k++)                      /* mclib.c:583, one line per event (index not kept) */
+            fprintf(fPtr, "Photon Hydro grid index not found, making sure it doesnt scatter.\n");
+        fflush(fPtr);
+    }
+    if (stats) *stats = st;
+    return MCRAT_HIP_OK;
+}

@@ -1,0 +1,57 @@
+/*
+ * mcrat_hip_host.h -- host-side C (gcc) on top of the C ABI of include/mcrat_hip.h.
+ *
+ * MCRaT's host code is C and stays C (BASELINE.json north_star): this file mirrors, for the accelerated path,
+ * the pieces of the reference's driver a maintainer would otherwise have to re-type:
+ *   - mcrat_host_scatter_frame(): the body of the scatter-frame loop of Src/mcrat.c:754-892 -- remaining_time
+ *     bookkeeping (:758), the while loop (:761-851, now one library call), phScattStats (:881) and the log
+ *     lines of :883-890, byte for byte in the reference's format;
+ *   - mcrat_host_read_mcpar(): the positional mc.par grammar of readMcPar (Src/mcrat_io.c:1136-1237), so the
+ *     run-size surface stays compatible (fps, last frame, domains, angle bins, spectrum, photon counts, i/c).
+ * It links against libmcrat_hip.so only; nothing here computes photon physics on the CPU.
+ */
+#ifndef MCRAT_HIP_HOST_H
+#define MCRAT_HIP_HOST_H
+
+#include <stdio.h>
+#include "mcrat_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* what readMcPar fills (Src/mcrat_io.c:1136): block 1 into hydro_dataframe, the rest into main()'s locals */
+typedef struct mcrat_host_mcpar {
+    double fps;
+    int    last_frame;
+    double r0_domain[2], r1_domain[2], r2_domain[2];
+    double theta_jmin, theta_j;      /* degrees, as the reference keeps them */
+    int    n_theta_j;
+    int   *frm0;                     /* [n_theta_j] first injection frame per angle bin                */
+    int   *frm2;                     /* [n_theta_j] frm0 + number of frames (mcrat_io.c:1201)          */
+    double *inj_radius;              /* [n_theta_j]                                                    */
+    char   spect;                    /* 'b' or 'w'                                                     */
+    int    min_photons, max_photons;
+    char   restart;                  /* 'i' or 'c'                                                     */
+} mcrat_host_mcpar;
+
+/* 0 on success, -1 if the file cannot be opened, -2 on a malformed file */
+int  mcrat_host_read_mcpar(const char *path, mcrat_host_mcpar *out);
+void mcrat_host_free_mcpar(mcrat_host_mcpar *p);
+
+/* One scatter frame on the device (replaces Src/mcrat.c:754-892 between getHydroData and saveCheckpoint).
+ *   list       caller-owned photon list; uploaded, propagated, downloaded in place
+ *   hydro      the frame getHydroData just produced
+ *   time_now   in/out, as in main()
+ *   scatt_frame, increment_scatt_frame, fps   give remaining_time = (scatt_frame+increment)/fps - time_now (:758)
+ *   seed       per-frame seed (the reference reseeds with gsl_rng_get at :701; pass that value)
+ *   fPtr       the rank's log file (may be NULL)
+ * Returns 0 or a negative MCRAT_HIP_E* code; *stats (may be NULL) receives the loop statistics. */
+int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, const mcrat_hip_hydro *hydro,
+                             double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
+                             uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

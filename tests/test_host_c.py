@@ -1,0 +1,140 @@
+"""Host-side C mirror (mcrat_amd/host): mc.par grammar and the scatter-frame driver."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the reference's sample_mc.par content is restated here as the grammar's known-answer case
+# (same positional layout as /root/reference/sample_mc.par; values chosen for the test)
+SAMPLE = """[Hydro/MHD Simulation Block]
+
+5.               # Number of frames per second of hydro simulation
+3000\t\t# Last available hydro simulation frame
+0 5e12\t\t# Max r0 coordinate limits of hydro simulation
+0 2.5e12\t\t# Max r1 coordinate limit of hydro simulation
+0 2e13\t\t# Max r2 coordinate limit of hydro simulation (if simulation is 3D)
+
+[MCRaT Injection Angles Block]
+
+0.               \t# The minimum off-axis angle to inject photons (in degrees)
+6.               \t# The maximum off-axis angle to inject photons (in degrees)
+3.\t\t\t# Number of angle bins to consider
+200 210 220      \t# Frame at which photon injection starts for each angle bin
+2 3 4            \t# Number of frames for which photons are injected for each angle bin
+1e11 1.5e12 2e12\t# The radius at which the photons are injected for each angle bin
+
+[MCRaT Photon Block]
+
+b\t\t# Type of spectrum we inject with, w=wien b=blackbody
+1000\t\t# Min number of photons
+5000\t\t# Max number of photons
+
+[Initialization/Continuation Block]
+
+i\t\t# Initialize or continue simulation (i=initialize (delete all files) c=continue)
+"""
+
+
+class McPar(C.Structure):
+    _fields_ = [("fps", C.c_double), ("last_frame", C.c_int),
+                ("r0_domain", C.c_double * 2), ("r1_domain", C.c_double * 2), ("r2_domain", C.c_double * 2),
+                ("theta_jmin", C.c_double), ("theta_j", C.c_double), ("n_theta_j", C.c_int),
+                ("frm0", C.POINTER(C.c_int)), ("frm2", C.POINTER(C.c_int)), ("inj_radius", C.POINTER(C.c_double)),
+                ("spect", C.c_char), ("min_photons", C.c_int), ("max_photons", C.c_int), ("restart", C.c_char)]
+
+
+@pytest.fixture(scope="module")
+def host():
+    from mcrat_amd import build
+    from mcrat_amd.host import build_host
+    build.build()
+    lib = C.CDLL(build_host.build())
+    lib.mcrat_host_read_mcpar.restype = C.c_int
+    lib.mcrat_host_read_mcpar.argtypes = [C.c_char_p, C.POINTER(McPar)]
+    lib.mcrat_host_free_mcpar.argtypes = [C.POINTER(McPar)]
+    return lib
+
+
+def test_mcpar_grammar(host, tmp_path):
+    path = tmp_path / "mc.par"
+    path.write_text(SAMPLE)
+    p = McPar()
+    assert host.mcrat_host_read_mcpar(str(path).encode(), C.byref(p)) == 0
+    assert p.fps == 5.0 and p.last_frame == 3000
+    assert list(p.r0_domain) == [0.0, 5e12] and list(p.r1_domain) == [0.0, 2.5e12] and list(p.r2_domain) == [0.0, 2e13]
+    assert (p.theta_jmin, p.theta_j, p.n_theta_j) == (0.0, 6.0, 3)
+    assert [p.frm0[i] for i in range(3)] == [200, 210, 220]
+    assert [p.frm2[i] for i in range(3)] == [202, 213, 224]          # start + number of frames, mcrat_io.c:1201
+    assert [p.inj_radius[i] for i in range(3)] == [float(np.float32(1e11)), float(np.float32(1.5e12)), float(np.float32(2e12))]
+    assert (p.spect, p.min_photons, p.max_photons, p.restart) == (b"b", 1000, 5000, b"i")
+    host.mcrat_host_free_mcpar(C.byref(p))
+    # errors are codes, not crashes (the reference dereferences a NULL FILE* on a missing file)
+    assert host.mcrat_host_read_mcpar(str(tmp_path / "absent.par").encode(), C.byref(p)) == -1
+    (tmp_path / "bad.par").write_text(SAMPLE.replace("5000", "").replace("\nb\t", "\nx\t"))
+    assert host.mcrat_host_read_mcpar(str(tmp_path / "bad.par").encode(), C.byref(p)) == -2
+
+
+def test_reference_sample_file_parses_if_present(host):
+    ref = "/root/reference/sample_mc.par"          # not present on the GPU box; read as data, not imported
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not mounted here")
+    p = McPar()
+    assert host.mcrat_host_read_mcpar(ref.encode(), C.byref(p)) == 0
+    assert p.fps == 5.0 and p.last_frame == 3000 and p.n_theta_j == 3 and p.min_photons == 1000 and p.max_photons == 5000
+    assert [p.frm2[i] - p.frm0[i] for i in range(3)] == [2, 2, 2]
+    host.mcrat_host_free_mcpar(C.byref(p))
+
+
+@pytest.mark.gpu
+def test_scatter_frame_driver_matches_engine_and_logs_like_the_reference(host, tmp_path):
+    from mcrat_amd import engine
+    frame, ph, cfg = synth.config1(n_photons=400, n0=16, n1=16)
+    fps, scatt_frame, time_now, seed = 400.0, 7, 7.0 / 400.0, 99        # a 2.5 ms frame: a few hundred events
+    frame["fps"] = fps
+    e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    tn, st = e.propagate_frame(time_now, (scatt_frame + 1) / fps - time_now, seed)
+    want = e.get_photons_aos()
+
+    # the same frame through the C driver on caller-owned struct photon records
+    e2 = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    aos = synth.photons_to_aos(ph, engine.PHOTON_DTYPE)
+    plist = engine.PhotonList(aos.ctypes.data, None, len(aos), 0, len(aos))
+    keep, h = [], engine.Hydro()
+    h.num_elements = frame["num_elements"]
+    for f in ("r0", "r1", "r0_size", "r1_size", "v0", "v1", "dens_lab", "temp", "gamma"):
+        a = np.ascontiguousarray(frame[f], dtype=np.float64)
+        keep.append(a)
+        setattr(h, f, a.ctypes.data_as(C.POINTER(C.c_double)))
+    for k in ("r0_domain", "r1_domain"):
+        getattr(h, k)[0], getattr(h, k)[1] = frame[k]
+    h.fps = fps
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    log = tmp_path / "mc_output_0.log"
+    fp = libc.fopen(str(log).encode(), b"a")
+    host.mcrat_host_scatter_frame.restype = C.c_int
+    host.mcrat_host_scatter_frame.argtypes = [C.c_void_p, C.POINTER(engine.PhotonList), C.POINTER(engine.Hydro), C.POINTER(C.c_double),
+                                              C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_void_p, C.POINTER(engine.FrameStats)]
+    t = C.c_double(time_now)
+    st2 = engine.FrameStats()
+    rc = host.mcrat_host_scatter_frame(e2.ctx, C.byref(plist), C.byref(h), C.byref(t), scatt_frame, 1, fps, seed, fp, C.byref(st2))
+    libc.fclose(fp)
+    assert rc == 0
+    assert t.value == tn == pytest.approx((scatt_frame + 1) / fps, rel=1e-13)
+    assert st2.frame_scatt_cnt == st.frame_scatt_cnt > 50 and st2.iterations == st.iterations
+    for k in aos.dtype.names:
+        assert np.array_equal(aos[k], want[k]), k
+    text = log.read_text()
+    assert "The number of scatterings in this frame is: %d\n" % st.frame_scatt_cnt in text
+    assert "MCRaT had to refind the position of photons %d times in this frame.\n" % st.num_photons_find_new_element in text
+    assert "The maximum number of scatterings for a photon is: %d\n" % int(want["num_scatt"].max()) in text
+    assert "The average number of scatterings thus far is: %f\n" % want["num_scatt"].mean() in text
