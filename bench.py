@@ -31,6 +31,20 @@ ALGORITHMIC_BYTES_PER_PHOTON_STEP = 110      # SURVEY.md section 8(d) / BASELINE
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def committed_traffic():
+    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/*_step_kernel_pmc.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as the gfx950 note of
+    MI355X_MICROARCH.md prescribes).  bench.py itself does not run under the profiler, so this is the latest
+    committed measurement of the same kernel on the same workload, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_step_kernel_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("traffic_bytes_per_launch"), os.path.basename(files[-1])
+
+
 def cpu_baseline(frame, ph, cfg, seed, n_sample, iters):
     """The oracle (oracle/, plain-C restatement of the reference: 176-B AoS photons, full redraw and full
     qsort_r argsort per event, linear cell search, one thread) on a bounded sample of the same workload."""
@@ -163,9 +177,10 @@ def main():
         avg_ms = (ps.step_kernel_ms - p0.step_kernel_ms) / max(1, launches)
         ev_ms = (ps.event_kernel_ms - p0.event_kernel_ms) / max(1, launches)
         achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * n / (avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic() if (n == 1_000_000 and args.nzc == 64) else (None, None)
         roof = {
             "kernel": "step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "bytes_per_launch": ALGORITHMIC_BYTES_PER_PHOTON_STEP * n,
             "avg_launch_ms": avg_ms, "launches": int(launches), "event_kernel_avg_ms": ev_ms,
         }
