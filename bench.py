@@ -1,21 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py -- the photon loop on the BASELINE.json workload.
+"""bench.py -- MCRaT's photon loop on the BASELINE.json workload (configs[1]).
 
-    python bench.py --gpus 1 --steps 2000 --warmup 50
+    python bench.py                                   # 1 GPU, defaults
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A *step* is one pass of MCRaT's `while (remaining_time > 0)` body (Src/mcrat.c:761-851) over the
-whole photon list: re-locate every photon, draw every free path, pick the earliest, advance all, scatter
-one -- i.e. one launch of the step kernel + one of the event kernel.  Workload: configs[1] of
-BASELINE.json (synthetic 2-D FLASH-like cylindrical GRB-jet frame, 1 048 576 cells, 1e6 photons),
-photons and hydro frame resident in HBM before the timed region.
+Workload: synthetic 2-D FLASH-like cylindrical GRB-jet frame (16 384 leaf blocks = 1 048 576 cells, Lundman
+structured jet), 10^6 photons per GPU, Compton + Klein-Nishina, photons and frame resident in HBM before the
+timed region.  Two run shapes of the same loop (Src/mcrat.c:761-851):
 
-Prints ONE JSON line (rank 0).  `value` = scatter events per second over all ranks; the same line carries
-photon-steps/s (slots x iterations / s, the quantity the HBM roofline is priced on), the roofline object
-of the step kernel and the CPU baseline (oracle = faithful restatement of the reference's algorithm,
-timed on this box's host cores on a bounded sample).
+  --mode ranks (default)  the 10^6 photons are `--rank-photons`-sized independent photon lists ("virtual ranks"),
+                          each with its own clock and RNG stream -- how MCRaT is actually run (10^3 - 5*10^3
+                          photons per MPI rank, Doc/mcrat_doc.tex:165-166,222).  One workgroup runs one list's
+                          whole loop in one launch.  A *step* is one hydro frame (1/fps) for all lists; every
+                          step starts from the same resident photon snapshot (device-to-device restore, inside
+                          the timed region) with a fresh seed.
+  --mode list             ONE list of 10^6 photons with one clock: every loop pass sweeps all photons
+                          (step kernel, HBM-bound) and scatters one.  A *step* is one pass.  This is the shape
+                          the HBM roofline is priced on.
+
+Prints ONE JSON line (rank 0): `value` = scatter events per second of the selected mode (whole job), plus
+photon-steps/s, the roofline object of that mode's dominant kernel, a short measurement of the other mode, and
+the CPU baseline (oracle/ = faithful C restatement of the reference, one host core, bounded sample, same shape).
 """
+
 import argparse
+import glob
 import json
 import os
 import sys
@@ -29,15 +38,14 @@ import numpy as np  # noqa: E402
 
 ALGORITHMIC_BYTES_PER_PHOTON_STEP = 110      # SURVEY.md section 8(d) / BASELINE.md section 2
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+SEED = 0x4D435261
 
 
-def committed_traffic():
-    """HBM bytes per step-kernel launch from the committed rocprofv3 PMC passes (profiles/*_step_kernel_pmc.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as the gfx950 note of
-    MI355X_MICROARCH.md prescribes).  bench.py itself does not run under the profiler, so this is the latest
-    committed measurement of the same kernel on the same workload, or None."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_step_kernel_pmc.json")))
+def committed_traffic(pattern):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<pattern>: FETCH_SIZE and WRITE_SIZE
+    in separate passes, FETCH_SIZE doubled as the gfx950 note of MI355X_MICROARCH.md prescribes).  bench.py does
+    not run under the profiler, so this is the latest committed measurement of the same kernel and workload."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
         return None, None
     with open(files[-1]) as f:
@@ -45,62 +53,80 @@ def committed_traffic():
     return d.get("traffic_bytes_per_launch"), os.path.basename(files[-1])
 
 
-def cpu_baseline(frame, ph, cfg, seed, n_sample, iters):
-    """The oracle (oracle/, plain-C restatement of the reference: 176-B AoS photons, full redraw and full
-    qsort_r argsort per event, linear cell search, one thread) on a bounded sample of the same workload."""
+def sub_photons(ph, lo, hi):
+    return {k: (v[lo:hi].copy() if isinstance(v, np.ndarray) else v) for k, v in ph.items()}
+
+
+def cpu_baseline_list(frame, ph, cfg, n_sample, iters):
+    """one list: first n_sample photons, `iters` passes timed after the forced O(N*M) re-location pass"""
     from mcrat_amd import synth
     from oracle import oracle_py as O
-    sub = {k: (v[:n_sample].copy() if isinstance(v, np.ndarray) else v) for k, v in ph.items()}
     H = O.OracleHydro(frame)
-    P = O.OraclePhotons(synth.photons_to_aos(sub, O.PHOTON_DTYPE))
+    P = O.OraclePhotons(synth.photons_to_aos(sub_photons(ph, 0, n_sample), O.PHOTON_DTYPE))
     c = O.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
     rem = 1.0 / frame["fps"]
     t0 = time.perf_counter()
-    st1, tn, rem, sw = O.photon_loop(c, P, H, seed=seed, time_now=0.0, remaining_time=rem, max_iterations=1)
+    st1, tn, rem, sw = O.photon_loop(c, P, H, seed=SEED, time_now=0.0, remaining_time=rem, max_iterations=1)
     t1 = time.perf_counter()
-    # the jet is optically thin: with a few thousand photons a frame holds only a handful of events, so the
-    # sample keeps iterating on the frozen frame (remaining_time re-armed) until `iters` passes are timed
     done, scatt, base = 0, 0, 1
-    while done < iters:
+    while done < iters:            # the jet is thin: re-arm the frame time so that `iters` passes can be timed
         if rem <= 0:
             rem = 1.0 / frame["fps"]
-        st, tn, rem, sw = O.photon_loop(c, P, H, seed=seed, time_now=tn, remaining_time=rem,
+        st, tn, rem, sw = O.photon_loop(c, P, H, seed=SEED, time_now=tn, remaining_time=rem,
                                         max_iterations=iters - done, iteration_base=base, find_switch=sw)
         done += st.iterations
         base += st.iterations
         scatt += st.frame_scatt_cnt
         if st.iterations == 0:
             break
-    t2 = time.perf_counter()
-    dt = t2 - t1
-    return {
-        "value": scatt / dt,
-        "unit": "scatter-events/s",
-        "cores": 1,
-        "kind": "port",
-        "photon_steps_per_s": n_sample * done / dt,
-        "first_pass_s": t1 - t0,
-        "sample": ("oracle/ (faithful C restatement; reference itself needs GSL and cannot be built here), 1 thread: "
-                   "first %d photons of the same photon set on the same %d-cell frame, %d loop iterations timed after "
-                   "the forced O(N*M) re-location pass (that pass alone took first_pass_s); per-event cost grows as "
-                   "N log N, compare photon_steps_per_s" % (n_sample, frame["num_elements"], done)),
-    }
+    dt = time.perf_counter() - t1
+    return {"value": scatt / dt, "unit": "scatter-events/s", "cores": 1, "kind": "port",
+            "photon_steps_per_s": n_sample * done / dt, "first_pass_s": t1 - t0,
+            "sample": ("oracle/ (faithful C restatement; the reference needs GSL and cannot be built here), 1 thread, one list of "
+                       "the first %d photons on the same %d-cell frame: %d loop passes timed after the forced O(N*M) "
+                       "re-location pass (first_pass_s)" % (n_sample, frame["num_elements"], done))}
+
+
+def cpu_baseline_ranks(frame, ph, cfg, per, n_ranks):
+    """virtual ranks: the first n_ranks lists of `per` photons, one whole frame each, one after the other on one core
+    -- what one MPI rank of the reference does per frame, forced re-location pass included"""
+    from mcrat_amd import synth
+    from oracle import oracle_py as O
+    H = O.OracleHydro(frame)
+    c = O.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    scatt = steps = 0
+    t0 = time.perf_counter()
+    for r in range(n_ranks):
+        P = O.OraclePhotons(synth.photons_to_aos(sub_photons(ph, r * per, (r + 1) * per), O.PHOTON_DTYPE))
+        st, _, _, _ = O.photon_loop(c, P, H, seed=SEED, time_now=0.0, remaining_time=1.0 / frame["fps"], stream=r)
+        scatt += st.frame_scatt_cnt
+        steps += st.photon_steps
+    dt = time.perf_counter() - t0
+    return {"value": scatt / dt, "unit": "scatter-events/s", "cores": 1, "kind": "port",
+            "photon_steps_per_s": steps / dt, "seconds_per_rank_frame": dt / n_ranks,
+            "sample": ("oracle/ (faithful C restatement; the reference needs GSL and cannot be built here), 1 thread: the first %d "
+                       "virtual ranks of %d photons each, one whole frame (1/fps) per rank on the same %d-cell frame, "
+                       "including each rank's forced O(n*M) re-location pass; the reference scales by running one such rank "
+                       "per core" % (n_ranks, per, frame["num_elements"]))}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--mode", choices=("ranks", "list"), default="ranks")
+    ap.add_argument("--steps", type=int, default=0, help="ranks: frames (default 20); list: loop passes (default 2000)")
+    ap.add_argument("--warmup", type=int, default=-1, help="ranks: frames (default 2); list: passes (default 50)")
     ap.add_argument("--photons", type=int, default=1_000_000, help="photon slots per GPU")
+    ap.add_argument("--rank-photons", type=int, default=1000, help="photons per virtual rank (ranks mode)")
     ap.add_argument("--nzc", type=int, default=64, help="mesh scale: 64 -> 1 048 576 cells")
     ap.add_argument("--stokes", type=int, default=0)
     ap.add_argument("--graph", type=int, default=1)
-    ap.add_argument("--profile-steps", type=int, default=300)
-    ap.add_argument("--cpu-photons", type=int, default=1024)
-    ap.add_argument("--cpu-steps", type=int, default=300)
+    ap.add_argument("--profile-steps", type=int, default=300, help="list-mode passes bracketed by HIP events for the roofline")
+    ap.add_argument("--other-mode", type=int, default=1, help="also measure the other run shape briefly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    steps = args.steps if args.steps > 0 else (20 if args.mode == "ranks" else 2000)
+    warmup = args.warmup if args.warmup >= 0 else (2 if args.mode == "ranks" else 50)
 
     import torch
     from mcrat_amd import engine, synth
@@ -120,19 +146,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    # ---- workload: every rank owns an independent photon set on a replica of the frame (weak scaling;
-    # the reference's ranks own disjoint photons and never talk during the loop)
-    seed = 0x4D435261
-    frame, ph, cfg = synth.config2(n_photons=args.photons, seed=seed + rank, nzc=args.nzc, stokes=args.stokes)
+    # every GPU owns an independent photon set on a replica of the frame (weak scaling): the reference's ranks own
+    # disjoint photons and never talk during the loop -- no data-path collective
+    frame, ph, cfg = synth.config2(n_photons=args.photons, seed=SEED + rank, nzc=args.nzc, stokes=args.stokes)
     n = int(ph["p0"].size)
-    per_sync = max(50, min(500, args.steps))
-    stream = torch.cuda.current_stream().cuda_stream
-    eng = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
-                        rng_stream=rank, iterations_per_sync=per_sync, use_graph=bool(args.graph))
-    eng.set_hydro(frame)
-    eng.set_photons(ph)
     remaining = 1.0 / frame["fps"]
-    eng.begin_frame(seed, 0.0, remaining)
+    stream = torch.cuda.current_stream().cuda_stream
+    first_stream = rank * 100000           # RNG streams of this GPU's virtual ranks
 
     def sync():
         torch.cuda.synchronize()
@@ -140,80 +160,173 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    w = eng.run(args.warmup) if args.warmup > 0 else None      # includes the forced re-location pass
-    it0 = w.iterations if w else 0
-    sc0 = w.frame_scatt_cnt if w else 0
-    sync()
-    t0 = time.perf_counter()
-    st = eng.run(args.steps)
-    sync()
-    dt = time.perf_counter() - t0
-    steps_done = st.iterations - it0
-    scatt = st.frame_scatt_cnt - sc0
-    if steps_done != args.steps:
-        raise SystemExit("the frame ended after %d of %d timed steps; lower --steps" % (steps_done, args.steps))
+    def make_engine(mode, profile=False, per_sync=None):
+        if mode == "ranks":
+            e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
+                              rng_stream=first_stream, virtual_rank_photons=args.rank_photons, profile=profile)
+        else:
+            e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
+                              rng_stream=first_stream, iterations_per_sync=per_sync or 500, use_graph=bool(args.graph),
+                              profile=profile)
+        e.set_hydro(frame)
+        e.set_photons(ph)
+        return e
 
-    t_max, scatt_all, slots_all = dt, scatt, n
+    def run_ranks(e, k_frames, seed0):
+        """k_frames frames, each from the resident snapshot with its own seed -> (events, photon_steps, passes)"""
+        ev = ps = it = 0
+        for k in range(k_frames):
+            e.restore_photons()
+            e.begin_frame(seed0 + k, 0.0, remaining)
+            st = e.run(0)
+            ev += st.frame_scatt_cnt
+            ps += st.photon_steps
+            it += st.iterations
+        return ev, ps, it
+
+    def measure_ranks(k_frames, k_warm, with_roofline):
+        e = make_engine("ranks")
+        e.snapshot_photons()
+        run_ranks(e, k_warm, SEED + 1000)
+        sync()
+        t0 = time.perf_counter()
+        ev, ps, it = run_ranks(e, k_frames, SEED)
+        sync()
+        dt = time.perf_counter() - t0
+        nr = e.num_virtual_ranks()
+        e.close()
+        roof = None
+        if with_roofline:
+            # rank_loop_kernel between HIP events (one launch per frame here); algorithmic bytes = 110 B x the
+            # photon-steps that launch performed
+            p = make_engine("ranks", profile=True)
+            p.snapshot_photons()
+            ms = psteps = launches = 0
+            for k in range(5):
+                p.restore_photons()
+                p.begin_frame(SEED + 5000 + k, 0.0, remaining)
+                st = p.run(0)
+                ms += st.step_kernel_ms
+                launches += st.step_kernel_launches
+                psteps += st.photon_steps
+            p.close()
+            launch_ms = ms / max(1, launches)
+            bytes_per_launch = ALGORITHMIC_BYTES_PER_PHOTON_STEP * psteps / max(1, launches)
+            achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
+            full = (n == 1_000_000 and args.nzc == 64 and args.rank_photons == 1000)
+            traffic, src = committed_traffic("*_rank_loop_kernel_pmc.json") if full else (None, None)
+            roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches),
+                    "note": "latency-bound persistent kernel (one workgroup walks one list's whole frame; the forced "
+                            "re-location pass of the new frame is inside the launch); the HBM-bound kernel of this path is "
+                            "step_kernel, see other_mode.roofline"}
+        return dict(events=ev, photon_steps=ps, passes=it, seconds=dt, ranks=nr, roofline=roof)
+
+    def measure_list(k_steps, k_warm, prof_steps):
+        e = make_engine("list", per_sync=max(50, min(500, k_steps)))
+        e.begin_frame(SEED, 0.0, remaining)
+        w = e.run(k_warm) if k_warm > 0 else None          # includes the forced re-location pass
+        it0, sc0 = (w.iterations, w.frame_scatt_cnt) if w else (0, 0)
+        rel0 = w.num_photons_find_new_element if w else 0
+        sync()
+        t0 = time.perf_counter()
+        st = e.run(k_steps)
+        sync()
+        dt = time.perf_counter() - t0
+        if st.iterations - it0 != k_steps:
+            raise SystemExit("the frame ended after %d of %d timed passes; lower --steps" % (st.iterations - it0, k_steps))
+        roof = None
+        if prof_steps > 0:
+            # the step kernel's launches bracketed by HIP events, in a separate pass that continues the same frame
+            p = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
+                              rng_stream=first_stream, iterations_per_sync=min(500, prof_steps), profile=True)
+            p.set_hydro(frame)
+            p.set_photons(e.get_photons())
+            p.begin_frame(SEED + 1, 0.0, remaining)
+            p.step_locate_sample(0)      # the photons are already located: skip the forced pass
+            p0 = p.run(20)
+            ps = p.run(prof_steps)
+            launches = ps.step_kernel_launches - p0.step_kernel_launches
+            avg_ms = (ps.step_kernel_ms - p0.step_kernel_ms) / max(1, launches)
+            ev_ms = (ps.event_kernel_ms - p0.event_kernel_ms) / max(1, launches)
+            achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * n / (avg_ms * 1e-3) / 1e9
+            traffic, src = committed_traffic("*_step_kernel_pmc.json") if (n == 1_000_000 and args.nzc == 64) else (None, None)
+            roof = {"kernel": "step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                    "bytes_per_launch": ALGORITHMIC_BYTES_PER_PHOTON_STEP * n, "avg_launch_ms": avg_ms,
+                    "launches": int(launches), "event_kernel_avg_ms": ev_ms}
+            p.close()
+        e.close()
+        return dict(events=st.frame_scatt_cnt - sc0, photon_steps=n * k_steps, passes=k_steps, seconds=dt, roofline=roof,
+                    relocations_per_pass=(st.num_photons_find_new_element - rel0) / k_steps,
+                    kn_rejections=st.kn_rejections, rescans=st.rescans)
+
+    if args.mode == "ranks":
+        main_res = measure_ranks(steps, warmup, rank == 0)
+    else:
+        main_res = measure_list(steps, warmup, args.profile_steps if rank == 0 else 0)
+
+    t_max, events_all, steps_all = main_res["seconds"], float(main_res["events"]), float(main_res["photon_steps"])
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([t_max], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c = torch.tensor([float(scatt), float(n)], dtype=torch.float64, device="cuda")
+        c = torch.tensor([events_all, steps_all], dtype=torch.float64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        t_max, scatt_all, slots_all = float(t.item()), float(c[0].item()), float(c[1].item())
+        t_max, events_all, steps_all = float(t.item()), float(c[0].item()), float(c[1].item())
 
-    # ---- roofline of the step kernel: its launches bracketed by HIP events on the engine's stream, in a
-    # separate pass that continues the same frame (event records perturb the timed region, so they are not in it)
-    roof = None
-    if rank == 0 and args.profile_steps > 0:
-        prof = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
-                             rng_stream=rank, iterations_per_sync=min(per_sync, args.profile_steps), profile=True)
-        prof.set_hydro(frame)
-        prof.set_photons(eng.get_photons())
-        prof.begin_frame(seed + 1, 0.0, remaining)
-        prof.step_locate_sample(0)       # the photons are already located: skip the forced re-location pass
-        p0 = prof.run(20)                # warm caches; not counted
-        ps = prof.run(args.profile_steps)
-        launches = ps.step_kernel_launches - p0.step_kernel_launches
-        avg_ms = (ps.step_kernel_ms - p0.step_kernel_ms) / max(1, launches)
-        ev_ms = (ps.event_kernel_ms - p0.event_kernel_ms) / max(1, launches)
-        achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * n / (avg_ms * 1e-3) / 1e9
-        traffic, traffic_src = committed_traffic() if (n == 1_000_000 and args.nzc == 64) else (None, None)
-        roof = {
-            "kernel": "step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "bytes_per_launch": ALGORITHMIC_BYTES_PER_PHOTON_STEP * n,
-            "avg_launch_ms": avg_ms, "launches": int(launches), "event_kernel_avg_ms": ev_ms,
-        }
-        prof.close()
+    other = None
+    if rank == 0 and world == 1 and args.other_mode:
+        if args.mode == "ranks":
+            r = measure_list(500, 50, 200)
+            other = {"mode": "list", "note": "one list of %d photons with one clock, one loop pass per step" % n, "steps": 500,
+                     "ms_per_step": r["seconds"] * 1e3 / 500, "scatter_events_per_s": r["events"] / r["seconds"],
+                     "photon_steps_per_s": r["photon_steps"] / r["seconds"], "roofline": r["roofline"],
+                     "relocations_per_pass": r["relocations_per_pass"]}
+        else:
+            r = measure_ranks(5, 1, True)
+            other = {"mode": "ranks", "rank_photons": args.rank_photons, "ranks": r["ranks"], "steps": 5,
+                     "ms_per_step": r["seconds"] * 1e3 / 5, "scatter_events_per_s": r["events"] / r["seconds"],
+                     "photon_steps_per_s": r["photon_steps"] / r["seconds"], "roofline": r["roofline"]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(frame, ph, cfg, seed, min(args.cpu_photons, n), args.cpu_steps)
+        if args.mode == "ranks":
+            cpu = cpu_baseline_ranks(frame, ph, cfg, args.rank_photons, 6)
+        else:
+            cpu = cpu_baseline_list(frame, ph, cfg, min(1024, n), 300)
 
     if rank == 0:
+        if args.mode == "ranks":
+            shape = ("%d virtual ranks x %d photons (independent lists, own clock and RNG stream each; one workgroup per list); "
+                     "step = one hydro frame (1/fps = %.2f s) for all lists, restarted from the resident snapshot"
+                     % (main_res.get("ranks", 0), args.rank_photons, remaining))
+        else:
+            shape = "one list, one clock; step = one loop pass over all photons"
         out = {
             "metric": "photon-scatter-events/sec at 1e6 photons, 2D FLASH jet",
-            "value": scatt_all / t_max,
+            "value": events_all / t_max,
             "unit": "scatter-events/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": t_max * 1e3 / args.steps,
+            "steps": steps,
+            "warmup": warmup,
+            "ms_per_step": t_max * 1e3 / steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 2D FLASH-like cylindrical GRB-jet frame (%d cells, "
-                                   "Lundman structured jet), %d photons per GPU, Compton+KN, STOKES %s, exact "
-                                   "event-driven loop" % (frame["num_elements"], n, "on" if args.stokes else "off"),
-                       "photons_per_gpu": n, "cells": int(frame["num_elements"]), "parallelism": "independent photon shards x%d" % world,
-                       "graph": bool(args.graph)},
-            "photon_steps_per_s": slots_all * args.steps / t_max,
-            "scatter_events": scatt_all,
-            "relocations_per_step": (st.num_photons_find_new_element - (w.num_photons_find_new_element if w else 0)) / args.steps,
-            "kn_rejections": st.kn_rejections, "rescans": st.rescans,
-            "roofline": roof,
+            "config": {"workload": "BASELINE.json configs[1]: 2D FLASH-like cylindrical GRB-jet frame (%d cells, Lundman structured "
+                                   "jet), %d photons per GPU, Compton+KN, STOKES %s; %s"
+                                   % (frame["num_elements"], n, "on" if args.stokes else "off", shape),
+                       "mode": args.mode, "photons_per_gpu": n, "cells": int(frame["num_elements"]),
+                       "rank_photons": args.rank_photons if args.mode == "ranks" else None,
+                       "parallelism": "independent photon shards x%d" % world},
+            "photon_steps_per_s": steps_all / t_max,
+            "scatter_events": events_all,
+            "loop_passes": main_res["passes"],
+            "roofline": main_res["roofline"],
+            "other_mode": other,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))

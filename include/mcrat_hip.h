@@ -73,6 +73,11 @@ typedef struct mcrat_hip_config {
     int iterations_per_sync;     /* loop iterations queued between host status reads (0: 256) */
     int use_graph;               /* replay the iteration batch as a hipGraph (0/1)            */
     int profile;                 /* bracket every step-kernel launch with HIP events (0/1)    */
+    int virtual_rank_photons;    /* 0: the photon list is ONE list with one clock (one MPI rank of the reference).
+                                    n > 0: the list is split into ceil(capacity/n) *virtual ranks* of n consecutive
+                                    slots, each an independent photon list with its own clock and RNG stream
+                                    (rng_stream + r) -- the reference's many-small-ranks run shape
+                                    (Doc/mcrat_doc.tex:165-166,222) on one GPU; see DESIGN.md section 2 */
 } mcrat_hip_config;
 
 /* == struct photon, Src/mcrat.h:142-171 (thermal-only build): 176 bytes on x86-64,
@@ -184,6 +189,14 @@ int mcrat_hip_propagate_frame(mcrat_hip_ctx *ctx, double *time_now, double remai
  * passes (<= 0: until the frame time is used up) and is synchronous on return. */
 int mcrat_hip_begin_frame(mcrat_hip_ctx *ctx, uint64_t seed, double time_now, double remaining_time);
 int mcrat_hip_run(mcrat_hip_ctx *ctx, long long max_iterations, mcrat_hip_frame_stats *stats);
+
+/* keep / bring back a device-side copy of the resident photons (repeatable frames without a host round trip) */
+int mcrat_hip_snapshot_photons(mcrat_hip_ctx *ctx);
+int mcrat_hip_restore_photons(mcrat_hip_ctx *ctx);
+
+/* virtual-rank mode: number of lists, and the loop statistics / clock of one of them */
+int mcrat_hip_num_virtual_ranks(const mcrat_hip_ctx *ctx);
+int mcrat_hip_rank_stats(mcrat_hip_ctx *ctx, int rank, mcrat_hip_frame_stats *stats);
 
 /* function-granular A/B entry points (one kernel each, for parity tests against the
  * reference functions): the findContainingHydroCell + calcMeanFreePath half of an

@@ -62,9 +62,20 @@ struct alignas(32) CellFluid {   // gathered when tau or the comoving momentum i
 // exact accelerator for findContainingBlock (geometry.c:350-391): uniform buckets (optionally in
 // log of the coordinate) whose member lists are ascending in cell index, so the first hit of the
 // closed-interval test is the lowest-index containing cell, i.e. what the reference's linear scan returns.
+// bucket-list entry: the cell index with copies of everything the slow path needs from that cell, so that a
+// re-location costs two dependent load rounds (list range, then up to four entries) instead of five
+struct alignas(32) FatCell {
+    double c0, c1, s0, s1;       // CellGeom
+    double a, b, gamma, dens_lab;   // CellFluid
+    double c2, s2;               // CellGeom2 (3-D)
+    double fc;                   // HydroDev::fluid_c
+    int cell;
+    int pad;
+};
+
 struct GridDev {
     const int *start;            // [nb+1]
-    const int *cells;            // [start[nb]]
+    const FatCell *cells;        // [start[nb]], ascending in cell index inside each bucket
     double org[3];
     double inv[3];
     int dim[3];
@@ -110,6 +121,8 @@ struct alignas(256) LoopState {
     long long rescans;
     double t_cut;                        // free times below this go on the shortlist (speed only, never results)
     double t_est;                        // running estimate of the smallest free time per iteration
+    int force_relocate;                  // virtual-rank mode: the next pass is the forced re-location pass of a new frame
+    int pad0;
 };
 
 // Candidates of one iteration.  Every slot whose free time is below LoopState::t_cut is appended here

@@ -37,6 +37,8 @@ struct mcrat_hip_ctx {
     PhotonDev ph{};
     void *ph_buf = nullptr;
     size_t ph_bytes = 0;
+    void *ph_snap = nullptr;          // mcrat_hip_snapshot_photons
+    size_t ph_snap_bytes = 0;
     bool have_photons = false;
     int step_blocks = 0;
     Cand *partials = nullptr;
@@ -56,6 +58,12 @@ struct mcrat_hip_ctx {
     int find_switch = 1;
     RngKey key{0, 0};
     long long frame_photon_steps = 0;
+
+    // virtual ranks (cfg.virtual_rank_photons > 0): one LoopState per list
+    int n_ranks = 0;
+    LoopState *d_rstates = nullptr;
+    LoopState *h_rstates = nullptr;   // pinned
+    int rstates_cap = 0;
 
     // scratch
     ReducePartial *d_red = nullptr;
@@ -124,6 +132,7 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
     if (!geometry_supported(cfg->dimensions, cfg->geometry)) return MCRAT_HIP_EINVAL;
     if (cfg->tau_calculation != MCRAT_HIP_TAU_DIRECT) return MCRAT_HIP_EINVAL;   // TABLE: SURVEY.md 8(f) #4
     if (cfg->cyclosynchrotron_switch != 0) return MCRAT_HIP_EINVAL;
+    if (cfg->virtual_rank_photons < 0) return MCRAT_HIP_EINVAL;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MCRAT_HIP_ENODEV;
@@ -165,9 +174,12 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     drop_graph(c);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ph_buf) (void)hipFree(c->ph_buf);
+    if (c->ph_snap) (void)hipFree(c->ph_snap);
     if (c->hy_buf) (void)hipFree(c->hy_buf);
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
+    if (c->d_rstates) (void)hipFree(c->d_rstates);
+    if (c->h_rstates) (void)hipHostFree(c->h_rstates);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->d_red) (void)hipFree(c->d_red);
@@ -324,7 +336,7 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     const size_t o_fc = !two ? take(sizeof(double) * M) : 0;
     const size_t o_k2e = any_hot ? take(sizeof(double) * M) : 0;
     const size_t o_start = take(sizeof(int) * g.start.size());
-    const size_t o_cells = take(sizeof(int) * std::max<size_t>(g.cells.size(), 1));
+    const size_t o_cells = take(sizeof(FatCell) * std::max<size_t>(g.cells.size(), 1));
     const size_t total = off;
 
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -372,7 +384,18 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     }
     memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
     memcpy(host.data() + o_start, g.start.data(), sizeof(int) * g.start.size());
-    if (!g.cells.empty()) memcpy(host.data() + o_cells, g.cells.data(), sizeof(int) * g.cells.size());
+    {   // bucket lists as complete copies of the member cells' records (device_types.hpp, FatCell)
+        FatCell *fat = reinterpret_cast<FatCell *>(host.data() + o_cells);
+        for (size_t e = 0; e < g.cells.size(); ++e) {
+            const int ci = g.cells[e];
+            FatCell &f = fat[e];
+            f.c0 = geom[ci].c0; f.c1 = geom[ci].c1; f.s0 = geom[ci].s0; f.s1 = geom[ci].s1;
+            f.a = fluid[ci].a; f.b = fluid[ci].b; f.gamma = fluid[ci].gamma; f.dens_lab = fluid[ci].dens_lab;
+            f.c2 = three ? h->r2[ci] : 0.0; f.s2 = three ? h->r2_size[ci] : 0.0;
+            f.fc = fc ? fc[ci] : 0.0;
+            f.cell = ci; f.pad = 0;
+        }
+    }
     HIPCHK(c, hipMemcpy(c->hy_buf, host.data(), total, hipMemcpyHostToDevice));
 
     char *base = static_cast<char *>(c->hy_buf);
@@ -388,7 +411,7 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     hy.dom1[0] = h->r1_domain[0]; hy.dom1[1] = h->r1_domain[1];
     hy.dom2[0] = h->r2_domain[0]; hy.dom2[1] = h->r2_domain[1];
     hy.grid.start = reinterpret_cast<const int *>(base + o_start);
-    hy.grid.cells = reinterpret_cast<const int *>(base + o_cells);
+    hy.grid.cells = reinterpret_cast<const FatCell *>(base + o_cells);
     for (int k = 0; k < 3; ++k) {
         hy.grid.org[k] = g.org[k]; hy.grid.inv[k] = g.inv[k]; hy.grid.dim[k] = g.dim[k]; hy.grid.logmap[k] = g.logmap[k];
     }
@@ -439,6 +462,18 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
         c->partials = nullptr;
         HIPCHK(c, hipMalloc((void **)&c->partials, sizeof(Cand) * need));
         c->partials_cap = need;
+    }
+    c->n_ranks = 0;
+    if (c->cfg.virtual_rank_photons > 0) {
+        c->n_ranks = (n + c->cfg.virtual_rank_photons - 1) / c->cfg.virtual_rank_photons;
+        if (c->rstates_cap < c->n_ranks) {
+            if (c->d_rstates) HIPCHK(c, hipFree(c->d_rstates));
+            if (c->h_rstates) HIPCHK(c, hipHostFree(c->h_rstates));
+            c->d_rstates = nullptr; c->h_rstates = nullptr;
+            HIPCHK(c, hipMalloc((void **)&c->d_rstates, sizeof(LoopState) * c->n_ranks));
+            HIPCHK(c, hipHostMalloc((void **)&c->h_rstates, sizeof(LoopState) * c->n_ranks, hipHostMallocDefault));
+            c->rstates_cap = c->n_ranks;
+        }
     }
     if (!c->shortlist) HIPCHK(c, hipMalloc((void **)&c->shortlist, sizeof(Shortlist)));
     HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
@@ -530,10 +565,34 @@ extern "C" int mcrat_hip_set_photons_soa(mcrat_hip_ctx *c, const mcrat_hip_photo
     return upload_columns(c, n, src, s->nearest_block_index, flags.data(), s->type);
 }
 
+extern "C" int mcrat_hip_snapshot_photons(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    int rc = MCRAT_HIP_OK;
+    if (c->frame_open && c->n_ranks == 0) { HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream)); }
+    (void)rc;
+    if (c->ph_snap && c->ph_snap_bytes < c->ph_bytes) { HIPCHK(c, hipFree(c->ph_snap)); c->ph_snap = nullptr; }
+    if (!c->ph_snap) { HIPCHK(c, hipMalloc(&c->ph_snap, c->ph_bytes)); c->ph_snap_bytes = c->ph_bytes; }
+    HIPCHK(c, hipMemcpyAsync(c->ph_snap, c->ph_buf, c->ph_bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_restore_photons(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons || !c->ph_snap || c->ph_snap_bytes < c->ph_bytes) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, hipMemcpyAsync(c->ph_buf, c->ph_snap, c->ph_bytes, hipMemcpyDeviceToDevice, c->stream));
+    c->frame_open = false;        // the loop state no longer matches the photons: begin_frame comes next
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *c) { return (c && c->have_photons) ? c->ph.n : 0; }
 
 static int flush_pending(mcrat_hip_ctx *c)
 {
+    if (c->n_ranks > 0) return MCRAT_HIP_OK;      // rank_loop_kernel leaves the photons current
     HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
     return MCRAT_HIP_OK;
 }
@@ -625,6 +684,61 @@ static void fill_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
     s->event_kernel_ms = c->prof_event_ms;
 }
 
+static void state_to_stats(const LoopState &h, long long slots, mcrat_hip_frame_stats *s)
+{
+    memset(s, 0, sizeof *s);
+    s->iterations = h.iterations;
+    s->photon_steps = h.iterations * slots;
+    s->frame_scatt_cnt = h.frame_scatt_cnt;
+    s->num_photons_find_new_element = h.n_relocated;
+    s->not_found = h.not_found;
+    s->kn_rejections = h.kn_rejections;
+    s->rescans = h.rescans;
+    s->last_scattered_index = h.last_scattered_index;
+    s->last_scattered_temp = h.last_scattered_temp;
+    s->last_time_step = h.last_time_step;
+    s->remaining_time = h.remaining_time;
+    s->time_now = h.time_now;
+}
+
+static int rank_slots(const mcrat_hip_ctx *c, int r)
+{
+    const int per = c->cfg.virtual_rank_photons;
+    return std::min(per, c->ph.n - r * per);
+}
+
+// whole-job view of the virtual ranks: counters add up; the clock shown is that of the rank furthest behind
+static void fill_rank_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
+{
+    if (!s) return;
+    mcrat_hip_frame_stats t, acc;
+    memset(&acc, 0, sizeof acc);
+    for (int r = 0; r < c->n_ranks; ++r) {
+        state_to_stats(c->h_rstates[r], rank_slots(c, r), &t);
+        acc.iterations += t.iterations; acc.photon_steps += t.photon_steps; acc.frame_scatt_cnt += t.frame_scatt_cnt;
+        acc.num_photons_find_new_element += t.num_photons_find_new_element; acc.not_found += t.not_found;
+        acc.kn_rejections += t.kn_rejections; acc.rescans += t.rescans;
+        if (r == 0 || t.remaining_time > acc.remaining_time) {
+            acc.remaining_time = t.remaining_time; acc.time_now = t.time_now; acc.last_time_step = t.last_time_step;
+            acc.last_scattered_index = t.last_scattered_index; acc.last_scattered_temp = t.last_scattered_temp;
+        }
+    }
+    *s = acc;
+}
+
+extern "C" int mcrat_hip_num_virtual_ranks(const mcrat_hip_ctx *c) { return c ? c->n_ranks : 0; }
+
+extern "C" int mcrat_hip_rank_stats(mcrat_hip_ctx *c, int rank, mcrat_hip_frame_stats *stats)
+{
+    if (!c || !stats) return MCRAT_HIP_EINVAL;
+    if (c->n_ranks <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
+    if (rank < 0 || rank >= c->n_ranks) return MCRAT_HIP_EINVAL;
+    HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    state_to_stats(c->h_rstates[rank], rank_slots(c, rank), stats);
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double time_now, double remaining_time)
 {
     if (!c) return MCRAT_HIP_EINVAL;
@@ -638,6 +752,12 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     h.skip_idx = -1;
     h.last_scattered_index = -1;
     HIPCHK(c, hipMemcpyAsync(c->d_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+    if (c->n_ranks > 0) {
+        h.force_relocate = 1;                       // mcrat.c:756, per list
+        for (int r = 0; r < c->n_ranks; ++r) c->h_rstates[r] = h;
+        h.force_relocate = 0;
+        HIPCHK(c, hipMemcpyAsync(c->d_rstates, c->h_rstates, sizeof(LoopState) * c->n_ranks, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->key.seed = seed;
@@ -680,10 +800,47 @@ static int ensure_graph(mcrat_hip_ctx *c, int batch)
     return MCRAT_HIP_OK;
 }
 
+static int ensure_events(mcrat_hip_ctx *c, size_t n);
+
+// virtual-rank mode: every launch gives each unfinished list up to `per_launch` passes of its own loop
+static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame_stats *stats)
+{
+    const long long per_launch_cap = 4096;      // bounds one launch to seconds even for the densest lists
+    long long it = 0;
+    while (max_iterations <= 0 || it < max_iterations) {
+        long long batch = per_launch_cap;
+        if (max_iterations > 0 && batch > max_iterations - it) batch = max_iterations - it;
+        if (c->cfg.profile) {
+            int rc = ensure_events(c, 2);
+            if (rc) return rc;
+            HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        }
+        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->cfg.virtual_rank_photons, batch, c->stream));
+        if (c->cfg.profile) {
+            HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev[1]));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            c->prof_step_ms += ms;
+            c->prof_launches += 1;
+        }
+        it += batch;
+        HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bool all_done = true;
+        for (int r = 0; r < c->n_ranks && all_done; ++r) all_done = c->h_rstates[r].done != 0;
+        if (all_done) break;
+    }
+    fill_rank_stats(c, stats);
+    if (stats) { stats->step_kernel_ms = c->prof_step_ms; stats->step_kernel_launches = c->prof_launches; }
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame_stats *stats)
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->frame_open) return MCRAT_HIP_ESTATE;
+    if (c->n_ranks > 0) return run_ranks(c, max_iterations, stats);
     const int per_sync = c->cfg.iterations_per_sync;
     long long it = 0;
     int rc;
@@ -756,7 +913,7 @@ extern "C" int mcrat_hip_propagate_frame(mcrat_hip_ctx *c, double *time_now, dou
 extern "C" int mcrat_hip_step_locate_sample(mcrat_hip_ctx *c, int find_nearest_block_switch)
 {
     if (!c) return MCRAT_HIP_EINVAL;
-    if (!c->frame_open) return MCRAT_HIP_ESTATE;
+    if (!c->frame_open || c->n_ranks > 0) return MCRAT_HIP_ESTATE;
     HIPCHK(c, launch_step(c->kc, find_nearest_block_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
     c->find_switch = 0;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -766,7 +923,7 @@ extern "C" int mcrat_hip_step_locate_sample(mcrat_hip_ctx *c, int find_nearest_b
 extern "C" int mcrat_hip_step_event(mcrat_hip_ctx *c, mcrat_hip_frame_stats *stats)
 {
     if (!c) return MCRAT_HIP_EINVAL;
-    if (!c->frame_open) return MCRAT_HIP_ESTATE;
+    if (!c->frame_open || c->n_ranks > 0) return MCRAT_HIP_ESTATE;
     HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -33,7 +33,7 @@ __device__ int g_diag = 0;
 #else
 #define MC_DIAG(bit) 0
 #endif
-enum { DIAG_SKIP_SLOW = 1, DIAG_SKIP_INCELL = 2, DIAG_SKIP_SAMPLE = 4, DIAG_SKIP_ADVANCE = 8, DIAG_SKIP_MIN = 16 };
+enum { DIAG_SKIP_SLOW = 1, DIAG_SKIP_INCELL = 2, DIAG_SKIP_SAMPLE = 4, DIAG_SKIP_ADVANCE = 8, DIAG_SKIP_PHILOX = 16, DIAG_SKIP_COORDS = 32 };
 
 // ------------------------------------------------------------------ top-K of (time, slot), ascending, ties by slot
 __device__ __forceinline__ bool cand_less(double ta, int ia, double tb, int ib)
@@ -142,12 +142,23 @@ __device__ __forceinline__ void block_topk(TopK &mine, Cand (*s_w)[TOPK], Cand *
 }
 
 // ------------------------------------------------------------------ step kernel
+// x / C_LIGHT, correctly rounded, without the ~30-instruction IEEE division sequence: q = x*(1/c), one FMA for
+// the exact residual, one FMA to correct (Markstein's division by a constant).  Bit-identical to x / C_LIGHT on
+// 4e8 random doubles over 2^-40..2^80 (checked on the host); see DESIGN.md "Numerics".
+__device__ __forceinline__ double div_by_c(double x)
+{
+    constexpr double INV_C = 1.0 / C_LIGHT;
+    const double q = x * INV_C;
+    const double r = fma(-q, C_LIGHT, x);
+    return fma(r, INV_C, q);
+}
+
 // free time of a photon in a known cell: mclib.c:675-687
 __device__ __forceinline__ double sample_free_time(double ntau /* -1.0 / tau */, uint64_t bits)
 {
     const double rnd = bits_to_uniform_pos(bits);
     const double mfp = ntau * log(rnd);
-    return mfp / C_LIGHT;
+    return div_by_c(mfp);
 }
 
 // blocks b and b+8 share an XCD (and its L2): give every XCD one contiguous eighth of the photon chunks so
@@ -181,12 +192,14 @@ constexpr int Q_RECALC_ONLY = (int)0x80000000;   // queue entry flag: the slot i
 // 2: recalc tau only) when the slot must go through the slow path; the time returned then is a placeholder.
 template <int DIMS, int GEOM, bool FORCE>
 __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned fl, int cell,
-                                           double r0, double r1, double r2, double ntau, uint64_t bits, int &queue)
+                                           double r0, double r1, double r2, double ntau, uint64_t bits, int &queue, int &bucket)
 {
     queue = 0;
+    bucket = -1;
     if (!(fl & FLAG_VALID)) return INFINITY;
     double a0, a1, a2;
-    phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
+    if (MC_DIAG(DIAG_SKIP_COORDS)) { a0 = r0 + r1; a1 = r2; a2 = 0; }
+    else phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
     if (phys::in_domain<DIMS>(hy, a0, a1, a2) && (cell != -1)) {               // mclib.c:492-505
         if constexpr (FORCE) {
             queue = 1;                                                           // mclib.c:528, find_nearest_block_switch == 1
@@ -195,8 +208,9 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
             else if (!phys::check_in_block<DIMS>(hy, cell, a0, a1, a2)) queue = 1;    // mclib.c:507,528
             else if (fl & FLAG_RECALC) queue = 2;                                // mclib.c:668
         }
+        if (queue == 1) bucket = phys::grid_bucket(hy.grid, a0, a1, a2);        // where the slow path will search
         if (queue) return INFINITY;
-        if (MC_DIAG(DIAG_SKIP_SAMPLE)) return ntau * (double)(bits >> 40);
+        if (MC_DIAG(DIAG_SKIP_SAMPLE)) return 1e-3 + (double)i * 1e-12 + (double)(bits & 1) * 0.0 + ntau * 0.0;
         return sample_free_time(ntau, bits);
     }
     if (cell != -1) ph.idx[i] = -1;                                              // mclib.c:592
@@ -204,10 +218,11 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
 }
 
 // slow path of one queued slot: mclib.c:528-586 (re-location, comoving momentum, optical depth) or the
-// recalc_properties branch of calcMeanFreePath (mclib.c:668-673), then its free-time draw
+// recalc_properties branch of calcMeanFreePath (mclib.c:668-673), then its free-time draw.  Two dependent load
+// rounds: {photon columns, bucket range} then {bucket entries | the cell's fluid record}.
 template <int DIMS, int GEOM>
-__device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, bool relocate, bool count_it,
-                                           unsigned long long iter, const RngKey &key, int &relocated, int &not_found)
+__device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, bool relocate, int bucket, bool count_it,
+                                           unsigned long long iter, const RngKey &key, int rng_slot, int &relocated, int &not_found)
 {
     const double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
     const double p0 = ph.p0[i], p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
@@ -215,12 +230,15 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
     int cell;
     bool need_tau = (fl & FLAG_RECALC) != 0;
     bool new_cell = false;
+    double fa = 0, fb = 0, fc = 0, fgamma = 1, fdens = 0;
     if (relocate) {
         double a0, a1, a2;
         phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
-        cell = phys::find_containing_block<DIMS>(hy, a0, a1, a2);                // mclib.c:534
+        FatCell hit;
+        cell = phys::find_in_bucket<DIMS>(hy.grid, bucket, a0, a1, a2, hit);     // mclib.c:534
         ph.idx[i] = cell;                                                        // mclib.c:536
         if (cell != -1) {
+            fa = hit.a; fb = hit.b; fc = hit.fc; fgamma = hit.gamma; fdens = hit.dens_lab;
             new_cell = true;
             need_tau = true;                                                     // mclib.c:570
             if (count_it) relocated += 1;                                        // mclib.c:579,608-611
@@ -229,6 +247,11 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         }
     } else {
         cell = ph.idx[i];
+        if (cell != -1) {
+            const CellFluid f = hy.fluid[cell];
+            fa = f.a; fb = f.b; fgamma = f.gamma; fdens = f.dens_lab;
+            if constexpr (DIMS != DIM_TWO) fc = hy.fluid_c[cell];
+        }
     }
     double t;
     if (cell != -1) {
@@ -237,15 +260,14 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             double cphi, sphi;
             phys::cos_sin_of_atan2(r1, r0, cphi, sphi);                          // photon azimuth, mclib.c:549-552
             double beta[3];
-            phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);
+            phys::beta_from_record<DIMS>(fa, fb, fc, cphi, sphi, beta);
             if (new_cell) {
                 const double lab[4] = {p0, p1, p2, p3};
                 double comv[4];
                 phys::lorentz_boost(beta, lab, comv, true);                      // mclib.c:558
                 ph.c0[i] = comv[0]; ph.c1[i] = comv[1]; ph.c2[i] = comv[2]; ph.c3[i] = comv[3];
             }
-            const CellFluid f = hy.fluid[cell];
-            const double tau = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p1, p2, p3);
+            const double tau = phys::optical_depth_direct(beta, fgamma, fdens, p1, p2, p3);
             ntau = -1.0 / tau;
             ph.tau[i] = tau;
             ph.ntau[i] = ntau;
@@ -253,9 +275,9 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         } else {
             ntau = ph.ntau[i];
         }
-        const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)(i >> 1), RNG_FREEPATH, key.stream);
-        const uint64_t bits = (i & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
-                                      : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
+        const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)(rng_slot >> 1), RNG_FREEPATH, key.stream);
+        const uint64_t bits = (rng_slot & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
+                                             : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
         t = sample_free_time(ntau, bits);
     } else {
         t = 1e12 / C_LIGHT;
@@ -298,7 +320,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev
                                                           Cand *__restrict__ block_min, Shortlist *sl)
 {
     __shared__ int s_qn;
-    __shared__ int s_q[STEP_QCAP];
+    __shared__ int s_q[STEP_QCAP];          // slot | Q_RECALC_ONLY
+    __shared__ int s_qb[STEP_QCAP];         // bucket to search (re-locating slots)
     __shared__ double s_wt[STEP_BLOCK / 64];
     __shared__ int s_wi[STEP_BLOCK / 64];
     if (st->done) return;
@@ -334,17 +357,19 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev
             *reinterpret_cast<double2 *>(ph.r2 + i0) = in.R2;
         }
         // one Philox block serves both slots of the pair
-        const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)pair, RNG_FREEPATH, key.stream);
+        Philox4 blk;
+        if (MC_DIAG(DIAG_SKIP_PHILOX)) { blk.w[0] = pair * 2654435761u; blk.w[1] = pair ^ 0x9e3779b9u; blk.w[2] = ~blk.w[0]; blk.w[3] = blk.w[1] + 7u; }
+        else blk = keyed_block(key.seed, iter, (uint32_t)pair, RNG_FREEPATH, key.stream);
         const uint64_t bits0 = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
         const uint64_t bits1 = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
 
-        int q0, q1;
+        int q0, q1, b0, b1;
         double2 T;
-        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0);
-        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1);
+        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0, b0);
+        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1, b1);
         if constexpr (FORCE) {
-            if (q0) T.x = slow_one<DIMS, GEOM>(ph, hy, i0, true, false, iter, key, relocated, not_found);
-            if (q1) T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, true, false, iter, key, relocated, not_found);
+            if (q0) T.x = slow_one<DIMS, GEOM>(ph, hy, i0, true, b0, false, iter, key, i0, relocated, not_found);
+            if (q1) T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, true, b1, false, iter, key, i0 + 1, relocated, not_found);
             q0 = q1 = 0;
         } else {
             // ballot-compact the slots that need the slow path into the workgroup's LDS queue (one LDS atomic
@@ -357,11 +382,11 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base + c0 + c1 <= STEP_QCAP) {
                     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-                    if (q0) s_q[base + __popcll(m0 & below)] = i0 | (q0 == 2 ? Q_RECALC_ONLY : 0);
-                    if (q1) s_q[base + c0 + __popcll(m1 & below)] = (i0 + 1) | (q1 == 2 ? Q_RECALC_ONLY : 0);
+                    if (q0) { const int e = base + __popcll(m0 & below); s_q[e] = i0 | (q0 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b0; }
+                    if (q1) { const int e = base + c0 + __popcll(m1 & below); s_q[e] = (i0 + 1) | (q1 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b1; }
                 } else {
-                    if (q0) { T.x = slow_one<DIMS, GEOM>(ph, hy, i0, q0 == 1, true, iter, key, relocated, not_found); q0 = 0; }
-                    if (q1) { T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, q1 == 1, true, iter, key, relocated, not_found); q1 = 0; }
+                    if (q0) { T.x = slow_one<DIMS, GEOM>(ph, hy, i0, q0 == 1, b0, true, iter, key, i0, relocated, not_found); q0 = 0; }
+                    if (q1) { T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, q1 == 1, b1, true, iter, key, i0 + 1, relocated, not_found); q1 = 0; }
                 }
             }
         }
@@ -385,7 +410,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev
             const int entry = s_q[e];
             if (entry == -1) continue;
             const int i = entry & ~Q_RECALC_ONLY;
-            const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(entry & Q_RECALC_ONLY), true, iter, key, relocated, not_found);
+            const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(entry & Q_RECALC_ONLY), s_qb[e], true, iter, key, i, relocated, not_found);
             best.offer(t, i);
             if (t < t_cut) shortlist_push(sl, t, i);
         }
@@ -423,7 +448,7 @@ struct EventWalk {
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
 template <int DIMS, int GEOM, bool STOKES>
 __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
-                                             unsigned long long iter, EventWalk &w, double scatt_time, int i)
+                                             unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base)
 {
     // *scattered_ph_index (mclib.c:1341) is the last candidate photonEvent looked at; main() does not call
     // photonEvent at all when even the first free time exceeds the frame (mcrat.c:777,834)
@@ -465,7 +490,7 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
         s[0] = ph.s0[i]; s[1] = ph.s1[i]; s[2] = ph.s2[i]; s[3] = ph.s3[i];
         phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
     }
-    EventStream rng = event_stream(key.seed, iter, (uint32_t)i, key.stream);
+    EventStream rng = event_stream(key.seed, iter, (uint32_t)(i - slot_base), key.stream);
     const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
     double el[4];
     phys::single_thermal_electron(el, fluid_temp, k2e, pc, rng);       // mclib.c:1234
@@ -495,64 +520,51 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     return EV_DONE;
 }
 
-template <int DIMS, int GEOM, bool STOKES>
-__global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
-                                                            const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl)
-{
-    static_assert(EVENT_BLOCK == SHORTLIST_CAP, "one thread per shortlist entry");
-    __shared__ Cand s_w[EVENT_BLOCK / 64][TOPK];
-    __shared__ Cand s_c[TOPK];
-    __shared__ Cand s_raw[SHORTLIST_CAP];
-    __shared__ Cand s_list[SHORTLIST_CAP];
-    __shared__ double s_wt[EVENT_BLOCK / 64];
-    __shared__ int s_wi[EVENT_BLOCK / 64];
-    __shared__ int s_status;
-    __shared__ double s_last_t;
-    __shared__ int s_last_i;
-    __shared__ double s_seg[MAX_SEG];
-    if (st->done) return;
-    const int tid = threadIdx.x;
+// LDS scratch of the event walk (one per workgroup)
+struct EventShared {
+    Cand w[EVENT_BLOCK / 64][TOPK];
+    Cand c[TOPK];
+    Cand raw[SHORTLIST_CAP];
+    Cand list[SHORTLIST_CAP];
+    double wt[EVENT_BLOCK / 64];
+    int wi[EVENT_BLOCK / 64];
+    double seg[MAX_SEG];
+    double last_t;
+    int last_i;
+    int status;
+};
 
-    // ---- the iteration's candidates in sorted order: the shortlist if it is complete, else the global minimum
-    int n_list = sl->count;
-    if (n_list > SHORTLIST_CAP) n_list = 0;                // overflowed: incomplete, ignore it
-    if (tid < n_list) s_raw[tid] = sl->items[tid];
-    {
-        MinCand m;
-        m.init();
-        for (int e = tid; e < n_blocks; e += EVENT_BLOCK) m.offer(block_min[e].t, block_min[e].idx);
-        wave_min_pair_dpp(m.t, m.i);
-        if ((tid & 63) == 0) { s_wt[tid >> 6] = m.t; s_wi[tid >> 6] = m.i; }
-    }
-    __syncthreads();
-    if (tid < n_list) {                                    // rank sort (times with equal (t, idx) cannot occur)
-        const Cand me = s_raw[tid];
+// The second half of a loop pass for one photon list occupying slots [base, base + n): sort the shortlist
+// (sh.raw[0..n_raw), complete below t_cut unless it overflowed), walk it as photonEvent does, refill from
+// time_to_scatter if it runs out, then the bookkeeping of mcrat.c:782-784 / 837-845 into *st.
+// All EVENT_BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
+template <int DIMS, int GEOM, bool STOKES>
+__device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
+                                            EventShared &sh, int n_raw, Cand gmin, int base, int n)
+{
+    const int tid = threadIdx.x;
+    int n_list = (n_raw > SHORTLIST_CAP) ? 0 : n_raw;      // overflowed: incomplete, ignore it
+    if (tid < n_list) {                                    // rank sort (equal (t, idx) pairs cannot occur)
+        const Cand me = sh.raw[tid];
         int rank = 0;
-        for (int j = 0; j < n_list; ++j) rank += cand_less(s_raw[j].t, s_raw[j].idx, me.t, me.idx) ? 1 : 0;
-        s_list[rank] = me;
+        for (int j = 0; j < n_list; ++j) rank += cand_less(sh.raw[j].t, sh.raw[j].idx, me.t, me.idx) ? 1 : 0;
+        sh.list[rank] = me;
     }
-    if (n_list == 0 && tid == 0) {
-        MinCand g;
-        g.init();
-#pragma unroll
-        for (int w = 0; w < EVENT_BLOCK / 64; ++w) g.offer(s_wt[w], s_wi[w]);
-        s_list[0].t = g.t; s_list[0].idx = g.i; s_list[0].pad = 0;
-    }
+    if (n_list == 0 && tid == 0) sh.list[0] = gmin;
     __syncthreads();
-    if (n_list == 0 && s_list[0].idx != INT_MAX) n_list = 1;
+    if (n_list == 0 && gmin.idx != INT_MAX) n_list = 1;
 
     const unsigned long long iter = st->iteration;
     EventWalk w;
     w.dt_max = st->remaining_time;
-    w.seg = s_seg;
+    w.seg = sh.seg;
     w.old_scatt_time = 0; w.dt = 0; w.nseg = 0; w.skip = -1; w.rej = 0; w.first = true;
     w.last_idx = st->last_scattered_index;
     long long rescans = 0;
-    const double t_first = (n_list > 0) ? s_list[0].t : INFINITY;
+    const double t_first = (n_list > 0) ? sh.list[0].t : INFINITY;
 
-    // ---- walk the list (thread 0); refill it TOPK at a time from time_to_scatter if it runs out
-    const Cand *list = s_list;
-    const int max_rounds = ph.n / TOPK + 3;
+    const Cand *list = sh.list;
+    const int max_rounds = n / TOPK + 3;
     for (int round = 0; round < max_rounds; ++round) {
         if (tid == 0) {
             int status = EV_NEED_MORE;
@@ -561,33 +573,33 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
                 status = EV_DONE;
             }
             for (int c = 0; c < n_list && status == EV_NEED_MORE; ++c) {
-                if (try_candidate<DIMS, GEOM, STOKES>(ph, hy, st, key, iter, w, list[c].t, list[c].idx) == EV_DONE)
+                if (try_candidate<DIMS, GEOM, STOKES>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base) == EV_DONE)
                     status = EV_DONE;
             }
             if (status == EV_NEED_MORE) {
-                s_last_t = list[n_list - 1].t;
-                s_last_i = list[n_list - 1].idx;
+                sh.last_t = list[n_list - 1].t;
+                sh.last_i = list[n_list - 1].idx;
                 rescans += 1;
             }
-            s_status = status;
+            sh.status = status;
         }
         __syncthreads();
-        if (s_status != EV_NEED_MORE) break;
+        if (sh.status != EV_NEED_MORE) break;
         {
-            const double lt = s_last_t;
-            const int li = s_last_i;
+            const double lt = sh.last_t;
+            const int li = sh.last_i;
             TopK more;
             more.init();
-            for (int i = tid; i < ph.n; i += EVENT_BLOCK) {
+            for (int i = base + tid; i < base + n; i += EVENT_BLOCK) {
                 double t = ph.tts[i];
                 if (t != t) t = INFINITY;
                 if (cand_less(lt, li, t, i)) more.insert(t, i);
             }
-            block_topk<EVENT_BLOCK / 64>(more, s_w, s_c);
+            block_topk<EVENT_BLOCK / 64>(more, sh.w, sh.c);
         }
-        list = s_c;
+        list = sh.c;
         n_list = 0;
-        for (int c = 0; c < TOPK; ++c) n_list += (s_c[c].idx != INT_MAX) ? 1 : 0;
+        for (int c = 0; c < TOPK; ++c) n_list += (sh.c[c].idx != INT_MAX) ? 1 : 0;
     }
 
     if (tid == 0) {                                        // mcrat.c:782-784 / 837-845
@@ -604,13 +616,172 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
         st->last_scattered_index = w.last_idx;
         st->kn_rejections += w.rej;
         st->rescans += rescans;
-        // shortlist threshold for the next iteration: ~8 expected entries (speed only)
+        // shortlist threshold for the next pass: ~8 expected entries (speed only)
         if (t_first < INFINITY) {
             const double est = (st->t_est > 0) ? 0.875 * st->t_est + 0.125 * t_first : t_first;
             st->t_est = est;
             st->t_cut = 8.0 * est;
         }
-        sl->count = 0;
+    }
+}
+
+template <int DIMS, int GEOM, bool STOKES>
+__global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
+                                                            const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl)
+{
+    static_assert(EVENT_BLOCK == SHORTLIST_CAP, "one thread per shortlist entry");
+    __shared__ EventShared sh;
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    const int n_raw = sl->count;
+    if (tid < n_raw && tid < SHORTLIST_CAP) sh.raw[tid] = sl->items[tid];
+    MinCand m;
+    m.init();
+    for (int e = tid; e < n_blocks; e += EVENT_BLOCK) m.offer(block_min[e].t, block_min[e].idx);
+    wave_min_pair_dpp(m.t, m.i);
+    if ((tid & 63) == 0) { sh.wt[tid >> 6] = m.t; sh.wi[tid >> 6] = m.i; }
+    __syncthreads();
+    MinCand g;
+    g.init();
+#pragma unroll
+    for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(sh.wt[wv], sh.wi[wv]);
+    Cand gmin;
+    gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
+    event_block<DIMS, GEOM, STOKES>(ph, hy, st, key, sh, n_raw, gmin, 0, ph.n);
+    if (tid == 0) sl->count = 0;
+}
+
+// ------------------------------------------------------------------ virtual ranks
+// MCRaT is run as many MPI ranks of 10^3 - 5*10^3 photons, each an independent photon list with its own clock
+// (Doc/mcrat_doc.tex:165-166,222).  rank_loop_kernel runs R such lists per GPU, one workgroup per
+// list, the WHOLE loop of mcrat.c:761-851 inside one launch: the list's hot columns stay in the workgroup's L1/L2,
+// the per-pass state lives in LDS, and no pass costs a kernel launch or an N-wide sweep of HBM.  Every list sees
+// exactly the arithmetic and random numbers of a single-list context holding only its photons with
+// rng_stream = first_stream + r.
+struct RankLayout {
+    int n_ranks;
+    int rank_photons;     // slots per rank (the last rank may hold fewer)
+    int n_total;
+};
+
+constexpr int RANK_QCAP = 1024;
+
+template <int DIMS, int GEOM, bool STOKES>
+__global__ __launch_bounds__(EVENT_BLOCK) void rank_loop_kernel(PhotonDev ph, HydroDev hy, LoopState *states, RngKey key,
+                                                                RankLayout lay, long long max_passes)
+{
+    __shared__ LoopState st;
+    __shared__ EventShared sh;
+    __shared__ int s_qn, s_sln;
+    __shared__ int s_q[RANK_QCAP];
+    __shared__ int s_qb[RANK_QCAP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int rank = blockIdx.x;
+    const int base = rank * lay.rank_photons;
+    const int n = min(lay.rank_photons, lay.n_total - base);
+    if (tid == 0) st = states[rank];
+    __syncthreads();
+    if (st.done || n <= 0) return;
+    const RngKey rk = {key.seed, key.stream + (uint32_t)rank};
+
+    for (long long pass = 0; pass < max_passes; ++pass) {
+        const int nseg = st.nseg;
+        const int skip = st.skip_idx;
+        const unsigned long long iter = st.iteration;
+        const double t_cut = st.t_cut;
+        const bool force = st.force_relocate != 0;          // first pass of a frame, mcrat.c:756
+        if (tid == 0) { s_qn = 0; s_sln = 0; }
+        __syncthreads();
+
+        MinCand best;
+        best.init();
+        int relocated = 0, not_found = 0;
+        auto shortlist_lds = [&](double t, int i) {
+            const int pos = atomicAdd(&s_sln, 1);
+            if (pos < SHORTLIST_CAP) { sh.raw[pos].t = t; sh.raw[pos].idx = i; sh.raw[pos].pad = 0; }
+        };
+        // ---- phase 1: the step of every slot of this list (cf. step_kernel)
+        for (int il = tid; il < n; il += EVENT_BLOCK) {
+            const int i = base + il;
+            double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
+            const double ntau = ph.ntau[i];
+            const int cell = ph.idx[i];
+            const unsigned fl = ph.flags[i];
+            if (nseg > 0 && (fl & FLAG_MOVES) && i != skip) {
+                const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
+                for (int s = 0; s < nseg; ++s) {
+                    const double t = st.seg[s];
+                    r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
+                }
+                ph.r0[i] = r0; ph.r1[i] = r1; ph.r2[i] = r2;
+            }
+            const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)(il >> 1), RNG_FREEPATH, rk.stream);
+            const uint64_t bits = (il & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
+                                           : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
+            int q, bucket;
+            double t;
+            if (force) t = fast_one<DIMS, GEOM, true>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
+            else t = fast_one<DIMS, GEOM, false>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
+            if (q) {
+                const int e = atomicAdd(&s_qn, 1);
+                if (e < RANK_QCAP) { s_q[e] = il | (q == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = bucket; q = 0; t = INFINITY; }
+                else t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, !force, iter, rk, il, relocated, not_found);
+                if (e < RANK_QCAP) continue;
+            } else {
+                ph.tts[i] = t;
+            }
+            if (fl & FLAG_VALID) { best.offer(t, i); if (t < t_cut) shortlist_lds(t, i); }
+        }
+        __syncthreads();
+        // ---- phase 2: the queued slots, dense
+        {
+            int qn = s_qn;
+            if (qn > RANK_QCAP) qn = RANK_QCAP;
+            for (int e = tid; e < qn; e += EVENT_BLOCK) {
+                const int il = s_q[e] & ~Q_RECALC_ONLY;
+                const int i = base + il;
+                const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, iter, rk, il, relocated, not_found);
+                best.offer(t, i);
+                if (t < t_cut) shortlist_lds(t, i);
+            }
+        }
+        wave_min_pair_dpp(best.t, best.i);
+        if (lane == 0) { sh.wt[tid >> 6] = best.t; sh.wi[tid >> 6] = best.i; }
+        if (relocated) atomicAdd(reinterpret_cast<unsigned long long *>(&st.n_relocated), (unsigned long long)relocated);
+        if (not_found) atomicAdd(reinterpret_cast<unsigned long long *>(&st.not_found), (unsigned long long)not_found);
+        __syncthreads();
+        MinCand g;
+        g.init();
+#pragma unroll
+        for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(sh.wt[wv], sh.wi[wv]);
+        Cand gmin;
+        gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
+        // ---- the event half and the bookkeeping
+        event_block<DIMS, GEOM, STOKES>(ph, hy, &st, rk, sh, s_sln, gmin, base, n);
+        if (tid == 0) st.force_relocate = 0;
+        __syncthreads();
+        if (st.done) break;
+    }
+
+    // leave the photons current: apply the advance still pending (cf. flush_kernel)
+    {
+        const int nseg = st.nseg, skip = st.skip_idx;
+        if (nseg > 0) {
+            for (int il = tid; il < n; il += EVENT_BLOCK) {
+                const int i = base + il;
+                if ((ph.flags[i] & FLAG_MOVES) && i != skip) {
+                    const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
+                    double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
+                    for (int s = 0; s < nseg; ++s) {
+                        const double t = st.seg[s];
+                        r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
+                    }
+                    ph.r0[i] = r0; ph.r1[i] = r1; ph.r2[i] = r2;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { st.nseg = 0; st.skip_idx = -1; states[rank] = st; }
     }
 }
 
@@ -789,6 +960,19 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
             event_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl);
         else
             event_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl);
+    });
+}
+
+hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
+                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream)
+{
+    RankLayout lay = {n_ranks, rank_photons, ph.n};
+    return dispatch(kc, [&](auto D, auto G) {
+        constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
+        if (kc.stokes)
+            rank_loop_kernel<DV, GV, true><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes);
+        else
+            rank_loop_kernel<DV, GV, false><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes);
     });
 }
 

@@ -26,6 +26,9 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 // candidate selection + photonEvent + loop bookkeeping
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+// virtual ranks: every workgroup runs the whole loop of one independent photon list of `rank_photons` slots
+hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
+                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream);
 // apply the pending advance (end of run / before photons are read back) and clear it
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);

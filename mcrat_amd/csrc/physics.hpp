@@ -68,24 +68,9 @@ __device__ __forceinline__ bool check_in_block(const HydroDev &h, int cell, doub
     return in;
 }
 
-// findContainingBlock, geometry.c:350-391: lowest-index cell whose closed extent holds the point, or -1.
-// The bucket lists are ascending in cell index and hold every cell whose (slightly widened) extent
-// touches the bucket, so the first hit equals the reference's linear first match.
-// Latency matters here, not bandwidth (a handful of lanes per wave walk this path): the first four list
-// entries and their cell records are fetched as two batches of independent loads instead of a
-// load -> test -> load chain.
-template <int DIMS>
-__device__ __forceinline__ bool in_cell_rec(const CellGeom &g, const CellGeom2 &g2, double a0, double a1, double a2)
+// bucket of the cell-lookup grid that holds a point (engine.hip, build_grid)
+__device__ __forceinline__ int grid_bucket(const GridDev &g, double a0, double a1, double a2)
 {
-    bool in = (2 * fabs(a0 - g.c0) - g.s0 <= 0) && (2 * fabs(a1 - g.c1) - g.s1 <= 0);
-    if constexpr (DIMS == DIM_THREE) in = in && (2 * fabs(a2 - g2.c2) - g2.s2 <= 0);
-    return in;
-}
-
-template <int DIMS>
-__device__ __forceinline__ int find_containing_block(const HydroDev &h, double a0, double a1, double a2)
-{
-    const GridDev &g = h.grid;
     const double a[3] = {a0, a1, a2};
     int b[3] = {0, 0, 0};
 #pragma unroll
@@ -98,33 +83,63 @@ __device__ __forceinline__ int find_containing_block(const HydroDev &h, double a
             b[k] = bi;
         }
     }
-    const int bucket = (b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0];
+    return (b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0];
+}
+
+template <int DIMS>
+__device__ __forceinline__ bool in_fat_cell(const FatCell &f, double a0, double a1, double a2)
+{
+    bool in = (2 * fabs(a0 - f.c0) - f.s0 <= 0) && (2 * fabs(a1 - f.c1) - f.s1 <= 0);   // geometry.c:394-417
+    if constexpr (DIMS == DIM_THREE) in = in && (2 * fabs(a2 - f.c2) - f.s2 <= 0);
+    return in;
+}
+
+// findContainingBlock, geometry.c:350-391: lowest-index cell whose closed extent holds the point, or -1.
+// The bucket lists are ascending in cell index and hold every cell whose (slightly widened) extent touches
+// the bucket, so the first hit equals the reference's linear first match.  Latency matters here, not
+// bandwidth (a handful of lanes per workgroup walk this path): the first four entries, each a complete
+// copy of the cell's records, are fetched as one batch of independent loads.  `hit` receives the entry.
+template <int DIMS>
+__device__ __forceinline__ int find_in_bucket(const GridDev &g, int bucket, double a0, double a1, double a2, FatCell &hit)
+{
+    hit.cell = -1;
+    if (bucket < 0) return -1;
     const int e0 = g.start[bucket];
     const int e1 = g.start[bucket + 1];
     const int n = e1 - e0;
     constexpr int BATCH = 4;
-    int c[BATCH];
+    FatCell f[BATCH];
 #pragma unroll
-    for (int k = 0; k < BATCH; ++k) c[k] = (k < n) ? g.cells[e0 + k] : -1;
-    CellGeom gg[BATCH];
-    CellGeom2 gg2[BATCH];
-#pragma unroll
-    for (int k = 0; k < BATCH; ++k) {
-        const int ck = c[k] < 0 ? 0 : c[k];
-        gg[k] = h.geom[ck];
-        if constexpr (DIMS == DIM_THREE) gg2[k] = h.geom2[ck];
-        else { gg2[k].c2 = 0; gg2[k].s2 = 0; }
-    }
-    int found = -1;
+    for (int k = 0; k < BATCH; ++k) f[k] = g.cells[e0 + ((k < n) ? k : 0)];
 #pragma unroll
     for (int k = BATCH - 1; k >= 0; --k)
-        if (c[k] >= 0 && in_cell_rec<DIMS>(gg[k], gg2[k], a0, a1, a2)) found = c[k];
-    if (found >= 0 || n <= BATCH) return found;
+        if (k < n && in_fat_cell<DIMS>(f[k], a0, a1, a2)) hit = f[k];
+    if (hit.cell >= 0 || n <= BATCH) return hit.cell;
     for (int e = e0 + BATCH; e < e1; ++e) {
-        const int cc = g.cells[e];
-        if (check_in_block<DIMS>(h, cc, a0, a1, a2)) return cc;
+        const FatCell c = g.cells[e];
+        if (in_fat_cell<DIMS>(c, a0, a1, a2)) { hit = c; return c.cell; }
     }
     return -1;
+}
+
+template <int DIMS>
+__device__ __forceinline__ int find_containing_block(const HydroDev &h, double a0, double a1, double a2)
+{
+    FatCell hit;
+    return find_in_bucket<DIMS>(h.grid, grid_bucket(h.grid, a0, a1, a2), a0, a1, a2, hit);
+}
+
+// geometry.c:189-253 on a staged record (see cell_beta below)
+template <int DIMS>
+__device__ __forceinline__ void beta_from_record(double a, double b, double c, double cphi, double sphi, double out[3])
+{
+    if constexpr (DIMS == DIM_TWO) {
+        out[0] = a * cphi; out[1] = a * sphi; out[2] = b;
+    } else if constexpr (DIMS == DIM_TWO_POINT_FIVE) {
+        out[0] = a * cphi - c * sphi; out[1] = a * sphi + c * cphi; out[2] = b;
+    } else {
+        out[0] = a; out[1] = b; out[2] = c;
+    }
 }
 
 // cos and sin of atan2(y, x) without the angle (atan2(0,0) = 0 -> (1,0))
@@ -145,20 +160,9 @@ template <int DIMS>
 __device__ __forceinline__ void cell_beta(const HydroDev &h, int cell, double cphi, double sphi, double out[3])
 {
     const CellFluid f = h.fluid[cell];
-    if constexpr (DIMS == DIM_TWO) {
-        out[0] = f.a * cphi;
-        out[1] = f.a * sphi;
-        out[2] = f.b;
-    } else if constexpr (DIMS == DIM_TWO_POINT_FIVE) {
-        const double c = h.fluid_c[cell];
-        out[0] = f.a * cphi - c * sphi;
-        out[1] = f.a * sphi + c * cphi;
-        out[2] = f.b;
-    } else {
-        out[0] = f.a;
-        out[1] = f.b;
-        out[2] = h.fluid_c[cell];
-    }
+    double c = 0.0;
+    if constexpr (DIMS != DIM_TWO) c = h.fluid_c[cell];
+    beta_from_record<DIMS>(f.a, f.b, c, cphi, sphi, out);
 }
 
 // ---------------------------------------------------------------- boosts

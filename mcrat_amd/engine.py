@@ -44,7 +44,8 @@ class Config(C.Structure):
     _fields_ = [("abi_version", C.c_int), ("dimensions", C.c_int), ("geometry", C.c_int),
                 ("stokes_switch", C.c_int), ("tau_calculation", C.c_int), ("cyclosynchrotron_switch", C.c_int),
                 ("device", C.c_int), ("stream", C.c_void_p), ("rng_stream", C.c_uint32),
-                ("iterations_per_sync", C.c_int), ("use_graph", C.c_int), ("profile", C.c_int)]
+                ("iterations_per_sync", C.c_int), ("use_graph", C.c_int), ("profile", C.c_int),
+                ("virtual_rank_photons", C.c_int)]
 
 
 class PhotonList(C.Structure):
@@ -101,6 +102,10 @@ SYMBOLS = {
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
     "mcrat_hip_begin_frame": (C.c_int, [_ctx, C.c_uint64, C.c_double, C.c_double]),
     "mcrat_hip_run": (C.c_int, [_ctx, C.c_longlong, C.POINTER(FrameStats)]),
+    "mcrat_hip_snapshot_photons": (C.c_int, [_ctx]),
+    "mcrat_hip_restore_photons": (C.c_int, [_ctx]),
+    "mcrat_hip_num_virtual_ranks": (C.c_int, [_ctx]),
+    "mcrat_hip_rank_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(FrameStats)]),
     "mcrat_hip_step_locate_sample": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_step_event": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_ph_minmax": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
@@ -142,11 +147,11 @@ class Engine:
     """One context of the HIP photon-loop engine (one per rank / GPU)."""
 
     def __init__(self, dimensions, geometry, stokes=0, device=0, stream=None, rng_stream=0,
-                 iterations_per_sync=0, use_graph=False, profile=False):
+                 iterations_per_sync=0, use_graph=False, profile=False, virtual_rank_photons=0):
         self.lib = load_library()
         self.cfg = Config(ABI_VERSION, int(dimensions), int(geometry), int(bool(stokes)), TAU_DIRECT, 0,
                           int(device), C.c_void_p(stream) if stream else None, int(rng_stream),
-                          int(iterations_per_sync), int(bool(use_graph)), int(bool(profile)))
+                          int(iterations_per_sync), int(bool(use_graph)), int(bool(profile)), int(virtual_rank_photons))
         self.ctx = _ctx()
         rc = self.lib.mcrat_hip_init(C.byref(self.ctx), C.byref(self.cfg))
         if rc != 0:
@@ -259,6 +264,20 @@ class Engine:
         self._check(self.lib.mcrat_hip_propagate_frame(self.ctx, C.byref(tn), float(remaining_time), int(seed), C.byref(st)),
                     "propagate_frame")
         return tn.value, st
+
+    def snapshot_photons(self):
+        self._check(self.lib.mcrat_hip_snapshot_photons(self.ctx), "snapshot_photons")
+
+    def restore_photons(self):
+        self._check(self.lib.mcrat_hip_restore_photons(self.ctx), "restore_photons")
+
+    def num_virtual_ranks(self):
+        return int(self.lib.mcrat_hip_num_virtual_ranks(self.ctx))
+
+    def rank_stats(self, rank):
+        st = FrameStats()
+        self._check(self.lib.mcrat_hip_rank_stats(self.ctx, int(rank), C.byref(st)), "rank_stats")
+        return st
 
     def step_locate_sample(self, find_nearest_block_switch):
         self._check(self.lib.mcrat_hip_step_locate_sample(self.ctx, int(find_nearest_block_switch)), "step_locate_sample")

@@ -70,7 +70,7 @@ def test_no_cpu_fallback(engine):
     import torch
     lib = engine.load_library()
     ctx = C.c_void_p()
-    cfg = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 0, 0, None, 0, 0, 0, 0)
+    cfg = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 0, 0, None, 0, 0, 0, 0, 0)
     rc = lib.mcrat_hip_init(C.byref(ctx), C.byref(cfg))
     if not torch.cuda.is_available():
         assert rc == -2 and not ctx.value                  # MCRAT_HIP_ENODEV
@@ -79,9 +79,9 @@ def test_no_cpu_fallback(engine):
     else:
         assert rc == 0
         lib.mcrat_hip_destroy(ctx)
-    bad = engine.Config(engine.ABI_VERSION + 1, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 0, 0, None, 0, 0, 0, 0)
+    bad = engine.Config(engine.ABI_VERSION + 1, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 0, 0, None, 0, 0, 0, 0, 0)
     assert lib.mcrat_hip_init(C.byref(ctx), C.byref(bad)) == -1
-    table = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, 2, 0, 0, None, 0, 0, 0, 0)   # TAU_CALCULATION TABLE
+    table = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, 2, 0, 0, None, 0, 0, 0, 0, 0)   # TAU_CALCULATION TABLE
     assert lib.mcrat_hip_init(C.byref(ctx), C.byref(table)) == -1
     assert lib.mcrat_hip_init(None, C.byref(cfg)) == -1
 

@@ -328,3 +328,82 @@ def test_errors_are_reported_not_fatal(hip):
         e.begin_frame(1, 0.0, 0.2)                         # no hydro / photons staged yet
     with pytest.raises(hip.McratHipError):
         e.run(1)
+
+
+# ------------------------------------------------------------------ virtual ranks
+@pytest.mark.parametrize("case", ["cfg1", "cfg2-stokes", "cfg3-stokes"])
+def test_virtual_ranks_equal_independent_lists(hip, oracle, case):
+    """virtual_rank_photons = n: every block of n consecutive slots is an independent photon list with its own
+    clock and RNG stream rng_stream + r -- the reference's many-ranks run shape.  Each must equal the oracle run
+    on that sub-list alone (slot indices restart at 0, stream = first_stream + r), including the short last rank."""
+    if case == "cfg1":
+        frame, ph, cfg = synth.config1(n_photons=3000, n0=32, n1=32)
+    elif case == "cfg2-stokes":
+        frame, ph, cfg = synth.config2(n_photons=3000, nzc=8, stokes=1, lumi=1e54)
+    else:
+        frame, ph, cfg = synth.config3(n_photons=3000, nr=256, nth=128, lumi=1e54)
+    per, first_stream, seed, t0, rem, passes = 700, 5, 31, 2.0, 0.2, 300
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=first_stream, virtual_rank_photons=per)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    assert e.num_virtual_ranks() == 5
+    e.begin_frame(seed, t0, rem)
+    tot = e.run(passes)
+    out = e.get_photons()
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    n = 3000
+    sums = dict(it=0, sc=0, rel=0, rej=0, steps=0)
+    for r in range(5):
+        lo, hi = r * per, min((r + 1) * per, n)
+        sub = {k: (v[lo:hi].copy() if isinstance(v, np.ndarray) else v) for k, v in ph.items()}
+        P = oracle.OraclePhotons(synth.photons_to_aos(sub, oracle.PHOTON_DTYPE))
+        rst, rtn, rrem, _ = oracle.photon_loop(c, P, H, seed=seed, time_now=t0, remaining_time=rem, max_iterations=passes,
+                                               stream=first_stream + r)
+        st = e.rank_stats(r)
+        assert st.iterations == rst.iterations == passes
+        assert st.frame_scatt_cnt == rst.frame_scatt_cnt > 0
+        assert st.kn_rejections == rst.kn_rejections
+        assert st.num_photons_find_new_element == rst.num_photons_find_new_element
+        assert st.time_now == pytest.approx(rtn, rel=1e-12) and st.remaining_time == pytest.approx(rrem, rel=1e-9)
+        assert st.last_scattered_index - lo == rst.last_scattered_index
+        _compare({k: v[lo:hi] for k, v in out.items()}, P.aos)
+        sums["it"] += rst.iterations; sums["sc"] += rst.frame_scatt_cnt; sums["rel"] += rst.num_photons_find_new_element
+        sums["rej"] += rst.kn_rejections; sums["steps"] += rst.iterations * (hi - lo)
+    got = (tot.iterations, tot.frame_scatt_cnt, tot.num_photons_find_new_element, tot.kn_rejections, tot.photon_steps)
+    assert got == (sums["it"], sums["sc"], sums["rel"], sums["rej"], sums["steps"])
+
+
+def test_virtual_ranks_whole_frame_and_split_runs(hip, oracle):
+    frame, ph, cfg = synth.config1(n_photons=1500, n0=16, n1=16)
+    frame["r1_domain"] = (0.0, 1e12 + 2.0e9)
+    per, seed, t0, rem = 500, 8, 0.0, 0.02
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=per)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    tn, tot = e.propagate_frame(t0, rem, seed)
+    out = e.get_photons()
+    assert tn == pytest.approx(t0 + rem, rel=1e-13) and tot.remaining_time == 0.0
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    total = 0
+    for r in range(3):
+        sub = {k: (v[r * per:(r + 1) * per].copy() if isinstance(v, np.ndarray) else v) for k, v in ph.items()}
+        P = oracle.OraclePhotons(synth.photons_to_aos(sub, oracle.PHOTON_DTYPE))
+        rst, rtn, rrem, _ = oracle.photon_loop(c, P, H, seed=seed, time_now=t0, remaining_time=rem, stream=r)
+        assert rrem == 0.0 and e.rank_stats(r).iterations == rst.iterations
+        _compare({k: v[r * per:(r + 1) * per] for k, v in out.items()}, P.aos)
+        total += rst.frame_scatt_cnt
+    assert tot.frame_scatt_cnt == total > 100
+    # the same frame in bounded pieces is bitwise the same
+    e2 = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=per)
+    e2.set_hydro(frame)
+    e2.set_photons(ph)
+    e2.begin_frame(seed, t0, rem)
+    for _ in range(1000):
+        mid = e2.get_photons()
+        if e2.run(37).remaining_time == 0.0:
+            break
+    out2 = e2.get_photons()
+    for k in FLOAT_FIELDS + INT_FIELDS:
+        assert np.array_equal(out2[k], out[k]), k

@@ -18,9 +18,9 @@ lib.mcrat_hip_diag_set.restype, lib.mcrat_hip_diag_set.argtypes = C.c_int, [C.c_
 
 n = int(os.environ.get("N", "1000000"))
 frame, ph, cfg = synth.config2(n_photons=n)
-names = {0: "full", 1: "-slow", 2: "-incell(-slow)", 3: "-incell-slow", 4: "-sample", 8: "-advance", 7: "-slow-incell-sample",
-         15: "-slow-incell-sample-advance (loads+stores of tts only)"}
-for bits in (0, 1, 3, 4, 7, 8, 15):
+names = {0: "full", 1: "-slow", 3: "-slow -incell", 7: "-slow -incell -sample(log,div)", 23: "-slow -incell -sample -philox",
+         55: "-slow -incell -sample -philox -coords(sqrt)", 63: "... -advance (loads, stores, min only)", 19: "-slow -incell -philox"}
+for bits in (0, 1, 3, 19, 7, 23, 55, 63):
     e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], profile=True, iterations_per_sync=100)
     e.set_hydro(frame)
     e.set_photons(ph)
@@ -32,6 +32,6 @@ for bits in (0, 1, 3, 4, 7, 8, 15):
     ms = (st.step_kernel_ms - w.step_kernel_ms) / max(1, st.step_kernel_launches - w.step_kernel_launches)
     ev = (st.event_kernel_ms - w.event_kernel_ms) / max(1, st.step_kernel_launches - w.step_kernel_launches)
     print("diag bits %2d %-55s step %.1f us  event %.1f us  (%d launches)" % (bits, names.get(bits, ""), ms * 1e3, ev * 1e3,
-                                                                      st.step_kernel_launches - w.step_kernel_launches))
+                                                                      st.step_kernel_launches - w.step_kernel_launches), flush=True)
     e.close()
 lib.mcrat_hip_diag_set(0)
