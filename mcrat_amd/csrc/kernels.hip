@@ -665,9 +665,12 @@ struct RankLayout {
 };
 
 constexpr int RANK_QCAP = 1024;
+#ifndef RANK_WAVES_PER_SIMD
+#define RANK_WAVES_PER_SIMD 2      // 2 lists resident per CU without register spills; measured: 4 (with spills) is no faster -- the loop is VALU-issue bound
+#endif
 
 template <int DIMS, int GEOM, bool STOKES>
-__global__ __launch_bounds__(EVENT_BLOCK) void rank_loop_kernel(PhotonDev ph, HydroDev hy, LoopState *states, RngKey key,
+__global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev ph, HydroDev hy, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes)
 {
     __shared__ LoopState st;
