@@ -139,12 +139,21 @@ def main():
                          % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the photon loop")
+    # rehearsal on a one-GPU box: MCRAT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo for the scalar
+    # exchanges (RCCL refuses two ranks on one device); the real multi-GPU run uses nccl (= RCCL), one rank per GPU
+    one_device = os.environ.get("MCRAT_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    red_dev = "cpu" if one_device else "cuda"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # every GPU owns an independent photon set on a replica of the frame (weak scaling): the reference's ranks own
     # disjoint photons and never talk during the loop -- no data-path collective
@@ -269,9 +278,9 @@ def main():
 
     t_max, events_all, steps_all = main_res["seconds"], float(main_res["events"]), float(main_res["photon_steps"])
     if dist is not None:
-        t = torch.tensor([t_max], dtype=torch.float64, device="cuda")
+        t = torch.tensor([t_max], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        c = torch.tensor([events_all, steps_all], dtype=torch.float64, device="cuda")
+        c = torch.tensor([events_all, steps_all], dtype=torch.float64, device=red_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         t_max, events_all, steps_all = float(t.item()), float(c[0].item()), float(c[1].item())
 
