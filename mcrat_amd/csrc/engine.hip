@@ -251,15 +251,17 @@ bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
             const double a = c[k][i] - 0.5 * s[k][i], b = c[k][i] + 0.5 * s[k][i];
             w.push_back(g.logmap[k] ? std::log(b) - std::log(std::max(a, 1e-300)) : b - a);
         }
-        std::nth_element(w.begin(), w.begin() + w.size() / 2, w.end());
-        const double med = w[w.size() / 2];
+        // bucket width = a small typical cell (lower quartile): in a mesh with two refinement levels the fine cells,
+        // where the photons are, then get buckets of their own size instead of lists of nine
+        std::nth_element(w.begin(), w.begin() + w.size() / 4, w.end());
+        const double med = w[w.size() / 4];
         ext_lo[k] = g.logmap[k] ? std::log(lo) : lo;
         ext_hi[k] = g.logmap[k] ? std::log(hi) : hi;
         ncell[k] = std::max(1.0, (ext_hi[k] - ext_lo[k]) / med);
     }
     double prod = 1;
     for (int k = 0; k < naxes; ++k) prod *= ncell[k];
-    const double target = std::min(std::max((double)M, 1.0), 16777216.0);
+    const double target = std::min(std::max(4.0 * (double)M, 1.0), 16777216.0);
     double f = (prod > target) ? std::pow(target / prod, 1.0 / naxes) : 1.0;
 
     for (int attempt = 0; attempt < 12; ++attempt, f *= 0.5) {
@@ -267,9 +269,14 @@ bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
         for (int k = 0; k < 3; ++k) {
             g.dim[k] = 1; g.org[k] = 0; g.inv[k] = 0;
             if (k < naxes) {
-                g.dim[k] = (int)std::max(1.0, std::min(65536.0, std::floor(ncell[k] * f)));
-                g.org[k] = ext_lo[k];
-                g.inv[k] = g.dim[k] / (ext_hi[k] - ext_lo[k]);
+                // buckets of about one cell, shifted by half a bucket against the mesh: on a regular mesh a bucket then
+                // straddles 2 cells per axis (4 in 2-D, the batch the device fetches at once); aligned buckets would
+                // each touch 3 per axis because cell faces lie on bucket faces
+                const int nbk = (int)std::max(1.0, std::min(65536.0, std::floor(ncell[k] * f)));
+                const double width = (ext_hi[k] - ext_lo[k]) / nbk;
+                g.dim[k] = nbk + 1;
+                g.org[k] = ext_lo[k] - 0.5 * width;
+                g.inv[k] = 1.0 / width;
             }
             nb *= g.dim[k];
         }
@@ -296,6 +303,9 @@ bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
         for (size_t b = 0; b < (size_t)nb; ++b) count[b + 1] += count[b];
         g.start.resize((size_t)nb + 1);
         for (size_t b = 0; b <= (size_t)nb; ++b) g.start[b] = (int)count[b];
+        if (getenv("MCRAT_HIP_VERBOSE"))
+            fprintf(stderr, "mcrat_hip: cell-lookup grid %d x %d x %d buckets, %lld entries for %d cells (%.2f per bucket)\n",
+                    g.dim[0], g.dim[1], g.dim[2], total, M, (double)total / (double)nb);
         g.cells.assign((size_t)total, -1);
         std::vector<int> fill(g.start.begin(), g.start.end() - 1);
         for (int i = 0; i < M; ++i) {
