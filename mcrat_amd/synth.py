@@ -129,6 +129,27 @@ def uniform_mesh_3d_cartesian(lo, hi, n, fps):
     return _finish_frame(frame)
 
 
+def uniform_mesh_3d(geometry, lo, hi, n, fps, log_axis0=False):
+    """uniform 3-D cells in the hydro coordinates of `geometry` (axis 0 fastest): SPHERICAL (r, theta, phi),
+    POLAR (r, phi, z) or CARTESIAN (x, y, z); axis 0 may be log-spaced.  The domain equals the mesh extent."""
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    cs, ss = [], []
+    for a in range(3):
+        if a == 0 and log_axis0:
+            e = np.exp(np.linspace(np.log(lo[0]), np.log(hi[0]), n[0] + 1))
+        else:
+            e = np.linspace(lo[a], hi[a], n[a] + 1)
+        cs.append(0.5 * (e[1:] + e[:-1]))
+        ss.append(e[1:] - e[:-1])
+    C2, C1, C0 = np.meshgrid(cs[2], cs[1], cs[0], indexing="ij")
+    S2, S1, S0 = np.meshgrid(ss[2], ss[1], ss[0], indexing="ij")
+    frame = dict(dimensions=THREE, geometry=geometry,
+                 r0=C0.ravel().copy(), r1=C1.ravel().copy(), r2=C2.ravel().copy(),
+                 r0_size=S0.ravel().copy(), r1_size=S1.ravel().copy(), r2_size=S2.ravel().copy(),
+                 r0_domain=(lo[0], hi[0]), r1_domain=(lo[1], hi[1]), r2_domain=(lo[2], hi[2]), fps=float(fps))
+    return _finish_frame(frame)
+
+
 # --------------------------------------------------------------------------- fluids
 def _radial_velocity(frame, vel):
     dims, geom = frame["dimensions"], frame["geometry"]
@@ -357,7 +378,7 @@ def select_slab(frame, keep):
 
 
 # --------------------------------------------------------------------------- BASELINE.json configurations
-def config1(n_photons=10_000, seed=0, n0=64, n1=64, fps=5.0, r_inj=1e12):
+def config1(n_photons=10_000, seed=0, n0=64, n1=64, fps=5.0, r_inj=1e12, stokes=0):
     """cfg1: analytic spherical wind on a 2-D CARTESIAN uniform mesh, Compton-only, STOKES off.
     The mesh covers the photons' slab r in [r_inj-3c/fps, r_inj+3c/fps], theta in [0,5deg]."""
     th = 5.0 * np.pi / 180
@@ -367,7 +388,7 @@ def config1(n_photons=10_000, seed=0, n0=64, n1=64, fps=5.0, r_inj=1e12):
     frame = uniform_mesh_2d(0.0, x_hi, n0, z_lo, z_hi, n1, CARTESIAN, (0.0, 2.5e13), (0.0, 2.5e13), fps)
     spherical_outflow(frame)
     ph = inject_photons(frame, n_photons, r_inj, 0.0, 3.0 * np.pi / 180, seed)
-    cfg = dict(dimensions=TWO, geometry=CARTESIAN, stokes=0, name="cfg1-spherical-wind-2d-cartesian")
+    cfg = dict(dimensions=TWO, geometry=CARTESIAN, stokes=int(stokes), name="cfg1-spherical-wind-2d-cartesian")
     return frame, ph, cfg
 
 
@@ -393,6 +414,44 @@ def config3(n_photons=10_000_000, seed=0x4D435262, nr=2048, nth=512, fps=5.0, r_
     structured_fireball(frame, lumi=lumi)
     ph = inject_photons(frame, n_photons, r_inj, 0.0, 6.0 * np.pi / 180, seed)
     cfg = dict(dimensions=TWO, geometry=SPHERICAL, stokes=int(stokes), name="cfg3-pluto-2d-spherical-jet")
+    return frame, ph, cfg
+
+
+def add_toroidal_flow(frame, fraction=0.3):
+    """give the flow a phi component (v2) at unchanged speed, so that gamma stays consistent: exercises the v2 terms
+    of hydroVectorToCartesian (Src/geometry.c:212-225) in 2.5-D"""
+    k = np.sqrt(1.0 - fraction * fraction)
+    speed = np.sqrt(frame["v0"] ** 2 + frame["v1"] ** 2)
+    frame["v0"] = frame["v0"] * k
+    frame["v1"] = frame["v1"] * k
+    frame["v2"] = fraction * speed
+    return frame
+
+
+def config_25d(geometry=CYLINDRICAL, n_photons=2000, seed=21, stokes=1, lumi=1e54):
+    """TWO_POINT_FIVE: the cfg2 / cfg3 meshes with a three-component velocity (parity tests only)."""
+    if geometry == SPHERICAL:
+        frame, ph, cfg = config3(n_photons=n_photons, seed=seed, nr=256, nth=128, stokes=stokes, lumi=lumi)
+    else:
+        frame, ph, cfg = config2(n_photons=n_photons, seed=seed, nzc=8, stokes=stokes, lumi=lumi)
+    frame["dimensions"] = TWO_POINT_FIVE
+    add_toroidal_flow(frame)
+    ph = inject_photons(frame, n_photons, 1e12, 0.0, 3.0 * np.pi / 180, seed)
+    cfg = dict(cfg, dimensions=TWO_POINT_FIVE, name="2.5d-" + cfg["name"])
+    return frame, ph, cfg
+
+
+def config_3d(geometry, n_photons=1500, seed=9, fps=5.0, r_inj=1e12, stokes=1):
+    """small THREE/SPHERICAL or THREE/POLAR wedge around the jet axis with the spherical wind (parity tests only)."""
+    if geometry == SPHERICAL:
+        frame = uniform_mesh_3d(SPHERICAL, (0.97e12, 0.002, 0.0), (1.03e12, 0.08, 2 * np.pi), (24, 16, 12), fps, log_axis0=True)
+    elif geometry == POLAR:
+        frame = uniform_mesh_3d(POLAR, (1e9, 0.0, 0.97e12), (8e10, 2 * np.pi, 1.03e12), (20, 12, 24), fps)
+    else:
+        raise ValueError("use config_3d_cartesian")
+    spherical_outflow(frame)
+    ph = inject_photons(frame, n_photons, r_inj, 0.0, 3.0 * np.pi / 180, seed)
+    cfg = dict(dimensions=THREE, geometry=geometry, stokes=int(stokes), name="3d-%s-wind" % ("spherical" if geometry == SPHERICAL else "polar"))
     return frame, ph, cfg
 
 

@@ -70,7 +70,7 @@ def _compare(gpu, ref, rtol=RTOL):
 
 
 # ------------------------------------------------------------------ cell search
-@pytest.mark.parametrize("which", ["flash", "pluto", "cart3d"])
+@pytest.mark.parametrize("which", ["flash", "pluto", "cart3d", "sph3d", "polar3d"])
 def test_cell_lookup_equals_linear_scan(hip, oracle, which):
     """device bucket search == the reference's lowest-index linear scan (geometry.c:350-391), including
     points exactly on shared faces and corners (closed intervals -> two or four containing cells)."""
@@ -79,8 +79,12 @@ def test_cell_lookup_equals_linear_scan(hip, oracle, which):
         frame, _, cfg = synth.config2(n_photons=64, nzc=4)
     elif which == "pluto":
         frame, _, cfg = synth.config3(n_photons=64, nr=96, nth=48)
-    else:
+    elif which == "cart3d":
         frame, _, cfg = synth.config_3d_cartesian(n_photons=64, n=(8, 8, 8))
+    elif which == "sph3d":
+        frame, _, cfg = synth.config_3d(synth.SPHERICAL, n_photons=64)
+    else:
+        frame, _, cfg = synth.config_3d(synth.POLAR, n_photons=64)
     three = cfg["dimensions"] == synth.THREE
     M = frame["num_elements"]
     pick = rng.integers(0, M, 1500)
@@ -164,6 +168,12 @@ CASES = {
     "cfg3-spherical-jet-stokes": (synth.config3, dict(n_photons=2000, nr=256, nth=128, lumi=1e54), 1000),
     "cfg2-cylindrical-jet-thin": (synth.config2, dict(n_photons=2000, nzc=8), 0),
     "3d-cartesian-wind-stokes": (synth.config_3d_cartesian, dict(n_photons=1500), 800),
+    # every (DIMENSIONS, GEOMETRY) pair the reference supports (mcrat.h:196-204)
+    "2.5d-cylindrical-toroidal-flow-stokes": (synth.config_25d, dict(geometry=synth.CYLINDRICAL), 700),
+    "2.5d-spherical-toroidal-flow-stokes": (synth.config_25d, dict(geometry=synth.SPHERICAL), 700),
+    "3d-spherical-wind-stokes": (synth.config_3d, dict(geometry=synth.SPHERICAL), 700),
+    "3d-polar-wind-stokes": (synth.config_3d, dict(geometry=synth.POLAR), 700),
+    "2d-cartesian-wind-stokes": (synth.config1, dict(n_photons=1500, n0=32, n1=32, stokes=1), 700),
 }
 
 
