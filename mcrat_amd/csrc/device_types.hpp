@@ -46,6 +46,10 @@ struct PhotonDev {
     char *type;
     int n;                       // list_capacity
     int n_pad;
+    // The "hot" columns (r0-2, u0-2, ntau, idx, flags) are indexed as col[i - hot_bias].  0 in HBM; in
+    // rank_loop_kernel, when a list's hot columns live in LDS, the list's first slot (so that the LDS copies are
+    // indexed from 0 without ever forming an out-of-bounds pointer).
+    int hot_bias;
 };
 
 struct alignas(32) CellGeom {    // one 32-B sector per in-cell test (geometry.c:394-417)

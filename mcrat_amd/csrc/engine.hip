@@ -465,6 +465,7 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     p.type = b + o_type;
     p.n = n;
     p.n_pad = n_pad;
+    p.hot_bias = 0;
     c->step_blocks = step_grid_blocks(n_pad);
     const int need = c->step_blocks;                          // one candidate per workgroup of the step kernel
     if (c->partials_cap < need) {

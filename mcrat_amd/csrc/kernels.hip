@@ -213,7 +213,7 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
         if (MC_DIAG(DIAG_SKIP_SAMPLE)) return 1e-3 + (double)i * 1e-12 + (double)(bits & 1) * 0.0 + ntau * 0.0;
         return sample_free_time(ntau, bits);
     }
-    if (cell != -1) ph.idx[i] = -1;                                              // mclib.c:592
+    if (cell != -1) ph.idx[i - ph.hot_bias] = -1;                                // mclib.c:592
     return 1e12 / C_LIGHT;                                                       // mclib.c:620,684
 }
 
@@ -224,9 +224,10 @@ template <int DIMS, int GEOM>
 __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, bool relocate, int bucket, bool count_it,
                                            unsigned long long iter, const RngKey &key, int rng_slot, int &relocated, int &not_found)
 {
-    const double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
+    const int h = i - ph.hot_bias;               // index into the hot columns
+    const double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
     const double p0 = ph.p0[i], p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
-    const unsigned fl = ph.flags[i];
+    const unsigned fl = ph.flags[h];
     int cell;
     bool need_tau = (fl & FLAG_RECALC) != 0;
     bool new_cell = false;
@@ -236,7 +237,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
         FatCell hit;
         cell = phys::find_in_bucket<DIMS>(hy.grid, bucket, a0, a1, a2, hit);     // mclib.c:534
-        ph.idx[i] = cell;                                                        // mclib.c:536
+        ph.idx[h] = cell;                                                        // mclib.c:536
         if (cell != -1) {
             fa = hit.a; fb = hit.b; fc = hit.fc; fgamma = hit.gamma; fdens = hit.dens_lab;
             new_cell = true;
@@ -246,7 +247,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             not_found += 1;                                                      // mclib.c:583
         }
     } else {
-        cell = ph.idx[i];
+        cell = ph.idx[h];
         if (cell != -1) {
             const CellFluid f = hy.fluid[cell];
             fa = f.a; fb = f.b; fgamma = f.gamma; fdens = f.dens_lab;
@@ -270,10 +271,10 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             const double tau = phys::optical_depth_direct(beta, fgamma, fdens, p1, p2, p3);
             ntau = -1.0 / tau;
             ph.tau[i] = tau;
-            ph.ntau[i] = ntau;
-            if (fl & FLAG_RECALC) ph.flags[i] = (unsigned char)(fl & ~FLAG_RECALC);   // mclib.c:571-576,672
+            ph.ntau[h] = ntau;
+            if (fl & FLAG_RECALC) ph.flags[h] = (unsigned char)(fl & ~FLAG_RECALC);   // mclib.c:571-576,672
         } else {
-            ntau = ph.ntau[i];
+            ntau = ph.ntau[h];
         }
         const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)(rng_slot >> 1), RNG_FREEPATH, key.stream);
         const uint64_t bits = (rng_slot & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
@@ -466,13 +467,14 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     if (w.nseg < MAX_SEG) w.seg[w.nseg++] = this_seg;
     else w.seg[MAX_SEG - 1] += this_seg;
     w.old_scatt_time = scatt_time;
-    const int cell = ph.idx[i];
+    const int h = i - ph.hot_bias;               // index into the hot columns
+    const int cell = ph.idx[h];
     if (cell == -1) return EV_RUNNING;                     // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
 
     double p[4] = {ph.p0[i], ph.p1[i], ph.p2[i], ph.p3[i]};
-    double r[3] = {ph.r0[i], ph.r1[i], ph.r2[i]};
-    if (ph.flags[i] & FLAG_MOVES) {                        // the candidate's own position after mclib.c:1138
-        const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
+    double r[3] = {ph.r0[h], ph.r1[h], ph.r2[h]};
+    if (ph.flags[h] & FLAG_MOVES) {                        // the candidate's own position after mclib.c:1138
+        const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
         for (int s = 0; s < w.nseg; ++s) {
             r[0] += u0 * w.seg[s];
             r[1] += u1 * w.seg[s];
@@ -507,12 +509,12 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
     {
         const double d = 1.0 / p[0];                                   // mclib.c:1074-1080 factors of the new momentum
-        ph.u0[i] = p[1] * d * C_LIGHT; ph.u1[i] = p[2] * d * C_LIGHT; ph.u2[i] = p[3] * d * C_LIGHT;
+        ph.u0[h] = p[1] * d * C_LIGHT; ph.u1[h] = p[2] * d * C_LIGHT; ph.u2[h] = p[3] * d * C_LIGHT;
     }
     ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
-    ph.r0[i] = r[0]; ph.r1[i] = r[1]; ph.r2[i] = r[2];              // already advanced: the next step kernel skips it
+    ph.r0[h] = r[0]; ph.r1[h] = r[1]; ph.r2[h] = r[2];              // already advanced: the next step kernel skips it
     ph.num_scatt[i] += 1;                                              // mclib.c:1317
-    ph.flags[i] |= (unsigned char)FLAG_RECALC;                         // mclib.c:1322
+    ph.flags[h] |= (unsigned char)FLAG_RECALC;                         // mclib.c:1322
     st->frame_scatt_cnt += 1;                                          // mclib.c:1318
     st->last_scattered_temp = fluid_temp;
     w.skip = i;
@@ -670,9 +672,10 @@ constexpr int RANK_QCAP = 1024;
 #endif
 
 template <int DIMS, int GEOM, bool STOKES>
-__global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev ph, HydroDev hy, LoopState *states, RngKey key,
-                                                                RankLayout lay, long long max_passes)
+__global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
+                                                                RankLayout lay, long long max_passes, int lds_slots)
 {
+    extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's hot columns when it fits (lds_slots >= n)
     __shared__ LoopState st;
     __shared__ EventShared sh;
     __shared__ int s_qn, s_sln;
@@ -686,6 +689,30 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
     __syncthreads();
     if (st.done || n <= 0) return;
     const RngKey rk = {key.seed, key.stream + (uint32_t)rank};
+
+    // LDS residency: the columns every pass touches (r, u, -1/tau, cell index, flags: 61 B per slot) are copied into
+    // LDS once per launch and written back at the end; `ph` is the same PhotonDev with those column pointers aimed
+    // at LDS and hot_bias = base, so every device function below works on it unchanged (col[i - hot_bias]).
+    PhotonDev ph = gph;
+    const bool resident = lds_slots >= n;
+    if (resident) {
+        double *d = reinterpret_cast<double *>(s_dyn);
+        double *l_r0 = d, *l_r1 = d + lds_slots, *l_r2 = d + 2 * lds_slots, *l_u0 = d + 3 * lds_slots,
+               *l_u1 = d + 4 * lds_slots, *l_u2 = d + 5 * lds_slots, *l_nt = d + 6 * lds_slots;
+        int *l_idx = reinterpret_cast<int *>(d + 7 * lds_slots);
+        unsigned char *l_fl = reinterpret_cast<unsigned char *>(l_idx + lds_slots);
+        for (int il = tid; il < n; il += EVENT_BLOCK) {
+            const int i = base + il;
+            l_r0[il] = gph.r0[i]; l_r1[il] = gph.r1[i]; l_r2[il] = gph.r2[i];
+            l_u0[il] = gph.u0[i]; l_u1[il] = gph.u1[i]; l_u2[il] = gph.u2[i];
+            l_nt[il] = gph.ntau[i]; l_idx[il] = gph.idx[i]; l_fl[il] = gph.flags[i];
+        }
+        ph.r0 = l_r0; ph.r1 = l_r1; ph.r2 = l_r2;
+        ph.u0 = l_u0; ph.u1 = l_u1; ph.u2 = l_u2;
+        ph.ntau = l_nt; ph.idx = l_idx; ph.flags = l_fl;
+        ph.hot_bias = base;
+        __syncthreads();
+    }
 
     for (long long pass = 0; pass < max_passes; ++pass) {
         const int nseg = st.nseg;
@@ -706,17 +733,18 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
         // ---- phase 1: the step of every slot of this list (cf. step_kernel)
         for (int il = tid; il < n; il += EVENT_BLOCK) {
             const int i = base + il;
-            double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
-            const double ntau = ph.ntau[i];
-            const int cell = ph.idx[i];
-            const unsigned fl = ph.flags[i];
+            const int h = i - ph.hot_bias;
+            double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
+            const double ntau = ph.ntau[h];
+            const int cell = ph.idx[h];
+            const unsigned fl = ph.flags[h];
             if (nseg > 0 && (fl & FLAG_MOVES) && i != skip) {
-                const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
+                const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
                 for (int s = 0; s < nseg; ++s) {
                     const double t = st.seg[s];
                     r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
                 }
-                ph.r0[i] = r0; ph.r1[i] = r1; ph.r2[i] = r2;
+                ph.r0[h] = r0; ph.r1[h] = r1; ph.r2[h] = r2;
             }
             const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)(il >> 1), RNG_FREEPATH, rk.stream);
             const uint64_t bits = (il & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
@@ -772,18 +800,27 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
         if (nseg > 0) {
             for (int il = tid; il < n; il += EVENT_BLOCK) {
                 const int i = base + il;
-                if ((ph.flags[i] & FLAG_MOVES) && i != skip) {
-                    const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
-                    double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
+                const int h = i - ph.hot_bias;
+                if ((ph.flags[h] & FLAG_MOVES) && i != skip) {
+                    const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
+                    double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
                     for (int s = 0; s < nseg; ++s) {
                         const double t = st.seg[s];
                         r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
                     }
-                    ph.r0[i] = r0; ph.r1[i] = r1; ph.r2[i] = r2;
+                    ph.r0[h] = r0; ph.r1[h] = r1; ph.r2[h] = r2;
                 }
             }
         }
         __syncthreads();
+        if (resident) {
+            for (int il = tid; il < n; il += EVENT_BLOCK) {
+                const int i = base + il;
+                gph.r0[i] = ph.r0[il]; gph.r1[i] = ph.r1[il]; gph.r2[i] = ph.r2[il];
+                gph.u0[i] = ph.u0[il]; gph.u1[i] = ph.u1[il]; gph.u2[i] = ph.u2[il];
+                gph.ntau[i] = ph.ntau[il]; gph.idx[i] = ph.idx[il]; gph.flags[i] = ph.flags[il];
+            }
+        }
         if (tid == 0) { st.nseg = 0; st.skip_idx = -1; states[rank] = st; }
     }
 }
@@ -970,12 +1007,27 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_photons, long long max_passes, hipStream_t stream)
 {
     RankLayout lay = {n_ranks, rank_photons, ph.n};
+    // hot columns in LDS when two lists per CU still fit beside the static scratch: 61 B per slot
+    int lds_slots = 0;
+    if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && rank_photons <= 1024) lds_slots = (rank_photons + 15) & ~15;
+    size_t dyn = (size_t)lds_slots * (7 * sizeof(double) + sizeof(int) + 1);
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
-        if (kc.stokes)
-            rank_loop_kernel<DV, GV, true><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes);
-        else
-            rank_loop_kernel<DV, GV, false><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes);
+        // static + dynamic LDS exceeds the 64 KiB default: the kernel must be told, and if the runtime refuses
+        // the list simply stays in global memory (lds_slots = 0)
+        auto launch = [&](auto kernel) {
+            int slots = lds_slots;
+            size_t bytes = dyn;
+            if (bytes > 0 && hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                slots = 0;
+                bytes = 0;
+            }
+            kernel<<<dim3(n_ranks), dim3(EVENT_BLOCK), bytes, stream>>>(ph, hy, states, key, lay, max_passes, slots);
+        };
+        if (kc.stokes) launch(rank_loop_kernel<DV, GV, true>);
+        else launch(rank_loop_kernel<DV, GV, false>);
     });
 }
 
