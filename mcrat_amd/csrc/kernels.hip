@@ -730,8 +730,9 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             const int pos = atomicAdd(&s_sln, 1);
             if (pos < SHORTLIST_CAP) { sh.raw[pos].t = t; sh.raw[pos].idx = i; sh.raw[pos].pad = 0; }
         };
-        // ---- phase 1: the step of every slot of this list (cf. step_kernel)
-        for (int il = tid; il < n; il += EVENT_BLOCK) {
+        // ---- phase 1: the step of every slot of this list (cf. step_kernel); a thread owns slot pairs so that
+        // one Philox block serves two slots, as the draw order prescribes (rng.hpp)
+        auto one_slot = [&](int il, uint64_t bits) {
             const int i = base + il;
             const int h = i - ph.hot_bias;
             double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
@@ -746,22 +747,23 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                 }
                 ph.r0[h] = r0; ph.r1[h] = r1; ph.r2[h] = r2;
             }
-            const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)(il >> 1), RNG_FREEPATH, rk.stream);
-            const uint64_t bits = (il & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
-                                           : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
             int q, bucket;
             double t;
             if (force) t = fast_one<DIMS, GEOM, true>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
             else t = fast_one<DIMS, GEOM, false>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
             if (q) {
                 const int e = atomicAdd(&s_qn, 1);
-                if (e < RANK_QCAP) { s_q[e] = il | (q == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = bucket; q = 0; t = INFINITY; }
-                else t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, !force, iter, rk, il, relocated, not_found);
-                if (e < RANK_QCAP) continue;
+                if (e < RANK_QCAP) { s_q[e] = il | (q == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = bucket; return; }
+                t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, !force, iter, rk, il, relocated, not_found);
             } else {
                 ph.tts[i] = t;
             }
             if (fl & FLAG_VALID) { best.offer(t, i); if (t < t_cut) shortlist_lds(t, i); }
+        };
+        for (int pair = tid; 2 * pair < n; pair += EVENT_BLOCK) {
+            const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
+            one_slot(2 * pair, (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
+            if (2 * pair + 1 < n) one_slot(2 * pair + 1, (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32));
         }
         __syncthreads();
         // ---- phase 2: the queued slots, dense
