@@ -127,6 +127,7 @@ struct alignas(256) LoopState {
     double t_est;                        // running estimate of the smallest free time per iteration
     int force_relocate;                  // virtual-rank mode: the next pass is the forced re-location pass of a new frame
     int pad0;
+    long long stamps[8];                 // diagnostic build only (-DMCRAT_DIAG): s_memtime at points of the event walk
 };
 
 // Candidates of one iteration.  Every slot whose free time is below LoopState::t_cut is appended here

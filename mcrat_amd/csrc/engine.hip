@@ -737,6 +737,16 @@ static void fill_rank_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
     *s = acc;
 }
 
+#ifdef MCRAT_DIAG
+extern "C" int mcrat_hip_diag_stamps(mcrat_hip_ctx *c, long long out[8])
+{
+    if (!c || !out) return -1;
+    if (hipMemcpy(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out[k] = c->h_state->stamps[k];
+    return 0;
+}
+#endif
+
 extern "C" int mcrat_hip_num_virtual_ranks(const mcrat_hip_ctx *c) { return c ? c->n_ranks : 0; }
 
 extern "C" int mcrat_hip_rank_stats(mcrat_hip_ctx *c, int rank, mcrat_hip_frame_stats *stats)

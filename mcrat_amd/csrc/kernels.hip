@@ -33,7 +33,18 @@ __device__ int g_diag = 0;
 #else
 #define MC_DIAG(bit) 0
 #endif
-enum { DIAG_SKIP_SLOW = 1, DIAG_SKIP_INCELL = 2, DIAG_SKIP_SAMPLE = 4, DIAG_SKIP_ADVANCE = 8, DIAG_SKIP_PHILOX = 16, DIAG_SKIP_COORDS = 32 };
+#ifdef MCRAT_DIAG
+#define MC_STAMP(st, k)                                         \
+    do {                                                        \
+        __builtin_amdgcn_sched_barrier(0);                      \
+        (st)->stamps[k] = (long long)__builtin_amdgcn_s_memtime(); \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    } while (0)
+#else
+#define MC_STAMP(st, k) do { } while (0)
+#endif
+enum { DIAG_SKIP_SLOW = 1, DIAG_SKIP_INCELL = 2, DIAG_SKIP_SAMPLE = 4, DIAG_SKIP_ADVANCE = 8, DIAG_SKIP_PHILOX = 16, DIAG_SKIP_COORDS = 32,
+       DIAG_SLOW_NO_SEARCH = 64, DIAG_SLOW_NO_PHYSICS = 128, DIAG_SLOW_EMPTY = 256 };
 
 // ------------------------------------------------------------------ top-K of (time, slot), ascending, ties by slot
 __device__ __forceinline__ bool cand_less(double ta, int ia, double tb, int ib)
@@ -232,6 +243,8 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
     bool need_tau = (fl & FLAG_RECALC) != 0;
     bool new_cell = false;
     double fa = 0, fb = 0, fc = 0, fgamma = 1, fdens = 0;
+    if (MC_DIAG(DIAG_SLOW_EMPTY)) { ph.tts[i] = 1e-3 + i * 1e-12; return 1e-3 + i * 1e-12; }
+    if (MC_DIAG(DIAG_SLOW_NO_SEARCH)) relocate = false;
     if (relocate) {
         double a0, a1, a2;
         phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
@@ -255,6 +268,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         }
     }
     double t;
+    if (MC_DIAG(DIAG_SLOW_NO_PHYSICS)) need_tau = false;
     if (cell != -1) {
         double ntau;
         if (need_tau) {
@@ -468,38 +482,42 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     else w.seg[MAX_SEG - 1] += this_seg;
     w.old_scatt_time = scatt_time;
     const int h = i - ph.hot_bias;               // index into the hot columns
+    // one round of independent loads for everything the candidate needs (this lane's latency is the kernel's)
     const int cell = ph.idx[h];
-    if (cell == -1) return EV_RUNNING;                     // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
-
     double p[4] = {ph.p0[i], ph.p1[i], ph.p2[i], ph.p3[i]};
     double r[3] = {ph.r0[h], ph.r1[h], ph.r2[h]};
-    if (ph.flags[h] & FLAG_MOVES) {                        // the candidate's own position after mclib.c:1138
-        const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
-        for (int s = 0; s < w.nseg; ++s) {
-            r[0] += u0 * w.seg[s];
-            r[1] += u1 * w.seg[s];
-            r[2] += u2 * w.seg[s];
+    double pc[4] = {ph.c0[i], ph.c1[i], ph.c2[i], ph.c3[i]};
+    const unsigned cand_flags = ph.flags[h];
+    const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
+    double s[4] = {1, 0, 0, 0};
+    if constexpr (STOKES) { s[0] = ph.s0[i]; s[1] = ph.s1[i]; s[2] = ph.s2[i]; s[3] = ph.s3[i]; }
+    if (cell == -1) return EV_RUNNING;                     // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
+
+    if (cand_flags & FLAG_MOVES) {                         // the candidate's own position after mclib.c:1138
+        for (int k = 0; k < w.nseg; ++k) {
+            r[0] += u0 * w.seg[k];
+            r[1] += u1 * w.seg[k];
+            r[2] += u2 * w.seg[k];
         }
     }
+    MC_STAMP(st, 2);
     const double fluid_temp = hy.temp[cell];               // mclib.c:1148
     double cphi, sphi;
     phys::cos_sin_of_atan2(r[1], r[0], cphi, sphi);        // ph_phi, mclib.c:1151
     double beta[3];
     phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);     // mclib.c:1167-1174
-    double pc[4] = {ph.c0[i], ph.c1[i], ph.c2[i], ph.c3[i]};
-    double s[4] = {1, 0, 0, 0};
-    if constexpr (STOKES) {
-        s[0] = ph.s0[i]; s[1] = ph.s1[i]; s[2] = ph.s2[i]; s[3] = ph.s3[i];
-        phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
-    }
+    if constexpr (STOKES) phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
     EventStream rng = event_stream(key.seed, iter, (uint32_t)(i - slot_base), key.stream);
     const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
     double el[4];
+    MC_STAMP(st, 3);
     phys::single_thermal_electron(el, fluid_temp, k2e, pc, rng);       // mclib.c:1234
+    MC_STAMP(st, 4);
     if (!phys::single_scatter<STOKES>(el, pc, s, rng)) {               // mclib.c:1245
         w.rej += 1;
         return EV_RUNNING;
     }
+    MC_STAMP(st, 5);
     const double nb[3] = {-1 * beta[0], -1 * beta[1], -1 * beta[2]};
     phys::lorentz_boost(nb, pc, p, true);                              // mclib.c:1265
     if constexpr (STOKES) {
@@ -519,6 +537,7 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     st->last_scattered_temp = fluid_temp;
     w.skip = i;
     w.dt = scatt_time;
+    MC_STAMP(st, 6);
     return EV_DONE;
 }
 
@@ -542,7 +561,8 @@ struct EventShared {
 // All EVENT_BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
 template <int DIMS, int GEOM, bool STOKES>
 __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
-                                            EventShared &sh, int n_raw, Cand gmin, int base, int n)
+                                            EventShared &sh, int n_raw, Cand gmin, int base, int n,
+                                            unsigned long long iter, double dt_max, int last_idx, double t_est)
 {
     const int tid = threadIdx.x;
     int n_list = (n_raw > SHORTLIST_CAP) ? 0 : n_raw;      // overflowed: incomplete, ignore it
@@ -556,12 +576,12 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
     __syncthreads();
     if (n_list == 0 && gmin.idx != INT_MAX) n_list = 1;
 
-    const unsigned long long iter = st->iteration;
+    if (tid == 0) MC_STAMP(st, 1);
     EventWalk w;
-    w.dt_max = st->remaining_time;
+    w.dt_max = dt_max;
     w.seg = sh.seg;
     w.old_scatt_time = 0; w.dt = 0; w.nseg = 0; w.skip = -1; w.rej = 0; w.first = true;
-    w.last_idx = st->last_scattered_index;
+    w.last_idx = last_idx;
     long long rescans = 0;
     const double t_first = (n_list > 0) ? sh.list[0].t : INFINITY;
 
@@ -620,10 +640,11 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
         st->rescans += rescans;
         // shortlist threshold for the next pass: ~8 expected entries (speed only)
         if (t_first < INFINITY) {
-            const double est = (st->t_est > 0) ? 0.875 * st->t_est + 0.125 * t_first : t_first;
+            const double est = (t_est > 0) ? 0.875 * t_est + 0.125 * t_first : t_first;
             st->t_est = est;
             st->t_cut = 8.0 * est;
         }
+        MC_STAMP(st, 7);
     }
 }
 
@@ -633,13 +654,20 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
 {
     static_assert(EVENT_BLOCK == SHORTLIST_CAP, "one thread per shortlist entry");
     __shared__ EventShared sh;
-    if (st->done) return;
     const int tid = threadIdx.x;
+    // every load this prologue needs is independent of the others: issue them together, then look at `done`
+    const int done = st->done;
+    const unsigned long long iter = st->iteration;
+    const double dt_max = st->remaining_time, t_est = st->t_est;
+    const int last_idx = st->last_scattered_index;
     const int n_raw = sl->count;
-    if (tid < n_raw && tid < SHORTLIST_CAP) sh.raw[tid] = sl->items[tid];
+    const Cand mine = sl->items[tid];                     // EVENT_BLOCK == SHORTLIST_CAP; validity decided by n_raw
     MinCand m;
     m.init();
     for (int e = tid; e < n_blocks; e += EVENT_BLOCK) m.offer(block_min[e].t, block_min[e].idx);
+    if (done) return;
+    if (tid == 0) MC_STAMP(st, 0);
+    if (tid < n_raw) sh.raw[tid] = mine;
     wave_min_pair_dpp(m.t, m.i);
     if ((tid & 63) == 0) { sh.wt[tid >> 6] = m.t; sh.wi[tid >> 6] = m.i; }
     __syncthreads();
@@ -649,7 +677,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
     for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(sh.wt[wv], sh.wi[wv]);
     Cand gmin;
     gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
-    event_block<DIMS, GEOM, STOKES>(ph, hy, st, key, sh, n_raw, gmin, 0, ph.n);
+    event_block<DIMS, GEOM, STOKES>(ph, hy, st, key, sh, n_raw, gmin, 0, ph.n, iter, dt_max, last_idx, t_est);
     if (tid == 0) sl->count = 0;
 }
 
@@ -790,7 +818,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
         Cand gmin;
         gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
         // ---- the event half and the bookkeeping
-        event_block<DIMS, GEOM, STOKES>(ph, hy, &st, rk, sh, s_sln, gmin, base, n);
+        event_block<DIMS, GEOM, STOKES>(ph, hy, &st, rk, sh, s_sln, gmin, base, n, iter, st.remaining_time, st.last_scattered_index, st.t_est);
         if (tid == 0) st.force_relocate = 0;
         __syncthreads();
         if (st.done) break;

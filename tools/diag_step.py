@@ -18,9 +18,9 @@ lib.mcrat_hip_diag_set.restype, lib.mcrat_hip_diag_set.argtypes = C.c_int, [C.c_
 
 n = int(os.environ.get("N", "1000000"))
 frame, ph, cfg = synth.config2(n_photons=n)
-names = {0: "full", 1: "-slow", 3: "-slow -incell", 7: "-slow -incell -sample(log,div)", 23: "-slow -incell -sample -philox",
-         55: "-slow -incell -sample -philox -coords(sqrt)", 63: "... -advance (loads, stores, min only)", 19: "-slow -incell -philox"}
-for bits in (0, 1, 3, 19, 7, 23, 55, 63):
+names = {0: "full", 64: "slow path without the cell search", 128: "slow path without boost/tau", 192: "slow path: loads + draw only",
+         256: "slow path empty (queue + barrier + loop only)", 3: "no in-cell test, no slow path"}
+for bits in (0, 64, 128, 192, 256, 3):
     e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], profile=True, iterations_per_sync=100)
     e.set_hydro(frame)
     e.set_photons(ph)
