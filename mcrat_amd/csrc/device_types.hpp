@@ -20,6 +20,8 @@ constexpr int DIM_TWO = 0, DIM_TWO_POINT_FIVE = 1, DIM_THREE = 2;
 constexpr unsigned FLAG_RECALC = 1u;   // recalc_properties == 1                       (mcrat.h:161)
 constexpr unsigned FLAG_MOVES = 2u;    // type != CS_POOL_PHOTON && weight != 0        (mclib.c:1070)
 constexpr unsigned FLAG_VALID = 4u;    // slot index < list_capacity (padding slots are not valid)
+constexpr unsigned FLAG_TAU_FRESH = 8u;  // set with RECALC by the event kernel: tau of the new momentum is already stored for the
+                                       // cached cell, so a slot that is still in that cell needs no slow path next pass
 
 constexpr int TOPK = 4;          // candidates fetched per rescan of time_to_scatter in the event kernel
 constexpr int MAX_SEG = 8;       // advance segments remembered per iteration (one per tried candidate)
@@ -41,6 +43,9 @@ struct PhotonDev {
     // derived columns, maintained wherever p or tau change, so that the streaming pass needs no division:
     double *u0, *u1, *u2;        // (p_k * (1/p0)) * C_LIGHT: the velocity factor of mclib.c:1076-1080, rounded as there
     double *ntau;                // -1.0 / total_optical_depth, the factor of mclib.c:680
+    double *tau_next;            // optical depth precomputed at scatter time (FLAG_TAU_FRESH); becomes `tau` when the next
+                                 // pass confirms the slot is still in its cell, so a read-back in between shows what the
+                                 // reference would show (recalc_properties = 1, old total_optical_depth)
     int *idx;                    // nearest_block_index
     unsigned char *flags;
     char *type;

@@ -441,8 +441,8 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     const int n_pad = (int)align_up((size_t)std::max(n, 1), 2 * STEP_BLOCK);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    size_t o_d[23];
-    for (int k = 0; k < 23; ++k) o_d[k] = take(sizeof(double) * n_pad);
+    size_t o_d[24];
+    for (int k = 0; k < 24; ++k) o_d[k] = take(sizeof(double) * n_pad);
     const size_t o_idx = take(sizeof(int) * n_pad);
     const size_t o_flags = take(n_pad);
     const size_t o_type = take(n_pad);
@@ -460,6 +460,7 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     p.u1 = reinterpret_cast<double *>(b + o_d[20]);
     p.u2 = reinterpret_cast<double *>(b + o_d[21]);
     p.ntau = reinterpret_cast<double *>(b + o_d[22]);
+    p.tau_next = reinterpret_cast<double *>(b + o_d[23]);
     p.idx = reinterpret_cast<int *>(b + o_idx);
     p.flags = reinterpret_cast<unsigned char *>(b + o_flags);
     p.type = b + o_type;

@@ -217,7 +217,14 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
         } else {
             if (MC_DIAG(DIAG_SKIP_INCELL)) queue = 0;
             else if (!phys::check_in_block<DIMS>(hy, cell, a0, a1, a2)) queue = 1;    // mclib.c:507,528
-            else if (fl & FLAG_RECALC) queue = 2;                                // mclib.c:668
+            else if (fl & FLAG_RECALC) {                                         // mclib.c:668
+                if (fl & FLAG_TAU_FRESH) {
+                    ph.flags[i - ph.hot_bias] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                    ph.tau[i] = ph.tau_next[i];
+                } else {
+                    queue = 2;
+                }
+            }
         }
         if (queue == 1) bucket = phys::grid_bucket(hy.grid, a0, a1, a2);        // where the slow path will search
         if (queue) return INFINITY;
@@ -286,7 +293,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             ntau = -1.0 / tau;
             ph.tau[i] = tau;
             ph.ntau[h] = ntau;
-            if (fl & FLAG_RECALC) ph.flags[h] = (unsigned char)(fl & ~FLAG_RECALC);   // mclib.c:571-576,672
+            if (fl & FLAG_RECALC) ph.flags[h] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));   // mclib.c:571-576,672
         } else {
             ntau = ph.ntau[h];
         }
@@ -532,7 +539,16 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
     ph.r0[h] = r[0]; ph.r1[h] = r[1]; ph.r2[h] = r[2];              // already advanced: the next step kernel skips it
     ph.num_scatt[i] += 1;                                              // mclib.c:1317
-    ph.flags[h] |= (unsigned char)FLAG_RECALC;                         // mclib.c:1322
+    // recalc_properties = 1 (mclib.c:1322).  The optical depth the next pass would recompute for this slot in its
+    // cached cell (calcMeanFreePath, mclib.c:668-673: same position, same cell record, the new momentum) is computed
+    // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
+    {
+        const CellFluid f = hy.fluid[cell];
+        const double tau = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p[1], p[2], p[3]);
+        ph.tau_next[i] = tau;
+        ph.ntau[h] = -1.0 / tau;
+    }
+    ph.flags[h] = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
     st->frame_scatt_cnt += 1;                                          // mclib.c:1318
     st->last_scattered_temp = fluid_temp;
     w.skip = i;
