@@ -204,6 +204,35 @@ int mcrat_hip_rank_stats(mcrat_hip_ctx *ctx, int rank, mcrat_hip_frame_stats *st
 int mcrat_hip_step_locate_sample(mcrat_hip_ctx *ctx, int find_nearest_block_switch);
 int mcrat_hip_step_event(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);
 
+/* ONE photon list split over several GPUs, ONE clock ------------------------------------------------------------
+ * The reference never does this: its ranks own disjoint photons AND disjoint clocks (mcrat.c:761-851 runs per rank;
+ * SURVEY.md 8e).  This mode keeps the event order of a single list -- what one rank holding all the photons would
+ * compute -- while the N-wide work is spread over `world` GPUs: every GPU owns the contiguous global slots
+ * [slot_base, slot_base + n), with n the capacity of its own mcrat_hip_set_photons list.  A round is
+ *
+ *     mcrat_hip_shared_clock_propose(ctx);          findContainingHydroCell + calcMeanFreePath on the own slots, then
+ *                                                    the own earliest candidates (the argsort prefix of mclib.c:702-712)
+ *                                                    with the photon data photonEvent needs -> send buffer
+ *     all-gather send -> recv over the GPUs          the min-reduction of SURVEY.md 8e; bytes_per_rank each; the host's
+ *                                                    job: ncclAllGather / MPI_Allgather on the context's stream
+ *     mcrat_hip_shared_clock_resolve(ctx);          photonEvent (mclib.c:1107) on the merged candidates, identically on
+ *                                                    every GPU; the owner of the scattered photon stores it
+ *
+ * and mcrat_hip_shared_clock_poll tells when the frame is over (rounds after that are no-ops, so polling every few
+ * dozen rounds is enough).  All contexts of the group use the same rng_stream, seed, time_now and remaining_time;
+ * the photons end up bit-identical to a single context holding the concatenated list.  In this mode
+ * last_scattered_index in the stats is a GLOBAL slot, num_photons_find_new_element / not_found count the own slots,
+ * and `rescans` counts the rounds that continued an undecided iteration.
+ * send/recv: device buffers of bytes_per_rank and world * bytes_per_rank bytes; pass NULL to let the library
+ * allocate them (read them back with mcrat_hip_shared_clock_buffers); with world == 1 recv may equal send. */
+size_t mcrat_hip_shared_clock_bytes_per_rank(void);
+int mcrat_hip_shared_clock_attach(mcrat_hip_ctx *ctx, int world, int rank, long long slot_base, void *send, void *recv);
+int mcrat_hip_shared_clock_buffers(mcrat_hip_ctx *ctx, void **send, void **recv);
+int mcrat_hip_shared_clock_propose(mcrat_hip_ctx *ctx);
+int mcrat_hip_shared_clock_resolve(mcrat_hip_ctx *ctx);
+int mcrat_hip_shared_clock_poll(mcrat_hip_ctx *ctx, int *frame_done, mcrat_hip_frame_stats *stats);   /* synchronises the stream */
+int mcrat_hip_shared_clock_finish(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);   /* apply the pending advance, final stats */
+
 /* per-frame reductions on the resident photons ------------------------------- */
 int mcrat_hip_ph_minmax(mcrat_hip_ctx *ctx, double *min_r, double *max_r, double *min_theta, double *max_theta); /* mclib.c:1465 */
 int mcrat_hip_scatt_stats(mcrat_hip_ctx *ctx, int *max_scatt, int *min_scatt, double *avg_scatt, double *avg_r); /* mclib.c:1385 */

@@ -148,6 +148,47 @@ struct alignas(16) Shortlist {
 struct RngKey {
     uint64_t seed;
     uint32_t stream;
+    uint32_t slot_base;          // global index of this context's slot 0 (even; 0 unless the list is split over GPUs)
+};
+
+// ---- one photon list split over several GPUs, ONE clock (SURVEY.md 8e "exact mode") ------------------------------
+// Every GPU owns a contiguous range of the list's slots.  Each round it proposes its earliest candidates WITH the
+// data photonEvent needs from them; the proposals are all-gathered and every GPU walks the merged, sorted chain with
+// identical arithmetic, so all copies of LoopState stay bit-identical and only the owner of the scattered photon
+// stores anything.  The chain is trusted up to the smallest `horizon` of the proposals; if the walk needs more
+// (rare: Klein-Nishina rejections) the iteration continues in a "midpass" round that re-reads time_to_scatter
+// beyond the cursor instead of redrawing.
+constexpr int SC_K = 4;              // candidates one GPU proposes per round
+constexpr int SC_MAX_WORLD = 16;
+constexpr int LOOP_DONE = 1;         // LoopState::done values
+constexpr int LOOP_MIDPASS = 2;      // shared clock only: the iteration is not decided yet, the step kernel must not redraw
+
+struct alignas(16) ScRecord {        // one candidate: 176 B
+    double t;                        // time_to_scatter
+    long long gid;                   // global slot
+    double r[3], u[3], p[4], pc[4], s[4];
+    int cell;
+    unsigned flags;
+};
+
+struct alignas(16) ScProposal {      // what one GPU sends per round
+    int n;                           // records that follow
+    int pad0;
+    long long horizon_gid;           // this GPU has told everything it holds with (t, gid) <= (horizon_t, horizon_gid)
+    double horizon_t;
+    double pad1;
+    ScRecord rec[SC_K];
+};
+
+struct alignas(64) ScState {         // per GPU; content identical on every GPU
+    double cursor_t;                 // midpass: last candidate the walk tried
+    long long cursor_gid;
+    double old_scatt_time;           // photonEvent's old_scatt_time across rounds (mclib.c:1138)
+    double t_first;                  // first candidate time of the iteration (shortlist threshold estimate)
+    double cut_mid;                  // midpass: time_to_scatter below this goes on the shortlist
+    int first;                       // no candidate tried yet in this iteration
+    int pad0;
+    long long rounds, midpass_rounds;
 };
 
 }  // namespace mcrat

@@ -56,7 +56,7 @@ struct mcrat_hip_ctx {
     LoopState *h_state = nullptr;     // pinned
     bool frame_open = false;
     int find_switch = 1;
-    RngKey key{0, 0};
+    RngKey key{0, 0, 0};
     long long frame_photon_steps = 0;
 
     // virtual ranks (cfg.virtual_rank_photons > 0): one LoopState per list
@@ -64,6 +64,12 @@ struct mcrat_hip_ctx {
     LoopState *d_rstates = nullptr;
     LoopState *h_rstates = nullptr;   // pinned
     int rstates_cap = 0;
+
+    // one list over several GPUs, one clock (mcrat_hip_shared_clock_*)
+    int sc_world = 0, sc_rank = 0;
+    ScState *d_sc = nullptr;
+    ScProposal *sc_send = nullptr, *sc_recv = nullptr;
+    bool sc_own_send = false, sc_own_recv = false;
 
     // scratch
     ReducePartial *d_red = nullptr;
@@ -178,6 +184,9 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->hy_buf) (void)hipFree(c->hy_buf);
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
+    if (c->d_sc) (void)hipFree(c->d_sc);
+    if (c->sc_own_send && c->sc_send) (void)hipFree(c->sc_send);
+    if (c->sc_own_recv && c->sc_recv) (void)hipFree(c->sc_recv);
     if (c->d_rstates) (void)hipFree(c->d_rstates);
     if (c->h_rstates) (void)hipHostFree(c->h_rstates);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -781,6 +790,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
         HIPCHK(c, hipMemcpyAsync(c->d_rstates, c->h_rstates, sizeof(LoopState) * c->n_ranks, hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
+    if (c->sc_world > 0) HIPCHK(c, hipMemsetAsync(c->d_sc, 0, sizeof(ScState), c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->key.seed = seed;
     c->find_switch = 1;           // mcrat.c:756
@@ -862,6 +872,7 @@ extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_h
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->frame_open) return MCRAT_HIP_ESTATE;
+    if (c->sc_world > 0) { c->last_error = "shared clock attached: drive the frame with mcrat_hip_shared_clock_*"; return MCRAT_HIP_ESTATE; }
     if (c->n_ranks > 0) return run_ranks(c, max_iterations, stats);
     const int per_sync = c->cfg.iterations_per_sync;
     long long it = 0;
@@ -951,6 +962,86 @@ extern "C" int mcrat_hip_step_event(mcrat_hip_ctx *c, mcrat_hip_frame_stats *sta
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fill_stats(c, stats);
     return MCRAT_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- shared clock
+extern "C" size_t mcrat_hip_shared_clock_bytes_per_rank(void) { return sizeof(ScProposal); }
+
+extern "C" int mcrat_hip_shared_clock_attach(mcrat_hip_ctx *c, int world, int rank, long long slot_base, void *send, void *recv)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (world < 1 || world > SC_MAX_WORLD || rank < 0 || rank >= world) return MCRAT_HIP_EINVAL;
+    if (slot_base < 0 || (slot_base & 1) || slot_base > 0xffffffffll - 0x7fffffffll) {
+        c->last_error = "slot_base must be even, non-negative and leave room for 2^31 slots below 2^32";
+        return MCRAT_HIP_EINVAL;
+    }
+    if (c->n_ranks > 0 || c->cfg.virtual_rank_photons > 0) { c->last_error = "shared clock and virtual ranks exclude each other"; return MCRAT_HIP_EINVAL; }
+    if (c->frame_open && c->h_state && !c->h_state->done) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!c->d_sc) HIPCHK(c, hipMalloc((void **)&c->d_sc, sizeof(ScState)));
+    if (c->sc_own_send && c->sc_send) { (void)hipFree(c->sc_send); c->sc_send = nullptr; }
+    if (c->sc_own_recv && c->sc_recv) { (void)hipFree(c->sc_recv); c->sc_recv = nullptr; }
+    c->sc_own_send = c->sc_own_recv = false;
+    if (send) c->sc_send = (ScProposal *)send;
+    else { HIPCHK(c, hipMalloc((void **)&c->sc_send, sizeof(ScProposal))); c->sc_own_send = true; }
+    if (recv) c->sc_recv = (ScProposal *)recv;
+    else if (world == 1) c->sc_recv = c->sc_send;
+    else { HIPCHK(c, hipMalloc((void **)&c->sc_recv, sizeof(ScProposal) * world)); c->sc_own_recv = true; }
+    HIPCHK(c, hipMemset(c->sc_send, 0, sizeof(ScProposal)));
+    if (c->sc_recv != c->sc_send) HIPCHK(c, hipMemset(c->sc_recv, 0, sizeof(ScProposal) * world));
+    c->sc_world = world;
+    c->sc_rank = rank;
+    c->key.slot_base = (uint32_t)slot_base;
+    c->frame_open = false;
+    drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_buffers(mcrat_hip_ctx *c, void **send, void **recv)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (c->sc_world <= 0) return MCRAT_HIP_ESTATE;
+    if (send) *send = c->sc_send;
+    if (recv) *recv = c->sc_recv;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_propose(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, launch_sc_propose(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->d_sc, c->key, c->partials, c->step_blocks,
+                                c->shortlist, c->sc_send, c->stream));
+    c->find_switch = 0;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_resolve(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, launch_sc_resolve(c->kc, c->ph, c->hy, c->d_state, c->d_sc, c->key, c->sc_recv, c->sc_world, c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_poll(mcrat_hip_ctx *c, int *frame_done, mcrat_hip_frame_stats *stats)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (frame_done) *frame_done = c->h_state->done == LOOP_DONE;
+    fill_stats(c, stats);
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_finish(mcrat_hip_ctx *c, mcrat_hip_frame_stats *stats)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
+    int rc;
+    if ((rc = flush_pending(c))) return rc;
+    return mcrat_hip_shared_clock_poll(c, nullptr, stats);
 }
 
 // ---------------------------------------------------------------------------------------------- reductions

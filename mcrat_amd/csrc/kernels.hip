@@ -297,8 +297,9 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         } else {
             ntau = ph.ntau[h];
         }
-        const Philox4 blk = keyed_block(key.seed, iter, (uint32_t)(rng_slot >> 1), RNG_FREEPATH, key.stream);
-        const uint64_t bits = (rng_slot & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
+        const uint32_t gslot = (uint32_t)rng_slot + key.slot_base;
+        const Philox4 blk = keyed_block(key.seed, iter, gslot >> 1, RNG_FREEPATH, key.stream);
+        const uint64_t bits = (gslot & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
                                              : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
         t = sample_free_time(ntau, bits);
     } else {
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev
         // one Philox block serves both slots of the pair
         Philox4 blk;
         if (MC_DIAG(DIAG_SKIP_PHILOX)) { blk.w[0] = pair * 2654435761u; blk.w[1] = pair ^ 0x9e3779b9u; blk.w[2] = ~blk.w[0]; blk.w[3] = blk.w[1] + 7u; }
-        else blk = keyed_block(key.seed, iter, (uint32_t)pair, RNG_FREEPATH, key.stream);
+        else blk = keyed_block(key.seed, iter, (uint32_t)pair + (key.slot_base >> 1), RNG_FREEPATH, key.stream);
         const uint64_t bits0 = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
         const uint64_t bits1 = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
 
@@ -467,6 +468,61 @@ struct EventWalk {
     bool first;           // the next candidate is the head of the sorted list
 };
 
+// the physics of one candidate between mclib.c:1144 and :1322: fluid frame at the photon's azimuth, Stokes rotation
+// into the comoving frame, electron draw, singleScatter, boost back.  r is the candidate's position at the event.
+// Returns false on a Klein-Nishina rejection (p, pc, s are then unspecified, nothing was stored).  tau_new is the
+// optical depth of the new momentum in the cached cell (see commit_scatter).
+template <int DIMS, int GEOM, bool STOKES>
+__device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter,
+                                             uint32_t rng_slot, int cell, const double r[3], double p[4], double pc[4], double s[4],
+                                             double &fluid_temp, double &tau_new)
+{
+    MC_STAMP(st, 2);
+    fluid_temp = hy.temp[cell];                            // mclib.c:1148
+    double cphi, sphi;
+    phys::cos_sin_of_atan2(r[1], r[0], cphi, sphi);        // ph_phi, mclib.c:1151
+    double beta[3];
+    phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);     // mclib.c:1167-1174
+    if constexpr (STOKES) phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
+    EventStream rng = event_stream(key.seed, iter, rng_slot, key.stream);
+    const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
+    double el[4];
+    MC_STAMP(st, 3);
+    phys::single_thermal_electron(el, fluid_temp, k2e, pc, rng);       // mclib.c:1234
+    MC_STAMP(st, 4);
+    if (!phys::single_scatter<STOKES>(el, pc, s, rng)) return false;   // mclib.c:1245
+    MC_STAMP(st, 5);
+    const double nb[3] = {-1 * beta[0], -1 * beta[1], -1 * beta[2]};
+    phys::lorentz_boost(nb, pc, p, true);                              // mclib.c:1265
+    if constexpr (STOKES) phys::stokes_rotation(nb, pc + 1, p + 1, s); // mclib.c:1280
+    // recalc_properties = 1 (mclib.c:1322).  The optical depth the next pass would recompute for this slot in its
+    // cached cell (calcMeanFreePath, mclib.c:668-673: same position, same cell record, the new momentum) is computed
+    // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
+    const CellFluid f = hy.fluid[cell];
+    tau_new = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p[1], p[2], p[3]);
+    return true;
+}
+
+// stores of a successful scatter, mclib.c:1290-1322
+template <bool STOKES>
+__device__ __forceinline__ void commit_scatter(const PhotonDev &ph, int i, const double p[4], const double pc[4], const double s[4],
+                                               const double r[3], double tau_new, unsigned cand_flags)
+{
+    const int h = i - ph.hot_bias;
+    if constexpr (STOKES) { ph.s0[i] = s[0]; ph.s1[i] = s[1]; ph.s2[i] = s[2]; ph.s3[i] = s[3]; }
+    ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
+    {
+        const double d = 1.0 / p[0];                                   // mclib.c:1074-1080 factors of the new momentum
+        ph.u0[h] = p[1] * d * C_LIGHT; ph.u1[h] = p[2] * d * C_LIGHT; ph.u2[h] = p[3] * d * C_LIGHT;
+    }
+    ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
+    ph.r0[h] = r[0]; ph.r1[h] = r[1]; ph.r2[h] = r[2];              // already advanced: the next step kernel skips it
+    ph.num_scatt[i] += 1;                                              // mclib.c:1317
+    ph.tau_next[i] = tau_new;
+    ph.ntau[h] = -1.0 / tau_new;
+    ph.flags[h] = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
+}
+
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
 template <int DIMS, int GEOM, bool STOKES>
 __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
@@ -507,48 +563,12 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
             r[2] += u2 * w.seg[k];
         }
     }
-    MC_STAMP(st, 2);
-    const double fluid_temp = hy.temp[cell];               // mclib.c:1148
-    double cphi, sphi;
-    phys::cos_sin_of_atan2(r[1], r[0], cphi, sphi);        // ph_phi, mclib.c:1151
-    double beta[3];
-    phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);     // mclib.c:1167-1174
-    if constexpr (STOKES) phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
-    EventStream rng = event_stream(key.seed, iter, (uint32_t)(i - slot_base), key.stream);
-    const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
-    double el[4];
-    MC_STAMP(st, 3);
-    phys::single_thermal_electron(el, fluid_temp, k2e, pc, rng);       // mclib.c:1234
-    MC_STAMP(st, 4);
-    if (!phys::single_scatter<STOKES>(el, pc, s, rng)) {               // mclib.c:1245
+    double fluid_temp, tau_new;
+    if (!scatter_core<DIMS, GEOM, STOKES>(hy, st, key, iter, (uint32_t)(i - slot_base) + key.slot_base, cell, r, p, pc, s, fluid_temp, tau_new)) {
         w.rej += 1;
         return EV_RUNNING;
     }
-    MC_STAMP(st, 5);
-    const double nb[3] = {-1 * beta[0], -1 * beta[1], -1 * beta[2]};
-    phys::lorentz_boost(nb, pc, p, true);                              // mclib.c:1265
-    if constexpr (STOKES) {
-        phys::stokes_rotation(nb, pc + 1, p + 1, s);                   // mclib.c:1280
-        ph.s0[i] = s[0]; ph.s1[i] = s[1]; ph.s2[i] = s[2]; ph.s3[i] = s[3];
-    }
-    ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
-    {
-        const double d = 1.0 / p[0];                                   // mclib.c:1074-1080 factors of the new momentum
-        ph.u0[h] = p[1] * d * C_LIGHT; ph.u1[h] = p[2] * d * C_LIGHT; ph.u2[h] = p[3] * d * C_LIGHT;
-    }
-    ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
-    ph.r0[h] = r[0]; ph.r1[h] = r[1]; ph.r2[h] = r[2];              // already advanced: the next step kernel skips it
-    ph.num_scatt[i] += 1;                                              // mclib.c:1317
-    // recalc_properties = 1 (mclib.c:1322).  The optical depth the next pass would recompute for this slot in its
-    // cached cell (calcMeanFreePath, mclib.c:668-673: same position, same cell record, the new momentum) is computed
-    // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
-    {
-        const CellFluid f = hy.fluid[cell];
-        const double tau = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p[1], p[2], p[3]);
-        ph.tau_next[i] = tau;
-        ph.ntau[h] = -1.0 / tau;
-    }
-    ph.flags[h] = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
+    commit_scatter<STOKES>(ph, i, p, pc, s, r, tau_new, cand_flags);
     st->frame_scatt_cnt += 1;                                          // mclib.c:1318
     st->last_scattered_temp = fluid_temp;
     w.skip = i;
@@ -732,7 +752,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
     if (tid == 0) st = states[rank];
     __syncthreads();
     if (st.done || n <= 0) return;
-    const RngKey rk = {key.seed, key.stream + (uint32_t)rank};
+    const RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
 
     // LDS residency: the columns every pass touches (r, u, -1/tau, cell index, flags: 61 B per slot) are copied into
     // LDS once per launch and written back at the end; `ph` is the same PhotonDev with those column pointers aimed
@@ -868,6 +888,285 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             }
         }
         if (tid == 0) { st.nseg = 0; st.skip_idx = -1; states[rank] = st; }
+    }
+}
+
+// ------------------------------------------------------------------ one list over several GPUs, one clock
+// (device_types.hpp, "ScProposal").  A round is: step_kernel (returns at once in a midpass round) ->
+// sc_midpass_kernel (returns at once unless midpass) -> sc_propose_kernel -> all-gather of the proposals (host:
+// RCCL / MPI) -> sc_resolve_kernel.  Global slot = key.slot_base + local slot; ties are broken by global slot, as
+// the single-list engine breaks them by slot.
+__device__ __forceinline__ bool sc_less(double ta, long long ga, double tb, long long gb)
+{
+    return (ta < tb) || (ta == tb && ga < gb);
+}
+
+// midpass: apply the advance the walk has accumulated so far (mclib.c:1138 for every candidate already tried) and
+// collect the candidates beyond the cursor from time_to_scatter -- the free times of this iteration are NOT redrawn
+__global__ __launch_bounds__(STEP_BLOCK) void sc_midpass_kernel(PhotonDev ph, const LoopState *__restrict__ st, const ScState *__restrict__ sc,
+                                                                RngKey key, Cand *__restrict__ block_min, Shortlist *sl)
+{
+    __shared__ double s_wt[STEP_BLOCK / 64];
+    __shared__ int s_wi[STEP_BLOCK / 64];
+    if (st->done != LOOP_MIDPASS) return;
+    const int nseg = st->nseg;
+    const double cur_t = sc->cursor_t, cut = sc->cut_mid;
+    const long long cur_g = sc->cursor_gid;
+    const int G = gridDim.x, lane = threadIdx.x & 63;
+    const int nchunks = ph.n_pad / (2 * STEP_BLOCK);
+    MinCand best;
+    best.init();
+    for (int chunk = xcd_contiguous_chunk(blockIdx.x, G); chunk < nchunks; chunk += G) {
+        const int i0 = (chunk * STEP_BLOCK + threadIdx.x) << 1;
+        PairIn in = load_pair(ph, i0, nseg > 0);
+        if (nseg > 0) {
+            const bool m0 = (in.FL.x & FLAG_MOVES) != 0, m1 = (in.FL.y & FLAG_MOVES) != 0;
+            for (int s = 0; s < nseg; ++s) {
+                const double t = st->seg[s];
+                if (m0) { in.R0.x += in.U0.x * t; in.R1.x += in.U1.x * t; in.R2.x += in.U2.x * t; }
+                if (m1) { in.R0.y += in.U0.y * t; in.R1.y += in.U1.y * t; in.R2.y += in.U2.y * t; }
+            }
+            *reinterpret_cast<double2 *>(ph.r0 + i0) = in.R0;
+            *reinterpret_cast<double2 *>(ph.r1 + i0) = in.R1;
+            *reinterpret_cast<double2 *>(ph.r2 + i0) = in.R2;
+        }
+        const double2 T = *reinterpret_cast<const double2 *>(ph.tts + i0);
+        double t0 = T.x, t1 = T.y;
+        if (t0 != t0) t0 = INFINITY;
+        if (t1 != t1) t1 = INFINITY;
+        if ((in.FL.x & FLAG_VALID) && sc_less(cur_t, cur_g, t0, (long long)key.slot_base + i0)) {
+            best.offer(t0, i0);
+            if (t0 < cut) shortlist_push(sl, t0, i0);
+        }
+        if ((in.FL.y & FLAG_VALID) && sc_less(cur_t, cur_g, t1, (long long)key.slot_base + i0 + 1)) {
+            best.offer(t1, i0 + 1);
+            if (t1 < cut) shortlist_push(sl, t1, i0 + 1);
+        }
+    }
+    wave_min_pair_dpp(best.t, best.i);
+    if (lane == 0) { s_wt[threadIdx.x >> 6] = best.t; s_wi[threadIdx.x >> 6] = best.i; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinCand m;
+        m.init();
+#pragma unroll
+        for (int w = 0; w < STEP_BLOCK / 64; ++w) m.offer(s_wt[w], s_wi[w]);
+        Cand c;
+        c.t = m.t; c.idx = m.i; c.pad = 0;
+        block_min[blockIdx.x] = c;
+    }
+}
+
+// this GPU's earliest candidates of the round, with their data, into `out`
+template <bool STOKES>
+__global__ __launch_bounds__(EVENT_BLOCK) void sc_propose_kernel(PhotonDev ph, LoopState *st, const ScState *__restrict__ sc, RngKey key,
+                                                                 const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl,
+                                                                 ScProposal *__restrict__ out)
+{
+    static_assert(EVENT_BLOCK == SHORTLIST_CAP, "one thread per shortlist entry");
+    __shared__ Cand s_raw[SHORTLIST_CAP];
+    __shared__ Cand s_list[SHORTLIST_CAP];
+    __shared__ double s_wt[EVENT_BLOCK / 64];
+    __shared__ int s_wi[EVENT_BLOCK / 64];
+    const int tid = threadIdx.x;
+    const int done = st->done;
+    if (done == LOOP_DONE) return;
+    const bool midpass = done == LOOP_MIDPASS;
+    const double cut = midpass ? sc->cut_mid : st->t_cut;          // the threshold the shortlist was filled with
+    const int n_raw = sl->count;
+    const Cand mine = sl->items[tid];
+    MinCand m;
+    m.init();
+    for (int e = tid; e < n_blocks; e += EVENT_BLOCK) m.offer(block_min[e].t, block_min[e].idx);
+    if (tid < n_raw) s_raw[tid] = mine;
+    wave_min_pair_dpp(m.t, m.i);
+    if ((tid & 63) == 0) { s_wt[tid >> 6] = m.t; s_wi[tid >> 6] = m.i; }
+    __syncthreads();
+    MinCand g;
+    g.init();
+#pragma unroll
+    for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(s_wt[wv], s_wi[wv]);
+
+    int n_list = (n_raw > SHORTLIST_CAP) ? 0 : n_raw;              // overflowed: incomplete, ignore it
+    if (tid < n_list) {
+        const Cand me = s_raw[tid];
+        int rank = 0;
+        for (int j = 0; j < n_list; ++j) rank += cand_less(s_raw[j].t, s_raw[j].idx, me.t, me.idx) ? 1 : 0;
+        s_list[rank] = me;
+    }
+    // what this GPU vouches for: with a usable shortlist, everything below `cut` (or up to its SC_K-th entry);
+    // without one, only its minimum
+    double hor_t;
+    long long hor_g;
+    int n_out;
+    if (n_list == 0) {
+        if (tid == 0) { s_list[0].t = g.t; s_list[0].idx = g.i; }
+        if (g.i == INT_MAX) { n_out = 0; hor_t = INFINITY; hor_g = LLONG_MAX; }      // nothing left to try on this GPU
+        else { n_out = 1; hor_t = g.t; hor_g = (long long)key.slot_base + g.i; }
+    } else if (n_list > SC_K) {
+        n_out = SC_K;
+        hor_t = 0; hor_g = 0;                                       // filled below from the SC_K-th entry
+    } else {
+        n_out = n_list;
+        hor_t = cut; hor_g = -1;
+    }
+    __syncthreads();
+    if (n_list > SC_K) { hor_t = s_list[SC_K - 1].t; hor_g = (long long)key.slot_base + s_list[SC_K - 1].idx; }
+    if (tid < n_out) {
+        const int i = s_list[tid].idx;
+        ScRecord rec;
+        rec.t = s_list[tid].t;
+        rec.gid = (long long)key.slot_base + i;
+        rec.r[0] = ph.r0[i]; rec.r[1] = ph.r1[i]; rec.r[2] = ph.r2[i];
+        rec.u[0] = ph.u0[i]; rec.u[1] = ph.u1[i]; rec.u[2] = ph.u2[i];
+        rec.p[0] = ph.p0[i]; rec.p[1] = ph.p1[i]; rec.p[2] = ph.p2[i]; rec.p[3] = ph.p3[i];
+        rec.pc[0] = ph.c0[i]; rec.pc[1] = ph.c1[i]; rec.pc[2] = ph.c2[i]; rec.pc[3] = ph.c3[i];
+        if constexpr (STOKES) { rec.s[0] = ph.s0[i]; rec.s[1] = ph.s1[i]; rec.s[2] = ph.s2[i]; rec.s[3] = ph.s3[i]; }
+        else { rec.s[0] = 1; rec.s[1] = 0; rec.s[2] = 0; rec.s[3] = 0; }
+        rec.cell = ph.idx[i];
+        rec.flags = ph.flags[i];
+        out->rec[tid] = rec;
+    }
+    if (tid == 0) {
+        out->n = n_out; out->pad0 = 0; out->horizon_t = hor_t; out->horizon_gid = hor_g; out->pad1 = 0;
+        sl->count = 0;
+        if (midpass) st->nseg = 0;                                  // sc_midpass_kernel has applied them
+    }
+}
+
+// every GPU: merge the gathered proposals, walk the chain as photonEvent does (mclib.c:1128-1339), store the
+// scatter if the photon is ours, and do the bookkeeping of mcrat.c:782-784 / 837-845 -- identically everywhere
+template <int DIMS, int GEOM, bool STOKES>
+__global__ __launch_bounds__(EVENT_BLOCK) void sc_resolve_kernel(PhotonDev ph, HydroDev hy, LoopState *st, ScState *sc, RngKey key,
+                                                                 const ScProposal *__restrict__ all, int world)
+{
+    __shared__ ScRecord s_rec[SC_MAX_WORLD * SC_K];
+    __shared__ int s_order[SC_MAX_WORLD * SC_K];
+    __shared__ int s_off[SC_MAX_WORLD + 1];
+    __shared__ double s_seg[MAX_SEG];
+    const int tid = threadIdx.x;
+    const int done = st->done;
+    if (done == LOOP_DONE) return;
+    if (tid == 0) {
+        int o = 0;
+        for (int g = 0; g < world; ++g) { s_off[g] = o; int n = all[g].n; n = n < 0 ? 0 : (n > SC_K ? SC_K : n); o += n; }
+        s_off[world] = o;
+    }
+    __syncthreads();
+    const int E = s_off[world];
+    if (tid < world * SC_K) {
+        const int g = tid / SC_K, k = tid % SC_K;
+        if (k < s_off[g + 1] - s_off[g]) s_rec[s_off[g] + k] = all[g].rec[k];
+    }
+    __syncthreads();
+    if (tid < E) {                                                   // rank sort by (t, gid); pairs are distinct
+        int rank = 0;
+        for (int j = 0; j < E; ++j) rank += sc_less(s_rec[j].t, s_rec[j].gid, s_rec[tid].t, s_rec[tid].gid) ? 1 : 0;
+        s_order[rank] = tid;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+
+    double hor_t = INFINITY;
+    long long hor_g = LLONG_MAX;
+    for (int g = 0; g < world; ++g)
+        if (sc_less(all[g].horizon_t, all[g].horizon_gid, hor_t, hor_g)) { hor_t = all[g].horizon_t; hor_g = all[g].horizon_gid; }
+
+    const bool midpass = done == LOOP_MIDPASS;
+    const unsigned long long iter = st->iteration;
+    const double dt_max = st->remaining_time;
+    double old_scatt_time = midpass ? sc->old_scatt_time : 0.0;
+    bool first = midpass ? (sc->first != 0) : true;
+    double t_first = midpass ? sc->t_first : ((E > 0) ? s_rec[s_order[0]].t : INFINITY);
+    int nseg = midpass ? 0 : 0;
+    int last_idx = st->last_scattered_index;
+    long long rej = 0;
+    int skip = -1;
+    double dt = 0;
+    bool decided = false;
+    double last_t = midpass ? sc->cursor_t : 0.0;
+    long long last_g = midpass ? sc->cursor_gid : -1;
+    const long long lo = (long long)key.slot_base, hi = lo + ph.n;
+
+    for (int e = 0; e < E && !decided; ++e) {
+        const ScRecord &c = s_rec[s_order[e]];
+        if (sc_less(hor_t, hor_g, c.t, c.gid)) break;               // beyond what every GPU vouches for
+        if (nseg == MAX_SEG) break;                                 // continue in a midpass round: segments are never merged
+        const bool in_frame = c.t < dt_max;
+        if (!(first && !in_frame)) last_idx = (int)c.gid;           // *scattered_ph_index, as a GLOBAL slot
+        first = false;
+        if (!in_frame) {                                            // mclib.c:1327-1335
+            s_seg[nseg++] = dt_max - old_scatt_time;
+            dt = dt_max;
+            decided = true;
+            break;
+        }
+        s_seg[nseg++] = c.t - old_scatt_time;                       // mclib.c:1138
+        old_scatt_time = c.t;
+        last_t = c.t; last_g = c.gid;
+        if (c.cell == -1) continue;
+        double r[3] = {c.r[0], c.r[1], c.r[2]};
+        if (c.flags & FLAG_MOVES) {
+            for (int k = 0; k < nseg; ++k) {
+                r[0] += c.u[0] * s_seg[k];
+                r[1] += c.u[1] * s_seg[k];
+                r[2] += c.u[2] * s_seg[k];
+            }
+        }
+        double p[4] = {c.p[0], c.p[1], c.p[2], c.p[3]};
+        double pc[4] = {c.pc[0], c.pc[1], c.pc[2], c.pc[3]};
+        double s[4] = {c.s[0], c.s[1], c.s[2], c.s[3]};
+        double fluid_temp, tau_new;
+        if (!scatter_core<DIMS, GEOM, STOKES>(hy, st, key, iter, (uint32_t)c.gid, c.cell, r, p, pc, s, fluid_temp, tau_new)) {
+            rej += 1;
+            continue;
+        }
+        if (c.gid >= lo && c.gid < hi) {                            // ours
+            skip = (int)(c.gid - lo);
+            commit_scatter<STOKES>(ph, skip, p, pc, s, r, tau_new, c.flags);
+        }
+        st->frame_scatt_cnt += 1;                                   // mclib.c:1318
+        st->last_scattered_temp = fluid_temp;
+        dt = c.t;
+        decided = true;
+    }
+    if (!decided && hor_t == INFINITY && hor_g == LLONG_MAX && nseg < MAX_SEG) {
+        // every GPU has run out of slots to try: the loop of mclib.c:1128 ends
+        dt = first ? dt_max : old_scatt_time;
+        decided = true;
+    }
+    st->kn_rejections += rej;
+    st->last_scattered_index = last_idx;
+    st->nseg = nseg;
+    for (int k = 0; k < MAX_SEG; ++k) st->seg[k] = (k < nseg) ? s_seg[k] : 0.0;
+    sc->rounds += 1;
+    if (decided) {                                                  // mcrat.c:782-784 / 837-845
+        st->time_now += dt;
+        const double rem = dt_max - dt;
+        st->remaining_time = rem;
+        st->last_time_step = dt;
+        st->iteration = iter + 1;
+        st->iterations += 1;
+        st->done = !(rem > 0) ? LOOP_DONE : 0;
+        st->skip_idx = skip;
+        if (t_first < INFINITY) {
+            const double t_est = st->t_est;
+            const double est = (t_est > 0) ? 0.875 * t_est + 0.125 * t_first : t_first;
+            st->t_est = est;
+            st->t_cut = 8.0 * est;
+        }
+    } else {
+        st->done = LOOP_MIDPASS;
+        st->skip_idx = -1;
+        st->rescans += 1;
+        sc->midpass_rounds += 1;
+        sc->cursor_t = last_t;
+        sc->cursor_gid = last_g;
+        sc->old_scatt_time = old_scatt_time;
+        sc->first = first ? 1 : 0;
+        sc->t_first = t_first;
+        const double est = (st->t_est > 0) ? st->t_est : last_t;
+        sc->cut_mid = last_t + 8.0 * est;
     }
 }
 
@@ -1074,6 +1373,27 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
         };
         if (kc.stokes) launch(rank_loop_kernel<DV, GV, true>);
         else launch(rank_loop_kernel<DV, GV, false>);
+    });
+}
+
+hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream)
+{
+    hipError_t e = launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream);
+    if (e != hipSuccess) return e;
+    sc_midpass_kernel<<<dim3(blocks), dim3(STEP_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, sl);
+    if (kc.stokes) sc_propose_kernel<true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, blocks, sl, out);
+    else sc_propose_kernel<false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, blocks, sl, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
+                             const ScProposal *all, int world, hipStream_t stream)
+{
+    return dispatch(kc, [&](auto D, auto G) {
+        constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
+        if (kc.stokes) sc_resolve_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, sc, key, all, world);
+        else sc_resolve_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, sc, key, all, world);
     });
 }
 

@@ -29,6 +29,12 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 // virtual ranks: every workgroup runs the whole loop of one independent photon list of `rank_photons` slots
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_photons, long long max_passes, hipStream_t stream);
+// one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...
+hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+// ... and, after the host has all-gathered the proposals into `all`, the replicated walk of photonEvent
+hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
+                             const ScProposal *all, int world, hipStream_t stream);
 // apply the pending advance (end of run / before photons are read back) and clear it
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);

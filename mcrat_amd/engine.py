@@ -108,6 +108,13 @@ SYMBOLS = {
     "mcrat_hip_rank_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(FrameStats)]),
     "mcrat_hip_step_locate_sample": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_step_event": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
+    "mcrat_hip_shared_clock_bytes_per_rank": (C.c_size_t, []),
+    "mcrat_hip_shared_clock_attach": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "mcrat_hip_shared_clock_buffers": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mcrat_hip_shared_clock_propose": (C.c_int, [_ctx]),
+    "mcrat_hip_shared_clock_resolve": (C.c_int, [_ctx]),
+    "mcrat_hip_shared_clock_poll": (C.c_int, [_ctx, _ip, C.POINTER(FrameStats)]),
+    "mcrat_hip_shared_clock_finish": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_ph_minmax": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
     "mcrat_hip_scatt_stats": (C.c_int, [_ctx, _ip, _ip, _dp, _dp]),
     "mcrat_hip_avg_energy": (C.c_int, [_ctx, _dp]),
@@ -127,6 +134,13 @@ def load_library():
             raise RuntimeError(
                 "libmcrat_hip.so is missing (%s): build it with `python -m mcrat_amd.build`; "
                 "there is no CPU fallback for the photon loop" % LIB_PATH)
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64, and torch finds no GPU if the
+        # system copy was mapped first.  Loading torch first makes this library bind to the copy torch uses, so that
+        # torch streams / tensors / collectives and the engine share one runtime (shared_clock.py, bench.py).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(lib, name)
@@ -285,6 +299,32 @@ class Engine:
     def step_event(self):
         st = FrameStats()
         self._check(self.lib.mcrat_hip_step_event(self.ctx, C.byref(st)), "step_event")
+        return st
+
+    # ---- one list over several GPUs, one clock (mcrat_amd/shared_clock.py drives these)
+    def shared_clock_bytes_per_rank(self):
+        return int(self.lib.mcrat_hip_shared_clock_bytes_per_rank())
+
+    def shared_clock_attach(self, world, rank, slot_base, send_ptr=None, recv_ptr=None):
+        self._check(self.lib.mcrat_hip_shared_clock_attach(self.ctx, int(world), int(rank), int(slot_base),
+                                                           C.c_void_p(send_ptr) if send_ptr else None,
+                                                           C.c_void_p(recv_ptr) if recv_ptr else None), "shared_clock_attach")
+
+    def shared_clock_propose(self):
+        self._check(self.lib.mcrat_hip_shared_clock_propose(self.ctx), "shared_clock_propose")
+
+    def shared_clock_resolve(self):
+        self._check(self.lib.mcrat_hip_shared_clock_resolve(self.ctx), "shared_clock_resolve")
+
+    def shared_clock_poll(self):
+        st = FrameStats()
+        done = C.c_int(0)
+        self._check(self.lib.mcrat_hip_shared_clock_poll(self.ctx, C.byref(done), C.byref(st)), "shared_clock_poll")
+        return bool(done.value), st
+
+    def shared_clock_finish(self):
+        st = FrameStats()
+        self._check(self.lib.mcrat_hip_shared_clock_finish(self.ctx, C.byref(st)), "shared_clock_finish")
         return st
 
     # ---- reductions

@@ -18,9 +18,17 @@ def shard_bounds(n_photons, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def shard_photons(ph, world_size, rank):
+def shard_bounds_even(n_photons, world_size, rank):
+    """like shard_bounds, but every boundary is an even slot (the shared-clock mode pairs slots for its free-path
+    random numbers, rng.hpp); only the last shard may hold an odd count."""
+    pairs = (int(n_photons) + 1) // 2
+    lo, hi = shard_bounds(pairs, world_size, rank)
+    return min(2 * lo, int(n_photons)), min(2 * hi, int(n_photons))
+
+
+def shard_photons(ph, world_size, rank, even=False):
     n = len(ph["p0"])
-    lo, hi = shard_bounds(n, world_size, rank)
+    lo, hi = (shard_bounds_even if even else shard_bounds)(n, world_size, rank)
     return {k: (v[lo:hi].copy() if hasattr(v, "__len__") and len(v) == n else v) for k, v in ph.items()}
 
 
