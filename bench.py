@@ -113,7 +113,7 @@ def cpu_baseline_ranks(frame, ph, cfg, per, n_ranks):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--mode", choices=("ranks", "list"), default="ranks")
+    ap.add_argument("--mode", choices=("ranks", "list", "shared-clock"), default="ranks")
     ap.add_argument("--steps", type=int, default=0, help="ranks: frames (default 20); list: loop passes (default 2000)")
     ap.add_argument("--warmup", type=int, default=-1, help="ranks: frames (default 2); list: passes (default 50)")
     ap.add_argument("--photons", type=int, default=1_000_000, help="photon slots per GPU")
@@ -124,9 +124,13 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=300, help="list-mode passes bracketed by HIP events for the roofline")
     ap.add_argument("--other-mode", type=int, default=1, help="also measure the other run shape briefly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shared-clock-rounds", type=int, default=300,
+                    help="also time this many rounds of the one-list-over-all-GPUs mode (0: skip)")
     args = ap.parse_args()
     steps = args.steps if args.steps > 0 else (20 if args.mode == "ranks" else 2000)
     warmup = args.warmup if args.warmup >= 0 else (2 if args.mode == "ranks" else 50)
+    if args.photons % 2:
+        raise SystemExit("--photons must be even")
 
     import torch
     from mcrat_amd import engine, synth
@@ -271,10 +275,40 @@ def main():
                     relocations_per_pass=(st.num_photons_find_new_element - rel0) / k_steps,
                     kn_rejections=st.kn_rejections, rescans=st.rescans)
 
+    def measure_shared(k_rounds, k_warm):
+        """ONE list of world x n photons with one clock, its slots spread over the GPUs (mcrat_amd/shared_clock.py):
+        per round every GPU steps its own slots, the 736-B proposals are all-gathered (RCCL), and every GPU walks the
+        merged candidates.  A round decides one loop pass unless it ends undecided (midpass, Klein-Nishina chains)."""
+        from mcrat_amd import shared_clock
+        e = shared_clock.make_engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, rng_stream=0)
+        e.set_hydro(frame)
+        e.set_photons(ph)
+        sc = shared_clock.SharedClock(e, world, rank, rank * n, host_staged=(one_device and world > 1))
+        e.begin_frame(SEED, 0.0, remaining)
+        with torch.cuda.stream(sc.stream):
+            for _ in range(k_warm):
+                sc.round()                                   # includes the forced re-location pass
+            _, w = e.shared_clock_poll()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(k_rounds):
+                sc.round()
+            done, st = e.shared_clock_poll()
+            sync()
+            dt = time.perf_counter() - t0
+        if done:
+            raise SystemExit("the frame ended inside the timed rounds; lower the round count")
+        passes = st.iterations - w.iterations
+        e.close()
+        return dict(events=st.frame_scatt_cnt - w.frame_scatt_cnt, photon_steps=n * passes, passes=passes, seconds=dt,
+                    roofline=None, midpass_rounds=st.rescans - w.rescans, rounds=k_rounds)
+
     if args.mode == "ranks":
         main_res = measure_ranks(steps, warmup, rank == 0)
-    else:
+    elif args.mode == "list":
         main_res = measure_list(steps, warmup, args.profile_steps if rank == 0 else 0)
+    else:
+        main_res = measure_shared(steps, warmup)
 
     t_max, events_all, steps_all = main_res["seconds"], float(main_res["events"]), float(main_res["photon_steps"])
     if dist is not None:
@@ -283,6 +317,8 @@ def main():
         c = torch.tensor([events_all, steps_all], dtype=torch.float64, device=red_dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         t_max, events_all, steps_all = float(t.item()), float(c[0].item()), float(c[1].item())
+        if args.mode == "shared-clock":
+            events_all = float(main_res["events"])       # one list: every GPU counts the same events
 
     other = None
     if rank == 0 and world == 1 and args.other_mode:
@@ -298,6 +334,24 @@ def main():
                      "ms_per_step": r["seconds"] * 1e3 / 5, "scatter_events_per_s": r["events"] / r["seconds"],
                      "photon_steps_per_s": r["photon_steps"] / r["seconds"], "roofline": r["roofline"]}
 
+    # the one-list-over-all-GPUs mode, timed briefly beside the main result.  It is the only part of this file with a
+    # data-path collective; a watchdog makes sure that a stuck collective costs this extra, not the bench line.
+    shared = None
+    if args.mode != "shared-clock" and args.shared_clock_rounds > 0:
+        import threading
+        state = {"line": None}
+
+        def give_up():
+            if rank == 0 and state["line"] is not None:
+                state["line"]["shared_clock"] = {"error": "no result within 120 s"}
+                print(json.dumps(state["line"]), flush=True)
+            os._exit(0)
+
+        timer = threading.Timer(120.0, give_up)
+        timer.daemon = True
+    else:
+        timer = None
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.mode == "ranks":
@@ -310,8 +364,11 @@ def main():
             shape = ("%d virtual ranks x %d photons (independent lists, own clock and RNG stream each; one workgroup per list); "
                      "step = one hydro frame (1/fps = %.2f s) for all lists, restarted from the resident snapshot"
                      % (main_res.get("ranks", 0), args.rank_photons, remaining))
-        else:
+        elif args.mode == "list":
             shape = "one list, one clock; step = one loop pass over all photons"
+        else:
+            shape = ("ONE list of %d photons with one clock, its slots spread over %d GPU(s); step = one round: own slots "
+                     "stepped, 736-B proposals all-gathered (RCCL), merged candidates walked on every GPU" % (n * world, world))
         out = {
             "metric": "photon-scatter-events/sec at 1e6 photons, 2D FLASH jet",
             "value": events_all / t_max,
@@ -330,7 +387,8 @@ def main():
                                    % (frame["num_elements"], n, "on" if args.stokes else "off", shape),
                        "mode": args.mode, "photons_per_gpu": n, "cells": int(frame["num_elements"]),
                        "rank_photons": args.rank_photons if args.mode == "ranks" else None,
-                       "parallelism": "independent photon shards x%d" % world},
+                       "parallelism": ("one list, slots sharded x%d, all-gather per round" % world) if args.mode == "shared-clock"
+                                      else "independent photon shards x%d" % world},
             "photon_steps_per_s": steps_all / t_max,
             "scatter_events": events_all,
             "loop_passes": main_res["passes"],
@@ -338,7 +396,33 @@ def main():
             "other_mode": other,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+    else:
+        out = None
+    if timer is not None:
+        state["line"] = out
+        timer.start()
+        try:
+            r = measure_shared(args.shared_clock_rounds, 20)
+            tt = torch.tensor([r["seconds"]], dtype=torch.float64, device=red_dev)
+            if dist is not None:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sec = float(tt.item())
+            shared = {"mode": "shared-clock", "note": "ONE list of %d photons with one clock, slots spread over %d GPU(s); per "
+                      "round one all-gather of 736 B per GPU (RCCL) and a replicated photonEvent walk" % (n * world, world),
+                      "photons_total": n * world, "rounds": r["rounds"], "loop_passes": r["passes"], "midpass_rounds": r["midpass_rounds"],
+                      "ms_per_round": sec * 1e3 / r["rounds"], "scatter_events_per_s": r["events"] / sec,
+                      "photon_steps_per_s": float(n) * world * r["passes"] / sec}
+        except BaseException as ex:          # the bench line matters more than this extra
+            shared = {"error": "%s: %s" % (type(ex).__name__, ex)}
+            if out is not None:
+                out["shared_clock"] = shared
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        timer.cancel()
+        if out is not None:
+            out["shared_clock"] = shared
+    if out is not None:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
