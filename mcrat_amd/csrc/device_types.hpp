@@ -82,9 +82,24 @@ struct alignas(32) FatCell {
     int pad;
 };
 
+// one bucket of the lookup grid: its list, and for each octant (half a bucket per axis; quadrant in 2-D) the one
+// list entry whose cell covers that octant, if exactly one cell reaches into it.  A point well inside an octant
+// and well inside the hinted cell is in no other cell, so a lookup then costs this record and ONE FatCell
+// (112 B) instead of the whole list; every other point takes the exact list walk.
+constexpr unsigned GRID_NO_HINT = 15u;
+constexpr int GRID_CODE_OCT_SHIFT = 27;      // bucket code = bucket | octant << 27 | (position usable for a hint) << 30
+constexpr int GRID_CODE_HINT_OK = 1 << 30;
+constexpr int GRID_CODE_BUCKET_MASK = (1 << GRID_CODE_OCT_SHIFT) - 1;
+struct alignas(16) BucketDir {
+    int e0;                      // first entry in GridDev::cells
+    int n;                       // entries
+    unsigned hints;              // 4 bits per octant: entry offset 0..14, GRID_NO_HINT = none
+    unsigned pad;
+};
+
 struct GridDev {
-    const int *start;            // [nb+1]
-    const FatCell *cells;        // [start[nb]], ascending in cell index inside each bucket
+    const BucketDir *dir;        // [nb]
+    const FatCell *cells;        // bucket lists, ascending in cell index inside each bucket
     double org[3];
     double inv[3];
     int dim[3];

@@ -216,6 +216,7 @@ namespace {
 
 struct GridHost {
     std::vector<int> start, cells;
+    std::vector<unsigned> hints;      // per bucket, see BucketDir
     double org[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
     int dim[3] = {1, 1, 1}, logmap[3] = {0, 0, 0}, naxes = 2;
 };
@@ -324,6 +325,44 @@ bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
                 for (int y = lo[1]; y <= hi[1]; ++y)
                     for (int x = lo[0]; x <= hi[0]; ++x) g.cells[(size_t)fill[((size_t)z * g.dim[1] + y) * g.dim[0] + x]++] = i;
         }
+        if (nb > (long long)GRID_CODE_BUCKET_MASK) continue;      // bucket codes keep 27 bits for the index
+        // hints: an octant of a bucket gets the entry whose cell is the ONLY one reaching into the octant's interior
+        // (extents shrunk by the 1e-9 margin the lists were widened by, so cells that merely abut do not count)
+        g.hints.assign((size_t)nb, 0);
+        const int nocts = 1 << naxes;
+        auto mapped = [&](double x, int k) { return g.logmap[k] ? std::log(std::max(x, 1e-300)) : x; };
+        for (long long b = 0; b < nb; ++b) {
+            int bi[3] = {(int)(b % g.dim[0]), (int)((b / g.dim[0]) % g.dim[1]), (int)(b / ((long long)g.dim[0] * g.dim[1]))};
+            const int e0 = g.start[(size_t)b], n = g.start[(size_t)b + 1] - e0;
+            unsigned h = 0;
+            for (int o = 0; o < 8; ++o) {
+                unsigned pick = GRID_NO_HINT;
+                if (o < nocts) {
+                    int found = 0;
+                    for (int e = 0; e < n && found < 2; ++e) {
+                        const int ci = g.cells[(size_t)e0 + e];
+                        bool reaches = true;
+                        for (int k = 0; k < naxes && reaches; ++k) {
+                            const double w = 1.0 / g.inv[k];
+                            const double olo = g.org[k] + (bi[k] + 0.5 * ((o >> k) & 1)) * w, ohi = olo + 0.5 * w;
+                            const double m = 1e-9 * (std::fabs(c[k][ci]) + s[k][ci]);
+                            const double clo = mapped(c[k][ci] - 0.5 * s[k][ci] + m, k), chi = mapped(c[k][ci] + 0.5 * s[k][ci] - m, k);
+                            reaches = (clo < ohi) && (chi > olo);
+                        }
+                        if (reaches) { found += 1; if (e < (int)GRID_NO_HINT) pick = (unsigned)e; else found = 2; }
+                    }
+                    if (found != 1) pick = GRID_NO_HINT;
+                }
+                h |= pick << (4 * o);
+            }
+            g.hints[(size_t)b] = h;
+        }
+        if (getenv("MCRAT_HIP_VERBOSE")) {
+            long long hinted = 0;
+            for (long long b = 0; b < nb; ++b)
+                for (int o = 0; o < nocts; ++o) hinted += ((g.hints[(size_t)b] >> (4 * o)) & 15u) != GRID_NO_HINT;
+            fprintf(stderr, "mcrat_hip: %.1f %% of the bucket octants have a single-cell hint\n", 100.0 * hinted / ((double)nb * nocts));
+        }
         return true;
     }
     return false;
@@ -354,7 +393,8 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     const size_t o_temp = take(sizeof(double) * M);
     const size_t o_fc = !two ? take(sizeof(double) * M) : 0;
     const size_t o_k2e = any_hot ? take(sizeof(double) * M) : 0;
-    const size_t o_start = take(sizeof(int) * g.start.size());
+    const size_t n_buckets = g.start.size() - 1;
+    const size_t o_start = take(sizeof(BucketDir) * n_buckets);
     const size_t o_cells = take(sizeof(FatCell) * std::max<size_t>(g.cells.size(), 1));
     const size_t total = off;
 
@@ -402,7 +442,12 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
         for (int i = 0; i < M; ++i) { g2[i].c2 = h->r2[i]; g2[i].s2 = h->r2_size[i]; }
     }
     memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
-    memcpy(host.data() + o_start, g.start.data(), sizeof(int) * g.start.size());
+    {
+        BucketDir *dir = reinterpret_cast<BucketDir *>(host.data() + o_start);
+        for (size_t b = 0; b < n_buckets; ++b) {
+            dir[b].e0 = g.start[b]; dir[b].n = g.start[b + 1] - g.start[b]; dir[b].hints = g.hints[b]; dir[b].pad = 0;
+        }
+    }
     {   // bucket lists as complete copies of the member cells' records (device_types.hpp, FatCell)
         FatCell *fat = reinterpret_cast<FatCell *>(host.data() + o_cells);
         for (size_t e = 0; e < g.cells.size(); ++e) {
@@ -429,7 +474,7 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     hy.dom0[0] = h->r0_domain[0]; hy.dom0[1] = h->r0_domain[1];
     hy.dom1[0] = h->r1_domain[0]; hy.dom1[1] = h->r1_domain[1];
     hy.dom2[0] = h->r2_domain[0]; hy.dom2[1] = h->r2_domain[1];
-    hy.grid.start = reinterpret_cast<const int *>(base + o_start);
+    hy.grid.dir = reinterpret_cast<const BucketDir *>(base + o_start);
     hy.grid.cells = reinterpret_cast<const FatCell *>(base + o_cells);
     for (int k = 0; k < 3; ++k) {
         hy.grid.org[k] = g.org[k]; hy.grid.inv[k] = g.inv[k]; hy.grid.dim[k] = g.dim[k]; hy.grid.logmap[k] = g.logmap[k];
@@ -748,6 +793,15 @@ static void fill_rank_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
 }
 
 #ifdef MCRAT_DIAG
+extern "C" int mcrat_hip_diag_rank_stamps(mcrat_hip_ctx *c, int rank, long long out[8])
+{
+    if (!c || !out || rank < 0 || rank >= c->n_ranks) return -1;
+    LoopState h;
+    if (hipMemcpy(&h, c->d_rstates + rank, sizeof(LoopState), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    for (int k = 0; k < 8; ++k) out[k] = h.stamps[k];
+    return 0;
+}
+
 extern "C" int mcrat_hip_diag_stamps(mcrat_hip_ctx *c, long long out[8])
 {
     if (!c || !out) return -1;

@@ -735,7 +735,7 @@ constexpr int RANK_QCAP = 1024;
 #define RANK_WAVES_PER_SIMD 2      // 2 lists resident per CU without register spills; measured: 4 (with spills) is no faster -- the loop is VALU-issue bound
 #endif
 
-template <int DIMS, int GEOM, bool STOKES>
+template <int DIMS, int GEOM, bool STOKES, bool RESIDENT>
 __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
@@ -753,13 +753,21 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
     __syncthreads();
     if (st.done || n <= 0) return;
     const RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
+#ifdef MCRAT_DIAG
+    long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ticks: load, forced step, step, event, store; [5] passes
+    long long dg_t = (long long)__builtin_amdgcn_s_memtime();
+#define RANK_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const long long n_ = (long long)__builtin_amdgcn_s_memtime(); dg[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RANK_TICK(k) do { } while (0)
+#endif
 
     // LDS residency: the columns every pass touches (r, u, -1/tau, cell index, flags: 61 B per slot) are copied into
     // LDS once per launch and written back at the end; `ph` is the same PhotonDev with those column pointers aimed
     // at LDS and hot_bias = base, so every device function below works on it unchanged (col[i - hot_bias]).
+    // (RESIDENT is a template parameter so that the column pointers provably address LDS and the accesses below compile
+    // to ds_read / ds_write instead of flat loads)
     PhotonDev ph = gph;
-    const bool resident = lds_slots >= n;
-    if (resident) {
+    if constexpr (RESIDENT) {
         double *d = reinterpret_cast<double *>(s_dyn);
         double *l_r0 = d, *l_r1 = d + lds_slots, *l_r2 = d + 2 * lds_slots, *l_u0 = d + 3 * lds_slots,
                *l_u1 = d + 4 * lds_slots, *l_u2 = d + 5 * lds_slots, *l_nt = d + 6 * lds_slots;
@@ -777,6 +785,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
         ph.hot_bias = base;
         __syncthreads();
     }
+    RANK_TICK(0);
 
     for (long long pass = 0; pass < max_passes; ++pass) {
         const int nseg = st.nseg;
@@ -795,7 +804,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             if (pos < SHORTLIST_CAP) { sh.raw[pos].t = t; sh.raw[pos].idx = i; sh.raw[pos].pad = 0; }
         };
         // ---- phase 1: the step of every slot of this list (cf. step_kernel); a thread owns slot pairs so that
-        // one Philox block serves two slots, as the draw order prescribes (rng.hpp)
+        // one Philox block serves two slots, as the draw order prescribes (rng.hpp).  one_slot: the forced pass.
         auto one_slot = [&](int il, uint64_t bits) {
             const int i = base + il;
             const int h = i - ph.hot_bias;
@@ -813,23 +822,137 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             }
             int q, bucket;
             double t;
-            if (force) t = fast_one<DIMS, GEOM, true>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
-            else t = fast_one<DIMS, GEOM, false>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
+            t = fast_one<DIMS, GEOM, true>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
             if (q) {
                 const int e = atomicAdd(&s_qn, 1);
                 if (e < RANK_QCAP) { s_q[e] = il | (q == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = bucket; return; }
-                t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, !force, iter, rk, il, relocated, not_found);
+                t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, false, iter, rk, il, relocated, not_found);
             } else {
                 ph.tts[i] = t;
             }
             if (fl & FLAG_VALID) { best.offer(t, i); if (t < t_cut) shortlist_lds(t, i); }
         };
-        for (int pair = tid; 2 * pair < n; pair += EVENT_BLOCK) {
-            const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
-            one_slot(2 * pair, (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
-            if (2 * pair + 1 < n) one_slot(2 * pair + 1, (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32));
+        if (force) {
+            for (int pair = tid; 2 * pair < n; pair += EVENT_BLOCK) {
+                const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
+                one_slot(2 * pair, (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
+                if (2 * pair + 1 < n) one_slot(2 * pair + 1, (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32));
+            }
+        } else {
+            // Two slot pairs per thread per trip, every stage written over all four slots before the next stage:
+            // with two lists per CU a SIMD holds two waves, so what this loop costs is the LATENCY of one slot's
+            // dependent chain (LDS loads -> sqrt -> cell-record gather -> Philox -> log), not issue slots; four
+            // independent chains in flight hide most of it.  Same arithmetic per slot as fast_one.
+            constexpr int NS = 4;
+            const int hoff = base - ph.hot_bias;
+            for (int pair = tid; 2 * pair < n; pair += 2 * EVENT_BLOCK) {
+                int il[NS];
+                bool live[NS];
+                il[0] = 2 * pair; il[1] = 2 * pair + 1; il[2] = 2 * (pair + EVENT_BLOCK); il[3] = il[2] + 1;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) { live[k] = il[k] < n; if (!live[k]) il[k] = 0; }
+                double r0[NS], r1[NS], r2[NS], ntau[NS];
+                int cell[NS];
+                unsigned fl[NS];
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int h = il[k] + hoff;
+                    r0[k] = ph.r0[h]; r1[k] = ph.r1[h]; r2[k] = ph.r2[h];
+                    ntau[k] = ph.ntau[h]; cell[k] = ph.idx[h]; fl[k] = ph.flags[h];
+                }
+                if (nseg > 0) {                                  // pending updatePhotonPosition, mclib.c:1067-1095
+                    double u0[NS], u1[NS], u2[NS];
+                    bool mv[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const int h = il[k] + hoff;
+                        u0[k] = ph.u0[h]; u1[k] = ph.u1[h]; u2[k] = ph.u2[h];
+                        mv[k] = live[k] && (fl[k] & FLAG_MOVES) && (base + il[k] != skip);
+                    }
+                    for (int sg = 0; sg < nseg; ++sg) {
+                        const double t = st.seg[sg];
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {
+                            const double n0 = r0[k] + u0[k] * t, n1 = r1[k] + u1[k] * t, n2 = r2[k] + u2[k] * t;
+                            r0[k] = mv[k] ? n0 : r0[k]; r1[k] = mv[k] ? n1 : r1[k]; r2[k] = mv[k] ? n2 : r2[k];
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NS; ++k)
+                        if (mv[k]) { const int h = il[k] + hoff; ph.r0[h] = r0[k]; ph.r1[h] = r1[k]; ph.r2[h] = r2[k]; }
+                }
+                double a0[NS], a1[NS], a2[NS], tf[NS];
+                bool dom[NS], inb[NS];
+                CellGeom cg[NS];
+                CellGeom2 cg2[NS];
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int cc = (cell[k] < 0 || MC_DIAG(DIAG_SKIP_INCELL)) ? 0 : cell[k];
+                    cg[k] = hy.geom[cc];                                         // geometry.c:394-417 operands
+                    if constexpr (DIMS == DIM_THREE) cg2[k] = hy.geom2[cc];
+                }
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    if (MC_DIAG(DIAG_SKIP_COORDS)) { a0[k] = r0[k] + r1[k]; a1[k] = r2[k]; a2[k] = 0; }
+                    else phys::hydro_coords<DIMS, GEOM>(r0[k], r1[k], r2[k], a0[k], a1[k], a2[k]);
+                    dom[k] = phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);      // mclib.c:492-505
+                }
+                Philox4 ba, bb;
+                if (MC_DIAG(DIAG_SKIP_PHILOX)) {
+                    ba.w[0] = pair * 2654435761u + (uint32_t)iter; ba.w[1] = pair ^ 0x9e3779b9u; ba.w[2] = ~ba.w[0]; ba.w[3] = ba.w[1] + 7u;
+                    bb = ba; bb.w[1] ^= 0x5bd1e995u; bb.w[3] += 77u;
+                } else {
+                    ba = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
+                    bb = keyed_block(rk.seed, iter, (uint32_t)(pair + EVENT_BLOCK), RNG_FREEPATH, rk.stream);
+                }
+                const uint64_t bits[NS] = {(uint64_t)ba.w[0] | ((uint64_t)ba.w[1] << 32), (uint64_t)ba.w[2] | ((uint64_t)ba.w[3] << 32),
+                                           (uint64_t)bb.w[0] | ((uint64_t)bb.w[1] << 32), (uint64_t)bb.w[2] | ((uint64_t)bb.w[3] << 32)};
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    inb[k] = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) && (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
+                    if constexpr (DIMS == DIM_THREE) inb[k] = inb[k] && (2 * fabs(a2[k] - cg2[k].c2) - cg2[k].s2 <= 0);
+                    tf[k] = sample_free_time(ntau[k], bits[k]);                   // mclib.c:675-687
+                    if (MC_DIAG(DIAG_SKIP_SAMPLE)) tf[k] = 1e-7 * (1.0 + (double)(bits[k] >> 40) * 1e-3) + ntau[k] * 0.0;
+                    if (MC_DIAG(DIAG_SKIP_INCELL)) inb[k] = true;
+                }
+                // decisions, slot by slot (rarely anything but the first branch)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    if (!live[k]) continue;
+                    const int i = base + il[k], h = il[k] + hoff;
+                    double t;
+                    if (!(fl[k] & FLAG_VALID)) { ph.tts[i] = INFINITY; continue; }
+                    if (dom[k] && cell[k] != -1) {
+                        int q = 0;
+                        if (!inb[k]) q = 1;                                       // mclib.c:507,528
+                        else if (fl[k] & FLAG_RECALC) {                           // mclib.c:668
+                            if (fl[k] & FLAG_TAU_FRESH) {
+                                ph.flags[h] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                                ph.tau[i] = ph.tau_next[i];
+                            } else q = 2;
+                        }
+                        if (q) {
+                            const int bucket = (q == 1) ? phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]) : -1;
+                            const int e = atomicAdd(&s_qn, 1);
+                            if (e < RANK_QCAP) { s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = bucket; continue; }
+                            t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, true, iter, rk, il[k], relocated, not_found);
+                        } else {
+                            t = tf[k];
+                            ph.tts[i] = t;
+                        }
+                    } else {
+                        if (cell[k] != -1) ph.idx[h] = -1;                        // mclib.c:592
+                        t = 1e12 / C_LIGHT;                                       // mclib.c:620,684
+                        ph.tts[i] = t;
+                    }
+                    best.offer(t, i);
+                    if (t < t_cut) shortlist_lds(t, i);
+                }
+            }
         }
+        if (!force) RANK_TICK(6);
         __syncthreads();
+        if (!force) RANK_TICK(7);
         // ---- phase 2: the queued slots, dense
         {
             int qn = s_qn;
@@ -853,10 +976,15 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
         for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(sh.wt[wv], sh.wi[wv]);
         Cand gmin;
         gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
+        if (force) RANK_TICK(1); else RANK_TICK(2);
         // ---- the event half and the bookkeeping
         event_block<DIMS, GEOM, STOKES>(ph, hy, &st, rk, sh, s_sln, gmin, base, n, iter, st.remaining_time, st.last_scattered_index, st.t_est);
         if (tid == 0) st.force_relocate = 0;
         __syncthreads();
+        RANK_TICK(3);
+#ifdef MCRAT_DIAG
+        dg[5] += 1;
+#endif
         if (st.done) break;
     }
 
@@ -879,7 +1007,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             }
         }
         __syncthreads();
-        if (resident) {
+        if constexpr (RESIDENT) {
             for (int il = tid; il < n; il += EVENT_BLOCK) {
                 const int i = base + il;
                 gph.r0[i] = ph.r0[il]; gph.r1[i] = ph.r1[il]; gph.r2[i] = ph.r2[il];
@@ -887,6 +1015,11 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                 gph.ntau[i] = ph.ntau[il]; gph.idx[i] = ph.idx[il]; gph.flags[i] = ph.flags[il];
             }
         }
+#ifdef MCRAT_DIAG
+        __syncthreads();
+        RANK_TICK(4);
+        if (tid == 0) for (int k = 0; k < 8; ++k) st.stamps[k] = dg[k];
+#endif
         if (tid == 0) { st.nseg = 0; st.skip_idx = -1; states[rank] = st; }
     }
 }
@@ -1369,10 +1502,19 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                 slots = 0;
                 bytes = 0;
             }
-            kernel<<<dim3(n_ranks), dim3(EVENT_BLOCK), bytes, stream>>>(ph, hy, states, key, lay, max_passes, slots);
+            if (slots > 0) {
+                kernel<<<dim3(n_ranks), dim3(EVENT_BLOCK), bytes, stream>>>(ph, hy, states, key, lay, max_passes, slots);
+                return true;
+            }
+            return false;
         };
-        if (kc.stokes) launch(rank_loop_kernel<DV, GV, true>);
-        else launch(rank_loop_kernel<DV, GV, false>);
+        bool done;
+        if (kc.stokes) done = lds_slots > 0 && launch(rank_loop_kernel<DV, GV, true, true>);
+        else done = lds_slots > 0 && launch(rank_loop_kernel<DV, GV, false, true>);
+        if (!done) {
+            if (kc.stokes) rank_loop_kernel<DV, GV, true, false><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+            else rank_loop_kernel<DV, GV, false, false><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+        }
     });
 }
 

@@ -68,22 +68,31 @@ __device__ __forceinline__ bool check_in_block(const HydroDev &h, int cell, doub
     return in;
 }
 
-// bucket of the cell-lookup grid that holds a point (engine.hip, build_grid)
+// bucket of the cell-lookup grid that holds a point (engine.hip, build_grid), as a code: bucket index, the octant
+// of the bucket the point lies in, and whether it lies far enough (1e-6 bucket widths) from the octant's faces for
+// the bucket's hint to be used (device_types.hpp, BucketDir).  -1: the coordinates are NaN.
 __device__ __forceinline__ int grid_bucket(const GridDev &g, double a0, double a1, double a2)
 {
     const double a[3] = {a0, a1, a2};
     int b[3] = {0, 0, 0};
+    int oct = 0;
+    bool ok = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         if (k < g.naxes) {
             double u = g.logmap[k] ? log(a[k]) : a[k];
-            double f = floor((u - g.org[k]) * g.inv[k]);
+            const double x = (u - g.org[k]) * g.inv[k];
+            double f = floor(x);
             if (!(f == f)) return -1;
+            const double fr = x - f;
+            const double d0 = fr, d1 = fabs(fr - 0.5), d2 = 1.0 - fr;
+            ok = ok && (f >= 0.0) && (f <= (double)(g.dim[k] - 1)) && (d0 > 1e-6) && (d1 > 1e-6) && (d2 > 1e-6);
+            oct |= (fr >= 0.5 ? 1 : 0) << k;
             int bi = (f < 0.0) ? 0 : ((f > (double)(g.dim[k] - 1)) ? g.dim[k] - 1 : (int)f);
             b[k] = bi;
         }
     }
-    return (b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0];
+    return ((b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0]) | (oct << GRID_CODE_OCT_SHIFT) | (ok ? GRID_CODE_HINT_OK : 0);
 }
 
 template <int DIMS>
@@ -94,19 +103,20 @@ __device__ __forceinline__ bool in_fat_cell(const FatCell &f, double a0, double 
     return in;
 }
 
-// findContainingBlock, geometry.c:350-391: lowest-index cell whose closed extent holds the point, or -1.
-// The bucket lists are ascending in cell index and hold every cell whose (slightly widened) extent touches
-// the bucket, so the first hit equals the reference's linear first match.  Latency matters here, not
-// bandwidth (a handful of lanes per workgroup walk this path): the first four entries, each a complete
-// copy of the cell's records, are fetched as one batch of independent loads.  `hit` receives the entry.
+// inside by a margin of 1e-8 of the cell's size on every axis: then no other cell of a (non-overlapping) mesh holds
+// the point, not even through the closed-interval rounding at shared faces
 template <int DIMS>
-__device__ __forceinline__ int find_in_bucket(const GridDev &g, int bucket, double a0, double a1, double a2, FatCell &hit)
+__device__ __forceinline__ bool well_in_fat_cell(const FatCell &f, double a0, double a1, double a2)
 {
-    hit.cell = -1;
-    if (bucket < 0) return -1;
-    const int e0 = g.start[bucket];
-    const int e1 = g.start[bucket + 1];
-    const int n = e1 - e0;
+    bool in = (2 * fabs(a0 - f.c0) - f.s0 < -1e-8 * f.s0) && (2 * fabs(a1 - f.c1) - f.s1 < -1e-8 * f.s1);
+    if constexpr (DIMS == DIM_THREE) in = in && (2 * fabs(a2 - f.c2) - f.s2 < -1e-8 * f.s2);
+    return in;
+}
+
+// the exact walk of a bucket list: lowest-index entry whose closed extent holds the point
+template <int DIMS>
+__device__ __forceinline__ int walk_bucket(const GridDev &g, int e0, int n, double a0, double a1, double a2, FatCell &hit)
+{
     constexpr int BATCH = 4;
     FatCell f[BATCH];
 #pragma unroll
@@ -115,11 +125,31 @@ __device__ __forceinline__ int find_in_bucket(const GridDev &g, int bucket, doub
     for (int k = BATCH - 1; k >= 0; --k)
         if (k < n && in_fat_cell<DIMS>(f[k], a0, a1, a2)) hit = f[k];
     if (hit.cell >= 0 || n <= BATCH) return hit.cell;
-    for (int e = e0 + BATCH; e < e1; ++e) {
+    for (int e = e0 + BATCH; e < e0 + n; ++e) {
         const FatCell c = g.cells[e];
         if (in_fat_cell<DIMS>(c, a0, a1, a2)) { hit = c; return c.cell; }
     }
     return -1;
+}
+
+// findContainingBlock, geometry.c:350-391: lowest-index cell whose closed extent holds the point, or -1.
+// The bucket lists are ascending in cell index and hold every cell whose (slightly widened) extent touches
+// the bucket, so the first hit of the list walk equals the reference's linear first match; the hinted entry
+// (BucketDir) short-cuts the walk only where it provably gives the same answer.  Two dependent loads: the
+// bucket's record, then one entry -- each entry a complete copy of the cell's records.  `hit` receives the entry.
+template <int DIMS>
+__device__ __forceinline__ int find_in_bucket(const GridDev &g, int code, double a0, double a1, double a2, FatCell &hit)
+{
+    hit.cell = -1;
+    if (code < 0) return -1;
+    const BucketDir d = g.dir[code & GRID_CODE_BUCKET_MASK];
+    if (d.n <= 0) return -1;
+    const unsigned hint = (d.hints >> (4 * ((code >> GRID_CODE_OCT_SHIFT) & 7))) & 15u;
+    if ((code & GRID_CODE_HINT_OK) && hint != GRID_NO_HINT) {
+        const FatCell f = g.cells[d.e0 + (int)hint];
+        if (well_in_fat_cell<DIMS>(f, a0, a1, a2)) { hit = f; return f.cell; }
+    }
+    return walk_bucket<DIMS>(g, d.e0, d.n, a0, a1, a2, hit);
 }
 
 template <int DIMS>
