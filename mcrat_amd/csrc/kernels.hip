@@ -335,11 +335,13 @@ __device__ __forceinline__ PairIn load_pair(const PhotonDev &ph, int i0, bool ne
     return in;
 }
 
+// (launch bounds: three waves per SIMD -- 768 resident workgroups -- is what the grid is sized for; the kernel sits
+// at that register budget, 168 VGPRs)
 // One workgroup streams its chunks of 512 slots (phase 1, two chunks in flight per thread), collecting in an
 // LDS queue the few slots that need the slow path, then finishes those with dense lanes (phase 2) and
 // publishes its minimum.  On the forced pass of a new frame every slot takes the slow path, in line.
 template <int DIMS, int GEOM, bool FORCE>
-__global__ __launch_bounds__(STEP_BLOCK) void step_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
+__global__ __launch_bounds__(STEP_BLOCK, 3) void step_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
                                                           Cand *__restrict__ block_min, Shortlist *sl)
 {
     __shared__ int s_qn;
