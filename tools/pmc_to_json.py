@@ -1,0 +1,68 @@
+"""Turn the output of tools/profile_round.sh (merged back under gpurun_out/round) into the files committed under
+profiles/:  <tag>_bench.json, <tag>_kernel_stats.csv (default command), <tag>_list_kernel_stats.csv,
+<tag>_rank_loop_kernel_pmc.json, <tag>_step_kernel_pmc.json, <tag>_pmc_summary.txt.
+usage: pmc_to_json.py gpurun_out/round profiles r01"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def counters(sub):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"].split("(")[0].replace("void mcrat::", "")
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+def stats_file(sub):
+    f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    return f[0] if f else None
+
+
+lines = []
+out = {}
+for sub, want, bytes_note in (("pmc_ranks", "rank_loop_kernel", "ranks"), ("pmc_list", "step_kernel", "list")):
+    acc = counters(sub)
+    for k in sorted(acc):
+        lines.append("[%s] %s" % (sub, k))
+        for c, v in sorted(acc[k].items()):
+            lines.append("    %-24s n=%4d mean=%.6g min=%.6g max=%.6g" % (c, len(v), sum(v) / len(v), min(v), max(v)))
+    ks = [k for k in acc if want in k and "FETCH_SIZE" in acc[k]]
+    if not ks:
+        continue
+    # the variant that does the work: the one with the largest mean FETCH_SIZE (step_kernel<.., true> is the forced pass)
+    k = max(ks, key=lambda q: sum(acc[q]["FETCH_SIZE"]) / len(acc[q]["FETCH_SIZE"]) * len(acc[q]["FETCH_SIZE"]))
+    fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
+    write_kb = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
+    if want == "step_kernel":
+        rd = 2 * fetch_kb * 1024
+        corr = ("gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read stream, so read bytes = 2 x FETCH_SIZE x 1024; "
+                "WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM section)")
+    else:
+        rd = fetch_kb * 1024
+        corr = ("this kernel loads 8 B per lane and gathers 16-96 B records (not the 16 B/lane wide streams for which MI355X_MICROARCH.md "
+                "prescribes doubling FETCH_SIZE); that width is uncalibrated, so FETCH_SIZE is taken as counted: a lower bound on read bytes")
+    wr = write_kb * 1024
+    out[want] = {"kernel": k, "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb, "launches_counted": len(acc[k]["FETCH_SIZE"]),
+                 "correction": corr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
+                 "command": "tools/profile_round.sh (rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE in separate passes, --kernel-trace)"}
+    if want == "step_kernel":
+        out[want]["algorithmic_bytes_per_launch"] = 110000000
+    json.dump(out[want], open(os.path.join(dst, "%s_%s_pmc.json" % (tag, want)), "w"), indent=1)
+open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
+for sub, name in (("kt_default", "%s_kernel_stats.csv" % tag), ("kt_list", "%s_list_kernel_stats.csv" % tag)):
+    f = stats_file(sub)
+    if f:
+        shutil.copy(f, os.path.join(dst, name))
+b = os.path.join(src, "bench.json")
+if os.path.exists(b) and os.path.getsize(b) > 0:
+    shutil.copy(b, os.path.join(dst, "%s_bench.json" % tag))
+print(json.dumps({k: v["traffic_bytes_per_launch"] for k, v in out.items()}))
