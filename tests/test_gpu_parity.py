@@ -417,3 +417,41 @@ def test_virtual_ranks_whole_frame_and_split_runs(hip, oracle):
     out2 = e2.get_photons()
     for k in FLOAT_FIELDS + INT_FIELDS:
         assert np.array_equal(out2[k], out[k]), k
+
+
+def test_virtual_ranks_are_deterministic_and_equal_single_list_contexts_at_scale(hip):
+    """300 lists on the 1 048 576-cell frame, run twice (once split after the forced pass): identical counters and
+    photons both times, and a sample of lists bit-identical to single-list contexts holding only their photons
+    (rng_stream = first stream + r).  Guards the workgroup-level hand-offs of rank_loop_kernel against races."""
+    n, per = 300000, 1000
+    frame, ph, cfg = synth.config2(n_photons=n)
+    rem = 1.0 / frame["fps"]
+    runs = []
+    for split in (False, True):
+        e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=per)
+        e.set_hydro(frame)
+        e.set_photons(ph)
+        e.begin_frame(1, 0.0, rem)
+        if split:
+            e.run(1)
+        st = e.run(0)
+        out = e.get_photons()
+        per_rank = [(e.rank_stats(r).iterations, e.rank_stats(r).frame_scatt_cnt) for r in range(0, e.num_virtual_ranks(), 7)]
+        runs.append((st.iterations, st.frame_scatt_cnt, st.num_photons_find_new_element, per_rank, out))
+        e.close()
+    assert runs[0][:4] == runs[1][:4]
+    for k in FLOAT_FIELDS + INT_FIELDS:
+        assert np.array_equal(np.asarray(runs[0][4][k]), np.asarray(runs[1][4][k]), equal_nan=True), k
+    out = runs[0][4]
+    for r in (0, 113, 276, 299):
+        lo, hi = r * per, (r + 1) * per
+        sub = {k: (v[lo:hi].copy() if hasattr(v, "__len__") and len(v) == n else v) for k, v in ph.items()}
+        s = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=r)
+        s.set_hydro(frame)
+        s.set_photons(sub)
+        s.begin_frame(1, 0.0, rem)
+        s.run(0)
+        o = s.get_photons()
+        for k in FLOAT_FIELDS + INT_FIELDS:
+            assert np.array_equal(np.asarray(o[k]), np.asarray(out[k])[lo:hi], equal_nan=True), (r, k)
+        s.close()
