@@ -57,7 +57,7 @@ extern "C" {
 #define MCRAT_HIP_TWO_POINT_FIVE   1
 #define MCRAT_HIP_THREE            2
 #define MCRAT_HIP_TAU_DIRECT       1
-#define MCRAT_HIP_TAU_TABLE        2   /* not yet supported: MCRAT_HIP_EINVAL */
+#define MCRAT_HIP_TAU_TABLE        2   /* needs mcrat_hip_set_hot_cross_section before the first frame */
 
 /* the compile-time switches of Src/mcrat_input.h:49-71 that the loop depends on */
 typedef struct mcrat_hip_config {
@@ -65,7 +65,7 @@ typedef struct mcrat_hip_config {
     int dimensions;              /* DIMENSIONS                                                */
     int geometry;                /* GEOMETRY                                                  */
     int stokes_switch;           /* STOKES_SWITCH   (0/1)                                     */
-    int tau_calculation;         /* TAU_CALCULATION (only MCRAT_HIP_TAU_DIRECT)               */
+    int tau_calculation;         /* TAU_CALCULATION: MCRAT_HIP_TAU_DIRECT or MCRAT_HIP_TAU_TABLE */
     int cyclosynchrotron_switch; /* CYCLOSYNCHROTRON_SWITCH (only 0)                          */
     int device;                  /* HIP device ordinal                                        */
     void *stream;                /* hipStream_t to launch on, or NULL for a private stream    */
@@ -153,6 +153,7 @@ typedef struct mcrat_hip_frame_stats {
     double step_kernel_ms;                   /* profile=1: summed duration of step-kernel launches */
     long long step_kernel_launches;
     double event_kernel_ms;                  /* profile=1: summed duration of event-kernel launches */
+    long long table_misses;                  /* TAU_CALCULATION == TABLE: cross-section lookups outside the table (clamped) */
 } mcrat_hip_frame_stats;
 
 typedef struct mcrat_hip_ctx mcrat_hip_ctx;
@@ -166,6 +167,16 @@ const char *mcrat_hip_last_error(const mcrat_hip_ctx *ctx);   /* text of the las
 
 /* staging: once per hydro frame (after getHydroData, mcrat.c:721) ------------- */
 int mcrat_hip_set_hydro(mcrat_hip_ctx *ctx, const mcrat_hip_hydro *hydro);
+
+/* TAU_CALCULATION == TABLE, once per run (after initalizeHotCrossSection, hot_x_section.c:29-80): the table
+ * getThermalCrossSection interpolates (optical_depth.c:132-149).  thermal_table is the reference's global
+ * thermal_table[N_PH_E + 1][N_T + 1] (hot_x_section.c; log10 of the cross section over sigma_T, photon-energy index
+ * first), the four bounds are LOG_PH_E_MIN/MAX and LOG_T_MIN/MAX of hot_x_section.h:2-10.  Creating the table
+ * (createHotCrossSection, GSL Monte-Carlo integration) stays host-side work of MCRaT; mcrat_host_read_hot_cross_section
+ * (mcrat_amd/host) reads the file MCRaT writes.  A lookup outside the table is clamped to its edge and counted in
+ * mcrat_hip_frame_stats.table_misses (the reference re-integrates such a cross section on the spot). */
+int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *ctx, const double *thermal_table, int n_ph_e, int n_t,
+                                    double log_ph_e_min, double log_ph_e_max, double log_t_min, double log_t_max);
 
 /* photons host -> device (after photonInjection mcrat.c:645 / readCheckpoint) and back
  * (before saveCheckpoint mcrat.c:902 / printPhotons mcrat.c:907).  NULL-photon slots

@@ -13,9 +13,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcrat_hip.so")
-SOURCES = ["kernels.hip", "engine.hip"]
-HEADERS = ["device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
+SOURCES = ["kernels.hip", "kernels_table.hip", "engine.hip"]
+HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+OBJDIR = os.path.join(HERE, "_obj")
 
 
 def hipcc():
@@ -35,17 +36,33 @@ def stale():
 def build(force=False, resource_log=None):
     if not force and not stale():
         return LIB
-    cmd = [hipcc()] + FLAGS
+    # one hipcc per translation unit, side by side (kernels.hip and kernels_table.hip take minutes each), then the link
+    os.makedirs(OBJDIR, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"] + ["-c"]
     if resource_log:
-        cmd.append("-Rpass-analysis=kernel-resource-usage")
-    cmd += [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+        cflags.append("-Rpass-analysis=kernel-resource-usage")
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        procs.append((src, obj, subprocess.Popen([hipcc()] + cflags + [os.path.join(CSRC, src), "-o", obj],
+                                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    log, failed = [], False
+    for src, obj, p in procs:
+        _, err = p.communicate()
+        log.append(err)
+        if p.returncode != 0:
+            sys.stderr.write(err)
+            failed = True
     if resource_log:
         with open(resource_log, "w") as f:
-            f.write(r.stderr)
+            f.write("".join(log))
+    if failed:
+        raise RuntimeError("hipcc failed building libmcrat_hip.so")
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, obj, _ in procs] + ["-o", LIB],
+                       capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr)
-        raise RuntimeError("hipcc failed building libmcrat_hip.so")
+        raise RuntimeError("hipcc failed linking libmcrat_hip.so")
     return LIB
 
 

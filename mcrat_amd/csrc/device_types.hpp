@@ -117,6 +117,12 @@ struct HydroDev {
     int M;
     double dom0[2], dom1[2], dom2[2];
     GridDev grid;
+    // TAU_CALCULATION == TABLE (optical_depth.c:132-149): thermal_table[i][j] of hot_x_section.c, log10(sigma/sigma_T) on
+    // the (n_ph_e+1) x (n_t+1) grid of hot_x_section.h:2-10; null in DIRECT builds
+    const double *hot_table;
+    int hot_n_ph_e, hot_n_t;
+    double hot_e0, hot_de, hot_t0, hot_dt;
+    int *table_misses;           // lookups outside the tabulated range (clamped to its edge)
 };
 
 struct alignas(16) Cand {

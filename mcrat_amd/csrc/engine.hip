@@ -51,6 +51,12 @@ struct mcrat_hip_ctx {
     size_t hy_bytes = 0;
     bool have_hydro = false;
 
+    // TAU_CALCULATION == TABLE
+    double *d_hot_table = nullptr;
+    int hot_n_ph_e = 0, hot_n_t = 0;
+    double hot_grid[4] = {0, 0, 0, 0};          // log10 photon energy min/max, log10 theta min/max
+    int *d_table_misses = nullptr;
+
     // loop
     LoopState *d_state = nullptr;
     LoopState *h_state = nullptr;     // pinned
@@ -136,7 +142,7 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
     *out = nullptr;
     if (cfg->abi_version != MCRAT_HIP_ABI_VERSION) return MCRAT_HIP_EINVAL;
     if (!geometry_supported(cfg->dimensions, cfg->geometry)) return MCRAT_HIP_EINVAL;
-    if (cfg->tau_calculation != MCRAT_HIP_TAU_DIRECT) return MCRAT_HIP_EINVAL;   // TABLE: SURVEY.md 8(f) #4
+    if (cfg->tau_calculation != MCRAT_HIP_TAU_DIRECT && cfg->tau_calculation != MCRAT_HIP_TAU_TABLE) return MCRAT_HIP_EINVAL;
     if (cfg->cyclosynchrotron_switch != 0) return MCRAT_HIP_EINVAL;
     if (cfg->virtual_rank_photons < 0) return MCRAT_HIP_EINVAL;
 
@@ -151,6 +157,7 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
     c->kc.dimensions = cfg->dimensions;
     c->kc.geometry = cfg->geometry;
     c->kc.stokes = cfg->stokes_switch ? 1 : 0;
+    c->kc.table = cfg->tau_calculation == MCRAT_HIP_TAU_TABLE ? 1 : 0;
     c->key.stream = cfg->rng_stream & 0xffffffu;
 
     auto fail = [&](int code) { mcrat_hip_destroy(c); return code; };
@@ -161,6 +168,8 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
         c->own_stream = true;
     }
     if (hipMalloc((void **)&c->d_state, sizeof(LoopState)) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
+    if (hipMalloc((void **)&c->d_table_misses, sizeof(int)) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
+    if (hipMemset(c->d_table_misses, 0, sizeof(int)) != hipSuccess) return fail(MCRAT_HIP_ENODEV);
     if (hipHostMalloc((void **)&c->h_state, sizeof(LoopState), hipHostMallocDefault) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
     if (hipMalloc((void **)&c->d_red, sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
     if (hipHostMalloc((void **)&c->h_red, sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS, hipHostMallocDefault) != hipSuccess)
@@ -184,6 +193,8 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->hy_buf) (void)hipFree(c->hy_buf);
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
+    if (c->d_hot_table) (void)hipFree(c->d_hot_table);
+    if (c->d_table_misses) (void)hipFree(c->d_table_misses);
     if (c->d_sc) (void)hipFree(c->d_sc);
     if (c->sc_own_send && c->sc_send) (void)hipFree(c->sc_send);
     if (c->sc_own_recv && c->sc_recv) (void)hipFree(c->sc_recv);
@@ -370,6 +381,38 @@ bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
 
 }  // namespace
 
+static void apply_hot_table(mcrat_hip_ctx *c)
+{
+    HydroDev &hy = c->hy;
+    const bool table = c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && c->d_hot_table;
+    hy.hot_table = table ? c->d_hot_table : nullptr;
+    hy.hot_n_ph_e = c->hot_n_ph_e; hy.hot_n_t = c->hot_n_t;
+    hy.hot_e0 = c->hot_grid[0]; hy.hot_t0 = c->hot_grid[2];
+    // the grid steps as hot_x_section.c:464 forms them
+    hy.hot_de = table ? (c->hot_grid[1] - c->hot_grid[0]) / c->hot_n_ph_e : 0.0;
+    hy.hot_dt = table ? (c->hot_grid[3] - c->hot_grid[2]) / c->hot_n_t : 0.0;
+    hy.table_misses = c->d_table_misses;
+}
+
+extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *thermal_table, int n_ph_e, int n_t,
+                                               double log_ph_e_min, double log_ph_e_max, double log_t_min, double log_t_max)
+{
+    if (!c || !thermal_table || n_ph_e < 1 || n_t < 1 || !(log_ph_e_max > log_ph_e_min) || !(log_t_max > log_t_min)) return MCRAT_HIP_EINVAL;
+    if (c->cfg.tau_calculation != MCRAT_HIP_TAU_TABLE) { c->last_error = "the context was created with TAU_CALCULATION == DIRECT"; return MCRAT_HIP_ESTATE; }
+    const size_t count = (size_t)(n_ph_e + 1) * (size_t)(n_t + 1);
+    for (size_t k = 0; k < count; ++k)
+        if (!(thermal_table[k] == thermal_table[k])) { c->last_error = "NaN in the cross-section table"; return MCRAT_HIP_EINVAL; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_hot_table) { (void)hipFree(c->d_hot_table); c->d_hot_table = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->d_hot_table, count * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_hot_table, thermal_table, count * sizeof(double), hipMemcpyHostToDevice));
+    c->hot_n_ph_e = n_ph_e; c->hot_n_t = n_t;
+    c->hot_grid[0] = log_ph_e_min; c->hot_grid[1] = log_ph_e_max; c->hot_grid[2] = log_t_min; c->hot_grid[3] = log_t_max;
+    apply_hot_table(c);
+    drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
 {
     if (!c || !h || h->num_elements <= 0) return MCRAT_HIP_EINVAL;
@@ -480,6 +523,7 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
         hy.grid.org[k] = g.org[k]; hy.grid.inv[k] = g.inv[k]; hy.grid.dim[k] = g.dim[k]; hy.grid.logmap[k] = g.logmap[k];
     }
     hy.grid.naxes = g.naxes;
+    apply_hot_table(c);
     if (any_hot) {
         HIPCHK(c, launch_k2e(hy.temp, reinterpret_cast<double *>(base + o_k2e), M, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -729,6 +773,14 @@ extern "C" int mcrat_hip_get_photons(mcrat_hip_ctx *c, mcrat_hip_photon_list *l)
 }
 
 // ---------------------------------------------------------------------------------------------- the loop
+static long long read_table_misses(mcrat_hip_ctx *c)
+{
+    int m = 0;
+    if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && c->d_table_misses &&
+        hipMemcpy(&m, c->d_table_misses, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) m = -1;
+    return m;
+}
+
 static void fill_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
 {
     if (!s) return;
@@ -748,6 +800,7 @@ static void fill_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
     s->step_kernel_ms = c->prof_step_ms;
     s->step_kernel_launches = c->prof_launches;
     s->event_kernel_ms = c->prof_event_ms;
+    s->table_misses = read_table_misses(c);
 }
 
 static void state_to_stats(const LoopState &h, long long slots, mcrat_hip_frame_stats *s)
@@ -828,7 +881,12 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->have_hydro || !c->have_photons) return MCRAT_HIP_ESTATE;
+    if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && !c->d_hot_table) {
+        c->last_error = "TAU_CALCULATION == TABLE needs mcrat_hip_set_hot_cross_section first";
+        return MCRAT_HIP_ESTATE;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
     LoopState &h = *c->h_state;
     memset(&h, 0, sizeof h);
     h.remaining_time = remaining_time;
@@ -918,7 +976,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
         if (all_done) break;
     }
     fill_rank_stats(c, stats);
-    if (stats) { stats->step_kernel_ms = c->prof_step_ms; stats->step_kernel_launches = c->prof_launches; }
+    if (stats) { stats->step_kernel_ms = c->prof_step_ms; stats->step_kernel_launches = c->prof_launches; stats->table_misses = read_table_misses(c); }
     return MCRAT_HIP_OK;
 }
 

@@ -23,7 +23,23 @@
 #include "physics.hpp"
 #include "rng.hpp"
 
+// This file is compiled twice: as it stands (TAU_CALCULATION == DIRECT, optical_depth.c:125-127) and through
+// kernels_table.hip with MCRAT_TAU_TABLE_TU = 1 (TAU_CALCULATION == TABLE, optical_depth.c:132-149), each into its own
+// namespace.  The reference makes the same choice at compile time (mcrat_input.h); a run-time branch costs the DIRECT
+// kernels registers they do not have (step_kernel sits exactly at its 168-VGPR budget).
+#ifndef MCRAT_TAU_TABLE_TU
+#define MCRAT_TAU_TABLE_TU 0
+#endif
+#if MCRAT_TAU_TABLE_TU
+#define MCRAT_TU_NS tau_table
+#else
+#define MCRAT_TU_NS tau_direct
+#endif
+
 namespace mcrat {
+namespace MCRAT_TU_NS {
+
+constexpr bool TABLE_MODE = MCRAT_TAU_TABLE_TU != 0;
 
 // Diagnostic build only (-DMCRAT_DIAG, tools/diag_build.sh): g_diag bits knock out parts of the step kernel so that
 // their cost can be read off the kernel trace.  Results are wrong with any bit set; the product build has no such code.
@@ -283,13 +299,20 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             phys::cos_sin_of_atan2(r1, r0, cphi, sphi);                          // photon azimuth, mclib.c:549-552
             double beta[3];
             phys::beta_from_record<DIMS>(fa, fb, fc, cphi, sphi, beta);
+            double comv0 = 0;
             if (new_cell) {
                 const double lab[4] = {p0, p1, p2, p3};
                 double comv[4];
                 phys::lorentz_boost(beta, lab, comv, true);                      // mclib.c:558
                 ph.c0[i] = comv[0]; ph.c1[i] = comv[1]; ph.c2[i] = comv[2]; ph.c3[i] = comv[3];
+                comv0 = comv[0];
             }
-            const double tau = phys::optical_depth_direct(beta, fgamma, fdens, p1, p2, p3);
+            double norm = 1.0;
+            if constexpr (TABLE_MODE) {                                          // TAU_CALCULATION == TABLE, optical_depth.c:58
+                if (!new_cell) comv0 = ph.c0[i];
+                norm = phys::thermal_cross_section(hy, comv0, hy.temp[cell]);
+            }
+            const double tau = phys::optical_depth_direct(beta, fgamma, fdens, p1, p2, p3, norm);
             ntau = -1.0 / tau;
             ph.tau[i] = tau;
             ph.ntau[h] = ntau;
@@ -501,7 +524,9 @@ __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, 
     // cached cell (calcMeanFreePath, mclib.c:668-673: same position, same cell record, the new momentum) is computed
     // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
     const CellFluid f = hy.fluid[cell];
-    tau_new = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p[1], p[2], p[3]);
+    double norm = 1.0;
+    if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], fluid_temp);          // optical_depth.c:58
+    tau_new = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p[1], p[2], p[3], norm);
     return true;
 }
 
@@ -1523,7 +1548,7 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream)
 {
-    hipError_t e = launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream);
+    hipError_t e = MCRAT_TU_NS::launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream);
     if (e != hipSuccess) return e;
     sc_midpass_kernel<<<dim3(blocks), dim3(STEP_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, sl);
     if (kc.stokes) sc_propose_kernel<true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, blocks, sl, out);
@@ -1541,7 +1566,7 @@ hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const 
     });
 }
 
-#ifdef MCRAT_DIAG
+#if defined(MCRAT_DIAG) && !MCRAT_TAU_TABLE_TU
 extern "C" int mcrat_hip_diag_set(int bits)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &bits, sizeof(int)) == hipSuccess ? 0 : -1;
@@ -1577,5 +1602,69 @@ hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, cons
         hipLaunchKernelGGL((lookup_kernel<DIM_TWO>), dim3(blocks), dim3(256), 0, stream, hy, n, a0, a1, a2, out);
     return hipGetLastError();
 }
+
+}  // namespace MCRAT_TU_NS
+
+#if !MCRAT_TAU_TABLE_TU
+// ------------------------------------------------------------------ the launchers of launch.hpp
+namespace tau_table {
+hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy,
+                       LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
+                        const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
+                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream);
+hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
+                             const ScProposal *all, int world, hipStream_t stream);
+}  // namespace tau_table
+
+int step_grid_blocks(int n_pad) { return tau_direct::step_grid_blocks(n_pad); }
+
+hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy,
+                       LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream)
+{
+    return kc.table ? tau_table::launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream)
+                    : tau_direct::launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream);
+}
+
+hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
+                        const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream)
+{
+    return kc.table ? tau_table::launch_event(kc, ph, hy, st, key, block_min, n_blocks, sl, stream)
+                    : tau_direct::launch_event(kc, ph, hy, st, key, block_min, n_blocks, sl, stream);
+}
+
+hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
+                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream)
+{
+    return kc.table ? tau_table::launch_rank_loop(kc, ph, hy, states, key, n_ranks, rank_photons, max_passes, stream)
+                    : tau_direct::launch_rank_loop(kc, ph, hy, states, key, n_ranks, rank_photons, max_passes, stream);
+}
+
+hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream)
+{
+    return kc.table ? tau_table::launch_sc_propose(kc, force_relocate, ph, hy, st, sc, key, block_min, blocks, sl, out, stream)
+                    : tau_direct::launch_sc_propose(kc, force_relocate, ph, hy, st, sc, key, block_min, blocks, sl, out, stream);
+}
+
+hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
+                             const ScProposal *all, int world, hipStream_t stream)
+{
+    return kc.table ? tau_table::launch_sc_resolve(kc, ph, hy, st, sc, key, all, world, stream)
+                    : tau_direct::launch_sc_resolve(kc, ph, hy, st, sc, key, all, world, stream);
+}
+
+hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream) { return tau_direct::launch_flush(ph, st, blocks, stream); }
+hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream) { return tau_direct::launch_k2e(temp, k2e, M, stream); }
+hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream) { return tau_direct::launch_reduce(ph, out, blocks, stream); }
+hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, const double *a0, const double *a1, const double *a2, int *out,
+                         hipStream_t stream)
+{
+    return tau_direct::launch_lookup(kc, hy, n, a0, a1, a2, out, stream);
+}
+#endif
 
 }  // namespace mcrat

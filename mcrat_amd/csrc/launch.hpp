@@ -9,6 +9,7 @@ struct KernelConfig {
     int dimensions;
     int geometry;
     int stokes;
+    int table;      // TAU_CALCULATION == TABLE: the kernels of kernels_table.hip
 };
 
 struct ReducePartial {      // one per workgroup of the reduction kernels

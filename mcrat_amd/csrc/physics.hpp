@@ -236,7 +236,7 @@ __device__ __forceinline__ void lorentz_boost(const double b[3], const double p[
 // ---------------------------------------------------------------- optical depth
 // optical_depth.c:7-59 (TAU_CALCULATION == DIRECT): tau' = n_lab sigma_T (1 - beta cos(angle to the flow)) [1/cm]
 __device__ __forceinline__ double optical_depth_direct(const double fluid_beta[3], double gamma_cell, double dens_lab,
-                                                       double p1, double p2, double p3)
+                                                       double p1, double p2, double p3, double norm_cross_section = 1.0)
 {
     const double fl_v_norm = sqrt(fluid_beta[0] * fluid_beta[0] + fluid_beta[1] * fluid_beta[1] + fluid_beta[2] * fluid_beta[2]);
     const double ph_v_norm = sqrt(p1 * p1 + p2 * p2 + p3 * p3);
@@ -244,7 +244,47 @@ __device__ __forceinline__ double optical_depth_direct(const double fluid_beta[3
     const double beta = sqrt(1.0 - 1.0 / (gamma_cell * gamma_cell));
     const double fluid_factor = (1.0 - beta * n_cosangle);
     const double thermal_n_dens_lab = dens_lab / M_P;
-    return (thermal_n_dens_lab) * (THOM_X_SECT * 1.0) * fluid_factor;
+    return (thermal_n_dens_lab) * (THOM_X_SECT * norm_cross_section) * fluid_factor;
+}
+
+// getCrossSection / getThermalCrossSection, optical_depth.c:117-149: 1 in DIRECT; in TABLE
+// 10^interp(log10(h nu'/m_e c^2), log10(kT/m_e c^2)) with GSL's bilinear interp2d scheme on the uniform grid of
+// hot_x_section.c:461-502 (cell with x_i <= x < x_{i+1}, last cell closed).  Outside the table the reference
+// re-integrates the cross section by Monte Carlo (hot_x_section.c:563-599); here the arguments are clamped to the
+// table's edge and the lookup is counted (HydroDev::table_misses), as in the oracle.
+__device__ __forceinline__ int table_cell(double x0, double dx, int n_cells, double x)
+{
+    int i = (int)floor((x - x0) / dx);
+    i = i < 0 ? 0 : (i > n_cells - 1 ? n_cells - 1 : i);
+    // settle on the cell GSL's bisection finds: x0 + i dx <= x < x0 + (i+1) dx
+    while (i > 0 && x0 + i * dx > x) --i;
+    while (i < n_cells - 1 && !(x0 + (i + 1) * dx > x)) ++i;
+    return i;
+}
+
+__device__ __forceinline__ double thermal_cross_section(const HydroDev &h, double photon_comv_e, double fluid_temp)
+{
+    if (!h.hot_table) return 1.0;
+    const double normalized_photon_comv_e = photon_comv_e / (M_EL * C_LIGHT);
+    const double theta = K_B * fluid_temp / (M_EL * C_LIGHT * C_LIGHT);
+    double x = log10(normalized_photon_comv_e), y = log10(theta);
+    const double x_hi = h.hot_e0 + h.hot_n_ph_e * h.hot_de, y_hi = h.hot_t0 + h.hot_n_t * h.hot_dt;
+    bool out = false;
+    if (!(x >= h.hot_e0)) { x = h.hot_e0; out = true; }
+    if (x > x_hi) { x = x_hi; out = true; }
+    if (!(y >= h.hot_t0)) { y = h.hot_t0; out = true; }
+    if (y > y_hi) { y = y_hi; out = true; }
+    if (out) atomicAdd(h.table_misses, 1);
+    const int xi = table_cell(h.hot_e0, h.hot_de, h.hot_n_ph_e, x);
+    const int yi = table_cell(h.hot_t0, h.hot_dt, h.hot_n_t, y);
+    const double xmin = h.hot_e0 + xi * h.hot_de, xmax = h.hot_e0 + (xi + 1) * h.hot_de;
+    const double ymin = h.hot_t0 + yi * h.hot_dt, ymax = h.hot_t0 + (yi + 1) * h.hot_dt;
+    const int ny = h.hot_n_t + 1;
+    const double zminmin = h.hot_table[xi * ny + yi], zminmax = h.hot_table[xi * ny + yi + 1];
+    const double zmaxmin = h.hot_table[(xi + 1) * ny + yi], zmaxmax = h.hot_table[(xi + 1) * ny + yi + 1];
+    const double t = (x - xmin) / (xmax - xmin), u = (y - ymin) / (ymax - ymin);
+    const double z = (1. - t) * (1. - u) * zminmin + t * (1. - u) * zmaxmin + (1. - t) * u * zminmax + t * u * zmaxmax;
+    return pow(10.0, z);
 }
 
 // ---------------------------------------------------------------- Stokes helpers

@@ -15,6 +15,7 @@ ABI_VERSION = 1
 CARTESIAN, SPHERICAL, CYLINDRICAL, POLAR = 0, 1, 2, 3
 TWO, TWO_POINT_FIVE, THREE = 0, 1, 2
 TAU_DIRECT = 1
+TAU_TABLE = 2
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -79,7 +80,8 @@ class FrameStats(C.Structure):
                 ("kn_rejections", C.c_longlong), ("rescans", C.c_longlong),
                 ("last_scattered_index", C.c_int), ("last_scattered_temp", C.c_double),
                 ("last_time_step", C.c_double), ("remaining_time", C.c_double), ("time_now", C.c_double),
-                ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_longlong), ("event_kernel_ms", C.c_double)]
+                ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_longlong), ("event_kernel_ms", C.c_double),
+                ("table_misses", C.c_longlong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -94,6 +96,7 @@ SYMBOLS = {
     "mcrat_hip_strerror": (C.c_char_p, [C.c_int]),
     "mcrat_hip_last_error": (C.c_char_p, [_ctx]),
     "mcrat_hip_set_hydro": (C.c_int, [_ctx, C.POINTER(Hydro)]),
+    "mcrat_hip_set_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "mcrat_hip_set_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
     "mcrat_hip_get_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
     "mcrat_hip_set_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
@@ -161,9 +164,9 @@ class Engine:
     """One context of the HIP photon-loop engine (one per rank / GPU)."""
 
     def __init__(self, dimensions, geometry, stokes=0, device=0, stream=None, rng_stream=0,
-                 iterations_per_sync=0, use_graph=False, profile=False, virtual_rank_photons=0):
+                 iterations_per_sync=0, use_graph=False, profile=False, virtual_rank_photons=0, tau_calculation=TAU_DIRECT):
         self.lib = load_library()
-        self.cfg = Config(ABI_VERSION, int(dimensions), int(geometry), int(bool(stokes)), TAU_DIRECT, 0,
+        self.cfg = Config(ABI_VERSION, int(dimensions), int(geometry), int(bool(stokes)), int(tau_calculation), 0,
                           int(device), C.c_void_p(stream) if stream else None, int(rng_stream),
                           int(iterations_per_sync), int(bool(use_graph)), int(bool(profile)), int(virtual_rank_photons))
         self.ctx = _ctx()
@@ -190,6 +193,13 @@ class Engine:
                                                  self.lib.mcrat_hip_last_error(self.ctx).decode()))
 
     # ---- staging
+    def set_hot_cross_section(self, thermal_table, grid=(-12.0, 6.0, -4.0, 4.0)):
+        """thermal_table: (N_PH_E + 1, N_T + 1) log10(sigma / sigma_T); grid: LOG_PH_E_MIN/MAX, LOG_T_MIN/MAX (hot_x_section.h:2-10)"""
+        t = np.ascontiguousarray(thermal_table, dtype=np.float64)
+        self._check(self.lib.mcrat_hip_set_hot_cross_section(self.ctx, t.ctypes.data_as(_dp), t.shape[0] - 1, t.shape[1] - 1,
+                                                             float(grid[0]), float(grid[1]), float(grid[2]), float(grid[3])),
+                    "set_hot_cross_section")
+
     def set_hydro(self, frame):
         n = int(frame["num_elements"])
         keep, h = [], Hydro()

@@ -100,6 +100,43 @@ void mcrat_host_free_mcpar(mcrat_host_mcpar *p)
     p->inj_radius = NULL;
 }
 
+static int is_dash_line(const char *line)
+{
+    int n = 0;
+    for (; *line && *line != '\r' && *line != '\n'; ++line) {
+        if (*line != '-') return 0;
+        n++;
+    }
+    return n > 0;
+}
+
+int mcrat_host_read_hot_cross_section(const char *path, double *table, int n_ph_e, int n_t)
+{
+    if (!path || !table || n_ph_e < 1 || n_t < 1) return -2;
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    const size_t count = (size_t)(n_ph_e + 1) * (size_t)(n_t + 1);
+    unsigned char *seen = (unsigned char *)calloc(count, 1);
+    if (!seen) { fclose(f); return -2; }
+    char line[1024];
+    int rc = -2, in_data = 0;
+    size_t filled = 0;
+    while (fgets(line, sizeof line, f)) {
+        if (!in_data) { in_data = is_dash_line(line); continue; }     /* hot_x_section.c:229-236 */
+        int i, j;
+        double e, t, v;
+        if (sscanf(line, "%d %d %lf %lf %lf", &i, &j, &e, &t, &v) != 5) continue;
+        if (i < 0 || i > n_ph_e || j < 0 || j > n_t) { filled = count + 1; break; }   /* :242-251 */
+        const size_t k = (size_t)i * (size_t)(n_t + 1) + (size_t)j;
+        if (!seen[k]) { seen[k] = 1; filled++; }
+        table[k] = v;
+    }
+    if (in_data && filled == count) rc = 0;
+    free(seen);
+    fclose(f);
+    return rc;
+}
+
 int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, const mcrat_hip_hydro *hydro,
                              double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
                              uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats)

@@ -7,7 +7,8 @@
  *     bookkeeping (:758), the while loop (:761-851, now one library call), phScattStats (:881) and the log
  *     lines of :883-890, byte for byte in the reference's format;
  *   - mcrat_host_read_mcpar(): the positional mc.par grammar of readMcPar (Src/mcrat_io.c:1136-1237), so the
- *     run-size surface stays compatible (fps, last frame, domains, angle bins, spectrum, photon counts, i/c).
+ *     run-size surface stays compatible (fps, last frame, domains, angle bins, spectrum, photon counts, i/c);
+ *   - mcrat_host_read_hot_cross_section(): the thermal cross-section table file of TAU_CALCULATION == TABLE builds.
  * It links against libmcrat_hip.so only; nothing here computes photon physics on the CPU.
  */
 #ifndef MCRAT_HIP_HOST_H
@@ -38,6 +39,14 @@ typedef struct mcrat_host_mcpar {
 /* 0 on success, -1 if the file cannot be opened, -2 on a malformed file */
 int  mcrat_host_read_mcpar(const char *path, mcrat_host_mcpar *out);
 void mcrat_host_free_mcpar(mcrat_host_mcpar *p);
+
+/* thermal_hot_x_section.dat as createHotCrossSection writes it and readHotCrossSection reads it
+ * (Src/hot_x_section.c:107-133, 208-254): header lines up to a line of dashes, then rows
+ * "i <TAB> j <TAB> log10(energy) <TAB> log10(theta) <TAB> log10(cross section)".  Fills table[(n_ph_e+1)*(n_t+1)]
+ * (photon-energy index first, the layout mcrat_hip_set_hot_cross_section takes); every entry must be present.
+ * 0 on success, -1 if the file cannot be opened, -2 on a malformed or incomplete file or an index outside the bounds
+ * (the reference exits with "The bounds of the input file exceed what MCRaT has been compiled with"). */
+int mcrat_host_read_hot_cross_section(const char *path, double *table, int n_ph_e, int n_t);
 
 /* One scatter frame on the device (replaces Src/mcrat.c:754-892 between getHydroData and saveCheckpoint).
  *   list       caller-owned photon list; uploaded, propagated, downloaded in place

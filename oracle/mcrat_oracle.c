@@ -541,7 +541,57 @@ int orc_singleScatter(const orc_config *c, double el_comov[4], double ph_comov[4
 }
 
 /* ------------------------------------------------------------------ */
-/* optical_depth.c:7-59 with TAU_CALCULATION == DIRECT (getCrossSection = 1, :125-127) */
+/* getThermalCrossSection, optical_depth.c:132-149: 10^interp(log10(h nu'/m_e c^2), log10(kT/m_e c^2)), the
+ * interpolation being gsl_spline2d_eval_e on a gsl_interp2d_bilinear spline over the grid of hot_x_section.c:461-502.
+ * GSL is not in this image; its published bilinear scheme (interp2d/bilinear.c of GSL 2.x: cell found by bisection
+ * with x[i] <= x < x[i+1], the last cell closed; t = (x-x_i)/(x_{i+1}-x_i), u likewise;
+ * z = (1-t)(1-u) z00 + t(1-u) z10 + (1-t)u z01 + t u z11) is restated here.
+ * Deviation: outside the tabulated range GSL reports GSL_EDOM and the reference integrates the cross section
+ * afresh with gsl_monte_plain (hot_x_section.c:563-599, consuming random numbers); here the arguments are clamped
+ * to the table's edge and the event is counted (table_misses). */
+static long long g_table_misses = 0;
+long long orc_table_misses(void) { return g_table_misses; }
+void orc_reset_table_misses(void) { g_table_misses = 0; }
+
+static int bisect_cell(double x0, double dx, int n_cells, double x)
+{
+    /* gsl_interp_bsearch(xa, x, 0, n_cells) on xa[i] = x0 + i*dx */
+    int ilo = 0, ihi = n_cells;
+    while (ihi > ilo + 1) {
+        int i = (ihi + ilo) / 2;
+        if (x0 + i * dx > x) ihi = i; else ilo = i;
+    }
+    return ilo;
+}
+
+double orc_getThermalCrossSection(const orc_config *c, double photon_comv_e, double fluid_temp, int *miss)
+{
+    if (c->tau_calculation != ORC_TAU_TABLE) return 1;                         /* optical_depth.c:125-127,147 */
+    const double normalized_photon_comv_e = photon_comv_e / (ORC_M_EL * ORC_C_LIGHT);     /* :139 */
+    const double theta = ORC_K_B * fluid_temp / (ORC_M_EL * ORC_C_LIGHT * ORC_C_LIGHT);   /* calcDimlessTheta, mc_cyclosynch.c:48-52 */
+    double x = log10(normalized_photon_comv_e), y = log10(theta);
+    const double dx = (c->log_ph_e_max - c->log_ph_e_min) / c->n_ph_e;        /* hot_x_section.c:464 */
+    const double dy = (c->log_t_max - c->log_t_min) / c->n_t;
+    const double x_hi = c->log_ph_e_min + c->n_ph_e * dx, y_hi = c->log_t_min + c->n_t * dy;
+    int out = 0;
+    if (!(x >= c->log_ph_e_min)) { x = c->log_ph_e_min; out = 1; }
+    if (x > x_hi) { x = x_hi; out = 1; }
+    if (!(y >= c->log_t_min)) { y = c->log_t_min; out = 1; }
+    if (y > y_hi) { y = y_hi; out = 1; }
+    if (out) { g_table_misses += 1; if (miss) *miss += 1; }
+    const int xi = bisect_cell(c->log_ph_e_min, dx, c->n_ph_e, x);
+    const int yi = bisect_cell(c->log_t_min, dy, c->n_t, y);
+    const double xmin = c->log_ph_e_min + xi * dx, xmax = c->log_ph_e_min + (xi + 1) * dx;
+    const double ymin = c->log_t_min + yi * dy, ymax = c->log_t_min + (yi + 1) * dy;
+    const int ny = c->n_t + 1;
+    const double zminmin = c->hot_table[xi * ny + yi], zminmax = c->hot_table[xi * ny + yi + 1];
+    const double zmaxmin = c->hot_table[(xi + 1) * ny + yi], zmaxmax = c->hot_table[(xi + 1) * ny + yi + 1];
+    const double t = (x - xmin) / (xmax - xmin), u = (y - ymin) / (ymax - ymin);
+    const double z = (1. - t) * (1. - u) * zminmin + t * (1. - u) * zmaxmin + (1. - t) * u * zminmax + t * u * zmaxmax;
+    return pow(10.0, z);                                                        /* :143 */
+}
+
+/* optical_depth.c:7-59 (getCrossSection :117-130: 1 in DIRECT, the table in TABLE) */
 void orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hydro *h)
 {
     int idx = ph->nearest_block_index;
@@ -556,7 +606,7 @@ void orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hy
     double beta = sqrt(1.0 - 1.0 / (h->gamma[idx] * h->gamma[idx]));
     double fluid_factor = (1.0 - beta * n_cosangle);
     double thermal_n_dens_lab = h->dens_lab[idx] / ORC_M_P;
-    double norm_cross_section = 1;
+    double norm_cross_section = orc_getThermalCrossSection(c, ph->comv_p0, h->temp[idx], NULL);   /* :58 */
     ph->total_optical_depth = (thermal_n_dens_lab) * (ORC_THOM_X_SECT * norm_cross_section) * fluid_factor;
 }
 
@@ -778,6 +828,7 @@ void orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro *h
 {
     long long it = 0;
     double time_step = 0;
+    const long long misses0 = g_table_misses;
     while (*remaining_time > 0 && (max_iterations <= 0 || it < max_iterations)) {
         orc_rng_set_iteration(rng, iteration_base + (uint64_t)it);
         st->num_photons_find_new_element += orc_findContainingHydroCell(c, l, h, *find_nearest_grid_switch, st);
@@ -802,4 +853,5 @@ void orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro *h
     st->last_time_step = time_step;
     st->remaining_time = *remaining_time;
     st->time_now = *time_now;
+    st->table_misses += g_table_misses - misses0;
 }

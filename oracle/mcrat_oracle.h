@@ -94,10 +94,19 @@ typedef struct orc_hydro {
     double fps;
 } orc_hydro;
 
+#define ORC_TAU_DIRECT 1
+#define ORC_TAU_TABLE  2
 typedef struct orc_config {
     int dimensions;     /* ORC_TWO / ORC_TWO_POINT_FIVE / ORC_THREE  (mcrat_input.h DIMENSIONS) */
     int geometry;       /* ORC_CARTESIAN ...                          (mcrat_input.h GEOMETRY)   */
     int stokes_switch;  /* STOKES_SWITCH                                                        */
+    int tau_calculation;/* TAU_CALCULATION: ORC_TAU_DIRECT (also when 0) or ORC_TAU_TABLE        */
+    /* TAU_CALCULATION == TABLE: thermal_table[i][j] of hot_x_section.c (i: photon energy, j: temperature; values are
+     * log10 of the cross section over sigma_T) on the grid of hot_x_section.h:2-10.  The table is an INPUT here: its
+     * creation (hot_x_section.c:82-133, GSL Monte-Carlo integration) is host-side work of the reference. */
+    const double *hot_table;
+    int n_ph_e, n_t;                /* N_PH_E, N_T: the table has (n_ph_e + 1) x (n_t + 1) entries */
+    double log_ph_e_min, log_ph_e_max, log_t_min, log_t_max;
 } orc_config;
 
 typedef struct orc_stats {
@@ -112,6 +121,7 @@ typedef struct orc_stats {
     double last_time_step;
     double remaining_time;
     double time_now;
+    long long table_misses;          /* TABLE: lookups outside the tabulated range (clamped; see orc_getThermalCrossSection) */
 } orc_stats;
 
 /* ---- L1 maths -------------------------------------------------------- */
@@ -141,6 +151,9 @@ int    orc_singleScatter(const orc_config *c, double el_comov[4], double ph_como
 
 /* ---- the loop (reference signatures minus gsl_rng*, FILE*) ------------ */
 void   orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hydro *h);       /* optical_depth.c:7 */
+double orc_getThermalCrossSection(const orc_config *c, double photon_comv_e, double fluid_temp, int *miss); /* optical_depth.c:132 */
+long long orc_table_misses(void);   /* lookups outside the table since orc_reset_table_misses() */
+void   orc_reset_table_misses(void);
 int    orc_findContainingHydroCell(const orc_config *c, orc_photon_list *l, const orc_hydro *h,
                                    int find_nearest_block_switch, orc_stats *st);                /* mclib.c:436 */
 void   orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hydro *h, orc_rng *rng); /* mclib.c:617 */

@@ -56,7 +56,9 @@ class Hydro(C.Structure):
 
 
 class Config(C.Structure):
-    _fields_ = [("dimensions", C.c_int), ("geometry", C.c_int), ("stokes_switch", C.c_int)]
+    _fields_ = [("dimensions", C.c_int), ("geometry", C.c_int), ("stokes_switch", C.c_int), ("tau_calculation", C.c_int),
+                ("hot_table", C.POINTER(C.c_double)), ("n_ph_e", C.c_int), ("n_t", C.c_int),
+                ("log_ph_e_min", C.c_double), ("log_ph_e_max", C.c_double), ("log_t_min", C.c_double), ("log_t_max", C.c_double)]
 
 
 class Stats(C.Structure):
@@ -64,7 +66,7 @@ class Stats(C.Structure):
                 ("frame_scatt_cnt", C.c_longlong), ("num_photons_find_new_element", C.c_longlong),
                 ("not_found", C.c_longlong), ("kn_rejections", C.c_longlong), ("event_draws", C.c_longlong),
                 ("last_scattered_index", C.c_int), ("last_time_step", C.c_double),
-                ("remaining_time", C.c_double), ("time_now", C.c_double)]
+                ("remaining_time", C.c_double), ("time_now", C.c_double), ("table_misses", C.c_longlong)]
 
 
 def build(force=False):
@@ -117,6 +119,9 @@ def lib():
             "orc_singleThermalElectron": (None, [_dp, d, _dp, rp]),
             "orc_singleScatter": (i, [cfgp, _dp, _dp, _dp, rp]),
             "orc_calculateOpticalDepth": (None, [cfgp, p, hp]),
+            "orc_getThermalCrossSection": (d, [cfgp, d, d, C.POINTER(i)]),
+            "orc_table_misses": (C.c_longlong, []),
+            "orc_reset_table_misses": (None, []),
             "orc_findContainingHydroCell": (i, [cfgp, lp, hp, i, sp]),
             "orc_calcMeanFreePath": (None, [cfgp, lp, hp, rp]),
             "orc_updatePhotonPosition": (None, [lp, d]),
@@ -182,8 +187,19 @@ class OraclePhotons:
         self.c.list_capacity = n
 
 
-def make_config(dimensions, geometry, stokes):
-    return Config(int(dimensions), int(geometry), int(bool(stokes)))
+def make_config(dimensions, geometry, stokes, hot_table=None, grid=None):
+    """hot_table: (N_PH_E + 1, N_T + 1) array of log10(sigma / sigma_T) -> TAU_CALCULATION == TABLE on the grid
+    (log_ph_e_min, log_ph_e_max, log_t_min, log_t_max), default the reference's (hot_x_section.h:2-10)."""
+    c = Config(int(dimensions), int(geometry), int(bool(stokes)), 1)
+    if hot_table is not None:
+        import numpy as np
+        t = np.ascontiguousarray(hot_table, dtype=np.float64)
+        c._keep = t                              # the C side holds a pointer into it
+        c.tau_calculation = 2
+        c.hot_table = t.ctypes.data_as(C.POINTER(C.c_double))
+        c.n_ph_e, c.n_t = t.shape[0] - 1, t.shape[1] - 1
+        c.log_ph_e_min, c.log_ph_e_max, c.log_t_min, c.log_t_max = grid if grid is not None else (-12.0, 6.0, -4.0, 4.0)
+    return c
 
 
 def photon_loop(cfg, photons, hydro, seed, time_now, remaining_time, max_iterations=0,

@@ -81,8 +81,10 @@ def test_no_cpu_fallback(engine):
         lib.mcrat_hip_destroy(ctx)
     bad = engine.Config(engine.ABI_VERSION + 1, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 0, 0, None, 0, 0, 0, 0, 0)
     assert lib.mcrat_hip_init(C.byref(ctx), C.byref(bad)) == -1
-    table = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, 2, 0, 0, None, 0, 0, 0, 0, 0)   # TAU_CALCULATION TABLE
-    assert lib.mcrat_hip_init(C.byref(ctx), C.byref(table)) == -1
+    unknown_tau = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, 7, 0, 0, None, 0, 0, 0, 0, 0)   # no such TAU_CALCULATION
+    assert lib.mcrat_hip_init(C.byref(ctx), C.byref(unknown_tau)) == -1
+    cyclo = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 1, 0, None, 0, 0, 0, 0, 0)   # CYCLOSYNCHROTRON_SWITCH ON
+    assert lib.mcrat_hip_init(C.byref(ctx), C.byref(cyclo)) == -1
     assert lib.mcrat_hip_init(None, C.byref(cfg)) == -1
 
 

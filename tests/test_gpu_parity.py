@@ -455,3 +455,94 @@ def test_virtual_ranks_are_deterministic_and_equal_single_list_contexts_at_scale
         for k in FLOAT_FIELDS + INT_FIELDS:
             assert np.array_equal(np.asarray(o[k]), np.asarray(out[k])[lo:hi], equal_nan=True), (r, k)
         s.close()
+
+
+# ------------------------------------------------------------------ TAU_CALCULATION == TABLE
+def _hot_table():
+    """a smooth stand-in for thermal_hot_x_section.dat on the reference's grid (hot_x_section.h:2-10); the real table
+    is created by MCRaT itself (GSL Monte-Carlo integration) and handed to the engine"""
+    i, j = np.meshgrid(np.arange(221), np.arange(81), indexing="ij")
+    x = -12.0 + i * (18.0 / 220)
+    y = -4.0 + j * (8.0 / 80)
+    return -0.35 * np.log1p(np.exp(2.0 * (x + 0.5))) / np.log(10) - 0.02 * (y + 4.0) * (1 + 0.1 * np.tanh(x))
+
+
+@pytest.mark.parametrize("case", ["cfg2-stokes", "cfg1-hot-kn", "cfg2-virtual-ranks"])
+def test_table_optical_depth_trajectories(hip, oracle, case):
+    """the optical depth carries the interpolated thermal cross section of (comv_p0, T_cell) wherever the reference
+    recomputes it: on re-location (mclib.c:570) and after a scatter (mclib.c:668-673)"""
+    tab = _hot_table()
+    if case == "cfg1-hot-kn":
+        frame, ph, cfg = synth.config1(n_photons=600, n0=16, n1=16)
+        frame["temp"] = np.full(frame["num_elements"], 4e9)
+        for k in ("p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3"):
+            ph[k] = ph[k] * 300.0
+        seed, t0, rem, iters = 77, 0.0, 0.2, 500
+    else:
+        frame, ph, cfg = synth.config2(n_photons=2000, nzc=8, stokes=1, lumi=1e54)
+        seed, t0, rem, iters = 0x4D435261, 3.0, 1.0 / frame["fps"], 800
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"], hot_table=tab)
+    per = 500 if case == "cfg2-virtual-ranks" else 0
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], tau_calculation=hip.TAU_TABLE, virtual_rank_photons=per)
+    e.set_hot_cross_section(tab)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    e.begin_frame(seed, t0, rem)
+    st = e.run(iters)
+    out = e.get_photons()
+    H = oracle.OracleHydro(frame)
+    if per == 0:
+        P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+        rst, rtn, rrem, _ = oracle.photon_loop(c, P, H, seed=seed, time_now=t0, remaining_time=rem, max_iterations=iters)
+        assert st.iterations == rst.iterations == iters
+        assert st.frame_scatt_cnt == rst.frame_scatt_cnt > 100 and st.kn_rejections == rst.kn_rejections
+        assert st.table_misses == rst.table_misses == 0
+        _compare(out, P.aos)
+        # ... and the table matters: the DIRECT trajectory is a different one
+        d, dout, dst = _gpu_run(hip, frame, ph, cfg, seed, t0, rem, iters)
+        assert not np.array_equal(dout["num_scatt"], out["num_scatt"])
+    else:
+        n = len(ph["p0"])
+        for r in range(e.num_virtual_ranks()):
+            lo, hi = r * per, min(n, (r + 1) * per)
+            sub = {k: (v[lo:hi].copy() if hasattr(v, "__len__") and len(v) == n else v) for k, v in ph.items()}
+            P = oracle.OraclePhotons(synth.photons_to_aos(sub, oracle.PHOTON_DTYPE))
+            rst, rtn, rrem, _ = oracle.photon_loop(c, P, H, seed=seed, time_now=t0, remaining_time=rem, max_iterations=iters, stream=r)
+            rs = e.rank_stats(r)
+            assert rs.iterations == rst.iterations and rs.frame_scatt_cnt == rst.frame_scatt_cnt
+            _compare({k: np.asarray(v)[lo:hi] for k, v in out.items()}, P.aos)
+
+
+def test_table_lookups_outside_the_table_are_clamped_and_counted(hip, oracle):
+    tab = _hot_table()
+    frame, ph, cfg = synth.config1(n_photons=300, n0=16, n1=16)
+    grid = (-2.0, 6.0, -4.0, 4.0)                    # a table that starts above the photons' energies
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"], hot_table=tab, grid=grid)
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], tau_calculation=hip.TAU_TABLE)
+    e.set_hot_cross_section(tab, grid)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    e.begin_frame(9, 0.0, 0.2)
+    st = e.run(100)
+    out = e.get_photons()
+    P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    H = oracle.OracleHydro(frame)
+    rst, _, _, _ = oracle.photon_loop(c, P, H, seed=9, time_now=0.0, remaining_time=0.2, max_iterations=100)
+    # counted per evaluation: the engine evaluates the optical depth of a scattered photon at once (and again if the
+    # photon has left its cell by the next pass), the reference at the next pass -- at most one more per scattering
+    assert rst.table_misses > 300 and 0 <= st.table_misses - rst.table_misses <= st.frame_scatt_cnt
+    _compare(out, P.aos)
+
+
+def test_table_mode_needs_its_table(hip):
+    frame, ph, cfg = synth.config1(n_photons=100, n0=8, n1=8)
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], 0, tau_calculation=hip.TAU_TABLE)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    with pytest.raises(hip.McratHipError):
+        e.begin_frame(1, 0.0, 0.1)                    # no table yet
+    with pytest.raises(hip.McratHipError):
+        e.set_hot_cross_section(np.full((5, 5), np.nan))
+    d = hip.Engine(cfg["dimensions"], cfg["geometry"], 0)
+    with pytest.raises(hip.McratHipError):
+        d.set_hot_cross_section(_hot_table())         # a DIRECT context takes no table

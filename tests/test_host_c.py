@@ -79,6 +79,33 @@ def test_mcpar_grammar(host, tmp_path):
     assert host.mcrat_host_read_mcpar(str(tmp_path / "bad.par").encode(), C.byref(p)) == -2
 
 
+def test_hot_cross_section_file(host, tmp_path):
+    """the file format of createHotCrossSection / readHotCrossSection (hot_x_section.c:107-133, 208-254)"""
+    n_e, n_t = 6, 4
+    rng = np.random.default_rng(3)
+    tab = rng.normal(size=(n_e + 1, n_t + 1))
+    lines = ["The comoving photon energy and the temperatures are normalized by the electron rest mass",
+             "The calculated hot cross sections are normalized by the thompson cross section.",
+             "Photon index\tTheta Index\tlog10(Comoving Photon Energy)\tlog10(Theta)\tlog10(Hot Cross Section)",
+             "------------------------------------------------"]
+    for i in range(n_e + 1):
+        for j in range(n_t + 1):
+            lines.append("%d\t%d\t%g\t%g\t%15.10g" % (i, j, -12 + i * 3.0, -4 + j * 2.0, tab[i, j]))
+    f = tmp_path / "thermal_hot_x_section.dat"
+    f.write_text("\n".join(lines) + "\n")
+    host.mcrat_host_read_hot_cross_section.restype = C.c_int
+    host.mcrat_host_read_hot_cross_section.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_int]
+    out = np.zeros((n_e + 1, n_t + 1))
+    assert host.mcrat_host_read_hot_cross_section(str(f).encode(), out.ctypes.data_as(C.POINTER(C.c_double)), n_e, n_t) == 0
+    assert np.allclose(out, tab, rtol=1e-9, atol=0)               # %15.10g
+    # a file larger than the compiled bounds, a truncated file, a missing file
+    assert host.mcrat_host_read_hot_cross_section(str(f).encode(), out.ctypes.data_as(C.POINTER(C.c_double)), n_e - 1, n_t) == -2
+    g = tmp_path / "short.dat"
+    g.write_text("\n".join(lines[:-3]) + "\n")
+    assert host.mcrat_host_read_hot_cross_section(str(g).encode(), out.ctypes.data_as(C.POINTER(C.c_double)), n_e, n_t) == -2
+    assert host.mcrat_host_read_hot_cross_section(b"/nonexistent/x.dat", out.ctypes.data_as(C.POINTER(C.c_double)), n_e, n_t) == -1
+
+
 def test_reference_sample_file_parses_if_present(host):
     ref = "/root/reference/sample_mc.par"          # not present on the GPU box; read as data, not imported
     if not os.path.exists(ref):

@@ -565,3 +565,69 @@ def test_per_frame_reductions(oracle):
     assert c_.value == pytest.approx(th[live].min(), rel=1e-12) and d.value == pytest.approx(th[live].max(), rel=1e-12)
     e = L.orc_averagePhotonEnergy(C.byref(P.c))
     assert e == pytest.approx(C_LIGHT * (ph["p0"] * ph["weight"]).sum() / ph["weight"].sum(), rel=1e-12)
+
+
+# ------------------------------------------------------------------ TAU_CALCULATION == TABLE
+def _hot_table():
+    """a smooth stand-in for thermal_hot_x_section.dat on the reference's grid (hot_x_section.h:2-10): Klein-Nishina
+    suppression with energy, a mild temperature dependence (the real table is created by MCRaT with GSL)"""
+    i, j = np.meshgrid(np.arange(221), np.arange(81), indexing="ij")
+    x = -12.0 + i * (18.0 / 220)
+    y = -4.0 + j * (8.0 / 80)
+    return -0.35 * np.log1p(np.exp(2.0 * (x + 0.5))) / np.log(10) - 0.02 * (y + 4.0) * (1 + 0.1 * np.tanh(x))
+
+
+def test_hot_cross_section_interpolation(oracle):
+    """getThermalCrossSection (optical_depth.c:132-149) with GSL's bilinear scheme: exact at the nodes, exact for a
+    function that is bilinear in every cell, 1 in DIRECT builds; outside the table the edge value, counted"""
+    L = oracle.lib()
+    ME, CL, KB = 9.1093879e-28, 2.99792458e10, 1.380658e-16
+    i, j = np.meshgrid(np.arange(221), np.arange(81), indexing="ij")
+    x = -12.0 + i * (18.0 / 220)
+    y = -4.0 + j * (8.0 / 80)
+    tab = 0.1 * x - 0.05 * y + 0.01 * x * y
+    c = oracle.make_config(0, 2, 0, hot_table=tab)
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        xx, yy = rng.uniform(-12, 6), rng.uniform(-4, 4)
+        e, T = 10.0 ** xx * ME * CL, 10.0 ** yy * ME * CL * CL / KB
+        m = C.c_int(0)
+        got = L.orc_getThermalCrossSection(C.byref(c), e, T, C.byref(m))
+        assert m.value == 0
+        assert got == pytest.approx(10.0 ** (0.1 * xx - 0.05 * yy + 0.01 * xx * yy), rel=2e-12)
+    # nodes: log10 of the result is the table entry
+    tab2 = _hot_table()
+    c2 = oracle.make_config(0, 2, 0, hot_table=tab2)
+    for (a, b) in [(0, 0), (17, 3), (110, 40), (219, 79)]:
+        e, T = 10.0 ** x[a, b] * ME * CL, 10.0 ** y[a, b] * ME * CL * CL / KB
+        got = L.orc_getThermalCrossSection(C.byref(c2), e * (1 + 1e-13), T * (1 + 1e-13), None)
+        assert np.log10(got) == pytest.approx(tab2[a, b], abs=1e-11)
+    # outside: clamped and counted
+    L.orc_reset_table_misses()
+    m = C.c_int(0)
+    got = L.orc_getThermalCrossSection(C.byref(c2), 1e-14 * ME * CL, 1e7, C.byref(m))
+    edge = L.orc_getThermalCrossSection(C.byref(c2), 1e-12 * ME * CL, 1e7, None)
+    assert m.value == 1 and L.orc_table_misses() == 1 and got == pytest.approx(edge, rel=1e-12)
+    # DIRECT
+    d = oracle.make_config(0, 2, 0)
+    assert L.orc_getThermalCrossSection(C.byref(d), 1e-20, 1e7, None) == 1.0
+
+
+def test_table_optical_depth_scales_the_direct_one(oracle):
+    """calculateOpticalDepth (optical_depth.c:7-59): TABLE = DIRECT x the interpolated cross section of (comv_p0, T_cell)"""
+    L = oracle.lib()
+    frame, ph, cfg = synth.config2(n_photons=50, nzc=4)
+    H = oracle.OracleHydro(frame)
+    aos = synth.photons_to_aos(ph, oracle.PHOTON_DTYPE)
+    tab = _hot_table()
+    cd = oracle.make_config(cfg["dimensions"], cfg["geometry"], 0)
+    ct = oracle.make_config(cfg["dimensions"], cfg["geometry"], 0, hot_table=tab)
+    for k in range(10):
+        a, b = aos[k:k + 1].copy(), aos[k:k + 1].copy()
+        a["nearest_block_index"] = b["nearest_block_index"] = 100 + 37 * k
+        a["comv_p0"] = b["comv_p0"] = 1e-17 * 10.0 ** k            # 1e-17 .. 1e-8 erg/c: Thomson to deep Klein-Nishina
+        L.orc_calculateOpticalDepth(C.byref(cd), a.ctypes.data_as(C.c_void_p), C.byref(H.c))
+        L.orc_calculateOpticalDepth(C.byref(ct), b.ctypes.data_as(C.c_void_p), C.byref(H.c))
+        s = L.orc_getThermalCrossSection(C.byref(ct), float(b["comv_p0"][0]), float(frame["temp"][100 + 37 * k]), None)
+        assert 0 < s <= 1.0
+        assert b["total_optical_depth"][0] == pytest.approx(a["total_optical_depth"][0] * s, rel=1e-14)
