@@ -211,8 +211,11 @@ int mcrat_hip_rank_stats(mcrat_hip_ctx *ctx, int rank, mcrat_hip_frame_stats *st
 
 /* function-granular A/B entry points (one kernel each, for parity tests against the
  * reference functions): the findContainingHydroCell + calcMeanFreePath half of an
- * iteration and the photonEvent half. */
+ * iteration and the photonEvent half.  mcrat_amd/host/mcrat_hip_host.h wraps them in shims with the reference's
+ * own signatures (mclib.h:8-29) for A/B runs function by function. */
 int mcrat_hip_step_locate_sample(mcrat_hip_ctx *ctx, int find_nearest_block_switch);
+int mcrat_hip_frame_statistics(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);   /* the loop counters so far (synchronises) */
+int mcrat_hip_update_photon_position(mcrat_hip_ctx *ctx, double t);   /* updatePhotonPosition, mclib.c:1054-1100, on the resident photons */
 int mcrat_hip_step_event(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);
 
 /* ONE photon list split over several GPUs, ONE clock ------------------------------------------------------------

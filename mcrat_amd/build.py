@@ -17,6 +17,9 @@ SOURCES = ["kernels.hip", "kernels_table.hip", "engine.hip"]
 HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 OBJDIR = os.path.join(HERE, "_obj")
+_KERNEL_DEPS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"]
+DEPS = {"kernels.hip": _KERNEL_DEPS, "kernels_table.hip": _KERNEL_DEPS + ["kernels_table.hip"],
+        "engine.hip": ["engine.hip", "device_types.hpp", "launch.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]}
 
 
 def hipcc():
@@ -44,10 +47,15 @@ def build(force=False, resource_log=None):
     procs = []
     for src in SOURCES:
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
-        procs.append((src, obj, subprocess.Popen([hipcc()] + cflags + [os.path.join(CSRC, src), "-o", obj],
-                                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+        deps = [os.path.join(CSRC, d) for d in DEPS[src]]
+        fresh = (not force and not resource_log and os.path.exists(obj) and
+                 all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps))
+        procs.append((src, obj, None if fresh else subprocess.Popen([hipcc()] + cflags + [os.path.join(CSRC, src), "-o", obj],
+                                                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
     log, failed = [], False
     for src, obj, p in procs:
+        if p is None:
+            continue
         _, err = p.communicate()
         log.append(err)
         if p.returncode != 0:

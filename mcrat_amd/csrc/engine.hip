@@ -64,6 +64,7 @@ struct mcrat_hip_ctx {
     int find_switch = 1;
     RngKey key{0, 0, 0};
     long long frame_photon_steps = 0;
+    bool pending_applied = false;     // step_locate_sample has applied the pending advance that LoopState still lists
 
     // virtual ranks (cfg.virtual_rank_photons > 0): one LoopState per list
     int n_ranks = 0;
@@ -703,6 +704,7 @@ extern "C" int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *c) { return (c &&
 static int flush_pending(mcrat_hip_ctx *c)
 {
     if (c->n_ranks > 0) return MCRAT_HIP_OK;      // rank_loop_kernel leaves the photons current
+    if (c->pending_applied) return MCRAT_HIP_OK;  // between the two halves of a pass: the step kernel has applied it, the event kernel will replace it
     HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
     return MCRAT_HIP_OK;
 }
@@ -906,6 +908,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->key.seed = seed;
     c->find_switch = 1;           // mcrat.c:756
+    c->pending_applied = false;
     c->frame_open = true;
     c->prof_step_ms = c->prof_event_ms = 0;
     c->prof_launches = 0;
@@ -1061,6 +1064,34 @@ extern "C" int mcrat_hip_step_locate_sample(mcrat_hip_ctx *c, int find_nearest_b
     if (!c->frame_open || c->n_ranks > 0) return MCRAT_HIP_ESTATE;
     HIPCHK(c, launch_step(c->kc, find_nearest_block_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
     c->find_switch = 0;
+    c->pending_applied = true;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_frame_statistics(mcrat_hip_ctx *c, mcrat_hip_frame_stats *stats)
+{
+    if (!c || !stats) return MCRAT_HIP_EINVAL;
+    if (!c->frame_open || c->n_ranks > 0) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    fill_stats(c, stats);
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_update_photon_position(mcrat_hip_ctx *c, double t)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    int rc;
+    if (c->frame_open && c->n_ranks == 0 && (rc = flush_pending(c))) return rc;      // what the loop still owes the photons
+    c->pending_applied = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int nseg = 1, skip = -1;
+    HIPCHK(c, hipMemcpy(reinterpret_cast<char *>(c->d_state) + offsetof(LoopState, seg), &t, sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(reinterpret_cast<char *>(c->d_state) + offsetof(LoopState, nseg), &nseg, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(reinterpret_cast<char *>(c->d_state) + offsetof(LoopState, skip_idx), &skip, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));          // r += (p/p0) c t, mclib.c:1067-1095
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCRAT_HIP_OK;
 }
@@ -1070,6 +1101,7 @@ extern "C" int mcrat_hip_step_event(mcrat_hip_ctx *c, mcrat_hip_frame_stats *sta
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->frame_open || c->n_ranks > 0) return MCRAT_HIP_ESTATE;
     HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+    c->pending_applied = false;
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     fill_stats(c, stats);

@@ -111,6 +111,8 @@ SYMBOLS = {
     "mcrat_hip_rank_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(FrameStats)]),
     "mcrat_hip_step_locate_sample": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_step_event": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
+    "mcrat_hip_update_photon_position": (C.c_int, [_ctx, C.c_double]),
+    "mcrat_hip_frame_statistics": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_shared_clock_bytes_per_rank": (C.c_size_t, []),
     "mcrat_hip_shared_clock_attach": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
     "mcrat_hip_shared_clock_buffers": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
@@ -305,6 +307,14 @@ class Engine:
 
     def step_locate_sample(self, find_nearest_block_switch):
         self._check(self.lib.mcrat_hip_step_locate_sample(self.ctx, int(find_nearest_block_switch)), "step_locate_sample")
+
+    def frame_statistics(self):
+        st = FrameStats()
+        self._check(self.lib.mcrat_hip_frame_statistics(self.ctx, C.byref(st)), "frame_statistics")
+        return st
+
+    def update_photon_position(self, t):
+        self._check(self.lib.mcrat_hip_update_photon_position(self.ctx, float(t)), "update_photon_position")
 
     def step_event(self):
         st = FrameStats()

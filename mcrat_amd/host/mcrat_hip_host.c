@@ -2,6 +2,7 @@
 #include "mcrat_hip_host.h"
 
 #include <ctype.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -169,4 +170,91 @@ int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, co
     }
     if (stats) *stats = st;
     return MCRAT_HIP_OK;
+}
+
+/* ------------------------------------------------------------------ A/B shims (mcrat_hip_host.h) */
+int mcrat_ab_begin_frame(mcrat_ab_rng *rng, mcrat_hip_ctx *ctx, const mcrat_hip_photon_list *ph, const mcrat_hip_hydro *hydro,
+                         uint64_t seed, double time_now, double remaining_time)
+{
+    int rc;
+    if (!rng || !ctx || !ph || !hydro) return MCRAT_HIP_EINVAL;
+    rng->ctx = ctx; rng->relocated_seen = 0; rng->scatt_seen = 0;
+    if ((rc = mcrat_hip_set_hydro(ctx, hydro)) == 0 && (rc = mcrat_hip_set_photons(ctx, ph)) == 0)
+        rc = mcrat_hip_begin_frame(ctx, seed, time_now, remaining_time);
+    rng->last_rc = rc;
+    return rc;
+}
+
+int mcrat_ab_findContainingHydroCell(mcrat_hip_photon_list *ph, const mcrat_hip_hydro *hydro, int find_nearest_block_switch,
+                                     mcrat_ab_rng *rng, FILE *fPtr)
+{
+    mcrat_hip_frame_stats st;
+    int rc, n = 0;
+    long long k;
+    (void)hydro;                                   /* staged by mcrat_ab_begin_frame */
+    if (!ph || !rng || !rng->ctx) return 0;
+    if ((rc = mcrat_hip_step_locate_sample(rng->ctx, find_nearest_block_switch)) == 0 &&
+        (rc = mcrat_hip_frame_statistics(rng->ctx, &st)) == 0 && (rc = mcrat_hip_get_photons(rng->ctx, ph)) == 0) {
+        n = (int)(st.num_photons_find_new_element - rng->relocated_seen);       /* 0 on the forced pass, mclib.c:608-611 */
+        rng->relocated_seen = st.num_photons_find_new_element;
+        if (fPtr)
+            for (k = 0; k < st.not_found; ++k)                                   /* mclib.c:583 */
+                fprintf(fPtr, "Photon Hydro grid index not found, making sure it doesnt scatter.\n");
+    }
+    rng->last_rc = rc;
+    return n;
+}
+
+static const mcrat_hip_photon *ab_sort_key;
+static int ab_cmp(const void *a, const void *b)
+{
+    const int ia = *(const int *)a, ib = *(const int *)b;
+    double ta = ab_sort_key[ia].time_to_scatter, tb = ab_sort_key[ib].time_to_scatter;
+    if (ta != ta) ta = HUGE_VAL;
+    if (tb != tb) tb = HUGE_VAL;
+    if (ta < tb) return -1;
+    if (ta > tb) return 1;
+    return (ia > ib) - (ia < ib);
+}
+
+void mcrat_ab_calcMeanFreePath(mcrat_hip_photon_list *ph, const mcrat_hip_hydro *hydro, mcrat_ab_rng *rng, FILE *fPtr)
+{
+    int i;
+    (void)hydro; (void)fPtr;
+    if (!ph || !rng || !ph->sorted_indexes) { if (rng) rng->last_rc = MCRAT_HIP_EINVAL; return; }
+    /* time_to_scatter came back with mcrat_ab_findContainingHydroCell (one fused kernel); what remains of
+     * calcMeanFreePath is its argsort, mclib.c:702-712 */
+    for (i = 0; i < ph->list_capacity; ++i) ph->sorted_indexes[i] = i;
+    ab_sort_key = ph->photons;
+    qsort(ph->sorted_indexes, (size_t)ph->list_capacity, sizeof(int), ab_cmp);
+    rng->last_rc = 0;
+}
+
+double mcrat_ab_photonEvent(mcrat_hip_photon_list *ph, double dt_max, const mcrat_hip_hydro *hydro, int *scattered_ph_index,
+                            int *frame_scatt_cnt, int *frame_abs_cnt, mcrat_ab_rng *rng, FILE *fPtr)
+{
+    mcrat_hip_frame_stats st;
+    int rc;
+    (void)hydro; (void)frame_abs_cnt; (void)fPtr;   /* absorption belongs to the cyclo-synchrotron build */
+    if (!ph || !rng || !rng->ctx) return 0;
+    if ((rc = mcrat_hip_frame_statistics(rng->ctx, &st)) == 0 && st.remaining_time != dt_max)
+        rc = MCRAT_HIP_ESTATE;                      /* main() passes remaining_time (mcrat.c:781); the context keeps the same clock */
+    if (rc == 0 && (rc = mcrat_hip_step_event(rng->ctx, &st)) == 0 && (rc = mcrat_hip_get_photons(rng->ctx, ph)) == 0) {
+        if (scattered_ph_index) *scattered_ph_index = st.last_scattered_index;
+        if (frame_scatt_cnt) *frame_scatt_cnt += (int)(st.frame_scatt_cnt - rng->scatt_seen);
+        rng->scatt_seen = st.frame_scatt_cnt;
+        rng->last_rc = 0;
+        return st.last_time_step;
+    }
+    rng->last_rc = rc;
+    return 0;
+}
+
+void mcrat_ab_updatePhotonPosition(mcrat_hip_photon_list *ph, double t, mcrat_ab_rng *rng, FILE *fPtr)
+{
+    int rc;
+    (void)fPtr;
+    if (!ph || !rng || !rng->ctx) return;
+    if ((rc = mcrat_hip_update_photon_position(rng->ctx, t)) == 0) rc = mcrat_hip_get_photons(rng->ctx, ph);
+    rng->last_rc = rc;
 }

@@ -60,6 +60,34 @@ int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, co
                              double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
                              uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats);
 
+/* ---- A/B shims: the reference's loop functions with their own argument order (Src/mclib.h:8-29) ----------------
+ * For checking the engine against the CPU functions one call at a time inside MCRaT's own loop (mcrat.c:761-851):
+ * replace `findContainingHydroCell(&photon_list, &hydrodata, sw, rng, fPtr)` by
+ * `mcrat_ab_findContainingHydroCell(&pl, &hy, sw, &ab, fPtr)` and so on.  gsl_rng* becomes mcrat_ab_rng*: the engine's
+ * random source is keyed by (frame seed, loop iteration), both held by the context, so the handle carries the context
+ * instead of a generator state.  Within a frame the photons live on the device; every shim copies them back into the
+ * caller's list afterwards (host <- device per call: a debugging path; production is mcrat_host_scatter_frame).
+ * The engine fuses findContainingHydroCell and calcMeanFreePath into one kernel: the first shim runs it (and already
+ * fills time_to_scatter), the second fills sorted_indexes as the argsort of mclib.c:702-712 does (ties by slot).
+ * The reference's functions report no status; the shims leave the MCRAT_HIP_E* code of the last call in last_rc. */
+typedef struct mcrat_ab_rng {
+    mcrat_hip_ctx *ctx;
+    int last_rc;
+    long long relocated_seen;      /* internal: counters already reported */
+    long long scatt_seen;
+} mcrat_ab_rng;
+
+/* once per scatter frame, where mcrat.c:754-758 sets find_nearest_grid_switch = 1 and remaining_time: stages the hydro
+ * frame and the photon list and opens the frame with the seed main() draws at mcrat.c:701 */
+int    mcrat_ab_begin_frame(mcrat_ab_rng *rng, mcrat_hip_ctx *ctx, const mcrat_hip_photon_list *ph, const mcrat_hip_hydro *hydro,
+                            uint64_t seed, double time_now, double remaining_time);
+int    mcrat_ab_findContainingHydroCell(mcrat_hip_photon_list *ph, const mcrat_hip_hydro *hydro, int find_nearest_block_switch,
+                                        mcrat_ab_rng *rng, FILE *fPtr);                                   /* mclib.c:436 */
+void   mcrat_ab_calcMeanFreePath(mcrat_hip_photon_list *ph, const mcrat_hip_hydro *hydro, mcrat_ab_rng *rng, FILE *fPtr);   /* mclib.c:617 */
+double mcrat_ab_photonEvent(mcrat_hip_photon_list *ph, double dt_max, const mcrat_hip_hydro *hydro, int *scattered_ph_index,
+                            int *frame_scatt_cnt, int *frame_abs_cnt, mcrat_ab_rng *rng, FILE *fPtr);    /* mclib.c:1107 */
+void   mcrat_ab_updatePhotonPosition(mcrat_hip_photon_list *ph, double t, mcrat_ab_rng *rng, FILE *fPtr);  /* mclib.c:1054 (+ the handle) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,3 +165,97 @@ def test_scatter_frame_driver_matches_engine_and_logs_like_the_reference(host, t
     assert "MCRaT had to refind the position of photons %d times in this frame.\n" % st.num_photons_find_new_element in text
     assert "The maximum number of scatterings for a photon is: %d\n" % int(want["num_scatt"].max()) in text
     assert "The average number of scatterings thus far is: %f\n" % want["num_scatt"].mean() in text
+
+
+@pytest.mark.gpu
+def test_ab_shims_run_mains_loop_function_by_function(host, oracle):
+    """the loop of mcrat.c:761-851 written as main() writes it, once on the reference-signature shims
+    (mcrat_ab_findContainingHydroCell / calcMeanFreePath / photonEvent / updatePhotonPosition) and once on the oracle's
+    restatements of the same functions: the same decisions and photons after every call"""
+    from mcrat_amd import engine
+    frame, ph, cfg = synth.config2(n_photons=600, nzc=8, lumi=1e54)
+    seed, time_now0, remaining0 = 4242, 1.0, 2.0e-3               # a 2 ms stretch of the frame: a few dozen passes, then the frame ends
+
+    class Ab(C.Structure):
+        _fields_ = [("ctx", C.c_void_p), ("last_rc", C.c_int), ("relocated_seen", C.c_longlong), ("scatt_seen", C.c_longlong)]
+
+    PL, HY = C.POINTER(engine.PhotonList), C.POINTER(engine.Hydro)
+    host.mcrat_ab_begin_frame.restype = C.c_int
+    host.mcrat_ab_begin_frame.argtypes = [C.POINTER(Ab), C.c_void_p, PL, HY, C.c_uint64, C.c_double, C.c_double]
+    host.mcrat_ab_findContainingHydroCell.restype = C.c_int
+    host.mcrat_ab_findContainingHydroCell.argtypes = [PL, HY, C.c_int, C.POINTER(Ab), C.c_void_p]
+    host.mcrat_ab_calcMeanFreePath.restype = None
+    host.mcrat_ab_calcMeanFreePath.argtypes = [PL, HY, C.POINTER(Ab), C.c_void_p]
+    host.mcrat_ab_photonEvent.restype = C.c_double
+    host.mcrat_ab_photonEvent.argtypes = [PL, C.c_double, HY, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(Ab), C.c_void_p]
+    host.mcrat_ab_updatePhotonPosition.restype = None
+    host.mcrat_ab_updatePhotonPosition.argtypes = [PL, C.c_double, C.POINTER(Ab), C.c_void_p]
+
+    e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    aos = synth.photons_to_aos(ph, engine.PHOTON_DTYPE)
+    sorted_idx = np.zeros(len(aos), dtype=np.int32)
+    plist = engine.PhotonList(aos.ctypes.data, sorted_idx.ctypes.data_as(C.POINTER(C.c_int)), len(aos), 0, len(aos))
+    keep, h = [], engine.Hydro()
+    h.num_elements = frame["num_elements"]
+    for f in ("r0", "r1", "r0_size", "r1_size", "v0", "v1", "dens_lab", "temp", "gamma"):
+        a = np.ascontiguousarray(frame[f], dtype=np.float64)
+        keep.append(a)
+        setattr(h, f, a.ctypes.data_as(C.POINTER(C.c_double)))
+    for k in ("r0_domain", "r1_domain"):
+        getattr(h, k)[0], getattr(h, k)[1] = frame[k]
+    h.fps = frame["fps"]
+    ab = Ab()
+    assert host.mcrat_ab_begin_frame(C.byref(ab), e.ctx, C.byref(plist), C.byref(h), seed, time_now0, remaining0) == 0
+
+    # the oracle side, function by function (orc_* restate the same reference functions)
+    L = oracle.lib()
+    oc = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    H = oracle.OracleHydro(frame)
+    P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), seed, 0)
+    ost = oracle.Stats()
+
+    def same_photons(tag):
+        for k in ("nearest_block_index", "num_scatt", "recalc_properties"):
+            assert np.array_equal(aos[k], P.aos[k]), (tag, k)
+        for k in ("r0", "r1", "r2", "p0", "comv_p0", "time_to_scatter", "total_optical_depth"):
+            assert np.allclose(aos[k], P.aos[k], rtol=1e-9, atol=0), (tag, k)
+
+    # mcrat.c:754-851
+    find_switch, remaining, o_remaining = 1, remaining0, remaining0
+    time_now = o_time_now = time_now0
+    scatt_cnt, o_scatt_cnt = C.c_int(0), C.c_longlong(0)
+    idx, o_idx = C.c_int(-1), C.c_int(-1)
+    relocated = o_relocated = passes = 0
+    while remaining > 0:
+        L.orc_rng_set_iteration(C.byref(rng), passes)
+        n = host.mcrat_ab_findContainingHydroCell(C.byref(plist), C.byref(h), find_switch, C.byref(ab), None)
+        assert ab.last_rc == 0
+        o_n = L.orc_findContainingHydroCell(C.byref(oc), C.byref(P.c), C.byref(H.c), find_switch, C.byref(ost))
+        assert n == o_n
+        relocated += n
+        host.mcrat_ab_calcMeanFreePath(C.byref(plist), C.byref(h), C.byref(ab), None)
+        L.orc_calcMeanFreePath(C.byref(oc), C.byref(P.c), C.byref(H.c), C.byref(rng))
+        o_sorted = np.ctypeslib.as_array(P.c.sorted_indexes, shape=(len(aos),))
+        assert np.array_equal(sorted_idx[:8], o_sorted[:8])
+        same_photons("after the free-path draw of pass %d" % passes)
+        find_switch = 0
+        if aos["time_to_scatter"][sorted_idx[0]] < remaining:                       # mcrat.c:777
+            dt = host.mcrat_ab_photonEvent(C.byref(plist), remaining, C.byref(h), C.byref(idx), C.byref(scatt_cnt), None, C.byref(ab), None)
+            assert ab.last_rc == 0
+            o_dt = L.orc_photonEvent(C.byref(oc), C.byref(P.c), o_remaining, C.byref(H.c), C.byref(o_idx), C.byref(o_scatt_cnt), C.byref(rng), C.byref(ost))
+            assert dt == pytest.approx(o_dt, rel=1e-12) and idx.value == o_idx.value and scatt_cnt.value == o_scatt_cnt.value
+            time_now += dt; remaining -= dt                                          # mcrat.c:782-784
+            o_time_now += o_dt; o_remaining -= o_dt
+        else:                                                                        # mcrat.c:834-845
+            host.mcrat_ab_updatePhotonPosition(C.byref(plist), remaining, C.byref(ab), None)
+            assert ab.last_rc == 0
+            L.orc_updatePhotonPosition(C.byref(P.c), o_remaining)
+            time_now += remaining; remaining = 0
+            o_time_now += o_remaining; o_remaining = 0
+        same_photons("after the event of pass %d" % passes)
+        passes += 1
+        assert passes < 400
+    assert passes > 10 and scatt_cnt.value > 10 and relocated > 0
+    assert time_now == pytest.approx(time_now0 + remaining0, rel=1e-13)
