@@ -50,6 +50,11 @@ struct mcrat_hip_ctx {
     void *hy_buf = nullptr;
     size_t hy_bytes = 0;
     bool have_hydro = false;
+    void *grid_buf = nullptr;          // bucket records, bucket lists (+ build scratch)
+    size_t grid_bytes = 0;
+    unsigned *grid_count = nullptr;    // per-bucket counters of the device build
+    size_t grid_count_cap = 0;
+    unsigned long long *d_grid_total = nullptr;
 
     // TAU_CALCULATION == TABLE
     double *d_hot_table = nullptr;
@@ -192,6 +197,9 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->ph_buf) (void)hipFree(c->ph_buf);
     if (c->ph_snap) (void)hipFree(c->ph_snap);
     if (c->hy_buf) (void)hipFree(c->hy_buf);
+    if (c->grid_buf) (void)hipFree(c->grid_buf);
+    if (c->grid_count) (void)hipFree(c->grid_count);
+    if (c->d_grid_total) (void)hipFree(c->d_grid_total);
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
     if (c->d_hot_table) (void)hipFree(c->d_hot_table);
@@ -219,7 +227,7 @@ extern "C" int mcrat_hip_synchronize(mcrat_hip_ctx *c)
 extern "C" size_t mcrat_hip_device_bytes(const mcrat_hip_ctx *c)
 {
     if (!c) return 0;
-    return c->ph_bytes + c->hy_bytes + sizeof(Shortlist) + sizeof(LoopState) + (size_t)c->partials_cap * sizeof(Cand) +
+    return c->ph_bytes + c->hy_bytes + c->grid_bytes + c->grid_count_cap * sizeof(unsigned) + sizeof(Shortlist) + sizeof(LoopState) + (size_t)c->partials_cap * sizeof(Cand) +
            sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS;
 }
 
@@ -229,6 +237,7 @@ namespace {
 struct GridHost {
     std::vector<int> start, cells;
     std::vector<unsigned> hints;      // per bucket, see BucketDir
+    double ext_lo[3] = {0, 0, 0}, ext_hi[3] = {0, 0, 0}, ncell[3] = {1, 1, 1}, f0 = 1.0;   // grid_plan()
     double org[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
     int dim[3] = {1, 1, 1}, logmap[3] = {0, 0, 0}, naxes = 2;
 };
@@ -249,13 +258,14 @@ inline int bucket_of(double x, int logmap, double org, double inv, int dim)
 // point and applies the reference's own closed-interval test, so it returns the lowest-index containing
 // cell exactly as the linear scan does.  (The reference's own buildSpatialGrid, geometry.c:526-676, is
 // disabled at HEAD and tests DIMENSIONS against the wrong constants; it is not reproduced.)
-bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
+// extents, log mapping and typical cell widths of the mesh: what fixes the bucket grid up to a scale factor f
+bool grid_plan(const mcrat_hip_hydro *h, int naxes, GridHost &g)
 {
     const int M = h->num_elements;
     const double *c[3] = {h->r0, h->r1, h->r2};
     const double *s[3] = {h->r0_size, h->r1_size, h->r2_size};
     g.naxes = naxes;
-    double ext_lo[3], ext_hi[3], ncell[3];
+    double *ext_lo = g.ext_lo, *ext_hi = g.ext_hi, *ncell = g.ncell;
     for (int k = 0; k < naxes; ++k) {
         double lo = INFINITY, hi = -INFINITY, smin = INFINITY, smax = 0;
         for (int i = 0; i < M; ++i) {
@@ -284,24 +294,42 @@ bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
     double prod = 1;
     for (int k = 0; k < naxes; ++k) prod *= ncell[k];
     const double target = std::min(std::max(4.0 * (double)M, 1.0), 16777216.0);
-    double f = (prod > target) ? std::pow(target / prod, 1.0 / naxes) : 1.0;
+    g.f0 = (prod > target) ? std::pow(target / prod, 1.0 / naxes) : 1.0;
+    return true;
+}
+
+// the bucket grid for scale factor f; returns the number of buckets
+long long grid_dims(GridHost &g, int naxes, double f)
+{
+    long long nb = 1;
+    for (int k = 0; k < 3; ++k) {
+        g.dim[k] = 1; g.org[k] = 0; g.inv[k] = 0;
+        if (k < naxes) {
+            // buckets of about one cell, shifted by half a bucket against the mesh: on a regular mesh a bucket then
+            // straddles 2 cells per axis (4 in 2-D); aligned buckets would each touch 3 per axis because cell faces lie
+            // on bucket faces
+            const int nbk = (int)std::max(1.0, std::min(65536.0, std::floor(g.ncell[k] * f)));
+            const double width = (g.ext_hi[k] - g.ext_lo[k]) / nbk;
+            g.dim[k] = nbk + 1;
+            g.org[k] = g.ext_lo[k] - 0.5 * width;
+            g.inv[k] = 1.0 / width;
+        }
+        nb *= g.dim[k];
+    }
+    return nb;
+}
+
+// the host build (MCRAT_HIP_HOST_GRID=1): the cross-check of grid_build.hip
+bool build_grid(const mcrat_hip_hydro *h, int naxes, GridHost &g)
+{
+    const int M = h->num_elements;
+    const double *c[3] = {h->r0, h->r1, h->r2};
+    const double *s[3] = {h->r0_size, h->r1_size, h->r2_size};
+    if (!grid_plan(h, naxes, g)) return false;
+    double f = g.f0;
 
     for (int attempt = 0; attempt < 12; ++attempt, f *= 0.5) {
-        long long nb = 1;
-        for (int k = 0; k < 3; ++k) {
-            g.dim[k] = 1; g.org[k] = 0; g.inv[k] = 0;
-            if (k < naxes) {
-                // buckets of about one cell, shifted by half a bucket against the mesh: on a regular mesh a bucket then
-                // straddles 2 cells per axis (4 in 2-D, the batch the device fetches at once); aligned buckets would
-                // each touch 3 per axis because cell faces lie on bucket faces
-                const int nbk = (int)std::max(1.0, std::min(65536.0, std::floor(ncell[k] * f)));
-                const double width = (ext_hi[k] - ext_lo[k]) / nbk;
-                g.dim[k] = nbk + 1;
-                g.org[k] = ext_lo[k] - 0.5 * width;
-                g.inv[k] = 1.0 / width;
-            }
-            nb *= g.dim[k];
-        }
+        const long long nb = grid_dims(g, naxes, f);
         std::vector<long long> count((size_t)nb + 1, 0);
         auto range = [&](int i, int k, int &b0, int &b1) {
             const double m = 1e-9 * (std::fabs(c[k][i]) + s[k][i]);
@@ -423,9 +451,12 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     if (three && (!h->r2 || !h->r2_size)) return MCRAT_HIP_EINVAL;
     if (!two && !h->v2) return MCRAT_HIP_EINVAL;
 
+    // the cell-lookup grid is built on the device (grid_build.hip) from the staged per-cell records; the host build is the
+    // cross-check (MCRAT_HIP_HOST_GRID=1)
+    const int naxes = three ? 3 : 2;
+    const bool host_grid = getenv("MCRAT_HIP_HOST_GRID") != nullptr;
     GridHost g;
-    if (!build_grid(h, three ? 3 : 2, g)) { c->last_error = "cell-lookup grid: degenerate mesh"; return MCRAT_HIP_EINVAL; }
-
+    if (host_grid ? !build_grid(h, naxes, g) : !grid_plan(h, naxes, g)) { c->last_error = "cell-lookup grid: degenerate mesh"; return MCRAT_HIP_EINVAL; }
     bool any_hot = false;
     for (int i = 0; i < M; ++i) any_hot = any_hot || (h->temp[i] >= 1e7);
 
@@ -437,9 +468,6 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     const size_t o_temp = take(sizeof(double) * M);
     const size_t o_fc = !two ? take(sizeof(double) * M) : 0;
     const size_t o_k2e = any_hot ? take(sizeof(double) * M) : 0;
-    const size_t n_buckets = g.start.size() - 1;
-    const size_t o_start = take(sizeof(BucketDir) * n_buckets);
-    const size_t o_cells = take(sizeof(FatCell) * std::max<size_t>(g.cells.size(), 1));
     const size_t total = off;
 
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -486,24 +514,6 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
         for (int i = 0; i < M; ++i) { g2[i].c2 = h->r2[i]; g2[i].s2 = h->r2_size[i]; }
     }
     memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
-    {
-        BucketDir *dir = reinterpret_cast<BucketDir *>(host.data() + o_start);
-        for (size_t b = 0; b < n_buckets; ++b) {
-            dir[b].e0 = g.start[b]; dir[b].n = g.start[b + 1] - g.start[b]; dir[b].hints = g.hints[b]; dir[b].pad = 0;
-        }
-    }
-    {   // bucket lists as complete copies of the member cells' records (device_types.hpp, FatCell)
-        FatCell *fat = reinterpret_cast<FatCell *>(host.data() + o_cells);
-        for (size_t e = 0; e < g.cells.size(); ++e) {
-            const int ci = g.cells[e];
-            FatCell &f = fat[e];
-            f.c0 = geom[ci].c0; f.c1 = geom[ci].c1; f.s0 = geom[ci].s0; f.s1 = geom[ci].s1;
-            f.a = fluid[ci].a; f.b = fluid[ci].b; f.gamma = fluid[ci].gamma; f.dens_lab = fluid[ci].dens_lab;
-            f.c2 = three ? h->r2[ci] : 0.0; f.s2 = three ? h->r2_size[ci] : 0.0;
-            f.fc = fc ? fc[ci] : 0.0;
-            f.cell = ci; f.pad = 0;
-        }
-    }
     HIPCHK(c, hipMemcpy(c->hy_buf, host.data(), total, hipMemcpyHostToDevice));
 
     char *base = static_cast<char *>(c->hy_buf);
@@ -518,8 +528,80 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     hy.dom0[0] = h->r0_domain[0]; hy.dom0[1] = h->r0_domain[1];
     hy.dom1[0] = h->r1_domain[0]; hy.dom1[1] = h->r1_domain[1];
     hy.dom2[0] = h->r2_domain[0]; hy.dom2[1] = h->r2_domain[1];
-    hy.grid.dir = reinterpret_cast<const BucketDir *>(base + o_start);
-    hy.grid.cells = reinterpret_cast<const FatCell *>(base + o_cells);
+
+    // ---- the grid
+    long long nb = 0, entries_total = 0;
+    if (host_grid) {
+        nb = (long long)g.start.size() - 1;
+        entries_total = (long long)g.cells.size();
+    } else {
+        if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+        double f = g.f0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 12 && !ok; ++attempt, f *= 0.5) {
+            nb = grid_dims(g, naxes, f);
+            if (nb > (long long)GRID_CODE_BUCKET_MASK) continue;              // bucket codes keep 27 bits for the index
+            if (c->grid_count_cap < (size_t)nb) {
+                if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
+                HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)nb));
+                c->grid_count_cap = (size_t)nb;
+            }
+            GridPlan plan;
+            for (int k = 0; k < 3; ++k) { plan.org[k] = g.org[k]; plan.inv[k] = g.inv[k]; plan.dim[k] = g.dim[k]; plan.logmap[k] = g.logmap[k]; }
+            plan.naxes = naxes;
+            HIPCHK(c, grid_count(plan, hy.geom, hy.geom2, M, c->grid_count, nb, c->d_grid_total, c->stream));
+            unsigned long long tot = 0;
+            HIPCHK(c, hipMemcpyAsync(&tot, c->d_grid_total, sizeof tot, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (tot > (unsigned long long)(64LL * M + 1024) || tot > 2000000000ull) continue;   // too fine for this mesh: coarsen and retry
+            entries_total = (long long)tot;
+            ok = true;
+            if (getenv("MCRAT_HIP_VERBOSE"))
+                fprintf(stderr, "mcrat_hip: cell-lookup grid %d x %d x %d buckets, %lld entries for %d cells (%.2f per bucket), built on the device\n",
+                        g.dim[0], g.dim[1], g.dim[2], entries_total, M, (double)entries_total / (double)nb);
+        }
+        if (!ok) { c->last_error = "cell-lookup grid: no bucket size fits this mesh"; return MCRAT_HIP_EINVAL; }
+    }
+    size_t goff = 0;
+    auto gtake = [&](size_t bytes) { size_t o = goff; goff = align_up(goff + bytes, 256); return o; };
+    const size_t o_dir = gtake(sizeof(BucketDir) * (size_t)nb);
+    const size_t o_cells = gtake(sizeof(FatCell) * std::max<size_t>((size_t)entries_total, 1));
+    const size_t o_start = gtake(sizeof(int) * ((size_t)nb + 1));                // device build only: scratch
+    const size_t o_scan = gtake(sizeof(int) * grid_scan_scratch_ints(nb));
+    const size_t o_entries = gtake(sizeof(int) * std::max<size_t>((size_t)entries_total, 1));
+    const size_t gtotal = goff;
+    if (c->grid_buf && c->grid_bytes < gtotal) { HIPCHK(c, hipFree(c->grid_buf)); c->grid_buf = nullptr; c->grid_bytes = 0; }
+    if (!c->grid_buf) { HIPCHK(c, hipMalloc(&c->grid_buf, gtotal)); c->grid_bytes = gtotal; }
+    char *gbase = static_cast<char *>(c->grid_buf);
+    if (host_grid) {
+        std::vector<char> gh(o_start, 0);
+        BucketDir *dir = reinterpret_cast<BucketDir *>(gh.data() + o_dir);
+        for (size_t b = 0; b < (size_t)nb; ++b) {
+            dir[b].e0 = g.start[b]; dir[b].n = g.start[b + 1] - g.start[b]; dir[b].hints = g.hints[b]; dir[b].pad = 0;
+        }
+        // bucket lists as complete copies of the member cells' records (device_types.hpp, FatCell)
+        FatCell *fat = reinterpret_cast<FatCell *>(gh.data() + o_cells);
+        for (size_t e = 0; e < g.cells.size(); ++e) {
+            const int ci = g.cells[e];
+            FatCell &f = fat[e];
+            f.c0 = geom[ci].c0; f.c1 = geom[ci].c1; f.s0 = geom[ci].s0; f.s1 = geom[ci].s1;
+            f.a = fluid[ci].a; f.b = fluid[ci].b; f.gamma = fluid[ci].gamma; f.dens_lab = fluid[ci].dens_lab;
+            f.c2 = three ? h->r2[ci] : 0.0; f.s2 = three ? h->r2_size[ci] : 0.0;
+            f.fc = fc ? fc[ci] : 0.0;
+            f.cell = ci; f.pad = 0;
+        }
+        HIPCHK(c, hipMemcpy(gbase, gh.data(), o_start, hipMemcpyHostToDevice));
+    } else {
+        GridPlan plan;
+        for (int k = 0; k < 3; ++k) { plan.org[k] = g.org[k]; plan.inv[k] = g.inv[k]; plan.dim[k] = g.dim[k]; plan.logmap[k] = g.logmap[k]; }
+        plan.naxes = naxes;
+        HIPCHK(c, grid_build(plan, hy.geom, hy.geom2, hy.fluid, hy.fluid_c, M, c->grid_count, reinterpret_cast<int *>(gbase + o_start),
+                             reinterpret_cast<int *>(gbase + o_scan), reinterpret_cast<int *>(gbase + o_entries),
+                             reinterpret_cast<FatCell *>(gbase + o_cells), reinterpret_cast<BucketDir *>(gbase + o_dir), nb, entries_total, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    hy.grid.dir = reinterpret_cast<const BucketDir *>(gbase + o_dir);
+    hy.grid.cells = reinterpret_cast<const FatCell *>(gbase + o_cells);
     for (int k = 0; k < 3; ++k) {
         hy.grid.org[k] = g.org[k]; hy.grid.inv[k] = g.inv[k]; hy.grid.dim[k] = g.dim[k]; hy.grid.logmap[k] = g.logmap[k];
     }

@@ -40,6 +40,18 @@ hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const 
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);
 hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream);
+// the cell-lookup grid, built on the device (grid_build.hip)
+struct GridPlan {
+    double org[3], inv[3];
+    int dim[3], logmap[3];
+    int naxes;
+};
+hipError_t grid_count(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, int M, unsigned *count, long long nb,
+                      unsigned long long *d_total, hipStream_t stream);
+size_t grid_scan_scratch_ints(long long nb);
+hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
+                      unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
+                      long long total, hipStream_t stream);
 hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, const double *a0, const double *a1,
                          const double *a2, int *out, hipStream_t stream);
 

@@ -546,3 +546,37 @@ def test_table_mode_needs_its_table(hip):
     d = hip.Engine(cfg["dimensions"], cfg["geometry"], 0)
     with pytest.raises(hip.McratHipError):
         d.set_hot_cross_section(_hot_table())         # a DIRECT context takes no table
+
+
+@pytest.mark.parametrize("which", ["flash", "pluto", "sph3d"])
+def test_device_built_grid_equals_host_built_grid(hip, which, monkeypatch):
+    """the cell-lookup grid is built on the device (grid_build.hip); the host build (MCRAT_HIP_HOST_GRID=1) is its
+    cross-check: same answers for interior points, face / corner points and points outside the mesh"""
+    rng = np.random.default_rng(11)
+    if which == "flash":
+        frame, _, cfg = synth.config2(n_photons=64, nzc=16)
+    elif which == "pluto":
+        frame, _, cfg = synth.config3(n_photons=64, nr=192, nth=96)
+    else:
+        frame, _, cfg = synth.config_3d(synth.SPHERICAL, n_photons=64)
+    three = cfg["dimensions"] == synth.THREE
+    M = frame["num_elements"]
+    pick = rng.integers(0, M, 20000)
+    u = rng.random((3, pick.size)) - 0.5
+    snap = (np.arange(pick.size) % 3 == 0)
+    u[:, snap] = np.sign(u[:, snap]) * 0.5
+    a0 = frame["r0"][pick] + u[0] * frame["r0_size"][pick]
+    a1 = frame["r1"][pick] + u[1] * frame["r1_size"][pick]
+    a2 = frame["r2"][pick] + u[2] * frame["r2_size"][pick] if three else None
+    got = []
+    for host_grid in (False, True):
+        if host_grid:
+            monkeypatch.setenv("MCRAT_HIP_HOST_GRID", "1")
+        else:
+            monkeypatch.delenv("MCRAT_HIP_HOST_GRID", raising=False)
+        e = hip.Engine(cfg["dimensions"], cfg["geometry"], 0)
+        e.set_hydro(frame)
+        got.append(e.lookup_cell(a0, a1, a2))
+        e.close()
+    assert np.array_equal(got[0], got[1])
+    assert (got[0][~snap] == pick[~snap]).all()
