@@ -40,6 +40,8 @@ struct mcrat_hip_ctx {
     void *ph_snap = nullptr;          // mcrat_hip_snapshot_photons
     size_t ph_snap_bytes = 0;
     bool have_photons = false;
+    void *aos_buf = nullptr;          // device copy of the caller's struct photon records (mcrat_hip_set_photons / get_photons)
+    size_t aos_bytes = 0;
     int step_blocks = 0;
     Cand *partials = nullptr;
     int partials_cap = 0;
@@ -196,6 +198,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->ph_buf) (void)hipFree(c->ph_buf);
     if (c->ph_snap) (void)hipFree(c->ph_snap);
+    if (c->aos_buf) (void)hipFree(c->aos_buf);
     if (c->hy_buf) (void)hipFree(c->hy_buf);
     if (c->grid_buf) (void)hipFree(c->grid_buf);
     if (c->grid_count) (void)hipFree(c->grid_count);
@@ -716,28 +719,28 @@ static int upload_columns(mcrat_hip_ctx *c, int n, const std::vector<const doubl
     return MCRAT_HIP_OK;
 }
 
+static int ensure_aos(mcrat_hip_ctx *c, size_t bytes)
+{
+    if (c->aos_buf && c->aos_bytes < bytes) { HIPCHK(c, hipFree(c->aos_buf)); c->aos_buf = nullptr; c->aos_bytes = 0; }
+    if (!c->aos_buf) { HIPCHK(c, hipMalloc(&c->aos_buf, bytes)); c->aos_bytes = bytes; }
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_set_photons(mcrat_hip_ctx *c, const mcrat_hip_photon_list *l)
 {
     if (!c || !l || !l->photons || l->list_capacity <= 0) return MCRAT_HIP_EINVAL;
     const int n = l->list_capacity;
     int rc = alloc_photons(c, n);
     if (rc) return rc;
-    std::vector<double> col((size_t)19 * n);
-    std::vector<int> idx(n);
-    std::vector<unsigned char> flags(n);
-    std::vector<char> type(n);
-    for (int i = 0; i < n; ++i) {
-        const mcrat_hip_photon &q = l->photons[i];
-        const double v[19] = {q.r0, q.r1, q.r2, q.p0, q.p1, q.p2, q.p3, q.comv_p0, q.comv_p1, q.comv_p2, q.comv_p3,
-                              q.s0, q.s1, q.s2, q.s3, q.num_scatt, q.weight, q.total_optical_depth, q.time_to_scatter};
-        for (int k = 0; k < 19; ++k) col[(size_t)k * n + i] = v[k];
-        idx[i] = q.nearest_block_index;
-        flags[i] = make_flags(q.type, q.weight, q.recalc_properties);
-        type[i] = q.type;
-    }
-    std::vector<const double *> src(19);
-    for (int k = 0; k < 19; ++k) src[k] = col.data() + (size_t)k * n;
-    return upload_columns(c, n, src, idx.data(), flags.data(), type.data());
+    // the records cross PCIe as they lie in the caller's memory; staging.hip transposes them on the device
+    const size_t bytes = sizeof(mcrat_hip_photon) * (size_t)n;
+    if ((rc = ensure_aos(c, bytes))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->aos_buf, l->photons, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_aos_to_soa(c->aos_buf, c->ph, n, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_photons = true;
+    c->frame_open = false;
+    return MCRAT_HIP_OK;
 }
 
 extern "C" int mcrat_hip_set_photons_soa(mcrat_hip_ctx *c, const mcrat_hip_photon_soa *s)
@@ -825,34 +828,16 @@ extern "C" int mcrat_hip_get_photons(mcrat_hip_ctx *c, mcrat_hip_photon_list *l)
     if (!c->have_photons) return MCRAT_HIP_ESTATE;
     if (l->list_capacity != c->ph.n) return MCRAT_HIP_EINVAL;
     const int n = c->ph.n;
-    std::vector<double> col((size_t)19 * n);
-    std::vector<int> idx(n), recalc(n);
-    std::vector<char> type(n);
-    mcrat_hip_photon_soa s;
-    memset(&s, 0, sizeof s);
-    s.n = n;
-    double **dst[19] = {&s.r0, &s.r1, &s.r2, &s.p0, &s.p1, &s.p2, &s.p3, &s.comv_p0, &s.comv_p1, &s.comv_p2, &s.comv_p3,
-                        &s.s0, &s.s1, &s.s2, &s.s3, &s.num_scatt, &s.weight, &s.total_optical_depth, &s.time_to_scatter};
-    for (int k = 0; k < 19; ++k) *dst[k] = col.data() + (size_t)k * n;
-    s.nearest_block_index = idx.data();
-    s.recalc_properties = recalc.data();
-    s.type = type.data();
-    int rc = mcrat_hip_get_photons_soa(c, &s);
+    int rc = flush_pending(c);
     if (rc) return rc;
-    for (int i = 0; i < n; ++i) {
-        mcrat_hip_photon &q = l->photons[i];
-        q.type = type[i];
-        q.r0 = s.r0[i]; q.r1 = s.r1[i]; q.r2 = s.r2[i];
-        q.p0 = s.p0[i]; q.p1 = s.p1[i]; q.p2 = s.p2[i]; q.p3 = s.p3[i];
-        q.comv_p0 = s.comv_p0[i]; q.comv_p1 = s.comv_p1[i]; q.comv_p2 = s.comv_p2[i]; q.comv_p3 = s.comv_p3[i];
-        q.s0 = s.s0[i]; q.s1 = s.s1[i]; q.s2 = s.s2[i]; q.s3 = s.s3[i];
-        q.num_scatt = s.num_scatt[i];
-        q.weight = s.weight[i];
-        q.total_optical_depth = s.total_optical_depth[i];
-        q.time_to_scatter = s.time_to_scatter[i];
-        q.nearest_block_index = idx[i];
-        q.recalc_properties = recalc[i];
-    }
+    const size_t bytes = sizeof(mcrat_hip_photon) * (size_t)n;
+    const bool fresh = !c->aos_buf || c->aos_bytes < bytes;
+    if ((rc = ensure_aos(c, bytes))) return rc;
+    // photons that came in as SoA columns have no uploaded records: the bytes between the members are the caller's
+    if (fresh) HIPCHK(c, hipMemcpyAsync(c->aos_buf, l->photons, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_soa_to_aos(c->ph, c->aos_buf, n, c->stream));
+    HIPCHK(c, hipMemcpyAsync(l->photons, c->aos_buf, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCRAT_HIP_OK;
 }
 

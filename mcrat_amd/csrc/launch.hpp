@@ -40,6 +40,10 @@ hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const 
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);
 hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream);
+// struct photon records <-> SoA columns on the device (staging.hip); `aos` is a device buffer of n 176-B records
+hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream);
+hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int n, hipStream_t stream);
+
 // the cell-lookup grid, built on the device (grid_build.hip)
 struct GridPlan {
     double org[3], inv[3];

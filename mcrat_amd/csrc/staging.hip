@@ -1,0 +1,76 @@
+// staging.hip -- struct photon records (Src/mcrat.h:142-171, 176 B, AoS) <-> the engine's SoA columns, on the device.
+// The caller's photon list crosses PCIe once as it lies in memory; the transposition, the derived columns
+// (device_types.hpp: u = (p_k (1/p0)) c as mclib.c:1074-1080 forms it, -1/tau as mclib.c:680) and the flag byte are
+// produced here instead of in a host loop over 10^6 - 10^8 records.
+#include <hip/hip_runtime.h>
+#include "../../include/mcrat_hip.h"
+#include "device_types.hpp"
+#include "launch.hpp"
+
+namespace mcrat {
+
+namespace {
+
+__global__ __launch_bounds__(256) void aos_to_soa_kernel(const mcrat_hip_photon *__restrict__ aos, PhotonDev ph, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const mcrat_hip_photon q = aos[i];
+    ph.r0[i] = q.r0; ph.r1[i] = q.r1; ph.r2[i] = q.r2;
+    ph.p0[i] = q.p0; ph.p1[i] = q.p1; ph.p2[i] = q.p2; ph.p3[i] = q.p3;
+    ph.c0[i] = q.comv_p0; ph.c1[i] = q.comv_p1; ph.c2[i] = q.comv_p2; ph.c3[i] = q.comv_p3;
+    ph.s0[i] = q.s0; ph.s1[i] = q.s1; ph.s2[i] = q.s2; ph.s3[i] = q.s3;
+    ph.num_scatt[i] = q.num_scatt;
+    ph.weight[i] = q.weight;
+    ph.tau[i] = q.total_optical_depth;
+    ph.tts[i] = q.time_to_scatter;
+    double u0 = 0, u1 = 0, u2 = 0;
+    if (q.p0 != 0) {
+        const double d = 1.0 / q.p0;
+        u0 = q.p1 * d * C_LIGHT; u1 = q.p2 * d * C_LIGHT; u2 = q.p3 * d * C_LIGHT;
+    }
+    ph.u0[i] = u0; ph.u1[i] = u1; ph.u2[i] = u2;
+    ph.ntau[i] = -1.0 / q.total_optical_depth;
+    ph.tau_next[i] = 0.0;
+    ph.idx[i] = q.nearest_block_index;
+    unsigned f = FLAG_VALID;
+    if (q.type != 'p' && q.weight != 0) f |= FLAG_MOVES;      // mclib.c:1070
+    if (q.recalc_properties == 1) f |= FLAG_RECALC;
+    ph.flags[i] = (unsigned char)f;
+    ph.type[i] = q.type;
+}
+
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(PhotonDev ph, mcrat_hip_photon *__restrict__ aos, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    mcrat_hip_photon q = aos[i];          // keeps the bytes between the members as they were uploaded
+    q.type = ph.type[i];
+    q.r0 = ph.r0[i]; q.r1 = ph.r1[i]; q.r2 = ph.r2[i];
+    q.p0 = ph.p0[i]; q.p1 = ph.p1[i]; q.p2 = ph.p2[i]; q.p3 = ph.p3[i];
+    q.comv_p0 = ph.c0[i]; q.comv_p1 = ph.c1[i]; q.comv_p2 = ph.c2[i]; q.comv_p3 = ph.c3[i];
+    q.s0 = ph.s0[i]; q.s1 = ph.s1[i]; q.s2 = ph.s2[i]; q.s3 = ph.s3[i];
+    q.num_scatt = ph.num_scatt[i];
+    q.weight = ph.weight[i];
+    q.total_optical_depth = ph.tau[i];
+    q.time_to_scatter = ph.tts[i];
+    q.nearest_block_index = ph.idx[i];
+    q.recalc_properties = (ph.flags[i] & FLAG_RECALC) ? 1 : 0;
+    aos[i] = q;
+}
+
+}  // namespace
+
+hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream)
+{
+    aos_to_soa_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(static_cast<const mcrat_hip_photon *>(aos), ph, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int n, hipStream_t stream)
+{
+    soa_to_aos_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(ph, static_cast<mcrat_hip_photon *>(aos), n);
+    return hipGetLastError();
+}
+
+}  // namespace mcrat
