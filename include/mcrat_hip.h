@@ -168,6 +168,16 @@ const char *mcrat_hip_last_error(const mcrat_hip_ctx *ctx);   /* text of the las
 /* staging: once per hydro frame (after getHydroData, mcrat.c:721) ------------- */
 int mcrat_hip_set_hydro(mcrat_hip_ctx *ctx, const mcrat_hip_hydro *hydro);
 
+/* photonInjection (mclib.c:9-300; mcrat.c:645) on the device, from the staged hydro frame: afterwards the context holds
+ * the new photons (*num_photons of them, all of weight *ph_weight_adjusted -- the reference's min/max-photons loop of
+ * mclib.c:87-136 runs on the device counts) exactly as if they had been injected on the host and handed to
+ * mcrat_hip_set_photons; mcrat_hip_get_photons returns them as struct photon records (the caller allocates
+ * *num_photons of them, as setPhotonList would).  spect: 'b' black body, 'w' Wien (mc.par); fps as in hydro_dataframe.
+ * The random numbers are the engine's keyed source with the reference's draw order (seed: any 64-bit value, e.g. the
+ * gsl_rng_get() of the rank); the Poisson counts come from the engine's own sampler. */
+int mcrat_hip_inject_photons(mcrat_hip_ctx *ctx, double r_inj, double ph_weight, int min_photons, int max_photons, char spect,
+                             double theta_min, double theta_max, double fps, uint64_t seed, int *num_photons, double *ph_weight_adjusted);
+
 /* TAU_CALCULATION == TABLE, once per run (after initalizeHotCrossSection, hot_x_section.c:29-80): the table
  * getThermalCrossSection interpolates (optical_depth.c:132-149).  thermal_table is the reference's global
  * thermal_table[N_PH_E + 1][N_T + 1] (hot_x_section.c; log10 of the cross section over sigma_T, photon-energy index

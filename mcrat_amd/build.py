@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcrat_hip.so")
-SOURCES = ["kernels.hip", "kernels_table.hip", "grid_build.hip", "staging.hip", "engine.hip"]
+SOURCES = ["kernels.hip", "kernels_table.hip", "grid_build.hip", "staging.hip", "inject.hip", "engine.hip"]
 HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 OBJDIR = os.path.join(HERE, "_obj")
@@ -21,6 +21,7 @@ _KERNEL_DEPS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", 
 DEPS = {"kernels.hip": _KERNEL_DEPS, "kernels_table.hip": _KERNEL_DEPS + ["kernels_table.hip"],
         "grid_build.hip": ["grid_build.hip", "device_types.hpp", "launch.hpp"],
         "staging.hip": ["staging.hip", "device_types.hpp", "launch.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")],
+        "inject.hip": ["inject.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"],
         "engine.hip": ["engine.hip", "device_types.hpp", "launch.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]}
 
 

@@ -743,6 +743,59 @@ extern "C" int mcrat_hip_set_photons(mcrat_hip_ctx *c, const mcrat_hip_photon_li
     return MCRAT_HIP_OK;
 }
 
+extern "C" int mcrat_hip_inject_photons(mcrat_hip_ctx *c, double r_inj, double ph_weight, int min_photons, int max_photons, char spect,
+                                        double theta_min, double theta_max, double fps, uint64_t seed, int *num_photons,
+                                        double *ph_weight_adjusted)
+{
+    if (!c || !(ph_weight > 0) || !(fps > 0) || min_photons < 0 || max_photons < min_photons || (spect != 'b' && spect != 'w')) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro) return MCRAT_HIP_ESTATE;
+    const int M = c->hy.M;
+    InjectParams p;
+    p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry;
+    p.rmin = r_inj - 0.5 * C_LIGHT / fps;                      // mclib.c:34-35
+    p.rmax = r_inj + 0.5 * C_LIGHT / fps;
+    p.theta_min = theta_min; p.theta_max = theta_max;
+    p.num_dens_coeff = (spect == 'w') ? (double)8.44f : (double)20.29f;   // a float in the reference, mclib.c:17,23-32
+    p.wien = spect == 'w';
+    RngKey key = c->key;
+    key.seed = seed;
+    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+    if (c->grid_count_cap < (size_t)M) {
+        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
+        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)M));
+        c->grid_count_cap = (size_t)M;
+    }
+    // mclib.c:87-136: draw the per-cell counts; too many photons -> weight x 10, too few -> weight x 0.5, draw again
+    double weight = ph_weight;
+    unsigned long long total = 0;
+    bool ok = false;
+    for (unsigned long long attempt = 0; attempt <= 200; ++attempt) {
+        HIPCHK(c, launch_inject_count(p, c->hy, weight, attempt, key, c->grid_count, c->d_grid_total, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (total > (unsigned long long)max_photons) weight *= 10;
+        else if (total < (unsigned long long)min_photons) weight *= 0.5;
+        else { ok = true; break; }
+    }
+    if (!ok) { c->last_error = "photon injection: no weight puts the photon count between min_photons and max_photons"; return MCRAT_HIP_EINVAL; }
+    if (total == 0) { c->last_error = "photon injection: no photons (no cell of the frame touches the injection slab?)"; return MCRAT_HIP_EINVAL; }
+    const int n = (int)total;
+    int rc = alloc_photons(c, n);
+    if (rc) return rc;
+    // cell -> first photon: exclusive scan of the counts (scratch: the record staging buffer)
+    const size_t scan_bytes = sizeof(int) * ((size_t)M + 1 + grid_scan_scratch_ints(M));
+    if ((rc = ensure_aos(c, scan_bytes))) return rc;
+    int *start = static_cast<int *>(c->aos_buf), *scratch = start + M + 1;
+    HIPCHK(c, launch_exclusive_scan(c->grid_count, M, start, scratch, (long long)total, c->stream));
+    HIPCHK(c, launch_inject_generate(p, c->hy, weight, key, start, c->ph, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_photons = true;
+    c->frame_open = false;
+    if (num_photons) *num_photons = n;
+    if (ph_weight_adjusted) *ph_weight_adjusted = weight;
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_set_photons_soa(mcrat_hip_ctx *c, const mcrat_hip_photon_soa *s)
 {
     if (!c || !s || s->n <= 0) return MCRAT_HIP_EINVAL;

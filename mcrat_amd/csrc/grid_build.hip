@@ -241,15 +241,23 @@ hipError_t grid_count(const GridPlan &p, const CellGeom *geom, const CellGeom2 *
 
 size_t grid_scan_scratch_ints(long long nb) { return (size_t)((nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK) + 1; }
 
+// start[0..n] = exclusive prefix sums of count[0..n), start[n] = total; scratch holds grid_scan_scratch_ints(n) ints
+hipError_t launch_exclusive_scan(const unsigned *count, long long n, int *start, int *scratch, long long total, hipStream_t stream)
+{
+    const int nblocks = (int)((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
+    scan_blocks_kernel<<<dim3(nblocks), dim3(256), 0, stream>>>(count, n, start, scratch);
+    scan_sums_kernel<<<dim3(1), dim3(256), 0, stream>>>(scratch, nblocks);
+    scan_add_kernel<<<dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream>>>(start, n, scratch, (int)total);
+    return hipGetLastError();
+}
+
 hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
                       unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
                       long long total, hipStream_t stream)
 {
-    const int nblocks = (int)((nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK);
-    scan_blocks_kernel<<<dim3(nblocks), dim3(256), 0, stream>>>(count, nb, start, scan_scratch);
-    scan_sums_kernel<<<dim3(1), dim3(256), 0, stream>>>(scan_scratch, nblocks);
-    scan_add_kernel<<<dim3((unsigned)((nb + 1 + 255) / 256)), dim3(256), 0, stream>>>(start, nb, scan_scratch, (int)total);
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(unsigned) * (size_t)nb, stream);      // now the fill cursors
+    hipError_t e = launch_exclusive_scan(count, nb, start, scan_scratch, total, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(count, 0, sizeof(unsigned) * (size_t)nb, stream);      // now the fill cursors
     if (e != hipSuccess) return e;
     grid_fill_kernel<<<dim3((M + 255) / 256), dim3(256), 0, stream>>>(p, geom, geom2, M, start, count, entries);
     grid_finish_kernel<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream>>>(p, nb, start, entries, geom, geom2, fluid, fluid_c, cells, dir);

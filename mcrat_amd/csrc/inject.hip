@@ -1,0 +1,264 @@
+// inject.hip -- photonInjection on the device (Src/mclib.c:9-300): the producer of the loop's input.
+// Cells of the staged hydro frame that touch the injection slab r_inj -+ c/(2 fps), theta_min..theta_max get a Poisson
+// number of photons with mean (4/3) V gamma a_n T^3 / weight; the weight is adjusted (x10 / x0.5) until the total lies
+// in [min_photons, max_photons]; each photon draws a comoving black-body (Bjorkman & Wood 2001) or Wien frequency, an
+// isotropic comoving direction, is boosted to the lab frame with its cell's velocity and placed uniformly in the cell.
+// Random numbers: rng.hpp's keyed source -- the count of cell i in attempt a from the stream {a, i, INJECT_COUNT}, the
+// draws of photon k (numbered over the whole injection, cells ascending) from the stream {0, k, INJECT_PHOTON}, in the
+// reference's draw order.  gsl_ran_poisson's algorithm lives in GSL; the count sampler here (Knuth below a mean of 30,
+// Hormann's PTRS above) is the one the oracle restates.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "device_types.hpp"
+#include "launch.hpp"
+#include "physics.hpp"
+#include "rng.hpp"
+
+namespace mcrat {
+
+namespace {
+
+constexpr uint32_t RNG_INJECT_COUNT = 2u;
+constexpr uint32_t RNG_INJECT_PHOTON = 3u;
+
+__device__ __forceinline__ EventStream keyed_stream(const RngKey &key, unsigned long long iteration, uint32_t word2, uint32_t purpose)
+{
+    const Philox4 b = keyed_block(key.seed, iteration, word2, purpose, key.stream);
+    EventStream s;
+    s.state = (uint64_t)b.w[0] | ((uint64_t)b.w[1] << 32);
+    return s;
+}
+
+// geometry.c:66-106
+__device__ __forceinline__ void hydro_to_spherical(int dims, int geom, double r0, double r1, double r2, double &r, double &theta)
+{
+    r = 0; theta = 0;
+    if (dims == DIM_TWO || dims == DIM_TWO_POINT_FIVE) {
+        if (geom == GEOM_CARTESIAN || geom == GEOM_CYLINDRICAL) { r = sqrt(r0 * r0 + r1 * r1); theta = atan2(r0, r1); }
+        if (geom == GEOM_SPHERICAL) { r = r0; theta = r1; }
+    } else {
+        if (geom == GEOM_CARTESIAN) { r = sqrt(r0 * r0 + r1 * r1 + r2 * r2); theta = acos(r2 / r); }
+        if (geom == GEOM_SPHERICAL) { r = r0; theta = r1; }
+        if (geom == GEOM_POLAR) { r = sqrt(r0 * r0 + r2 * r2); theta = acos(r2 / r); }
+    }
+}
+
+// geometry.c:108-156
+__device__ __forceinline__ void hydro_to_mcrat(int dims, int geom, double r0, double r1, double r2, double out[3])
+{
+    double x = 0, y = 0, z = 0;
+    if (dims == DIM_TWO || dims == DIM_TWO_POINT_FIVE) {
+        if (geom == GEOM_CARTESIAN || geom == GEOM_CYLINDRICAL) { x = r0 * cos(r2); y = r0 * sin(r2); z = r1; }
+        if (geom == GEOM_SPHERICAL) { x = r0 * sin(r1) * cos(r2); y = r0 * sin(r1) * sin(r2); z = r0 * cos(r1); }
+    } else {
+        if (geom == GEOM_CARTESIAN) { x = r0; y = r1; z = r2; }
+        if (geom == GEOM_SPHERICAL) { x = r0 * sin(r1) * cos(r2); y = r0 * sin(r1) * sin(r2); z = r0 * cos(r1); }
+        if (geom == GEOM_POLAR) { x = r0 * cos(r1); y = r0 * sin(r1); z = r2; }
+    }
+    out[0] = x; out[1] = y; out[2] = z;
+}
+
+struct CellRec {
+    double c0, c1, c2, s0, s1, s2;
+};
+
+__device__ __forceinline__ CellRec load_cell(const HydroDev &hy, int dims, int i)
+{
+    const CellGeom g = hy.geom[i];
+    CellRec c;
+    c.c0 = g.c0; c.c1 = g.c1; c.s0 = g.s0; c.s1 = g.s1; c.c2 = 0; c.s2 = 0;
+    if (dims == DIM_THREE) { const CellGeom2 g2 = hy.geom2[i]; c.c2 = g2.c2; c.s2 = g2.s2; }
+    return c;
+}
+
+// hydroElementVolume, geometry.c:255-296
+__device__ __forceinline__ double element_volume(int dims, int geom, const CellRec &c)
+{
+    const double r0_max = c.c0 + 0.5 * c.s0, r0_min = c.c0 - 0.5 * c.s0;
+    const double r1_max = c.c1 + 0.5 * c.s1, r1_min = c.c1 - 0.5 * c.s1;
+    double V = 0;
+    if (dims == DIM_TWO || dims == DIM_TWO_POINT_FIVE) {
+        if (geom == GEOM_CARTESIAN || geom == GEOM_CYLINDRICAL) V = M_PI * (r0_max * r0_max - r0_min * r0_min) * c.s1;
+        if (geom == GEOM_SPHERICAL) V = (2.0 * M_PI / 3.0) * (r0_max * r0_max * r0_max - r0_min * r0_min * r0_min) * (cos(r1_min) - cos(r1_max));
+    } else {
+        const double r2_max = c.c2 + 0.5 * c.s2, r2_min = c.c2 - 0.5 * c.s2;
+        if (geom == GEOM_CARTESIAN) V = c.s0 * c.s1 * c.s2;
+        if (geom == GEOM_SPHERICAL) V = (1.0 / 3.0) * (r0_max * r0_max * r0_max - r0_min * r0_min * r0_min) * (cos(r1_min) - cos(r1_max)) * (r2_max - r2_min);
+        if (geom == GEOM_POLAR) V = 0.5 * (r0_max * r0_max - r0_min * r0_min) * c.s1 * c.s2;
+    }
+    return V;
+}
+
+// mclib.c:40-57
+__device__ __forceinline__ bool in_injection_slab(const InjectParams &p, const CellRec &c)
+{
+    double r_in, th_in, r_out, th_out;
+    if (p.dimensions == DIM_THREE) {
+        hydro_to_spherical(p.dimensions, p.geometry, fabs(c.c0) - 0.5 * c.s0, fabs(c.c1) - 0.5 * c.s1, fabs(c.c2) - 0.5 * c.s2, r_in, th_in);
+        hydro_to_spherical(p.dimensions, p.geometry, fabs(c.c0) + 0.5 * c.s0, fabs(c.c1) + 0.5 * c.s1, fabs(c.c2) + 0.5 * c.s2, r_out, th_out);
+    } else {
+        hydro_to_spherical(p.dimensions, p.geometry, c.c0 - 0.5 * c.s0, c.c1 - 0.5 * c.s1, 0, r_in, th_in);
+        hydro_to_spherical(p.dimensions, p.geometry, c.c0 + 0.5 * c.s0, c.c1 + 0.5 * c.s1, 0, r_out, th_out);
+    }
+    return (p.rmin <= r_out) && (r_in <= p.rmax) && (th_out >= p.theta_min) && (th_in <= p.theta_max);
+}
+
+// stands for gsl_ran_poisson (mclib.c:114): see the head of this file
+__device__ __forceinline__ long long poisson(EventStream &rng, double mean)
+{
+    if (!(mean > 0)) return 0;
+    if (mean < 30.0) {
+        const double L = exp(-mean);
+        long long k = 0;
+        double prod = 1.0;
+        do {
+            k += 1;
+            prod *= rng.uniform_pos();
+        } while (prod > L);
+        return k - 1;
+    }
+    const double smu = sqrt(mean);
+    const double b = 0.931 + 2.53 * smu;
+    const double a = -0.059 + 0.02483 * b;
+    const double inv_alpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double v_r = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < phys::REJECTION_CAP; ++it) {
+        const double U = rng.uniform() - 0.5;
+        const double V = rng.uniform_pos();
+        const double us = 0.5 - fabs(U);
+        const double kf = floor((2.0 * a / us + b) * U + mean + 0.43);
+        if (us >= 0.07 && V <= v_r) return (long long)kf;
+        if (kf < 0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(inv_alpha) - log(a / (us * us) + b) <= -mean + kf * log(mean) - lgamma(kf + 1.0)) return (long long)kf;
+    }
+    return (long long)mean;
+}
+
+__global__ __launch_bounds__(256) void inject_count_kernel(InjectParams p, HydroDev hy, double weight, unsigned long long attempt, RngKey key,
+                                                           unsigned *__restrict__ count, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned long long s_sum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (i < hy.M) {
+        const CellRec c = load_cell(hy, p.dimensions, i);
+        unsigned n = 0;
+        if (in_injection_slab(p, c)) {
+            const double T = hy.temp[i];
+            const double gamma = hy.fluid[i].gamma;
+            const double ph_dens_calc = (4.0 / 3.0) * element_volume(p.dimensions, p.geometry, c) * ((gamma * p.num_dens_coeff * T * T * T) / weight);   // mclib.c:110
+            EventStream rng = keyed_stream(key, attempt, (uint32_t)i, RNG_INJECT_COUNT);
+            const long long k = poisson(rng, ph_dens_calc);
+            n = (unsigned)(k < 0 ? 0 : (k > 0x7fffffffll ? 0x7fffffffll : k));
+        }
+        count[i] = n;
+        mine = n;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+
+__global__ __launch_bounds__(256) void inject_generate_kernel(InjectParams p, HydroDev hy, double weight, RngKey key, const int *__restrict__ start,
+                                                              PhotonDev ph)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ph.n) return;
+    // the cell of photon k: start[i] <= k < start[i+1]
+    int lo = 0, hi = hy.M;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int i = lo;
+    const CellRec c = load_cell(hy, p.dimensions, i);
+    const double T = hy.temp[i];
+    EventStream rng = keyed_stream(key, 0ull, (uint32_t)k, RNG_INJECT_PHOTON);
+    double fr_dum = 0;
+    if (p.wien) {                                                            // mclib.c:175-190
+        double y_dum = 1, yfr_dum = 0;
+        for (int it = 0; it < phys::REJECTION_CAP && (y_dum > yfr_dum); ++it) {
+            fr_dum = rng.uniform_pos() * 6.3e11 * T;
+            y_dum = rng.uniform_pos();
+            yfr_dum = (1.0 / (1.29e31)) * pow((fr_dum / T), 3.0) / (exp((PL_CONST * fr_dum) / (K_B * T)) - 1);
+        }
+    } else {                                                                 // mclib.c:199-214
+        double test = 0, test_cnt = 0;
+        const double r1 = rng.uniform_pos(), r2 = rng.uniform_pos(), r3 = rng.uniform_pos(), r4 = rng.uniform_pos(), r5 = rng.uniform_pos();
+        while (test < M_PI * M_PI * M_PI * M_PI * r1 / 90.0) {
+            test_cnt += 1;
+            test += 1 / (test_cnt * test_cnt * test_cnt * test_cnt);
+        }
+        fr_dum = -log(r2 * r3 * r4 * r5) / test_cnt;
+        fr_dum *= K_B * T / PL_CONST;
+    }
+    double position_phi = 0;
+    if (p.dimensions != DIM_THREE) position_phi = rng.uniform() * 2 * M_PI;   // mclib.c:223-227
+    const double com_v_phi = rng.uniform() * 2 * M_PI;
+    const double com_v_theta = acos((rng.uniform() * 2) - 1);
+    double p_comv[4];
+    p_comv[0] = PL_CONST * fr_dum / C_LIGHT;                                 // mclib.c:232-235
+    p_comv[1] = (PL_CONST * fr_dum / C_LIGHT) * sin(com_v_theta) * cos(com_v_phi);
+    p_comv[2] = (PL_CONST * fr_dum / C_LIGHT) * sin(com_v_theta) * sin(com_v_phi);
+    p_comv[3] = (PL_CONST * fr_dum / C_LIGHT) * cos(com_v_theta);
+    // fluid velocity of the cell at the photon's azimuth (mclib.c:239-246), from the staged record (physics.hpp, cell_beta)
+    const CellFluid f = hy.fluid[i];
+    const double fcv = hy.fluid_c ? hy.fluid_c[i] : 0.0;
+    const double cphi = cos(position_phi), sphi = sin(position_phi);
+    double boost[3];
+    if (p.dimensions == DIM_TWO) phys::beta_from_record<DIM_TWO>(f.a, f.b, fcv, cphi, sphi, boost);
+    else if (p.dimensions == DIM_TWO_POINT_FIVE) phys::beta_from_record<DIM_TWO_POINT_FIVE>(f.a, f.b, fcv, cphi, sphi, boost);
+    else phys::beta_from_record<DIM_THREE>(f.a, f.b, fcv, cphi, sphi, boost);
+    boost[0] *= -1; boost[1] *= -1; boost[2] *= -1;
+    double l_boost[4];
+    phys::lorentz_boost(boost, p_comv, l_boost, true);                       // mclib.c:252
+    const double position_rand = rng.uniform_pos() * c.s0 - 0.5 * c.s0;      // mclib.c:265-266
+    const double position2_rand = rng.uniform_pos() * c.s1 - 0.5 * c.s1;
+    double xyz[3];
+    if (p.dimensions == DIM_THREE) {
+        const double position3_rand = rng.uniform_pos() * c.s2 - 0.5 * c.s2;
+        hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, c.c2 + position3_rand, xyz);
+    } else {
+        hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, position_phi, xyz);
+    }
+    ph.r0[k] = xyz[0]; ph.r1[k] = xyz[1]; ph.r2[k] = xyz[2];
+    ph.p0[k] = l_boost[0]; ph.p1[k] = l_boost[1]; ph.p2[k] = l_boost[2]; ph.p3[k] = l_boost[3];
+    ph.c0[k] = p_comv[0]; ph.c1[k] = p_comv[1]; ph.c2[k] = p_comv[2]; ph.c3[k] = p_comv[3];
+    ph.s0[k] = 1; ph.s1[k] = 0; ph.s2[k] = 0; ph.s3[k] = 0;                  // mclib.c:281-291
+    ph.num_scatt[k] = 0;
+    ph.weight[k] = weight;
+    ph.tau[k] = 0; ph.tts[k] = 0; ph.tau_next[k] = 0;
+    double u0 = 0, u1 = 0, u2 = 0;
+    if (l_boost[0] != 0) {
+        const double d = 1.0 / l_boost[0];
+        u0 = l_boost[1] * d * C_LIGHT; u1 = l_boost[2] * d * C_LIGHT; u2 = l_boost[3] * d * C_LIGHT;
+    }
+    ph.u0[k] = u0; ph.u1[k] = u1; ph.u2[k] = u2;
+    ph.ntau[k] = -INFINITY;                                                  // -1 / total_optical_depth with the 0 of a fresh photon
+    ph.idx[k] = 0;
+    unsigned fl = FLAG_VALID | FLAG_RECALC;                                  // recalc_properties = 1
+    if (weight != 0) fl |= FLAG_MOVES;                                       // type 'i' is not a CS-pool photon
+    ph.flags[k] = (unsigned char)fl;
+    ph.type[k] = 'i';                                                        // INJECTED_PHOTON, mcrat.h
+}
+
+}  // namespace
+
+hipError_t launch_inject_count(const InjectParams &p, const HydroDev &hy, double ph_weight_adjusted, unsigned long long attempt, RngKey key,
+                               unsigned *count, unsigned long long *d_total, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    inject_count_kernel<<<dim3((hy.M + 255) / 256), dim3(256), 0, stream>>>(p, hy, ph_weight_adjusted, attempt, key, count, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_inject_generate(const InjectParams &p, const HydroDev &hy, double ph_weight_adjusted, RngKey key, const int *start,
+                                  const PhotonDev &ph, hipStream_t stream)
+{
+    inject_generate_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(p, hy, ph_weight_adjusted, key, start, ph);
+    return hipGetLastError();
+}
+
+}  // namespace mcrat

@@ -53,6 +53,21 @@ struct GridPlan {
 hipError_t grid_count(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, int M, unsigned *count, long long nb,
                       unsigned long long *d_total, hipStream_t stream);
 size_t grid_scan_scratch_ints(long long nb);
+hipError_t launch_exclusive_scan(const unsigned *count, long long n, int *start, int *scratch, long long total, hipStream_t stream);
+
+// photonInjection on the device (inject.hip; mclib.c:9-300)
+struct InjectParams {
+    int dimensions, geometry;
+    double rmin, rmax, theta_min, theta_max;   // the injection slab, mclib.c:34-35,57
+    double num_dens_coeff;                     // 8.44f / 20.29f widened (mclib.c:23-32)
+    int wien;                                  // spect == 'w'
+};
+// Poisson photon count of every cell for one weight (mclib.c:87-136); *total receives the sum
+hipError_t launch_inject_count(const InjectParams &p, const HydroDev &hy, double ph_weight_adjusted, unsigned long long attempt, RngKey key,
+                               unsigned *count, unsigned long long *d_total, hipStream_t stream);
+// the photons themselves (mclib.c:150-296), ordered by cell then draw, into the SoA columns
+hipError_t launch_inject_generate(const InjectParams &p, const HydroDev &hy, double ph_weight_adjusted, RngKey key, const int *start,
+                                  const PhotonDev &ph, hipStream_t stream);
 hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
                       unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
                       long long total, hipStream_t stream);

@@ -96,6 +96,8 @@ SYMBOLS = {
     "mcrat_hip_strerror": (C.c_char_p, [C.c_int]),
     "mcrat_hip_last_error": (C.c_char_p, [_ctx]),
     "mcrat_hip_set_hydro": (C.c_int, [_ctx, C.POINTER(Hydro)]),
+    "mcrat_hip_inject_photons": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char, C.c_double, C.c_double, C.c_double,
+                                           C.c_uint64, _ip, _dp]),
     "mcrat_hip_set_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "mcrat_hip_set_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
     "mcrat_hip_get_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
@@ -201,6 +203,15 @@ class Engine:
         self._check(self.lib.mcrat_hip_set_hot_cross_section(self.ctx, t.ctypes.data_as(_dp), t.shape[0] - 1, t.shape[1] - 1,
                                                              float(grid[0]), float(grid[1]), float(grid[2]), float(grid[3])),
                     "set_hot_cross_section")
+
+    def inject_photons(self, r_inj, ph_weight, min_photons, max_photons, spect, theta_min, theta_max, fps, seed):
+        """photonInjection (mclib.c:9-300) on the device; returns (number of photons, adjusted weight)"""
+        n, w = C.c_int(0), C.c_double(0)
+        self._check(self.lib.mcrat_hip_inject_photons(self.ctx, float(r_inj), float(ph_weight), int(min_photons), int(max_photons),
+                                                      spect.encode() if isinstance(spect, str) else spect, float(theta_min), float(theta_max),
+                                                      float(fps), int(seed), C.byref(n), C.byref(w)), "inject_photons")
+        self.n = n.value
+        return n.value, w.value
 
     def set_hydro(self, frame):
         n = int(frame["num_elements"])

@@ -855,3 +855,192 @@ void orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro *h
     st->time_now = *time_now;
     st->table_misses += g_table_misses - misses0;
 }
+
+/* ------------------------------------------------------------------ */
+/* photonInjection and its helpers */
+
+/* geometry.c:66-106 */
+void orc_hydroCoordinateToSpherical(const orc_config *c, double *r, double *theta, double r0, double r1, double r2)
+{
+    double sph_r = 0, sph_theta = 0;
+    if (c->dimensions == ORC_TWO || c->dimensions == ORC_TWO_POINT_FIVE) {
+        if (c->geometry == ORC_CARTESIAN || c->geometry == ORC_CYLINDRICAL) {
+            sph_r = sqrt(r0 * r0 + r1 * r1);
+            sph_theta = atan2(r0, r1);
+        }
+        if (c->geometry == ORC_SPHERICAL) { sph_r = r0; sph_theta = r1; }
+    } else {
+        if (c->geometry == ORC_CARTESIAN) { sph_r = sqrt(r0 * r0 + r1 * r1 + r2 * r2); sph_theta = acos(r2 / sph_r); }
+        if (c->geometry == ORC_SPHERICAL) { sph_r = r0; sph_theta = r1; }
+        if (c->geometry == ORC_POLAR) { sph_r = sqrt(r0 * r0 + r2 * r2); sph_theta = acos(r2 / sph_r); }
+    }
+    *r = sph_r;
+    *theta = sph_theta;
+}
+
+/* geometry.c:108-156 */
+void orc_hydroCoordinateToMcratCoordinate(const orc_config *c, double out[3], double r0, double r1, double r2)
+{
+    double x = 0, y = 0, z = 0;
+    if (c->dimensions == ORC_TWO || c->dimensions == ORC_TWO_POINT_FIVE) {
+        if (c->geometry == ORC_CARTESIAN || c->geometry == ORC_CYLINDRICAL) { x = r0 * cos(r2); y = r0 * sin(r2); z = r1; }
+        if (c->geometry == ORC_SPHERICAL) { x = r0 * sin(r1) * cos(r2); y = r0 * sin(r1) * sin(r2); z = r0 * cos(r1); }
+    } else {
+        if (c->geometry == ORC_CARTESIAN) { x = r0; y = r1; z = r2; }
+        if (c->geometry == ORC_SPHERICAL) { x = r0 * sin(r1) * cos(r2); y = r0 * sin(r1) * sin(r2); z = r0 * cos(r1); }
+        if (c->geometry == ORC_POLAR) { x = r0 * cos(r1); y = r0 * sin(r1); z = r2; }
+    }
+    out[0] = x; out[1] = y; out[2] = z;
+}
+
+/* stands for gsl_ran_poisson (mclib.c:110): Knuth's product of uniforms below a mean of 30, PTRS (W. Hormann, "The
+ * transformed rejection method for generating Poisson random variables", Insurance: Mathematics and Economics 12, 1993)
+ * above */
+long long orc_poisson(orc_rng *r, double mean)
+{
+    if (!(mean > 0)) return 0;
+    if (mean < 30.0) {
+        const double L = exp(-mean);
+        long long k = 0;
+        double p = 1.0;
+        do {
+            k += 1;
+            p *= orc_rng_uniform_pos(r);
+        } while (p > L);
+        return k - 1;
+    }
+    const double smu = sqrt(mean);
+    const double b = 0.931 + 2.53 * smu;
+    const double a = -0.059 + 0.02483 * b;
+    const double inv_alpha = 1.1239 + 1.1328 / (b - 3.4);
+    const double v_r = 0.9277 - 3.6224 / (b - 2.0);
+    for (int it = 0; it < (1 << 22); ++it) {
+        const double U = orc_rng_uniform(r) - 0.5;
+        const double V = orc_rng_uniform_pos(r);
+        const double us = 0.5 - fabs(U);
+        const double kf = floor((2.0 * a / us + b) * U + mean + 0.43);
+        if (us >= 0.07 && V <= v_r) return (long long)kf;
+        if (kf < 0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(inv_alpha) - log(a / (us * us) + b) <= -mean + kf * log(mean) - lgamma(kf + 1.0)) return (long long)kf;
+    }
+    return (long long)mean;
+}
+
+void orc_free(void *p) { free(p); }
+
+static int cell_in_injection_slab(const orc_config *c, const orc_hydro *h, int i, double rmin, double rmax, double theta_min, double theta_max)
+{
+    double r_in, th_in, r_out, th_out;
+    if (c->dimensions == ORC_THREE) {                                   /* mclib.c:42-49 */
+        orc_hydroCoordinateToSpherical(c, &r_in, &th_in, fabs(h->r0[i]) - 0.5 * h->r0_size[i], fabs(h->r1[i]) - 0.5 * h->r1_size[i],
+                                       fabs(h->r2[i]) - 0.5 * h->r2_size[i]);
+        orc_hydroCoordinateToSpherical(c, &r_out, &th_out, fabs(h->r0[i]) + 0.5 * h->r0_size[i], fabs(h->r1[i]) + 0.5 * h->r1_size[i],
+                                       fabs(h->r2[i]) + 0.5 * h->r2_size[i]);
+    } else {                                                            /* mclib.c:51-52 */
+        orc_hydroCoordinateToSpherical(c, &r_in, &th_in, h->r0[i] - 0.5 * h->r0_size[i], h->r1[i] - 0.5 * h->r1_size[i], 0);
+        orc_hydroCoordinateToSpherical(c, &r_out, &th_out, h->r0[i] + 0.5 * h->r0_size[i], h->r1[i] + 0.5 * h->r1_size[i], 0);
+    }
+    return (rmin <= r_out) && (r_in <= rmax) && (th_out >= theta_min) && (th_in <= theta_max);   /* mclib.c:57 */
+}
+
+/* mclib.c:9-300 */
+int orc_photonInjection(const orc_config *c, orc_photon **out, int *n_out, double *weight_out, double r_inj, double ph_weight,
+                        int min_photons, int max_photons, char spect, double theta_min, double theta_max,
+                        const orc_hydro *h, uint64_t seed, uint32_t stream)
+{
+    const float num_dens_coeff = (spect == 'w') ? 8.44f : 20.29f;      /* :23-32: a float in the reference */
+    const double rmin = r_inj - 0.5 * ORC_C_LIGHT / h->fps, rmax = r_inj + 0.5 * ORC_C_LIGHT / h->fps;
+    const int M = h->num_elements;
+    int *ph_dens = (int *)malloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    if (!ph_dens) return -1;
+    orc_rng rng;
+    orc_rng_init(&rng, seed, stream);
+    long long ph_tot = 0;
+    double ph_weight_adjusted = ph_weight;
+    uint64_t attempt = 0;
+    while ((ph_tot > max_photons) || (ph_tot < min_photons)) {          /* :87-136 */
+        ph_tot = 0;
+        orc_rng_set_iteration(&rng, attempt);
+        for (int i = 0; i < M; i++) {
+            ph_dens[i] = 0;
+            if (cell_in_injection_slab(c, h, i, rmin, rmax, theta_min, theta_max)) {
+                const double ph_dens_calc = (4.0 / 3.0) * orc_hydroElementVolume(c, h, i) *
+                                            (((h->gamma)[i] * num_dens_coeff * (h->temp)[i] * (h->temp)[i] * (h->temp)[i]) / ph_weight_adjusted);
+                orc_rng_stream_begin(&rng, (uint32_t)i, ORC_PURPOSE_INJECT_COUNT);
+                {   /* :114; a count beyond int range (a weight far too small) is held at INT_MAX, the total is summed in 64 bits */
+                    const long long kk = orc_poisson(&rng, ph_dens_calc);
+                    ph_dens[i] = (int)(kk > INT_MAX ? INT_MAX : kk);
+                }
+                ph_tot += ph_dens[i];
+            }
+        }
+        if (ph_tot > max_photons) ph_weight_adjusted *= 10;
+        else if (ph_tot < min_photons) ph_weight_adjusted *= 0.5;
+        attempt += 1;
+        if (attempt > 200) { free(ph_dens); return -2; }
+    }
+    orc_photon *ph = (orc_photon *)calloc((size_t)(ph_tot > 0 ? ph_tot : 1), sizeof(orc_photon));
+    if (!ph) { free(ph_dens); return -1; }
+    orc_rng_set_iteration(&rng, 0);
+    long long k = 0;
+    for (int i = 0; i < M; i++) {
+        for (int j = 0; j < ph_dens[i]; j++, k++) {
+            double fr_dum = 0;
+            orc_rng_stream_begin(&rng, (uint32_t)k, ORC_PURPOSE_INJECT_PHOTON);
+            if (spect == 'w') {                                         /* :175-190 */
+                double y_dum = 1, yfr_dum = 0;
+                while (y_dum > yfr_dum) {
+                    fr_dum = orc_rng_uniform_pos(&rng) * 6.3e11 * ((h->temp)[i]);
+                    y_dum = orc_rng_uniform_pos(&rng);
+                    yfr_dum = (1.0 / (1.29e31)) * pow((fr_dum / ((h->temp)[i])), 3.0) / (exp((ORC_PL_CONST * fr_dum) / (ORC_K_B * ((h->temp)[i]))) - 1);
+                }
+            } else {                                                    /* :199-214, Bjorkman & Wood 2001 */
+                double test = 0, test_cnt = 0;
+                const double test_rand1 = orc_rng_uniform_pos(&rng), test_rand2 = orc_rng_uniform_pos(&rng), test_rand3 = orc_rng_uniform_pos(&rng),
+                             test_rand4 = orc_rng_uniform_pos(&rng), test_rand5 = orc_rng_uniform_pos(&rng);
+                while (test < M_PI * M_PI * M_PI * M_PI * test_rand1 / 90.0) {
+                    test_cnt += 1;
+                    test += 1 / (test_cnt * test_cnt * test_cnt * test_cnt);
+                }
+                fr_dum = -log(test_rand2 * test_rand3 * test_rand4 * test_rand5) / test_cnt;
+                fr_dum *= ORC_K_B * ((h->temp)[i]) / ORC_PL_CONST;
+            }
+            double position_phi = 0;
+            if (c->dimensions != ORC_THREE) position_phi = orc_rng_uniform(&rng) * 2 * M_PI;      /* :223-227 */
+            const double com_v_phi = orc_rng_uniform(&rng) * 2 * M_PI;
+            const double com_v_theta = acos((orc_rng_uniform(&rng) * 2) - 1);
+            double p_comv[4], boost[3], l_boost[4];
+            p_comv[0] = ORC_PL_CONST * fr_dum / ORC_C_LIGHT;                                      /* :232-235 */
+            p_comv[1] = (ORC_PL_CONST * fr_dum / ORC_C_LIGHT) * sin(com_v_theta) * cos(com_v_phi);
+            p_comv[2] = (ORC_PL_CONST * fr_dum / ORC_C_LIGHT) * sin(com_v_theta) * sin(com_v_phi);
+            p_comv[3] = (ORC_PL_CONST * fr_dum / ORC_C_LIGHT) * cos(com_v_theta);
+            cell_beta_cartesian(c, h, i, position_phi, boost);                                      /* :239-246 */
+            boost[0] *= -1; boost[1] *= -1; boost[2] *= -1;
+            orc_lorentzBoost(boost, p_comv, l_boost, 'p');                                          /* :252 */
+            orc_photon *q = &ph[k];
+            q->p0 = l_boost[0]; q->p1 = l_boost[1]; q->p2 = l_boost[2]; q->p3 = l_boost[3];
+            q->comv_p0 = p_comv[0]; q->comv_p1 = p_comv[1]; q->comv_p2 = p_comv[2]; q->comv_p3 = p_comv[3];
+            const double position_rand = orc_rng_uniform_pos(&rng) * ((h->r0_size)[i]) - 0.5 * ((h->r0_size)[i]);   /* :265-266 */
+            const double position2_rand = orc_rng_uniform_pos(&rng) * ((h->r1_size)[i]) - 0.5 * ((h->r1_size)[i]);
+            double xyz[3];
+            if (c->dimensions == ORC_THREE) {
+                const double position3_rand = orc_rng_uniform_pos(&rng) * ((h->r2_size)[i]) - 0.5 * ((h->r2_size)[i]);
+                orc_hydroCoordinateToMcratCoordinate(c, xyz, (h->r0)[i] + position_rand, (h->r1)[i] + position2_rand, (h->r2)[i] + position3_rand);
+            } else {
+                orc_hydroCoordinateToMcratCoordinate(c, xyz, (h->r0)[i] + position_rand, (h->r1)[i] + position2_rand, position_phi);
+            }
+            q->r0 = xyz[0]; q->r1 = xyz[1]; q->r2 = xyz[2];
+            q->s0 = 1; q->s1 = 0; q->s2 = 0; q->s3 = 0;                                             /* :281-291 */
+            q->num_scatt = 0;
+            q->weight = ph_weight_adjusted;
+            q->nearest_block_index = 0;
+            q->type = ORC_INJECTED_PHOTON;
+            q->recalc_properties = 1;
+        }
+    }
+    free(ph_dens);
+    *out = ph;
+    *n_out = (int)ph_tot;
+    *weight_out = ph_weight_adjusted;
+    return 0;
+}

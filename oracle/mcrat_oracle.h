@@ -124,6 +124,18 @@ typedef struct orc_stats {
     long long table_misses;          /* TABLE: lookups outside the tabulated range (clamped; see orc_getThermalCrossSection) */
 } orc_stats;
 
+/* ---- photonInjection ------------------------------------ */
+/* mclib.c:9-300.  Allocates *out (malloc) with *n_out photons; *weight_out is ph_weight_adjusted.  The Poisson sampler
+ * is the oracle's own (gsl_ran_poisson's algorithm lives in GSL; the count is a random input of the path): Knuth's
+ * product method below a mean of 30, Hormann's PTRS transformed rejection (1993) above. */
+long long orc_poisson(orc_rng *r, double mean);
+int    orc_photonInjection(const orc_config *c, orc_photon **out, int *n_out, double *weight_out, double r_inj, double ph_weight,
+                           int min_photons, int max_photons, char spect, double theta_min, double theta_max,
+                           const orc_hydro *h, uint64_t seed, uint32_t stream);
+void   orc_free(void *p);
+void   orc_hydroCoordinateToSpherical(const orc_config *c, double *r, double *theta, double r0, double r1, double r2);   /* geometry.c:66 */
+void   orc_hydroCoordinateToMcratCoordinate(const orc_config *c, double out[3], double r0, double r1, double r2);         /* geometry.c:108 */
+
 /* ---- L1 maths -------------------------------------------------------- */
 void   orc_lorentzBoost(const double boost[3], const double p[4], double result[4], char object); /* mclib.c:302 */
 void   orc_zeroNorm(double p[4]);                                                                /* mclib.c:409 */

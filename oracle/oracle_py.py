@@ -119,6 +119,10 @@ def lib():
             "orc_singleThermalElectron": (None, [_dp, d, _dp, rp]),
             "orc_singleScatter": (i, [cfgp, _dp, _dp, _dp, rp]),
             "orc_calculateOpticalDepth": (None, [cfgp, p, hp]),
+            "orc_poisson": (C.c_longlong, [rp, d]),
+            "orc_rng_stream_begin": (None, [rp, C.c_uint32, C.c_uint32]),
+            "orc_photonInjection": (i, [cfgp, C.POINTER(C.c_void_p), C.POINTER(i), _dp, d, d, i, i, C.c_char, d, d, hp, C.c_uint64, C.c_uint32]),
+            "orc_free": (None, [C.c_void_p]),
             "orc_getThermalCrossSection": (d, [cfgp, d, d, C.POINTER(i)]),
             "orc_table_misses": (C.c_longlong, []),
             "orc_reset_table_misses": (None, []),
@@ -200,6 +204,22 @@ def make_config(dimensions, geometry, stokes, hot_table=None, grid=None):
         c.n_ph_e, c.n_t = t.shape[0] - 1, t.shape[1] - 1
         c.log_ph_e_min, c.log_ph_e_max, c.log_t_min, c.log_t_max = grid if grid is not None else (-12.0, 6.0, -4.0, 4.0)
     return c
+
+
+def photon_injection(cfg, hydro, r_inj, ph_weight, min_photons, max_photons, spect, theta_min, theta_max, seed, stream=0):
+    """orc_photonInjection (mclib.c:9-300) -> (structured array of the injected photons, adjusted weight)"""
+    import numpy as np
+    L = lib()
+    out, n, w = C.c_void_p(), C.c_int(0), C.c_double(0)
+    rc = L.orc_photonInjection(C.byref(cfg), C.byref(out), C.byref(n), C.byref(w), float(r_inj), float(ph_weight), int(min_photons),
+                               int(max_photons), spect.encode() if isinstance(spect, str) else spect, float(theta_min), float(theta_max),
+                               C.byref(hydro.c), int(seed), int(stream))
+    if rc != 0:
+        raise RuntimeError("orc_photonInjection failed: %d" % rc)
+    buf = (C.c_char * (n.value * PHOTON_DTYPE.itemsize)).from_address(out.value)
+    a = np.frombuffer(buf, dtype=PHOTON_DTYPE).copy()
+    L.orc_free(out)
+    return a, w.value
 
 
 def photon_loop(cfg, photons, hydro, seed, time_now, remaining_time, max_iterations=0,

@@ -85,6 +85,14 @@ void orc_rng_event_begin(orc_rng *r, uint32_t slot)
     r->n_draws = 0;
 }
 
+void orc_rng_stream_begin(orc_rng *r, uint32_t word2, uint32_t purpose)
+{
+    uint32_t w[4];
+    keyed_block(r, word2, purpose, w);
+    r->ev_state = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    r->n_draws = 0;
+}
+
 double orc_rng_uniform(orc_rng *r)
 {
     r->n_draws++;

@@ -39,6 +39,11 @@
 
 #define ORC_PURPOSE_FREEPATH 0u
 #define ORC_PURPOSE_EVENT    1u
+/* photonInjection (mclib.c:9-300): the Poisson photon count of hydro cell i in weight-adjustment attempt a is drawn from
+ * the SplitMix64 stream keyed {ctr = {a_lo, a_hi, i, INJECT_COUNT | stream<<8}}, the draws of injected photon number k
+ * (counted over the whole injection) from the stream keyed {ctr = {0, 0, k, INJECT_PHOTON | stream<<8}} */
+#define ORC_PURPOSE_INJECT_COUNT  2u
+#define ORC_PURPOSE_INJECT_PHOTON 3u
 
 typedef struct orc_rng {
     uint64_t seed;       /* frame seed (reference: gsl_rng_get at mcrat.c:701)   */
@@ -61,6 +66,8 @@ uint64_t orc_rng_freepath_bits(const orc_rng *r, uint32_t slot);
 
 /* open the event stream of candidate slot i in the current iteration */
 void   orc_rng_event_begin(orc_rng *r, uint32_t slot);
+/* open the stream {iteration field = r->iteration, word2, purpose}: the generalisation the injection uses */
+void   orc_rng_stream_begin(orc_rng *r, uint32_t word2, uint32_t purpose);
 double orc_rng_uniform(orc_rng *r);       /* [0,1) */
 double orc_rng_uniform_pos(orc_rng *r);   /* (0,1) */
 double orc_rng_gaussian(orc_rng *r, double sigma);

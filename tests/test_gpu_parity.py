@@ -580,3 +580,57 @@ def test_device_built_grid_equals_host_built_grid(hip, which, monkeypatch):
         e.close()
     assert np.array_equal(got[0], got[1])
     assert (got[0][~snap] == pick[~snap]).all()
+
+
+# ------------------------------------------------------------------ photonInjection on the device
+@pytest.mark.parametrize("case", ["cfg2-bb", "cfg2-wien", "cfg3-spherical", "3d-cartesian"])
+def test_photon_injection_equals_oracle(hip, oracle, case):
+    """mcrat_hip_inject_photons against orc_photonInjection on the same frame and seed: the same number of photons (the
+    Poisson counts and the weight loop of mclib.c:87-136), the same weight, the same photons in the same order"""
+    if case.startswith("cfg2"):
+        frame, _, cfg = synth.config2(n_photons=64, nzc=16)
+        args = dict(r_inj=1e12, theta_min=0.0, theta_max=np.radians(3.0))
+    elif case == "cfg3-spherical":
+        frame, _, cfg = synth.config3(n_photons=64, nr=256, nth=128)
+        args = dict(r_inj=1e12, theta_min=0.0, theta_max=np.radians(6.0))
+    else:
+        frame, _, cfg = synth.config_3d_cartesian(n_photons=64)
+        R = np.sqrt(frame["r0"] ** 2 + frame["r1"] ** 2 + frame["r2"] ** 2)
+        args = dict(r_inj=float(np.median(R)), theta_min=0.0, theta_max=np.pi)
+    spect = "w" if case == "cfg2-wien" else "b"
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 0)
+    ref, wref = oracle.photon_injection(c, H, args["r_inj"], 1e42, 20000, 60000, spect, args["theta_min"], args["theta_max"], seed=2024)
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], 0)
+    e.set_hydro(frame)
+    n, w = e.inject_photons(args["r_inj"], 1e42, 20000, 60000, spect, args["theta_min"], args["theta_max"], frame["fps"], 2024)
+    assert n == len(ref) and 20000 <= n <= 60000 and w == wref
+    out = e.get_photons_aos()
+    for k in ("type", "num_scatt", "weight", "nearest_block_index", "recalc_properties", "s0", "s1", "s2", "s3"):
+        assert np.array_equal(out[k], ref[k]), k
+    for k in ("r0", "r1", "r2", "p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3"):
+        scale = np.abs(ref[k])
+        if k in ("p1", "p2", "p3"):
+            scale = np.abs(ref["p0"])
+        if k in ("comv_p1", "comv_p2", "comv_p3"):
+            scale = np.abs(ref["comv_p0"])
+        if k in ("r0", "r1", "r2"):
+            scale = np.maximum(scale, 1e9)
+        assert (np.abs(out[k] - ref[k]) <= 1e-11 * scale).all(), k
+    # ... and the injected photons run: one forced pass locates every one of them in a cell
+    e.begin_frame(5, 0.0, 1.0 / frame["fps"])
+    st = e.run(3)
+    assert st.iterations == 3 and st.not_found == 0
+    assert (e.get_photons()["nearest_block_index"] >= 0).all()
+
+
+def test_photon_injection_errors(hip):
+    frame, _, cfg = synth.config2(n_photons=64, nzc=8)
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], 0)
+    with pytest.raises(hip.McratHipError):
+        e.inject_photons(1e12, 1e45, 100, 1000, "b", 0.0, 0.05, 5.0, 1)          # no hydro frame staged
+    e.set_hydro(frame)
+    with pytest.raises(hip.McratHipError):
+        e.inject_photons(1e12, 1e45, 100, 1000, "x", 0.0, 0.05, 5.0, 1)          # unknown spectrum
+    with pytest.raises(hip.McratHipError):
+        e.inject_photons(1e15, 1e45, 100, 1000, "b", 0.0, 0.05, 5.0, 1)          # no cell touches the slab: the count stays 0

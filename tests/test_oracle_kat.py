@@ -631,3 +631,65 @@ def test_table_optical_depth_scales_the_direct_one(oracle):
         s = L.orc_getThermalCrossSection(C.byref(ct), float(b["comv_p0"][0]), float(frame["temp"][100 + 37 * k]), None)
         assert 0 < s <= 1.0
         assert b["total_optical_depth"][0] == pytest.approx(a["total_optical_depth"][0] * s, rel=1e-14)
+
+
+# ------------------------------------------------------------------ photonInjection
+@pytest.mark.parametrize("mean", [0.3, 4.0, 29.0, 31.0, 250.0, 2.0e4])
+def test_poisson_sampler_moments(oracle, mean):
+    """the stand-in for gsl_ran_poisson (mclib.c:114): mean and variance of the counts, both branches (Knuth < 30 <= PTRS)"""
+    L = oracle.lib()
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), 12345, 0)
+    n = 40000
+    x = np.empty(n)
+    for k in range(n):
+        L.orc_rng_stream_begin(C.byref(rng), k, 2)
+        x[k] = L.orc_poisson(C.byref(rng), mean)
+    assert (x >= 0).all() and (x == np.floor(x)).all()
+    assert abs(x.mean() - mean) < 5 * np.sqrt(mean / n)
+    assert abs(x.var() - mean) < 6 * mean * np.sqrt(2.0 / n) + 6 * np.sqrt(mean / n)
+    if mean < 10:                                                       # the pmf itself
+        ks = np.arange(0, 12)
+        got = np.array([(x == k).mean() for k in ks])
+        assert np.abs(got - stats.poisson.pmf(ks, mean)).max() < 0.012
+
+
+@pytest.mark.parametrize("spect", ["b", "w"])
+def test_photon_injection_rules(oracle, spect):
+    """photonInjection (mclib.c:9-300): count between min and max through the weight loop, photons inside cells that
+    touch the slab, lab 4-momenta null and boosted from an isotropic comoving field, <h nu> = 3.83 kT in the fluid frame"""
+    frame, _, cfg = synth.config2(n_photons=64, nzc=8)
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 0)
+    r_inj, th0, th1 = 1e12, 0.0, np.radians(3.0)
+    # 1e40 is far too small a weight (1e6 x too many photons): the x10 branch of mclib.c:123-127 has to act several times
+    ph, w = oracle.photon_injection(c, H, r_inj, 1e40, 4000, 20000, spect, th0, th1, seed=7)
+    n = len(ph)
+    assert 4000 <= n <= 20000 and w > 1e40
+    assert any(w == pytest.approx(1e40 * 10.0 ** a * 0.5 ** b, rel=1e-12) for a in range(3, 14) for b in range(0, 4))   # x10 and x0.5 steps only
+    assert (ph["weight"] == w).all() and (ph["type"] == b"i").all() and (ph["recalc_properties"] == 1).all()
+    assert (ph["s0"] == 1).all() and (ph["s1"] == 0).all() and (ph["num_scatt"] == 0).all() and (ph["nearest_block_index"] == 0).all()
+    # too large a weight: the x0.5 branch
+    ph2, w2 = oracle.photon_injection(c, H, r_inj, w * 64, 4000, 20000, spect, th0, th1, seed=7)
+    assert 4000 <= len(ph2) <= 20000 and w2 < w * 64
+    # where they are: inside the slab's cells
+    L = oracle.lib()
+    rr = np.hypot(ph["r0"], ph["r1"])
+    cell = np.array([L.orc_findContainingBlock(C.byref(c), float(a), float(b), 0.0, C.byref(H.c)) for a, b in zip(rr[:500], ph["r2"][:500])])
+    assert (cell >= 0).all()
+    R = np.sqrt(rr ** 2 + ph["r2"] ** 2)
+    half = 0.5 * synth.C_LIGHT / frame["fps"]
+    big = frame["r0_size"].max() + frame["r1_size"].max()
+    assert (R > r_inj - half - big).all() and (R < r_inj + half + big).all()
+    assert (np.arctan2(rr, ph["r2"]) < th1 + big / r_inj).all()
+    # momenta
+    assert np.allclose(np.sqrt(ph["p1"] ** 2 + ph["p2"] ** 2 + ph["p3"] ** 2), ph["p0"], rtol=1e-12)
+    mu = ph["comv_p3"] / ph["comv_p0"]
+    assert abs(mu.mean()) < 5 / np.sqrt(3 * n) and abs((mu ** 2).mean() - 1 / 3) < 0.02
+    T = frame["temp"][cell]
+    x = ph["comv_p0"][:500] * synth.C_LIGHT / (synth.K_B * T)
+    # both samplers draw from x^3 / (e^x - 1), x = h nu / kT (Bjorkman & Wood's sum of four exponentials over m with
+    # P(m) ~ m^-4, mclib.c:199-214; the rejection curve of mclib.c:188): <x> = 360 zeta(5) / pi^4 = 3.832
+    assert x.mean() == pytest.approx(3.832, rel=0.1)
+    # the outflow beams the photons outward: lab energies exceed comoving ones on average
+    assert (ph["p0"] / ph["comv_p0"]).mean() > 5
