@@ -13,9 +13,19 @@ from collections import defaultdict
 src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
 
 
+def newest(files):
+    """gpurun merges successive runs into the same local directory (file names carry the pid): keep the latest per directory"""
+    by_dir = {}
+    for f in files:
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
 def counters(sub):
     acc = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"].split("(")[0].replace("void mcrat::", "")
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -23,7 +33,7 @@ def counters(sub):
 
 
 def stats_file(sub):
-    f = glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True)
+    f = newest(glob.glob(os.path.join(src, sub, "**", "*kernel_stats.csv"), recursive=True))
     return f[0] if f else None
 
 
