@@ -830,54 +830,28 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             const int pos = atomicAdd(&s_sln, 1);
             if (pos < SHORTLIST_CAP) { sh.raw[pos].t = t; sh.raw[pos].idx = i; sh.raw[pos].pad = 0; }
         };
-        // ---- phase 1: the step of every slot of this list (cf. step_kernel); a thread owns slot pairs so that
-        // one Philox block serves two slots, as the draw order prescribes (rng.hpp).  one_slot: the forced pass.
-        auto one_slot = [&](int il, uint64_t bits) {
-            const int i = base + il;
-            const int h = i - ph.hot_bias;
-            double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
-            const double ntau = ph.ntau[h];
-            const int cell = ph.idx[h];
-            const unsigned fl = ph.flags[h];
-            if (nseg > 0 && (fl & FLAG_MOVES) && i != skip) {
-                const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
-                for (int s = 0; s < nseg; ++s) {
-                    const double t = st.seg[s];
-                    r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
-                }
-                ph.r0[h] = r0; ph.r1[h] = r1; ph.r2[h] = r2;
+        // ---- phase 1 + phase 2, in chunks of RANK_QCAP slots so that the slow-path queue always holds a chunk's worth
+        // (a list of up to 1024 photons is one chunk).  Phase 1: the step of every slot (cf. step_kernel); a thread owns
+        // slot pairs so that one Philox block serves two slots, as the draw order prescribes (rng.hpp).
+        for (int c0 = 0; c0 < n; c0 += RANK_QCAP) {
+            const int c1 = min(n, c0 + RANK_QCAP);
+            if (c0 > 0) {
+                __syncthreads();                             // the previous chunk's queue has been worked off
+                if (tid == 0) s_qn = 0;
+                __syncthreads();
             }
-            int q, bucket;
-            double t;
-            t = fast_one<DIMS, GEOM, true>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, q, bucket);
-            if (q) {
-                const int e = atomicAdd(&s_qn, 1);
-                if (e < RANK_QCAP) { s_q[e] = il | (q == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = bucket; return; }
-                t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, false, iter, rk, il, relocated, not_found);
-            } else {
-                ph.tts[i] = t;
-            }
-            if (fl & FLAG_VALID) { best.offer(t, i); if (t < t_cut) shortlist_lds(t, i); }
-        };
-        if (force) {
-            for (int pair = tid; 2 * pair < n; pair += EVENT_BLOCK) {
-                const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
-                one_slot(2 * pair, (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
-                if (2 * pair + 1 < n) one_slot(2 * pair + 1, (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32));
-            }
-        } else {
             // Two slot pairs per thread per trip, every stage written over all four slots before the next stage:
-            // with two lists per CU a SIMD holds two waves, so what this loop costs is the LATENCY of one slot's
-            // dependent chain (LDS loads -> sqrt -> cell-record gather -> Philox -> log), not issue slots; four
-            // independent chains in flight hide most of it.  Same arithmetic per slot as fast_one.
+            // with two lists per CU a SIMD holds two waves, and four independent chains (LDS loads -> sqrt -> cell-record
+            // gather -> Philox -> log) in flight hide part of each other's latency.  Same arithmetic per slot as fast_one;
+            // on the forced pass of a new frame (mcrat.c:756) every located slot goes to the queue (mclib.c:528).
             constexpr int NS = 4;
             const int hoff = base - ph.hot_bias;
-            for (int pair = tid; 2 * pair < n; pair += 2 * EVENT_BLOCK) {
+            for (int pair = (c0 >> 1) + tid; 2 * pair < c1; pair += 2 * EVENT_BLOCK) {
                 int il[NS];
                 bool live[NS];
                 il[0] = 2 * pair; il[1] = 2 * pair + 1; il[2] = 2 * (pair + EVENT_BLOCK); il[3] = il[2] + 1;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) { live[k] = il[k] < n; if (!live[k]) il[k] = 0; }
+                for (int k = 0; k < NS; ++k) { live[k] = il[k] < c1; if (!live[k]) il[k] = c0; }
                 double r0[NS], r1[NS], r2[NS], ntau[NS];
                 int cell[NS];
                 unsigned fl[NS];
@@ -951,7 +925,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                     if (!(fl[k] & FLAG_VALID)) { ph.tts[i] = INFINITY; continue; }
                     if (dom[k] && cell[k] != -1) {
                         int q = 0;
-                        if (!inb[k]) q = 1;                                       // mclib.c:507,528
+                        if (force || !inb[k]) q = 1;                              // mclib.c:507,528
                         else if (fl[k] & FLAG_RECALC) {                           // mclib.c:668
                             if (fl[k] & FLAG_TAU_FRESH) {
                                 ph.flags[h] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
@@ -960,9 +934,10 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                         }
                         if (q) {
                             const int bucket = (q == 1) ? phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]) : -1;
-                            const int e = atomicAdd(&s_qn, 1);
-                            if (e < RANK_QCAP) { s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = bucket; continue; }
-                            t = slow_one<DIMS, GEOM>(ph, hy, i, q == 1, bucket, true, iter, rk, il[k], relocated, not_found);
+                            const int e = atomicAdd(&s_qn, 1);                    // < RANK_QCAP: a chunk has no more slots than that
+                            s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0);
+                            s_qb[e] = bucket;
+                            continue;
                         } else {
                             t = tf[k];
                             ph.tts[i] = t;
@@ -976,14 +951,11 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                     if (t < t_cut) shortlist_lds(t, i);
                 }
             }
-        }
-        if (!force) RANK_TICK(6);
-        __syncthreads();
-        if (!force) RANK_TICK(7);
-        // ---- phase 2: the queued slots, dense
-        {
-            int qn = s_qn;
-            if (qn > RANK_QCAP) qn = RANK_QCAP;
+            if (!force) RANK_TICK(6);
+            __syncthreads();
+            if (!force) RANK_TICK(7);
+            // ---- phase 2: the queued slots, dense
+            const int qn = s_qn;
             for (int e = tid; e < qn; e += EVENT_BLOCK) {
                 const int il = s_q[e] & ~Q_RECALC_ONLY;
                 const int i = base + il;
