@@ -148,7 +148,7 @@ def load_library():
             import torch  # noqa: F401
         except ImportError:
             pass
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(os.environ.get("MCRAT_HIP_LIB", LIB_PATH))     # MCRAT_HIP_LIB: another build of the same ABI (A/B timing)
         for name, (res, args) in SYMBOLS.items():
             f = getattr(lib, name)
             f.restype, f.argtypes = res, args
