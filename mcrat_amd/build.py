@@ -13,17 +13,19 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcrat_hip.so")
-SOURCES = ["kernels.hip", "kernels_table.hip", "grid_build.hip", "staging.hip", "inject.hip", "engine.hip"]
+KERNEL_TUS = ["kernels%s_d%d.hip" % (m, d) for m in ("", "_table") for d in (0, 1, 2)]   # kernels.hip per TAU_CALCULATION x DIMENSIONS
+SOURCES = KERNEL_TUS + ["launchers.hip", "grid_build.hip", "staging.hip", "inject.hip", "engine.hip"]
 HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
 OBJDIR = os.path.join(HERE, "_obj")
 _KERNEL_DEPS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"]
-DEPS = {"kernels.hip": _KERNEL_DEPS, "kernels_table.hip": _KERNEL_DEPS + ["kernels_table.hip"],
+DEPS = {"launchers.hip": ["launchers.hip", "device_types.hpp", "launch.hpp"],
         "grid_build.hip": ["grid_build.hip", "device_types.hpp", "launch.hpp"],
         "staging.hip": ["staging.hip", "device_types.hpp", "launch.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")],
         "inject.hip": ["inject.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"],
         "engine.hip": ["engine.hip", "device_types.hpp", "launch.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]}
-
+for _tu in KERNEL_TUS:
+    DEPS[_tu] = _KERNEL_DEPS + [_tu]
 
 def hipcc():
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -39,17 +41,21 @@ def stale():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, resource_log=None):
-    if not force and not stale():
-        return LIB
+def build(force=False, resource_log=None, extra_flags=(), lib=None, objdir=None):
+    """extra_flags / lib / objdir: another build of the same sources beside the product one (tools/: -DMCRAT_DIAG=1)"""
+    variant = lib is not None
+    lib = lib or LIB
+    objdir = objdir or OBJDIR
+    if not variant and not force and not stale():
+        return lib
     # one hipcc per translation unit, side by side (kernels.hip and kernels_table.hip take minutes each), then the link
-    os.makedirs(OBJDIR, exist_ok=True)
-    cflags = [f for f in FLAGS if f != "-shared"] + ["-c"]
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"] + list(extra_flags) + ["-c"]
     if resource_log:
         cflags.append("-Rpass-analysis=kernel-resource-usage")
     procs = []
     for src in SOURCES:
-        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         deps = [os.path.join(CSRC, d) for d in DEPS[src]]
         fresh = (not force and not resource_log and os.path.exists(obj) and
                  all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps))
@@ -69,12 +75,12 @@ def build(force=False, resource_log=None):
             f.write("".join(log))
     if failed:
         raise RuntimeError("hipcc failed building libmcrat_hip.so")
-    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, obj, _ in procs] + ["-o", LIB],
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, obj, _ in procs] + ["-o", lib],
                        capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr)
         raise RuntimeError("hipcc failed linking libmcrat_hip.so")
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

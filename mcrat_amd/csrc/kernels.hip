@@ -23,17 +23,20 @@
 #include "physics.hpp"
 #include "rng.hpp"
 
-// This file is compiled twice: as it stands (TAU_CALCULATION == DIRECT, optical_depth.c:125-127) and through
-// kernels_table.hip with MCRAT_TAU_TABLE_TU = 1 (TAU_CALCULATION == TABLE, optical_depth.c:132-149), each into its own
-// namespace.  The reference makes the same choice at compile time (mcrat_input.h); a run-time branch costs the DIRECT
-// kernels registers they do not have (step_kernel sits exactly at its 168-VGPR budget).
-#ifndef MCRAT_TAU_TABLE_TU
-#define MCRAT_TAU_TABLE_TU 0
+// This file is a template for six translation units (kernels_d{0,1,2}.hip, kernels_table_d{0,1,2}.hip): one per
+// TAU_CALCULATION (DIRECT, optical_depth.c:125-127 / TABLE, :132-149) and DIMENSIONS (TWO, TWO_POINT_FIVE, THREE), each
+// compiled into its own namespace, side by side.  The reference makes the same choices at compile time
+// (mcrat_input.h); a run-time TAU branch costs the DIRECT kernels registers they do not have (step_kernel sits exactly
+// at its 168-VGPR budget), and one TU for all of it takes minutes to compile.  launchers.hip picks the namespace.
+#if !defined(MCRAT_TAU_TABLE_TU) || !defined(MCRAT_TU_DIMS)
+#error "compile kernels.hip through kernels_d*.hip / kernels_table_d*.hip"
 #endif
+#define MCRAT_NS_CAT2(a, b) a##b
+#define MCRAT_NS_CAT(a, b) MCRAT_NS_CAT2(a, b)
 #if MCRAT_TAU_TABLE_TU
-#define MCRAT_TU_NS tau_table
+#define MCRAT_TU_NS MCRAT_NS_CAT(tau_table_d, MCRAT_TU_DIMS)
 #else
-#define MCRAT_TU_NS tau_direct
+#define MCRAT_TU_NS MCRAT_NS_CAT(tau_direct_d, MCRAT_TU_DIMS)
 #endif
 
 namespace mcrat {
@@ -1443,15 +1446,20 @@ template <class F>
 static hipError_t dispatch(const KernelConfig &kc, F &&f)
 {
     const int d = kc.dimensions, g = kc.geometry;
-    if (d == DIM_TWO && g == GEOM_CARTESIAN) f(ic<DIM_TWO>{}, ic<GEOM_CARTESIAN>{});
-    else if (d == DIM_TWO && g == GEOM_CYLINDRICAL) f(ic<DIM_TWO>{}, ic<GEOM_CYLINDRICAL>{});
-    else if (d == DIM_TWO && g == GEOM_SPHERICAL) f(ic<DIM_TWO>{}, ic<GEOM_SPHERICAL>{});
-    else if (d == DIM_TWO_POINT_FIVE && g == GEOM_CARTESIAN) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CARTESIAN>{});
-    else if (d == DIM_TWO_POINT_FIVE && g == GEOM_CYLINDRICAL) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CYLINDRICAL>{});
-    else if (d == DIM_TWO_POINT_FIVE && g == GEOM_SPHERICAL) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_SPHERICAL>{});
-    else if (d == DIM_THREE && g == GEOM_CARTESIAN) f(ic<DIM_THREE>{}, ic<GEOM_CARTESIAN>{});
-    else if (d == DIM_THREE && g == GEOM_SPHERICAL) f(ic<DIM_THREE>{}, ic<GEOM_SPHERICAL>{});
-    else if (d == DIM_THREE && g == GEOM_POLAR) f(ic<DIM_THREE>{}, ic<GEOM_POLAR>{});
+    if (d != MCRAT_TU_DIMS) return hipErrorInvalidValue;          // launchers.hip routes by DIMENSIONS
+#if MCRAT_TU_DIMS == 0
+    if (g == GEOM_CARTESIAN) f(ic<DIM_TWO>{}, ic<GEOM_CARTESIAN>{});
+    else if (g == GEOM_CYLINDRICAL) f(ic<DIM_TWO>{}, ic<GEOM_CYLINDRICAL>{});
+    else if (g == GEOM_SPHERICAL) f(ic<DIM_TWO>{}, ic<GEOM_SPHERICAL>{});
+#elif MCRAT_TU_DIMS == 1
+    if (g == GEOM_CARTESIAN) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CARTESIAN>{});
+    else if (g == GEOM_CYLINDRICAL) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CYLINDRICAL>{});
+    else if (g == GEOM_SPHERICAL) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_SPHERICAL>{});
+#else
+    if (g == GEOM_CARTESIAN) f(ic<DIM_THREE>{}, ic<GEOM_CARTESIAN>{});
+    else if (g == GEOM_SPHERICAL) f(ic<DIM_THREE>{}, ic<GEOM_SPHERICAL>{});
+    else if (g == GEOM_POLAR) f(ic<DIM_THREE>{}, ic<GEOM_POLAR>{});
+#endif
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -1538,7 +1546,7 @@ hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const 
     });
 }
 
-#if defined(MCRAT_DIAG) && !MCRAT_TAU_TABLE_TU
+#if defined(MCRAT_DIAG) && !MCRAT_TAU_TABLE_TU && MCRAT_TU_DIMS == 0
 extern "C" int mcrat_hip_diag_set(int bits)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &bits, sizeof(int)) == hipSuccess ? 0 : -1;
@@ -1576,67 +1584,5 @@ hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, cons
 }
 
 }  // namespace MCRAT_TU_NS
-
-#if !MCRAT_TAU_TABLE_TU
-// ------------------------------------------------------------------ the launchers of launch.hpp
-namespace tau_table {
-hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy,
-                       LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
-hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
-                        const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
-hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream);
-hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
-hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
-}  // namespace tau_table
-
-int step_grid_blocks(int n_pad) { return tau_direct::step_grid_blocks(n_pad); }
-
-hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy,
-                       LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream)
-{
-    return kc.table ? tau_table::launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream)
-                    : tau_direct::launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream);
-}
-
-hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
-                        const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream)
-{
-    return kc.table ? tau_table::launch_event(kc, ph, hy, st, key, block_min, n_blocks, sl, stream)
-                    : tau_direct::launch_event(kc, ph, hy, st, key, block_min, n_blocks, sl, stream);
-}
-
-hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream)
-{
-    return kc.table ? tau_table::launch_rank_loop(kc, ph, hy, states, key, n_ranks, rank_photons, max_passes, stream)
-                    : tau_direct::launch_rank_loop(kc, ph, hy, states, key, n_ranks, rank_photons, max_passes, stream);
-}
-
-hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream)
-{
-    return kc.table ? tau_table::launch_sc_propose(kc, force_relocate, ph, hy, st, sc, key, block_min, blocks, sl, out, stream)
-                    : tau_direct::launch_sc_propose(kc, force_relocate, ph, hy, st, sc, key, block_min, blocks, sl, out, stream);
-}
-
-hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream)
-{
-    return kc.table ? tau_table::launch_sc_resolve(kc, ph, hy, st, sc, key, all, world, stream)
-                    : tau_direct::launch_sc_resolve(kc, ph, hy, st, sc, key, all, world, stream);
-}
-
-hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream) { return tau_direct::launch_flush(ph, st, blocks, stream); }
-hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream) { return tau_direct::launch_k2e(temp, k2e, M, stream); }
-hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream) { return tau_direct::launch_reduce(ph, out, blocks, stream); }
-hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, const double *a0, const double *a1, const double *a2, int *out,
-                         hipStream_t stream)
-{
-    return tau_direct::launch_lookup(kc, hy, n, a0, a1, a2, out, stream);
-}
-#endif
 
 }  // namespace mcrat

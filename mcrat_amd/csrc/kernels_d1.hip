@@ -1,0 +1,4 @@
+// kernels_d1.hip -- kernels.hip for TAU_CALCULATION == DIRECT, DIMENSIONS == TWO_POINT_FIVE (see the head of kernels.hip)
+#define MCRAT_TAU_TABLE_TU 0
+#define MCRAT_TU_DIMS 1
+#include "kernels.hip"

@@ -10,8 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcrat_amd import build, engine, synth  # noqa: E402
 
 diag_lib = os.path.join(os.path.dirname(build.LIB), "libmcrat_hip_diag.so")
-cmd = [build.hipcc()] + build.FLAGS + ["-DMCRAT_DIAG=1"] + [os.path.join(build.CSRC, s) for s in build.SOURCES] + ["-o", diag_lib]
-subprocess.run(cmd, check=True)
+build.build(force=True, extra_flags=["-DMCRAT_DIAG=1"], lib=diag_lib, objdir=os.path.join(os.path.dirname(build.LIB), "_obj_diag"))
 engine.LIB_PATH = diag_lib
 lib = engine.load_library()
 lib.mcrat_hip_diag_set.restype, lib.mcrat_hip_diag_set.argtypes = C.c_int, [C.c_int]
