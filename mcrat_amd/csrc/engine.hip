@@ -1007,25 +1007,19 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
         c->last_error = "TAU_CALCULATION == TABLE needs mcrat_hip_set_hot_cross_section first";
         return MCRAT_HIP_ESTATE;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // everything below is ordered on the context's stream behind whatever the previous frame left there: no wait
     HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
-    LoopState &h = *c->h_state;
+    LoopState h;
     memset(&h, 0, sizeof h);
     h.remaining_time = remaining_time;
     h.time_now = time_now;
     h.done = !(remaining_time > 0);
     h.skip_idx = -1;
     h.last_scattered_index = -1;
-    HIPCHK(c, hipMemcpyAsync(c->d_state, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
-    if (c->n_ranks > 0) {
-        h.force_relocate = 1;                       // mcrat.c:756, per list
-        for (int r = 0; r < c->n_ranks; ++r) c->h_rstates[r] = h;
-        h.force_relocate = 0;
-        HIPCHK(c, hipMemcpyAsync(c->d_rstates, c->h_rstates, sizeof(LoopState) * c->n_ranks, hipMemcpyHostToDevice, c->stream));
-    }
+    HIPCHK(c, launch_init_states(c->d_state, c->d_rstates, c->n_ranks, h, c->stream));     // per list: force_relocate = 1, mcrat.c:756
+    *c->h_state = h;                               // the host's view until the next read-back (every read-back is followed by a wait)
     HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     if (c->sc_world > 0) HIPCHK(c, hipMemsetAsync(c->d_sc, 0, sizeof(ScState), c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->key.seed = seed;
     c->find_switch = 1;           // mcrat.c:756
     c->pending_applied = false;

@@ -41,6 +41,7 @@ hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStrea
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);
 hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream);
 // struct photon records <-> SoA columns on the device (staging.hip); `aos` is a device buffer of n 176-B records
+hipError_t launch_init_states(LoopState *single, LoopState *ranks, int n_ranks, const LoopState &v, hipStream_t stream);
 hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream);
 hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int n, hipStream_t stream);
 

@@ -59,7 +59,27 @@ __global__ __launch_bounds__(256) void soa_to_aos_kernel(PhotonDev ph, mcrat_hip
     aos[i] = q;
 }
 
+// the loop state of a new frame (mcrat.c:754-758): one record for the single list, one per virtual rank with the forced
+// re-location pending.  The record travels as a kernel argument, so opening a frame needs no host buffer and no wait.
+__global__ __launch_bounds__(256) void init_states_kernel(LoopState *__restrict__ single, LoopState *__restrict__ ranks, int n_ranks, LoopState v)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) *single = v;
+    if (r < n_ranks) {
+        LoopState w = v;
+        w.force_relocate = 1;
+        ranks[r] = w;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_init_states(LoopState *single, LoopState *ranks, int n_ranks, const LoopState &v, hipStream_t stream)
+{
+    const int n = n_ranks > 0 ? n_ranks : 1;
+    init_states_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(single, ranks, n_ranks, v);
+    return hipGetLastError();
+}
 
 hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream)
 {
