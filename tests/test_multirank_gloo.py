@@ -68,3 +68,20 @@ def test_two_ranks_independent_shards(tmp_path):
         assert got[r]["tot"][0] == got[0]["scatt"] + got[1]["scatt"]
         assert got[r]["tot"][1] == got[0]["steps"] + got[1]["steps"]
         assert got[r]["tot"][3] == 2.0                                  # slowest rank
+
+
+def test_even_shard_bounds_for_the_shared_clock_mode():
+    """mcrat_amd.sharding.shard_bounds_even: contiguous, covering, every boundary on an even slot (the shared-clock mode
+    pairs slots for its free-path random numbers), sizes within one pair of each other"""
+    from mcrat_amd import sharding
+    for n in (1, 2, 7, 100, 2001, 1_000_000, 10_000_001):
+        for world in (1, 2, 3, 8):
+            prev = 0
+            sizes = []
+            for r in range(world):
+                lo, hi = sharding.shard_bounds_even(n, world, r)
+                assert lo == prev and (lo % 2 == 0 or lo == hi) and lo <= hi <= n      # (an empty trailing shard may start at an odd n)
+                sizes.append(hi - lo)
+                prev = hi
+            assert prev == n
+            assert max(sizes) - min(sizes) <= 3
