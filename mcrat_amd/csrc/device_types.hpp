@@ -27,8 +27,11 @@ constexpr int TOPK = 4;          // candidates fetched per rescan of time_to_sca
 constexpr int MAX_SEG = 8;       // advance segments remembered per iteration (one per tried candidate)
 constexpr int STEP_BLOCK = 256;  // threads per workgroup of the step kernel; each thread owns slot pairs
 constexpr int STEP_QCAP = 1024;  // LDS queue of slots awaiting the slow path, per workgroup
-constexpr int SHORTLIST_CAP = 256;   // early candidates (free time below LoopState::t_cut) collected per iteration
-constexpr int EVENT_BLOCK = 256;    // one workgroup; only lane 0 runs the scattering physics, so leave it the whole register file
+#ifndef MCRAT_EVENT_BLOCK
+#define MCRAT_EVENT_BLOCK 256
+#endif
+constexpr int SHORTLIST_CAP = MCRAT_EVENT_BLOCK;   // early candidates (free time below LoopState::t_cut) collected per iteration
+constexpr int EVENT_BLOCK = MCRAT_EVENT_BLOCK;    // one workgroup; only lane 0 runs the scattering physics, so leave it the whole register file
 
 // SoA photon columns in HBM.  Capacity is padded to a multiple of 2*STEP_BLOCK; every column is 256-B aligned.
 struct PhotonDev {
@@ -51,10 +54,14 @@ struct PhotonDev {
     char *type;
     int n;                       // list_capacity
     int n_pad;
-    // The "hot" columns (r0-2, u0-2, ntau, idx, flags) are indexed as col[i - hot_bias].  0 in HBM; in
+    // The "hot" columns r0-2 and ntau are indexed as col[i - hot_bias].  0 in HBM; in
     // rank_loop_kernel, when a list's hot columns live in LDS, the list's first slot (so that the LDS copies are
     // indexed from 0 without ever forming an out-of-bounds pointer).
     int hot_bias;
+    // the same for the other per-pass columns: rank_loop_kernel keeps r and -1/tau in LDS (hot_bias = the list's first slot)
+    // and leaves idx, flags (if_bias) and u0-2 (u_bias) in HBM/L2, so that four lists fit a CU
+    int if_bias;
+    int u_bias;
 };
 
 struct alignas(32) CellGeom {    // one 32-B sector per in-cell test (geometry.c:394-417)

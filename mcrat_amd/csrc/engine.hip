@@ -75,6 +75,9 @@ struct mcrat_hip_ctx {
 
     // virtual ranks (cfg.virtual_rank_photons > 0): one LoopState per list
     int n_ranks = 0;
+    int rank_block = 256;             // threads per list of the next launches (choose_rank_block)
+    bool rank_block_fixed = false;
+    double rank_passes_per_list = 0;  // of the last completed frame
     LoopState *d_rstates = nullptr;
     LoopState *h_rstates = nullptr;   // pinned
     int rstates_cap = 0;
@@ -1023,6 +1026,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     c->key.seed = seed;
     c->find_switch = 1;           // mcrat.c:756
     c->pending_applied = false;
+    c->rank_block_fixed = false;
     c->frame_open = true;
     c->prof_step_ms = c->prof_event_ms = 0;
     c->prof_launches = 0;
@@ -1064,8 +1068,23 @@ static int ensure_graph(mcrat_hip_ctx *c, int batch)
 static int ensure_events(mcrat_hip_ctx *c, size_t n);
 
 // virtual-rank mode: every launch gives each unfinished list up to `per_launch` passes of its own loop
+// Threads per list (launch.hpp).  Lists per CU is what the virtual-rank kernel's throughput hangs on (kernels.hip), so many
+// lists get 128-thread workgroups, four to a CU -- unless there are too few lists to fill the device that way, or the lists
+// are too long to keep in LDS, or the frames are optically thin: a thin frame is a dozen passes in which half the photons
+// change cell, i.e. slow-path throughput per list, and there 256 threads per list do better.  The engine cannot know the
+// optical depth before it has run a frame; it looks at the previous one (passes per list).
+static void choose_rank_block(mcrat_hip_ctx *c)
+{
+    if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) { c->rank_block = (atoi(e) == 128) ? 128 : 256; return; }
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const bool many = c->n_ranks > 2 * cus && c->cfg.virtual_rank_photons <= 1024;
+    c->rank_block = (many && c->rank_passes_per_list >= 48.0) ? 128 : 256;
+}
+
 static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame_stats *stats)
 {
+    if (!c->rank_block_fixed) { choose_rank_block(c); c->rank_block_fixed = true; }    // one choice per frame (begin_frame resets)
     const long long per_launch_cap = 4096;      // bounds one launch to seconds even for the densest lists
     long long it = 0;
     while (max_iterations <= 0 || it < max_iterations) {
@@ -1076,7 +1095,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
             if (rc) return rc;
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
-        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->cfg.virtual_rank_photons, batch, c->stream));
+        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->cfg.virtual_rank_photons, batch, c->rank_block, c->stream));
         if (c->cfg.profile) {
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
             HIPCHK(c, hipEventSynchronize(c->ev[1]));
@@ -1093,6 +1112,12 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
         if (all_done) break;
     }
     fill_rank_stats(c, stats);
+    {   // what the next frame's choice of workgroup size looks at
+        long long it_sum = 0;
+        bool done = true;
+        for (int r = 0; r < c->n_ranks; ++r) { it_sum += c->h_rstates[r].iterations; done = done && c->h_rstates[r].done; }
+        if (done && c->n_ranks > 0) c->rank_passes_per_list = (double)it_sum / c->n_ranks;
+    }
     if (stats) { stats->step_kernel_ms = c->prof_step_ms; stats->step_kernel_launches = c->prof_launches; stats->table_misses = read_table_misses(c); }
     return MCRAT_HIP_OK;
 }

@@ -238,7 +238,7 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
             else if (!phys::check_in_block<DIMS>(hy, cell, a0, a1, a2)) queue = 1;    // mclib.c:507,528
             else if (fl & FLAG_RECALC) {                                         // mclib.c:668
                 if (fl & FLAG_TAU_FRESH) {
-                    ph.flags[i - ph.hot_bias] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                    ph.flags[i - ph.if_bias] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));
                     ph.tau[i] = ph.tau_next[i];
                 } else {
                     queue = 2;
@@ -250,7 +250,7 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
         if (MC_DIAG(DIAG_SKIP_SAMPLE)) return 1e-3 + (double)i * 1e-12 + (double)(bits & 1) * 0.0 + ntau * 0.0;
         return sample_free_time(ntau, bits);
     }
-    if (cell != -1) ph.idx[i - ph.hot_bias] = -1;                                // mclib.c:592
+    if (cell != -1) ph.idx[i - ph.if_bias] = -1;                                 // mclib.c:592
     return 1e12 / C_LIGHT;                                                       // mclib.c:620,684
 }
 
@@ -264,7 +264,8 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
     const int h = i - ph.hot_bias;               // index into the hot columns
     const double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
     const double p0 = ph.p0[i], p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
-    const unsigned fl = ph.flags[h];
+    const int hf = i - ph.if_bias;               // index into idx and flags
+    const unsigned fl = ph.flags[hf];
     int cell;
     bool need_tau = (fl & FLAG_RECALC) != 0;
     bool new_cell = false;
@@ -276,7 +277,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
         FatCell hit;
         cell = phys::find_in_bucket<DIMS>(hy.grid, bucket, a0, a1, a2, hit);     // mclib.c:534
-        ph.idx[h] = cell;                                                        // mclib.c:536
+        ph.idx[hf] = cell;                                                       // mclib.c:536
         if (cell != -1) {
             fa = hit.a; fb = hit.b; fc = hit.fc; fgamma = hit.gamma; fdens = hit.dens_lab;
             new_cell = true;
@@ -286,7 +287,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             not_found += 1;                                                      // mclib.c:583
         }
     } else {
-        cell = ph.idx[h];
+        cell = ph.idx[hf];
         if (cell != -1) {
             const CellFluid f = hy.fluid[cell];
             fa = f.a; fb = f.b; fgamma = f.gamma; fdens = f.dens_lab;
@@ -319,7 +320,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             ntau = -1.0 / tau;
             ph.tau[i] = tau;
             ph.ntau[h] = ntau;
-            if (fl & FLAG_RECALC) ph.flags[h] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));   // mclib.c:571-576,672
+            if (fl & FLAG_RECALC) ph.flags[hf] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));  // mclib.c:571-576,672
         } else {
             ntau = ph.ntau[h];
         }
@@ -543,14 +544,15 @@ __device__ __forceinline__ void commit_scatter(const PhotonDev &ph, int i, const
     ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
     {
         const double d = 1.0 / p[0];                                   // mclib.c:1074-1080 factors of the new momentum
-        ph.u0[h] = p[1] * d * C_LIGHT; ph.u1[h] = p[2] * d * C_LIGHT; ph.u2[h] = p[3] * d * C_LIGHT;
+        const int hu = i - ph.u_bias;
+        ph.u0[hu] = p[1] * d * C_LIGHT; ph.u1[hu] = p[2] * d * C_LIGHT; ph.u2[hu] = p[3] * d * C_LIGHT;
     }
     ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
     ph.r0[h] = r[0]; ph.r1[h] = r[1]; ph.r2[h] = r[2];              // already advanced: the next step kernel skips it
     ph.num_scatt[i] += 1;                                              // mclib.c:1317
     ph.tau_next[i] = tau_new;
     ph.ntau[h] = -1.0 / tau_new;
-    ph.flags[h] = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
+    ph.flags[i - ph.if_bias] = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
 }
 
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
@@ -576,12 +578,12 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     w.old_scatt_time = scatt_time;
     const int h = i - ph.hot_bias;               // index into the hot columns
     // one round of independent loads for everything the candidate needs (this lane's latency is the kernel's)
-    const int cell = ph.idx[h];
+    const int cell = ph.idx[i - ph.if_bias];
     double p[4] = {ph.p0[i], ph.p1[i], ph.p2[i], ph.p3[i]};
     double r[3] = {ph.r0[h], ph.r1[h], ph.r2[h]};
     double pc[4] = {ph.c0[i], ph.c1[i], ph.c2[i], ph.c3[i]};
-    const unsigned cand_flags = ph.flags[h];
-    const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
+    const unsigned cand_flags = ph.flags[i - ph.if_bias];
+    const double u0 = ph.u0[i - ph.u_bias], u1 = ph.u1[i - ph.u_bias], u2 = ph.u2[i - ph.u_bias];
     double s[4] = {1, 0, 0, 0};
     if constexpr (STOKES) { s[0] = ph.s0[i]; s[1] = ph.s1[i]; s[2] = ph.s2[i]; s[3] = ph.s3[i]; }
     if (cell == -1) return EV_RUNNING;                     // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
@@ -608,30 +610,33 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
 }
 
 // LDS scratch of the event walk (one per workgroup)
-struct EventShared {
-    Cand w[EVENT_BLOCK / 64][TOPK];
+// (BLOCK threads, one per shortlist entry: the shortlist of a workgroup of BLOCK threads holds BLOCK candidates)
+template <int BLOCK>
+struct EventSharedT {
+    Cand w[BLOCK / 64][TOPK];
     Cand c[TOPK];
-    Cand raw[SHORTLIST_CAP];
-    Cand list[SHORTLIST_CAP];
-    double wt[EVENT_BLOCK / 64];
-    int wi[EVENT_BLOCK / 64];
+    Cand raw[BLOCK];
+    Cand list[BLOCK];
+    double wt[BLOCK / 64];
+    int wi[BLOCK / 64];
     double seg[MAX_SEG];
     double last_t;
     int last_i;
     int status;
 };
+using EventShared = EventSharedT<EVENT_BLOCK>;
 
 // The second half of a loop pass for one photon list occupying slots [base, base + n): sort the shortlist
 // (sh.raw[0..n_raw), complete below t_cut unless it overflowed), walk it as photonEvent does, refill from
 // time_to_scatter if it runs out, then the bookkeeping of mcrat.c:782-784 / 837-845 into *st.
-// All EVENT_BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
-template <int DIMS, int GEOM, bool STOKES>
+// All BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
+template <int DIMS, int GEOM, bool STOKES, int BLOCK>
 __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
-                                            EventShared &sh, int n_raw, Cand gmin, int base, int n,
+                                            EventSharedT<BLOCK> &sh, int n_raw, Cand gmin, int base, int n,
                                             unsigned long long iter, double dt_max, int last_idx, double t_est)
 {
     const int tid = threadIdx.x;
-    int n_list = (n_raw > SHORTLIST_CAP) ? 0 : n_raw;      // overflowed: incomplete, ignore it
+    int n_list = (n_raw > BLOCK) ? 0 : n_raw;              // overflowed: incomplete, ignore it
     if (tid < n_list) {                                    // rank sort (equal (t, idx) pairs cannot occur)
         const Cand me = sh.raw[tid];
         int rank = 0;
@@ -678,12 +683,12 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
             const int li = sh.last_i;
             TopK more;
             more.init();
-            for (int i = base + tid; i < base + n; i += EVENT_BLOCK) {
+            for (int i = base + tid; i < base + n; i += BLOCK) {
                 double t = ph.tts[i];
                 if (t != t) t = INFINITY;
                 if (cand_less(lt, li, t, i)) more.insert(t, i);
             }
-            block_topk<EVENT_BLOCK / 64>(more, sh.w, sh.c);
+            block_topk<BLOCK / 64>(more, sh.w, sh.c);
         }
         list = sh.c;
         n_list = 0;
@@ -743,7 +748,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
     for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(sh.wt[wv], sh.wi[wv]);
     Cand gmin;
     gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
-    event_block<DIMS, GEOM, STOKES>(ph, hy, st, key, sh, n_raw, gmin, 0, ph.n, iter, dt_max, last_idx, t_est);
+    event_block<DIMS, GEOM, STOKES, EVENT_BLOCK>(ph, hy, st, key, sh, n_raw, gmin, 0, ph.n, iter, dt_max, last_idx, t_est);
     if (tid == 0) sl->count = 0;
 }
 
@@ -760,21 +765,33 @@ struct RankLayout {
     int n_total;
 };
 
-constexpr int RANK_QCAP = 1024;
+// Four lists per CU.  Measured by varying the number of lists on a dense jet: a workgroup alone on its CU needs 25 us per
+// pass, two per CU 27 us each -- a pass is a chain of latencies (LDS -> sqrt -> gather -> Philox -> log; two dependent loads and a
+// boost; 3 500 dependent f64 instructions on one lane), workgroups overlap almost freely, so LISTS PER CU is what counts.  A
+// list therefore gets a workgroup of 128 threads (two waves; eight waves per CU = four lists at 256 VGPRs, no spills) and keeps
+// only r and -1/tau in LDS (32 B per slot; idx, flags and u stay in HBM/L2), which with the small static scratch below is under
+// 40 KB per list.  1000 lists of 1000 photons are then resident all at once.
+// The workgroup size is a template parameter: 256 threads per list when there are few lists (each list then gets the CU
+// it sits on) or the frame is optically thin (its cost is slow-path throughput per list), 128 otherwise; engine.hip picks.
+constexpr int rank_lds_bytes_per_slot(int block) { return block >= 256 ? 7 * (int)sizeof(double) + (int)sizeof(int) + 1 : 4 * (int)sizeof(double); }
 #ifndef RANK_WAVES_PER_SIMD
-#define RANK_WAVES_PER_SIMD 2      // 2 lists resident per CU without register spills; measured: 4 (with spills) is no faster -- the loop is VALU-issue bound
+#define RANK_WAVES_PER_SIMD 2
 #endif
 
-template <int DIMS, int GEOM, bool STOKES, bool RESIDENT>
-__global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
+template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK>
+__global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
-    extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's hot columns when it fits (lds_slots >= n)
+    constexpr int EVENT_BLOCK = RANK_BLOCK;                    // (shadows the event kernel's block size inside this kernel)
+    constexpr int RANK_QCAP = 4 * RANK_BLOCK;                  // slots per chunk = capacity of the slow-path queue
+    extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's r and -1/tau columns when it fits (lds_slots >= n)
     __shared__ LoopState st;
-    __shared__ EventShared sh;
+    __shared__ EventSharedT<RANK_BLOCK> sh;
     __shared__ int s_qn, s_sln;
-    __shared__ int s_q[RANK_QCAP];
     __shared__ int s_qb[RANK_QCAP];
+    // the slow-path queue shares memory with the event walk's sorted list: the queue is empty before the list is written
+    static_assert(sizeof(sh.list) >= sizeof(int) * RANK_QCAP, "queue fits into the sorted-list storage");
+    int *const s_q = reinterpret_cast<int *>(sh.list);
     const int tid = threadIdx.x, lane = tid & 63;
     const int rank = blockIdx.x;
     const int base = rank * lay.rank_photons;
@@ -791,28 +808,36 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
 #define RANK_TICK(k) do { } while (0)
 #endif
 
-    // LDS residency: the columns every pass touches (r, u, -1/tau, cell index, flags: 61 B per slot) are copied into
-    // LDS once per launch and written back at the end; `ph` is the same PhotonDev with those column pointers aimed
-    // at LDS and hot_bias = base, so every device function below works on it unchanged (col[i - hot_bias]).
-    // (RESIDENT is a template parameter so that the column pointers provably address LDS and the accesses below compile
-    // to ds_read / ds_write instead of flat loads)
+    // LDS residency.  128-thread workgroups: r and -1/tau, read and written every pass (32 B per slot; idx, flags and u come
+    // from HBM/L2), so that four lists fit a CU.  256-thread workgroups (two per CU by their registers anyway): all the
+    // per-pass columns (r, u, -1/tau, idx, flags: 61 B per slot).  The columns are copied in once per launch and written back
+    // at the end; `ph` is the same PhotonDev with those column pointers aimed at LDS and the biases set, so every device
+    // function below works on it unchanged (col[i - bias]).  (RESIDENT is a template parameter so that the pointers provably
+    // address LDS and the accesses compile to ds_read / ds_write instead of flat loads.)
+    constexpr bool FULL_HOT = RANK_BLOCK >= 256;
     PhotonDev ph = gph;
     if constexpr (RESIDENT) {
         double *d = reinterpret_cast<double *>(s_dyn);
-        double *l_r0 = d, *l_r1 = d + lds_slots, *l_r2 = d + 2 * lds_slots, *l_u0 = d + 3 * lds_slots,
-               *l_u1 = d + 4 * lds_slots, *l_u2 = d + 5 * lds_slots, *l_nt = d + 6 * lds_slots;
+        double *l_r0 = d, *l_r1 = d + lds_slots, *l_r2 = d + 2 * lds_slots, *l_nt = d + 3 * lds_slots;
+        double *l_u0 = d + 4 * lds_slots, *l_u1 = d + 5 * lds_slots, *l_u2 = d + 6 * lds_slots;     // FULL_HOT only
         int *l_idx = reinterpret_cast<int *>(d + 7 * lds_slots);
         unsigned char *l_fl = reinterpret_cast<unsigned char *>(l_idx + lds_slots);
         for (int il = tid; il < n; il += EVENT_BLOCK) {
             const int i = base + il;
             l_r0[il] = gph.r0[i]; l_r1[il] = gph.r1[i]; l_r2[il] = gph.r2[i];
-            l_u0[il] = gph.u0[i]; l_u1[il] = gph.u1[i]; l_u2[il] = gph.u2[i];
-            l_nt[il] = gph.ntau[i]; l_idx[il] = gph.idx[i]; l_fl[il] = gph.flags[i];
+            l_nt[il] = gph.ntau[i];
+            if constexpr (FULL_HOT) {
+                l_u0[il] = gph.u0[i]; l_u1[il] = gph.u1[i]; l_u2[il] = gph.u2[i];
+                l_idx[il] = gph.idx[i]; l_fl[il] = gph.flags[i];
+            }
         }
         ph.r0 = l_r0; ph.r1 = l_r1; ph.r2 = l_r2;
-        ph.u0 = l_u0; ph.u1 = l_u1; ph.u2 = l_u2;
-        ph.ntau = l_nt; ph.idx = l_idx; ph.flags = l_fl;
+        ph.ntau = l_nt;
         ph.hot_bias = base;
+        if constexpr (FULL_HOT) {
+            ph.u0 = l_u0; ph.u1 = l_u1; ph.u2 = l_u2; ph.u_bias = base;
+            ph.idx = l_idx; ph.flags = l_fl; ph.if_bias = base;
+        }
         __syncthreads();
     }
     RANK_TICK(0);
@@ -831,7 +856,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
         int relocated = 0, not_found = 0;
         auto shortlist_lds = [&](double t, int i) {
             const int pos = atomicAdd(&s_sln, 1);
-            if (pos < SHORTLIST_CAP) { sh.raw[pos].t = t; sh.raw[pos].idx = i; sh.raw[pos].pad = 0; }
+            if (pos < RANK_BLOCK) { sh.raw[pos].t = t; sh.raw[pos].idx = i; sh.raw[pos].pad = 0; }
         };
         // ---- phase 1 + phase 2, in chunks of RANK_QCAP slots so that the slow-path queue always holds a chunk's worth
         // (a list of up to 1024 photons is one chunk).  Phase 1: the step of every slot (cf. step_kernel); a thread owns
@@ -862,7 +887,8 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                 for (int k = 0; k < NS; ++k) {
                     const int h = il[k] + hoff;
                     r0[k] = ph.r0[h]; r1[k] = ph.r1[h]; r2[k] = ph.r2[h];
-                    ntau[k] = ph.ntau[h]; cell[k] = ph.idx[h]; fl[k] = ph.flags[h];
+                    const int hf = base + il[k] - ph.if_bias;
+                    ntau[k] = ph.ntau[h]; cell[k] = ph.idx[hf]; fl[k] = ph.flags[hf];
                 }
                 if (nseg > 0) {                                  // pending updatePhotonPosition, mclib.c:1067-1095
                     double u0[NS], u1[NS], u2[NS];
@@ -870,7 +896,8 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
                         const int h = il[k] + hoff;
-                        u0[k] = ph.u0[h]; u1[k] = ph.u1[h]; u2[k] = ph.u2[h];
+                        const int hu = base + il[k] - ph.u_bias;
+                        u0[k] = ph.u0[hu]; u1[k] = ph.u1[hu]; u2[k] = ph.u2[hu];
                         mv[k] = live[k] && (fl[k] & FLAG_MOVES) && (base + il[k] != skip);
                     }
                     for (int sg = 0; sg < nseg; ++sg) {
@@ -931,7 +958,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                         if (force || !inb[k]) q = 1;                              // mclib.c:507,528
                         else if (fl[k] & FLAG_RECALC) {                           // mclib.c:668
                             if (fl[k] & FLAG_TAU_FRESH) {
-                                ph.flags[h] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                                ph.flags[i - ph.if_bias] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
                                 ph.tau[i] = ph.tau_next[i];
                             } else q = 2;
                         }
@@ -946,7 +973,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
                             ph.tts[i] = t;
                         }
                     } else {
-                        if (cell[k] != -1) ph.idx[h] = -1;                        // mclib.c:592
+                        if (cell[k] != -1) ph.idx[i - ph.if_bias] = -1;           // mclib.c:592
                         t = 1e12 / C_LIGHT;                                       // mclib.c:620,684
                         ph.tts[i] = t;
                     }
@@ -980,7 +1007,7 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
         gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
         if (force) RANK_TICK(1); else RANK_TICK(2);
         // ---- the event half and the bookkeeping
-        event_block<DIMS, GEOM, STOKES>(ph, hy, &st, rk, sh, s_sln, gmin, base, n, iter, st.remaining_time, st.last_scattered_index, st.t_est);
+        event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n, iter, st.remaining_time, st.last_scattered_index, st.t_est);
         if (tid == 0) st.force_relocate = 0;
         __syncthreads();
         RANK_TICK(3);
@@ -997,8 +1024,8 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             for (int il = tid; il < n; il += EVENT_BLOCK) {
                 const int i = base + il;
                 const int h = i - ph.hot_bias;
-                if ((ph.flags[h] & FLAG_MOVES) && i != skip) {
-                    const double u0 = ph.u0[h], u1 = ph.u1[h], u2 = ph.u2[h];
+                if ((ph.flags[i - ph.if_bias] & FLAG_MOVES) && i != skip) {
+                    const double u0 = ph.u0[i - ph.u_bias], u1 = ph.u1[i - ph.u_bias], u2 = ph.u2[i - ph.u_bias];
                     double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
                     for (int s = 0; s < nseg; ++s) {
                         const double t = st.seg[s];
@@ -1013,8 +1040,11 @@ __global__ __launch_bounds__(EVENT_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ke
             for (int il = tid; il < n; il += EVENT_BLOCK) {
                 const int i = base + il;
                 gph.r0[i] = ph.r0[il]; gph.r1[i] = ph.r1[il]; gph.r2[i] = ph.r2[il];
-                gph.u0[i] = ph.u0[il]; gph.u1[i] = ph.u1[il]; gph.u2[i] = ph.u2[il];
-                gph.ntau[i] = ph.ntau[il]; gph.idx[i] = ph.idx[il]; gph.flags[i] = ph.flags[il];
+                gph.ntau[i] = ph.ntau[il];
+                if constexpr (FULL_HOT) {
+                    gph.u0[i] = ph.u0[il]; gph.u1[i] = ph.u1[il]; gph.u2[i] = ph.u2[il];
+                    gph.idx[i] = ph.idx[il]; gph.flags[i] = ph.flags[il];
+                }
             }
         }
 #ifdef MCRAT_DIAG
@@ -1489,38 +1519,32 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 }
 
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream)
+                            int n_ranks, int rank_photons, long long max_passes, int block, hipStream_t stream)
 {
     RankLayout lay = {n_ranks, rank_photons, ph.n};
-    // hot columns in LDS when two lists per CU still fit beside the static scratch: 61 B per slot
+    // per-pass columns in LDS (32 B per slot with 128 threads, 61 B with 256: rank_loop_kernel) for lists of up to 1024 photons
     int lds_slots = 0;
     if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && rank_photons <= 1024) lds_slots = (rank_photons + 15) & ~15;
-    size_t dyn = (size_t)lds_slots * (7 * sizeof(double) + sizeof(int) + 1);
+    size_t dyn = (size_t)lds_slots * rank_lds_bytes_per_slot(block == 128 ? 128 : 256);
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
-        // static + dynamic LDS exceeds the 64 KiB default: the kernel must be told, and if the runtime refuses
+        // static + dynamic LDS may exceed the 64 KiB default: the kernel must be told, and if the runtime refuses
         // the list simply stays in global memory (lds_slots = 0)
-        auto launch = [&](auto kernel) {
-            int slots = lds_slots;
-            size_t bytes = dyn;
-            if (bytes > 0 && hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)bytes) != hipSuccess) {
+        auto launch = [&](auto kernel, auto kernel_global, int threads) {
+            if (lds_slots > 0 &&
+                hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) {
+                kernel<<<dim3(n_ranks), dim3(threads), dyn, stream>>>(ph, hy, states, key, lay, max_passes, lds_slots);
+            } else {
                 (void)hipGetLastError();
-                slots = 0;
-                bytes = 0;
+                kernel_global<<<dim3(n_ranks), dim3(threads), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
             }
-            if (slots > 0) {
-                kernel<<<dim3(n_ranks), dim3(EVENT_BLOCK), bytes, stream>>>(ph, hy, states, key, lay, max_passes, slots);
-                return true;
-            }
-            return false;
         };
-        bool done;
-        if (kc.stokes) done = lds_slots > 0 && launch(rank_loop_kernel<DV, GV, true, true>);
-        else done = lds_slots > 0 && launch(rank_loop_kernel<DV, GV, false, true>);
-        if (!done) {
-            if (kc.stokes) rank_loop_kernel<DV, GV, true, false><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
-            else rank_loop_kernel<DV, GV, false, false><<<dim3(n_ranks), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+        if (block == 128) {
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 128>, rank_loop_kernel<DV, GV, true, false, 128>, 128);
+            else launch(rank_loop_kernel<DV, GV, false, true, 128>, rank_loop_kernel<DV, GV, false, false, 128>, 128);
+        } else {
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256>, rank_loop_kernel<DV, GV, true, false, 256>, 256);
+            else launch(rank_loop_kernel<DV, GV, false, true, 256>, rank_loop_kernel<DV, GV, false, false, 256>, 256);
         }
     });
 }

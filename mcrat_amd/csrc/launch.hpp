@@ -27,9 +27,9 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 // candidate selection + photonEvent + loop bookkeeping
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
-// virtual ranks: every workgroup runs the whole loop of one independent photon list of `rank_photons` slots
+// virtual ranks: every workgroup (of `block` = 128 or 256 threads) runs the whole loop of one independent photon list of `rank_photons` slots
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_photons, long long max_passes, hipStream_t stream);
+                            int n_ranks, int rank_photons, long long max_passes, int block, hipStream_t stream);
 // one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
