@@ -419,15 +419,17 @@ def test_virtual_ranks_whole_frame_and_split_runs(hip, oracle):
         assert np.array_equal(out2[k], out[k]), k
 
 
-def test_virtual_ranks_are_deterministic_and_equal_single_list_contexts_at_scale(hip):
-    """300 lists on the 1 048 576-cell frame, run twice (once split after the forced pass): identical counters and
+def test_virtual_ranks_are_deterministic_and_equal_single_list_contexts_at_scale(hip, monkeypatch):
+    """300 lists on the 1 048 576-cell frame, run three times (once split after the forced pass, once with 128-thread
+    workgroups): identical counters and
     photons both times, and a sample of lists bit-identical to single-list contexts holding only their photons
     (rng_stream = first stream + r).  Guards the workgroup-level hand-offs of rank_loop_kernel against races."""
     n, per = 300000, 1000
     frame, ph, cfg = synth.config2(n_photons=n)
     rem = 1.0 / frame["fps"]
     runs = []
-    for split in (False, True):
+    for split, block in ((False, "256"), (True, "256"), (False, "128")):       # 128: four lists per CU, same arithmetic
+        monkeypatch.setenv("MCRAT_HIP_RANK_BLOCK", block)
         e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=per)
         e.set_hydro(frame)
         e.set_photons(ph)
@@ -439,9 +441,10 @@ def test_virtual_ranks_are_deterministic_and_equal_single_list_contexts_at_scale
         per_rank = [(e.rank_stats(r).iterations, e.rank_stats(r).frame_scatt_cnt) for r in range(0, e.num_virtual_ranks(), 7)]
         runs.append((st.iterations, st.frame_scatt_cnt, st.num_photons_find_new_element, per_rank, out))
         e.close()
-    assert runs[0][:4] == runs[1][:4]
-    for k in FLOAT_FIELDS + INT_FIELDS:
-        assert np.array_equal(np.asarray(runs[0][4][k]), np.asarray(runs[1][4][k]), equal_nan=True), k
+    for other in runs[1:]:
+        assert runs[0][:4] == other[:4]
+        for k in FLOAT_FIELDS + INT_FIELDS:
+            assert np.array_equal(np.asarray(runs[0][4][k]), np.asarray(other[4][k]), equal_nan=True), k
     out = runs[0][4]
     for r in (0, 113, 276, 299):
         lo, hi = r * per, (r + 1) * per
