@@ -168,6 +168,77 @@ const char *mcrat_hip_last_error(const mcrat_hip_ctx *ctx);   /* text of the las
 /* staging: once per hydro frame (after getHydroData, mcrat.c:721) ------------- */
 int mcrat_hip_set_hydro(mcrat_hip_ctx *ctx, const mcrat_hip_hydro *hydro);
 
+/* getHydroData (mcrat_io.c:1898-1990; mcrat.c:640,721) on the device, file reading excluded: the caller hands over the
+ * buffers a reader holds right after its H5Dread / fread calls, in code units; the expansion to cells, the unit
+ * scaling, the slab selection with the reader's elem_factor loop, the derived columns (gamma, dens_lab, temp),
+ * fillHydroCoordinateToSpherical (geometry.c:156) and the SIMULATION_TYPE overwrite (analytic_outflows.c) run on the
+ * device, in the reference's cell order, and the result is staged exactly as mcrat_hip_set_hydro would stage it -- no
+ * host copy of the selected frame is made (mcrat_hip_get_hydro returns one when the caller needs it).
+ *   mcrat_hip_ingest_flash  replaces readAndDecimate (mclib_flash.c:60-431) after line 197 (datasets read)
+ *   mcrat_hip_ingest_pluto  replaces readPluto (mclib_pluto.c:1058-1459) after line 1128 (file read)
+ * mcrat_host_read_pluto (mcrat_amd/host) parses grid.out, dbl.out and the .dbl file into mcrat_hip_pluto_grid. */
+typedef struct mcrat_hip_slab {           /* the selecting arguments of getHydroData (mcrat_io.h:26) + frame constants */
+    double r_inj;
+    int    ph_inj_switch;                 /* 1: every cell with r > 0.95 r_inj (injection frame); 0: the photons' slab */
+    double min_r, max_r, min_theta, max_theta;   /* phMinMax of the photon list (mcrat.c:716) */
+    double fps;                           /* hydro_data->fps */
+    double r0_domain[2], r1_domain[2], r2_domain[2];   /* hydro_data->r*_domain (mc.par / mcrat_input.h) */
+} mcrat_hip_slab;
+
+typedef struct mcrat_hip_flash_blocks {   /* the datasets of a FLASH checkpoint, mclib_flash.c:143-193 */
+    int n_blocks;                         /* dims[0] of "coordinates" */
+    int coord_stride, bsize_stride;       /* doubles per row of "coordinates" / "block size" */
+    const double *coordinates, *block_size;
+    const int    *node_type;              /* leaf blocks have 1 */
+    const double *velx, *vely, *dens, *pres;   /* [n_blocks][1][8][8] */
+    double l_scale, d_scale, p_scale;     /* HYDRO_L_SCALE, HYDRO_D_SCALE, HYDRO_P_SCALE */
+} mcrat_hip_flash_blocks;
+
+typedef struct mcrat_hip_pluto_grid {     /* a PLUTO .dbl frame: readGridFile's arrays + the variable blocks */
+    int nx, ny, nz;                       /* nz ignored unless DIMENSIONS == THREE */
+    const double *x1, *dx1, *x2, *dx2, *x3, *dx3;   /* cell centres and widths per axis, code units (mclib_pluto.c:951-971) */
+    const double *rho, *vx1, *vx2, *vx3, *prs;      /* [nz][ny][nx]; vx3 may be NULL in 2-D */
+    double l_scale, d_scale, p_scale;
+} mcrat_hip_pluto_grid;
+
+#define MCRAT_HIP_SCIENCE                       0   /* SIMULATION_TYPE, mcrat.h:30-33 */
+#define MCRAT_HIP_CYLINDRICAL_OUTFLOW           1
+#define MCRAT_HIP_SPHERICAL_OUTFLOW             2
+#define MCRAT_HIP_STRUCTURED_SPHERICAL_OUTFLOW  3
+typedef struct mcrat_hip_outflow {        /* the constants analytic_outflows.c hard-codes (lines 5, 65, 140-141) */
+    int simulation_type;
+    double gamma_infinity;                /* gamma_0 of the structured fireball */
+    double lumi, r00;
+    double t_comov, ddensity;             /* cylindrical outflow */
+    double theta_j, p;                    /* structured fireball */
+} mcrat_hip_outflow;
+void mcrat_hip_outflow_defaults(int simulation_type, mcrat_hip_outflow *out);   /* the reference's values */
+
+typedef struct mcrat_hip_ingest_result {
+    int num_elements;                     /* hydro_data->num_elements */
+    int elem_factor;                      /* the reader's log line "Elem factor: %d" */
+    long long cells_read;                 /* cells examined (leaf blocks x 64, or nx ny nz) */
+} mcrat_hip_ingest_result;
+
+/* outflow may be NULL (SCIENCE).  MCRAT_HIP_EINVAL with last_error set when no elem_factor up to 1000 selects a cell
+ * (the reference would loop forever). */
+int mcrat_hip_ingest_flash(mcrat_hip_ctx *ctx, const mcrat_hip_flash_blocks *blocks, const mcrat_hip_slab *slab,
+                           const mcrat_hip_outflow *outflow, mcrat_hip_ingest_result *result);
+int mcrat_hip_ingest_pluto(mcrat_hip_ctx *ctx, const mcrat_hip_pluto_grid *grid, const mcrat_hip_slab *slab,
+                           const mcrat_hip_outflow *outflow, mcrat_hip_ingest_result *result);
+
+/* every column of the staged frame (struct hydro_dataframe, mcrat.h:194-244), host pointers of num_elements doubles
+ * allocated by the caller; NULL pointers are skipped.  After mcrat_hip_set_hydro the columns that call did not carry
+ * (dens, pres) read as zero. */
+typedef struct mcrat_hip_hydro_columns {
+    int num_elements;                     /* in: capacity of the arrays; out: elements written */
+    double *r0, *r1, *r2, *r0_size, *r1_size, *r2_size;
+    double *v0, *v1, *v2;
+    double *dens, *dens_lab, *pres, *temp, *gamma;
+    double *r, *theta;
+} mcrat_hip_hydro_columns;
+int mcrat_hip_get_hydro(mcrat_hip_ctx *ctx, mcrat_hip_hydro_columns *out);
+
 /* photonInjection (mclib.c:9-300; mcrat.c:645) on the device, from the staged hydro frame: afterwards the context holds
  * the new photons (*num_photons of them, all of weight *ph_weight_adjusted -- the reference's min/max-photons loop of
  * mclib.c:87-136 runs on the device counts) exactly as if they had been injected on the host and handed to

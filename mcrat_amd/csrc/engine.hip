@@ -57,6 +57,12 @@ struct mcrat_hip_ctx {
     unsigned *grid_count = nullptr;    // per-bucket counters of the device build
     size_t grid_count_cap = 0;
     unsigned long long *d_grid_total = nullptr;
+    HydroCols hcol{};                  // the frame as struct hydro_dataframe's columns (set_hydro / ingest), kept for get_hydro
+    void *hcol_buf = nullptr;
+    size_t hcol_bytes = 0;
+    int hcol_M = 0;
+    void *raw_buf = nullptr;           // device copy of a reader's buffers (mcrat_hip_ingest_*)
+    size_t raw_bytes = 0;
 
     // TAU_CALCULATION == TABLE
     double *d_hot_table = nullptr;
@@ -204,6 +210,8 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->aos_buf) (void)hipFree(c->aos_buf);
     if (c->hy_buf) (void)hipFree(c->hy_buf);
     if (c->grid_buf) (void)hipFree(c->grid_buf);
+    if (c->hcol_buf) (void)hipFree(c->hcol_buf);
+    if (c->raw_buf) (void)hipFree(c->raw_buf);
     if (c->grid_count) (void)hipFree(c->grid_count);
     if (c->d_grid_total) (void)hipFree(c->d_grid_total);
     if (c->partials) (void)hipFree(c->partials);
@@ -265,30 +273,27 @@ inline int bucket_of(double x, int logmap, double org, double inv, int dim)
 // cell exactly as the linear scan does.  (The reference's own buildSpatialGrid, geometry.c:526-676, is
 // disabled at HEAD and tests DIMENSIONS against the wrong constants; it is not reproduced.)
 // extents, log mapping and typical cell widths of the mesh: what fixes the bucket grid up to a scale factor f
-bool grid_plan(const mcrat_hip_hydro *h, int naxes, GridHost &g)
+struct MeshStats {      // what the plan needs from the mesh: per axis the extent, the smallest and largest width, and every
+    double lo[3], hi[3], smin[3], smax[3];       // stride-th cell's centre and width (stride = max(1, M / 4096))
+    std::vector<double> sc[3], ss[3];
+};
+inline int plan_stride(int M) { return std::max(1, M / 4096); }
+
+bool grid_plan_from_stats(const MeshStats &ms, int M, int naxes, GridHost &g)
 {
-    const int M = h->num_elements;
-    const double *c[3] = {h->r0, h->r1, h->r2};
-    const double *s[3] = {h->r0_size, h->r1_size, h->r2_size};
     g.naxes = naxes;
     double *ext_lo = g.ext_lo, *ext_hi = g.ext_hi, *ncell = g.ncell;
     for (int k = 0; k < naxes; ++k) {
-        double lo = INFINITY, hi = -INFINITY, smin = INFINITY, smax = 0;
-        for (int i = 0; i < M; ++i) {
-            lo = std::min(lo, c[k][i] - 0.5 * s[k][i]);
-            hi = std::max(hi, c[k][i] + 0.5 * s[k][i]);
-            smin = std::min(smin, s[k][i]);
-            smax = std::max(smax, s[k][i]);
-        }
+        const double lo = ms.lo[k], hi = ms.hi[k], smin = ms.smin[k], smax = ms.smax[k];
         if (!(hi > lo) || !(smin > 0)) return false;
         g.logmap[k] = (lo > 0 && smax / smin > 4.0) ? 1 : 0;
         // typical cell width in the mapped coordinate: median over a sample
         std::vector<double> w;
-        const int stride = std::max(1, M / 4096);
-        for (int i = 0; i < M; i += stride) {
-            const double a = c[k][i] - 0.5 * s[k][i], b = c[k][i] + 0.5 * s[k][i];
+        for (size_t i = 0; i < ms.sc[k].size(); ++i) {
+            const double a = ms.sc[k][i] - 0.5 * ms.ss[k][i], b = ms.sc[k][i] + 0.5 * ms.ss[k][i];
             w.push_back(g.logmap[k] ? std::log(b) - std::log(std::max(a, 1e-300)) : b - a);
         }
+        if (w.empty()) return false;
         // bucket width = a small typical cell (lower quartile): in a mesh with two refinement levels the fine cells,
         // where the photons are, then get buckets of their own size instead of lists of nine
         std::nth_element(w.begin(), w.begin() + w.size() / 4, w.end());
@@ -302,6 +307,26 @@ bool grid_plan(const mcrat_hip_hydro *h, int naxes, GridHost &g)
     const double target = std::min(std::max(4.0 * (double)M, 1.0), 16777216.0);
     g.f0 = (prod > target) ? std::pow(target / prod, 1.0 / naxes) : 1.0;
     return true;
+}
+
+bool grid_plan(const mcrat_hip_hydro *h, int naxes, GridHost &g)
+{
+    const int M = h->num_elements;
+    const double *c[3] = {h->r0, h->r1, h->r2};
+    const double *s[3] = {h->r0_size, h->r1_size, h->r2_size};
+    MeshStats ms;
+    for (int k = 0; k < naxes; ++k) {
+        double lo = INFINITY, hi = -INFINITY, smin = INFINITY, smax = 0;
+        for (int i = 0; i < M; ++i) {
+            lo = std::min(lo, c[k][i] - 0.5 * s[k][i]);
+            hi = std::max(hi, c[k][i] + 0.5 * s[k][i]);
+            smin = std::min(smin, s[k][i]);
+            smax = std::max(smax, s[k][i]);
+        }
+        ms.lo[k] = lo; ms.hi[k] = hi; ms.smin[k] = smin; ms.smax[k] = smax;
+        for (int i = 0; i < M; i += plan_stride(M)) { ms.sc[k].push_back(c[k][i]); ms.ss[k].push_back(s[k][i]); }
+    }
+    return grid_plan_from_stats(ms, M, naxes, g);
 }
 
 // the bucket grid for scale factor f; returns the number of buckets
@@ -448,23 +473,22 @@ extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *t
     return MCRAT_HIP_OK;
 }
 
-extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
-{
-    if (!c || !h || h->num_elements <= 0) return MCRAT_HIP_EINVAL;
-    const int M = h->num_elements;
-    const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
-    if (!h->r0 || !h->r1 || !h->r0_size || !h->r1_size || !h->v0 || !h->v1 || !h->dens_lab || !h->temp || !h->gamma) return MCRAT_HIP_EINVAL;
-    if (three && (!h->r2 || !h->r2_size)) return MCRAT_HIP_EINVAL;
-    if (!two && !h->v2) return MCRAT_HIP_EINVAL;
+static int ensure_aos(mcrat_hip_ctx *c, size_t bytes);
 
-    // the cell-lookup grid is built on the device (grid_build.hip) from the staged per-cell records; the host build is the
-    // cross-check (MCRAT_HIP_HOST_GRID=1)
+// The frame's per-cell records and cell-lookup grid.  h == nullptr (the product path): from the device columns c->hcol,
+// on the device -- stage_cells_kernel (ingest.hip) + grid_build.hip; the host only plans the bucket grid from the mesh
+// statistics the kernel reduces.  h != nullptr (MCRAT_HIP_HOST_GRID=1): staging loop and grid build on the host, the
+// cross-check of the device path (tests/test_gpu_parity.py).
+static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const double *dom0, const double *dom1, const double *dom2)
+{
+    const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
     const int naxes = three ? 3 : 2;
-    const bool host_grid = getenv("MCRAT_HIP_HOST_GRID") != nullptr;
+    const bool host_grid = h != nullptr;
     GridHost g;
-    if (host_grid ? !build_grid(h, naxes, g) : !grid_plan(h, naxes, g)) { c->last_error = "cell-lookup grid: degenerate mesh"; return MCRAT_HIP_EINVAL; }
+    if (host_grid && !build_grid(h, naxes, g)) { c->last_error = "cell-lookup grid: degenerate mesh"; return MCRAT_HIP_EINVAL; }
     bool any_hot = false;
-    for (int i = 0; i < M; ++i) any_hot = any_hot || (h->temp[i] >= 1e7);
+    if (host_grid)
+        for (int i = 0; i < M; ++i) any_hot = any_hot || (h->temp[i] >= 1e7);
 
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -473,21 +497,55 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     const size_t o_fluid = take(sizeof(CellFluid) * M);
     const size_t o_temp = take(sizeof(double) * M);
     const size_t o_fc = !two ? take(sizeof(double) * M) : 0;
-    const size_t o_k2e = any_hot ? take(sizeof(double) * M) : 0;
+    const size_t o_k2e = (any_hot || !host_grid) ? take(sizeof(double) * M) : 0;     // device path: known only after staging
     const size_t total = off;
 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->hy_buf && c->hy_bytes < total) { HIPCHK(c, hipFree(c->hy_buf)); c->hy_buf = nullptr; c->hy_bytes = 0; }
     if (!c->hy_buf) { HIPCHK(c, hipMalloc(&c->hy_buf, total)); c->hy_bytes = total; }
+    char *base = static_cast<char *>(c->hy_buf);
 
-    std::vector<char> host(total, 0);
+    if (!host_grid) {
+        const int nblk = stage_cells_blocks(M), stride = plan_stride(M), nsamp = (M + stride - 1) / stride;
+        const size_t scratch_bytes = sizeof(StagePartial) * (size_t)nblk + sizeof(double) * 2 * naxes * (size_t)nsamp;
+        int rc = ensure_aos(c, scratch_bytes);
+        if (rc) return rc;
+        StagePartial *d_part = static_cast<StagePartial *>(c->aos_buf);
+        double *d_samp = reinterpret_cast<double *>(d_part + nblk);
+        HIPCHK(c, launch_stage_cells(c->kc.dimensions, c->kc.geometry, c->hcol, M, reinterpret_cast<CellGeom *>(base + o_geom),
+                                     three ? reinterpret_cast<CellGeom2 *>(base + o_geom2) : nullptr, reinterpret_cast<CellFluid *>(base + o_fluid),
+                                     !two ? reinterpret_cast<double *>(base + o_fc) : nullptr, reinterpret_cast<double *>(base + o_temp),
+                                     d_part, d_samp, stride, nsamp, c->stream));
+        std::vector<char> hs(scratch_bytes);
+        HIPCHK(c, hipMemcpyAsync(hs.data(), c->aos_buf, scratch_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const StagePartial *part = reinterpret_cast<const StagePartial *>(hs.data());
+        const double *samp = reinterpret_cast<const double *>(part + nblk);
+        MeshStats ms;
+        for (int k = 0; k < naxes; ++k) {
+            double lo = INFINITY, hi = -INFINITY, smin = INFINITY, smax = 0;
+            for (int b = 0; b < nblk; ++b) {
+                lo = std::min(lo, part[b].lo[k]);
+                hi = std::max(hi, part[b].hi[k]);
+                smin = (part[b].smin[k] < smin || !(part[b].smin[k] == part[b].smin[k])) ? part[b].smin[k] : smin;
+                smax = std::max(smax, part[b].smax[k]);
+            }
+            ms.lo[k] = lo; ms.hi[k] = hi; ms.smin[k] = smin; ms.smax[k] = smax;
+            ms.sc[k].assign(samp + (size_t)(2 * k) * nsamp, samp + (size_t)(2 * k + 1) * nsamp);
+            ms.ss[k].assign(samp + (size_t)(2 * k + 1) * nsamp, samp + (size_t)(2 * k + 2) * nsamp);
+        }
+        for (int b = 0; b < nblk; ++b) any_hot = any_hot || part[b].any_hot;
+        if (!grid_plan_from_stats(ms, M, naxes, g)) { c->last_error = "cell-lookup grid: degenerate mesh"; return MCRAT_HIP_EINVAL; }
+    }
+
+    std::vector<char> host(host_grid ? total : 0, 0);
     CellGeom *geom = reinterpret_cast<CellGeom *>(host.data() + o_geom);
     CellFluid *fluid = reinterpret_cast<CellFluid *>(host.data() + o_fluid);
-    // the per-cell part of hydroVectorToCartesian (geometry.c:189-253) is applied here, once per frame, in
-    // host double arithmetic; the device adds the photon-azimuth part (physics.hpp, cell_beta)
+    // the per-cell part of hydroVectorToCartesian (geometry.c:189-253) is applied here, once per frame; the device adds the
+    // photon-azimuth part (physics.hpp, cell_beta)
     double *fc = !two ? reinterpret_cast<double *>(host.data() + o_fc) : nullptr;
     const int geomv = c->kc.geometry;
-    for (int i = 0; i < M; ++i) {
+    for (int i = 0; host_grid && i < M; ++i) {
         geom[i].c0 = h->r0[i]; geom[i].c1 = h->r1[i]; geom[i].s0 = h->r0_size[i]; geom[i].s1 = h->r1_size[i];
         fluid[i].gamma = h->gamma[i]; fluid[i].dens_lab = h->dens_lab[i];
         const double v0 = h->v0[i], v1 = h->v1[i], v2 = two ? 0.0 : h->v2[i];
@@ -515,14 +573,15 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
             fc[i] = v2;
         }
     }
-    if (three) {
-        CellGeom2 *g2 = reinterpret_cast<CellGeom2 *>(host.data() + o_geom2);
-        for (int i = 0; i < M; ++i) { g2[i].c2 = h->r2[i]; g2[i].s2 = h->r2_size[i]; }
+    if (host_grid) {
+        if (three) {
+            CellGeom2 *g2 = reinterpret_cast<CellGeom2 *>(host.data() + o_geom2);
+            for (int i = 0; i < M; ++i) { g2[i].c2 = h->r2[i]; g2[i].s2 = h->r2_size[i]; }
+        }
+        memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
+        HIPCHK(c, hipMemcpy(c->hy_buf, host.data(), total, hipMemcpyHostToDevice));
     }
-    memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
-    HIPCHK(c, hipMemcpy(c->hy_buf, host.data(), total, hipMemcpyHostToDevice));
 
-    char *base = static_cast<char *>(c->hy_buf);
     HydroDev &hy = c->hy;
     hy.geom = reinterpret_cast<const CellGeom *>(base + o_geom);
     hy.geom2 = three ? reinterpret_cast<const CellGeom2 *>(base + o_geom2) : nullptr;
@@ -531,9 +590,9 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     hy.fluid_c = !two ? reinterpret_cast<const double *>(base + o_fc) : nullptr;
     hy.k2e = any_hot ? reinterpret_cast<const double *>(base + o_k2e) : nullptr;
     hy.M = M;
-    hy.dom0[0] = h->r0_domain[0]; hy.dom0[1] = h->r0_domain[1];
-    hy.dom1[0] = h->r1_domain[0]; hy.dom1[1] = h->r1_domain[1];
-    hy.dom2[0] = h->r2_domain[0]; hy.dom2[1] = h->r2_domain[1];
+    hy.dom0[0] = dom0[0]; hy.dom0[1] = dom0[1];
+    hy.dom1[0] = dom1[0]; hy.dom1[1] = dom1[1];
+    hy.dom2[0] = dom2[0]; hy.dom2[1] = dom2[1];
 
     // ---- the grid
     long long nb = 0, entries_total = 0;
@@ -619,6 +678,232 @@ extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
     }
     c->have_hydro = true;
     drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
+// struct hydro_dataframe's columns on the device: 16 arrays of M doubles
+static int ensure_hcol(mcrat_hip_ctx *c, int M)
+{
+    const size_t stride = align_up(sizeof(double) * (size_t)M, 256), total = 16 * stride;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->hcol_buf && c->hcol_bytes < total) { HIPCHK(c, hipFree(c->hcol_buf)); c->hcol_buf = nullptr; c->hcol_bytes = 0; }
+    if (!c->hcol_buf) { HIPCHK(c, hipMalloc(&c->hcol_buf, total)); c->hcol_bytes = total; }
+    char *b = static_cast<char *>(c->hcol_buf);
+    double **cols[16] = {&c->hcol.r0, &c->hcol.r1, &c->hcol.r2, &c->hcol.s0, &c->hcol.s1, &c->hcol.s2, &c->hcol.v0, &c->hcol.v1, &c->hcol.v2,
+                         &c->hcol.dens, &c->hcol.dens_lab, &c->hcol.pres, &c->hcol.temp, &c->hcol.gamma, &c->hcol.r, &c->hcol.theta};
+    for (int k = 0; k < 16; ++k) *cols[k] = reinterpret_cast<double *>(b + k * stride);
+    c->hcol_M = M;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
+{
+    if (!c || !h || h->num_elements <= 0) return MCRAT_HIP_EINVAL;
+    const int M = h->num_elements;
+    const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
+    if (!h->r0 || !h->r1 || !h->r0_size || !h->r1_size || !h->v0 || !h->v1 || !h->dens_lab || !h->temp || !h->gamma) return MCRAT_HIP_EINVAL;
+    if (three && (!h->r2 || !h->r2_size)) return MCRAT_HIP_EINVAL;
+    if (!two && !h->v2) return MCRAT_HIP_EINVAL;
+    c->have_hydro = false;
+    // the columns cross PCIe as they lie in the caller's memory; per-cell records and the cell-lookup grid are produced on
+    // the device (stage_hydro)
+    int rc = ensure_hcol(c, M);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->hcol_buf, 0, c->hcol_bytes, c->stream));
+    const struct { double *dst; const double *src; } copy[12] = {
+        {c->hcol.r0, h->r0}, {c->hcol.r1, h->r1}, {c->hcol.r2, three ? h->r2 : nullptr}, {c->hcol.s0, h->r0_size}, {c->hcol.s1, h->r1_size},
+        {c->hcol.s2, three ? h->r2_size : nullptr}, {c->hcol.v0, h->v0}, {c->hcol.v1, h->v1}, {c->hcol.v2, !two ? h->v2 : nullptr},
+        {c->hcol.dens_lab, h->dens_lab}, {c->hcol.temp, h->temp}, {c->hcol.gamma, h->gamma}};
+    for (const auto &cp : copy)
+        if (cp.src) HIPCHK(c, hipMemcpyAsync(cp.dst, cp.src, sizeof(double) * (size_t)M, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_fill_spherical(c->kc.dimensions, c->kc.geometry, c->hcol, M, c->stream));
+    return stage_hydro(c, getenv("MCRAT_HIP_HOST_GRID") ? h : nullptr, M, h->r0_domain, h->r1_domain, h->r2_domain);
+}
+
+extern "C" void mcrat_hip_outflow_defaults(int simulation_type, mcrat_hip_outflow *o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof *o);
+    o->simulation_type = simulation_type;
+    if (simulation_type == MCRAT_HIP_CYLINDRICAL_OUTFLOW) { o->gamma_infinity = 100; o->t_comov = 1e5; o->ddensity = 3e-7; }                      // analytic_outflows.c:5
+    if (simulation_type == MCRAT_HIP_SPHERICAL_OUTFLOW) { o->gamma_infinity = 100; o->lumi = 1e54; o->r00 = 1e8; }                                // :65
+    if (simulation_type == MCRAT_HIP_STRUCTURED_SPHERICAL_OUTFLOW) { o->gamma_infinity = 100; o->lumi = 1e52; o->r00 = 1e8; o->theta_j = 1e-2; o->p = 4; }   // :140
+}
+
+namespace {
+
+// device copies of a reader's buffers, packed into c->raw_buf
+struct RawPacker {
+    mcrat_hip_ctx *c;
+    size_t off = 0;
+    std::vector<std::pair<size_t, std::pair<const void *, size_t>>> items;
+    size_t add(const void *src, size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); items.push_back({o, {src, bytes}}); return o; }
+    int upload()
+    {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->raw_buf && c->raw_bytes < off) { HIPCHK(c, hipFree(c->raw_buf)); c->raw_buf = nullptr; c->raw_bytes = 0; }
+        if (!c->raw_buf) { HIPCHK(c, hipMalloc(&c->raw_buf, off)); c->raw_bytes = off; }
+        for (const auto &it : items)
+            if (it.second.first) HIPCHK(c, hipMemcpyAsync(static_cast<char *>(c->raw_buf) + it.first, it.second.first, it.second.second, hipMemcpyHostToDevice, c->stream));
+        return MCRAT_HIP_OK;
+    }
+    template <class T> const T *at(size_t o) const { return reinterpret_cast<const T *>(static_cast<const char *>(c->raw_buf) + o); }
+};
+
+// the slab for one elem_factor (mclib_flash.c:84-85,309 == mclib_pluto.c:1081-1082,1276)
+SlabDev slab_for(const mcrat_hip_ctx *c, const mcrat_hip_slab *s, int elem_factor)
+{
+    SlabDev d{};
+    d.dimensions = c->kc.dimensions; d.geometry = c->kc.geometry; d.ph_inj_switch = s->ph_inj_switch;
+    d.r_inj_095 = 0.95 * s->r_inj;
+    if (s->ph_inj_switch == 0) {
+        d.r_lo = s->min_r - elem_factor * C_LIGHT / s->fps;
+        d.r_hi = s->max_r + elem_factor * C_LIGHT / s->fps;
+        d.th_lo = s->min_theta - 2 * 0.017453292519943295;
+        d.th_hi = s->max_theta + 2 * 0.017453292519943295;
+    }
+    return d;
+}
+
+// the part of getHydroData both readers share: count with a growing elem_factor, scan, write, fill r/theta, overwrite
+// with the analytic outflow, stage
+template <class Count, class Write>
+int ingest_common(mcrat_hip_ctx *c, long long n_virtual, const mcrat_hip_slab *slab, const mcrat_hip_outflow *outflow,
+                  mcrat_hip_ingest_result *result, Count count, Write write)
+{
+    const long long nblk = ingest_blocks(n_virtual);
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return MCRAT_HIP_EINVAL;
+    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+    if (c->grid_count_cap < (size_t)nblk) {
+        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
+        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)nblk));
+        c->grid_count_cap = (size_t)nblk;
+    }
+    // CYCLOSYNCHROTRON_SWITCH is OFF in this engine (mcrat_hip_init refuses it): elem_factor starts at 0 (mclib_flash.c:275-279)
+    int elem_factor = 0;
+    unsigned long long total = 0;
+    SlabDev sd{};
+    while (total == 0) {
+        elem_factor++;
+        if (elem_factor > 1000) {
+            c->last_error = "hydro ingest: no cell lies in the requested slab for any elem_factor up to 1000 (the reference would not return)";
+            return MCRAT_HIP_EINVAL;
+        }
+        sd = slab_for(c, slab, elem_factor);
+        HIPCHK(c, count(sd));
+        HIPCHK(c, hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (total > 0x7fffffffull) { c->last_error = "hydro ingest: more than INT_MAX cells selected"; return MCRAT_HIP_EINVAL; }
+    const int M = (int)total;
+    int rc = ensure_hcol(c, M);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->hcol_buf, 0, c->hcol_bytes, c->stream));
+    const size_t scan_bytes = sizeof(int) * ((size_t)nblk + 1 + grid_scan_scratch_ints(nblk));
+    if ((rc = ensure_aos(c, scan_bytes))) return rc;
+    int *start = static_cast<int *>(c->aos_buf), *scratch = start + nblk + 1;
+    HIPCHK(c, launch_exclusive_scan(c->grid_count, nblk, start, scratch, (long long)total, c->stream));
+    HIPCHK(c, write(sd, start));
+    HIPCHK(c, launch_fill_spherical(c->kc.dimensions, c->kc.geometry, c->hcol, M, c->stream));          // mcrat_io.c:1962
+    if (outflow && outflow->simulation_type != MCRAT_HIP_SCIENCE) {                                      // mcrat_io.c:1967-1973
+        OutflowDev o{outflow->simulation_type, outflow->gamma_infinity, outflow->lumi, outflow->r00, outflow->t_comov, outflow->ddensity,
+                     outflow->theta_j, outflow->p};
+        HIPCHK(c, launch_outflow_prep(c->kc.dimensions, c->kc.geometry, o, c->hcol, M, c->stream));
+    }
+    if (result) { result->num_elements = M; result->elem_factor = elem_factor; }
+    return stage_hydro(c, nullptr, M, slab->r0_domain, slab->r1_domain, slab->r2_domain);
+}
+
+bool slab_ok(const mcrat_hip_slab *s) { return s && s->fps > 0 && (s->ph_inj_switch == 0 || s->ph_inj_switch == 1); }
+bool outflow_ok(const mcrat_hip_outflow *o) { return !o || (o->simulation_type >= MCRAT_HIP_SCIENCE && o->simulation_type <= MCRAT_HIP_STRUCTURED_SPHERICAL_OUTFLOW); }
+
+}  // namespace
+
+extern "C" int mcrat_hip_ingest_flash(mcrat_hip_ctx *c, const mcrat_hip_flash_blocks *b, const mcrat_hip_slab *slab, const mcrat_hip_outflow *outflow,
+                                      mcrat_hip_ingest_result *result)
+{
+    if (!c || !b || !slab_ok(slab) || !outflow_ok(outflow)) return MCRAT_HIP_EINVAL;
+    if (b->n_blocks <= 0 || b->coord_stride < 2 || b->bsize_stride < 2 || !b->coordinates || !b->block_size || !b->node_type || !b->velx || !b->vely ||
+        !b->dens || !b->pres)
+        return MCRAT_HIP_EINVAL;
+    if (c->kc.dimensions != DIM_TWO) { c->last_error = "FLASH frames are two-dimensional (mcrat_io.c:1938: 3D FLASH is not supported)"; return MCRAT_HIP_EINVAL; }
+    c->have_hydro = false;
+    const size_t nb = (size_t)b->n_blocks;
+    RawPacker pk{c};
+    const size_t o_coord = pk.add(b->coordinates, sizeof(double) * nb * b->coord_stride), o_bs = pk.add(b->block_size, sizeof(double) * nb * b->bsize_stride);
+    const size_t o_node = pk.add(b->node_type, sizeof(int) * nb);
+    const size_t o_vx = pk.add(b->velx, sizeof(double) * nb * 64), o_vy = pk.add(b->vely, sizeof(double) * nb * 64);
+    const size_t o_d = pk.add(b->dens, sizeof(double) * nb * 64), o_p = pk.add(b->pres, sizeof(double) * nb * 64);
+    int rc = pk.upload();
+    if (rc) return rc;
+    FlashDev f{};
+    f.coord = pk.at<double>(o_coord); f.bsize = pk.at<double>(o_bs); f.node = pk.at<int>(o_node);
+    f.velx = pk.at<double>(o_vx); f.vely = pk.at<double>(o_vy); f.dens = pk.at<double>(o_d); f.pres = pk.at<double>(o_p);
+    f.coord_stride = b->coord_stride; f.bsize_stride = b->bsize_stride; f.n_blocks = b->n_blocks;
+    f.L = b->l_scale; f.D = b->d_scale; f.P = b->p_scale;
+    if (result) { memset(result, 0, sizeof *result); }
+    rc = ingest_common(c, (long long)nb * 64, slab, outflow, result,
+                       [&](const SlabDev &sd) { return ingest_count_flash(f, sd, c->grid_count, c->d_grid_total, c->stream); },
+                       [&](const SlabDev &sd, const int *start) { return ingest_write_flash(f, sd, start, c->hcol, c->stream); });
+    if (rc == MCRAT_HIP_OK && result) {
+        long long leaves = 0;
+        for (size_t i = 0; i < nb; ++i) leaves += b->node_type[i] == 1;
+        result->cells_read = leaves * 64;
+    }
+    return rc;
+}
+
+extern "C" int mcrat_hip_ingest_pluto(mcrat_hip_ctx *c, const mcrat_hip_pluto_grid *g, const mcrat_hip_slab *slab, const mcrat_hip_outflow *outflow,
+                                      mcrat_hip_ingest_result *result)
+{
+    if (!c || !g || !slab_ok(slab) || !outflow_ok(outflow)) return MCRAT_HIP_EINVAL;
+    const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
+    if (g->nx <= 0 || g->ny <= 0 || (three && g->nz <= 0) || !g->x1 || !g->dx1 || !g->x2 || !g->dx2 || !g->rho || !g->vx1 || !g->vx2 || !g->prs)
+        return MCRAT_HIP_EINVAL;
+    if (three && (!g->x3 || !g->dx3)) return MCRAT_HIP_EINVAL;
+    if (!two && !g->vx3) return MCRAT_HIP_EINVAL;
+    const int nz = three ? g->nz : 1;
+    const size_t cells = (size_t)g->nx * g->ny * nz;
+    if (cells > 0x7fffffffull) return MCRAT_HIP_EINVAL;            // the reference's grid_size is an int (mclib_pluto.c:1061)
+    c->have_hydro = false;
+    RawPacker pk{c};
+    const size_t o_x1 = pk.add(g->x1, sizeof(double) * g->nx), o_dx1 = pk.add(g->dx1, sizeof(double) * g->nx);
+    const size_t o_x2 = pk.add(g->x2, sizeof(double) * g->ny), o_dx2 = pk.add(g->dx2, sizeof(double) * g->ny);
+    const size_t o_x3 = three ? pk.add(g->x3, sizeof(double) * nz) : 0, o_dx3 = three ? pk.add(g->dx3, sizeof(double) * nz) : 0;
+    const size_t o_rho = pk.add(g->rho, sizeof(double) * cells), o_v1 = pk.add(g->vx1, sizeof(double) * cells), o_v2 = pk.add(g->vx2, sizeof(double) * cells);
+    const size_t o_v3 = !two ? pk.add(g->vx3, sizeof(double) * cells) : 0, o_p = pk.add(g->prs, sizeof(double) * cells);
+    int rc = pk.upload();
+    if (rc) return rc;
+    PlutoDev d{};
+    d.nx = g->nx; d.ny = g->ny; d.nz = nz;
+    d.x1 = pk.at<double>(o_x1); d.dx1 = pk.at<double>(o_dx1); d.x2 = pk.at<double>(o_x2); d.dx2 = pk.at<double>(o_dx2);
+    d.x3 = three ? pk.at<double>(o_x3) : nullptr; d.dx3 = three ? pk.at<double>(o_dx3) : nullptr;
+    d.rho = pk.at<double>(o_rho); d.vx1 = pk.at<double>(o_v1); d.vx2 = pk.at<double>(o_v2); d.vx3 = !two ? pk.at<double>(o_v3) : nullptr;
+    d.prs = pk.at<double>(o_p);
+    d.L = g->l_scale; d.D = g->d_scale; d.P = g->p_scale;
+    if (result) { memset(result, 0, sizeof *result); }
+    rc = ingest_common(c, (long long)cells, slab, outflow, result,
+                       [&](const SlabDev &sd) { return ingest_count_pluto(d, sd, c->grid_count, c->d_grid_total, c->stream); },
+                       [&](const SlabDev &sd, const int *start) { return ingest_write_pluto(d, sd, start, c->hcol, c->stream); });
+    if (rc == MCRAT_HIP_OK && result) result->cells_read = (long long)cells;
+    return rc;
+}
+
+extern "C" int mcrat_hip_get_hydro(mcrat_hip_ctx *c, mcrat_hip_hydro_columns *out)
+{
+    if (!c || !out) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro || !c->hcol_buf) return MCRAT_HIP_ESTATE;
+    const int M = c->hcol_M;
+    if (out->num_elements < M) return MCRAT_HIP_EINVAL;
+    const struct { double *dst; const double *src; } copy[16] = {
+        {out->r0, c->hcol.r0}, {out->r1, c->hcol.r1}, {out->r2, c->hcol.r2}, {out->r0_size, c->hcol.s0}, {out->r1_size, c->hcol.s1},
+        {out->r2_size, c->hcol.s2}, {out->v0, c->hcol.v0}, {out->v1, c->hcol.v1}, {out->v2, c->hcol.v2}, {out->dens, c->hcol.dens},
+        {out->dens_lab, c->hcol.dens_lab}, {out->pres, c->hcol.pres}, {out->temp, c->hcol.temp}, {out->gamma, c->hcol.gamma},
+        {out->r, c->hcol.r}, {out->theta, c->hcol.theta}};
+    for (const auto &cp : copy)
+        if (cp.dst) HIPCHK(c, hipMemcpyAsync(cp.dst, cp.src, sizeof(double) * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->num_elements = M;
     return MCRAT_HIP_OK;
 }
 

@@ -69,6 +69,50 @@ hipError_t launch_inject_count(const InjectParams &p, const HydroDev &hy, double
 // the photons themselves (mclib.c:150-296), ordered by cell then draw, into the SoA columns
 hipError_t launch_inject_generate(const InjectParams &p, const HydroDev &hy, double ph_weight_adjusted, RngKey key, const int *start,
                                   const PhotonDev &ph, hipStream_t stream);
+// getHydroData on the device (ingest.hip; mcrat_io.c:1898-1990)
+struct HydroCols {          // struct hydro_dataframe's columns (mcrat.h:194-244), device arrays of M doubles
+    double *r0, *r1, *r2, *s0, *s1, *s2;
+    double *v0, *v1, *v2;
+    double *dens, *dens_lab, *pres, *temp, *gamma;
+    double *r, *theta;
+};
+struct SlabDev {
+    int dimensions, geometry, ph_inj_switch;
+    double r_inj_095;                          // 0.95 r_inj
+    double r_lo, r_hi, th_lo, th_hi;           // the widened slab for the current elem_factor
+};
+struct FlashDev {           // device copies of a FLASH checkpoint's datasets (mclib_flash.c:143-193)
+    const double *coord, *bsize;
+    const int *node;
+    const double *velx, *vely, *dens, *pres;
+    int coord_stride, bsize_stride;
+    long long n_blocks;
+    double L, D, P;
+};
+struct PlutoDev {           // device copies of readGridFile's arrays and the .dbl variable blocks
+    int nx, ny, nz;
+    const double *x1, *dx1, *x2, *dx2, *x3, *dx3;
+    const double *rho, *vx1, *vx2, *vx3, *prs;
+    double L, D, P;
+};
+struct OutflowDev {
+    int simulation_type;
+    double gamma_infinity, lumi, r00, t_comov, ddensity, theta_j, p;
+};
+struct StagePartial {       // one per workgroup of stage_cells_kernel
+    double lo[3], hi[3], smin[3], smax[3];
+    int any_hot, pad;
+};
+long long ingest_blocks(long long n_virtual);   // workgroups (and block_count entries) of the two selection passes
+hipError_t ingest_count_flash(const FlashDev &f, const SlabDev &slab, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
+hipError_t ingest_write_flash(const FlashDev &f, const SlabDev &slab, const int *block_start, const HydroCols &out, hipStream_t stream);
+hipError_t ingest_count_pluto(const PlutoDev &g, const SlabDev &slab, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
+hipError_t ingest_write_pluto(const PlutoDev &g, const SlabDev &slab, const int *block_start, const HydroCols &out, hipStream_t stream);
+hipError_t launch_fill_spherical(int dims, int geom, const HydroCols &h, int M, hipStream_t stream);
+hipError_t launch_outflow_prep(int dims, int geom, const OutflowDev &o, const HydroCols &h, int M, hipStream_t stream);
+int stage_cells_blocks(int M);
+hipError_t launch_stage_cells(int dims, int geom, const HydroCols &h, int M, CellGeom *og, CellGeom2 *og2, CellFluid *of, double *ofc, double *otemp,
+                              StagePartial *partials, double *samples, int stride, int nsamp, hipStream_t stream);
 hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
                       unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
                       long long total, hipStream_t stream);

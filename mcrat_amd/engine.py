@@ -87,6 +87,44 @@ class FrameStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class Slab(C.Structure):
+    """mcrat_hip_slab: the selecting arguments of getHydroData (mcrat_io.h:26) + fps and the hydro domains"""
+    _fields_ = [("r_inj", C.c_double), ("ph_inj_switch", C.c_int), ("min_r", C.c_double), ("max_r", C.c_double),
+                ("min_theta", C.c_double), ("max_theta", C.c_double), ("fps", C.c_double),
+                ("r0_domain", C.c_double * 2), ("r1_domain", C.c_double * 2), ("r2_domain", C.c_double * 2)]
+
+
+class FlashBlocks(C.Structure):
+    _fields_ = [("n_blocks", C.c_int), ("coord_stride", C.c_int), ("bsize_stride", C.c_int),
+                ("coordinates", _dp), ("block_size", _dp), ("node_type", _ip),
+                ("velx", _dp), ("vely", _dp), ("dens", _dp), ("pres", _dp),
+                ("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double)]
+
+
+class PlutoGrid(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int)] + \
+               [(f, _dp) for f in ("x1", "dx1", "x2", "dx2", "x3", "dx3", "rho", "vx1", "vx2", "vx3", "prs")] + \
+               [("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double)]
+
+
+class Outflow(C.Structure):
+    _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
+                ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
+
+
+class IngestResult(C.Structure):
+    _fields_ = [("num_elements", C.c_int), ("elem_factor", C.c_int), ("cells_read", C.c_longlong)]
+
+
+HYDRO_COLUMNS = ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size", "v0", "v1", "v2", "dens", "dens_lab", "pres", "temp", "gamma", "r", "theta")
+
+
+class HydroColumns(C.Structure):
+    _fields_ = [("num_elements", C.c_int)] + [(f, _dp) for f in HYDRO_COLUMNS]
+
+
+SCIENCE, CYLINDRICAL_OUTFLOW, SPHERICAL_OUTFLOW, STRUCTURED_SPHERICAL_OUTFLOW = 0, 1, 2, 3    # SIMULATION_TYPE, mcrat.h:30-33
+
 # every symbol include/mcrat_hip.h declares: (restype, argtypes)
 _ctx = C.c_void_p
 SYMBOLS = {
@@ -96,6 +134,10 @@ SYMBOLS = {
     "mcrat_hip_strerror": (C.c_char_p, [C.c_int]),
     "mcrat_hip_last_error": (C.c_char_p, [_ctx]),
     "mcrat_hip_set_hydro": (C.c_int, [_ctx, C.POINTER(Hydro)]),
+    "mcrat_hip_outflow_defaults": (None, [C.c_int, C.POINTER(Outflow)]),
+    "mcrat_hip_ingest_flash": (C.c_int, [_ctx, C.POINTER(FlashBlocks), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
+    "mcrat_hip_ingest_pluto": (C.c_int, [_ctx, C.POINTER(PlutoGrid), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
+    "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
     "mcrat_hip_inject_photons": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char, C.c_double, C.c_double, C.c_double,
                                            C.c_uint64, _ip, _dp]),
     "mcrat_hip_set_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
@@ -213,7 +255,67 @@ class Engine:
         self.n = n.value
         return n.value, w.value
 
+    @staticmethod
+    def outflow(simulation_type, **overrides):
+        """the constants analytic_outflows.c hard-codes for this SIMULATION_TYPE, optionally overridden"""
+        o = Outflow()
+        load_library().mcrat_hip_outflow_defaults(int(simulation_type), C.byref(o))
+        for k, v in overrides.items():
+            setattr(o, k, float(v))
+        return o
+
+    @staticmethod
+    def _slab(slab):
+        s = Slab(float(slab["r_inj"]), int(slab["ph_inj_switch"]), float(slab["min_r"]), float(slab["max_r"]),
+                 float(slab["min_theta"]), float(slab["max_theta"]), float(slab["fps"]))
+        for k in ("r0_domain", "r1_domain", "r2_domain"):
+            dom = slab.get(k, (0.0, 0.0))
+            getattr(s, k)[0], getattr(s, k)[1] = float(dom[0]), float(dom[1])
+        return s
+
+    def ingest(self, raw, slab, outflow=None):
+        """getHydroData (mcrat_io.c:1898-1990) on the device from a reader's buffers: raw["kind"] "flash" (coordinates,
+        block_size, node_type, velx, vely, dens, pres) or "pluto" (nx, ny, nz, x1..dx3, rho, vx1, vx2, vx3, prs), with
+        l_scale, d_scale, p_scale; slab: r_inj, ph_inj_switch, min_r, max_r, min_theta, max_theta, fps, r*_domain.
+        The selected frame is staged for the loop; returns (num_elements, elem_factor, cells_read)."""
+        keep, res, s = [], IngestResult(), self._slab(slab)
+
+        def ptr(a, dtype=np.float64, ctype=C.c_double):
+            arr = np.ascontiguousarray(a, dtype=dtype)
+            keep.append(arr)
+            return arr.ctypes.data_as(C.POINTER(ctype))
+        op = C.byref(outflow) if outflow is not None else None
+        if raw["kind"] == "flash":
+            coords, bsize = _f8(raw["coordinates"]), _f8(raw["block_size"])
+            b = FlashBlocks(coords.shape[0], coords.shape[1], bsize.shape[1], ptr(coords), ptr(bsize), ptr(raw["node_type"], np.int32, C.c_int),
+                            ptr(raw["velx"]), ptr(raw["vely"]), ptr(raw["dens"]), ptr(raw["pres"]),
+                            float(raw.get("l_scale", 1.0)), float(raw.get("d_scale", 1.0)), float(raw.get("p_scale", 1.0)))
+            self._check(self.lib.mcrat_hip_ingest_flash(self.ctx, C.byref(b), C.byref(s), op, C.byref(res)), "ingest_flash")
+        else:
+            g = PlutoGrid()
+            g.nx, g.ny, g.nz = int(raw["nx"]), int(raw["ny"]), int(raw.get("nz", 1))
+            for k in ("x1", "dx1", "x2", "dx2", "x3", "dx3", "rho", "vx1", "vx2", "vx3", "prs"):
+                setattr(g, k, ptr(raw[k]) if raw.get(k) is not None else None)
+            g.l_scale, g.d_scale, g.p_scale = float(raw.get("l_scale", 1.0)), float(raw.get("d_scale", 1.0)), float(raw.get("p_scale", 1.0))
+            self._check(self.lib.mcrat_hip_ingest_pluto(self.ctx, C.byref(g), C.byref(s), op, C.byref(res)), "ingest_pluto")
+        self.num_elements = res.num_elements
+        return res.num_elements, res.elem_factor, res.cells_read
+
+    def get_hydro(self, num_elements=None):
+        """the staged frame's columns (struct hydro_dataframe) as a dict of numpy arrays"""
+        n = int(num_elements if num_elements is not None else self.num_elements)
+        out, cols = HydroColumns(), {}
+        out.num_elements = n
+        for f in HYDRO_COLUMNS:
+            cols[f] = np.empty(n)
+            setattr(out, f, cols[f].ctypes.data_as(_dp))
+        self._check(self.lib.mcrat_hip_get_hydro(self.ctx, C.byref(out)), "get_hydro")
+        cols = {f: a[:out.num_elements] for f, a in cols.items()}
+        cols["num_elements"] = out.num_elements
+        return cols
+
     def set_hydro(self, frame):
+        self.num_elements = int(frame["num_elements"])
         n = int(frame["num_elements"])
         keep, h = [], Hydro()
         h.num_elements = n

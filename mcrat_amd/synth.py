@@ -150,6 +150,88 @@ def uniform_mesh_3d(geometry, lo, hi, n, fps, log_axis0=False):
     return _finish_frame(frame)
 
 
+# --------------------------------------------------------------------------- reader inputs
+def _raw_fluid(x, y, rng, v3=False):
+    """smooth, physical code-unit fluid for reader tests: |v| < 1, positive density and pressure"""
+    rr = np.sqrt(x * x + y * y) + 1e-300
+    speed = 0.2 + 0.75 / (1.0 + (np.arctan2(x, y) / 0.3) ** 2)
+    jitter = 1.0 + 0.01 * rng.standard_normal(x.shape)
+    vx, vy = speed * x / rr * jitter, speed * y / rr
+    out = dict(vx1=vx, vx2=vy, rho=1e-9 * (1.0 + rng.random(x.shape)) / (1.0 + (rr / rr.mean()) ** 2),
+               prs=3e-7 * (1.0 + 0.1 * rng.random(x.shape)) / (1.0 + (rr / rr.mean()) ** 2.5))
+    if v3:
+        out["vx3"] = 0.1 * rng.standard_normal(x.shape) * np.sqrt(np.maximum(1 - vx * vx - vy * vy, 0)) * 0.5
+    return out
+
+
+def flash_raw_blocks(block_side, nxf, nxc, nzc, z_lo, l_scale=1e9, seed=0, parent_every=5):
+    """The datasets of a FLASH checkpoint as readAndDecimate reads them (Src/mclib_flash.c:143-193), in code units
+    (cm / l_scale): the leaf blocks are flash_like_mesh's, in its order; after every `parent_every` leaves comes a
+    parent block (node type 2, overlapping its neighbours, garbage-free but different data) that the reader must
+    skip.  'coordinates' has three doubles per block, 'block size' three (the reader copies it with a stride of two:
+    mclib_flash.c:112,135 -- pass bsize as [n,2] accordingly), the variables are [n_blocks, 1, 8, 8] with x fastest."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for (nx, nz, side, x_lo) in ((nxf, 2 * nzc, block_side, 0.0), (nxc, nzc, 2.0 * block_side, nxf * block_side)):
+        bx = x_lo + side * (np.arange(nx) + 0.5)
+        bz = z_lo + side * (np.arange(nz) + 0.5)
+        BX, BZ = np.meshgrid(bx, bz, indexing="xy")
+        for cx, cz in zip(BX.ravel(), BZ.ravel()):
+            rows.append((cx, cz, side, 1))
+            if parent_every and len([r for r in rows if r[3] == 1]) % parent_every == 0:
+                rows.append((cx + side, cz + side, 2.0 * side, 2))
+    rows = np.array(rows)
+    n = len(rows)
+    coords = np.zeros((n, 3)); coords[:, 0], coords[:, 1] = rows[:, 0] / l_scale, rows[:, 1] / l_scale
+    bsize = np.zeros((n, 2)); bsize[:, 0] = bsize[:, 1] = rows[:, 2] / l_scale
+    off = (np.arange(8) - 3.5) / 8.0
+    x = (coords[:, 0, None, None] + bsize[:, 0, None, None] * off[None, None, :]) * l_scale + 0 * off[None, :, None]
+    y = (coords[:, 1, None, None] + bsize[:, 1, None, None] * off[None, :, None]) * l_scale + 0 * off[None, None, :]
+    f = _raw_fluid(x, y, rng)
+    shape = (n, 1, 8, 8)
+    return dict(kind="flash", coordinates=coords, block_size=bsize, node_type=rows[:, 3].astype(np.int32),
+                velx=f["vx1"].reshape(shape), vely=f["vx2"].reshape(shape), dens=f["rho"].reshape(shape), pres=f["prs"].reshape(shape),
+                l_scale=float(l_scale), d_scale=1.0, p_scale=C_LIGHT ** 2)
+
+
+def pluto_raw_grid(dimensions, geometry, lo, hi, n, l_scale=1e9, seed=0, log_axis0=False):
+    """A PLUTO .dbl frame as readPluto holds it after the file reads (Src/mclib_pluto.c:1085-1128): readGridFile's
+    centre / width arrays per axis (in code units; angles in radians) and the variable blocks [nz][ny][nx].
+    lo / hi / n: per-axis bounds in physical units (cm or rad) and cell counts; axes that are lengths in `geometry` are
+    stored divided by l_scale."""
+    rng = np.random.default_rng(seed)
+    three = dimensions == THREE
+    naxes = 3 if three else 2
+    length = {CARTESIAN: (1, 1, 1), CYLINDRICAL: (1, 1, 1), SPHERICAL: (1, 0, 0), POLAR: (1, 0, 1)}[geometry]
+    cs, ws = [], []
+    for a in range(naxes):
+        edges = np.exp(np.linspace(np.log(lo[a]), np.log(hi[a]), n[a] + 1)) if (a == 0 and log_axis0) else np.linspace(lo[a], hi[a], n[a] + 1)
+        if length[a]:
+            edges = edges / l_scale
+        cs.append(0.5 * (edges[:-1] + edges[1:]))
+        ws.append(edges[1:] - edges[:-1])
+    nx, ny, nz = n[0], n[1], (n[2] if three else 1)
+    phys = [cs[a] * (l_scale if length[a] else 1.0) for a in range(naxes)]
+    if three:
+        X3, X2, X1 = np.meshgrid(phys[2], phys[1], phys[0], indexing="ij")
+    else:
+        X2, X1 = np.meshgrid(phys[1], phys[0], indexing="ij")
+        X2, X1 = X2[None], X1[None]
+    # an (x, y) pair in the meridional plane for the smooth test fluid
+    if geometry == SPHERICAL:
+        px, py = X1 * np.sin(X2), X1 * np.cos(X2)
+    elif geometry == POLAR:
+        px, py = X1, X3
+    else:
+        px, py = X1, (X3 if (three and geometry == CARTESIAN) else X2)
+    f = _raw_fluid(px, py, rng, v3=dimensions != TWO)
+    raw = dict(kind="pluto", nx=nx, ny=ny, nz=nz, x1=cs[0], dx1=ws[0], x2=cs[1], dx2=ws[1],
+               x3=cs[2] if three else None, dx3=ws[2] if three else None,
+               rho=f["rho"], vx1=f["vx1"], vx2=f["vx2"], vx3=f.get("vx3"), prs=f["prs"],
+               l_scale=float(l_scale), d_scale=1.0, p_scale=C_LIGHT ** 2)
+    return raw
+
+
 # --------------------------------------------------------------------------- fluids
 def _radial_velocity(frame, vel):
     dims, geom = frame["dimensions"], frame["geometry"]

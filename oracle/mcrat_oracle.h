@@ -183,6 +183,60 @@ void   orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro 
                        double *time_now, double *remaining_time, int *find_nearest_grid_switch,
                        long long max_iterations, uint64_t iteration_base, orc_stats *st);
 
+/* ---- hydro ingest (oracle_ingest.c) ---------------------- */
+/* every column of struct hydro_dataframe (Src/mcrat.h:194-244) a thermal build fills; malloc'ed, orc_frame_free() */
+typedef struct orc_frame {
+    int num_elements;
+    double *r0, *r1, *r2, *r0_size, *r1_size, *r2_size;
+    double *v0, *v1, *v2;
+    double *dens, *dens_lab, *pres, *temp, *gamma;
+    double *r, *theta;
+} orc_frame;
+/* the arguments of getHydroData that select the slab (mcrat_io.h:26) + hydro_data->fps */
+typedef struct orc_slab {
+    double r_inj;
+    int    ph_inj_switch;
+    double min_r, max_r, min_theta, max_theta;
+    double fps;
+} orc_slab;
+/* a FLASH checkpoint's datasets as H5Dread leaves them (mclib_flash.c:143-193) */
+typedef struct orc_flash_blocks {
+    int n_blocks, coord_stride, bsize_stride;
+    const double *coordinates, *block_size;
+    const int *node_type;
+    const double *velx, *vely, *dens, *pres;     /* [n_blocks][1][8][8] */
+    double l_scale, d_scale, p_scale;            /* HYDRO_L_SCALE, HYDRO_D_SCALE, HYDRO_P_SCALE */
+    int cyclosynchrotron;                        /* CYCLOSYNCHROTRON_SWITCH: elem_factor starts at 2 */
+} orc_flash_blocks;
+/* a PLUTO .dbl frame: readGridFile's arrays and the variable blocks (mclib_pluto.c:1085-1128) */
+typedef struct orc_pluto_grid {
+    int nx, ny, nz;
+    const double *x1, *dx1, *x2, *dx2, *x3, *dx3;
+    const double *rho, *vx1, *vx2, *vx3, *prs;   /* [nz][ny][nx] */
+    double l_scale, d_scale, p_scale;
+    int cyclosynchrotron;
+} orc_pluto_grid;
+#define ORC_SCIENCE                       0
+#define ORC_CYLINDRICAL_OUTFLOW           1
+#define ORC_SPHERICAL_OUTFLOW             2
+#define ORC_STRUCTURED_SPHERICAL_OUTFLOW  3
+typedef struct orc_outflow {
+    int simulation_type;
+    double gamma_infinity;      /* gamma_0 of the structured fireball */
+    double lumi, r00;
+    double t_comov, ddensity;   /* cylindrical outflow */
+    double theta_j, p;          /* structured fireball */
+} orc_outflow;
+int  orc_flash_select(const orc_config *c, const orc_flash_blocks *b, const orc_slab *s, int max_elem_factor, orc_frame *out, int *elem_factor_out);
+int  orc_pluto_select(const orc_config *c, const orc_pluto_grid *g, const orc_slab *s, int max_elem_factor, orc_frame *out, int *elem_factor_out);
+void orc_frame_free(orc_frame *f);
+void orc_fillHydroCoordinateToSpherical(const orc_config *c, orc_frame *f);      /* geometry.c:156 */
+void orc_outflow_defaults(int simulation_type, orc_outflow *o);
+void orc_cylindricalPrep(const orc_config *c, const orc_outflow *o, orc_frame *f);        /* analytic_outflows.c:3 */
+void orc_sphericalPrep(const orc_config *c, const orc_outflow *o, orc_frame *f);          /* analytic_outflows.c:63 */
+void orc_structuredFireballPrep(const orc_config *c, const orc_outflow *o, orc_frame *f); /* analytic_outflows.c:138 */
+void orc_hydro_post_read(const orc_config *c, const orc_outflow *o, orc_frame *f);        /* mcrat_io.c:1962-1975 */
+
 /* helpers for ctypes */
 int    orc_sizeof_photon(void);
 

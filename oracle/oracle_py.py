@@ -69,10 +69,40 @@ class Stats(C.Structure):
                 ("remaining_time", C.c_double), ("time_now", C.c_double), ("table_misses", C.c_longlong)]
 
 
+FRAME_FIELDS = ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size", "v0", "v1", "v2", "dens", "dens_lab", "pres", "temp", "gamma", "r", "theta")
+
+
+class Frame(C.Structure):
+    _fields_ = [("num_elements", C.c_int)] + [(f, C.POINTER(C.c_double)) for f in FRAME_FIELDS]
+
+
+class Slab(C.Structure):
+    _fields_ = [("r_inj", C.c_double), ("ph_inj_switch", C.c_int), ("min_r", C.c_double), ("max_r", C.c_double),
+                ("min_theta", C.c_double), ("max_theta", C.c_double), ("fps", C.c_double)]
+
+
+class FlashBlocks(C.Structure):
+    _fields_ = [("n_blocks", C.c_int), ("coord_stride", C.c_int), ("bsize_stride", C.c_int),
+                ("coordinates", C.POINTER(C.c_double)), ("block_size", C.POINTER(C.c_double)), ("node_type", C.POINTER(C.c_int)),
+                ("velx", C.POINTER(C.c_double)), ("vely", C.POINTER(C.c_double)), ("dens", C.POINTER(C.c_double)), ("pres", C.POINTER(C.c_double)),
+                ("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double), ("cyclosynchrotron", C.c_int)]
+
+
+class PlutoGrid(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int)] + \
+               [(f, C.POINTER(C.c_double)) for f in ("x1", "dx1", "x2", "dx2", "x3", "dx3", "rho", "vx1", "vx2", "vx3", "prs")] + \
+               [("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double), ("cyclosynchrotron", C.c_int)]
+
+
+class Outflow(C.Structure):
+    _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
+                ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
+
+
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("mcrat_oracle.c", "mcrat_oracle.h", "oracle_rng.c", "oracle_rng.h")):
+            for f in ("mcrat_oracle.c", "oracle_ingest.c", "mcrat_oracle.h", "oracle_rng.c", "oracle_rng.h")):
         subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
     return _LIB_PATH
 
@@ -134,6 +164,11 @@ def lib():
             "orc_phScattStats": (None, [lp, C.POINTER(i), C.POINTER(i), _dp, _dp]),
             "orc_phMinMax": (None, [lp, _dp, _dp, _dp, _dp]),
             "orc_photon_loop": (None, [cfgp, lp, hp, rp, _dp, _dp, C.POINTER(i), C.c_longlong, C.c_uint64, sp]),
+            "orc_flash_select": (i, [cfgp, C.POINTER(FlashBlocks), C.POINTER(Slab), i, C.POINTER(Frame), C.POINTER(i)]),
+            "orc_pluto_select": (i, [cfgp, C.POINTER(PlutoGrid), C.POINTER(Slab), i, C.POINTER(Frame), C.POINTER(i)]),
+            "orc_frame_free": (None, [C.POINTER(Frame)]),
+            "orc_outflow_defaults": (None, [i, C.POINTER(Outflow)]),
+            "orc_hydro_post_read": (None, [cfgp, C.POINTER(Outflow), C.POINTER(Frame)]),
             "orc_sizeof_photon": (i, []),
         }
         for name, (res, args) in sig.items():
@@ -233,3 +268,62 @@ def photon_loop(cfg, photons, hydro, seed, time_now, remaining_time, max_iterati
     L.orc_photon_loop(C.byref(cfg), C.byref(photons.c), C.byref(hydro.c), C.byref(rng),
                       C.byref(tn), C.byref(rem), C.byref(sw), int(max_iterations), int(iteration_base), C.byref(st))
     return st, tn.value, rem.value, sw.value
+
+
+# ---------------------------------------------------------------------------------------------- hydro ingest (oracle_ingest.c)
+def _fill(struct, arrays, keep):
+    for k, a in arrays.items():
+        ctype = C.c_int if k == "node_type" else C.c_double
+        arr = np.ascontiguousarray(a, dtype=np.int32 if k == "node_type" else np.float64)
+        keep.append(arr)
+        setattr(struct, k, arr.ctypes.data_as(C.POINTER(ctype)))
+
+
+def outflow(simulation_type, **overrides):
+    """the reference's hard-coded constants (analytic_outflows.c:5,65,140), optionally overridden"""
+    o = Outflow()
+    lib().orc_outflow_defaults(int(simulation_type), C.byref(o))
+    for k, v in overrides.items():
+        setattr(o, k, float(v))
+    return o
+
+
+def hydro_ingest(cfg, raw, slab, outflow_params=None, max_elem_factor=1000):
+    """getHydroData (mcrat_io.c:1898-1990) on buffers instead of files: the reader's expansion, slab selection and derived
+    columns, fillHydroCoordinateToSpherical and the analytic-outflow overwrite.  `raw` is a dict: kind "flash"
+    (coordinates, block_size, node_type, velx, vely, dens, pres) or "pluto" (nx, ny, nz, x1..dx3, rho, vx1, vx2, vx3, prs),
+    plus l_scale, d_scale, p_scale.  `slab`: r_inj, ph_inj_switch, min_r, max_r, min_theta, max_theta, fps.
+    -> (dict of numpy columns, elem_factor)"""
+    L = lib()
+    keep = []
+    s = Slab(float(slab["r_inj"]), int(slab["ph_inj_switch"]), float(slab["min_r"]), float(slab["max_r"]),
+             float(slab["min_theta"]), float(slab["max_theta"]), float(slab["fps"]))
+    out, ef = Frame(), C.c_int(0)
+    scales = dict(l_scale=float(raw.get("l_scale", 1.0)), d_scale=float(raw.get("d_scale", 1.0)), p_scale=float(raw.get("p_scale", 1.0)))
+    if raw["kind"] == "flash":
+        coords = np.ascontiguousarray(raw["coordinates"], dtype=np.float64)
+        bsize = np.ascontiguousarray(raw["block_size"], dtype=np.float64)
+        b = FlashBlocks()
+        b.n_blocks, b.coord_stride, b.bsize_stride = coords.shape[0], coords.shape[1], bsize.shape[1]
+        _fill(b, dict(coordinates=coords, block_size=bsize, node_type=raw["node_type"], velx=raw["velx"], vely=raw["vely"],
+                      dens=raw["dens"], pres=raw["pres"]), keep)
+        b.l_scale, b.d_scale, b.p_scale = scales["l_scale"], scales["d_scale"], scales["p_scale"]
+        b.cyclosynchrotron = int(raw.get("cyclosynchrotron", 0))
+        rc = L.orc_flash_select(C.byref(cfg), C.byref(b), C.byref(s), int(max_elem_factor), C.byref(out), C.byref(ef))
+    else:
+        g = PlutoGrid()
+        g.nx, g.ny, g.nz = int(raw["nx"]), int(raw["ny"]), int(raw.get("nz", 1))
+        zeros = np.zeros(1)
+        _fill(g, {k: (raw[k] if raw.get(k) is not None else zeros) for k in ("x1", "dx1", "x2", "dx2", "x3", "dx3", "rho", "vx1", "vx2", "vx3", "prs")}, keep)
+        g.l_scale, g.d_scale, g.p_scale = scales["l_scale"], scales["d_scale"], scales["p_scale"]
+        g.cyclosynchrotron = int(raw.get("cyclosynchrotron", 0))
+        rc = L.orc_pluto_select(C.byref(cfg), C.byref(g), C.byref(s), int(max_elem_factor), C.byref(out), C.byref(ef))
+    if rc != 0:
+        L.orc_frame_free(C.byref(out))
+        raise RuntimeError("no cell selected up to elem_factor %d" % max_elem_factor)
+    L.orc_hydro_post_read(C.byref(cfg), C.byref(outflow_params) if outflow_params is not None else None, C.byref(out))
+    n = out.num_elements
+    cols = {f: np.ctypeslib.as_array(getattr(out, f), shape=(n,)).copy() for f in FRAME_FIELDS}
+    cols["num_elements"] = n
+    L.orc_frame_free(C.byref(out))
+    return cols, ef.value

@@ -1,0 +1,201 @@
+"""GPU parity of the hydro ingest (include/mcrat_hip.h mcrat_hip_ingest_*): getHydroData on the device
+against the oracle's restatement of readAndDecimate / readPluto + fillHydroCoordinateToSpherical + the analytic
+outflows (oracle/oracle_ingest.c), on the same reader buffers.
+
+Bar: the integers (number of selected cells, elem_factor, and with them WHICH cells and in which order) exact; columns
+that are copies, products, quotients and square roots of the inputs bit-identical (IEEE, -ffp-contract=off on both
+sides); columns that go through pow / atan2 / acos / sin / cos to 1e-13 relative (libm vs the device's last ulp).
+"""
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+EXACT = ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size", "v0", "v1", "v2", "dens", "pres", "gamma", "dens_lab")
+LIBM = ("temp", "r", "theta")
+ALL = EXACT + LIBM
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mcrat_amd import engine
+    engine.load_library()
+    return engine
+
+
+def _close(a, b, name, rtol=1e-13):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, name
+    scale = np.maximum(np.abs(b), 1e-300)
+    bad = ~((np.abs(a - b) <= rtol * scale) | ((a != a) & (b != b)))
+    assert not bad.any(), (name, int(bad.sum()), a[bad][:3], b[bad][:3])
+
+
+def _compare(got, ref, exact=EXACT, libm=LIBM):
+    assert got["num_elements"] == ref["num_elements"]
+    for k in exact:
+        assert np.array_equal(got[k], ref[k], equal_nan=True), (k, np.flatnonzero(got[k] != ref[k])[:5])
+    for k in libm:
+        _close(got[k], ref[k], k)
+
+
+def _small_flash(seed=3):
+    side = 2.5e8 * 8
+    return synth.flash_raw_blocks(side, 8, 16, 8, 1e12 - 8 * side, seed=seed)
+
+
+DOMAINS = dict(r0_domain=(0.0, 5e12), r1_domain=(0.0, 2.5e13), r2_domain=(0.0, 0.0))
+
+
+def _ingest_both(hip, oracle, dims, geom, raw, slab, outflow_type=None, **overrides):
+    cfg = oracle.make_config(dims, geom, 0)
+    ref, ef_ref = oracle.hydro_ingest(cfg, raw, slab, oracle.outflow(outflow_type, **overrides) if outflow_type else None)
+    e = hip.Engine(dims, geom, 0)
+    n, ef, cells = e.ingest(raw, dict(slab, **DOMAINS), hip.Engine.outflow(outflow_type, **overrides) if outflow_type else None)
+    got = e.get_hydro()
+    assert (n, ef) == (ref["num_elements"], ef_ref)
+    return e, got, ref, cells
+
+
+@pytest.mark.parametrize("switch", [0, 1])
+def test_flash_selection_matches_the_reader(hip, oracle, switch):
+    raw = _small_flash()
+    # the small mesh starts at 0.984e12 cm: an injection radius whose 0.95 r_inj cut passes through it
+    slab = dict(r_inj=1.045e12 if switch else 1e12, ph_inj_switch=switch, min_r=0.995e12, max_r=1.002e12, min_theta=0.0, max_theta=0.04, fps=5.0)
+    e, got, ref, cells = _ingest_both(hip, oracle, synth.TWO, synth.CYLINDRICAL, raw, slab)
+    assert cells == 64 * int((raw["node_type"] == 1).sum())
+    assert 0 < got["num_elements"] < cells                 # a real selection, and parent blocks skipped
+    _compare(got, ref)
+    e.close()
+
+
+def test_flash_elem_factor_grows_until_a_cell_is_selected_and_gives_up_like_no_reader_would(hip, oracle):
+    raw = _small_flash()
+    top = 1e12 + 8 * 2.5e8 * 8                              # the mesh ends here in z
+    gap = 2.4 * synth.C_LIGHT / 5.0
+    slab = dict(r_inj=1e12, ph_inj_switch=0, min_r=top + gap, max_r=top + gap + 1e9, min_theta=0.0, max_theta=0.02, fps=5.0)
+    e, got, ref, _ = _ingest_both(hip, oracle, synth.TWO, synth.CYLINDRICAL, raw, slab)
+    cfg = oracle.make_config(synth.TWO, synth.CYLINDRICAL, 0)
+    assert oracle.hydro_ingest(cfg, raw, slab)[1] == 3     # 1 and 2 light-frames of margin do not reach the mesh
+    _compare(got, ref)
+    # a slab no cell can reach in angle: the reference would loop forever; the engine reports it
+    bad = dict(slab, min_theta=2.5, max_theta=2.6, **DOMAINS)
+    with pytest.raises(hip.McratHipError):
+        e.ingest(raw, bad)
+    with pytest.raises(RuntimeError):
+        oracle.hydro_ingest(cfg, raw, dict(slab, min_theta=2.5, max_theta=2.6), max_elem_factor=50)
+    e.close()
+
+
+@pytest.mark.parametrize("case", ["2d-spherical", "2d-cylindrical", "25d-spherical", "3d-spherical", "3d-cartesian", "3d-polar"])
+@pytest.mark.parametrize("switch", [0, 1])
+def test_pluto_selection_matches_the_reader(hip, oracle, case, switch):
+    S, C, P = synth.SPHERICAL, synth.CARTESIAN, synth.POLAR
+    dims, geom, lo, hi, n, log0 = {
+        "2d-spherical": (synth.TWO, S, (1e11, 0.0), (4e12, 0.6), (96, 40), True),
+        "2d-cylindrical": (synth.TWO, synth.CYLINDRICAL, (0.0, 8e11), (3e11, 1.3e12), (48, 80), False),
+        "25d-spherical": (synth.TWO_POINT_FIVE, S, (1e11, 0.0), (4e12, 0.6), (64, 32), True),
+        "3d-spherical": (synth.THREE, S, (2e11, 0.0, 0.0), (3e12, 0.5, 2 * np.pi), (40, 16, 12), True),
+        "3d-cartesian": (synth.THREE, C, (-3e11, -3e11, 8e11), (3e11, 3e11, 1.3e12), (20, 20, 24), False),
+        "3d-polar": (synth.THREE, P, (1e9, 0.0, 8e11), (3e11, 2 * np.pi, 1.3e12), (20, 12, 24), False),
+    }[case]
+    raw = synth.pluto_raw_grid(dims, geom, lo, hi, n, seed=11, log_axis0=log0)
+    slab = dict(r_inj=1e12, ph_inj_switch=switch, min_r=0.97e12, max_r=1.01e12, min_theta=0.01, max_theta=0.12, fps=5.0)
+    e, got, ref, cells = _ingest_both(hip, oracle, dims, geom, raw, slab)
+    assert cells == int(np.prod(n))
+    assert 0 < got["num_elements"] < cells
+    _compare(got, ref)
+    e.close()
+
+
+@pytest.mark.parametrize("outflow", [1, 2, 3])
+@pytest.mark.parametrize("mesh", ["flash", "pluto-2d-spherical", "pluto-3d-cartesian", "pluto-3d-polar"])
+def test_analytic_outflows_overwrite_the_selected_frame(hip, oracle, outflow, mesh):
+    """SIMULATION_TYPE != SCIENCE (analytic_outflows.c): every fluid column is an analytic function of the selected cells'
+    positions; the constants are the reference's, except a jet wide enough to vary over the test mesh"""
+    over = dict(theta_j=0.05, lumi=3e50) if outflow == 3 else {}
+    slab = dict(r_inj=1e12, ph_inj_switch=0, min_r=0.99e12, max_r=1.005e12, min_theta=0.0, max_theta=0.1, fps=5.0)
+    if mesh == "flash":
+        dims, geom, raw = synth.TWO, synth.CYLINDRICAL, _small_flash(5)
+    elif mesh == "pluto-2d-spherical":
+        dims, geom = synth.TWO, synth.SPHERICAL
+        raw = synth.pluto_raw_grid(dims, geom, (1e11, 0.0), (4e12, 0.6), (96, 40), seed=2, log_axis0=True)
+    elif mesh == "pluto-3d-cartesian":
+        dims, geom = synth.THREE, synth.CARTESIAN
+        raw = synth.pluto_raw_grid(dims, geom, (-3e11, -3e11, 8e11), (3e11, 3e11, 1.3e12), (20, 20, 24), seed=2)
+    else:
+        dims, geom = synth.THREE, synth.POLAR
+        raw = synth.pluto_raw_grid(dims, geom, (1e9, 0.0, 8e11), (3e11, 2 * np.pi, 1.3e12), (20, 12, 24), seed=2)
+    e, got, ref, _ = _ingest_both(hip, oracle, dims, geom, raw, slab, outflow, **over)
+    geometry = ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size")
+    _compare(got, ref, exact=geometry, libm=tuple(k for k in ALL if k not in geometry))
+    assert np.isfinite(got["gamma"]).all() and (got["gamma"] >= 1).all()
+    if outflow == 1:
+        assert (got["temp"] == 1e5).all() and (got["gamma"] == 100).all()
+    e.close()
+
+
+def test_ingested_frame_drives_the_loop_like_a_frame_set_from_the_host(hip, oracle):
+    """ingest -> inject -> propagate on one context equals set_hydro(the same columns) -> the same photons -> propagate
+    on another, bit for bit; and the oracle's loop on the oracle's selection of the same buffers agrees to 1e-9."""
+    raw = _small_flash(8)
+    slab = dict(r_inj=1e12, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0)
+    over = dict(lumi=1e53, theta_j=0.1)                   # dense enough for a few hundred scatterings in 400 passes
+    a = hip.Engine(synth.TWO, synth.CYLINDRICAL, 0)
+    a.ingest(raw, dict(slab, **DOMAINS), hip.Engine.outflow(3, **over))
+    cols = a.get_hydro()
+    n, w = a.inject_photons(1e12, 1e50, 1500, 3000, "b", 0.0, 0.05, 5.0, seed=77)
+    injected = a.get_photons()
+    a.begin_frame(5, 0.0, 0.2)
+    st_a = a.run(400)
+    out_a = a.get_photons()
+
+    frame = dict(cols, dimensions=synth.TWO, geometry=synth.CYLINDRICAL, fps=5.0, **DOMAINS)
+    b = hip.Engine(synth.TWO, synth.CYLINDRICAL, 0)
+    b.set_hydro(frame)
+    b.set_photons(injected)
+    b.begin_frame(5, 0.0, 0.2)
+    st_b = b.run(400)
+    out_b = b.get_photons()
+    assert (st_a.iterations, st_a.frame_scatt_cnt, st_a.num_photons_find_new_element) == (st_b.iterations, st_b.frame_scatt_cnt, st_b.num_photons_find_new_element)
+    assert st_a.frame_scatt_cnt > 50
+    for k in out_a:
+        x, y = np.asarray(out_a[k]), np.asarray(out_b[k])
+        assert np.array_equal(x, y, equal_nan=x.dtype.kind == "f"), k
+
+    cfg = oracle.make_config(synth.TWO, synth.CYLINDRICAL, 0)
+    ref, _ = oracle.hydro_ingest(cfg, raw, slab, oracle.outflow(3, **over))
+    H = oracle.OracleHydro(dict(ref, **DOMAINS, fps=5.0))
+    P = oracle.OraclePhotons(synth.photons_to_aos(injected, oracle.PHOTON_DTYPE))
+    st, _, _, _ = oracle.photon_loop(cfg, P, H, seed=5, time_now=0.0, remaining_time=0.2, max_iterations=400)
+    assert (st.iterations, st.frame_scatt_cnt) == (st_a.iterations, st_a.frame_scatt_cnt)
+    assert np.array_equal(P.aos["nearest_block_index"], np.asarray(out_a["nearest_block_index"]))
+    assert np.array_equal(P.aos["num_scatt"], np.asarray(out_a["num_scatt"]))
+    for k in ("r0", "r1", "r2", "p0"):
+        _close(np.asarray(out_a[k]), P.aos[k], k, rtol=1e-9)
+    a.close()
+    b.close()
+
+
+def test_full_size_flash_frame(hip, oracle):
+    """BASELINE's cfg2 mesh as a FLASH checkpoint: 16 384 leaf blocks (+ parents) = 1 048 576 cells, the photons' slab
+    selected and overwritten with the structured jet; against the oracle (linear in the cells: a second on the CPU)."""
+    side = 2.5e8
+    raw = synth.flash_raw_blocks(side, 64, 128, 64, 1e12 - 64 * side, seed=1)
+    assert int((raw["node_type"] == 1).sum()) == 16384
+    slab = dict(r_inj=1e12, ph_inj_switch=0, min_r=0.9985e12, max_r=1.0015e12, min_theta=0.0, max_theta=0.052, fps=5.0)
+    over = dict(lumi=3e50, theta_j=0.1)
+    e, got, ref, cells = _ingest_both(hip, oracle, synth.TWO, synth.CYLINDRICAL, raw, slab, 3, **over)
+    assert cells == 1048576 and 10000 < got["num_elements"] < cells
+    geometry = ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size")
+    _compare(got, ref, exact=geometry, libm=tuple(k for k in ALL if k not in geometry))
+    # the staged frame answers cell look-ups like the reference's linear search over the selected cells
+    rng = np.random.default_rng(0)
+    pick = rng.integers(0, got["num_elements"], 2000)
+    x = got["r0"][pick] + (rng.random(2000) - 0.5) * 0.9 * got["r0_size"][pick]
+    z = got["r1"][pick] + (rng.random(2000) - 0.5) * 0.9 * got["r1_size"][pick]
+    idx = e.lookup_cell(x, z)                              # hydro coordinates (r, z)
+    assert np.array_equal(idx, pick)
+    e.close()
