@@ -138,6 +138,130 @@ int mcrat_host_read_hot_cross_section(const char *path, double *table, int n_ph_
     return rc;
 }
 
+/* ---- PLUTO .dbl frames (mclib_pluto.c:803-1128) ---------------------------------------------------------- */
+void mcrat_host_pluto_name(char *out, size_t n, const char *prefix, int frame)
+{
+    snprintf(out, n, "%s%04d.dbl", prefix, frame);      /* "%s%.3d%d%s" with 000 / "%.2d%d" with 00 / ... (:829-844) */
+}
+
+void mcrat_host_free_pluto(mcrat_host_pluto *p)
+{
+    if (!p) return;
+    for (int i = 0; p->var_names && i < p->num_vars; i++) free(p->var_names[i]);
+    free(p->var_names);
+    free(p->axes);
+    free(p->data);
+    memset(p, 0, sizeof *p);
+}
+
+/* "# X1: [ 1.0,  100.0], 1024 point(s), 0 ghosts": the third comma-separated field starts with the count (:880-895) */
+static int header_count(const char *line)
+{
+    const char *c1 = strchr(line, ','), *c2 = c1 ? strchr(c1 + 1, ',') : NULL;
+    if (!c2) return -1;
+    char *end;
+    long v = strtol(c2 + 1, &end, 10);
+    return (end == c2 + 1 || v <= 0 || v > 0x7fffffffL) ? -1 : (int)v;
+}
+
+int mcrat_host_read_pluto(const char *grid_out, const char *dbl_out, const char *dbl_file, int three_dimensional,
+                          double l_scale, double d_scale, double p_scale, mcrat_host_pluto *out)
+{
+    if (!grid_out || !dbl_out || !dbl_file || !out) return -2;
+    memset(out, 0, sizeof *out);
+    char line[2000];
+    int n[3] = {0, 0, 1}, naxes = three_dimensional ? 3 : 2, rc = -2;
+
+    /* grid.out: the header */
+    FILE *f = fopen(grid_out, "r");
+    if (!f) return -1;
+    long data_pos = 0;
+    for (;;) {
+        data_pos = ftell(f);
+        if (!fgets(line, sizeof line, f)) { fclose(f); return -2; }
+        if (line[0] != '#') break;
+        for (int a = 0; a < naxes; a++) {
+            char tag[8];
+            snprintf(tag, sizeof tag, "X%d:", a + 1);
+            if (strstr(line, tag)) n[a] = header_count(line);
+        }
+    }
+    for (int a = 0; a < naxes; a++)
+        if (n[a] <= 0) { fclose(f); return -2; }
+    const size_t total_axes = 2 * ((size_t)n[0] + (size_t)n[1] + (size_t)n[2]);
+    out->axes = (double *)calloc(total_axes, sizeof(double));
+    if (!out->axes) { fclose(f); return -2; }
+    double *centre[3], *width[3], *p = out->axes;
+    for (int a = 0; a < 3; a++) { centre[a] = p; p += n[a]; width[a] = p; p += n[a]; }
+    /* per axis: a count line, then rows "index left right" (:935-971) */
+    fseek(f, data_pos, SEEK_SET);
+    for (int a = 0; a < naxes; a++) {
+        int count = 0, idx;
+        double left, right;
+        if (fscanf(f, "%d", &count) != 1 || count != n[a]) goto done_grid;
+        for (int i = 0; i < n[a]; i++) {
+            if (fscanf(f, "%d %lf %lf", &idx, &left, &right) != 3) goto done_grid;
+            centre[a][i] = 0.5 * (left + right);
+            width[a][i] = (right - left);
+        }
+    }
+    rc = 0;
+done_grid:
+    fclose(f);
+    if (rc) { mcrat_host_free_pluto(out); return -2; }
+    rc = -2;
+
+    /* dbl.out: "0 0.000000e+00 1.000000e-04 0 single_file little rho vx1 vx2 prs" (:1003-1050) */
+    f = fopen(dbl_out, "r");
+    if (!f) { mcrat_host_free_pluto(out); return -1; }
+    if (!fgets(line, sizeof line, f)) { fclose(f); mcrat_host_free_pluto(out); return -2; }
+    fclose(f);
+    {
+        char *save = NULL, *tok = strtok_r(line, " \t\r\n", &save);
+        int field = 0, cap = 16;
+        out->var_names = (char **)calloc((size_t)cap, sizeof(char *));
+        for (; tok && out->var_names; tok = strtok_r(NULL, " \t\r\n", &save), field++) {
+            if (field < 6) continue;                    /* index, time, dt, step, file layout, endianness */
+            if (out->num_vars == cap) {
+                cap *= 2;
+                char **grown = (char **)realloc(out->var_names, (size_t)cap * sizeof(char *));
+                if (!grown) break;
+                out->var_names = grown;
+            }
+            out->var_names[out->num_vars] = strdup(tok);
+            out->num_vars++;
+        }
+        if (!out->var_names || out->num_vars == 0) { mcrat_host_free_pluto(out); return -2; }
+    }
+
+    /* the frame: num_vars blocks of grid_size doubles (:1116-1128) */
+    const size_t grid_size = (size_t)n[0] * (size_t)n[1] * (size_t)n[2];
+    out->data = (double *)malloc(sizeof(double) * grid_size * (size_t)out->num_vars);
+    if (!out->data) { mcrat_host_free_pluto(out); return -2; }
+    f = fopen(dbl_file, "rb");
+    if (!f) { mcrat_host_free_pluto(out); return -1; }
+    const size_t got = fread(out->data, sizeof(double), grid_size * (size_t)out->num_vars, f);
+    fclose(f);
+    if (got != grid_size * (size_t)out->num_vars) { mcrat_host_free_pluto(out); return -2; }
+
+    mcrat_hip_pluto_grid *g = &out->grid;
+    g->nx = n[0]; g->ny = n[1]; g->nz = n[2];
+    g->x1 = centre[0]; g->dx1 = width[0]; g->x2 = centre[1]; g->dx2 = width[1];
+    g->x3 = three_dimensional ? centre[2] : NULL; g->dx3 = three_dimensional ? width[2] : NULL;
+    g->l_scale = l_scale; g->d_scale = d_scale; g->p_scale = p_scale;
+    for (int v = 0; v < out->num_vars; v++) {           /* :1147-1212 */
+        const double *block = out->data + (size_t)v * grid_size;
+        const char *name = out->var_names[v];
+        if (strcmp(name, "rho") == 0) g->rho = block;
+        else if (strcmp(name, "vx1") == 0) g->vx1 = block;
+        else if (strcmp(name, "vx2") == 0) g->vx2 = block;
+        else if (strcmp(name, "vx3") == 0) g->vx3 = block;
+        else if (strcmp(name, "prs") == 0) g->prs = block;
+    }
+    if (!g->rho || !g->vx1 || !g->vx2 || !g->prs) { mcrat_host_free_pluto(out); return -2; }
+    return 0;
+}
+
 int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, const mcrat_hip_hydro *hydro,
                              double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
                              uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats)

@@ -8,7 +8,8 @@
  *     lines of :883-890, byte for byte in the reference's format;
  *   - mcrat_host_read_mcpar(): the positional mc.par grammar of readMcPar (Src/mcrat_io.c:1136-1237), so the
  *     run-size surface stays compatible (fps, last frame, domains, angle bins, spectrum, photon counts, i/c);
- *   - mcrat_host_read_hot_cross_section(): the thermal cross-section table file of TAU_CALCULATION == TABLE builds.
+ *   - mcrat_host_read_hot_cross_section(): the thermal cross-section table file of TAU_CALCULATION == TABLE builds;
+ *   - mcrat_host_read_pluto(): PLUTO's grid.out / dbl.out / .dbl files into the buffers mcrat_hip_ingest_pluto takes.
  * It links against libmcrat_hip.so only; nothing here computes photon physics on the CPU.
  */
 #ifndef MCRAT_HIP_HOST_H
@@ -47,6 +48,28 @@ void mcrat_host_free_mcpar(mcrat_host_mcpar *p);
  * 0 on success, -1 if the file cannot be opened, -2 on a malformed or incomplete file or an index outside the bounds
  * (the reference exits with "The bounds of the input file exceed what MCRaT has been compiled with"). */
 int mcrat_host_read_hot_cross_section(const char *path, double *table, int n_ph_e, int n_t);
+
+/* A PLUTO .dbl frame from disk: what readPluto holds after readGridFile, readDblOutFile and its fread
+ * (Src/mclib_pluto.c:852-1128), ready for mcrat_hip_ingest_pluto.
+ *   grid_out   PLUTO's grid.out: '#' header whose "# X1: [ a, b], N point(s), ..." lines carry the cell counts, then per
+ *              axis a count line and N rows "index left right"; centre = (left+right)/2, width = right-left (:951-971)
+ *   dbl_out    PLUTO's dbl.out: its first line ends with the variable names in file order (:990-1056)
+ *   dbl_file   the frame, num_vars blocks of nx*ny*nz doubles (single_file layout; mcrat_host_pluto_name builds the name)
+ *   three_dimensional   DIMENSIONS == THREE: read the X3 axis (otherwise nz = 1)
+ * The variables are picked by name (rho, vx1, vx2, vx3, prs; :1147-1212); grid.rho etc. point into `data`.
+ * 0 on success, -1 if a file cannot be opened, -2 on a malformed file, a short .dbl file or a missing variable. */
+typedef struct mcrat_host_pluto {
+    mcrat_hip_pluto_grid grid;
+    int     num_vars;
+    char  **var_names;       /* [num_vars] */
+    double *axes;            /* the six 1-D arrays grid.x1 ... grid.dx3 point into */
+    double *data;            /* [num_vars][nz][ny][nx], the file as read */
+} mcrat_host_pluto;
+int  mcrat_host_read_pluto(const char *grid_out, const char *dbl_out, const char *dbl_file, int three_dimensional,
+                           double l_scale, double d_scale, double p_scale, mcrat_host_pluto *out);
+void mcrat_host_free_pluto(mcrat_host_pluto *p);
+/* modifyPlutoName (mclib_pluto.c:803-850): prefix + frame zero-padded to four digits + ".dbl" */
+void mcrat_host_pluto_name(char *out, size_t n, const char *prefix, int frame);
 
 /* One scatter frame on the device (replaces Src/mcrat.c:754-892 between getHydroData and saveCheckpoint).
  *   list       caller-owned photon list; uploaded, propagated, downloaded in place
