@@ -239,6 +239,28 @@ typedef struct mcrat_hip_hydro_columns {
 } mcrat_hip_hydro_columns;
 int mcrat_hip_get_hydro(mcrat_hip_ctx *ctx, mcrat_hip_hydro_columns *out);
 
+/* The consumers after a frame: what printPhotons and saveCheckpoint read from the photon list.
+ *   mcrat_hip_get_output         printPhotons' gathering loop (mcrat_io.c:137-181): the photons with weight != 0, in slot
+ *                                order, as the arrays it hands to H5Dwrite (datasets P0-3, COMV_P0-3, R0-2, S0-3, NS, PW, PT),
+ *                                compacted on the device.  count: in, capacity of the arrays; out, photons written.  With
+ *                                every pointer NULL the call only reports the count (MCRAT_HIP_EINVAL + the needed count if
+ *                                the capacity is too small).  NULL columns are skipped (COMV_SWITCH / STOKES_SWITCH / SAVE_TYPE
+ *                                OFF builds).  The reference holds these arrays on the stack (mcrat_io.c:123-124).
+ *   mcrat_hip_get_photons_range  struct photon records of the slots first .. first+count-1 (saveCheckpoint's fwrite loop,
+ *                                mcrat_io.c:883-896, in pieces: a 10^8-photon list is 17.6 GB as records).  Bytes between
+ *                                the members are zero. */
+typedef struct mcrat_hip_output_columns {
+    int count;
+    double *p0, *p1, *p2, *p3;
+    double *comv_p0, *comv_p1, *comv_p2, *comv_p3;
+    double *r0, *r1, *r2;
+    double *s0, *s1, *s2, *s3;
+    double *num_scatt, *weight;
+    char   *type;
+} mcrat_hip_output_columns;
+int mcrat_hip_get_output(mcrat_hip_ctx *ctx, mcrat_hip_output_columns *out);
+int mcrat_hip_get_photons_range(mcrat_hip_ctx *ctx, int first, int count, mcrat_hip_photon *records);
+
 /* photonInjection (mclib.c:9-300; mcrat.c:645) on the device, from the staged hydro frame: afterwards the context holds
  * the new photons (*num_photons of them, all of weight *ph_weight_adjusted -- the reference's min/max-photons loop of
  * mclib.c:87-136 runs on the device counts) exactly as if they had been injected on the host and handed to

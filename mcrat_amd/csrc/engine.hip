@@ -1176,8 +1176,69 @@ extern "C" int mcrat_hip_get_photons(mcrat_hip_ctx *c, mcrat_hip_photon_list *l)
     if ((rc = ensure_aos(c, bytes))) return rc;
     // photons that came in as SoA columns have no uploaded records: the bytes between the members are the caller's
     if (fresh) HIPCHK(c, hipMemcpyAsync(c->aos_buf, l->photons, bytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, launch_soa_to_aos(c->ph, c->aos_buf, n, c->stream));
+    HIPCHK(c, launch_soa_to_aos(c->ph, c->aos_buf, 0, n, c->stream));
     HIPCHK(c, hipMemcpyAsync(l->photons, c->aos_buf, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_get_photons_range(mcrat_hip_ctx *c, int first, int count, mcrat_hip_photon *records)
+{
+    if (!c || !records || first < 0 || count <= 0) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    if ((long long)first + count > c->ph.n) return MCRAT_HIP_EINVAL;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    const size_t bytes = sizeof(mcrat_hip_photon) * (size_t)count;
+    if ((rc = ensure_aos(c, bytes))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->aos_buf, 0, bytes, c->stream));        // the bytes between the members: zero
+    HIPCHK(c, launch_soa_to_aos(c->ph, c->aos_buf, first, count, c->stream));
+    HIPCHK(c, hipMemcpyAsync(records, c->aos_buf, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_get_output(mcrat_hip_ctx *c, mcrat_hip_output_columns *out)
+{
+    if (!c || !out) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    const int n = c->ph.n;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    const long long nblk = (n + 255) / 256;
+    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+    if (c->grid_count_cap < (size_t)nblk) {
+        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
+        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)nblk));
+        c->grid_count_cap = (size_t)nblk;
+    }
+    unsigned long long total = 0;
+    HIPCHK(c, launch_output_count(c->ph, n, c->grid_count, c->d_grid_total, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int m = (int)total;
+    double *dst[17] = {out->p0, out->p1, out->p2, out->p3, out->comv_p0, out->comv_p1, out->comv_p2, out->comv_p3, out->r0, out->r1, out->r2,
+                       out->s0, out->s1, out->s2, out->s3, out->num_scatt, out->weight};
+    bool any = out->type != nullptr;
+    for (double *d : dst) any = any || d;
+    if (!any) { out->count = m; return MCRAT_HIP_OK; }            // sizing call
+    if (out->count < m) { out->count = m; return MCRAT_HIP_EINVAL; }
+    out->count = m;
+    if (m == 0) return MCRAT_HIP_OK;
+    const size_t stride = align_up(sizeof(double) * (size_t)m, 256);
+    const size_t o_scan = 17 * stride + align_up((size_t)m, 256);
+    const size_t bytes = o_scan + sizeof(int) * ((size_t)nblk + 1 + grid_scan_scratch_ints(nblk));
+    if ((rc = ensure_aos(c, bytes))) return rc;
+    char *base = static_cast<char *>(c->aos_buf);
+    OutputCols oc;
+    for (int k = 0; k < 17; ++k) oc.col[k] = reinterpret_cast<double *>(base + k * stride);
+    oc.type = base + 17 * stride;
+    int *start = reinterpret_cast<int *>(base + o_scan), *scratch = start + nblk + 1;
+    HIPCHK(c, launch_exclusive_scan(c->grid_count, nblk, start, scratch, (long long)total, c->stream));
+    HIPCHK(c, launch_output_write(c->ph, n, start, oc, c->stream));
+    for (int k = 0; k < 17; ++k)
+        if (dst[k]) HIPCHK(c, hipMemcpyAsync(dst[k], oc.col[k], sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+    if (out->type) HIPCHK(c, hipMemcpyAsync(out->type, oc.type, (size_t)m, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return MCRAT_HIP_OK;
 }

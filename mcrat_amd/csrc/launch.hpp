@@ -43,7 +43,14 @@ hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hi
 // struct photon records <-> SoA columns on the device (staging.hip); `aos` is a device buffer of n 176-B records
 hipError_t launch_init_states(LoopState *single, LoopState *ranks, int n_ranks, const LoopState &v, hipStream_t stream);
 hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream);
-hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int n, hipStream_t stream);
+hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int first, int n, hipStream_t stream);   // record k = slot first + k
+// printPhotons' arrays (mcrat_io.c:137-181): photons with weight != 0, slot order; col: p0-3, comv_p0-3, r0-2, s0-3, num_scatt, weight
+struct OutputCols {
+    double *col[17];
+    char *type;
+};
+hipError_t launch_output_count(const PhotonDev &ph, int n, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
+hipError_t launch_output_write(const PhotonDev &ph, int n, const int *block_start, const OutputCols &out, hipStream_t stream);
 
 // the cell-lookup grid, built on the device (grid_build.hip)
 struct GridPlan {

@@ -40,11 +40,13 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const mcrat_hip_photon 
     ph.type[i] = q.type;
 }
 
-__global__ __launch_bounds__(256) void soa_to_aos_kernel(PhotonDev ph, mcrat_hip_photon *__restrict__ aos, int n)
+// record k of `aos` is photon slot first + k
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(PhotonDev ph, mcrat_hip_photon *__restrict__ aos, int first, int n)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    mcrat_hip_photon q = aos[i];          // keeps the bytes between the members as they were uploaded
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int i = first + k;
+    mcrat_hip_photon q = aos[k];          // keeps the bytes between the members as they were uploaded
     q.type = ph.type[i];
     q.r0 = ph.r0[i]; q.r1 = ph.r1[i]; q.r2 = ph.r2[i];
     q.p0 = ph.p0[i]; q.p1 = ph.p1[i]; q.p2 = ph.p2[i]; q.p3 = ph.p3[i];
@@ -56,7 +58,43 @@ __global__ __launch_bounds__(256) void soa_to_aos_kernel(PhotonDev ph, mcrat_hip
     q.time_to_scatter = ph.tts[i];
     q.nearest_block_index = ph.idx[i];
     q.recalc_properties = (ph.flags[i] & FLAG_RECALC) ? 1 : 0;
-    aos[i] = q;
+    aos[k] = q;
+}
+
+// printPhotons' gathering loop (mcrat_io.c:137-181): the photons with weight != 0, in slot order, as the arrays it hands to
+// H5Dwrite.  Pass 1 counts per workgroup, a scan places the workgroups, pass 2 writes.
+__global__ __launch_bounds__(256) void output_count_kernel(PhotonDev ph, int n, unsigned *__restrict__ block_count, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < n && ph.weight[i] != 0;
+    const unsigned long long m = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned c = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        block_count[blockIdx.x] = c;
+        if (c) atomicAdd(total, (unsigned long long)c);
+    }
+}
+
+__global__ __launch_bounds__(256) void output_write_kernel(PhotonDev ph, int n, const int *__restrict__ block_start, OutputCols out)
+{
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool keep = i < n && ph.weight[i] != 0;
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (!keep) return;
+    unsigned pos = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_w[w];
+    const size_t j = (size_t)block_start[blockIdx.x] + pos;
+    const double *src[17] = {ph.p0, ph.p1, ph.p2, ph.p3, ph.c0, ph.c1, ph.c2, ph.c3, ph.r0, ph.r1, ph.r2, ph.s0, ph.s1, ph.s2, ph.s3, ph.num_scatt, ph.weight};
+#pragma unroll
+    for (int k = 0; k < 17; ++k) out.col[k][j] = src[k][i];
+    out.type[j] = ph.type[i];
 }
 
 // the loop state of a new frame (mcrat.c:754-758): one record for the single list, one per virtual rank with the forced
@@ -87,9 +125,23 @@ hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStr
     return hipGetLastError();
 }
 
-hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int n, hipStream_t stream)
+hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int first, int n, hipStream_t stream)
 {
-    soa_to_aos_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(ph, static_cast<mcrat_hip_photon *>(aos), n);
+    soa_to_aos_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(ph, static_cast<mcrat_hip_photon *>(aos), first, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_output_count(const PhotonDev &ph, int n, unsigned *block_count, unsigned long long *d_total, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    output_count_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(ph, n, block_count, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_output_write(const PhotonDev &ph, int n, const int *block_start, const OutputCols &out, hipStream_t stream)
+{
+    output_write_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(ph, n, block_start, out);
     return hipGetLastError();
 }
 

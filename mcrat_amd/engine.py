@@ -123,6 +123,13 @@ class HydroColumns(C.Structure):
     _fields_ = [("num_elements", C.c_int)] + [(f, _dp) for f in HYDRO_COLUMNS]
 
 
+OUTPUT_COLUMNS = ("p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3", "r0", "r1", "r2", "s0", "s1", "s2", "s3", "num_scatt", "weight")
+
+
+class OutputColumns(C.Structure):
+    _fields_ = [("count", C.c_int)] + [(f, _dp) for f in OUTPUT_COLUMNS] + [("type", C.c_char_p)]
+
+
 SCIENCE, CYLINDRICAL_OUTFLOW, SPHERICAL_OUTFLOW, STRUCTURED_SPHERICAL_OUTFLOW = 0, 1, 2, 3    # SIMULATION_TYPE, mcrat.h:30-33
 
 # every symbol include/mcrat_hip.h declares: (restype, argtypes)
@@ -138,6 +145,8 @@ SYMBOLS = {
     "mcrat_hip_ingest_flash": (C.c_int, [_ctx, C.POINTER(FlashBlocks), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_ingest_pluto": (C.c_int, [_ctx, C.POINTER(PlutoGrid), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
+    "mcrat_hip_get_output": (C.c_int, [_ctx, C.POINTER(OutputColumns)]),
+    "mcrat_hip_get_photons_range": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
     "mcrat_hip_inject_photons": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char, C.c_double, C.c_double, C.c_double,
                                            C.c_uint64, _ip, _dp]),
     "mcrat_hip_set_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
@@ -373,6 +382,25 @@ class Engine:
         s.recalc_properties = out["recalc_properties"].ctypes.data_as(_ip)
         self._check(self.lib.mcrat_hip_get_photons_soa(self.ctx, C.byref(s)), "get_photons_soa")
         return out
+
+    def get_output(self):
+        """printPhotons' arrays (mcrat_io.c:137-181): photons with weight != 0 in slot order, compacted on the device"""
+        o = OutputColumns()
+        self._check(self.lib.mcrat_hip_get_output(self.ctx, C.byref(o)), "get_output (count)")
+        m = o.count
+        out = {f: np.empty(m) for f in OUTPUT_COLUMNS}
+        out["type"] = np.empty(m, dtype="S1")
+        for f in OUTPUT_COLUMNS:
+            setattr(o, f, out[f].ctypes.data_as(_dp))
+        o.type = out["type"].ctypes.data_as(C.c_char_p)
+        self._check(self.lib.mcrat_hip_get_output(self.ctx, C.byref(o)), "get_output")
+        assert o.count == m
+        return out
+
+    def get_photons_range(self, first, count):
+        a = np.zeros(count, dtype=PHOTON_DTYPE)
+        self._check(self.lib.mcrat_hip_get_photons_range(self.ctx, int(first), int(count), a.ctypes.data), "get_photons_range")
+        return a
 
     def set_photons_aos(self, aos):
         """aos: numpy array of PHOTON_DTYPE (the reference's struct photon records)."""

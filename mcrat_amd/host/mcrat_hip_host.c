@@ -262,6 +262,106 @@ done_grid:
     return 0;
 }
 
+/* ---- checkpoints (mcrat_io.c:838-1134) -------------------------------------------------------------------- */
+static int copy_file(const char *from, const char *to)        /* "exec cp file file_old", mcrat_io.c:849 */
+{
+    FILE *in = fopen(from, "rb");
+    if (!in) return -1;
+    FILE *out = fopen(to, "wb");
+    if (!out) { fclose(in); return -1; }
+    char buf[1 << 16];
+    size_t n;
+    int rc = 0;
+    while ((n = fread(buf, 1, sizeof buf, in)) > 0)
+        if (fwrite(buf, 1, n, out) != n) { rc = -1; break; }
+    fclose(in);
+    if (fclose(out) != 0) rc = -1;
+    return rc;
+}
+
+int mcrat_host_save_checkpoint(const char *dir, int frame, int frame2, int scatt_frame, double time_now, mcrat_hip_ctx *ctx,
+                               const mcrat_hip_photon_list *list, int list_capacity, int last_frame, int angle_rank, int angle_size)
+{
+    char file[2000], old[2100];
+    if (!dir || list_capacity < 0 || (!ctx && list_capacity > 0 && (!list || !list->photons))) return 1;
+    snprintf(file, sizeof file, "%s%s%d%s", dir, "mc_chkpt_", angle_rank, ".dat");
+    snprintf(old, sizeof old, "%s_old", file);
+    const int continuing = (scatt_frame != last_frame) || (scatt_frame == frame);       /* the three cases of :846,:898,:947 */
+    if (scatt_frame == frame) remove(file);
+    else (void)copy_file(file, old);
+    FILE *f = fopen(file, "wb");
+    if (!f) { printf("Cannot open %s to save checkpoint\n", file); return 1; }
+    char restart = continuing ? 'c' : 'i';                     /* CONTINUE / INITALIZE, mcrat.h */
+    int ok = fwrite(&angle_size, sizeof(int), 1, f) == 1 && fwrite(&restart, sizeof(char), 1, f) == 1 &&
+             fwrite(&frame, sizeof(int), 1, f) == 1 && fwrite(&frame2, sizeof(int), 1, f) == 1;
+    if (ok && continuing) {
+        int ph_num = list_capacity;
+        ok = fwrite(&scatt_frame, sizeof(int), 1, f) == 1 && fwrite(&time_now, sizeof(double), 1, f) == 1 &&
+             fwrite(&ph_num, sizeof(int), 1, f) == 1;
+    }
+    if (ok && list_capacity > 0) {
+        if (ctx) {
+            const int piece = 1 << 20;                          /* 185 MB of records at a time */
+            mcrat_hip_photon *buf = (mcrat_hip_photon *)malloc(sizeof(mcrat_hip_photon) * (size_t)(list_capacity < piece ? list_capacity : piece));
+            ok = buf != NULL;
+            for (int first = 0; ok && first < list_capacity; first += piece) {
+                const int n = list_capacity - first < piece ? list_capacity - first : piece;
+                ok = mcrat_hip_get_photons_range(ctx, first, n, buf) == 0 && fwrite(buf, sizeof(mcrat_hip_photon), (size_t)n, f) == (size_t)n;
+            }
+            free(buf);
+        } else {
+            ok = fwrite(list->photons, sizeof(mcrat_hip_photon), (size_t)list_capacity, f) == (size_t)list_capacity;
+        }
+    }
+    if (fclose(f) != 0) ok = 0;
+    return ok ? 0 : 1;
+}
+
+int mcrat_host_read_checkpoint(const char *dir, mcrat_hip_photon_list *list, int *frame2, int *framestart, int *scatt_framestart,
+                               char *restart, double *time, int angle_rank, int *angle_size)
+{
+    char file[2000];
+    if (!dir || !list || !frame2 || !framestart || !scatt_framestart || !restart || !time || !angle_size) return -2;
+    snprintf(file, sizeof file, "%s%s%d%s", dir, "mc_chkpt_", angle_rank, ".dat");
+    FILE *f = fopen(file, "rb");
+    if (!f) {                                                   /* :1127-1131 */
+        *scatt_framestart = *framestart;
+        *restart = 'i';
+        return 0;
+    }
+    int rc = -2, ph_num = 0;
+    if (fread(angle_size, sizeof(int), 1, f) != 1 || fread(restart, sizeof(char), 1, f) != 1 || fread(framestart, sizeof(int), 1, f) != 1 ||
+        fread(frame2, sizeof(int), 1, f) != 1)
+        goto done;
+    if (*restart == 'c') {
+        if (fread(scatt_framestart, sizeof(int), 1, f) != 1) goto done;
+        *scatt_framestart += 1;                                 /* start at the frame after the interrupted one, :1052 */
+        if (fread(time, sizeof(double), 1, f) != 1 || fread(&ph_num, sizeof(int), 1, f) != 1 || ph_num < 0) goto done;
+        mcrat_hip_photon *ph = (mcrat_hip_photon *)calloc((size_t)(ph_num > 0 ? ph_num : 1), sizeof(mcrat_hip_photon));
+        if (!ph) goto done;
+        if (fread(ph, sizeof(mcrat_hip_photon), (size_t)ph_num, f) != (size_t)ph_num) { free(ph); goto done; }
+        int nulls = 0;
+        for (int i = 0; i < ph_num; i++) {                      /* the members the reference does not carry over (:1064-1083) */
+            ph[i].recalc_properties = 1;
+            ph[i].time_to_scatter = 0;
+            ph[i].total_optical_depth = 0;
+            nulls += ph[i].type == 'N';
+        }
+        list->photons = ph;
+        list->sorted_indexes = NULL;
+        list->list_capacity = ph_num;
+        list->num_null_photons = nulls;
+        list->num_photons = ph_num - nulls;
+    } else {
+        *framestart += 1;                                       /* :1117 */
+        *scatt_framestart = *framestart;
+    }
+    rc = 0;
+done:
+    fclose(f);
+    return rc;
+}
+
 int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, const mcrat_hip_hydro *hydro,
                              double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
                              uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats)

@@ -71,6 +71,29 @@ void mcrat_host_free_pluto(mcrat_host_pluto *p);
 /* modifyPlutoName (mclib_pluto.c:803-850): prefix + frame zero-padded to four digits + ".dbl" */
 void mcrat_host_pluto_name(char *out, size_t n, const char *prefix, int frame);
 
+/* saveCheckpoint (Src/mcrat_io.c:838-1009): mc_chkpt_<angle_rank>.dat in `dir`, byte for byte the reference's layout --
+ * angle_size (int), restart flag (char), frame, frame2 (int) and, unless this is the frame after the last one,
+ * scatt_frame (int), time_now (double), list_capacity (int) -- followed by the struct photon records (176 B each).  The
+ * previous file is kept as <file>_old except when scatt_frame == frame, where it is removed first (:849,:901,:951).
+ * With ctx != NULL the records stream from the device in pieces (mcrat_hip_get_photons_range): no host copy of the list;
+ * with ctx == NULL they are `list`'s.  Returns 0, or 1 if the file cannot be written (as the reference). */
+int mcrat_host_save_checkpoint(const char *dir, int frame, int frame2, int scatt_frame, double time_now, mcrat_hip_ctx *ctx,
+                               const mcrat_hip_photon_list *list, int list_capacity, int last_frame, int angle_rank, int angle_size);
+/* readCheckpoint (mcrat_io.c:1011-1134): fills the scalars with the reference's "+1" conventions; for a 'c' file
+ * list->photons is malloc'ed with list_capacity records (free() it) ready for mcrat_hip_set_photons.  A missing file is
+ * not an error (restart = 'i', scatt_framestart = framestart, :1127-1131).  Returns 0, -2 on a truncated file. */
+int mcrat_host_read_checkpoint(const char *dir, mcrat_hip_photon_list *list, int *frame2, int *framestart, int *scatt_framestart,
+                               char *restart, double *time, int angle_rank, int *angle_size);
+
+/* printPhotons (Src/mcrat_io.c:114-836; mcrat_hip_host_h5.c, built into libmcrat_hip_host_h5.so when the HDF5 C library is
+ * present): appends the frame's photons (weight != 0, compacted on the device by mcrat_hip_get_output) to group "<frame>" of
+ * <dir>mc_proc_<angle_rank>.h5 as the datasets P0-3, [COMV_P0-3], R0-2, [S0-3], NS, PW, [PT] -- chunked, unlimited, extended
+ * when the group already exists, as the reference writes them.  comv_switch / stokes_switch / save_type: COMV_SWITCH,
+ * STOKES_SWITCH, SAVE_TYPE of mcrat_input.h.  mcrat_host_h5_read reads one of them back (tests; dirFileMerge's per-dataset read). */
+int mcrat_host_print_photons(mcrat_hip_ctx *ctx, int frame, const char *dir, int angle_rank, int comv_switch, int stokes_switch,
+                             int save_type, FILE *fPtr);
+int mcrat_host_h5_read(const char *file, const char *group, const char *name, int is_char, void *data, int cap, int *n);
+
 /* One scatter frame on the device (replaces Src/mcrat.c:754-892 between getHydroData and saveCheckpoint).
  *   list       caller-owned photon list; uploaded, propagated, downloaded in place
  *   hydro      the frame getHydroData just produced
