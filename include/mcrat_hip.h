@@ -176,6 +176,7 @@ int mcrat_hip_set_hydro(mcrat_hip_ctx *ctx, const mcrat_hip_hydro *hydro);
  * host copy of the selected frame is made (mcrat_hip_get_hydro returns one when the caller needs it).
  *   mcrat_hip_ingest_flash  replaces readAndDecimate (mclib_flash.c:60-431) after line 197 (datasets read)
  *   mcrat_hip_ingest_pluto  replaces readPluto (mclib_pluto.c:1058-1459) after line 1128 (file read)
+ *   mcrat_hip_ingest_chombo replaces readPlutoChombo (mclib_pluto.c:12-801) after its HDF5 reads
  * mcrat_host_read_pluto (mcrat_amd/host) parses grid.out, dbl.out and the .dbl file into mcrat_hip_pluto_grid. */
 typedef struct mcrat_hip_slab {           /* the selecting arguments of getHydroData (mcrat_io.h:26) + frame constants */
     double r_inj;
@@ -200,6 +201,24 @@ typedef struct mcrat_hip_pluto_grid {     /* a PLUTO .dbl frame: readGridFile's 
     const double *rho, *vx1, *vx2, *vx3, *prs;      /* [nz][ny][nx]; vx3 may be NULL in 2-D */
     double l_scale, d_scale, p_scale;
 } mcrat_hip_pluto_grid;
+
+typedef struct mcrat_hip_chombo_level {   /* one "level_<i>" group of a PLUTO-Chombo file, mclib_pluto.c:206-276,349-430 */
+    int n_boxes;
+    const int *boxes;                     /* "boxes": n_boxes x {lo_i, lo_j, [lo_k], hi_i, hi_j, [hi_k]} (the compound type of :48-58) */
+    const int *box_offsets;               /* "data:offsets=0": start of each box's data within the level, in doubles */
+    long long data_len;                   /* length of "data:datatype=0" */
+    int prob_domain[6];                   /* attribute prob_domain, same member order as a box */
+    int ref_ratio, logr;                  /* attributes ref_ratio, logr */
+    double dx, dombeg1, dombeg2, dombeg3, g_x2stretch, g_x3stretch;   /* attributes dx, domBeg1-3, g_x2stretch, g_x3stretch */
+} mcrat_hip_chombo_level;
+
+typedef struct mcrat_hip_chombo {         /* a PLUTO-Chombo AMR frame after readPlutoChombo's HDF5 reads */
+    int num_levels, num_vars;             /* attributes num_levels, num_components */
+    const mcrat_hip_chombo_level *levels; /* level 0 (coarsest) first */
+    const char *const *var_names;         /* attributes component_0 ... ("rho", "vx1", "vx2", "vx3", "prs", ...) */
+    const double *data;                   /* the levels' "data:datatype=0", level 0 first (all_data, :151-155,:360) */
+    double l_scale, d_scale, p_scale;
+} mcrat_hip_chombo;
 
 #define MCRAT_HIP_SCIENCE                       0   /* SIMULATION_TYPE, mcrat.h:30-33 */
 #define MCRAT_HIP_CYLINDRICAL_OUTFLOW           1
@@ -226,6 +245,15 @@ int mcrat_hip_ingest_flash(mcrat_hip_ctx *ctx, const mcrat_hip_flash_blocks *blo
                            const mcrat_hip_outflow *outflow, mcrat_hip_ingest_result *result);
 int mcrat_hip_ingest_pluto(mcrat_hip_ctx *ctx, const mcrat_hip_pluto_grid *grid, const mcrat_hip_slab *slab,
                            const mcrat_hip_outflow *outflow, mcrat_hip_ingest_result *result);
+
+/* replaces readPlutoChombo (mclib_pluto.c:12-801) after line 430 (levels read).  Cells are numbered level by level, box
+ * by box, x fastest, as the reader numbers them; coarse cells covered by a finer level are dropped exactly where the
+ * reference drops them -- in injection frames (ph_inj_switch != 0, :672,:745) and not in the photons'-slab branch
+ * (:659,:703), which does not consult good_node_buffer.  The per-level 1-D coordinate arrays (:446-517, with libm's exp
+ * for logarithmic radial grids) are computed on the host; boxes must lie inside their level's prob_domain and their
+ * data must follow one another in "data:offsets=0" order. */
+int mcrat_hip_ingest_chombo(mcrat_hip_ctx *ctx, const mcrat_hip_chombo *frame, const mcrat_hip_slab *slab,
+                            const mcrat_hip_outflow *outflow, mcrat_hip_ingest_result *result);
 
 /* every column of the staged frame (struct hydro_dataframe, mcrat.h:194-244), host pointers of num_elements doubles
  * allocated by the caller; NULL pointers are skipped.  After mcrat_hip_set_hydro the columns that call did not carry

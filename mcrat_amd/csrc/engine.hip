@@ -889,6 +889,104 @@ extern "C" int mcrat_hip_ingest_pluto(mcrat_hip_ctx *c, const mcrat_hip_pluto_gr
     return rc;
 }
 
+extern "C" int mcrat_hip_ingest_chombo(mcrat_hip_ctx *c, const mcrat_hip_chombo *h, const mcrat_hip_slab *slab, const mcrat_hip_outflow *outflow,
+                                       mcrat_hip_ingest_result *result)
+{
+    if (!c || !h || !slab_ok(slab) || !outflow_ok(outflow)) return MCRAT_HIP_EINVAL;
+    if (h->num_levels <= 0 || h->num_vars <= 0 || !h->levels || !h->var_names || !h->data) return MCRAT_HIP_EINVAL;
+    const bool three = c->kc.dimensions == DIM_THREE;
+    const int nd = three ? 3 : 2, bi = 2 * nd, nl = h->num_levels, nv = h->num_vars;
+    // the box table in the reader's cell numbering, and the per-level coordinate arrays (mclib_pluto.c:446-517)
+    std::vector<ChomboBox> boxes;
+    std::vector<int> level_first_box(nl + 1, 0);
+    std::vector<double> xs[3], dxs[3];
+    long long total = 0;                                         // doubles of all levels: start_displacement (:151-155)
+    for (int i = 0; i < nl; ++i) {
+        const mcrat_hip_chombo_level &L = h->levels[i];
+        if (L.n_boxes < 0 || (L.n_boxes > 0 && (!L.boxes || !L.box_offsets)) || L.data_len < 0 || L.ref_ratio <= 0) return MCRAT_HIP_EINVAL;
+        int ext[3] = {1, 1, 1}, cb[3] = {0, 0, 0};
+        for (int a = 0; a < nd; ++a) {
+            ext[a] = L.prob_domain[nd + a] - L.prob_domain[a] + 1;
+            if (ext[a] <= 0) return MCRAT_HIP_EINVAL;
+            cb[a] = (int)xs[a].size();
+        }
+        for (int j = 0; j < ext[0]; ++j) {
+            const int g = L.prob_domain[0] + j;
+            if (L.logr == 0) { xs[0].push_back(L.dombeg1 + L.dx * (g + 0.5)); dxs[0].push_back(L.dx); }
+            else {
+                xs[0].push_back(L.dombeg1 * 0.5 * (std::exp(L.dx * (g + 1)) + std::exp(L.dx * g)));
+                dxs[0].push_back(L.dombeg1 * (std::exp(L.dx * (g + 1)) - std::exp(L.dx * g)));
+            }
+        }
+        for (int j = 0; j < ext[1]; ++j) { xs[1].push_back(L.dombeg2 + L.dx * L.g_x2stretch * (L.prob_domain[1] + j + 0.5)); dxs[1].push_back(L.dx * L.g_x2stretch); }
+        for (int j = 0; three && j < ext[2]; ++j) { xs[2].push_back(L.dombeg3 + L.dx * L.g_x3stretch * (L.prob_domain[2] + j + 0.5)); dxs[2].push_back(L.dx * L.g_x3stretch); }
+        level_first_box[i] = (int)boxes.size();
+        for (int j = 0; j < L.n_boxes; ++j) {
+            const int *b = L.boxes + (size_t)j * bi;
+            ChomboBox r{};
+            r.level = i;
+            long long ncell = 1;
+            for (int a = 0; a < 3; ++a) {
+                r.lo[a] = a < nd ? b[a] : 0;
+                r.n[a] = a < nd ? b[nd + a] - b[a] + 1 : 1;
+                r.cb[a] = cb[a];
+                // the reader indexes its coordinate arrays with the box's own indices (:541): they must exist
+                if (r.n[a] <= 0 || (a < nd && (r.lo[a] < 0 || r.lo[a] + r.n[a] > ext[a]))) { c->last_error = "PLUTO-Chombo ingest: a box lies outside its level's prob_domain"; return MCRAT_HIP_EINVAL; }
+                ncell *= r.n[a];
+            }
+            r.data_off = total + L.box_offsets[j];
+            r.first_cell = r.data_off / nv;
+            if (L.box_offsets[j] < 0 || L.box_offsets[j] + ncell * nv > L.data_len) { c->last_error = "PLUTO-Chombo ingest: a box's data lies outside its level's data"; return MCRAT_HIP_EINVAL; }
+            if (!boxes.empty() && r.first_cell != boxes.back().first_cell + (long long)boxes.back().n[0] * boxes.back().n[1] * boxes.back().n[2]) {
+                c->last_error = "PLUTO-Chombo ingest: box data do not follow one another in data:offsets order";
+                return MCRAT_HIP_EINVAL;
+            }
+            boxes.push_back(r);
+        }
+        total += L.data_len;
+    }
+    level_first_box[nl] = (int)boxes.size();
+    const long long cells = total / nv;
+    if (boxes.empty() || cells <= 0 || cells > 0x7fffffffLL || boxes.front().first_cell != 0) return MCRAT_HIP_EINVAL;
+    int kv[5] = {-1, -1, -1, -1, -1};
+    static const char *want[5] = {"rho", "vx1", "vx2", "vx3", "prs"};
+    for (int k = 0; k < nv; ++k)
+        for (int w = 0; w < 5; ++w)
+            if (h->var_names[k] && strcmp(h->var_names[k], want[w]) == 0) kv[w] = k;
+    if (kv[0] < 0 || kv[1] < 0 || kv[2] < 0 || kv[4] < 0 || (c->kc.dimensions != DIM_TWO && kv[3] < 0)) { c->last_error = "PLUTO-Chombo ingest: a component (rho, vx1, vx2, [vx3], prs) is missing"; return MCRAT_HIP_EINVAL; }
+
+    c->have_hydro = false;
+    const bool masked = slab->ph_inj_switch != 0;
+    RawPacker pk{c};
+    const size_t o_box = pk.add(boxes.data(), sizeof(ChomboBox) * boxes.size());
+    size_t o_x[3] = {0, 0, 0}, o_dx[3] = {0, 0, 0};
+    for (int a = 0; a < nd; ++a) { o_x[a] = pk.add(xs[a].data(), sizeof(double) * xs[a].size()); o_dx[a] = pk.add(dxs[a].data(), sizeof(double) * dxs[a].size()); }
+    const size_t o_data = pk.add(h->data, sizeof(double) * (size_t)total);
+    const size_t o_mask = masked ? pk.add(nullptr, (size_t)cells) : 0;
+    int rc = pk.upload();
+    if (rc) return rc;
+    ChomboDev d{};
+    d.boxes = pk.at<ChomboBox>(o_box); d.n_boxes = (int)boxes.size(); d.cells = cells;
+    d.data = pk.at<double>(o_data);
+    for (int a = 0; a < nd; ++a) { d.x[a] = pk.at<double>(o_x[a]); d.dx[a] = pk.at<double>(o_dx[a]); }
+    for (int w = 0; w < 5; ++w) d.kv[w] = kv[w];
+    d.L = h->l_scale; d.D = h->d_scale; d.P = h->p_scale;
+    if (masked) {
+        unsigned char *mask = static_cast<unsigned char *>(c->raw_buf) + o_mask;
+        HIPCHK(c, hipMemsetAsync(mask, 0, (size_t)cells, c->stream));
+        for (int i = nl - 2; i >= 0; --i)                      // :206-345
+            HIPCHK(c, launch_chombo_mask(d.boxes, level_first_box[i], level_first_box[i + 1], level_first_box[i + 1], level_first_box[i + 2],
+                                         h->levels[i].ref_ratio, three ? 1 : 0, mask, c->stream));
+        d.covered = mask;
+    }
+    if (result) { memset(result, 0, sizeof *result); }
+    rc = ingest_common(c, cells, slab, outflow, result,
+                       [&](const SlabDev &sd) { return ingest_count_chombo(d, sd, c->grid_count, c->d_grid_total, c->stream); },
+                       [&](const SlabDev &sd, const int *start) { return ingest_write_chombo(d, sd, start, c->hcol, c->stream); });
+    if (rc == MCRAT_HIP_OK && result) result->cells_read = cells;
+    return rc;
+}
+
 extern "C" int mcrat_hip_get_hydro(mcrat_hip_ctx *c, mcrat_hip_hydro_columns *out)
 {
     if (!c || !out) return MCRAT_HIP_EINVAL;

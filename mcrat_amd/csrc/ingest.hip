@@ -101,6 +101,80 @@ struct PlutoSource {
     }
 };
 
+// mclib_pluto.c:520-612 (readPlutoChombo): cells numbered level by level, box by box, x fastest
+struct ChomboSource {
+    ChomboDev h;
+    int scale1, scale2, three, v3;
+    __device__ long long count() const { return h.cells; }
+    __device__ int box_of(long long i) const
+    {
+        int lo = 0, hi = h.n_boxes - 1;                  // last box with first_cell <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (h.boxes[mid].first_cell <= i) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }
+    __device__ bool present(long long i) const { return !h.covered || h.covered[i] == 0; }
+    __device__ RawCell geom(long long i) const
+    {
+        const ChomboBox b = h.boxes[box_of(i)];
+        const long long q = i - b.first_cell;
+        const int n = (int)(q % b.n[0]);
+        const long long t = q / b.n[0];
+        const int m = (int)(t % b.n[1]), l = (int)(t / b.n[1]);
+        RawCell c;
+        c.x0 = h.x[0][b.cb[0] + b.lo[0] + n] * h.L; c.s0 = h.dx[0][b.cb[0] + b.lo[0] + n] * h.L;
+        c.x1 = h.x[1][b.cb[1] + b.lo[1] + m]; c.s1 = h.dx[1][b.cb[1] + b.lo[1] + m];
+        if (scale1) { c.x1 *= h.L; c.s1 *= h.L; }
+        c.x2 = 0; c.s2 = 0;
+        if (three) {
+            c.x2 = h.x[2][b.cb[2] + b.lo[2] + l]; c.s2 = h.dx[2][b.cb[2] + b.lo[2] + l];
+            if (scale2) { c.x2 *= h.L; c.s2 *= h.L; }
+        }
+        return c;
+    }
+    __device__ void fluid(long long i, double &v0, double &v1, double &v2, double &dens, double &pres) const
+    {
+        const ChomboBox b = h.boxes[box_of(i)];
+        const long long vs = (long long)b.n[0] * b.n[1] * b.n[2];
+        const double *d = h.data + b.data_off + (i - b.first_cell);
+        dens = h.kv[0] >= 0 ? d[h.kv[0] * vs] * h.D : 0.0;
+        v0 = h.kv[1] >= 0 ? d[h.kv[1] * vs] : 0.0;
+        v1 = h.kv[2] >= 0 ? d[h.kv[2] * vs] : 0.0;
+        v2 = (v3 && h.kv[3] >= 0) ? d[h.kv[3] * vs] : 0.0;
+        pres = h.kv[4] >= 0 ? d[h.kv[4] * vs] * h.P : 0.0;
+    }
+};
+
+__device__ __forceinline__ int floor_div(int a, int b) { const int q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+__device__ __forceinline__ int ceil_div(int a, int b) { return -floor_div(-a, b); }
+
+// good_node_buffer (mclib_pluto.c:206-345): a cell of level i at index g is covered when ref_ratio * g lies inside a box
+// of level i+1, i.e. ceil(lo / ref) <= g <= floor(hi / ref) on every axis.  One thread per (coarse box, fine box) pair;
+// a pair that overlaps marks its intersection (fine boxes are disjoint, so every covered cell is marked once).
+__global__ __launch_bounds__(IB) void chombo_mask_kernel(const ChomboBox *__restrict__ boxes, int c0, int nc, int f0, int nf, int ref, int three,
+                                                         unsigned char *__restrict__ covered)
+{
+    const long long pairs = (long long)nc * nf;
+    for (long long p = (long long)blockIdx.x * IB + threadIdx.x; p < pairs; p += (long long)gridDim.x * IB) {
+        const ChomboBox c = boxes[c0 + (int)(p / nf)], f = boxes[f0 + (int)(p % nf)];
+        int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        bool any = true;
+        for (int a = 0; a < (three ? 3 : 2); ++a) {
+            const int flo = ceil_div(f.lo[a], ref), fhi = floor_div(f.lo[a] + f.n[a] - 1, ref);
+            lo[a] = max(c.lo[a], flo) - c.lo[a];
+            hi[a] = min(c.lo[a] + c.n[a] - 1, fhi) - c.lo[a];
+            any = any && lo[a] <= hi[a];
+        }
+        if (!any) continue;
+        for (int l = lo[2]; l <= hi[2]; ++l)
+            for (int m = lo[1]; m <= hi[1]; ++m)
+                for (int n = lo[0]; n <= hi[0]; ++n)
+                    covered[c.first_cell + (long long)l * c.n[0] * c.n[1] + (long long)m * c.n[0] + n] = 1;
+    }
+}
+
 // mclib_flash.c:288-318 == mclib_pluto.c:1260-1301
 __device__ __forceinline__ bool in_slab(const SlabDev &s, const RawCell &c)
 {
@@ -401,7 +475,41 @@ PlutoSource pluto_source(const PlutoDev &g, int dims, int geom)
     return s;
 }
 
+ChomboSource chombo_source(const ChomboDev &h, int dims, int geom)
+{
+    ChomboSource s;
+    s.h = h;
+    s.three = dims == DIM_THREE;
+    s.v3 = dims != DIM_TWO;
+    s.scale1 = (geom == GEOM_CARTESIAN || geom == GEOM_CYLINDRICAL);
+    s.scale2 = (geom == GEOM_CARTESIAN || geom == GEOM_POLAR);
+    return s;
+}
+
 }  // namespace
+
+hipError_t ingest_count_chombo(const ChomboDev &h, const SlabDev &slab, unsigned *block_count, unsigned long long *d_total, hipStream_t stream)
+{
+    return count_impl(chombo_source(h, slab.dimensions, slab.geometry), h.cells, slab, block_count, d_total, stream);
+}
+
+hipError_t ingest_write_chombo(const ChomboDev &h, const SlabDev &slab, const int *block_start, const HydroCols &out, hipStream_t stream)
+{
+    const long long blocks = ingest_blocks(h.cells);
+    hipLaunchKernelGGL((ingest_write_kernel<ChomboSource, false>), dim3((unsigned)blocks), dim3(IB), 0, stream,
+                       chombo_source(h, slab.dimensions, slab.geometry), slab, block_start, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_chombo_mask(const ChomboBox *boxes, int c0, int c1, int f0, int f1, int ref_ratio, int three, unsigned char *covered, hipStream_t stream)
+{
+    const long long pairs = (long long)(c1 - c0) * (f1 - f0);
+    if (pairs <= 0) return hipSuccess;
+    long long blocks = (pairs + IB - 1) / IB;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(chombo_mask_kernel, dim3((unsigned)blocks), dim3(IB), 0, stream, boxes, c0, c1 - c0, f0, f1 - f0, ref_ratio, three, covered);
+    return hipGetLastError();
+}
 
 long long ingest_blocks(long long n_virtual) { return (n_virtual + IB - 1) / IB; }
 

@@ -102,6 +102,28 @@ struct PlutoDev {           // device copies of readGridFile's arrays and the .d
     const double *rho, *vx1, *vx2, *vx3, *prs;
     double L, D, P;
 };
+struct ChomboBox {          // one box of a PLUTO-Chombo level (mclib_pluto.c:520-545)
+    long long first_cell;   // (start_displacement + box_offset) / num_vars: where its cells sit in the reader's cell numbering
+    long long data_off;     // start_displacement + box_offset: its data in the concatenated "data:datatype=0" arrays
+    int level;
+    int lo[3], n[3];        // lo_i, lo_j, lo_k; cells per axis
+    int cb[3];              // where this level's 1-D coordinate arrays start in ChomboDev::x / dx
+    int pad[2];
+};
+struct ChomboDev {
+    const ChomboBox *boxes;
+    int n_boxes;
+    long long cells;
+    const double *data;
+    const double *x[3], *dx[3];        // per axis: the levels' x*_array / dx*_array (mclib_pluto.c:446-517), concatenated
+    const unsigned char *covered;      // good_node_buffer == 0 (:206-345); null when the mask is not consulted
+    int kv[5];                         // component index of rho, vx1, vx2, vx3, prs (-1: absent)
+    double L, D, P;
+};
+hipError_t ingest_count_chombo(const ChomboDev &h, const SlabDev &slab, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
+hipError_t ingest_write_chombo(const ChomboDev &h, const SlabDev &slab, const int *block_start, const HydroCols &out, hipStream_t stream);
+// marks the cells of boxes [c0, c1) that a box of [f0, f1) (the next finer level) covers
+hipError_t launch_chombo_mask(const ChomboBox *boxes, int c0, int c1, int f0, int f1, int ref_ratio, int three, unsigned char *covered, hipStream_t stream);
 struct OutflowDev {
     int simulation_type;
     double gamma_infinity, lumi, r00, t_comov, ddensity, theta_j, p;

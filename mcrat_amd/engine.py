@@ -107,6 +107,18 @@ class PlutoGrid(C.Structure):
                [("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double)]
 
 
+class ChomboLevel(C.Structure):
+    _fields_ = [("n_boxes", C.c_int), ("boxes", _ip), ("box_offsets", _ip), ("data_len", C.c_longlong),
+                ("prob_domain", C.c_int * 6), ("ref_ratio", C.c_int), ("logr", C.c_int),
+                ("dx", C.c_double), ("dombeg1", C.c_double), ("dombeg2", C.c_double), ("dombeg3", C.c_double),
+                ("g_x2stretch", C.c_double), ("g_x3stretch", C.c_double)]
+
+
+class Chombo(C.Structure):
+    _fields_ = [("num_levels", C.c_int), ("num_vars", C.c_int), ("levels", C.POINTER(ChomboLevel)), ("var_names", C.POINTER(C.c_char_p)),
+                ("data", _dp), ("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double)]
+
+
 class Outflow(C.Structure):
     _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
                 ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
@@ -144,6 +156,7 @@ SYMBOLS = {
     "mcrat_hip_outflow_defaults": (None, [C.c_int, C.POINTER(Outflow)]),
     "mcrat_hip_ingest_flash": (C.c_int, [_ctx, C.POINTER(FlashBlocks), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_ingest_pluto": (C.c_int, [_ctx, C.POINTER(PlutoGrid), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
+    "mcrat_hip_ingest_chombo": (C.c_int, [_ctx, C.POINTER(Chombo), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
     "mcrat_hip_get_output": (C.c_int, [_ctx, C.POINTER(OutputColumns)]),
     "mcrat_hip_get_photons_range": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
@@ -300,6 +313,24 @@ class Engine:
                             ptr(raw["velx"]), ptr(raw["vely"]), ptr(raw["dens"]), ptr(raw["pres"]),
                             float(raw.get("l_scale", 1.0)), float(raw.get("d_scale", 1.0)), float(raw.get("p_scale", 1.0)))
             self._check(self.lib.mcrat_hip_ingest_flash(self.ctx, C.byref(b), C.byref(s), op, C.byref(res)), "ingest_flash")
+        elif raw["kind"] == "chombo":
+            nl = len(raw["levels"])
+            levels = (ChomboLevel * nl)()
+            for i, lv in enumerate(raw["levels"]):
+                boxes = np.ascontiguousarray(lv["boxes"], dtype=np.int32)
+                L = levels[i]
+                L.n_boxes, L.boxes, L.box_offsets = boxes.shape[0], ptr(boxes, np.int32, C.c_int), ptr(lv["box_offsets"], np.int32, C.c_int)
+                L.data_len = int(len(lv["data"]))
+                for k in range(6):
+                    L.prob_domain[k] = int(lv["prob_domain"][k]) if k < len(lv["prob_domain"]) else 0
+                L.ref_ratio, L.logr = int(lv["ref_ratio"]), int(lv["logr"])
+                for k in ("dx", "dombeg1", "dombeg2", "dombeg3", "g_x2stretch", "g_x3stretch"):
+                    setattr(L, k, float(lv.get(k, 0.0)))
+            names = (C.c_char_p * len(raw["var_names"]))(*[v.encode() for v in raw["var_names"]])
+            keep += [levels, names]
+            h = Chombo(nl, len(raw["var_names"]), levels, names, ptr(np.concatenate([_f8(lv["data"]) for lv in raw["levels"]])),
+                       float(raw.get("l_scale", 1.0)), float(raw.get("d_scale", 1.0)), float(raw.get("p_scale", 1.0)))
+            self._check(self.lib.mcrat_hip_ingest_chombo(self.ctx, C.byref(h), C.byref(s), op, C.byref(res)), "ingest_chombo")
         else:
             g = PlutoGrid()
             g.nx, g.ny, g.nz = int(raw["nx"]), int(raw["ny"]), int(raw.get("nz", 1))

@@ -232,6 +232,72 @@ def pluto_raw_grid(dimensions, geometry, lo, hi, n, l_scale=1e9, seed=0, log_axi
     return raw
 
 
+def chombo_raw(dimensions, geometry, lo, hi, n0, levels=3, box=8, refine_below=(0.5, 0.25), l_scale=1e9, seed=0, logr=False,
+               var_names=("rho", "vx1", "vx2", "vx3", "prs", "tr1")):
+    """A PLUTO-Chombo AMR frame as readPlutoChombo holds it after its HDF5 reads (Src/mclib_pluto.c:60-430): per level
+    the "boxes" (lo_i, lo_j, [lo_k], hi_i, hi_j, [hi_k]), "data:offsets=0" and "data:datatype=0" (per box, variable-major,
+    x fastest) datasets and the attributes prob_domain, ref_ratio, dx, logr, domBeg1-3, g_x2stretch, g_x3stretch.
+    Level 0 tiles n0 cells over [lo, hi] (physical units; lengths are stored / l_scale) with boxes of `box` cells per side;
+    level l+1 refines (ratio 2) every level-l box whose centre lies in the lowest refine_below[l] fraction of axis 1's
+    range (the jet axis region), so the levels are properly nested.  Axis 0 may be logarithmic (logr, :454-457)."""
+    rng = np.random.default_rng(seed)
+    three = dimensions == THREE
+    nd = 3 if three else 2
+    length = {CARTESIAN: (1, 1, 1), CYLINDRICAL: (1, 1, 1), SPHERICAL: (1, 0, 0), POLAR: (1, 0, 1)}[geometry]
+    lo_c = [lo[a] / l_scale if length[a] else lo[a] for a in range(nd)]
+    hi_c = [hi[a] / l_scale if length[a] else hi[a] for a in range(nd)]
+    if logr:
+        dx0 = np.log(hi_c[0] / lo_c[0]) / n0[0]
+    else:
+        dx0 = (hi_c[0] - lo_c[0]) / n0[0]
+    stretch = [1.0] + [((hi_c[a] - lo_c[a]) / n0[a]) / dx0 for a in range(1, nd)]
+    names = [v for v in var_names if three or dimensions == TWO_POINT_FIVE or v != "vx3"]
+    nv = len(names)
+
+    def centres(level, a, idx):
+        dx = dx0 / 2 ** level
+        if a == 0 and logr:
+            return lo_c[0] * 0.5 * (np.exp(dx * (idx + 1)) + np.exp(dx * idx))
+        return lo_c[a] + dx * stretch[a] * (idx + 0.5)
+
+    out_levels = []
+    # level 0 boxes
+    counts = [n0[a] // box for a in range(nd)]
+    grids = np.meshgrid(*[np.arange(counts[a]) * box for a in reversed(range(nd))], indexing="ij")
+    los = np.stack([g.ravel() for g in reversed(grids)], axis=1)            # (n_boxes, nd), axis 0 fastest
+    for level in range(levels):
+        n_boxes = len(los)
+        boxes = np.concatenate([los, los + box - 1], axis=1).astype(np.int32)
+        cells_per_box = box ** nd
+        offsets = (np.arange(n_boxes) * cells_per_box * nv).astype(np.int32)
+        # cell positions of every box: index arrays with axis 0 fastest
+        loc = np.meshgrid(*[np.arange(box) for _ in range(nd)], indexing="ij")           # [k][j][i] order for nd=3
+        rel = [loc[nd - 1 - a].ravel() for a in range(nd)]                                # rel[a]: offset along axis a, x fastest
+        idx = [los[:, a, None] + rel[a][None, :] for a in range(nd)]                      # (n_boxes, cells_per_box)
+        phys = [centres(level, a, idx[a]) * (l_scale if length[a] else 1.0) for a in range(nd)]
+        if geometry == SPHERICAL:
+            px, py = phys[0] * np.sin(phys[1]), phys[0] * np.cos(phys[1])
+        elif geometry == POLAR:
+            px, py = phys[0], phys[2]
+        else:
+            px, py = phys[0], (phys[2] if (three and geometry == CARTESIAN) else phys[1])
+        f = _raw_fluid(px, py, rng, v3=True)
+        f["tr1"] = np.full_like(px, 1.0 + level)
+        data = np.stack([f[v] for v in names], axis=1).reshape(-1)                        # per box: variable-major
+        ext = [n0[a] * 2 ** level for a in range(nd)]
+        out_levels.append(dict(boxes=boxes, box_offsets=offsets, data=data, prob_domain=[0] * nd + [e - 1 for e in ext],
+                               ref_ratio=2, logr=int(bool(logr)), dx=dx0 / 2 ** level, dombeg1=lo_c[0], dombeg2=lo_c[1],
+                               dombeg3=lo_c[2] if three else 0.0, g_x2stretch=stretch[1], g_x3stretch=stretch[2] if three else 1.0))
+        if level + 1 < levels:
+            frac = refine_below[min(level, len(refine_below) - 1)]
+            mid1 = (los[:, 1] + 0.5 * box) / ext[1]
+            chosen = los[mid1 < frac]
+            kids = np.meshgrid(*[np.array([0, box]) for _ in range(nd)], indexing="ij")
+            kid = np.stack([kids[nd - 1 - a].ravel() for a in range(nd)], axis=1)         # (2^nd, nd)
+            los = (2 * chosen[:, None, :] + kid[None, :, :]).reshape(-1, nd)
+    return dict(kind="chombo", levels=out_levels, var_names=names, l_scale=float(l_scale), d_scale=1.0, p_scale=C_LIGHT ** 2)
+
+
 # --------------------------------------------------------------------------- fluids
 def _radial_velocity(frame, vel):
     dims, geom = frame["dimensions"], frame["geometry"]

@@ -216,6 +216,26 @@ typedef struct orc_pluto_grid {
     double l_scale, d_scale, p_scale;
     int cyclosynchrotron;
 } orc_pluto_grid;
+/* a PLUTO-Chombo frame as readPlutoChombo holds it after its H5Dread / H5Aread calls (mclib_pluto.c:60-430) */
+typedef struct orc_chombo_level {
+    int n_boxes;
+    const int *boxes;            /* n_boxes x {lo_i, lo_j, [lo_k], hi_i, hi_j, [hi_k]}: "boxes" */
+    const int *box_offsets;      /* "data:offsets=0": where each box's data starts within the level, in doubles */
+    long long data_len;          /* length of "data:datatype=0" */
+    int prob_domain[6];          /* same member order as a box */
+    int ref_ratio, logr;
+    double dx, dombeg1, dombeg2, dombeg3, g_x2stretch, g_x3stretch;
+} orc_chombo_level;
+typedef struct orc_chombo {
+    int num_levels, num_vars;
+    const orc_chombo_level *levels;
+    const char *const *var_names;    /* component_0 ... */
+    const double *data;              /* the levels' "data:datatype=0", level 0 first (all_data, :151-155,:360) */
+    double l_scale, d_scale, p_scale;
+    int cyclosynchrotron;
+} orc_chombo;
+int  orc_chombo_select(const orc_config *c, const orc_chombo *h, const orc_slab *s, int max_elem_factor, orc_frame *out, int *elem_factor_out);
+
 #define ORC_SCIENCE                       0
 #define ORC_CYLINDRICAL_OUTFLOW           1
 #define ORC_SPHERICAL_OUTFLOW             2

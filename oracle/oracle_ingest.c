@@ -330,3 +330,144 @@ void orc_hydro_post_read(const orc_config *c, const orc_outflow *o, orc_frame *f
     else if (o->simulation_type == ORC_SPHERICAL_OUTFLOW) orc_sphericalPrep(c, o, f);
     else if (o->simulation_type == ORC_STRUCTURED_SPHERICAL_OUTFLOW) orc_structuredFireballPrep(c, o, f);
 }
+
+/* readPlutoChombo, mclib_pluto.c:12-801, after its HDF5 reads: per level the "boxes", "data:offsets=0" and
+ * "data:datatype=0" datasets and the attributes prob_domain, ref_ratio, dx, logr, domBeg1-3, g_x2stretch, g_x3stretch; the
+ * component names.  Cells are numbered level by level (level 0 first, :151-155), box by box, x fastest (:520-545).
+ * Reference behaviour kept on purpose: cells of a level that a finer level covers (good_node_buffer == 0, :206-345) are
+ * dropped only in the injection-frame branch (ph_inj_switch != 0, :672 / :745); the photons'-slab branch (:659 / :703)
+ * does not look at the mask, so covered coarse cells stay in the frame there. */
+int orc_chombo_select(const orc_config *c, const orc_chombo *h, const orc_slab *s, int max_elem_factor, orc_frame *out, int *elem_factor_out)
+{
+    const int three = c->dimensions == ORC_THREE, v3 = c->dimensions != ORC_TWO, num_vars = h->num_vars, nl = h->num_levels;
+    const int bi = three ? 6 : 4;                       /* ints per box: lo_i, lo_j, [lo_k], hi_i, hi_j, [hi_k] */
+    long long total_size = 0;
+    long long *start_displacement = (long long *)calloc((size_t)nl, sizeof(long long));
+    int i, j, k, l, m, n;
+    for (i = 0; i < nl; i++) { start_displacement[i] = total_size; total_size += h->levels[i].data_len; }      /* :128-155 */
+    const long long cells = total_size / num_vars;
+    double *x1b = col((int)cells), *x2b = col((int)cells), *x3b = col((int)cells), *dx1b = col((int)cells), *dx2b = col((int)cells), *dx3b = col((int)cells);
+    double *densb = col((int)cells), *presb = col((int)cells), *v1b = col((int)cells), *v2b = col((int)cells), *v3b = col((int)cells);
+    int *good = (int *)malloc(sizeof(int) * (size_t)(cells > 0 ? cells : 1));
+    for (long long q = 0; q < cells; q++) good[q] = 1;                                                           /* :195-198 */
+#define LO(b, a) ((b)[(a)])
+#define HI(b, a) ((b)[(three ? 3 : 2) + (a)])
+    for (i = nl - 2; i >= 0; i--) {                                                                              /* :206-345 */
+        const orc_chombo_level *Li = &h->levels[i], *Lp = &h->levels[i + 1];
+        const int ref_ratio = Li->ref_ratio;
+        const long long offset = start_displacement[i];
+        for (j = 0; j < Li->n_boxes; j++) {
+            const int *bj = Li->boxes + (size_t)j * bi;
+            const int nbx = HI(bj, 0) - LO(bj, 0) + 1, nby = HI(bj, 1) - LO(bj, 1) + 1, nbz = three ? HI(bj, 2) - LO(bj, 2) + 1 : 1;
+            for (k = 0; k < Lp->n_boxes; k++) {
+                const int *bk = Lp->boxes + (size_t)k * bi;
+                int overlap = (ref_ratio * HI(bj, 0) >= LO(bk, 0)) && (ref_ratio * LO(bj, 0) <= HI(bk, 0)) &&
+                              (ref_ratio * HI(bj, 1) >= LO(bk, 1)) && (ref_ratio * LO(bj, 1) <= HI(bk, 1));
+                if (three) overlap = overlap && (ref_ratio * HI(bj, 2) >= LO(bk, 2)) && (ref_ratio * LO(bj, 2) <= HI(bk, 2));
+                if (!overlap) continue;
+                for (l = 0; l < nbz; l++)
+                    for (m = 0; m < nby; m++)
+                        for (n = 0; n < nbx; n++) {
+                            const int idx1 = ref_ratio * (LO(bj, 0) + n), idx2 = ref_ratio * (LO(bj, 1) + m), idx3 = three ? ref_ratio * (LO(bj, 2) + l) : 0;
+                            int inside = (HI(bk, 0) >= idx1) && (LO(bk, 0) <= idx1) && (HI(bk, 1) >= idx2) && (LO(bk, 1) <= idx2);
+                            if (three) inside = inside && (HI(bk, 2) >= idx3) && (LO(bk, 2) <= idx3);
+                            if (inside) good[(offset + Li->box_offsets[j]) / num_vars + (long long)l * nbx * nby + (long long)m * nbx + n] = 0;
+                        }
+            }
+        }
+    }
+    int kv[5] = {-1, -1, -1, -1, -1};                   /* rho, vx1, vx2, vx3, prs by component name (:547-590) */
+    for (k = 0; k < num_vars; k++) {
+        if (strcmp(h->var_names[k], "rho") == 0) kv[0] = k;
+        else if (strcmp(h->var_names[k], "vx1") == 0) kv[1] = k;
+        else if (strcmp(h->var_names[k], "vx2") == 0) kv[2] = k;
+        else if (strcmp(h->var_names[k], "vx3") == 0) kv[3] = k;
+        else if (strcmp(h->var_names[k], "prs") == 0) kv[4] = k;
+    }
+    for (i = nl - 1; i >= 0; i--) {                                                                              /* :349-623 */
+        const orc_chombo_level *L = &h->levels[i];
+        const long long offset = start_displacement[i];
+        const int n1 = L->prob_domain[three ? 3 : 2] - L->prob_domain[0] + 1, n2 = L->prob_domain[(three ? 3 : 2) + 1] - L->prob_domain[1] + 1;
+        const int n3 = three ? L->prob_domain[5] - L->prob_domain[2] + 1 : 1;
+        double *x1a = col(n1), *dx1a = col(n1), *x2a = col(n2), *dx2a = col(n2), *x3a = col(n3), *dx3a = col(n3);
+        for (j = 0; j < n1; j++) {                                                                               /* :446-466 */
+            if (L->logr == 0) {
+                x1a[j] = L->dombeg1 + L->dx * (L->prob_domain[0] + j + 0.5);
+                dx1a[j] = L->dx;
+            } else {
+                x1a[j] = L->dombeg1 * 0.5 * (exp(L->dx * (L->prob_domain[0] + j + 1)) + exp(L->dx * (L->prob_domain[0] + j)));
+                dx1a[j] = L->dombeg1 * (exp(L->dx * (L->prob_domain[0] + j + 1)) - exp(L->dx * (L->prob_domain[0] + j)));
+            }
+        }
+        for (j = 0; j < n2; j++) {                                                                               /* :477-480 */
+            x2a[j] = L->dombeg2 + L->dx * L->g_x2stretch * (L->prob_domain[1] + j + 0.5);
+            dx2a[j] = L->dx * L->g_x2stretch;
+        }
+        for (j = 0; three && j < n3; j++) {                                                                      /* :499-502 */
+            x3a[j] = L->dombeg3 + L->dx * L->g_x3stretch * (L->prob_domain[2] + j + 0.5);
+            dx3a[j] = L->dx * L->g_x3stretch;
+        }
+        for (j = 0; j < L->n_boxes; j++) {                                                                       /* :520-612 */
+            const int *b = L->boxes + (size_t)j * bi;
+            const int nbx = HI(b, 0) - LO(b, 0) + 1, nby = HI(b, 1) - LO(b, 1) + 1, nbz = three ? HI(b, 2) - LO(b, 2) + 1 : 1;
+            for (l = 0; l < nbz; l++)
+                for (m = 0; m < nby; m++)
+                    for (n = 0; n < nbx; n++) {
+                        const long long q = (offset + L->box_offsets[j]) / num_vars + (long long)l * nbx * nby + (long long)m * nbx + n;
+                        const long long d = offset + L->box_offsets[j] + (long long)l * nbx * nby + (long long)m * nbx + n;
+                        const long long vs = (long long)nbx * nby * nbz;
+                        x1b[q] = x1a[LO(b, 0) + n]; x2b[q] = x2a[LO(b, 1) + m];
+                        dx1b[q] = dx1a[LO(b, 0) + n]; dx2b[q] = dx2a[LO(b, 1) + m];
+                        if (three) { x3b[q] = x3a[LO(b, 2) + l]; dx3b[q] = dx3a[LO(b, 2) + l]; }
+                        x1b[q] *= h->l_scale; dx1b[q] *= h->l_scale;
+                        if (c->geometry == ORC_CARTESIAN || c->geometry == ORC_CYLINDRICAL) { x2b[q] *= h->l_scale; dx2b[q] *= h->l_scale; }
+                        if (three && (c->geometry == ORC_CARTESIAN || c->geometry == ORC_POLAR)) { x3b[q] *= h->l_scale; dx3b[q] *= h->l_scale; }
+                        if (kv[0] >= 0) densb[q] = h->data[d + kv[0] * vs] * h->d_scale;
+                        if (kv[1] >= 0) v1b[q] = h->data[d + kv[1] * vs];
+                        if (kv[2] >= 0) v2b[q] = h->data[d + kv[2] * vs];
+                        if (kv[4] >= 0) presb[q] = h->data[d + kv[4] * vs] * h->p_scale;
+                        if (v3 && kv[3] >= 0) v3b[q] = h->data[d + kv[3] * vs];
+                    }
+        }
+        free(x1a); free(dx1a); free(x2a); free(dx2a); free(x3a); free(dx3a);
+    }
+#undef LO
+#undef HI
+    int elem_factor = h->cyclosynchrotron ? 2 : 0, r_count = 0;                                                  /* :635-687 */
+    while (r_count == 0) {
+        r_count = 0;
+        elem_factor++;
+        if (elem_factor > max_elem_factor) break;
+        for (long long q = 0; q < cells; q++)
+            if (in_slab(c, s, elem_factor, x1b[q], x2b[q], x3b[q], dx1b[q], dx2b[q], dx3b[q], 1) && (s->ph_inj_switch == 0 || good[q] != 0)) r_count++;
+    }
+    int rc = 0;
+    if (r_count == 0) { rc = -1; frame_alloc(out, 0); }
+    else {
+        frame_alloc(out, r_count);
+        j = 0;
+        for (long long q = 0; q < cells; q++) {                                                                  /* :691-793 */
+            if (!(in_slab(c, s, elem_factor, x1b[q], x2b[q], x3b[q], dx1b[q], dx2b[q], dx3b[q], 1) && (s->ph_inj_switch == 0 || good[q] != 0))) continue;
+            out->pres[j] = presb[q];
+            out->v0[j] = v1b[q];
+            out->v1[j] = v2b[q];
+            out->dens[j] = densb[q];
+            out->r0[j] = x1b[q];
+            out->r1[j] = x2b[q];
+            out->r[j] = x1b[q];
+            out->theta[j] = x2b[q];
+            out->r0_size[j] = dx1b[q];
+            out->r1_size[j] = dx2b[q];
+            out->gamma[j] = 1 / sqrt(1.0 - (v1b[q] * v1b[q] + v2b[q] * v2b[q]));
+            out->dens_lab[j] = densb[q] / sqrt(1.0 - (v1b[q] * v1b[q] + v2b[q] * v2b[q]));
+            out->temp[j] = pow(3 * presb[q] / (ORC_A_RAD), 1.0 / 4.0);
+            if (three) { out->r2[j] = x3b[q]; out->r2_size[j] = dx3b[q]; }
+            if (v3) out->v2[j] = v3b[q];
+            j++;
+        }
+    }
+    if (elem_factor_out) *elem_factor_out = elem_factor;
+    free(start_displacement); free(good);
+    free(x1b); free(x2b); free(x3b); free(dx1b); free(dx2b); free(dx3b); free(densb); free(presb); free(v1b); free(v2b); free(v3b);
+    return rc;
+}

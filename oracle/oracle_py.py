@@ -94,6 +94,49 @@ class PlutoGrid(C.Structure):
                [("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double), ("cyclosynchrotron", C.c_int)]
 
 
+class ChomboLevel(C.Structure):
+    _fields_ = [("n_boxes", C.c_int), ("boxes", C.POINTER(C.c_int)), ("box_offsets", C.POINTER(C.c_int)), ("data_len", C.c_longlong),
+                ("prob_domain", C.c_int * 6), ("ref_ratio", C.c_int), ("logr", C.c_int),
+                ("dx", C.c_double), ("dombeg1", C.c_double), ("dombeg2", C.c_double), ("dombeg3", C.c_double),
+                ("g_x2stretch", C.c_double), ("g_x3stretch", C.c_double)]
+
+
+class Chombo(C.Structure):
+    _fields_ = [("num_levels", C.c_int), ("num_vars", C.c_int), ("levels", C.POINTER(ChomboLevel)), ("var_names", C.POINTER(C.c_char_p)),
+                ("data", C.POINTER(C.c_double)), ("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double),
+                ("cyclosynchrotron", C.c_int)]
+
+
+def fill_chombo(raw, level_type, top_type, keep):
+    """a ctypes view (oracle's orc_chombo or the engine's mcrat_hip_chombo: same members) of a synth.chombo_raw dict"""
+    nl = len(raw["levels"])
+    levels = (level_type * nl)()
+    for i, lv in enumerate(raw["levels"]):
+        boxes = np.ascontiguousarray(lv["boxes"], dtype=np.int32)
+        offs = np.ascontiguousarray(lv["box_offsets"], dtype=np.int32)
+        keep += [boxes, offs]
+        L = levels[i]
+        L.n_boxes = boxes.shape[0]
+        L.boxes = boxes.ctypes.data_as(C.POINTER(C.c_int))
+        L.box_offsets = offs.ctypes.data_as(C.POINTER(C.c_int))
+        L.data_len = int(len(lv["data"]))
+        for k in range(6):
+            L.prob_domain[k] = int(lv["prob_domain"][k]) if k < len(lv["prob_domain"]) else 0
+        L.ref_ratio, L.logr = int(lv["ref_ratio"]), int(lv["logr"])
+        for k in ("dx", "dombeg1", "dombeg2", "dombeg3", "g_x2stretch", "g_x3stretch"):
+            setattr(L, k, float(lv.get(k, 0.0)))
+    data = np.ascontiguousarray(np.concatenate([np.asarray(lv["data"], dtype=np.float64) for lv in raw["levels"]]))
+    names = (C.c_char_p * len(raw["var_names"]))(*[v.encode() for v in raw["var_names"]])
+    keep += [levels, data, names]
+    h = top_type()
+    h.num_levels, h.num_vars = nl, len(raw["var_names"])
+    h.levels = levels
+    h.var_names = names
+    h.data = data.ctypes.data_as(C.POINTER(C.c_double))
+    h.l_scale, h.d_scale, h.p_scale = float(raw.get("l_scale", 1.0)), float(raw.get("d_scale", 1.0)), float(raw.get("p_scale", 1.0))
+    return h
+
+
 class Outflow(C.Structure):
     _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
                 ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
@@ -166,6 +209,7 @@ def lib():
             "orc_photon_loop": (None, [cfgp, lp, hp, rp, _dp, _dp, C.POINTER(i), C.c_longlong, C.c_uint64, sp]),
             "orc_flash_select": (i, [cfgp, C.POINTER(FlashBlocks), C.POINTER(Slab), i, C.POINTER(Frame), C.POINTER(i)]),
             "orc_pluto_select": (i, [cfgp, C.POINTER(PlutoGrid), C.POINTER(Slab), i, C.POINTER(Frame), C.POINTER(i)]),
+            "orc_chombo_select": (i, [cfgp, C.POINTER(Chombo), C.POINTER(Slab), i, C.POINTER(Frame), C.POINTER(i)]),
             "orc_frame_free": (None, [C.POINTER(Frame)]),
             "orc_outflow_defaults": (None, [i, C.POINTER(Outflow)]),
             "orc_hydro_post_read": (None, [cfgp, C.POINTER(Outflow), C.POINTER(Frame)]),
@@ -310,6 +354,10 @@ def hydro_ingest(cfg, raw, slab, outflow_params=None, max_elem_factor=1000):
         b.l_scale, b.d_scale, b.p_scale = scales["l_scale"], scales["d_scale"], scales["p_scale"]
         b.cyclosynchrotron = int(raw.get("cyclosynchrotron", 0))
         rc = L.orc_flash_select(C.byref(cfg), C.byref(b), C.byref(s), int(max_elem_factor), C.byref(out), C.byref(ef))
+    elif raw["kind"] == "chombo":
+        h = fill_chombo(raw, ChomboLevel, Chombo, keep)
+        h.cyclosynchrotron = int(raw.get("cyclosynchrotron", 0))
+        rc = L.orc_chombo_select(C.byref(cfg), C.byref(h), C.byref(s), int(max_elem_factor), C.byref(out), C.byref(ef))
     else:
         g = PlutoGrid()
         g.nx, g.ny, g.nz = int(raw["nx"]), int(raw["ny"]), int(raw.get("nz", 1))

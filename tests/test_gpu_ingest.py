@@ -110,6 +110,59 @@ def test_pluto_selection_matches_the_reader(hip, oracle, case, switch):
     e.close()
 
 
+CHOMBO_CASES = {
+    "2d-spherical-logr": (synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.8), (64, 32), True),
+    "2d-cylindrical": (synth.TWO, synth.CYLINDRICAL, (0.0, 8e11), (4e11, 1.6e12), (32, 64), False),
+    "25d-spherical": (synth.TWO_POINT_FIVE, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.8), (64, 32), False),
+    "3d-spherical-logr": (synth.THREE, synth.SPHERICAL, (2e11, 0.0, 0.0), (3e12, 0.8, 2 * np.pi), (32, 16, 16), True),
+    "3d-cartesian": (synth.THREE, synth.CARTESIAN, (-4e11, 0.0, 8e11), (4e11, 8e11, 1.6e12), (16, 16, 16), False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CHOMBO_CASES))
+@pytest.mark.parametrize("switch", [0, 1])
+def test_pluto_chombo_selection_matches_the_reader(hip, oracle, case, switch):
+    """AMR levels, box by box; coarse cells under a finer level are dropped in injection frames only (as the reference)"""
+    dims, geom, lo, hi, n0, logr = CHOMBO_CASES[case]
+    raw = synth.chombo_raw(dims, geom, lo, hi, n0, seed=6, logr=logr)
+    slab = dict(r_inj=1e12, ph_inj_switch=switch, min_r=0.97e12, max_r=1.01e12, min_theta=0.01, max_theta=0.12, fps=5.0)
+    e, got, ref, cells = _ingest_both(hip, oracle, dims, geom, raw, slab)
+    assert cells == sum(len(lv["data"]) for lv in raw["levels"]) // len(raw["var_names"])
+    assert 0 < got["num_elements"] < cells
+    assert len(np.unique(got["r1_size"])) == 3                      # cells of all three levels are in the frame
+    _compare(got, ref)
+    e.close()
+
+
+def test_pluto_chombo_injection_frame_tiles_the_domain_once(hip, oracle):
+    """with the mask (ph_inj_switch = 1) and r_inj = 0 every point of the domain is in exactly one selected cell: the
+    selected cells' areas add up to the domain's; without it (the photons'-slab branch, whole domain) refined regions are
+    counted once per level, as the reference does"""
+    dims, geom, lo, hi, n0, logr = CHOMBO_CASES["2d-cylindrical"]
+    raw = synth.chombo_raw(dims, geom, lo, hi, n0, seed=6, logr=logr)
+    area = (hi[0] - lo[0]) * (hi[1] - lo[1])
+    e, got, ref, cells = _ingest_both(hip, oracle, dims, geom, raw, dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0))
+    assert got["num_elements"] < cells
+    assert np.isclose((got["r0_size"] * got["r1_size"]).sum(), area, rtol=1e-12)
+    _compare(got, ref)
+    e.close()
+    e, got, ref, cells = _ingest_both(hip, oracle, dims, geom, raw, dict(r_inj=0.0, ph_inj_switch=0, min_r=0.0, max_r=1e14, min_theta=0.0, max_theta=3.2, fps=5.0))
+    assert got["num_elements"] == cells
+    assert np.isclose((got["r0_size"] * got["r1_size"]).sum(), area * (1 + 0.5 + 0.25), rtol=1e-12)
+    e.close()
+    # malformed frames are refused, not read out of bounds
+    bad = dict(raw, levels=[dict(lv) for lv in raw["levels"]])
+    bad["levels"][1]["boxes"] = bad["levels"][1]["boxes"].copy()
+    bad["levels"][1]["boxes"][3, 2] += 10000                        # hi_i beyond the level's prob_domain
+    e = hip.Engine(dims, geom, 0)
+    with pytest.raises(hip.McratHipError):
+        e.ingest(bad, dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0, **DOMAINS))
+    bad = dict(raw, var_names=["rho", "vx1", "vx2", "pressure", "tr1"])
+    with pytest.raises(hip.McratHipError):
+        e.ingest(bad, dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0, **DOMAINS))
+    e.close()
+
+
 @pytest.mark.parametrize("outflow", [1, 2, 3])
 @pytest.mark.parametrize("mesh", ["flash", "pluto-2d-spherical", "pluto-3d-cartesian", "pluto-3d-polar"])
 def test_analytic_outflows_overwrite_the_selected_frame(hip, oracle, outflow, mesh):

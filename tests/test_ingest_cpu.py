@@ -127,6 +127,43 @@ def test_analytic_outflows_follow_the_closed_forms(oracle, geom):
         assert np.allclose(cyl["v0"], vel * np.cos(cyl["r1"])) and np.allclose(cyl["v1"], -vel * np.sin(cyl["r1"]))
 
 
+@pytest.mark.parametrize("case", ["2d-cylindrical", "3d-spherical-logr"])
+def test_chombo_levels_boxes_and_the_covered_cell_mask(oracle, case):
+    """readPlutoChombo (mclib_pluto.c:12-801): an injection frame (mask on) tiles the domain exactly once with cells of all
+    levels; coordinates follow domBeg + dx (i + 1/2) or the logarithmic radial rule; the photons'-slab branch keeps covered
+    coarse cells (reference behaviour)"""
+    if case == "2d-cylindrical":
+        dims, geom, lo, hi, n0, logr = synth.TWO, synth.CYLINDRICAL, (0.0, 8e11), (4e11, 1.6e12), (32, 64), False
+    else:
+        dims, geom, lo, hi, n0, logr = synth.THREE, synth.SPHERICAL, (2e11, 0.0, 0.0), (3e12, 0.8, 2 * np.pi), (32, 16, 16), True
+    raw = synth.chombo_raw(dims, geom, lo, hi, n0, seed=2, logr=logr)
+    cfg = oracle.make_config(dims, geom, 0)
+    cells = sum(len(lv["data"]) for lv in raw["levels"]) // len(raw["var_names"])
+    tiled, ef = oracle.hydro_ingest(cfg, raw, _slab(ph_inj_switch=1, r_inj=0.0))
+    assert ef == 1 and tiled["num_elements"] < cells
+    lo0, hi0 = tiled["r0"] - 0.5 * tiled["r0_size"], tiled["r0"] + 0.5 * tiled["r0_size"]
+    if logr:                                            # cell edges are lo * exp(dx i): measure in ln r
+        m0, total0 = np.log(hi0 / lo0), np.log(hi[0] / lo[0])
+        assert np.allclose(tiled["r0"], 0.5 * (lo0 + hi0), rtol=1e-14)
+    else:
+        m0, total0 = tiled["r0_size"], hi[0] - lo[0]
+    measure = m0 * tiled["r1_size"] * (tiled["r2_size"] if dims == synth.THREE else 1.0)
+    total = total0 * (hi[1] - lo[1]) * ((hi[2] - lo[2]) if dims == synth.THREE else 1.0)
+    assert np.isclose(measure.sum(), total, rtol=1e-11)
+    assert len(np.unique(np.round(tiled["r1_size"] / tiled["r1_size"].min()))) == 3      # three levels, ratio 2
+    assert lo0.min() >= lo[0] * (1 - 1e-12) and hi0.max() <= hi[0] * (1 + 1e-12)
+    # every cell of the file in file order: level 0 first, boxes of 8^d cells, x fastest
+    allc, _ = oracle.hydro_ingest(cfg, raw, _slab(min_r=0.0, max_r=1e14, min_theta=0.0, max_theta=3.2))
+    assert allc["num_elements"] == cells
+    lv0 = raw["levels"][0]
+    n_lv0 = len(lv0["data"]) // len(raw["var_names"])
+    assert len(np.unique(allc["r1_size"][:n_lv0])) == 1 and allc["r1_size"][:n_lv0][0] == allc["r1_size"].max()
+    assert (np.diff(allc["r0"][:8]) > 0).all() and allc["r1"][0] == allc["r1"][7]
+    k = raw["var_names"].index("rho")
+    nd = 3 if dims == synth.THREE else 2
+    assert np.array_equal(allc["dens"][:8 ** nd], lv0["data"][k * 8 ** nd:(k + 1) * 8 ** nd] * raw["d_scale"])     # variable-major per box
+
+
 # ---------------------------------------------------------------------------------------------- PLUTO files
 class PlutoGrid(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int)] + \
