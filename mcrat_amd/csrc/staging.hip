@@ -63,19 +63,28 @@ __global__ __launch_bounds__(256) void soa_to_aos_kernel(PhotonDev ph, mcrat_hip
 
 // printPhotons' gathering loop (mcrat_io.c:137-181): the photons with weight != 0, in slot order, as the arrays it hands to
 // H5Dwrite.  Pass 1 counts per workgroup, a scan places the workgroups, pass 2 writes.
+// (a workgroup counts OUT_CHUNKS chunks of 256 slots -- the unit pass 2 runs over -- and adds to the total once:
+// same-address atomics serialise)
+constexpr int OUT_CHUNKS = 8;
 __global__ __launch_bounds__(256) void output_count_kernel(PhotonDev ph, int n, unsigned *__restrict__ block_count, unsigned long long *__restrict__ total)
 {
-    __shared__ unsigned s_w[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool keep = i < n && ph.weight[i] != 0;
-    const unsigned long long m = __ballot(keep);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = (unsigned)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned c = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        block_count[blockIdx.x] = c;
-        if (c) atomicAdd(total, (unsigned long long)c);
+    __shared__ unsigned s_w[OUT_CHUNKS][4];
+    const int chunks = (n + 255) / 256;
+    for (int c = 0; c < OUT_CHUNKS; ++c) {
+        const int i = (blockIdx.x * OUT_CHUNKS + c) * 256 + threadIdx.x;
+        const bool keep = i < n && ph.weight[i] != 0;
+        const unsigned long long m = __ballot(keep);
+        if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = (unsigned)__popcll(m);
     }
+    __syncthreads();
+    unsigned cnt = 0;
+    if (threadIdx.x < OUT_CHUNKS) {
+        const int chunk = blockIdx.x * OUT_CHUNKS + threadIdx.x;
+        cnt = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+        if (chunk < chunks) block_count[chunk] = cnt;
+    }
+    for (int off = OUT_CHUNKS / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if (threadIdx.x == 0 && cnt) atomicAdd(total, (unsigned long long)cnt);
 }
 
 __global__ __launch_bounds__(256) void output_write_kernel(PhotonDev ph, int n, const int *__restrict__ block_start, OutputCols out)
@@ -135,7 +144,7 @@ hipError_t launch_output_count(const PhotonDev &ph, int n, unsigned *block_count
 {
     hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream);
     if (e != hipSuccess) return e;
-    output_count_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(ph, n, block_count, d_total);
+    output_count_kernel<<<dim3(((n + 255) / 256 + OUT_CHUNKS - 1) / OUT_CHUNKS), dim3(256), 0, stream>>>(ph, n, block_count, d_total);
     return hipGetLastError();
 }
 

@@ -102,7 +102,36 @@ def trajectory(name):
     return out
 
 
+# hydro ingest: reader buffers from mcrat_amd.synth (seeded) -> the frame getHydroData would hand to the loop
+INGEST = {
+    "flash": (synth.TWO, synth.CYLINDRICAL, lambda: synth.flash_raw_blocks(2e9, 8, 16, 8, 1e12 - 1.6e10, seed=21),
+              dict(r_inj=1e12, ph_inj_switch=0, min_r=0.995e12, max_r=1.002e12, min_theta=0.0, max_theta=0.04, fps=5.0), (3, dict(lumi=3e50, theta_j=0.1))),
+    "pluto": (synth.THREE, synth.SPHERICAL, lambda: synth.pluto_raw_grid(synth.THREE, synth.SPHERICAL, (2e11, 0.0, 0.0), (3e12, 0.5, 2 * np.pi), (40, 16, 12), seed=22, log_axis0=True),
+              dict(r_inj=1e12, ph_inj_switch=0, min_r=0.97e12, max_r=1.01e12, min_theta=0.01, max_theta=0.12, fps=5.0), None),
+    "chombo": (synth.TWO, synth.SPHERICAL, lambda: synth.chombo_raw(synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.8), (64, 32), seed=23, logr=True),
+               dict(r_inj=1e12, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0), (2, {})),
+}
+INGEST_COLUMNS = ("r0", "r1", "r2", "r0_size", "r1_size", "v0", "v1", "dens_lab", "temp", "gamma", "r", "theta")
+
+
+def ingest_vectors():
+    out = {}
+    for name, (dims, geom, make, slab, flow) in INGEST.items():
+        cfg = O.make_config(dims, geom, 0)
+        cols, ef = O.hydro_ingest(cfg, make(), slab, O.outflow(flow[0], **flow[1]) if flow else None)
+        out[name + "_counts"] = np.array([cols["num_elements"], ef], dtype=np.int64)
+        pick = np.unique(np.linspace(0, cols["num_elements"] - 1, 400).astype(int))      # a thinned sample keeps the fixture small
+        out[name + "_pick"] = pick
+        for k in INGEST_COLUMNS:
+            out[name + "_" + k] = cols[k][pick]
+        out[name + "_sums"] = np.array([cols[k].sum() for k in INGEST_COLUMNS])
+    return out
+
+
 if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "ingest.npz"), **ingest_vectors())
+    if "--ingest-only" in sys.argv:
+        sys.exit(0)
     np.savez_compressed(os.path.join(HERE, "functions.npz"), **function_vectors())
     for name in TRAJECTORIES:
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **trajectory(name))

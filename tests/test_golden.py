@@ -80,3 +80,33 @@ def test_hip_engine_reproduces_trajectory_vectors(name):
         assert _close(out[k], want[k], 1e-9, np.ones_like(want[k])), k
     for k in ("total_optical_depth", "time_to_scatter"):
         assert _close(out[k], want[k], 1e-9), k
+
+
+def test_oracle_reproduces_ingest_vectors(oracle):
+    want = np.load(os.path.join(GOLD, "ingest.npz"))
+    got = mg.ingest_vectors()
+    assert set(got) == set(want.files)
+    for k in want.files:
+        if k.endswith(("_counts", "_pick")):
+            assert np.array_equal(got[k], want[k]), k
+        else:
+            assert np.allclose(got[k], want[k], rtol=1e-12, atol=1e-300), k
+    assert all(want[n + "_counts"][0] > 100 for n in mg.INGEST)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(mg.INGEST))
+def test_hip_engine_reproduces_ingest_vectors(name):
+    from mcrat_amd import engine
+    want = np.load(os.path.join(GOLD, "ingest.npz"))
+    dims, geom, make, slab, flow = mg.INGEST[name]
+    e = engine.Engine(dims, geom, 0)
+    n, ef, _ = e.ingest(make(), dict(slab, r0_domain=(0.0, 5e12), r1_domain=(0.0, 2.5e13), r2_domain=(0.0, 7.0)),
+                        engine.Engine.outflow(flow[0], **flow[1]) if flow else None)
+    assert [n, ef] == list(want[name + "_counts"])
+    cols = e.get_hydro()
+    pick = want[name + "_pick"]
+    for k in mg.INGEST_COLUMNS:
+        assert np.allclose(cols[k][pick], want[name + "_" + k], rtol=1e-12, atol=1e-300), k
+    assert np.allclose([cols[k].sum() for k in mg.INGEST_COLUMNS], want[name + "_sums"], rtol=1e-11, atol=1e-300)
+    e.close()
