@@ -167,11 +167,33 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(GridPlan p, const CellGe
 
 __device__ __forceinline__ double mapped(double x, int logmap) { return logmap ? log(fmax(x, 1e-300)) : x; }
 
-// one thread per bucket: order its entries by cell index, write their records, find the octant hints
+// one thread per list entry: the entry's complete cell record (device_types.hpp, FatCell).  Neighbouring threads write
+// neighbouring 96-B records, so the ~4 M x 96 B of a 10^6-cell frame stream out coalesced (one thread per bucket writing
+// its whole list took 650 us per frame, this 130).
+__global__ __launch_bounds__(256) void grid_records_kernel(int naxes, long long total, const int *__restrict__ entries,
+                                                           const CellGeom *__restrict__ geom, const CellGeom2 *__restrict__ geom2,
+                                                           const CellFluid *__restrict__ fluid, const double *__restrict__ fluid_c,
+                                                           FatCell *__restrict__ cells)
+{
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int ci = entries[e];
+    const CellGeom g = geom[ci];
+    const CellFluid f = fluid[ci];
+    FatCell fc;
+    fc.c0 = g.c0; fc.c1 = g.c1; fc.s0 = g.s0; fc.s1 = g.s1;
+    fc.a = f.a; fc.b = f.b; fc.gamma = f.gamma; fc.dens_lab = f.dens_lab;
+    fc.c2 = 0; fc.s2 = 0;
+    if (naxes == 3) { const CellGeom2 g2 = geom2[ci]; fc.c2 = g2.c2; fc.s2 = g2.s2; }
+    fc.fc = fluid_c ? fluid_c[ci] : 0.0;
+    fc.cell = ci; fc.pad = 0;
+    cells[e] = fc;
+}
+
+// one thread per bucket: order its entries by cell index and find the octant hints (from the cells' geometry records)
 __global__ __launch_bounds__(256) void grid_finish_kernel(GridPlan p, long long nb, const int *__restrict__ start, int *__restrict__ entries,
                                                           const CellGeom *__restrict__ geom, const CellGeom2 *__restrict__ geom2,
-                                                          const CellFluid *__restrict__ fluid, const double *__restrict__ fluid_c,
-                                                          FatCell *__restrict__ cells, BucketDir *__restrict__ dir)
+                                                          BucketDir *__restrict__ dir)
 {
     const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
     if (b >= nb) return;
@@ -182,44 +204,44 @@ __global__ __launch_bounds__(256) void grid_finish_kernel(GridPlan p, long long 
         while (j >= 0 && entries[e0 + j] > key) { entries[e0 + j + 1] = entries[e0 + j]; --j; }
         entries[e0 + j + 1] = key;
     }
-    for (int e = 0; e < n; ++e) {
-        const int ci = entries[e0 + e];
-        const CellGeom g = geom[ci];
-        const CellFluid f = fluid[ci];
-        FatCell fc;
-        fc.c0 = g.c0; fc.c1 = g.c1; fc.s0 = g.s0; fc.s1 = g.s1;
-        fc.a = f.a; fc.b = f.b; fc.gamma = f.gamma; fc.dens_lab = f.dens_lab;
-        fc.c2 = 0; fc.s2 = 0;
-        if (p.naxes == 3) { const CellGeom2 g2 = geom2[ci]; fc.c2 = g2.c2; fc.s2 = g2.s2; }
-        fc.fc = fluid_c ? fluid_c[ci] : 0.0;
-        fc.cell = ci; fc.pad = 0;
-        cells[e0 + e] = fc;
-    }
     int bi[3];
     bi[0] = (int)(b % p.dim[0]);
     bi[1] = (int)((b / p.dim[0]) % p.dim[1]);
     bi[2] = (int)(b / ((long long)p.dim[0] * p.dim[1]));
     const int nocts = 1 << p.naxes;
+    // octant o is the half-bucket [olo, olo + w/2) per axis; a hint names the one entry that reaches into it.  Every entry's
+    // mapped extent is computed once and tested against the 2^naxes octants.
+    double olo[3][2] = {{0, 0}, {0, 0}, {0, 0}}, half[3] = {0, 0, 0};
+    for (int k = 0; k < p.naxes; ++k) {
+        const double w = 1.0 / p.inv[k];
+        olo[k][0] = p.org[k] + (bi[k] + 0.0) * w;
+        olo[k][1] = p.org[k] + (bi[k] + 0.5) * w;
+        half[k] = 0.5 * w;
+    }
+    unsigned char cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, first[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int e = 0; e < n; ++e) {
+        const int ci = entries[e0 + e];
+        const CellGeom g = geom[ci];
+        double c2 = 0, s2 = 0;
+        if (p.naxes == 3) { const CellGeom2 g2 = geom2[ci]; c2 = g2.c2; s2 = g2.s2; }
+        const double cc[3] = {g.c0, g.c1, c2}, ss[3] = {g.s0, g.s1, s2};
+        bool r[3][2] = {{true, true}, {true, true}, {true, true}};
+        for (int k = 0; k < p.naxes; ++k) {
+            const double m = 1e-9 * (fabs(cc[k]) + ss[k]);
+            const double clo = mapped(cc[k] - 0.5 * ss[k] + m, p.logmap[k]), chi = mapped(cc[k] + 0.5 * ss[k] - m, p.logmap[k]);
+            for (int h = 0; h < 2; ++h) r[k][h] = (clo < olo[k][h] + half[k]) && (chi > olo[k][h]);
+        }
+        for (int o = 0; o < nocts; ++o) {
+            const bool reaches = r[0][o & 1] && r[1][(o >> 1) & 1] && r[2][(o >> 2) & 1];
+            if (reaches) {
+                if (cnt[o] == 0) first[o] = (unsigned char)(e < (int)GRID_NO_HINT ? e : GRID_NO_HINT);
+                if (cnt[o] < 2) cnt[o] += 1;
+            }
+        }
+    }
     unsigned hints = 0;
     for (int o = 0; o < 8; ++o) {
-        unsigned pick = GRID_NO_HINT;
-        if (o < nocts) {
-            int found = 0;
-            for (int e = 0; e < n && found < 2; ++e) {
-                const FatCell &c = cells[e0 + e];
-                const double cc[3] = {c.c0, c.c1, c.c2}, ss[3] = {c.s0, c.s1, c.s2};
-                bool reaches = true;
-                for (int k = 0; k < p.naxes && reaches; ++k) {
-                    const double w = 1.0 / p.inv[k];
-                    const double olo = p.org[k] + (bi[k] + 0.5 * ((o >> k) & 1)) * w, ohi = olo + 0.5 * w;
-                    const double m = 1e-9 * (fabs(cc[k]) + ss[k]);
-                    const double clo = mapped(cc[k] - 0.5 * ss[k] + m, p.logmap[k]), chi = mapped(cc[k] + 0.5 * ss[k] - m, p.logmap[k]);
-                    reaches = (clo < ohi) && (chi > olo);
-                }
-                if (reaches) { found += 1; if (e < (int)GRID_NO_HINT) pick = (unsigned)e; else found = 2; }
-            }
-            if (found != 1) pick = GRID_NO_HINT;
-        }
+        const unsigned pick = (o < nocts && cnt[o] == 1) ? (unsigned)first[o] : GRID_NO_HINT;
         hints |= pick << (4 * o);
     }
     BucketDir d;
@@ -260,7 +282,9 @@ hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *
     e = hipMemsetAsync(count, 0, sizeof(unsigned) * (size_t)nb, stream);      // now the fill cursors
     if (e != hipSuccess) return e;
     grid_fill_kernel<<<dim3((M + 255) / 256), dim3(256), 0, stream>>>(p, geom, geom2, M, start, count, entries);
-    grid_finish_kernel<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream>>>(p, nb, start, entries, geom, geom2, fluid, fluid_c, cells, dir);
+    grid_finish_kernel<<<dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, stream>>>(p, nb, start, entries, geom, geom2, dir);
+    if (total > 0)
+        grid_records_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream>>>(p.naxes, total, entries, geom, geom2, fluid, fluid_c, cells);
     return hipGetLastError();
 }
 
