@@ -1,0 +1,102 @@
+"""The scatter-frame loop of main() across its three device-side stages (Src/mcrat.c:633-905), end to end on the GPU against
+the oracle doing the same steps: injection frame ingested (ph_inj_switch = 1) -> photonInjection -> for each hydro frame:
+phMinMax -> getHydroData with the photons' slab (ph_inj_switch = 0) -> the photon loop for 1/fps -> frame statistics; then
+the output columns and the checkpoint.  Every stage is compared where the reference hands data from one to the next."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DOM = dict(r0_domain=(1e11, 4e12), r1_domain=(0.0, 0.6), r2_domain=(0.0, 0.0))
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mcrat_amd import engine
+    engine.load_library()
+    return engine
+
+
+def _close(a, b, rtol, scale=None):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    s = np.maximum(np.abs(b), 1e-300) if scale is None else scale
+    bad = np.abs(a - b) > rtol * s
+    assert not bad.any(), (int(bad.sum()), a[bad][:3], b[bad][:3])
+
+
+@pytest.mark.parametrize("kind", ["pluto", "chombo"])
+def test_three_hydro_frames_like_main(hip, oracle, kind):
+    fps, r_inj, frames = 5.0, 1e12, 3
+    if kind == "pluto":
+        raw = synth.pluto_raw_grid(synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.6), (384, 96), seed=31, log_axis0=True)
+    else:
+        raw = synth.chombo_raw(synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.6), (128, 32), seed=31, logr=True, refine_below=(0.6, 0.4))
+    jet = dict(lumi=2e53, theta_j=0.1)                       # dense enough for hundreds of scatterings per frame
+    cfg = oracle.make_config(synth.TWO, synth.SPHERICAL, 1)
+    e = hip.Engine(synth.TWO, synth.SPHERICAL, 1)
+
+    # ---- the injection frame (mcrat.c:633-645)
+    inj = dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps)
+    n_cells, ef, _ = e.ingest(raw, dict(inj, **DOM), hip.Engine.outflow(3, **jet))
+    ref_frame, ef_ref = oracle.hydro_ingest(cfg, raw, inj, oracle.outflow(3, **jet))
+    assert (n_cells, ef) == (ref_frame["num_elements"], ef_ref)
+    n, w = e.inject_photons(r_inj, 1e50, 800, 1600, "b", 0.0, 0.08, fps, seed=404)
+    H = oracle.OracleHydro(dict(ref_frame, **DOM, fps=fps))
+    ref_ph, w_ref = oracle.photon_injection(cfg, H, r_inj, 1e50, 800, 1600, "b", 0.0, 0.08, seed=404)
+    assert (n, w) == (len(ref_ph), w_ref)
+    injected = e.get_photons_aos()
+    _close(injected["r0"], ref_ph["r0"], 1e-11)
+    _close(injected["p0"], ref_ph["p0"], 1e-11)
+    # from here on both sides carry the same list: a 1e-11 difference at injection would be amplified by the boosts
+    P = oracle.OraclePhotons(injected)
+
+    time_now, total_scatt = 0.0, 0
+    for k in range(frames):
+        # ---- phMinMax -> getHydroData(ph_inj_switch = 0) (mcrat.c:704-721)
+        mm = e.ph_minmax()
+        ref_mm = [C.c_double() for _ in range(4)]
+        oracle.lib().orc_phMinMax(C.byref(P.c), *[C.byref(x) for x in ref_mm])
+        _close(mm[:2], [x.value for x in ref_mm[:2]], 1e-13)
+        # theta = acos(z / r) near the axis is ill-conditioned (an ulp of z/r moves a 1e-3 angle by 1e-10 of itself)
+        assert abs(mm[2] - ref_mm[2].value) < 1e-12 and abs(mm[3] - ref_mm[3].value) < 1e-12
+        slab = dict(r_inj=r_inj, ph_inj_switch=0, min_r=mm[0], max_r=mm[1], min_theta=mm[2], max_theta=mm[3], fps=fps)
+        n_cells, ef, _ = e.ingest(raw, dict(slab, **DOM), hip.Engine.outflow(3, **jet))
+        ref_frame, ef_ref = oracle.hydro_ingest(cfg, raw, slab, oracle.outflow(3, **jet))
+        assert (n_cells, ef) == (ref_frame["num_elements"], ef_ref) and n_cells < (raw["nx"] * raw["ny"] if kind == "pluto" else 10 ** 9)
+        # ---- the loop for this hydro frame (mcrat.c:754-851)
+        remaining = (k + 1) / fps - time_now
+        new_time, st = e.propagate_frame(time_now, remaining, seed=1000 + k)
+        H = oracle.OracleHydro(dict(ref_frame, **DOM, fps=fps))
+        ost, otime, orem, _ = oracle.photon_loop(cfg, P, H, seed=1000 + k, time_now=time_now, remaining_time=remaining)
+        assert (st.iterations, st.frame_scatt_cnt, st.num_photons_find_new_element) == (ost.iterations, ost.frame_scatt_cnt, ost.num_photons_find_new_element)
+        assert new_time == pytest.approx(otime, rel=1e-14) and orem <= 0
+        time_now = new_time
+        total_scatt += st.frame_scatt_cnt
+        # ---- phScattStats (mcrat.c:881)
+        mx, mn, avg, ravg = e.scatt_stats()
+        r = [C.c_int(), C.c_int(), C.c_double(), C.c_double()]
+        oracle.lib().orc_phScattStats(C.byref(P.c), *[C.byref(x) for x in r])
+        assert (mx, mn) == (r[0].value, r[1].value) and avg == pytest.approx(r[2].value, rel=1e-12) and ravg == pytest.approx(r[3].value, rel=1e-9)
+    assert total_scatt > 300
+
+    # ---- the lists agree after three frames: integers exact, doubles to 1e-9
+    out = e.get_photons_aos()
+    assert np.array_equal(out["nearest_block_index"], P.aos["nearest_block_index"])
+    assert np.array_equal(out["num_scatt"], P.aos["num_scatt"])
+    p0 = np.abs(P.aos["p0"])
+    for k in ("p0", "p1", "p2", "p3"):
+        _close(out[k], P.aos[k], 1e-9, p0)
+    for k in ("r0", "r1", "r2"):
+        _close(out[k], P.aos[k], 1e-9, np.maximum(np.abs(P.aos[k]), 1e9))
+    for k in ("s0", "s1", "s2", "s3"):
+        _close(out[k], P.aos[k], 1e-9, np.ones(len(out)))
+    # ---- what printPhotons would write
+    cols = e.get_output()
+    keep = P.aos["weight"] != 0
+    assert len(cols["p0"]) == int(keep.sum())
+    _close(cols["comv_p0"], P.aos["comv_p0"][keep], 1e-9, np.abs(P.aos["comv_p0"][keep]))
+    e.close()
