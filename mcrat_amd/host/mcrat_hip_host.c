@@ -362,6 +362,21 @@ done:
     return rc;
 }
 
+/* the log lines of mcrat.c:883-890 and mclib.c:583, same wording */
+static void log_frame(FILE *fPtr, const mcrat_hip_frame_stats *st, double time_now, int max_scatt, int min_scatt, double avg_scatt, double avg_r)
+{
+    if (!fPtr) return;
+    fprintf(fPtr, "The number of scatterings in this frame is: %d\n", (int)st->frame_scatt_cnt);
+    fprintf(fPtr, "The last time step was: %e.\nThe time now is: %e\n", st->last_time_step, time_now);
+    fprintf(fPtr, "MCRaT had to refind the position of photons %d times in this frame.\n", (int)st->num_photons_find_new_element);
+    fprintf(fPtr, "The maximum number of scatterings for a photon is: %d\nThe minimum number of scatterings for a photon is: %d\n",
+            max_scatt, min_scatt);
+    fprintf(fPtr, "The average number of scatterings thus far is: %lf\nThe average position of photons is %e\n", avg_scatt, avg_r);
+    for (long long k = 0; k < st->not_found; k++)
+        fprintf(fPtr, "Photon Hydro grid index not found, making sure it doesnt scatter.\n");
+    fflush(fPtr);
+}
+
 int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, const mcrat_hip_hydro *hydro,
                              double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
                              uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats)
@@ -381,17 +396,37 @@ int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, co
     if ((rc = mcrat_hip_scatt_stats(ctx, &max_scatt, &min_scatt, &avg_scatt, &avg_r)) != 0) return rc;  /* mcrat.c:881 */
     if ((rc = mcrat_hip_get_photons(ctx, list)) != 0) return rc;          /* before saveCheckpoint/printPhotons, mcrat.c:902-907 */
 
-    if (fPtr) {                                                           /* mcrat.c:883-890, same wording */
-        fprintf(fPtr, "The number of scatterings in this frame is: %d\n", (int)st.frame_scatt_cnt);
-        fprintf(fPtr, "The last time step was: %e.\nThe time now is: %e\n", st.last_time_step, *time_now);
-        fprintf(fPtr, "MCRaT had to refind the position of photons %d times in this frame.\n", (int)st.num_photons_find_new_element);
-        fprintf(fPtr, "The maximum number of scatterings for a photon is: %d\nThe minimum number of scatterings for a photon is: %d\n",
-                max_scatt, min_scatt);
-        fprintf(fPtr, "The average number of scatterings thus far is: %lf\nThe average position of photons is %e\n", avg_scatt, avg_r);
-        for (long long k = 0; k < st.not_found; k++)                      /* mclib.c:583, one line per event (index not kept) */
-            fprintf(fPtr, "Photon Hydro grid index not found, making sure it doesnt scatter.\n");
-        fflush(fPtr);
-    }
+    log_frame(fPtr, &st, *time_now, max_scatt, min_scatt, avg_scatt, avg_r);
+    if (stats) *stats = st;
+    return MCRAT_HIP_OK;
+}
+
+int mcrat_host_scatter_frame_resident(mcrat_hip_ctx *ctx, mcrat_host_get_hydro_fn get_hydro, void *user, double inj_radius,
+                                      const double r0_domain[2], const double r1_domain[2], const double r2_domain[2],
+                                      double *time_now, int scatt_frame, int increment_scatt_frame, double fps, uint64_t seed,
+                                      FILE *fPtr, mcrat_hip_frame_stats *stats)
+{
+    mcrat_hip_frame_stats st;
+    mcrat_hip_slab slab;
+    int rc, max_scatt = 0, min_scatt = 0;
+    double avg_scatt = 0, avg_r = 0;
+    if (!ctx || !get_hydro || !time_now || !(fps > 0) || !r0_domain || !r1_domain || !r2_domain) return MCRAT_HIP_EINVAL;
+
+    memset(&slab, 0, sizeof slab);
+    slab.r_inj = inj_radius;
+    slab.ph_inj_switch = 0;
+    slab.fps = fps;
+    memcpy(slab.r0_domain, r0_domain, sizeof slab.r0_domain);
+    memcpy(slab.r1_domain, r1_domain, sizeof slab.r1_domain);
+    memcpy(slab.r2_domain, r2_domain, sizeof slab.r2_domain);
+    /* mcrat.c:704: where the photons are -> mcrat.c:721: the part of the hydro frame they can reach */
+    if ((rc = mcrat_hip_ph_minmax(ctx, &slab.min_r, &slab.max_r, &slab.min_theta, &slab.max_theta)) != 0) return rc;
+    if ((rc = get_hydro(user, ctx, scatt_frame, &slab)) != 0) return rc;
+
+    const double remaining_time = ((scatt_frame + increment_scatt_frame) / fps) - *time_now;                 /* mcrat.c:758 */
+    if ((rc = mcrat_hip_propagate_frame(ctx, time_now, remaining_time, seed, &st)) != 0) return rc;          /* mcrat.c:761-851 */
+    if ((rc = mcrat_hip_scatt_stats(ctx, &max_scatt, &min_scatt, &avg_scatt, &avg_r)) != 0) return rc;       /* mcrat.c:881 */
+    log_frame(fPtr, &st, *time_now, max_scatt, min_scatt, avg_scatt, avg_r);
     if (stats) *stats = st;
     return MCRAT_HIP_OK;
 }

@@ -106,6 +106,17 @@ int mcrat_host_scatter_frame(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list, co
                              double *time_now, int scatt_frame, int increment_scatt_frame, double fps,
                              uint64_t seed, FILE *fPtr, mcrat_hip_frame_stats *stats);
 
+/* The same loop body with the photons resident on the device from injection to the last frame (no list crosses PCIe between
+ * frames): phMinMax on the device (mcrat.c:704) -> the caller's reader with the photons' slab (mcrat.c:721; `get_hydro` is
+ * expected to end in mcrat_hip_ingest_flash / _pluto / _chombo or mcrat_hip_set_hydro for scatt_frame) -> the loop for this
+ * hydro frame -> phScattStats and the log lines.  saveCheckpoint / printPhotons afterwards: mcrat_host_save_checkpoint(ctx, ...)
+ * and mcrat_host_print_photons.  inj_radius and the domains are getHydroData's other arguments (mcrat_io.h:26, mc.par). */
+typedef int (*mcrat_host_get_hydro_fn)(void *user, mcrat_hip_ctx *ctx, int scatt_frame, const mcrat_hip_slab *slab);
+int mcrat_host_scatter_frame_resident(mcrat_hip_ctx *ctx, mcrat_host_get_hydro_fn get_hydro, void *user, double inj_radius,
+                                      const double r0_domain[2], const double r1_domain[2], const double r2_domain[2],
+                                      double *time_now, int scatt_frame, int increment_scatt_frame, double fps, uint64_t seed,
+                                      FILE *fPtr, mcrat_hip_frame_stats *stats);
+
 /* ---- A/B shims: the reference's loop functions with their own argument order (Src/mclib.h:8-29) ----------------
  * For checking the engine against the CPU functions one call at a time inside MCRaT's own loop (mcrat.c:761-851):
  * replace `findContainingHydroCell(&photon_list, &hydrodata, sw, rng, fPtr)` by

@@ -100,3 +100,76 @@ def test_three_hydro_frames_like_main(hip, oracle, kind):
     assert len(cols["p0"]) == int(keep.sum())
     _close(cols["comv_p0"], P.aos["comv_p0"][keep], 1e-9, np.abs(P.aos["comv_p0"][keep]))
     e.close()
+
+
+def test_resident_frame_driver_of_the_host_c_equals_the_steps_done_by_hand(hip, tmp_path):
+    """mcrat_host_scatter_frame_resident (host C): phMinMax -> the caller's reader (a callback that ends in
+    mcrat_hip_ingest_pluto) -> the loop -> statistics and the reference's log lines, photons resident throughout"""
+    from mcrat_amd.host import build_host
+    host = C.CDLL(build_host.build())
+    GET = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(hip.Slab))
+    host.mcrat_host_scatter_frame_resident.restype = C.c_int
+    host.mcrat_host_scatter_frame_resident.argtypes = [C.c_void_p, GET, C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double, C.c_uint64,
+                                                       C.c_void_p, C.POINTER(hip.FrameStats)]
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    fps, r_inj = 5.0, 1e12
+    raw = synth.pluto_raw_grid(synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.6), (384, 96), seed=31, log_axis0=True)
+    jet = hip.Engine.outflow(3, lumi=2e53, theta_j=0.1)
+    inj = dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **DOM)
+
+    def start():
+        e = hip.Engine(synth.TWO, synth.SPHERICAL, 1)
+        e.ingest(raw, inj, jet)
+        e.inject_photons(r_inj, 1e50, 800, 1600, "b", 0.0, 0.08, fps, seed=404)
+        return e
+
+    # by hand
+    a = start()
+    t_a, stats_a = 0.0, []
+    for k in range(3):
+        mm = a.ph_minmax()
+        a.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=0, min_r=mm[0], max_r=mm[1], min_theta=mm[2], max_theta=mm[3], fps=fps, **DOM), jet)
+        t_a, st = a.propagate_frame(t_a, (k + 1) / fps - t_a, 1000 + k)
+        stats_a.append((st.iterations, st.frame_scatt_cnt, a.num_elements))
+    out_a = a.get_photons_aos()
+    a.close()
+
+    # through the host C driver
+    b = start()
+    seen = []
+
+    def reader(user, ctx, scatt_frame, slab):
+        s = slab.contents
+        seen.append((scatt_frame, s.ph_inj_switch, s.min_r, s.max_r))
+        n, ef, _ = b.ingest(raw, dict(r_inj=s.r_inj, ph_inj_switch=s.ph_inj_switch, min_r=s.min_r, max_r=s.max_r, min_theta=s.min_theta,
+                                      max_theta=s.max_theta, fps=s.fps, r0_domain=tuple(s.r0_domain), r1_domain=tuple(s.r1_domain),
+                                      r2_domain=tuple(s.r2_domain)), jet)
+        return 0
+    cb = GET(reader)
+    log = libc.fopen(str(tmp_path / "mc_output_0.log").encode(), b"w")
+    t_b = C.c_double(0.0)
+    d0, d1, d2 = (C.c_double * 2)(*DOM["r0_domain"]), (C.c_double * 2)(*DOM["r1_domain"]), (C.c_double * 2)(*DOM["r2_domain"])
+    stats_b = []
+    for k in range(3):
+        st = hip.FrameStats()
+        assert host.mcrat_host_scatter_frame_resident(b.ctx, cb, None, r_inj, d0, d1, d2, C.byref(t_b), k, 1, fps, 1000 + k, log, C.byref(st)) == 0
+        stats_b.append((st.iterations, st.frame_scatt_cnt, b.num_elements))
+    libc.fclose(log)
+    out_b = b.get_photons_aos()
+    b.close()
+    assert stats_a == stats_b and t_b.value == t_a and [s[:2] for s in seen] == [(0, 0), (1, 0), (2, 0)]
+    for k in out_a.dtype.names:
+        assert np.array_equal(out_a[k], out_b[k], equal_nan=out_a[k].dtype.kind == "f"), k
+    text = (tmp_path / "mc_output_0.log").read_text()
+    assert text.count("The number of scatterings in this frame is: ") == 3
+    assert "The number of scatterings in this frame is: %d\n" % stats_b[0][1] in text
+    assert "MCRaT had to refind the position of photons" in text and "The average position of photons is" in text
+    # a failing reader stops the frame with its code
+    bad = GET(lambda user, ctx, frame, slab: -7)
+    c = start()
+    assert host.mcrat_host_scatter_frame_resident(c.ctx, bad, None, r_inj, d0, d1, d2, C.byref(t_b), 3, 1, fps, 1, None, None) == -7
+    c.close()
