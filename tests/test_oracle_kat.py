@@ -439,6 +439,83 @@ def test_kn_scatter_polarised_azimuth(oracle):
     assert num / den == pytest.approx(0.5, abs=0.05)
 
 
+def test_depaola_azimuthal_modulation(oracle):
+    """The reference's own check of its Klein-Nishina sampler (Doc/mcrat_doc.tex:527, Figure phi_sampling_depaola): 100 keV
+    photons, 100 % polarised along +Q, scattering angles 85 deg < theta < 90 deg; the azimuth follows Depaola (2003):
+    pdf(phi) ~ e'/e + e/e' - 2 sin^2(theta) cos^2(phi') with e'/e = 1 / (1 + eps (1 - cos theta)).  In the code's
+    azimuth convention (mcrat_scattering.c:568-575, the +cos 2 phi sign of the Thomson-limit test above) that is
+    pdf(phi) ~ (A - sin^2 theta) + sin^2 theta cos 2 phi."""
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 2003, 0)
+    L.orc_rng_event_begin(C.byref(r), 0)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 1)
+    th, ph = C.c_double(), C.c_double()
+    eps = 100.0 / 510.99891                              # 100 keV in units of m_e c^2
+    phis, thetas = [], []
+    for _ in range(400000):
+        if not L.orc_kleinNishinaScatter(C.byref(c), C.byref(th), C.byref(ph), eps * M_EL * C_LIGHT, 1.0, 0.0, C.byref(r)):
+            continue
+        if np.radians(85) < th.value < np.radians(90):
+            phis.append(ph.value)
+            thetas.append(th.value)
+    phis, thetas = np.array(phis), np.array(thetas)
+    assert len(phis) > 8000
+    ratio = 1.0 / (1.0 + eps * (1.0 - np.cos(thetas)))
+    A, s2 = ratio + 1.0 / ratio, np.sin(thetas) ** 2
+    assert np.mean(np.cos(2 * phis)) == pytest.approx(np.mean(s2 / (2 * (A - s2))), abs=0.02)      # ~0.484: the modulation factor
+    assert abs(np.mean(np.sin(2 * phis))) < 0.02                                                    # no U-like skew
+    # the whole curve: 24 azimuth bins against the analytic profile at the sample's mean angle
+    edges = np.linspace(0, 2 * np.pi, 25)
+    got, _ = np.histogram(np.mod(phis, 2 * np.pi), edges)
+    Am, sm = A.mean(), s2.mean()
+    cdf = lambda x: (Am - sm) * x + 0.5 * sm * np.sin(2 * x)                   # noqa: E731
+    want = (cdf(edges[1:]) - cdf(edges[:-1])) / cdf(2 * np.pi) * len(phis)
+    assert stats.chisquare(got, want).pvalue > 1e-3
+
+
+def test_krawczynski_setup_lorentz_and_stokes(oracle):
+    """The set-up the reference keeps commented out inside singleScatter (Src/mcrat_scattering.c:190-208; Doc/mcrat_doc.tex:530,
+    Krawczynski 2011 Fig. 6): a 1e12 Hz photon along +z, 100 % polarised along +Q (s = (1,1,0,0)), an electron with gamma = 100
+    at theta = 85 deg, phi = 0.  Figures are not numbers, so the pins are the set-up's exact invariants: Compton's formula in
+    the electron rest frame, a null outgoing 4-momentum, the Stokes vector normalised with V = 0 and a polarisation degree
+    that stays physical; the outgoing beam is blue-shifted by up to ~4 gamma^2 and collimated along the electron."""
+    L = oracle.lib()
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 2011, 0)
+    c = oracle.make_config(oracle.TWO, oracle.CYLINDRICAL, 1)
+    PL = 6.6260755e-27
+    k0 = PL * 1e12 / C_LIGHT
+    theta = np.radians(85.0)
+    bet = (1 - 100.0 ** -2.0) ** 0.5
+    el0 = np.array([100 * M_EL * C_LIGHT, 100 * M_EL * C_LIGHT * bet * np.sin(theta), 0.0, 100 * M_EL * C_LIGHT * bet * np.cos(theta)])
+    # exactly along z the Stokes basis of findXY is 0/0 (mcrat_scattering.c:51; NaN in the reference too): 1e-6 rad off axis
+    k_in = np.array([k0, k0 * np.sin(1e-6), 0.0, k0 * np.cos(1e-6)])
+    gains, pols, cosines = [], [], []
+    for case in range(3000):
+        L.orc_rng_set_iteration(C.byref(r), case)
+        L.orc_rng_event_begin(C.byref(r), 0)
+        el, elp = _v(*el0)
+        ph, php = _v(*k_in)
+        s, sp = _v(1.0, 1.0, 0.0, 0.0)
+        if not L.orc_singleScatter(C.byref(c), elp, php, sp, C.byref(r)):
+            continue
+        assert ph[0] == pytest.approx(np.linalg.norm(ph[1:]), rel=1e-13)
+        a, b, th_sc = _rest_frame_angle(el0, k_in, ph)
+        assert b[0] == pytest.approx(a[0] / (1 + a[0] / (M_EL * C_LIGHT) * (1 - np.cos(th_sc))), rel=1e-8)
+        assert s[0] == 1.0 and s[3] == 0.0 and np.hypot(s[1], s[2]) <= 1.0 + 1e-9
+        gains.append(ph[0] / k0)
+        pols.append(np.hypot(s[1], s[2]))
+        cosines.append(ph[1:] @ el0[1:] / (ph[0] * np.linalg.norm(el0[1:])))
+    gains, pols, cosines = np.array(gains), np.array(pols), np.array(cosines)
+    assert len(gains) > 2500
+    # head-on geometry: gamma^2 (1 - beta cos 85 deg) (1 + beta) = 1.83e4 at most; the mean gain of Thomson scattering is about half
+    g_max = 100.0 ** 2 * (1 - bet * np.cos(theta)) * (1 + bet)
+    assert gains.max() <= g_max * (1 + 1e-6) and gains.max() > 0.9 * g_max and 0.3 * g_max < gains.mean() < 0.7 * g_max
+    assert np.median(cosines) > np.cos(2.0 / 100)                           # beamed into ~1/gamma around the electron
+    assert 0.2 < pols.mean() <= 1.0                                           # a polarised beam stays substantially polarised
+
+
 def _rest_frame_angle(el, k_in, k_out):
     beta = el[1:] / el[0]
     a = synth.lorentz_boost(beta[None, :], k_in[None, :])[0]
