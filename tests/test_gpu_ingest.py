@@ -252,3 +252,40 @@ def test_full_size_flash_frame(hip, oracle):
     idx = e.lookup_cell(x, z)                              # hydro coordinates (r, z)
     assert np.array_equal(idx, pick)
     e.close()
+
+
+def test_edge_cases_single_cells_single_levels_and_argument_checks(hip, oracle):
+    """the smallest inputs the readers can produce, and the argument checks of the C ABI"""
+    # a slab that reaches exactly one PLUTO cell
+    raw = synth.pluto_raw_grid(synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.6), (16, 4), seed=1, log_axis0=True)
+    cfg = oracle.make_config(synth.TWO, synth.SPHERICAL, 0)
+    everything, _ = oracle.hydro_ingest(cfg, raw, dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0))
+    k = 37
+    r, th = everything["r0"][k], everything["r1"][k]
+    one = dict(r_inj=1e12, ph_inj_switch=0, min_r=r, max_r=r, min_theta=th + 0.0349066, max_theta=th - 0.0349066, fps=1e30)   # undo the 2 degrees, no light-frame margin
+    e, got, ref, _ = _ingest_both(hip, oracle, synth.TWO, synth.SPHERICAL, raw, one)
+    assert got["num_elements"] == 1 and got["r0"][0] == r and got["r1"][0] == th
+    _compare(got, ref)
+    assert e.lookup_cell(np.array([r]), np.array([th]))[0] == 0 and e.lookup_cell(np.array([r * 3]), np.array([th]))[0] == -1
+    e.close()
+    # one AMR level: nothing to mask
+    raw1 = synth.chombo_raw(synth.TWO, synth.CYLINDRICAL, (0.0, 8e11), (4e11, 1.6e12), (16, 32), levels=1, seed=2)
+    e, got, ref, cells = _ingest_both(hip, oracle, synth.TWO, synth.CYLINDRICAL, raw1, dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0))
+    assert got["num_elements"] == cells == 16 * 32
+    _compare(got, ref)
+    # argument checks: wrong dimensionality for FLASH, missing arrays, bad slab, unknown outflow
+    with pytest.raises(hip.McratHipError):
+        e.ingest(raw1, dict(r_inj=0.0, ph_inj_switch=2, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0, **DOMAINS))
+    with pytest.raises(hip.McratHipError):
+        e.ingest(raw1, dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=0.0, **DOMAINS))
+    bad_flow = hip.Engine.outflow(3)
+    bad_flow.simulation_type = 9
+    with pytest.raises(hip.McratHipError):
+        e.ingest(raw1, dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0, **DOMAINS), bad_flow)
+    e.close()
+    e3 = hip.Engine(synth.THREE, synth.CARTESIAN, 0)
+    with pytest.raises(hip.McratHipError):
+        e3.ingest(_small_flash(), dict(r_inj=0.0, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=5.0, **DOMAINS))
+    with pytest.raises(hip.McratHipError):
+        e3.get_hydro(10)                                  # nothing staged yet
+    e3.close()
