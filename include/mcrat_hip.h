@@ -309,6 +309,17 @@ int mcrat_hip_inject_photons(mcrat_hip_ctx *ctx, double r_inj, double ph_weight,
 int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *ctx, const double *thermal_table, int n_ph_e, int n_t,
                                     double log_ph_e_min, double log_ph_e_max, double log_t_min, double log_t_max);
 
+/* createHotCrossSection (hot_x_section.c:82-133) on the device: fills thermal_table[(n_ph_e + 1) * (n_t + 1)] (photon-energy
+ * index first, log10 of the cross section over sigma_T) with the Monte-Carlo integrals of calculateTotalThermalCrossSection
+ * (:324-357; `calls` samples per entry, 500 000 in the reference) over the Maxwell-Juttner electrons of
+ * singleMaxwellJuttner (electron.c:538) and boostedCrossSection (:370-400).  The samples come from the engine's keyed random
+ * source (the reference's are its GSL generator's: the table agrees within the Monte-Carlo error, ~1e-3), entry by entry
+ * independent of the launch shape.  The table is returned to the host -- write it with mcrat_host_write_hot_cross_section
+ * for later runs, hand it to mcrat_hip_set_hot_cross_section for this one.  221 x 81 entries x 500 000 samples: under a
+ * second (a quarter of an hour on one host core). */
+int mcrat_hip_create_hot_cross_section(mcrat_hip_ctx *ctx, double *thermal_table, int n_ph_e, int n_t, double log_ph_e_min,
+                                       double log_ph_e_max, double log_t_min, double log_t_max, long long calls, uint64_t seed);
+
 /* photons host -> device (after photonInjection mcrat.c:645 / readCheckpoint) and back
  * (before saveCheckpoint mcrat.c:902 / printPhotons mcrat.c:907).  NULL-photon slots
  * (type 'N', weight 0, index -1: photons.c:208) are carried through unchanged. */

@@ -245,6 +245,25 @@ extern "C" size_t mcrat_hip_device_bytes(const mcrat_hip_ctx *c)
            sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS;
 }
 
+extern "C" int mcrat_hip_create_hot_cross_section(mcrat_hip_ctx *c, double *thermal_table, int n_ph_e, int n_t, double log_ph_e_min,
+                                                  double log_ph_e_max, double log_t_min, double log_t_max, long long calls, uint64_t seed)
+{
+    if (!c || !thermal_table || n_ph_e < 1 || n_t < 1 || n_ph_e > 100000 || n_t > 100000 || calls < 1 || !(log_ph_e_max > log_ph_e_min) ||
+        !(log_t_max > log_t_min))
+        return MCRAT_HIP_EINVAL;
+    const size_t count = (size_t)(n_ph_e + 1) * (size_t)(n_t + 1);
+    if (count > 0x7fffffffull) return MCRAT_HIP_EINVAL;
+    double *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, count * sizeof(double)));
+    HotTableParams p{n_ph_e, n_t, log_ph_e_min, log_ph_e_max, log_t_min, log_t_max, calls, (unsigned long long)seed};
+    hipError_t e = launch_hot_table(p, d, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(thermal_table, d, count * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    HIPCHK(c, e);
+    return MCRAT_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- hydro staging
 namespace {
 

@@ -142,6 +142,15 @@ hipError_t launch_outflow_prep(int dims, int geom, const OutflowDev &o, const Hy
 int stage_cells_blocks(int M);
 hipError_t launch_stage_cells(int dims, int geom, const HydroCols &h, int M, CellGeom *og, CellGeom2 *og2, CellFluid *of, double *ofc, double *otemp,
                               StagePartial *partials, double *samples, int stride, int nsamp, hipStream_t stream);
+// createHotCrossSection on the device (hot_table.hip; hot_x_section.c:82-133,324-400)
+constexpr int HOT_TABLE_SUBSTREAMS = 256;   // sample k of an entry belongs to substream k % 256 (part of the table's definition)
+struct HotTableParams {
+    int n_ph_e, n_t;
+    double log_ph_e_min, log_ph_e_max, log_t_min, log_t_max;
+    long long calls;
+    unsigned long long seed;
+};
+hipError_t launch_hot_table(const HotTableParams &p, double *table, hipStream_t stream);
 hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
                       unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
                       long long total, hipStream_t stream);

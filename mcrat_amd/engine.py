@@ -163,6 +163,8 @@ SYMBOLS = {
     "mcrat_hip_inject_photons": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char, C.c_double, C.c_double, C.c_double,
                                            C.c_uint64, _ip, _dp]),
     "mcrat_hip_set_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "mcrat_hip_create_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
+                                                     C.c_uint64]),
     "mcrat_hip_set_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
     "mcrat_hip_get_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
     "mcrat_hip_set_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
@@ -267,6 +269,14 @@ class Engine:
         self._check(self.lib.mcrat_hip_set_hot_cross_section(self.ctx, t.ctypes.data_as(_dp), t.shape[0] - 1, t.shape[1] - 1,
                                                              float(grid[0]), float(grid[1]), float(grid[2]), float(grid[3])),
                     "set_hot_cross_section")
+
+    def create_hot_cross_section(self, n_ph_e=220, n_t=80, grid=(-12.0, 6.0, -4.0, 4.0), calls=500000, seed=1):
+        """createHotCrossSection (hot_x_section.c:82-133) on the device -> (n_ph_e + 1, n_t + 1) array of log10(sigma / sigma_T)"""
+        t = np.empty((n_ph_e + 1, n_t + 1))
+        self._check(self.lib.mcrat_hip_create_hot_cross_section(self.ctx, t.ctypes.data_as(_dp), int(n_ph_e), int(n_t), float(grid[0]),
+                                                                float(grid[1]), float(grid[2]), float(grid[3]), int(calls), int(seed)),
+                    "create_hot_cross_section")
+        return t
 
     def inject_photons(self, r_inj, ph_weight, min_photons, max_photons, spect, theta_min, theta_max, fps, seed):
         """photonInjection (mclib.c:9-300) on the device; returns (number of photons, adjusted weight)"""

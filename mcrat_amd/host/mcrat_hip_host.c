@@ -138,6 +138,23 @@ int mcrat_host_read_hot_cross_section(const char *path, double *table, int n_ph_
     return rc;
 }
 
+int mcrat_host_write_hot_cross_section(const char *path, const double *table, int n_ph_e, int n_t, double log_ph_e_min,
+                                       double log_ph_e_max, double log_t_min, double log_t_max)
+{
+    if (!path || !table || n_ph_e < 1 || n_t < 1) return -1;
+    FILE *fp = fopen(path, "w");
+    if (!fp) return -1;
+    const double dt = (log_t_max - log_t_min) / n_t, dph_e = (log_ph_e_max - log_ph_e_min) / n_ph_e;
+    fprintf(fp, "The comoving photon energy and the temperatures are normalized by the electron rest mass\n");
+    fprintf(fp, "The calculated hot cross sections are normalized by the thompson cross section.\n");
+    fprintf(fp, "Photon index\tTheta Index\tlog10(Comoving Photon Energy)\tlog10(Theta)\tlog10(Hot Cross Section)\n");
+    fprintf(fp, "------------------------------------------------\n");
+    for (int i = 0; i <= n_ph_e; i++)
+        for (int j = 0; j <= n_t; j++)
+            fprintf(fp, "%d\t%d\t%g\t%g\t%15.10g\n", i, j, log_ph_e_min + i * dph_e, log_t_min + j * dt, table[(size_t)i * (n_t + 1) + j]);
+    return fclose(fp) == 0 ? 0 : -1;
+}
+
 /* ---- PLUTO .dbl frames (mclib_pluto.c:803-1128) ---------------------------------------------------------- */
 void mcrat_host_pluto_name(char *out, size_t n, const char *prefix, int frame)
 {

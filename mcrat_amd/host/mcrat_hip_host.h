@@ -48,6 +48,10 @@ void mcrat_host_free_mcpar(mcrat_host_mcpar *p);
  * 0 on success, -1 if the file cannot be opened, -2 on a malformed or incomplete file or an index outside the bounds
  * (the reference exits with "The bounds of the input file exceed what MCRaT has been compiled with"). */
 int mcrat_host_read_hot_cross_section(const char *path, double *table, int n_ph_e, int n_t);
+/* the same file as createHotCrossSection writes it (hot_x_section.c:109-132): four header lines, then one row per entry,
+ * "%d\t%d\t%g\t%g\t%15.10g" -- for a table made by mcrat_hip_create_hot_cross_section.  0, or -1 if the file cannot be written. */
+int mcrat_host_write_hot_cross_section(const char *path, const double *table, int n_ph_e, int n_t, double log_ph_e_min,
+                                       double log_ph_e_max, double log_t_min, double log_t_max);
 
 /* A PLUTO .dbl frame from disk: what readPluto holds after readGridFile, readDblOutFile and its fread
  * (Src/mclib_pluto.c:852-1128), ready for mcrat_hip_ingest_pluto.

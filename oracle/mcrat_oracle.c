@@ -549,6 +549,57 @@ int orc_singleScatter(const orc_config *c, double el_comov[4], double ph_comov[4
  * Deviation: outside the tabulated range GSL reports GSL_EDOM and the reference integrates the cross section
  * afresh with gsl_monte_plain (hot_x_section.c:563-599, consuming random numbers); here the arguments are clamped
  * to the table's edge and the event is counted (table_misses). */
+/* electron.c:538-561 */
+double orc_singleMaxwellJuttner(double gamma, double theta)
+{
+    double normalization;
+    if (theta > 1.e-2) normalization = orc_bessel_K2(1. / theta) * exp(1. / theta);
+    else normalization = sqrt(M_PI * theta / 2.);
+    return ((gamma * sqrt(gamma * gamma - 1.) / (theta * normalization)) * exp(-(gamma - 1.) / theta));
+}
+
+/* hot_x_section.c:370-400 */
+double orc_boostedCrossSection(double norm_ph_comv, double mu, double gamma)
+{
+    const double beta = sqrt(gamma * gamma - 1.) / gamma;
+    const double norm_ph_e = norm_ph_comv * gamma * (1. - mu * beta);
+    return orc_kleinNishinaCrossSection(norm_ph_e) * (1. - mu * beta);
+}
+
+/* hot_x_section.c:324-357, with the plain Monte-Carlo rule written out (see mcrat_oracle.h) */
+double orc_calculateTotalThermalCrossSection(double ph_comv, double theta, long long calls, uint64_t seed, int entry)
+{
+    const double xl[2] = {1, -1}, xu[2] = {1. + 12 * theta, 1};
+    double total = 0;
+    orc_rng r;
+    orc_rng_init(&r, seed, 0);
+    orc_rng_set_iteration(&r, (uint64_t)entry);
+    for (int s = 0; s < 256 && s < calls; s++) {
+        orc_rng_stream_begin(&r, (uint32_t)s, 4u);
+        double sum = 0;
+        for (long long k = s; k < calls; k += 256) {
+            const double gamma = xl[0] + orc_rng_uniform_pos(&r) * (xu[0] - xl[0]);
+            const double mu = xl[1] + orc_rng_uniform_pos(&r) * (xu[1] - xl[1]);
+            sum += orc_singleMaxwellJuttner(gamma, theta) * orc_boostedCrossSection(ph_comv, mu, gamma);
+        }
+        total += sum;
+    }
+    const double result = ((xu[0] - xl[0]) * (xu[1] - xl[1])) * (total / (double)calls);
+    return 0.5 * result;
+}
+
+/* hot_x_section.c:82-107 */
+void orc_createHotCrossSection(double *thermal_table, int n_ph_e, int n_t, double log_ph_e_min, double log_ph_e_max,
+                               double log_t_min, double log_t_max, long long calls, uint64_t seed)
+{
+    const double dt = (log_t_max - log_t_min) / n_t, dph_e = (log_ph_e_max - log_ph_e_min) / n_ph_e;
+    for (int i = 0; i <= n_ph_e; i++)
+        for (int j = 0; j <= n_t; j++) {
+            const double comv_ph_e = pow(10., log_ph_e_min + i * dph_e), theta = pow(10., log_t_min + j * dt);
+            thermal_table[(size_t)i * (n_t + 1) + j] = log10(orc_calculateTotalThermalCrossSection(comv_ph_e, theta, calls, seed, i * (n_t + 1) + j));
+        }
+}
+
 static long long g_table_misses = 0;
 long long orc_table_misses(void) { return g_table_misses; }
 void orc_reset_table_misses(void) { g_table_misses = 0; }

@@ -164,6 +164,15 @@ int    orc_singleScatter(const orc_config *c, double el_comov[4], double ph_como
 /* ---- the loop (reference signatures minus gsl_rng*, FILE*) ------------ */
 void   orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hydro *h);       /* optical_depth.c:7 */
 double orc_getThermalCrossSection(const orc_config *c, double photon_comv_e, double fluid_temp, int *miss); /* optical_depth.c:132 */
+/* createHotCrossSection's integrals (hot_x_section.c:324-400, electron.c:538-561).  gsl_monte_plain_integrate lives in GSL:
+ * its published algorithm is volume x sample mean of the integrand at points x = xl + uniform_pos * (xu - xl) drawn
+ * coordinate by coordinate; the points here come from oracle_rng.h's keyed streams {iteration = entry, word2 = k % 256,
+ * purpose = 4}, sample k being the (k / 256)-th of its stream -- the source the engine uses. */
+double orc_singleMaxwellJuttner(double gamma, double theta);                               /* electron.c:538 */
+double orc_boostedCrossSection(double norm_ph_comv, double mu, double gamma);              /* hot_x_section.c:370 */
+double orc_calculateTotalThermalCrossSection(double ph_comv, double theta, long long calls, uint64_t seed, int entry); /* :324 */
+void   orc_createHotCrossSection(double *thermal_table, int n_ph_e, int n_t, double log_ph_e_min, double log_ph_e_max,
+                                 double log_t_min, double log_t_max, long long calls, uint64_t seed);  /* :82-107 */
 long long orc_table_misses(void);   /* lookups outside the table since orc_reset_table_misses() */
 void   orc_reset_table_misses(void);
 int    orc_findContainingHydroCell(const orc_config *c, orc_photon_list *l, const orc_hydro *h,

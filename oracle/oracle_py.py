@@ -197,6 +197,10 @@ def lib():
             "orc_photonInjection": (i, [cfgp, C.POINTER(C.c_void_p), C.POINTER(i), _dp, d, d, i, i, C.c_char, d, d, hp, C.c_uint64, C.c_uint32]),
             "orc_free": (None, [C.c_void_p]),
             "orc_getThermalCrossSection": (d, [cfgp, d, d, C.POINTER(i)]),
+            "orc_singleMaxwellJuttner": (d, [d, d]),
+            "orc_boostedCrossSection": (d, [d, d, d]),
+            "orc_calculateTotalThermalCrossSection": (d, [d, d, C.c_longlong, C.c_uint64, i]),
+            "orc_createHotCrossSection": (None, [_dp, i, i, d, d, d, d, C.c_longlong, C.c_uint64]),
             "orc_table_misses": (C.c_longlong, []),
             "orc_reset_table_misses": (None, []),
             "orc_findContainingHydroCell": (i, [cfgp, lp, hp, i, sp]),

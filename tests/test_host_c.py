@@ -259,3 +259,23 @@ def test_ab_shims_run_mains_loop_function_by_function(host, oracle):
         assert passes < 400
     assert passes > 10 and scatt_cnt.value > 10 and relocated > 0
     assert time_now == pytest.approx(time_now0 + remaining0, rel=1e-13)
+
+
+def test_hot_cross_section_file_written_like_the_reference_reads_back(host, tmp_path):
+    """mcrat_host_write_hot_cross_section writes createHotCrossSection's file format (hot_x_section.c:109-132); the reader of
+    readHotCrossSection's format gets the table back to the ten digits the format keeps"""
+    host.mcrat_host_write_hot_cross_section.restype = C.c_int
+    host.mcrat_host_write_hot_cross_section.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]
+    host.mcrat_host_read_hot_cross_section.restype = C.c_int
+    host.mcrat_host_read_hot_cross_section.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int, C.c_int]
+    rng = np.random.default_rng(3)
+    table = -rng.random((221, 81)) * 3
+    path = str(tmp_path / "thermal_hot_x_section.dat").encode()
+    assert host.mcrat_host_write_hot_cross_section(path, table.ctypes.data_as(C.POINTER(C.c_double)), 220, 80, -12.0, 6.0, -4.0, 4.0) == 0
+    lines = open(path).read().split("\n")
+    assert lines[3].startswith("----") and lines[4].split("\t")[:2] == ["0", "0"] and len(lines) == 4 + 221 * 81 + 1
+    assert lines[4 + 81].split("\t")[:4] == ["1", "0", "%g" % (-12.0 + 18.0 / 220), "-4"]
+    back = np.empty_like(table)
+    assert host.mcrat_host_read_hot_cross_section(path, back.ctypes.data_as(C.POINTER(C.c_double)), 220, 80) == 0
+    assert np.allclose(back, table, rtol=1e-9, atol=1e-12)
+    assert host.mcrat_host_write_hot_cross_section(str(tmp_path / "no" / "x.dat").encode(), table.ctypes.data_as(C.POINTER(C.c_double)), 220, 80, -12.0, 6.0, -4.0, 4.0) == -1

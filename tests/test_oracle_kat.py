@@ -770,3 +770,36 @@ def test_photon_injection_rules(oracle, spect):
     assert x.mean() == pytest.approx(3.832, rel=0.1)
     # the outflow beams the photons outward: lab energies exceed comoving ones on average
     assert (ph["p0"] / ph["comv_p0"]).mean() > 5
+
+
+# ------------------------------------------------------------------ createHotCrossSection (hot_x_section.c:82-133, 324-400)
+def test_hot_cross_section_integrals_known_limits(oracle):
+    L = oracle.lib()
+    # K_2 scaled over the whole range the Maxwell-Juttner normalisation uses (theta in (1e-2, 1e4])
+    for x in (1e-4, 1e-2, 0.3, 1.0, 7.0, 99.0):
+        assert L.orc_bessel_K2(x) * np.exp(x) == pytest.approx(special.kve(2, x), rel=1e-12)
+    # singleMaxwellJuttner is a normalised pdf in gamma: exactly for theta > 1e-2 (up to the 12-theta cut, e^-12), and to
+    # first order in theta below, where the reference switches to the theta -> 0 limit of the normalisation
+    from scipy import integrate
+    for theta, tol in ((1e-3, 4e-3), (5e-3, 2e-2), (0.1, 2e-3), (1.0, 2e-3), (30.0, 2e-3)):
+        val, _ = integrate.quad(lambda g: L.orc_singleMaxwellJuttner(g, theta), 1.0, 1.0 + 12 * theta, epsabs=0, epsrel=1e-9, limit=400)
+        assert val == pytest.approx(1.0, abs=tol), theta
+    # boostedCrossSection: sigma_KN in the electron frame times the flux factor
+    assert L.orc_boostedCrossSection(1e-9, 0.3, 1.0) == pytest.approx(1.0, abs=1e-8)
+    g, mu = 3.0, -0.5
+    b = np.sqrt(g * g - 1) / g
+    assert L.orc_boostedCrossSection(0.2, mu, g) == pytest.approx(L.orc_kleinNishinaCrossSection(0.2 * g * (1 - mu * b)) * (1 - mu * b), rel=1e-15)
+    # the integral: Thomson limit -> 1 at any temperature; cold electrons -> sigma_KN(eps); hotter electrons see harder photons
+    n = 200000
+    for theta in (1e-3, 0.1, 3.0):
+        vals = [L.orc_calculateTotalThermalCrossSection(1e-9, theta, n, seed, 0) for seed in (1, 2, 3)]
+        assert np.mean(vals) == pytest.approx(1.0, abs=1.5e-2) and np.std(vals) < 1.5e-2
+    for eps in (1e-2, 1.0, 30.0):
+        assert L.orc_calculateTotalThermalCrossSection(eps, 1e-4, n, 5, 1) == pytest.approx(L.orc_kleinNishinaCrossSection(eps), rel=2e-2)
+    hot = [L.orc_calculateTotalThermalCrossSection(1.0, th, n, 5, 2) for th in (1e-3, 0.1, 1.0, 10.0)]
+    assert all(a > b for a, b in zip(hot, hot[1:]))
+    # the table: entry (i, j) is log10 of the integral at (10^(e_min + i de), 10^(t_min + j dt)); entries do not depend on the table's size
+    t = np.empty((3, 2))
+    L.orc_createHotCrossSection(t.ctypes.data_as(C.POINTER(C.c_double)), 2, 1, -3.0, 1.0, -2.0, 0.0, 20000, 9)
+    assert t[2, 1] == pytest.approx(np.log10(L.orc_calculateTotalThermalCrossSection(10.0, 1.0, 20000, 9, 5)), rel=1e-15)
+    assert t[0, 0] == pytest.approx(0.0, abs=2e-2) and t[2, 0] < t[1, 0] < t[0, 0] + 2e-2
