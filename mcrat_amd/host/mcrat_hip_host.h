@@ -98,6 +98,29 @@ int mcrat_host_print_photons(mcrat_hip_ctx *ctx, int frame, const char *dir, int
                              int save_type, FILE *fPtr);
 int mcrat_host_h5_read(const char *file, const char *group, const char *name, int is_char, void *data, int cap, int *n);
 
+/* The HDF5 reads of the two HDF5-based readers, and nothing else of them (same file, mcrat_hip_host_h5.c):
+ *   mcrat_host_read_flash    readAndDecimate's H5Dread calls (mclib_flash.c:95-197): "coordinates", "block size", "node type",
+ *                            "velx", "vely", "dens", "pres" -> the buffers mcrat_hip_ingest_flash takes
+ *   mcrat_host_read_chombo   readPlutoChombo's (mclib_pluto.c:44-430): attributes num_levels, num_components, component_<k>;
+ *                            per level_<i>: "boxes", "data:offsets=0", "data:datatype=0", prob_domain, ref_ratio, dx, logr,
+ *                            domBeg1-3, g_x2stretch, g_x3stretch -> mcrat_hip_ingest_chombo's
+ * mcrat_host_flash_name is modifyFlashName (mclib_flash.c:15-58).  0, -1 if the file cannot be opened, -2 if a dataset or
+ * attribute is missing or has an unexpected shape. */
+typedef struct mcrat_host_flash {
+    mcrat_hip_flash_blocks blocks;       /* owns its arrays: mcrat_host_free_flash */
+} mcrat_host_flash;
+int  mcrat_host_read_flash(const char *file, double l_scale, double d_scale, double p_scale, mcrat_host_flash *out);
+void mcrat_host_free_flash(mcrat_host_flash *f);
+void mcrat_host_flash_name(char *out, size_t n, const char *prefix, int frame);
+typedef struct mcrat_host_chombo {
+    mcrat_hip_chombo frame;              /* points into the members below */
+    mcrat_hip_chombo_level *levels;
+    char  **var_names;
+    double *data;
+} mcrat_host_chombo;
+int  mcrat_host_read_chombo(const char *file, int three_dimensional, double l_scale, double d_scale, double p_scale, mcrat_host_chombo *out);
+void mcrat_host_free_chombo(mcrat_host_chombo *h);
+
 /* One scatter frame on the device (replaces Src/mcrat.c:754-892 between getHydroData and saveCheckpoint).
  *   list       caller-owned photon list; uploaded, propagated, downloaded in place
  *   hydro      the frame getHydroData just produced

@@ -120,3 +120,181 @@ int mcrat_host_h5_read(const char *file, const char *group, const char *name, in
     H5Fclose(f);
     return rc;
 }
+
+/* ---- the HDF5 file reads of readAndDecimate (mclib_flash.c:95-197) and readPlutoChombo (mclib_pluto.c:44-430) -------------
+ * Only the reads: everything those functions do afterwards is mcrat_hip_ingest_flash / mcrat_hip_ingest_chombo. */
+void mcrat_host_flash_name(char *out, size_t n, const char *prefix, int frame)
+{
+    snprintf(out, n, "%s%04d", prefix, frame);          /* modifyFlashName, mclib_flash.c:15-58: FILEPATH FILEROOT + four digits */
+}
+
+static void *read_dataset(hid_t file, const char *name, hid_t memtype, size_t elem, hsize_t dims_out[4], int *rank_out)
+{
+    hid_t d = H5Dopen2(file, name, H5P_DEFAULT);
+    if (d < 0) return NULL;
+    hid_t sp = H5Dget_space(d);
+    hsize_t dims[8] = {0};
+    const int rank = H5Sget_simple_extent_ndims(sp);
+    void *buf = NULL;
+    if (rank >= 1 && rank <= 8) {
+        H5Sget_simple_extent_dims(sp, dims, NULL);
+        size_t count = 1;
+        for (int k = 0; k < rank; k++) count *= (size_t)dims[k];
+        buf = malloc(elem * (count ? count : 1));
+        if (buf && H5Dread(d, memtype, H5S_ALL, H5S_ALL, H5P_DEFAULT, buf) < 0) { free(buf); buf = NULL; }
+        for (int k = 0; k < 4; k++) dims_out[k] = k < rank ? dims[k] : 1;
+        if (rank_out) *rank_out = rank;
+    }
+    H5Sclose(sp);
+    H5Dclose(d);
+    return buf;
+}
+
+void mcrat_host_free_flash(mcrat_host_flash *f)
+{
+    if (!f) return;
+    free((void *)f->blocks.coordinates); free((void *)f->blocks.block_size); free((void *)f->blocks.node_type);
+    free((void *)f->blocks.velx); free((void *)f->blocks.vely); free((void *)f->blocks.dens); free((void *)f->blocks.pres);
+    memset(f, 0, sizeof *f);
+}
+
+int mcrat_host_read_flash(const char *file, double l_scale, double d_scale, double p_scale, mcrat_host_flash *out)
+{
+    if (!file || !out) return -2;
+    memset(out, 0, sizeof *out);
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+    hid_t f = H5Fopen(file, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f < 0) return -1;
+    hsize_t dc[4], db[4], dn[4], dv[4];
+    mcrat_hip_flash_blocks *b = &out->blocks;
+    b->coordinates = (const double *)read_dataset(f, "coordinates", H5T_NATIVE_DOUBLE, sizeof(double), dc, NULL);
+    b->block_size = (const double *)read_dataset(f, "block size", H5T_NATIVE_DOUBLE, sizeof(double), db, NULL);
+    b->node_type = (const int *)read_dataset(f, "node type", H5T_NATIVE_INT, sizeof(int), dn, NULL);
+    const char *names[4] = {"velx", "vely", "dens", "pres"};
+    const double **slots[4] = {&b->velx, &b->vely, &b->dens, &b->pres};
+    int ok = b->coordinates && b->block_size && b->node_type && dc[0] > 0 && db[0] == dc[0] && dn[0] == dc[0] && dc[1] >= 2 && db[1] >= 2 &&
+             dc[0] <= 0x7fffffffu / 64;
+    for (int k = 0; k < 4 && ok; k++) {
+        *slots[k] = (const double *)read_dataset(f, names[k], H5T_NATIVE_DOUBLE, sizeof(double), dv, NULL);
+        ok = *slots[k] && dv[0] == dc[0] && dv[1] * dv[2] * dv[3] == 64;          /* PROP_DIM1 x PROP_DIM2 x PROP_DIM3, mclib_flash.c:10-12 */
+    }
+    H5Fclose(f);
+    if (!ok) { mcrat_host_free_flash(out); return -2; }
+    b->n_blocks = (int)dc[0];
+    b->coord_stride = (int)dc[1];
+    b->bsize_stride = (int)db[1];
+    b->l_scale = l_scale; b->d_scale = d_scale; b->p_scale = p_scale;
+    return 0;
+}
+
+void mcrat_host_free_chombo(mcrat_host_chombo *h)
+{
+    if (!h) return;
+    for (int i = 0; h->levels && i < h->frame.num_levels; i++) { free((void *)h->levels[i].boxes); free((void *)h->levels[i].box_offsets); }
+    for (int i = 0; h->var_names && i < h->frame.num_vars; i++) free(h->var_names[i]);
+    free(h->levels); free(h->var_names); free(h->data);
+    memset(h, 0, sizeof *h);
+}
+
+static int attr_read(hid_t obj, const char *name, hid_t type, void *out)
+{
+    hid_t a = H5Aopen(obj, name, H5P_DEFAULT);
+    if (a < 0) return -1;
+    const herr_t st = H5Aread(a, type, out);
+    H5Aclose(a);
+    return st < 0 ? -1 : 0;
+}
+
+int mcrat_host_read_chombo(const char *file, int three_dimensional, double l_scale, double d_scale, double p_scale, mcrat_host_chombo *out)
+{
+    if (!file || !out) return -2;
+    memset(out, 0, sizeof *out);
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+    hid_t f = H5Fopen(file, H5F_ACC_RDONLY, H5P_DEFAULT);
+    if (f < 0) return -1;
+    const int nd = three_dimensional ? 3 : 2, bi = 2 * nd;
+    int rc = -2, num_levels = 0, num_vars = 0;
+    /* the box compound of mclib_pluto.c:48-58, packed as the ints mcrat_hip_chombo_level.boxes expects */
+    static const char *members3[6] = {"lo_i", "lo_j", "lo_k", "hi_i", "hi_j", "hi_k"}, *members2[4] = {"lo_i", "lo_j", "hi_i", "hi_j"};
+    hid_t box_t = H5Tcreate(H5T_COMPOUND, sizeof(int) * (size_t)bi);
+    for (int k = 0; k < bi; k++) H5Tinsert(box_t, three_dimensional ? members3[k] : members2[k], sizeof(int) * (size_t)k, H5T_NATIVE_INT);
+    if (attr_read(f, "num_levels", H5T_NATIVE_INT, &num_levels) || attr_read(f, "num_components", H5T_NATIVE_INT, &num_vars) ||
+        num_levels <= 0 || num_vars <= 0 || num_levels > 64 || num_vars > 256)
+        goto done;
+    out->frame.num_levels = num_levels;
+    out->frame.num_vars = num_vars;
+    out->levels = (mcrat_hip_chombo_level *)calloc((size_t)num_levels, sizeof(mcrat_hip_chombo_level));
+    out->var_names = (char **)calloc((size_t)num_vars, sizeof(char *));
+    if (!out->levels || !out->var_names) goto done;
+    for (int k = 0; k < num_vars; k++) {                                    /* component_<k>, :98-113 */
+        char an[64];
+        snprintf(an, sizeof an, "component_%d", k);
+        hid_t a = H5Aopen(f, an, H5P_DEFAULT);
+        if (a < 0) goto done;
+        hid_t ft = H5Aget_type(a);
+        const size_t sdim = H5Tget_size(ft) + 1;
+        out->var_names[k] = (char *)calloc(sdim, 1);
+        hid_t mt = H5Tcopy(H5T_C_S1);
+        H5Tset_size(mt, sdim);
+        const herr_t st = out->var_names[k] ? H5Aread(a, mt, out->var_names[k]) : -1;
+        H5Tclose(mt); H5Tclose(ft); H5Aclose(a);
+        if (st < 0) goto done;
+    }
+    long long total = 0;
+    for (int i = 0; i < num_levels; i++) {                                  /* sizes first (:128-155), level 0 first in all_data */
+        char gn[64];
+        snprintf(gn, sizeof gn, "level_%d", i);
+        hid_t g = H5Gopen2(f, gn, H5P_DEFAULT);
+        if (g < 0) goto done;
+        hid_t d = H5Dopen2(g, "data:datatype=0", H5P_DEFAULT);
+        hsize_t dims[1] = {0};
+        if (d >= 0) { hid_t sp = H5Dget_space(d); H5Sget_simple_extent_dims(sp, dims, NULL); H5Sclose(sp); H5Dclose(d); }
+        H5Gclose(g);
+        if (d < 0) goto done;
+        out->levels[i].data_len = (long long)dims[0];
+        total += (long long)dims[0];
+    }
+    out->data = (double *)malloc(sizeof(double) * (size_t)(total > 0 ? total : 1));
+    if (!out->data) goto done;
+    long long offset = 0;
+    for (int i = 0; i < num_levels; i++) {                                  /* :349-430 */
+        mcrat_hip_chombo_level *L = &out->levels[i];
+        char gn[64];
+        snprintf(gn, sizeof gn, "level_%d", i);
+        hid_t g = H5Gopen2(f, gn, H5P_DEFAULT);
+        if (g < 0) goto done;
+        int bad = 0;
+        hid_t d = H5Dopen2(g, "data:datatype=0", H5P_DEFAULT);
+        bad |= d < 0 || H5Dread(d, H5T_NATIVE_DOUBLE, H5S_ALL, H5S_ALL, H5P_DEFAULT, out->data + offset) < 0;
+        if (d >= 0) H5Dclose(d);
+        hsize_t dims[4];
+        L->box_offsets = (const int *)read_dataset(g, "data:offsets=0", H5T_NATIVE_INT, sizeof(int), dims, NULL);
+        hsize_t nb[4];
+        L->boxes = (const int *)read_dataset(g, "boxes", box_t, sizeof(int) * (size_t)bi, nb, NULL);
+        bad |= !L->box_offsets || !L->boxes || dims[0] < nb[0];
+        L->n_boxes = (int)nb[0];
+        int pd[6] = {0, 0, 0, 0, 0, 0};
+        bad |= attr_read(g, "prob_domain", box_t, pd);
+        for (int k = 0; k < bi; k++) L->prob_domain[k] = pd[k];
+        L->ref_ratio = 2;
+        (void)attr_read(g, "ref_ratio", H5T_NATIVE_INT, &L->ref_ratio);     /* the finest level's is never used (:209-242) */
+        bad |= attr_read(g, "dx", H5T_NATIVE_DOUBLE, &L->dx) || attr_read(g, "logr", H5T_NATIVE_INT, &L->logr) ||
+               attr_read(g, "domBeg1", H5T_NATIVE_DOUBLE, &L->dombeg1) || attr_read(g, "g_x2stretch", H5T_NATIVE_DOUBLE, &L->g_x2stretch) ||
+               attr_read(g, "domBeg2", H5T_NATIVE_DOUBLE, &L->dombeg2);
+        if (three_dimensional)
+            bad |= attr_read(g, "g_x3stretch", H5T_NATIVE_DOUBLE, &L->g_x3stretch) || attr_read(g, "domBeg3", H5T_NATIVE_DOUBLE, &L->dombeg3);
+        H5Gclose(g);
+        if (bad) goto done;
+        offset += L->data_len;
+    }
+    out->frame.levels = out->levels;
+    out->frame.var_names = (const char *const *)out->var_names;
+    out->frame.data = out->data;
+    out->frame.l_scale = l_scale; out->frame.d_scale = d_scale; out->frame.p_scale = p_scale;
+    rc = 0;
+done:
+    H5Tclose(box_t);
+    H5Fclose(f);
+    if (rc) mcrat_host_free_chombo(out);
+    return rc;
+}

@@ -68,10 +68,15 @@ for sub, want, bytes_note in (("pmc_ranks", "rank_loop_kernel", "ranks"), ("pmc_
         out[want]["algorithmic_bytes_per_launch"] = 110000000
     json.dump(out[want], open(os.path.join(dst, "%s_%s_pmc.json" % (tag, want)), "w"), indent=1)
 open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
-for sub, name in (("kt_default", "%s_kernel_stats.csv" % tag), ("kt_list", "%s_list_kernel_stats.csv" % tag)):
+for sub, name in (("kt_default", "%s_kernel_stats.csv" % tag), ("kt_list", "%s_list_kernel_stats.csv" % tag),
+                  ("kt_ingest", "%s_ingest_kernel_stats.csv" % tag)):
     f = stats_file(sub)
     if f:
         shutil.copy(f, os.path.join(dst, name))
+t = os.path.join(src, "ingest_timings.txt")
+if os.path.exists(t) and os.path.getsize(t) > 0:
+    open(os.path.join(dst, "%s_ingest_timings.txt" % tag), "w").write(
+        "".join(ln for ln in open(t) if not ln.startswith(("W2", "E2", "I2")) and "amdgpu.ids" not in ln))
 b = os.path.join(src, "bench.json")
 if os.path.exists(b) and os.path.getsize(b) > 0:
     shutil.copy(b, os.path.join(dst, "%s_bench.json" % tag))

@@ -38,6 +38,10 @@ def main():
     timed("get_output (weight != 0 columns)", lambda: len(e.get_output()["p0"]))
     timed("get_photons_range 2^20 records", lambda: len(e.get_photons_range(0, min(e.n, 1 << 20))))
     e.close()
+    # the TAU_CALCULATION == TABLE input: 221 x 81 entries x 500 000 Monte-Carlo samples
+    e = engine.Engine(synth.TWO, synth.CYLINDRICAL, 0)
+    timed("hot cross-section table (reference size)", lambda: e.create_hot_cross_section().shape)
+    e.close()
     # cfg3: PLUTO 2048 x 512 spherical
     raw = synth.pluto_raw_grid(synth.TWO, synth.SPHERICAL, (1e9, 0.0), (2.5e13, np.pi / 2), (2048, 512), seed=2, log_axis0=True)
     e = engine.Engine(synth.TWO, synth.SPHERICAL, 1)

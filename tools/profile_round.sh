@@ -20,6 +20,8 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ
   echo "== pmc pass $i ($ctrs), list mode"
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_list/p$i -- python3 bench.py --mode list --steps 100 --warmup 10 --profile-steps 0 --graph 0 --other-mode 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/pmc_list_p$i.json 2> $out/pmc_list_p$i.err; echo "exit=$?"
 done
+echo "== kernel trace, producers and consumers around the loop (ingest, injection, output, hot table)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_ingest -- python3 tools/profile_ingest.py > $out/ingest_timings.txt 2> $out/kt_ingest.err; echo "exit=$?"
 # keep what travels back small: the per-dispatch traces are not needed, the stats and counter tables are
 find $out -name "*kernel_trace.csv" -delete
 find $out -name "*agent_info.csv" -delete
