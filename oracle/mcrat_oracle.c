@@ -197,8 +197,86 @@ int orc_checkInBlock(const orc_config *c, double a0, double a1, double a2, const
 
 /* geometry.c:350-391 (the path taken because hydro_data->grid == NULL,
  * mcrat_io.c:1985 -> geometry.c:426-430): lowest-index containing cell or -1 */
+/* ---- optimised mode only: an exact accelerator of the linear search.  Uniform buckets per axis over the mesh's extent;
+ * every cell is entered, in ascending cell order, into all buckets its closed extent (widened by 1e-9 relative) touches;
+ * a point's bucket list therefore holds every cell that can contain it, lowest index first, and the reference's own
+ * closed-interval test picks the first -- the answer of the linear scan. */
+typedef struct orc_grid {
+    const orc_hydro *h;
+    int naxes, dim[3];
+    double lo[3], inv[3];
+    int *start, *cells;
+} orc_grid;
+static orc_grid g_grid;
+
+void orc_grid_detach(void)
+{
+    free(g_grid.start); free(g_grid.cells);
+    memset(&g_grid, 0, sizeof g_grid);
+}
+
+static int grid_bucket_1d(const orc_grid *g, int k, double x)
+{
+    double f = floor((x - g->lo[k]) * g->inv[k]);
+    if (!(f == f) || f < 0) return 0;
+    if (f > g->dim[k] - 1) return g->dim[k] - 1;
+    return (int)f;
+}
+
+void orc_grid_attach(const orc_config *c, const orc_hydro *h)
+{
+    orc_grid_detach();
+    const int M = h->num_elements, naxes = (c->dimensions == ORC_THREE) ? 3 : 2;
+    const double *cc[3] = {h->r0, h->r1, h->r2}, *ss[3] = {h->r0_size, h->r1_size, h->r2_size};
+    orc_grid *g = &g_grid;
+    g->naxes = naxes;
+    long long nb = 1;
+    const int per_axis = (int)fmax(1.0, floor(pow((double)M, 1.0 / naxes)));
+    for (int k = 0; k < 3; k++) {
+        g->dim[k] = 1; g->lo[k] = 0; g->inv[k] = 0;
+        if (k >= naxes) continue;
+        double lo = INFINITY, hi = -INFINITY;
+        for (int i = 0; i < M; i++) { lo = fmin(lo, cc[k][i] - 0.5 * ss[k][i]); hi = fmax(hi, cc[k][i] + 0.5 * ss[k][i]); }
+        g->dim[k] = per_axis;
+        g->lo[k] = lo;
+        g->inv[k] = per_axis / (hi - lo);
+        nb *= per_axis;
+    }
+    g->start = (int *)calloc((size_t)nb + 1, sizeof(int));
+    for (int pass = 0; pass < 2; pass++) {
+        int *cursor = pass ? (int *)malloc(sizeof(int) * (size_t)nb) : NULL;
+        if (pass) { memcpy(cursor, g->start, sizeof(int) * (size_t)nb); g->cells = (int *)malloc(sizeof(int) * (size_t)(g->start[nb] > 0 ? g->start[nb] : 1)); }
+        for (int i = 0; i < M; i++) {
+            int b0[3] = {0, 0, 0}, b1[3] = {0, 0, 0};
+            for (int k = 0; k < naxes; k++) {
+                const double m = 1e-9 * (fabs(cc[k][i]) + ss[k][i]);
+                b0[k] = grid_bucket_1d(g, k, cc[k][i] - 0.5 * ss[k][i] - m);
+                b1[k] = grid_bucket_1d(g, k, cc[k][i] + 0.5 * ss[k][i] + m);
+            }
+            for (int z = b0[2]; z <= b1[2]; z++)
+                for (int y = b0[1]; y <= b1[1]; y++)
+                    for (int x = b0[0]; x <= b1[0]; x++) {
+                        const long long b = ((long long)z * g->dim[1] + y) * g->dim[0] + x;
+                        if (pass) g->cells[cursor[b]++] = i; else g->start[b + 1]++;
+                    }
+        }
+        if (!pass) for (long long b = 0; b < nb; b++) g->start[b + 1] += g->start[b];
+        free(cursor);
+    }
+    g->h = h;
+}
+
 int orc_findContainingBlock(const orc_config *c, double a0, double a1, double a2, const orc_hydro *h)
 {
+    if (c->optimised && g_grid.h == h) {
+        const orc_grid *g = &g_grid;
+        const double a[3] = {a0, a1, a2};
+        long long b = 0;
+        for (int k = g->naxes - 1; k >= 0; k--) b = b * g->dim[k] + grid_bucket_1d(g, k, a[k]);
+        for (int e = g->start[b]; e < g->start[b + 1]; e++)
+            if (orc_checkInBlock(c, a0, a1, a2, h, g->cells[e])) return g->cells[e];
+        return -1;
+    }
     for (int i = 0; i < h->num_elements; i++)
         if (orc_checkInBlock(c, a0, a1, a2, h, i)) return i;
     return -1;
@@ -723,6 +801,38 @@ static int cmp_time_then_slot(const void *a, const void *b, void *ctx)
     return (aa > bb) - (aa < bb);
 }
 
+/* optimised mode: photonEvent only ever reads sorted_indexes[0 .. k] for the few candidates it tries (mclib.c:1128-1133), so
+ * only that prefix of the sorted order is produced: the ORC_PREFIX smallest (time, slot) pairs by one pass with a small
+ * insertion buffer; if the walk runs past it (a long Klein-Nishina rejection chain) the full sort is done after all.
+ * sorted_valid[thread] says how much of sorted_indexes is in its final place. */
+#define ORC_PREFIX 8
+static _Thread_local int sorted_valid = 0;
+
+static int before(const orc_photon *ph, int a, int b)      /* the order of cmp_time_then_slot */
+{
+    return cmp_time_then_slot(&a, &b, (void *)ph) < 0;
+}
+
+static void sorted_prefix(orc_photon_list *l, int need)
+{
+    const int n = l->list_capacity;
+    if (need >= ORC_PREFIX || n <= ORC_PREFIX) {
+        for (int i = 0; i < n; i++) l->sorted_indexes[i] = i;
+        qsort_r(l->sorted_indexes, (size_t)n, sizeof(int), cmp_time_then_slot, l->photons);
+        sorted_valid = n;
+        return;
+    }
+    int best[ORC_PREFIX], k = 0;
+    for (int i = 0; i < n; i++) {
+        if (k == ORC_PREFIX && !before(l->photons, i, best[k - 1])) continue;
+        int j = (k < ORC_PREFIX) ? k++ : k - 1;
+        while (j > 0 && before(l->photons, i, best[j - 1])) { best[j] = best[j - 1]; j--; }
+        best[j] = i;
+    }
+    for (int i = 0; i < k; i++) l->sorted_indexes[i] = best[i];
+    sorted_valid = k;
+}
+
 /* mclib.c:617-714 */
 void orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hydro *h, orc_rng *rng)
 {
@@ -742,6 +852,7 @@ void orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hyd
         }
         ph->time_to_scatter = mfp / ORC_C_LIGHT;
     }
+    if (c->optimised) { sorted_prefix(l, 0); return; }
     for (int i = 0; i < l->list_capacity; i++) l->sorted_indexes[i] = i;
     qsort_r(l->sorted_indexes, (size_t)l->list_capacity, sizeof(int), cmp_time_then_slot, l->photons);
 }
@@ -768,6 +879,7 @@ double orc_photonEvent(const orc_config *c, orc_photon_list *l, double dt_max, c
     double scatt_time = 0, old_scatt_time = 0;
 
     while (i < l->list_capacity && event_did_occur == 0) {
+        if (c->optimised && i >= sorted_valid) sorted_prefix(l, i);
         ph_index = l->sorted_indexes[i];
         orc_photon *ph = &l->photons[ph_index];
         scatt_time = ph->time_to_scatter;

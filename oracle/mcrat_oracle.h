@@ -107,7 +107,15 @@ typedef struct orc_config {
     const double *hot_table;
     int n_ph_e, n_t;                /* N_PH_E, N_T: the table has (n_ph_e + 1) x (n_t + 1) entries */
     double log_ph_e_min, log_ph_e_max, log_t_min, log_t_max;
+    /* 0: the reference's algorithm as it is (linear cell search, full argsort every pass) -- the checker and the
+     * "port" baseline.  1: the same arithmetic and the same results, bit for bit, with the two costs a careful CPU
+     * author would remove: the cell search goes through an exact bucket grid (orc_grid_attach) and only the prefix of
+     * the sorted order that photonEvent consumes is produced (bench.py "cpu_optimised"). */
+    int optimised;
 } orc_config;
+/* builds (and replaces) the bucket grid for `h`; used by orc_findContainingBlock when c->optimised and the frame matches */
+void orc_grid_attach(const orc_config *c, const orc_hydro *h);
+void orc_grid_detach(void);
 
 typedef struct orc_stats {
     long long iterations;

@@ -58,7 +58,8 @@ class Hydro(C.Structure):
 class Config(C.Structure):
     _fields_ = [("dimensions", C.c_int), ("geometry", C.c_int), ("stokes_switch", C.c_int), ("tau_calculation", C.c_int),
                 ("hot_table", C.POINTER(C.c_double)), ("n_ph_e", C.c_int), ("n_t", C.c_int),
-                ("log_ph_e_min", C.c_double), ("log_ph_e_max", C.c_double), ("log_t_min", C.c_double), ("log_t_max", C.c_double)]
+                ("log_ph_e_min", C.c_double), ("log_ph_e_max", C.c_double), ("log_t_min", C.c_double), ("log_t_max", C.c_double),
+                ("optimised", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -201,6 +202,8 @@ def lib():
             "orc_boostedCrossSection": (d, [d, d, d]),
             "orc_calculateTotalThermalCrossSection": (d, [d, d, C.c_longlong, C.c_uint64, i]),
             "orc_createHotCrossSection": (None, [_dp, i, i, d, d, d, d, C.c_longlong, C.c_uint64]),
+            "orc_grid_attach": (None, [cfgp, hp]),
+            "orc_grid_detach": (None, []),
             "orc_table_misses": (C.c_longlong, []),
             "orc_reset_table_misses": (None, []),
             "orc_findContainingHydroCell": (i, [cfgp, lp, hp, i, sp]),
@@ -274,10 +277,11 @@ class OraclePhotons:
         self.c.list_capacity = n
 
 
-def make_config(dimensions, geometry, stokes, hot_table=None, grid=None):
+def make_config(dimensions, geometry, stokes, hot_table=None, grid=None, optimised=False):
     """hot_table: (N_PH_E + 1, N_T + 1) array of log10(sigma / sigma_T) -> TAU_CALCULATION == TABLE on the grid
     (log_ph_e_min, log_ph_e_max, log_t_min, log_t_max), default the reference's (hot_x_section.h:2-10)."""
     c = Config(int(dimensions), int(geometry), int(bool(stokes)), 1)
+    c.optimised = int(bool(optimised))           # same results with an exact cell-search grid (orc_grid_attach) and a prefix sort
     if hot_table is not None:
         import numpy as np
         t = np.ascontiguousarray(hot_table, dtype=np.float64)

@@ -803,3 +803,40 @@ def test_hot_cross_section_integrals_known_limits(oracle):
     L.orc_createHotCrossSection(t.ctypes.data_as(C.POINTER(C.c_double)), 2, 1, -3.0, 1.0, -2.0, 0.0, 20000, 9)
     assert t[2, 1] == pytest.approx(np.log10(L.orc_calculateTotalThermalCrossSection(10.0, 1.0, 20000, 9, 5)), rel=1e-15)
     assert t[0, 0] == pytest.approx(0.0, abs=2e-2) and t[2, 0] < t[1, 0] < t[0, 0] + 2e-2
+
+
+@pytest.mark.parametrize("case", ["cfg1", "cfg2-stokes", "cfg3-stokes", "3d-cartesian", "cfg1-hot-kn-chains"])
+def test_optimised_cpu_mode_is_bit_identical_to_the_faithful_one(oracle, case):
+    """orc_config.optimised (the "cpu_optimised" line of bench.py): exact bucket grid instead of the linear cell search, a
+    sorted prefix instead of the full argsort -- same photons, same counters, bit for bit; only faster"""
+    import time
+    if case == "cfg1":
+        frame, ph, cfg = synth.config1(n_photons=600, n0=48, n1=48)
+    elif case == "cfg2-stokes":
+        frame, ph, cfg = synth.config2(n_photons=700, nzc=8, stokes=1, lumi=1e53)
+    elif case == "cfg3-stokes":
+        frame, ph, cfg = synth.config3(n_photons=500, nr=192, nth=48, lumi=1e53)
+    elif case == "3d-cartesian":
+        frame, ph, cfg = synth.config_3d_cartesian(n_photons=400, n=(14, 14, 14))
+    else:
+        frame, ph, cfg = synth.config1(n_photons=300, n0=24, n1=24)
+        frame["temp"] = np.full_like(frame["temp"], 4e9)            # Maxwell-Juttner electrons, long rejection chains: walks past the prefix
+    out, times = [], []
+    for optimised in (False, True):
+        H = oracle.OracleHydro(frame)
+        P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+        c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"], optimised=optimised)
+        if optimised:
+            oracle.lib().orc_grid_attach(C.byref(c), C.byref(H.c))
+        t0 = time.perf_counter()
+        st, tn, rem, _ = oracle.photon_loop(c, P, H, seed=17, time_now=0.0, remaining_time=1.0 / frame["fps"], max_iterations=400)
+        times.append(time.perf_counter() - t0)
+        out.append((P.aos.copy(), (st.iterations, st.frame_scatt_cnt, st.num_photons_find_new_element, st.kn_rejections, st.not_found,
+                                   st.last_scattered_index, tn, rem)))
+    oracle.lib().orc_grid_detach()
+    assert out[0][1] == out[1][1] and out[0][1][1] > 10
+    for k in out[0][0].dtype.names:                                 # (field by field: the bytes between members are not data)
+        a, b = out[0][0][k], out[1][0][k]
+        assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), k
+    if case == "cfg1-hot-kn-chains":
+        assert out[0][1][3] > 50                                    # the rejection chains really happened
