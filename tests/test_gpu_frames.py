@@ -173,3 +173,37 @@ def test_resident_frame_driver_of_the_host_c_equals_the_steps_done_by_hand(hip, 
     c = start()
     assert host.mcrat_host_scatter_frame_resident(c.ctx, bad, None, r_inj, d0, d1, d2, C.byref(t_b), 3, 1, fps, 1, None, None) == -7
     c.close()
+
+
+def test_forty_frames_of_the_structured_jet_stay_consistent(hip):
+    """a short version of tools/lundman_run.py (the manual's global validation set-up): photons injected below the photosphere
+    of a structured jet, forty hydro frames of phMinMax -> slab ingest -> loop as virtual ranks, Stokes on.  Size-independent
+    checks: the clock lands on every frame boundary, the photons' scattering counts add up to the frames' event counters,
+    everything stays finite and physical, the selected slab follows the photons outwards."""
+    fps, r_inj = 5.0, 3e10
+    dom = dict(r0_domain=(1e9, 2.5e13), r1_domain=(0.0, np.pi / 2), r2_domain=(0.0, 0.0))
+    raw = synth.pluto_raw_grid(synth.TWO, synth.SPHERICAL, (1e9, 0.0), (2.5e13, np.pi / 2), (1024, 256), seed=1, log_axis0=True)
+    jet = hip.Engine.outflow(hip.STRUCTURED_SPHERICAL_OUTFLOW, lumi=3e50, theta_j=0.1, p=4.0)
+    e = hip.Engine(synth.TWO, synth.SPHERICAL, 1, virtual_rank_photons=500)
+    e.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **dom), jet)
+    n, w = e.inject_photons(r_inj, 1e48, 10000, 20000, "b", 0.0, 0.08, fps, seed=2014)
+    t, events, r_mean, cells = 0.0, 0, [], []
+    for k in range(40):
+        mm = e.ph_minmax()
+        m, ef, _ = e.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=0, min_r=mm[0], max_r=mm[1], min_theta=mm[2], max_theta=mm[3], fps=fps, **dom), jet)
+        t, st = e.propagate_frame(t, (k + 1) / fps - t, 700 + k)
+        assert t == pytest.approx((k + 1) / fps, rel=1e-14) and st.remaining_time == 0.0
+        events += st.frame_scatt_cnt
+        r_mean.append(e.scatt_stats()[3])
+        cells.append(m)
+        assert ef == 1 and m > 0
+    out = e.get_photons_aos()
+    assert int(out["num_scatt"].sum()) == events and events > 5 * n           # tau ~ 6 at injection on the axis
+    assert (np.diff(r_mean) > 0).all() and r_mean[-1] == pytest.approx(r_inj + 39.5 / fps * synth.C_LIGHT, rel=0.05)   # streaming outwards at ~c
+    for k in ("p0", "p1", "p2", "p3", "r0", "r1", "r2", "s0", "s1", "s2", "s3"):
+        assert np.isfinite(out[k]).all(), k
+    assert np.allclose(np.sqrt(out["p1"] ** 2 + out["p2"] ** 2 + out["p3"] ** 2), out["p0"], rtol=1e-12)     # null 4-momenta
+    assert (out["s0"] == 1).all() and (np.hypot(out["s1"], out["s2"]) <= 1 + 1e-9).all() and (out["s3"] == 0).all()
+    assert (out["weight"] == w).all() and (out["type"] == b"i").all()
+    assert cells[-1] < cells[0]                                                 # a narrower shell of the log-r mesh as the pulse thins out
+    e.close()
