@@ -125,7 +125,14 @@ def ingest_vectors():
         for k in INGEST_COLUMNS:
             out[name + "_" + k] = cols[k][pick]
         out[name + "_sums"] = np.array([cols[k].sum() for k in INGEST_COLUMNS])
+    # createHotCrossSection: a 5 x 4 table of 4000-sample Monte-Carlo integrals on an off-reference grid
+    t = np.empty((5, 4))
+    O.lib().orc_createHotCrossSection(t.ctypes.data_as(C.POINTER(C.c_double)), 4, 3, *HOT_GRID, 4000, 123)
+    out["hot_table"] = t
     return out
+
+
+HOT_GRID = (-5.0, 1.5, -2.5, 1.0)
 
 
 if __name__ == "__main__":

@@ -92,6 +92,7 @@ def test_oracle_reproduces_ingest_vectors(oracle):
         else:
             assert np.allclose(got[k], want[k], rtol=1e-12, atol=1e-300), k
     assert all(want[n + "_counts"][0] > 100 for n in mg.INGEST)
+    assert (want["hot_table"] < 0.03).all() and want["hot_table"][4, 3] < -0.5     # sigma <= sigma_T; hard photons, hot electrons
 
 
 @pytest.mark.gpu
@@ -109,4 +110,14 @@ def test_hip_engine_reproduces_ingest_vectors(name):
     for k in mg.INGEST_COLUMNS:
         assert np.allclose(cols[k][pick], want[name + "_" + k], rtol=1e-12, atol=1e-300), k
     assert np.allclose([cols[k].sum() for k in mg.INGEST_COLUMNS], want[name + "_sums"], rtol=1e-11, atol=1e-300)
+    e.close()
+
+
+@pytest.mark.gpu
+def test_hip_engine_reproduces_hot_table_vector():
+    from mcrat_amd import engine
+    want = np.load(os.path.join(GOLD, "ingest.npz"))["hot_table"]
+    e = engine.Engine(synth.TWO, synth.CYLINDRICAL, 0)
+    got = e.create_hot_cross_section(4, 3, mg.HOT_GRID, calls=4000, seed=123)
+    assert np.allclose(got, want, rtol=0, atol=1e-9)
     e.close()
