@@ -274,6 +274,42 @@ void orc_sphericalPrep(const orc_config *c, const orc_outflow *o, orc_frame *f);
 void orc_structuredFireballPrep(const orc_config *c, const orc_outflow *o, orc_frame *f); /* analytic_outflows.c:138 */
 void orc_hydro_post_read(const orc_config *c, const orc_outflow *o, orc_frame *f);        /* mcrat_io.c:1962-1975 */
 
+/* ---- cyclo-synchrotron, first part (oracle_cyclosynch.c) ---------------------------------- */
+#define ORC_B_INTERNAL_E 0      /* B_FIELD_CALC, mcrat.h:47-49 */
+#define ORC_B_TOTAL_E    1
+#define ORC_B_SIMULATION 2
+typedef struct orc_cs {
+    int    b_field_calc;
+    double epsilon_b;           /* EPSILON_B (mcrat.h:334 default 0.5) */
+    double rebin_e_perc;        /* CYCLOSYNCHROTRON_REBIN_E_PERC (mcrat.h:311 default 0.1) */
+    const double *dens;         /* hydro_data->dens (comoving density), per cell */
+    const double *B0, *B1, *B2; /* hydro_data->B0-2 when B_FIELD_CALC == SIMULATION */
+    int    scatt_frame_number, inj_frame_number;   /* hydro_data->scatt_frame_number / ->inj_frame_number */
+} orc_cs;
+typedef double (*orc_integrand)(double x, void *ctx);
+void   orc_list_init(orc_photon_list *l);                                         /* photons.c:3 */
+void   orc_list_free(orc_photon_list *l);                                         /* photons.c:12 */
+int    orc_list_set(orc_photon_list *l, const orc_photon *ph, int n);             /* setPhotonList, photons.c:82 */
+int    orc_list_realloc(orc_photon_list *l, int new_capacity);                    /* photons.c:37 */
+int    orc_list_add(orc_photon_list *l, const orc_photon *ph, int num);           /* addToPhotonList, photons.c:108 */
+int    orc_list_set_null(orc_photon_list *l, int index);                          /* setNullPhoton, photons.c:210 */
+double orc_calcCyclotronFreq(double magnetic_field);                              /* mc_cyclosynch.c:30 */
+double orc_calcEB(double magnetic_field);
+double orc_calcDimlessTheta(double temp);
+double orc_calcBoundaryE(double magnetic_field, double temp);
+double orc_calcB(const orc_cs *cs, double el_dens, double temp);                  /* :54 */
+double orc_getMagneticFieldMagnitude(const orc_config *c, const orc_cs *cs, const orc_hydro *h, int i);   /* :78 */
+double orc_blackbody_ph_spect(double nu, double temp);                            /* :185 */
+double orc_calcCyclosynchRLimits(int frame_scatt, int frame_inj, double fps, double r_inj, int want_max);  /* :225 */
+void   orc_qk21(orc_integrand f, void *ctx, double a, double b, double *result, double *abserr, double *resabs, double *resasc);
+int    orc_qags(orc_integrand f, void *ctx, double a, double b, double epsabs, double epsrel, int limit, double *result, double *abserr,
+                int *used_fallback);
+int    orc_photonEmitCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, double r_inj, double ph_weight, int maximum_photons,
+                                double theta_min, double theta_max, const orc_hydro *h, orc_rng *rng, int inject_single_switch, int scatt_ph_index,
+                                double *weight_out, int *used_fallback_out);     /* :1176 */
+double orc_phAbsCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, const orc_hydro *h, int *num_abs_ph,
+                           int *scatt_cyclosynch_num_ph);                        /* :1571 */
+
 /* helpers for ctypes */
 int    orc_sizeof_photon(void);
 

@@ -1,0 +1,407 @@
+/*
+ * oracle_cyclosynch.c -- CPU oracle for the cyclo-synchrotron row, first part: the photon-list
+ * operations it needs, the magnetic-field helpers, the emission of the pool photons and of a single replacement photon,
+ * and the absorption at the end of a frame.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see mcrat_oracle.h.  The device
+ * side of this row is not built yet: this file is the checker it will be built against.
+ * Not restated yet: rebinCyclosynchCompPhotons (mc_cyclosynch.c:246-712) and the loop hooks of mcrat.c:788-808,853-878.
+ *
+ * Restated from the reference:
+ *   list operations          Src/photons.c:3-285 (exit(1) paths become error returns)
+ *   calcCyclotronFreq ... getMagneticFieldMagnitude   Src/mc_cyclosynch.c:30-92
+ *   blackbody_ph_spect       :185-196;   calcCyclosynchRLimits :225-244
+ *   photonEmitCyclosynch     :1176-1569 (both inject_single_switch branches)
+ *   phAbsCyclosynch          :1571-1623
+ * Third-party arithmetic: gsl_integration_qags (:1276) lives in GSL (unpinned version).  Its published algorithm (QUADPACK
+ * QAGS) starts with one 21-point Gauss-Kronrod rule on the whole interval and returns at once when that rule's error
+ * estimate meets the tolerance; the integrand here -- the Planck photon number density from 10 Hz to the cyclotron
+ * frequency, far down the Rayleigh-Jeans tail, with epsrel = 1e-2 -- is linear in nu to many digits, so QAGS never gets
+ * past that first rule.  orc_qags restates the rule (QUADPACK's nodes, weights and error heuristic) and the first-step test;
+ * should a caller hand it an integrand that does not converge at once it falls back to plain bisection of the worst
+ * interval WITHOUT the epsilon-algorithm extrapolation and reports that through *used_fallback (tests assert it stays 0).
+ * gsl_ran_poisson: the oracle's own sampler, as for photonInjection (orc_poisson).
+ */
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "mcrat_oracle.h"
+
+#define ORC_CHARGE_EL 4.8032068e-10       /* Src/mclib.c:4-5 */
+
+/* ---- Src/photons.c ------------------------------------------------------------------------------------------- */
+void orc_list_init(orc_photon_list *l) { memset(l, 0, sizeof *l); }                       /* :3-10 */
+
+void orc_list_free(orc_photon_list *l)                                                     /* :12-21 */
+{
+    free(l->photons); free(l->sorted_indexes);
+    memset(l, 0, sizeof *l);
+}
+
+static int verify_num(const orc_photon_list *l) { return (l->num_photons + l->num_null_photons != l->list_capacity) ? -1 : 0; }   /* :277-285 */
+
+int orc_list_set_null(orc_photon_list *l, int index)                                       /* setNullPhoton :210-250 */
+{
+    orc_photon *p = &l->photons[index];
+    p->type = ORC_NULL_PHOTON;
+    p->weight = 0;
+    p->nearest_block_index = -1;
+    p->recalc_properties = 0;
+    p->p0 = p->p1 = p->p2 = p->p3 = 0;
+    p->comv_p0 = p->comv_p1 = p->comv_p2 = p->comv_p3 = 0;
+    p->r0 = p->r1 = p->r2 = 0;
+    p->s0 = p->s1 = p->s2 = p->s3 = 0;
+    p->num_scatt = 0;
+    p->total_optical_depth = 0;
+    l->num_photons -= 1;                                                                   /* incrementNullPhotonNum :268-274 */
+    l->num_null_photons += 1;
+    return verify_num(l);
+}
+
+int orc_list_realloc(orc_photon_list *l, int new_capacity)                                 /* :37-80 */
+{
+    const int old = l->list_capacity;
+    orc_photon *np = (orc_photon *)realloc(l->photons, (size_t)new_capacity * sizeof(orc_photon));
+    int *ns = (int *)realloc(l->sorted_indexes, (size_t)new_capacity * sizeof(int));
+    if (!np || !ns) return -2;
+    l->photons = np; l->sorted_indexes = ns;
+    l->list_capacity = new_capacity;
+    l->num_photons += (new_capacity - old);        /* the new slots count as real ... */
+    for (int i = old; i < new_capacity; i++)
+        if (orc_list_set_null(l, i)) return -1;    /* ... until setNullPhoton turns each into a null one */
+    return 0;
+}
+
+int orc_list_set(orc_photon_list *l, const orc_photon *ph, int n)                          /* setPhotonList :82-106 */
+{
+    if (l->photons) orc_list_free(l);
+    l->photons = (orc_photon *)malloc((size_t)(n > 0 ? n : 1) * sizeof(orc_photon));
+    l->sorted_indexes = (int *)malloc((size_t)(n > 0 ? n : 1) * sizeof(int));
+    if (!l->photons || !l->sorted_indexes) return -2;
+    memcpy(l->photons, ph, (size_t)n * sizeof(orc_photon));
+    l->list_capacity = n;
+    l->num_photons = n;                            /* as the reference: null photons are counted in num_photons here too */
+    int nulls = 0;
+    for (int i = 0; i < n; i++) nulls += l->photons[i].type == ORC_NULL_PHOTON;
+    l->num_null_photons = nulls;
+    return 0;
+}
+
+/* addToPhotonList :108-208.  Returns 0, -1 on the conservation error, -3 where the reference prints "Adding to the photon list
+ * has failed" and exits (fewer null slots than photons to add, and no growth) */
+int orc_list_add(orc_photon_list *l, const orc_photon *ph, int num)
+{
+    if ((l->num_photons >= l->list_capacity) && (l->num_null_photons <= num)) {
+        int new_capacity;
+        if (l->list_capacity * 2 > l->list_capacity + num) new_capacity = l->list_capacity * 2;
+        else new_capacity = l->list_capacity * (num / l->list_capacity);
+        const int rc = orc_list_realloc(l, new_capacity);
+        if (rc) return rc;
+    }
+    if (num == 1) {
+        int idx = 0;
+        if (l->num_null_photons == 0) idx = l->num_photons;
+        else
+            for (int i = 0; i < l->list_capacity; i++)
+                if (l->photons[i].type == ORC_NULL_PHOTON) { idx = i; break; }
+        if (idx < 0 || idx >= l->list_capacity) return -3;     /* the reference would write past the array here */
+        memcpy(&l->photons[idx], ph, sizeof(orc_photon));
+        l->num_photons += 1; l->num_null_photons -= 1;          /* incrementPhotonNum :260-266 */
+        return verify_num(l);
+    }
+    if (num > l->num_null_photons) return -3;
+    int *nulls = (int *)malloc(sizeof(int) * (size_t)(l->num_null_photons > 0 ? l->num_null_photons : 1)), j = 0;
+    for (int i = 0; i < l->list_capacity; i++)
+        if (l->photons[i].type == ORC_NULL_PHOTON) nulls[j++] = i;
+    int rc = 0;
+    for (int i = 0; i < num && !rc; i++)
+        if (ph[i].type != ORC_NULL_PHOTON) {
+            memcpy(&l->photons[nulls[i]], &ph[i], sizeof(orc_photon));
+            l->num_photons += 1; l->num_null_photons -= 1;
+            rc = verify_num(l);
+        }
+    free(nulls);
+    return rc;
+}
+
+/* ---- mc_cyclosynch.c:30-92 ----------------------------------------------------------------------------------- */
+double orc_calcCyclotronFreq(double magnetic_field) { return ORC_CHARGE_EL * magnetic_field / (2 * M_PI * ORC_M_EL * ORC_C_LIGHT); }
+double orc_calcEB(double magnetic_field) { return ORC_PL_CONST * orc_calcCyclotronFreq(magnetic_field); }
+double orc_calcDimlessTheta(double temp) { return ORC_K_B * temp / (ORC_M_EL * ORC_C_LIGHT * ORC_C_LIGHT); }
+double orc_calcBoundaryE(double magnetic_field, double temp)
+{
+    return 14 * pow(ORC_M_EL * ORC_C_LIGHT * ORC_C_LIGHT, 1.0 / 10.0) * pow(orc_calcEB(magnetic_field), 9.0 / 10.0) * pow(orc_calcDimlessTheta(temp), 3.0 / 10.0);
+}
+
+double orc_calcB(const orc_cs *cs, double el_dens, double temp)                            /* :54-76 */
+{
+    if (cs->b_field_calc == ORC_B_INTERNAL_E) return sqrt(cs->epsilon_b * 8 * M_PI * 3 * el_dens * ORC_K_B * temp / 2);
+    if (cs->b_field_calc == ORC_B_TOTAL_E)
+        return sqrt(8 * M_PI * cs->epsilon_b * (el_dens * ORC_M_P * ORC_C_LIGHT * ORC_C_LIGHT + 4 * ORC_A_RAD * temp * temp * temp * temp / 3));
+    return 0;
+}
+
+double orc_getMagneticFieldMagnitude(const orc_config *c, const orc_cs *cs, const orc_hydro *h, int i)   /* :78-92 */
+{
+    if (cs->b_field_calc == ORC_B_INTERNAL_E || cs->b_field_calc == ORC_B_TOTAL_E) return orc_calcB(cs, cs->dens[i] / ORC_M_P, h->temp[i]);
+    if (c->dimensions == ORC_TWO) return sqrt(cs->B0[i] * cs->B0[i] + cs->B1[i] * cs->B1[i]);          /* vectorMagnitude, geometry.c:176-187 */
+    return sqrt(cs->B0[i] * cs->B0[i] + cs->B1[i] * cs->B1[i] + cs->B2[i] * cs->B2[i]);
+}
+
+double orc_blackbody_ph_spect(double nu, double temp)                                       /* :185-196 */
+{
+    return (8 * M_PI * nu * nu) / (exp(ORC_PL_CONST * nu / (ORC_K_B * temp)) - 1) / (ORC_C_LIGHT * ORC_C_LIGHT * ORC_C_LIGHT);
+}
+
+double orc_calcCyclosynchRLimits(int frame_scatt, int frame_inj, double fps, double r_inj, int want_max)   /* :225-244 */
+{
+    double val = r_inj;
+    if (!want_max) val += (ORC_C_LIGHT * (frame_scatt - frame_inj) / fps - 0.5 * ORC_C_LIGHT / fps);
+    else val += (ORC_C_LIGHT * (frame_scatt - frame_inj) / fps + 0.5 * ORC_C_LIGHT / fps);
+    return val;
+}
+
+/* ---- QUADPACK's 21-point Gauss-Kronrod rule (dqk21) and QAGS' first step (see the head of this file) ---------- */
+static const double XGK[11] = {0.995657163025808080735527280689003, 0.973906528517171720077964012084452, 0.930157491355708226001207180059508,
+                               0.865063366688984510732096688423493, 0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+                               0.562757134668604683339000099272694, 0.433395394129247190799265943165784, 0.294392862701460198131126603103866,
+                               0.148874338981631210884826001129720, 0.0};
+static const double WGK[11] = {0.011694638867371874278064396062192, 0.032558162307964727478818972459390, 0.054755896574351996031381300244580,
+                               0.075039674810919952767043140916190, 0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+                               0.123491976262065851077958109585166, 0.134709217311473325928054001771707, 0.142775938577060080797094273138717,
+                               0.147739104901338491374841515972068, 0.149445554002916905664936468389821};
+static const double WG[5] = {0.066671344308688137593568809893332, 0.149451349150580593145776339657697, 0.219086362515982043995534934228163,
+                             0.269266719309996355091226921569469, 0.295524224714752870173815619188769};
+
+void orc_qk21(orc_integrand f, void *ctx, double a, double b, double *result, double *abserr, double *resabs, double *resasc)
+{
+    const double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    const double fc = f(centr, ctx);
+    double fv1[10], fv2[10], resg = 0, resk = WGK[10] * fc, rabs = fabs(resk);
+    for (int j = 0; j < 5; j++) {
+        const int jtw = 2 * j + 1;
+        const double absc = hlgth * XGK[jtw], f1 = f(centr - absc, ctx), f2 = f(centr + absc, ctx);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        resg += WG[j] * (f1 + f2);
+        resk += WGK[jtw] * (f1 + f2);
+        rabs += WGK[jtw] * (fabs(f1) + fabs(f2));
+    }
+    for (int j = 0; j < 5; j++) {
+        const int jtwm1 = 2 * j;
+        const double absc = hlgth * XGK[jtwm1], f1 = f(centr - absc, ctx), f2 = f(centr + absc, ctx);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        resk += WGK[jtwm1] * (f1 + f2);
+        rabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    const double reskh = resk * 0.5;
+    double rasc = WGK[10] * fabs(fc - reskh);
+    for (int j = 0; j < 10; j++) rasc += WGK[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    double err = fabs((resk - resg) * hlgth);
+    *result = resk * hlgth;
+    rabs *= dhlgth; rasc *= dhlgth;
+    if (rasc != 0 && err != 0) { const double s = pow(200 * err / rasc, 1.5); err = (s < 1) ? rasc * s : rasc; }
+    if (rabs > DBL_MIN / (50 * DBL_EPSILON)) { const double m = 50 * DBL_EPSILON * rabs; if (m > err) err = m; }
+    *abserr = err; *resabs = rabs; *resasc = rasc;
+}
+
+int orc_qags(orc_integrand f, void *ctx, double a, double b, double epsabs, double epsrel, int limit, double *result, double *abserr,
+             int *used_fallback)
+{
+    double res, err, rabs, rasc;
+    if (used_fallback) *used_fallback = 0;
+    orc_qk21(f, ctx, a, b, &res, &err, &rabs, &rasc);
+    double tol = fmax(epsabs, epsrel * fabs(res));
+    *result = res; *abserr = err;
+    if (err <= 100 * DBL_EPSILON * rabs && err > tol) return 1;                    /* GSL_EROUND */
+    if ((err <= tol && err != rasc) || err == 0.0) return 0;
+    if (limit <= 1) return 2;
+    /* not QAGS any more: bisect the interval with the largest error until the sum of the errors meets the tolerance */
+    if (used_fallback) *used_fallback = 1;
+    double *al = (double *)malloc(sizeof(double) * 4 * (size_t)limit), *bl = al + limit, *rl = bl + limit, *el = rl + limit;
+    int n = 1;
+    al[0] = a; bl[0] = b; rl[0] = res; el[0] = err;
+    int rc = 2;
+    while (n < limit) {
+        int worst = 0;
+        for (int k = 1; k < n; k++) if (el[k] > el[worst]) worst = k;
+        const double mid = 0.5 * (al[worst] + bl[worst]);
+        double r1, e1, r2, e2, t1, t2;
+        orc_qk21(f, ctx, al[worst], mid, &r1, &e1, &t1, &t2);
+        orc_qk21(f, ctx, mid, bl[worst], &r2, &e2, &t1, &t2);
+        al[n] = mid; bl[n] = bl[worst]; rl[n] = r2; el[n] = e2;
+        bl[worst] = mid; rl[worst] = r1; el[worst] = e1;
+        n++;
+        double sr = 0, se = 0;
+        for (int k = 0; k < n; k++) { sr += rl[k]; se += el[k]; }
+        *result = sr; *abserr = se;
+        tol = fmax(epsabs, epsrel * fabs(sr));
+        if (se <= tol) { rc = 0; break; }
+    }
+    free(al);
+    return rc;
+}
+
+static double planck_tail(double nu, void *ctx) { return orc_blackbody_ph_spect(nu, *(const double *)ctx); }
+
+/* ---- photonEmitCyclosynch, mc_cyclosynch.c:1176-1569 ---------------------------------------------------------- */
+#define RNG_CS_COUNT 5u
+#define RNG_CS_PHOTON 6u
+#define RNG_CS_SINGLE 7u
+
+static int in_emission_slab(const orc_config *c, const orc_hydro *h, int i, double rmin, double rmax, double theta_min, double theta_max)   /* :1215-1226 */
+{
+    double r_in, th_in, r_out, th_out;
+    if (c->dimensions == ORC_THREE) {
+        orc_hydroCoordinateToSpherical(c, &r_in, &th_in, fabs(h->r0[i]) - 0.5 * h->r0_size[i], fabs(h->r1[i]) - 0.5 * h->r1_size[i], fabs(h->r2[i]) - 0.5 * h->r2_size[i]);
+        orc_hydroCoordinateToSpherical(c, &r_out, &th_out, fabs(h->r0[i]) + 0.5 * h->r0_size[i], fabs(h->r1[i]) + 0.5 * h->r1_size[i], fabs(h->r2[i]) + 0.5 * h->r2_size[i]);
+    } else {
+        orc_hydroCoordinateToSpherical(c, &r_in, &th_in, h->r0[i] - 0.5 * h->r0_size[i], h->r1[i] - 0.5 * h->r1_size[i], 0);
+        orc_hydroCoordinateToSpherical(c, &r_out, &th_out, h->r0[i] + 0.5 * h->r0_size[i], h->r1[i] + 0.5 * h->r1_size[i], 0);
+    }
+    return (rmin <= r_out) && (r_in < rmax) && (th_out >= theta_min) && (th_in < theta_max);
+}
+
+/* one pool photon at the centre of cell i with the frequency nu_c, direction from three (two in 3-D) uniform draws (:1380-1440) */
+static void emit_one(const orc_config *c, const orc_hydro *h, int i, double nu_c, double weight, int block_index, orc_rng *rng, orc_photon *out,
+                     double *position_phi_out)
+{
+    const double fr_dum = nu_c;
+    double position_phi = 0;
+    if (c->dimensions != ORC_THREE) position_phi = orc_rng_uniform(rng) * 2 * M_PI;
+    const double com_v_phi = orc_rng_uniform(rng) * 2 * M_PI;
+    const double com_v_theta = orc_rng_uniform(rng) * M_PI;
+    double p_comv[4], boost[3], l_boost[4], pos[3];
+    p_comv[0] = ORC_PL_CONST * fr_dum / ORC_C_LIGHT;
+    p_comv[1] = (ORC_PL_CONST * fr_dum / ORC_C_LIGHT) * sin(com_v_theta) * cos(com_v_phi);
+    p_comv[2] = (ORC_PL_CONST * fr_dum / ORC_C_LIGHT) * sin(com_v_theta) * sin(com_v_phi);
+    p_comv[3] = (ORC_PL_CONST * fr_dum / ORC_C_LIGHT) * cos(com_v_theta);
+    if (c->dimensions == ORC_THREE) orc_hydroVectorToCartesian(c, boost, h->v0[i], h->v1[i], h->v2[i], h->r0[i], h->r1[i], h->r2[i]);
+    else if (c->dimensions == ORC_TWO_POINT_FIVE) orc_hydroVectorToCartesian(c, boost, h->v0[i], h->v1[i], h->v2[i], h->r0[i], h->r1[i], position_phi);
+    else orc_hydroVectorToCartesian(c, boost, h->v0[i], h->v1[i], 0, h->r0[i], h->r1[i], position_phi);
+    boost[0] *= -1; boost[1] *= -1; boost[2] *= -1;
+    orc_lorentzBoost(boost, p_comv, l_boost, 'p');
+    memset(out, 0, sizeof *out);
+    out->p0 = l_boost[0]; out->p1 = l_boost[1]; out->p2 = l_boost[2]; out->p3 = l_boost[3];
+    out->comv_p0 = p_comv[0]; out->comv_p1 = p_comv[1]; out->comv_p2 = p_comv[2]; out->comv_p3 = p_comv[3];
+    if (c->dimensions == ORC_THREE) orc_hydroCoordinateToMcratCoordinate(c, pos, h->r0[i], h->r1[i], h->r2[i]);
+    else orc_hydroCoordinateToMcratCoordinate(c, pos, h->r0[i], h->r1[i], position_phi);
+    out->r0 = pos[0]; out->r1 = pos[1]; out->r2 = pos[2];
+    out->s0 = 1; out->s1 = 0; out->s2 = 0; out->s3 = 0;
+    out->num_scatt = 0;
+    out->weight = weight;
+    out->nearest_block_index = block_index;
+    out->type = ORC_CS_POOL_PHOTON;
+    out->recalc_properties = 1;
+    if (position_phi_out) *position_phi_out = position_phi;
+}
+
+/* Returns the number of photons emitted (>= 0) or a negative orc_list_add error.  *weight_out receives ph_weight_adjusted (pool mode).
+ * rng: pool mode uses its seed / stream for the keyed streams described in the header; single mode draws from the stream
+ * {rng's current iteration, scatt_ph_index, CS_SINGLE}. */
+int orc_photonEmitCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, double r_inj, double ph_weight, int maximum_photons,
+                             double theta_min, double theta_max, const orc_hydro *h, orc_rng *rng, int inject_single_switch, int scatt_ph_index,
+                             double *weight_out, int *used_fallback_out)
+{
+    int ph_tot = 0, fallback_any = 0;
+    orc_photon *ph_emit = NULL;
+    if (inject_single_switch == 0) {
+        const double max_photons = cs->rebin_e_perc * maximum_photons;                      /* :1178 */
+        const double rmin = orc_calcCyclosynchRLimits(cs->scatt_frame_number, cs->inj_frame_number, h->fps, r_inj, 0);
+        const double rmax = orc_calcCyclosynchRLimits(cs->scatt_frame_number, cs->inj_frame_number, h->fps, r_inj, 1);
+        int block_cnt = 0, min_photons = 1;
+        for (int i = 0; i < h->num_elements; i++) block_cnt += in_emission_slab(c, h, i, rmin, rmax, theta_min, theta_max);
+        if (block_cnt == 0) min_photons = 0;                                                /* :1236-1239 */
+        int *ph_dens = (int *)calloc((size_t)(block_cnt > 0 ? block_cnt : 1), sizeof(int));
+        double ph_weight_adjusted = ph_weight;
+        ph_tot = -1;
+        for (uint64_t attempt = 0; (ph_tot > max_photons) || (ph_tot < min_photons); attempt++) {   /* :1244-1296 */
+            int j = 0;
+            ph_tot = 0;
+            orc_rng_set_iteration(rng, attempt);
+            for (int i = 0; i < h->num_elements; i++) {
+                if (!in_emission_slab(c, h, i, rmin, rmax, theta_min, theta_max)) continue;
+                const double b_field = orc_getMagneticFieldMagnitude(c, cs, h, i);
+                const double nu_c = orc_calcCyclotronFreq(b_field);
+                double temp = h->temp[i], ph_dens_calc = 0, error = 0;
+                int fb = 0;
+                (void)orc_qags(planck_tail, &temp, 10, nu_c, 0, 1e-2, 10000, &ph_dens_calc, &error, &fb);   /* :1276 */
+                fallback_any |= fb;
+                ph_dens_calc *= orc_hydroElementVolume(c, h, i) / ph_weight_adjusted;
+                orc_rng_stream_begin(rng, (uint32_t)i, RNG_CS_COUNT);
+                const long long k = orc_poisson(rng, ph_dens_calc);
+                ph_dens[j] = (k > 2147483647LL) ? 2147483647 : (int)k;
+                ph_tot += ph_dens[j];
+                j++;
+            }
+            if (ph_tot > max_photons) ph_weight_adjusted *= 10;
+            else if (ph_tot < min_photons) ph_weight_adjusted *= 0.5;
+            if (attempt > 400) { free(ph_dens); return -4; }
+        }
+        ph_emit = (orc_photon *)calloc((size_t)(ph_tot > 0 ? ph_tot : 1), sizeof(orc_photon));
+        const int net_ph = ph_tot;
+        int k = 0;
+        ph_tot = 0;
+        orc_rng_set_iteration(rng, 0);
+        for (int i = 0; i < h->num_elements && ph_tot < net_ph; i++) {                       /* :1340-1455 */
+            if (!in_emission_slab(c, h, i, rmin, rmax, theta_min, theta_max)) continue;
+            const double nu_c = orc_calcCyclotronFreq(orc_getMagneticFieldMagnitude(c, cs, h, i));
+            for (int j = 0; j < ph_dens[k] && ph_tot < net_ph; j++) {
+                orc_rng_stream_begin(rng, (uint32_t)ph_tot, RNG_CS_PHOTON);
+                emit_one(c, h, i, nu_c, ph_weight_adjusted, 0, rng, &ph_emit[ph_tot], NULL);   /* nearest_block_index = 0, :1436 */
+                ph_tot++;
+            }
+            k++;
+        }
+        free(ph_dens);
+        if (weight_out) *weight_out = ph_weight_adjusted;
+    } else {                                                                                /* :1467-1558 */
+        ph_tot = 1;
+        ph_emit = (orc_photon *)calloc(1, sizeof(orc_photon));
+        orc_photon *tmp = &l->photons[scatt_ph_index];
+        const int i = tmp->nearest_block_index;
+        const double nu_c = orc_calcCyclotronFreq(orc_getMagneticFieldMagnitude(c, cs, h, i));
+        double position_phi = 0, pos[3];
+        orc_rng_stream_begin(rng, (uint32_t)scatt_ph_index, RNG_CS_SINGLE);
+        emit_one(c, h, i, nu_c, tmp->weight, i, rng, &ph_emit[0], &position_phi);
+        /* the photon that just scattered is moved to a random place in its cell (:1540-1556) */
+        const double position_rand = orc_rng_uniform_pos(rng) * h->r0_size[i] - h->r0_size[i] / 2.0;
+        const double position2_rand = orc_rng_uniform_pos(rng) * h->r1_size[i] - h->r1_size[i] / 2.0;
+        if (c->dimensions == ORC_THREE) {
+            const double position3_rand = orc_rng_uniform_pos(rng) * h->r2_size[i] - h->r2_size[i] / 2.0;
+            orc_hydroCoordinateToMcratCoordinate(c, pos, h->r0[i] + position_rand, h->r1[i] + position2_rand, h->r2[i] + position3_rand);
+        } else {
+            orc_hydroCoordinateToMcratCoordinate(c, pos, h->r0[i] + position_rand, h->r1[i] + position2_rand, position_phi);
+        }
+        tmp->r0 = pos[0]; tmp->r1 = pos[1]; tmp->r2 = pos[2];
+    }
+    const int rc = (ph_tot > 0) ? orc_list_add(l, ph_emit, ph_tot) : 0;                     /* :1560 */
+    free(ph_emit);
+    if (used_fallback_out) *used_fallback_out = fallback_any;
+    return rc ? rc : ph_tot;
+}
+
+/* ---- phAbsCyclosynch, mc_cyclosynch.c:1571-1623 ---------------------------------------------------------------- */
+double orc_phAbsCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, const orc_hydro *h, int *num_abs_ph, int *scatt_cyclosynch_num_ph)
+{
+    int abs_ph_count = 0;
+    double abs_count = 0;
+    *scatt_cyclosynch_num_ph = 0;
+    for (int i = 0; i < l->list_capacity; i++) {
+        orc_photon *ph = &l->photons[i];
+        if ((ph->weight != 0) && (ph->nearest_block_index != -1)) {
+            const double b_field = orc_getMagneticFieldMagnitude(c, cs, h, ph->nearest_block_index);
+            const double nu_c = orc_calcCyclotronFreq(b_field);
+            if ((ph->comv_p0 * ORC_C_LIGHT / ORC_PL_CONST <= nu_c) || (ph->type == ORC_CS_POOL_PHOTON)) {
+                abs_ph_count++;
+                if ((ph->type == ORC_INJECTED_PHOTON) || (ph->type == ORC_UNABSORBED_CS_PHOTON)) {
+                    abs_count += ph->weight;
+                    ph->p0 = -1;                      /* overwritten by setNullPhoton right below, as in the reference */
+                }
+                (void)orc_list_set_null(l, i);
+            } else if ((ph->type == ORC_COMPTONIZED_PHOTON) || (ph->type == ORC_UNABSORBED_CS_PHOTON)) {
+                *scatt_cyclosynch_num_ph += 1;
+            }
+        }
+    }
+    *num_abs_ph = abs_ph_count;
+    return abs_count;
+}

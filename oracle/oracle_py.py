@@ -138,6 +138,13 @@ def fill_chombo(raw, level_type, top_type, keep):
     return h
 
 
+class CS(C.Structure):
+    """orc_cs: the cyclo-synchrotron switches and the extra hydro columns (oracle_cyclosynch.c)"""
+    _fields_ = [("b_field_calc", C.c_int), ("epsilon_b", C.c_double), ("rebin_e_perc", C.c_double), ("dens", C.POINTER(C.c_double)),
+                ("B0", C.POINTER(C.c_double)), ("B1", C.POINTER(C.c_double)), ("B2", C.POINTER(C.c_double)),
+                ("scatt_frame_number", C.c_int), ("inj_frame_number", C.c_int)]
+
+
 class Outflow(C.Structure):
     _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
                 ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
@@ -146,7 +153,7 @@ class Outflow(C.Structure):
 def build(force=False):
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("mcrat_oracle.c", "oracle_ingest.c", "mcrat_oracle.h", "oracle_rng.c", "oracle_rng.h")):
+            for f in ("mcrat_oracle.c", "oracle_ingest.c", "oracle_cyclosynch.c", "mcrat_oracle.h", "oracle_rng.c", "oracle_rng.h")):
         subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
     return _LIB_PATH
 
@@ -204,6 +211,15 @@ def lib():
             "orc_createHotCrossSection": (None, [_dp, i, i, d, d, d, d, C.c_longlong, C.c_uint64]),
             "orc_grid_attach": (None, [cfgp, hp]),
             "orc_grid_detach": (None, []),
+            "orc_list_init": (None, [lp]), "orc_list_free": (None, [lp]), "orc_list_set": (i, [lp, p, i]), "orc_list_realloc": (i, [lp, i]),
+            "orc_list_add": (i, [lp, p, i]), "orc_list_set_null": (i, [lp, i]),
+            "orc_calcCyclotronFreq": (d, [d]), "orc_calcEB": (d, [d]), "orc_calcDimlessTheta": (d, [d]), "orc_calcBoundaryE": (d, [d, d]),
+            "orc_calcB": (d, [C.POINTER(CS), d, d]), "orc_getMagneticFieldMagnitude": (d, [cfgp, C.POINTER(CS), hp, i]),
+            "orc_blackbody_ph_spect": (d, [d, d]), "orc_calcCyclosynchRLimits": (d, [i, i, d, d, i]),
+            "orc_qk21": (None, [C.c_void_p, p, d, d, _dp, _dp, _dp, _dp]),
+            "orc_qags": (i, [C.c_void_p, p, d, d, d, d, i, _dp, _dp, C.POINTER(i)]),
+            "orc_photonEmitCyclosynch": (i, [cfgp, C.POINTER(CS), lp, d, d, i, d, d, hp, rp, i, i, _dp, C.POINTER(i)]),
+            "orc_phAbsCyclosynch": (d, [cfgp, C.POINTER(CS), lp, hp, C.POINTER(i), C.POINTER(i)]),
             "orc_table_misses": (C.c_longlong, []),
             "orc_reset_table_misses": (None, []),
             "orc_findContainingHydroCell": (i, [cfgp, lp, hp, i, sp]),

@@ -1,0 +1,231 @@
+"""Known-answer tests for the first part of the cyclo-synchrotron oracle (oracle/oracle_cyclosynch.c): the
+photon-list operations (Src/photons.c), the magnetic-field helpers, QUADPACK's 21-point rule and QAGS' first step, the
+emission of pool photons / of a replacement photon and the absorption at the end of a frame (Src/mc_cyclosynch.c).  The
+device side of this row is not built yet: these tests pin the checker it will be built against."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy import integrate
+
+from mcrat_amd import synth
+
+CHARGE_EL, PL_CONST = 4.8032068e-10, 6.6260755e-27
+
+
+def _list(oracle, aos):
+    l = oracle.PhotonList()
+    L = oracle.lib()
+    L.orc_list_init(C.byref(l))
+    a = np.ascontiguousarray(aos, dtype=oracle.PHOTON_DTYPE)
+    assert L.orc_list_set(C.byref(l), a.ctypes.data, len(a)) == 0
+    return l
+
+
+def _view(oracle, l):
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    return np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE)
+
+
+def _photons(oracle, n=20, seed=1):
+    frame, ph, cfg = synth.config2(n_photons=n, nzc=4, seed=seed)
+    return frame, synth.photons_to_aos(ph, oracle.PHOTON_DTYPE), cfg
+
+
+def test_photon_list_operations(oracle):
+    """photons.c: null slots are reused first, in slot order; the list doubles when it is full; the conservation rule
+    num_photons + num_null_photons == list_capacity holds after every operation"""
+    L = oracle.lib()
+    _, aos, _ = _photons(oracle, 12)
+    l = _list(oracle, aos)
+    assert (l.list_capacity, l.num_photons, l.num_null_photons) == (12, 12, 0)
+    for i in (3, 7, 8):
+        assert L.orc_list_set_null(C.byref(l), i) == 0
+    v = _view(oracle, l)
+    assert (l.num_photons, l.num_null_photons) == (9, 3) and (v["type"][[3, 7, 8]] == b"N").all() and (v["weight"][[3, 7, 8]] == 0).all()
+    assert (v["nearest_block_index"][[3, 7, 8]] == -1).all() and (v["p0"][[3, 7, 8]] == 0).all()
+    # one photon goes into the first null slot
+    new = aos[:1].copy(); new["type"] = b"p"; new["weight"] = 5.0
+    assert L.orc_list_add(C.byref(l), new.ctypes.data, 1) == 0
+    v = _view(oracle, l)
+    assert v["type"][3] == b"p" and v["weight"][3] == 5.0 and (l.num_photons, l.num_null_photons) == (10, 2)
+    # two photons fill the remaining null slots in order; a third does not fit while the list still has null slots to count (:153-157)
+    two = aos[:2].copy(); two["type"] = b"p"; two["weight"] = [6.0, 7.0]
+    assert L.orc_list_add(C.byref(l), two.ctypes.data, 2) == 0
+    v = _view(oracle, l)
+    assert (v["weight"][[7, 8]] == [6.0, 7.0]).all() and (l.num_photons, l.num_null_photons) == (12, 0)
+    # a full list doubles (:112-121): the new slots are null, the photon takes the first of them
+    assert L.orc_list_add(C.byref(l), new.ctypes.data, 1) == 0
+    v = _view(oracle, l)
+    assert (l.list_capacity, l.num_photons, l.num_null_photons) == (24, 13, 11) and v["type"][12] == b"p" and (v["type"][13:] == b"N").all()
+    # more photons than null slots, list not full: the reference exits with "Adding to the photon list has failed"
+    many = np.repeat(new, 12)
+    assert L.orc_list_add(C.byref(l), many.ctypes.data, 12) == -3
+    L.orc_list_free(C.byref(l))
+    assert l.list_capacity == 0 and not l.photons
+
+
+def test_magnetic_field_and_frequencies(oracle):
+    L = oracle.lib()
+    cs = oracle.CS(oracle_b := 0, 0.5, 0.1)
+    n_e, T = 3e17, 2e6
+    assert L.orc_calcCyclotronFreq(1e6) == pytest.approx(CHARGE_EL * 1e6 / (2 * np.pi * synth.M_EL * synth.C_LIGHT), rel=1e-15)     # 2.8 MHz / G
+    assert L.orc_calcCyclotronFreq(1.0) == pytest.approx(2.799e6, rel=1e-3)
+    assert L.orc_calcDimlessTheta(5.93e9) == pytest.approx(1.0, rel=1e-3)
+    assert L.orc_calcEB(1e6) == pytest.approx(PL_CONST * L.orc_calcCyclotronFreq(1e6), rel=1e-15)
+    cs.b_field_calc = 0                                # INTERNAL_E: B^2 / 8 pi = eps_B * (3/2) n k T
+    b = L.orc_calcB(C.byref(cs), n_e, T)
+    assert b * b / (8 * np.pi) == pytest.approx(0.5 * 1.5 * n_e * synth.K_B * T, rel=1e-14)
+    cs.b_field_calc = 1                                # TOTAL_E: rest mass + radiation
+    b = L.orc_calcB(C.byref(cs), n_e, T)
+    assert b * b / (8 * np.pi) == pytest.approx(0.5 * (n_e * synth.M_P * synth.C_LIGHT ** 2 + 4 * synth.A_RAD * T ** 4 / 3), rel=1e-14)
+    cs.b_field_calc = 2
+    assert L.orc_calcB(C.byref(cs), n_e, T) == 0
+    # emission radii: the shell the injected photons have reached (:225-244)
+    lo = L.orc_calcCyclosynchRLimits(210, 200, 5.0, 1e12, 0)
+    hi = L.orc_calcCyclosynchRLimits(210, 200, 5.0, 1e12, 1)
+    assert lo == pytest.approx(1e12 + synth.C_LIGHT * (10 / 5.0 - 0.1), rel=1e-15) and hi - lo == pytest.approx(synth.C_LIGHT / 5.0, rel=1e-12)
+
+
+def test_gauss_kronrod_rule_and_qags_first_step(oracle):
+    """QUADPACK dqk21: exact for polynomials up to degree 31 (the embedded 10-point Gauss rule up to 19); QAGS returns after the
+    first rule when its error estimate meets the tolerance -- always the case for the Planck tail the emission integrates"""
+    L = oracle.lib()
+    FN = C.CFUNCTYPE(C.c_double, C.c_double, C.c_void_p)
+    res, err, rabs, rasc = (C.c_double() for _ in range(4))
+    for deg in (0, 1, 6, 19, 30, 31):
+        f = FN(lambda x, ctx, d=deg: x ** d)
+        L.orc_qk21(C.cast(f, C.c_void_p), None, -1.0, 2.0, C.byref(res), C.byref(err), C.byref(rabs), C.byref(rasc))
+        assert res.value == pytest.approx((2.0 ** (deg + 1) - (-1.0) ** (deg + 1)) / (deg + 1), rel=2e-14), deg
+    f = FN(lambda x, ctx: np.exp(-x * x))
+    fb = C.c_int(-1)
+    assert L.orc_qags(C.cast(f, C.c_void_p), None, 0.0, 1.0, 0.0, 1e-10, 100, C.byref(res), C.byref(err), C.byref(fb)) == 0
+    assert fb.value == 0 and res.value == pytest.approx(0.7468241328124271, rel=1e-13) and err.value < 1e-12
+    # a kink is not integrated by one rule: the fallback bisects (and says so)
+    f = FN(lambda x, ctx: abs(x - 0.3) ** 0.5)
+    assert L.orc_qags(C.cast(f, C.c_void_p), None, 0.0, 1.0, 0.0, 1e-6, 200, C.byref(res), C.byref(err), C.byref(fb)) == 0
+    assert fb.value == 1 and res.value == pytest.approx((0.3 ** 1.5 + 0.7 ** 1.5) / 1.5, rel=1e-5)
+    # the emission's integrand for the fields calcB gives over the densities and temperatures of a GRB jet: one rule suffices.
+    # (Where h nu / k T at the rule's nodes falls below ~1e-12 -- a weak field in a very hot cell -- the reference's exp(x) - 1
+    # loses its digits, QUADPACK's error heuristic sees the noise and QAGS would iterate: the fallback flag reports that case.)
+    cs = oracle.CS(1, 0.5, 0.1)
+    for temp in (1e5, 1e7, 1e9):
+        for n_e in (1e12, 1e16, 1e20):
+            nu_c = L.orc_calcCyclotronFreq(L.orc_calcB(C.byref(cs), n_e, temp))
+            planck = FN(lambda nu, ctx, T=temp: L.orc_blackbody_ph_spect(nu, T))
+            rc = L.orc_qags(C.cast(planck, C.c_void_p), None, 10.0, nu_c, 0.0, 1e-2, 10000, C.byref(res), C.byref(err), C.byref(fb))
+            want, _ = integrate.quad(lambda nu: L.orc_blackbody_ph_spect(nu, temp), 10.0, nu_c, epsrel=1e-10, limit=200)
+            assert rc == 0 and fb.value == 0 and res.value == pytest.approx(want, rel=1e-2), (temp, n_e, nu_c)
+    planck = FN(lambda nu, ctx: L.orc_blackbody_ph_spect(nu, 1e10))
+    assert L.orc_qags(C.cast(planck, C.c_void_p), None, 10.0, 1e3, 0.0, 1e-2, 10000, C.byref(res), C.byref(err), C.byref(fb)) in (0, 2) and fb.value == 1
+    # Rayleigh-Jeans: n(nu) = 8 pi nu k T / (h c^3)
+    # (to the digits exp(x) - 1 keeps at x = 5e-12: the reference does not use expm1)
+    assert L.orc_blackbody_ph_spect(1e6, 1e7) == pytest.approx(8 * np.pi * 1e6 * synth.K_B * 1e7 / (PL_CONST * synth.C_LIGHT ** 3), rel=1e-4)
+
+
+def _cs_setup(oracle, n_photons=400, lumi=1e53):
+    frame, ph, cfg = synth.config2(n_photons=n_photons, nzc=8, lumi=lumi)
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 1)
+    dens = np.ascontiguousarray(frame["dens"])
+    cs = oracle.CS(1, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, 200, 200)
+    cs._keep = dens
+    return frame, ph, c, H, cs
+
+
+def test_pool_emission_rules(oracle):
+    """photonEmitCyclosynch, inject_single_switch = 0 (mc_cyclosynch.c:1200-1460): photons of type 'p' at the centres of the cells
+    of the shell the injected photons occupy, all at their cell's cyclotron frequency in the fluid frame, unpolarised, one common
+    weight adjusted until 1 <= N <= CYCLOSYNCHROTRON_REBIN_E_PERC * max_photons, placed in the list's null slots"""
+    L = oracle.lib()
+    frame, ph, c, H, cs = _cs_setup(oracle)
+    aos = synth.photons_to_aos(ph, oracle.PHOTON_DTYPE)
+    l = _list(oracle, aos)
+    for i in range(0, 400, 2):                                   # room for the pool: 200 null slots
+        L.orc_list_set_null(C.byref(l), i)
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), 99, 0)
+    w, fb = C.c_double(0), C.c_int(-1)
+    n = L.orc_photonEmitCyclosynch(C.byref(c), C.byref(cs), C.byref(l), 1e12, 1e40, 1500, 0.0, 0.05, C.byref(H.c), C.byref(rng), 0, 0, C.byref(w), C.byref(fb))
+    assert 1 <= n <= 150 and fb.value == 0                       # 0.1 * 1500
+    assert (l.num_photons, l.num_null_photons, l.list_capacity) == (200 + n, 200 - n, 400)
+    v = _view(oracle, l)
+    pool = v[v["type"] == b"p"]
+    assert len(pool) == n and (np.flatnonzero(v["type"] == b"p") % 2 == 0).all()          # the first n null slots, in order
+    assert (pool["weight"] == w.value).all() and (pool["s0"] == 1).all() and (pool["s1"] == 0).all() and (pool["num_scatt"] == 0).all()
+    assert (pool["nearest_block_index"] == 0).all() and (pool["recalc_properties"] == 1).all()
+    # each sits on the centre of a cell of the shell r_inj -+ c / (2 fps), at that cell's cyclotron frequency in the fluid frame
+    rho, z = np.hypot(pool["r0"], pool["r1"]), pool["r2"]
+    cell = np.array([np.flatnonzero((frame["r0"] == a) & (frame["r1"] == b))[0] for a, b in
+                     zip(frame["r0"][np.argmin(np.abs(frame["r0"][None, :] - rho[:, None]) + np.abs(frame["r1"][None, :] - z[:, None]), axis=1)],
+                         frame["r1"][np.argmin(np.abs(frame["r0"][None, :] - rho[:, None]) + np.abs(frame["r1"][None, :] - z[:, None]), axis=1)])])
+    assert np.allclose(rho, frame["r0"][cell], rtol=1e-12) and np.allclose(z, frame["r1"][cell], rtol=1e-14)
+    r_sph = np.hypot(frame["r0"][cell], frame["r1"][cell])
+    half = 0.5 * synth.C_LIGHT / frame["fps"]
+    size = np.hypot(frame["r0_size"][cell], frame["r1_size"][cell])
+    assert (r_sph > 1e12 - half - size).all() and (r_sph < 1e12 + half + size).all()
+    nu_c = np.array([L.orc_calcCyclotronFreq(L.orc_getMagneticFieldMagnitude(C.byref(c), C.byref(cs), C.byref(H.c), int(k))) for k in cell])
+    assert np.allclose(pool["comv_p0"] * synth.C_LIGHT / PL_CONST, nu_c, rtol=1e-14)
+    assert np.allclose(np.sqrt(pool["p1"] ** 2 + pool["p2"] ** 2 + pool["p3"] ** 2), pool["p0"], rtol=1e-12)      # boosted null vectors
+    assert (pool["p0"] > pool["comv_p0"]).mean() > 0.6                                                            # mostly beamed forward by the jet
+    # the same call again gives the same photons (keyed streams), a different seed different directions
+    l2 = _list(oracle, aos)
+    for i in range(0, 400, 2):
+        L.orc_list_set_null(C.byref(l2), i)
+    L.orc_rng_init(C.byref(rng), 99, 0)
+    assert L.orc_photonEmitCyclosynch(C.byref(c), C.byref(cs), C.byref(l2), 1e12, 1e40, 1500, 0.0, 0.05, C.byref(H.c), C.byref(rng), 0, 0, C.byref(w), None) == n
+    assert _view(oracle, l2).tobytes() == v.tobytes()
+    # no cell in the shell: nothing is emitted (min_photons = 0, :1236-1239)
+    cs.scatt_frame_number = 100000
+    assert L.orc_photonEmitCyclosynch(C.byref(c), C.byref(cs), C.byref(l2), 1e12, 1e40, 1500, 0.0, 0.05, C.byref(H.c), C.byref(rng), 0, 0, C.byref(w), None) == 0
+    L.orc_list_free(C.byref(l)); L.orc_list_free(C.byref(l2))
+
+
+def test_single_replacement_and_absorption(oracle):
+    """inject_single_switch = 1 (:1467-1558): the pool photon that scattered is replaced by a new one at the centre of the same cell,
+    with its weight, and is itself moved to a random point of the cell.  phAbsCyclosynch (:1571-1623): photons below their cell's
+    cyclotron frequency and all pool photons become null slots; the weight of absorbed 'i' / 'c' photons is returned"""
+    L = oracle.lib()
+    frame, ph, c, H, cs = _cs_setup(oracle, n_photons=60)
+    aos = synth.photons_to_aos(ph, oracle.PHOTON_DTYPE)
+    # locate the photons first (the emission reads nearest_block_index)
+    P = oracle.OraclePhotons(aos)
+    st = oracle.Stats()
+    L.orc_findContainingHydroCell(C.byref(c), C.byref(P.c), C.byref(H.c), 1, C.byref(st))
+    located = P.aos.copy()
+    k = int(np.flatnonzero(located["nearest_block_index"] >= 0)[5])
+    located["type"][k] = b"k"; located["weight"][k] = 3.5                          # the pool photon that has just scattered (mcrat.c:790-791)
+    l = _list(oracle, located)
+    L.orc_list_set_null(C.byref(l), 0)
+    before = _view(oracle, l).copy()
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), 5, 0)
+    L.orc_rng_set_iteration(C.byref(rng), 77)
+    assert L.orc_photonEmitCyclosynch(C.byref(c), C.byref(cs), C.byref(l), 1e12, 1e40, 1500, 0.0, 0.05, C.byref(H.c), C.byref(rng), 1, k, None, None) == 1
+    v = _view(oracle, l)
+    cell = int(before["nearest_block_index"][k])
+    new = v[0]                                                                      # the null slot
+    assert new["type"] == b"p" and new["weight"] == 3.5 and new["nearest_block_index"] == cell and new["recalc_properties"] == 1
+    assert np.hypot(new["r0"], new["r1"]) == pytest.approx(frame["r0"][cell], rel=1e-12) and new["r2"] == pytest.approx(frame["r1"][cell], rel=1e-14)
+    moved = v[k]
+    assert (moved["r0"], moved["r1"], moved["r2"]) != (before["r0"][k], before["r1"][k], before["r2"][k])
+    assert abs(np.hypot(moved["r0"], moved["r1"]) - frame["r0"][cell]) <= 0.5 * frame["r0_size"][cell] * (1 + 1e-12)
+    assert abs(moved["r2"] - frame["r1"][cell]) <= 0.5 * frame["r1_size"][cell] * (1 + 1e-12)
+    assert np.arctan2(moved["r1"], moved["r0"]) == pytest.approx(np.arctan2(new["r1"], new["r0"]), abs=1e-12)     # the same azimuth draw
+    for f in ("p0", "p1", "p2", "p3", "weight", "num_scatt"):
+        assert moved[f] == before[f][k]
+    # absorption: make two photons soft (below nu_c), one of them an unabsorbed CS photon, and keep the pool photon
+    v = _view(oracle, l)
+    idx = np.flatnonzero((v["nearest_block_index"] >= 0) & (v["type"] == b"i"))[:3]
+    nu_c = L.orc_calcCyclotronFreq(L.orc_getMagneticFieldMagnitude(C.byref(c), C.byref(cs), C.byref(H.c), int(v["nearest_block_index"][idx[0]])))
+    v["comv_p0"][idx[0]] = 0.5 * nu_c * PL_CONST / synth.C_LIGHT
+    v["comv_p0"][idx[1]] = 0.5 * nu_c * PL_CONST / synth.C_LIGHT; v["type"][idx[1]] = b"c"; v["weight"][idx[1]] = 2.0
+    v["type"][idx[2]] = b"c"                                                        # hard enough: survives and is counted
+    n_before = l.num_photons
+    n_abs, n_scatt = C.c_int(), C.c_int()
+    absorbed = L.orc_phAbsCyclosynch(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(n_abs), C.byref(n_scatt))
+    v = _view(oracle, l)
+    assert n_abs.value == 3 and absorbed == pytest.approx(1.0 + 2.0)                # the 'i' (weight 1) and the 'c' photon; the pool photon's weight is not counted
+    assert (v["type"][[idx[0], idx[1], 0]] == b"N").all() and l.num_photons == n_before - 3
+    assert n_scatt.value == 2                                                       # the comptonised 'k' photon and the surviving 'c' photon
+    L.orc_list_free(C.byref(l))
