@@ -285,6 +285,7 @@ typedef struct orc_cs {
     const double *dens;         /* hydro_data->dens (comoving density), per cell */
     const double *B0, *B1, *B2; /* hydro_data->B0-2 when B_FIELD_CALC == SIMULATION */
     int    scatt_frame_number, inj_frame_number;   /* hydro_data->scatt_frame_number / ->inj_frame_number */
+    double rebin_ang, rebin_ang_phi;               /* CYCLOSYNCHROTRON_REBIN_ANG (0.5 deg), _ANG_PHI (10 deg), mcrat.h:315-321 */
 } orc_cs;
 typedef double (*orc_integrand)(double x, void *ctx);
 void   orc_list_init(orc_photon_list *l);                                         /* photons.c:3 */
@@ -307,6 +308,8 @@ int    orc_qags(orc_integrand f, void *ctx, double a, double b, double epsabs, d
 int    orc_photonEmitCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, double r_inj, double ph_weight, int maximum_photons,
                                 double theta_min, double theta_max, const orc_hydro *h, orc_rng *rng, int inject_single_switch, int scatt_ph_index,
                                 double *weight_out, int *used_fallback_out);     /* :1176 */
+int    orc_rebinCyclosynchCompPhotons(const orc_config *c, const orc_cs *cs, orc_photon_list *l, int *num_cyclosynch_ph_emit,
+                                      int *scatt_cyclosynch_num_ph, int max_photons);   /* mc_cyclosynch.c:610 */
 double orc_phAbsCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, const orc_hydro *h, int *num_abs_ph,
                            int *scatt_cyclosynch_num_ph);                        /* :1571 */
 

@@ -3,7 +3,7 @@
  * operations it needs, the magnetic-field helpers, the emission of the pool photons and of a single replacement photon,
  * and the absorption at the end of a frame.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see mcrat_oracle.h.  The device
  * side of this row is not built yet: this file is the checker it will be built against.
- * Not restated yet: rebinCyclosynchCompPhotons (mc_cyclosynch.c:246-712) and the loop hooks of mcrat.c:788-808,853-878.
+ * Not restated yet: the loop hooks of mcrat.c:788-808,853-878 (they call the functions below).
  *
  * Restated from the reference:
  *   list operations          Src/photons.c:3-285 (exit(1) paths become error returns)
@@ -11,6 +11,7 @@
  *   blackbody_ph_spect       :185-196;   calcCyclosynchRLimits :225-244
  *   photonEmitCyclosynch     :1176-1569 (both inject_single_switch branches)
  *   phAbsCyclosynch          :1571-1623
+ *   rebinCyclosynchCompPhotons :246-712 (the gsl_histogram2d objects only find bin indexes; restated)
  * Third-party arithmetic: gsl_integration_qags (:1276) lives in GSL (unpinned version).  Its published algorithm (QUADPACK
  * QAGS) starts with one 21-point Gauss-Kronrod rule on the whole interval and returns at once when that rule's error
  * estimate meets the tolerance; the integrand here -- the Planck photon number density from 10 Hz to the cyclotron
@@ -404,4 +405,160 @@ double orc_phAbsCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_lis
     }
     *num_abs_ph = abs_ph_count;
     return abs_count;
+}
+
+/* ---- rebinCyclosynchCompPhotons, mc_cyclosynch.c:246-712 ----------------------------------------------------------
+ * Every photon that is neither null, nor a pool photon, nor an injected one ('k', 'c', 'r') is replaced by one photon per
+ * non-empty (energy, theta[, phi]) bin carrying the bin's weight and its weighted averages.  No random numbers.  The three
+ * gsl_histogram2d objects serve only to find bin indexes: gsl_histogram2d_set_ranges_uniform puts edge i at
+ * ((n - i) / n) lo + (i / n) hi and gsl_histogram2d_find returns the i with edge[i] <= x < edge[i + 1] (GSL's published
+ * behaviour); both restated below. */
+#define ORC_DEG_TO_RAD (M_PI / 180.0)          /* mcrat.h:80-81 */
+#define ORC_RAD_TO_DEG (180.0 / M_PI)
+
+typedef struct { double lo, hi; int n; } uniform_axis;
+
+static double axis_edge(const uniform_axis *a, int i)
+{
+    const double f1 = ((double)(a->n - i)) / (double)a->n, f2 = ((double)i) / (double)a->n;
+    return f1 * a->lo + f2 * a->hi;
+}
+
+static int axis_find(const uniform_axis *a, double x)            /* -1: outside [lo, hi) -- GSL_EDOM */
+{
+    if (!(x >= axis_edge(a, 0)) || !(x < axis_edge(a, a->n))) return -1;
+    int lo = 0, hi = a->n;                                       /* edge[lo] <= x < edge[hi] */
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        if (x >= axis_edge(a, mid)) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+static void photon_position(const orc_config *c, const orc_photon *ph, double *r, double *theta, double *phi)   /* :246-270 */
+{
+    const double x = ph->r0, y = ph->r1, z = ph->r2;
+    *r = sqrt(x * x + y * y + z * z);
+    *phi = 0;
+    if (*r < DBL_MIN) { *theta = 0.0; return; }
+    *theta = acos(z / *r);
+    if (c->dimensions == ORC_THREE) *phi = fmod(atan2(y, x) * ORC_RAD_TO_DEG + 360.0, 360.0);
+}
+
+typedef struct {
+    double weighted_r, weighted_theta, weighted_phi_offset, weighted_stokes[4], weighted_scatt_count, total_weight;
+    double weighted_phi_dir, weighted_theta_dir, weighted_energy, weighted_phi_pos;
+} bin_stats;
+
+/* Returns the number of empty bins (>= 0) as the reference does, -1 on its error paths (no photon to rebin, more bins than
+ * max_photons, a photon outside the histograms), or an orc_list_add error. */
+int orc_rebinCyclosynchCompPhotons(const orc_config *c, const orc_cs *cs, orc_photon_list *l, int *num_cyclosynch_ph_emit,
+                                   int *scatt_cyclosynch_num_ph, int max_photons)
+{
+    const int three = c->dimensions == ORC_THREE;
+    /* collect_photon_statistics :273-322 */
+    double p0_min = DBL_MAX, p0_max = 0, theta_min = DBL_MAX, theta_max = 0, phi_min = DBL_MAX, phi_max = 0;
+    int valid = 0, synch = 0;
+    for (int i = 0; i < l->list_capacity; i++) {
+        const orc_photon *ph = &l->photons[i];
+        if ((ph->type != ORC_NULL_PHOTON) && (ph->type != ORC_CS_POOL_PHOTON) && (ph->type != ORC_INJECTED_PHOTON)) {
+            if (ph->p0 > 0) { p0_min = fmin(p0_min, ph->p0); p0_max = fmax(p0_max, ph->p0); valid++; }
+            double r, theta, phi;
+            photon_position(c, ph, &r, &theta, &phi);
+            theta_min = fmin(theta_min, theta); theta_max = fmax(theta_max, theta);
+            if (three) { phi_min = fmin(phi_min, phi); phi_max = fmax(phi_max, phi); }
+        }
+        if (ph->type == ORC_CS_POOL_PHOTON) synch++;
+    }
+    if (valid == 0) return -1;
+    const double log_p0_min = (p0_min > 0 && p0_max > 0) ? log10(p0_min) : 0.0, log_p0_max = (p0_min > 0 && p0_max > 0) ? log10(p0_max) : 1.0;
+    /* calculate_binning_params :324-347 */
+    const int num_bins = (int)(cs->rebin_e_perc * max_photons);
+    const int num_bins_theta = (int)ceil((theta_max - theta_min) / (cs->rebin_ang * ORC_DEG_TO_RAD));
+    const int num_bins_phi = three ? (int)ceil((phi_max - phi_min) / cs->rebin_ang_phi) : 1;
+    const int total_bins = num_bins_theta * num_bins * (three ? num_bins_phi : 1);
+    if (total_bins > max_photons) return -1;                                          /* :649-654 */
+    if (num_bins <= 0 || num_bins_theta <= 0 || num_bins_phi <= 0) return -1;         /* allocate_histograms :351-354 */
+    /* allocate_histograms :360-391: the ranges, widened by 1e-6 of their width so that the maxima fall inside */
+    const double e_eps = (log_p0_max - log_p0_min) * 1e-6, t_eps = (theta_max - theta_min) * 1e-6, p_eps = (phi_max - phi_min) * 1e-6;
+    const uniform_axis ax_e = {log_p0_min, log_p0_max + e_eps, num_bins}, ax_t = {theta_min, theta_max + t_eps, num_bins_theta},
+                       ax_p = {phi_min, phi_max + p_eps, num_bins_phi};
+    bin_stats *stats = (bin_stats *)calloc((size_t)total_bins, sizeof(bin_stats));
+    /* accumulate_bin_statistics :448-501 */
+    for (int i = 0; i < l->list_capacity; i++) {
+        const orc_photon *ph = &l->photons[i];
+        if ((ph->type == ORC_NULL_PHOTON) || (ph->type == ORC_CS_POOL_PHOTON) || (ph->type == ORC_INJECTED_PHOTON)) continue;
+        double r, theta, phi;
+        photon_position(c, ph, &r, &theta, &phi);
+        int idx_x = axis_find(&ax_e, log10(ph->p0)), idx_y = axis_find(&ax_t, theta), idx_z = 0;
+        if (idx_x < 0 || idx_y < 0) {            /* gsl_histogram2d_find leaves both indexes untouched (0) on a domain error */
+            idx_x = 0; idx_y = 0;
+        }
+        if (three) {
+            /* the second and third find calls overwrite idx_x / idx_y / idx_z pairwise (:459-460), each all-or-nothing */
+            const int ex = axis_find(&ax_e, log10(ph->p0)), pz = axis_find(&ax_p, phi);
+            if (ex >= 0 && pz >= 0) { idx_x = ex; idx_z = pz; }
+            const int ty = axis_find(&ax_t, theta);
+            if (ty >= 0 && pz >= 0) { idx_y = ty; idx_z = pz; }
+        }
+        int bin_idx;                                                                  /* calculate_bin_index :432-446 */
+        if (idx_x < 0 || idx_x >= num_bins || idx_y < 0 || idx_y >= num_bins_theta || (three && (idx_z < 0 || idx_z >= num_bins_phi))) bin_idx = -1;
+        else bin_idx = three ? idx_z * num_bins * num_bins_theta + idx_x * num_bins_theta + idx_y : idx_x * num_bins_theta + idx_y;
+        if (bin_idx < 0 || bin_idx >= total_bins) { free(stats); return -1; }         /* the reference exit(1)s */
+        bin_stats *s = &stats[bin_idx];
+        s->weighted_r += r * ph->weight;
+        s->weighted_theta += theta * ph->weight;
+        s->weighted_phi_offset += (atan2(ph->p2, ph->p1) - atan2(ph->r1, ph->r0)) * ORC_RAD_TO_DEG * ph->weight;
+        s->weighted_stokes[0] += ph->s0 * ph->weight; s->weighted_stokes[1] += ph->s1 * ph->weight;
+        s->weighted_stokes[2] += ph->s2 * ph->weight; s->weighted_stokes[3] += ph->s3 * ph->weight;
+        s->weighted_scatt_count += ph->num_scatt * ph->weight;
+        s->total_weight += ph->weight;
+        const double phi_dir = fmod(atan2(ph->p2, ph->p1) * ORC_RAD_TO_DEG + 360.0, 360.0);
+        const double theta_dir = acos(ph->p3 / ph->p0) * ORC_RAD_TO_DEG;
+        s->weighted_phi_dir += phi_dir * ph->weight;
+        s->weighted_theta_dir += theta_dir * ph->weight;
+        s->weighted_energy += ph->p0 * ph->weight;
+        if (three) s->weighted_phi_pos += phi * ph->weight;
+    }
+    /* create_rebinned_photons :504-607 */
+    orc_photon *rebin_ph = (orc_photon *)calloc((size_t)total_bins, sizeof(orc_photon));
+    int num_null_rebin_ph = 0;
+    for (int i = 0; i < total_bins; i++) {
+        const bin_stats *s = &stats[i];
+        orc_photon *np = &rebin_ph[i];
+        if (s->total_weight <= 0) {
+            np->type = ORC_NULL_PHOTON; np->weight = 0; np->nearest_block_index = -1; np->recalc_properties = 0;
+            num_null_rebin_ph++;
+            continue;
+        }
+        np->type = ORC_COMPTONIZED_PHOTON;
+        np->weight = s->total_weight;
+        const double avg_energy = s->weighted_energy / s->total_weight, avg_phi_dir = s->weighted_phi_dir / s->total_weight;
+        const double avg_theta_dir = s->weighted_theta_dir / s->total_weight, avg_r = s->weighted_r / s->total_weight;
+        const double avg_theta_pos = s->weighted_theta / s->total_weight;
+        np->p0 = avg_energy;
+        np->p1 = avg_energy * sin(avg_theta_dir * ORC_DEG_TO_RAD) * cos(avg_phi_dir * ORC_DEG_TO_RAD);
+        np->p2 = avg_energy * sin(avg_theta_dir * ORC_DEG_TO_RAD) * sin(avg_phi_dir * ORC_DEG_TO_RAD);
+        np->p3 = avg_energy * cos(avg_theta_dir * ORC_DEG_TO_RAD);
+        double pos_phi;
+        if (three) pos_phi = (s->weighted_phi_pos / s->total_weight) * ORC_DEG_TO_RAD;
+        else pos_phi = (avg_phi_dir - s->weighted_phi_offset / s->total_weight) * ORC_DEG_TO_RAD;
+        np->r0 = avg_r * sin(avg_theta_pos) * cos(pos_phi);
+        np->r1 = avg_r * sin(avg_theta_pos) * sin(pos_phi);
+        np->r2 = avg_r * cos(avg_theta_pos);
+        np->s0 = s->weighted_stokes[0] / s->total_weight; np->s1 = s->weighted_stokes[1] / s->total_weight;
+        np->s2 = s->weighted_stokes[2] / s->total_weight; np->s3 = s->weighted_stokes[3] / s->total_weight;
+        np->num_scatt = (int)(s->weighted_scatt_count / s->total_weight + 0.5);
+        np->nearest_block_index = 0;
+        np->recalc_properties = 1;
+    }
+    for (int i = 0; i < l->list_capacity; i++)
+        if (l->photons[i].type == ORC_UNABSORBED_CS_PHOTON || l->photons[i].type == ORC_COMPTONIZED_PHOTON) (void)orc_list_set_null(l, i);
+    const int rc = orc_list_add(l, rebin_ph, total_bins);
+    free(rebin_ph); free(stats);
+    if (rc) return rc;
+    if (l->num_photons < total_bins) return -1;
+    *scatt_cyclosynch_num_ph = total_bins - num_null_rebin_ph;                        /* :689-690 */
+    *num_cyclosynch_ph_emit = total_bins + synch - num_null_rebin_ph;
+    return num_null_rebin_ph;
 }

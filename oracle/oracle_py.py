@@ -142,7 +142,7 @@ class CS(C.Structure):
     """orc_cs: the cyclo-synchrotron switches and the extra hydro columns (oracle_cyclosynch.c)"""
     _fields_ = [("b_field_calc", C.c_int), ("epsilon_b", C.c_double), ("rebin_e_perc", C.c_double), ("dens", C.POINTER(C.c_double)),
                 ("B0", C.POINTER(C.c_double)), ("B1", C.POINTER(C.c_double)), ("B2", C.POINTER(C.c_double)),
-                ("scatt_frame_number", C.c_int), ("inj_frame_number", C.c_int)]
+                ("scatt_frame_number", C.c_int), ("inj_frame_number", C.c_int), ("rebin_ang", C.c_double), ("rebin_ang_phi", C.c_double)]
 
 
 class Outflow(C.Structure):
@@ -220,6 +220,7 @@ def lib():
             "orc_qags": (i, [C.c_void_p, p, d, d, d, d, i, _dp, _dp, C.POINTER(i)]),
             "orc_photonEmitCyclosynch": (i, [cfgp, C.POINTER(CS), lp, d, d, i, d, d, hp, rp, i, i, _dp, C.POINTER(i)]),
             "orc_phAbsCyclosynch": (d, [cfgp, C.POINTER(CS), lp, hp, C.POINTER(i), C.POINTER(i)]),
+            "orc_rebinCyclosynchCompPhotons": (i, [cfgp, C.POINTER(CS), lp, C.POINTER(i), C.POINTER(i), i]),
             "orc_table_misses": (C.c_longlong, []),
             "orc_reset_table_misses": (None, []),
             "orc_findContainingHydroCell": (i, [cfgp, lp, hp, i, sp]),

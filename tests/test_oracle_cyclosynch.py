@@ -229,3 +229,75 @@ def test_single_replacement_and_absorption(oracle):
     assert (v["type"][[idx[0], idx[1], 0]] == b"N").all() and l.num_photons == n_before - 3
     assert n_scatt.value == 2                                                       # the comptonised 'k' photon and the surviving 'c' photon
     L.orc_list_free(C.byref(l))
+
+
+def test_rebinning_conserves_weight_energy_and_polarisation(oracle):
+    """rebinCyclosynchCompPhotons (mc_cyclosynch.c:246-712): the comptonised ('k') and unabsorbed ('c') photons are replaced by one
+    photon per non-empty (log10 energy, polar angle of the position) bin with the bin's total weight and its weighted averages;
+    injected and pool photons are not touched; nothing random"""
+    L = oracle.lib()
+    rng = np.random.default_rng(4)
+    n = 3000
+    aos = np.zeros(n, dtype=oracle.PHOTON_DTYPE)
+    kind = rng.choice([b"k", b"c", b"i", b"p"], size=n, p=[0.5, 0.3, 0.15, 0.05])
+    aos["type"] = kind
+    th_pos = rng.uniform(0.01, 0.04, n)
+    phi_pos = rng.uniform(0, 2 * np.pi, n)
+    r = rng.uniform(1.0e12, 1.1e12, n)
+    aos["r0"], aos["r1"], aos["r2"] = r * np.sin(th_pos) * np.cos(phi_pos), r * np.sin(th_pos) * np.sin(phi_pos), r * np.cos(th_pos)
+    e = 10 ** rng.uniform(-18, -15, n)
+    th_d, ph_d = rng.uniform(0.0, 0.05, n), phi_pos + rng.normal(0, 0.01, n)
+    aos["p0"], aos["p1"], aos["p2"], aos["p3"] = e, e * np.sin(th_d) * np.cos(ph_d), e * np.sin(th_d) * np.sin(ph_d), e * np.cos(th_d)
+    aos["s0"], aos["s1"], aos["s2"] = 1.0, rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n)
+    aos["weight"] = 10 ** rng.uniform(45, 47, n)
+    aos["num_scatt"] = rng.integers(1, 40, n)
+    aos["nearest_block_index"] = 5
+    sel = (kind == b"k") | (kind == b"c")
+    c = oracle.make_config(synth.TWO, synth.CYLINDRICAL, 1)
+    cs = oracle.CS(1, 0.5, 0.1, None, None, None, None, 200, 200, 0.5, 10.0)
+    l = _list(oracle, aos)
+    emit, scatt = C.c_int(), C.c_int()
+    max_photons = 2000                                         # 200 energy bins x ceil(0.03 rad / 0.5 deg) = 4 theta bins = 800 <= 2000
+    nulls = L.orc_rebinCyclosynchCompPhotons(C.byref(c), C.byref(cs), C.byref(l), C.byref(emit), C.byref(scatt), max_photons)
+    v = _view(oracle, l)
+    out = v[v["type"] == b"k"]
+    assert nulls >= 0 and scatt.value == len(out) == 800 - nulls and emit.value == len(out) + int((kind == b"p").sum())
+    assert (v["type"] == b"c").sum() == 0 and len(out) < sel.sum()
+    w = aos["weight"][sel]
+    assert out["weight"].sum() == pytest.approx(w.sum(), rel=1e-12)
+    assert (out["weight"] * out["p0"]).sum() == pytest.approx((w * aos["p0"][sel]).sum(), rel=1e-12)          # energy
+    for s in ("s0", "s1", "s2"):
+        assert (out["weight"] * out[s]).sum() == pytest.approx((w * aos[s][sel]).sum(), rel=1e-10, abs=1e30)
+    assert np.allclose(np.sqrt(out["p1"] ** 2 + out["p2"] ** 2 + out["p3"] ** 2), out["p0"], rtol=1e-12)
+    r_out = np.sqrt(out["r0"] ** 2 + out["r1"] ** 2 + out["r2"] ** 2)
+    assert (r_out > 1.0e12).all() and (r_out < 1.1e12).all()
+    assert (out["nearest_block_index"] == 0).all() and (out["recalc_properties"] == 1).all() and (out["comv_p0"] == 0).all()
+    # injected and pool photons keep their slots and contents
+    for t in (b"i", b"p"):
+        keep = kind == t
+        for f in ("p0", "r0", "weight", "num_scatt"):
+            assert np.array_equal(v[f][:n][keep], aos[f][keep]), (t, f)
+    assert l.num_photons + l.num_null_photons == l.list_capacity
+    # two photons in one bin merge into their weighted mean
+    # (a third, much harder photon stretches the energy range to two bins; the ranges' extremes always sit in the outer bins)
+    two = aos[sel][:3].copy()
+    two["p0"] = [1e-16, 1.0000001e-16, 1e-14]; two["p1"] = 0; two["p2"] = 0; two["p3"] = two["p0"]
+    two["r0"], two["r1"], two["r2"] = [1e10, 1.0001e10, 1.0002e10], 0.0, 1e12
+    two["weight"] = [1e46, 3e46, 5e46]; two["num_scatt"] = [2, 6, 9]; two["s1"] = [0.2, -0.2, 0.0]
+    l2 = _list(oracle, two)
+    assert L.orc_rebinCyclosynchCompPhotons(C.byref(c), C.byref(cs), C.byref(l2), C.byref(emit), C.byref(scatt), 20) == 0
+    m = _view(oracle, l2)
+    m = m[m["type"] == b"k"]
+    m = m[np.argsort(m["p0"])]
+    assert len(m) == 2 and m["weight"][0] == 4e46 and m["num_scatt"][0] == 5 and m["s1"][0] == pytest.approx(-0.1, rel=1e-12)
+    assert m["p0"][0] == pytest.approx((1e-16 * 1e46 + 1.0000001e-16 * 3e46) / 4e46, rel=1e-14) and m["weight"][1] == 5e46
+    # refusals: photons at one polar angle give zero theta bins ("Invalid histogram dimensions", :351-354); nothing to rebin
+    same = two.copy(); same["r0"] = 1e10
+    l4 = _list(oracle, same)
+    assert L.orc_rebinCyclosynchCompPhotons(C.byref(c), C.byref(cs), C.byref(l4), C.byref(emit), C.byref(scatt), 20) == -1
+    L.orc_list_free(C.byref(l4))
+    only_i = aos[kind == b"i"].copy()
+    l3 = _list(oracle, only_i)
+    assert L.orc_rebinCyclosynchCompPhotons(C.byref(c), C.byref(cs), C.byref(l3), C.byref(emit), C.byref(scatt), 2000) == -1
+    for x in (l, l2, l3):
+        L.orc_list_free(C.byref(x))
