@@ -310,6 +310,13 @@ int    orc_photonEmitCyclosynch(const orc_config *c, const orc_cs *cs, orc_photo
                                 double *weight_out, int *used_fallback_out);     /* :1176 */
 int    orc_rebinCyclosynchCompPhotons(const orc_config *c, const orc_cs *cs, orc_photon_list *l, int *num_cyclosynch_ph_emit,
                                       int *scatt_cyclosynch_num_ph, int max_photons);   /* mc_cyclosynch.c:610 */
+typedef struct orc_cs_counts {          /* main()'s cyclo-synchrotron counters for one scatter frame */
+    int    num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph, frame_abs_cnt, rebins, error;
+    double n_comptonized, pool_weight;
+} orc_cs_counts;
+void   orc_scatter_frame_cs(const orc_config *c, orc_cs *cs, orc_photon_list *l, const orc_hydro *h, orc_rng *rng, double *time_now,
+                            double remaining_time, double r_inj, double ph_weight_suggest, int max_photons, double theta_jmin_thread,
+                            double theta_jmax_thread, int emit_pool, long long max_iterations, orc_stats *st, orc_cs_counts *cnt);   /* mcrat.c:706-878 */
 double orc_phAbsCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, const orc_hydro *h, int *num_abs_ph,
                            int *scatt_cyclosynch_num_ph);                        /* :1571 */
 

@@ -3,7 +3,7 @@
  * operations it needs, the magnetic-field helpers, the emission of the pool photons and of a single replacement photon,
  * and the absorption at the end of a frame.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED -- see mcrat_oracle.h.  The device
  * side of this row is not built yet: this file is the checker it will be built against.
- * Not restated yet: the loop hooks of mcrat.c:788-808,853-878 (they call the functions below).
+ * orc_scatter_frame_cs at the end of the file is the scatter-frame body of main() with the switch ON (mcrat.c:706-878).
  *
  * Restated from the reference:
  *   list operations          Src/photons.c:3-285 (exit(1) paths become error returns)
@@ -561,4 +561,69 @@ int orc_rebinCyclosynchCompPhotons(const orc_config *c, const orc_cs *cs, orc_ph
     *scatt_cyclosynch_num_ph = total_bins - num_null_rebin_ph;                        /* :689-690 */
     *num_cyclosynch_ph_emit = total_bins + synch - num_null_rebin_ph;
     return num_null_rebin_ph;
+}
+
+/* ---- the scatter-frame body of main() with CYCLOSYNCHROTRON_SWITCH ON, mcrat.c:706-878 ---------------------------------
+ * (between getHydroData and saveCheckpoint; the radius limits of :708-719 only widen getHydroData's slab and are the caller's).
+ * emit_pool is the condition `(scatt_frame != scatt_framestart) || (restrt == CONTINUE)` of :707,:727,:855.
+ * Reference behaviour kept: the photon photonEvent reports (:781,:786) is turned from a pool photon into a comptonised one and
+ * replaced even when every candidate of the pass was Klein-Nishina-rejected, because *scattered_ph_index then names the last
+ * candidate tried (mclib.c:1128,1337-1355). */
+void orc_scatter_frame_cs(const orc_config *c, orc_cs *cs, orc_photon_list *l, const orc_hydro *h, orc_rng *rng, double *time_now,
+                          double remaining_time, double r_inj, double ph_weight_suggest, int max_photons, double theta_jmin_thread,
+                          double theta_jmax_thread, int emit_pool, long long max_iterations, orc_stats *st, orc_cs_counts *cnt)
+{
+    memset(cnt, 0, sizeof *cnt);
+    if (emit_pool) {                                                                      /* :727-744 */
+        const int n = orc_photonEmitCyclosynch(c, cs, l, r_inj, ph_weight_suggest, max_photons, theta_jmin_thread, theta_jmax_thread, h, rng, 0, 0,
+                                               &cnt->pool_weight, NULL);
+        cnt->num_cyclosynch_ph_emit = n > 0 ? n : 0;
+        if (n < 0) cnt->error = n;
+    }
+    int find_nearest_grid_switch = 1;                                                     /* :756 */
+    long long it = 0;
+    double time_step = 0;
+    while (remaining_time > 0 && (max_iterations <= 0 || it < max_iterations) && !cnt->error) {   /* :761-851 */
+        orc_rng_set_iteration(rng, (uint64_t)it);
+        st->num_photons_find_new_element += orc_findContainingHydroCell(c, l, h, find_nearest_grid_switch, st);
+        orc_calcMeanFreePath(c, l, h, rng);
+        find_nearest_grid_switch = 0;
+        if (l->photons[l->sorted_indexes[0]].time_to_scatter < remaining_time) {
+            time_step = orc_photonEvent(c, l, remaining_time, h, &st->last_scattered_index, &st->frame_scatt_cnt, rng, st);
+            *time_now += time_step;
+            remaining_time -= time_step;
+            orc_photon *scattered = &l->photons[st->last_scattered_index];              /* :786-795 */
+            if (scattered->type == ORC_CS_POOL_PHOTON) {
+                cnt->n_comptonized += scattered->weight;
+                scattered->type = ORC_COMPTONIZED_PHOTON;
+                const int n = orc_photonEmitCyclosynch(c, cs, l, r_inj, ph_weight_suggest, max_photons, theta_jmin_thread, theta_jmax_thread, h, rng, 1,
+                                                       st->last_scattered_index, NULL, NULL);
+                if (n < 0) cnt->error = n; else cnt->num_cyclosynch_ph_emit += n;
+                cnt->scatt_cyclosynch_num_ph++;
+            }
+            if ((st->frame_scatt_cnt % 1000 == 0) && (st->frame_scatt_cnt != 0) && cnt->scatt_cyclosynch_num_ph > max_photons) {   /* :797-808 */
+                const int rc = orc_rebinCyclosynchCompPhotons(c, cs, l, &cnt->num_cyclosynch_ph_emit, &cnt->scatt_cyclosynch_num_ph, max_photons);
+                if (rc >= 0) cnt->rebins++;
+            }
+        } else {
+            *time_now += remaining_time;
+            orc_updatePhotonPosition(l, remaining_time);
+            time_step = remaining_time;
+            remaining_time = 0;
+        }
+        it++;
+        st->photon_steps += l->list_capacity;
+    }
+    if (emit_pool && !cnt->error) {                                                       /* :853-878 */
+        if (cnt->scatt_cyclosynch_num_ph > max_photons) {
+            const int rc = orc_rebinCyclosynchCompPhotons(c, cs, l, &cnt->num_cyclosynch_ph_emit, &cnt->scatt_cyclosynch_num_ph, max_photons);
+            if (rc >= 0) cnt->rebins++;
+        }
+        if (cnt->num_cyclosynch_ph_emit > 0)
+            cnt->n_comptonized -= orc_phAbsCyclosynch(c, cs, l, h, &cnt->frame_abs_cnt, &cnt->scatt_cyclosynch_num_ph);
+    }
+    st->iterations += it;
+    st->last_time_step = time_step;
+    st->remaining_time = remaining_time;
+    st->time_now = *time_now;
 }

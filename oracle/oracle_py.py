@@ -145,6 +145,11 @@ class CS(C.Structure):
                 ("scatt_frame_number", C.c_int), ("inj_frame_number", C.c_int), ("rebin_ang", C.c_double), ("rebin_ang_phi", C.c_double)]
 
 
+class CSCounts(C.Structure):
+    _fields_ = [("num_cyclosynch_ph_emit", C.c_int), ("scatt_cyclosynch_num_ph", C.c_int), ("frame_abs_cnt", C.c_int), ("rebins", C.c_int),
+                ("error", C.c_int), ("n_comptonized", C.c_double), ("pool_weight", C.c_double)]
+
+
 class Outflow(C.Structure):
     _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
                 ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
@@ -220,6 +225,7 @@ def lib():
             "orc_qags": (i, [C.c_void_p, p, d, d, d, d, i, _dp, _dp, C.POINTER(i)]),
             "orc_photonEmitCyclosynch": (i, [cfgp, C.POINTER(CS), lp, d, d, i, d, d, hp, rp, i, i, _dp, C.POINTER(i)]),
             "orc_phAbsCyclosynch": (d, [cfgp, C.POINTER(CS), lp, hp, C.POINTER(i), C.POINTER(i)]),
+            "orc_scatter_frame_cs": (None, [cfgp, C.POINTER(CS), lp, hp, rp, _dp, d, d, d, i, d, d, i, C.c_longlong, sp, C.POINTER(CSCounts)]),
             "orc_rebinCyclosynchCompPhotons": (i, [cfgp, C.POINTER(CS), lp, C.POINTER(i), C.POINTER(i), i]),
             "orc_table_misses": (C.c_longlong, []),
             "orc_reset_table_misses": (None, []),

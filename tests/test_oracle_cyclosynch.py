@@ -301,3 +301,52 @@ def test_rebinning_conserves_weight_energy_and_polarisation(oracle):
     assert L.orc_rebinCyclosynchCompPhotons(C.byref(c), C.byref(cs), C.byref(l3), C.byref(emit), C.byref(scatt), 2000) == -1
     for x in (l, l2, l3):
         L.orc_list_free(C.byref(x))
+
+
+def test_scatter_frame_with_the_switch_on(oracle):
+    """orc_scatter_frame_cs = mcrat.c:706-878: pool emission, the loop with the replacement hook, rebinning when too many
+    comptonised photons exist, absorption at the end.  Without a pool it is the plain loop, bit for bit; with one, the pool keeps
+    its size during the loop (every scattered pool photon is replaced), all pool photons are absorbed at the end, and the list's
+    conservation rule holds throughout."""
+    L = oracle.lib()
+    frame, ph, c, H, cs = _cs_setup(oracle, n_photons=300, lumi=3e53)
+    cs.rebin_ang, cs.rebin_ang_phi = 0.5, 10.0
+    aos = synth.photons_to_aos(ph, oracle.PHOTON_DTYPE)
+
+    # (1) no pool: the same photons as orc_photon_loop
+    l = _list(oracle, aos)
+    rng = oracle.Rng(); L.orc_rng_init(C.byref(rng), 31, 0)
+    st, cnt, t = oracle.Stats(), oracle.CSCounts(), C.c_double(0.0)
+    L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), 0.2, 1e12, 1e40, 2000, 0.0, 0.05, 0, 300,
+                           C.byref(st), C.byref(cnt))
+    P = oracle.OraclePhotons(aos)
+    st2, tn, rem, _ = oracle.photon_loop(c, P, H, seed=31, time_now=0.0, remaining_time=0.2, max_iterations=300)
+    v = _view(oracle, l)
+    for f in aos.dtype.names:
+        assert np.array_equal(v[f], P.aos[f], equal_nan=v[f].dtype.kind == "f"), f
+    assert (st.iterations, st.frame_scatt_cnt, t.value) == (st2.iterations, st2.frame_scatt_cnt, tn) and st.frame_scatt_cnt > 100
+    assert (cnt.num_cyclosynch_ph_emit, cnt.scatt_cyclosynch_num_ph, cnt.rebins, cnt.error) == (0, 0, 0, 0)
+    L.orc_list_free(C.byref(l))
+
+    # (2) with the pool
+    both = np.concatenate([aos, aos])                       # the second half becomes the null slots the pool goes into
+    l = _list(oracle, both)
+    for i in range(300, 600):
+        L.orc_list_set_null(C.byref(l), i)
+    L.orc_rng_init(C.byref(rng), 31, 0)
+    st, cnt, t = oracle.Stats(), oracle.CSCounts(), C.c_double(0.0)
+    L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), 0.2, 1e12, 1e40, 2000, 0.0, 0.05, 1, 600,
+                           C.byref(st), C.byref(cnt))
+    assert cnt.error == 0 and st.iterations == 600 and st.frame_scatt_cnt > 100
+    v = _view(oracle, l)
+    assert l.num_photons + l.num_null_photons == l.list_capacity and l.num_null_photons == int((v["type"] == b"N").sum())
+    assert (v["type"] == b"p").sum() == 0                                   # every pool photon is absorbed at the end of the frame (:1588)
+    pool0 = cnt.num_cyclosynch_ph_emit - cnt.scatt_cyclosynch_num_ph - 0     # emitted at the start = emitted in total - replacements...
+    assert cnt.num_cyclosynch_ph_emit >= 1 and cnt.frame_abs_cnt >= 1
+    k = v[v["type"] == b"k"]
+    assert cnt.scatt_cyclosynch_num_ph == len(k)                            # recounted by phAbsCyclosynch: the survivors
+    assert (k["num_scatt"] >= 1).all() and (k["weight"] == cnt.pool_weight).all()
+    nu_c = [L.orc_calcCyclotronFreq(L.orc_getMagneticFieldMagnitude(C.byref(c), C.byref(cs), C.byref(H.c), int(b))) for b in k["nearest_block_index"]]
+    assert (k["comv_p0"] * synth.C_LIGHT / PL_CONST > np.array(nu_c)).all()  # what survives absorption lies above its cell's cyclotron frequency
+    assert (v["type"] == b"i").sum() <= 300 and np.isfinite(v["p0"]).all()
+    L.orc_list_free(C.byref(l))
