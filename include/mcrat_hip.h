@@ -289,6 +289,26 @@ typedef struct mcrat_hip_output_columns {
 int mcrat_hip_get_output(mcrat_hip_ctx *ctx, mcrat_hip_output_columns *out);
 int mcrat_hip_get_photons_range(mcrat_hip_ctx *ctx, int first, int count, mcrat_hip_photon *records);
 
+/* Cyclo-synchrotron, first device piece: the absorption at the end of a scatter frame.  The rest of the row
+ * (pool emission, the replacement hook inside the loop, rebinning) is not on the device yet and mcrat_hip_init still refuses
+ * cyclosynchrotron_switch != 0; this call works on whatever photon types the list holds.
+ *   mcrat_hip_set_hydro_extras   the columns of struct hydro_dataframe the magnetic field needs and mcrat_hip_hydro does not carry:
+ *                                dens (comoving density; B_FIELD_CALC INTERNAL_E / TOTAL_E, mc_cyclosynch.c:82-83) and B0-2
+ *                                (B_FIELD_CALC == SIMULATION).  NULL pointers are skipped; after mcrat_hip_ingest_* dens is there already.
+ *   mcrat_hip_absorb_cyclosynch  phAbsCyclosynch (mc_cyclosynch.c:1571-1623): every photon with weight != 0 and a cell whose comoving
+ *                                frequency is at or below its cell's cyclotron frequency, and every pool photon, becomes a null
+ *                                slot (setNullPhoton, photons.c:210-250); returns the count, the number of comptonised / unabsorbed
+ *                                photons left (:1610-1614) and the weight of the absorbed 'i' / 'c' photons (the return value). */
+typedef struct mcrat_hip_cyclosynch {
+    int    b_field_calc;                  /* B_FIELD_CALC: 0 INTERNAL_E, 1 TOTAL_E, 2 SIMULATION (mcrat.h:47-49) */
+    double epsilon_b;                     /* EPSILON_B */
+    double rebin_e_perc, rebin_ang, rebin_ang_phi;   /* CYCLOSYNCHROTRON_REBIN_* (mcrat.h:310-321); unused by the absorption */
+    int    scatt_frame_number, inj_frame_number;     /* hydro_data->scatt_frame_number / ->inj_frame_number; unused by the absorption */
+} mcrat_hip_cyclosynch;
+int mcrat_hip_set_hydro_extras(mcrat_hip_ctx *ctx, const double *dens, const double *B0, const double *B1, const double *B2);
+int mcrat_hip_absorb_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, int *num_abs_ph, int *scatt_cyclosynch_num_ph,
+                                double *abs_weight);
+
 /* photonInjection (mclib.c:9-300; mcrat.c:645) on the device, from the staged hydro frame: afterwards the context holds
  * the new photons (*num_photons of them, all of weight *ph_weight_adjusted -- the reference's min/max-photons loop of
  * mclib.c:87-136 runs on the device counts) exactly as if they had been injected on the host and handed to

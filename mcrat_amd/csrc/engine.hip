@@ -493,6 +493,7 @@ extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *t
 }
 
 static int ensure_aos(mcrat_hip_ctx *c, size_t bytes);
+static int flush_pending(mcrat_hip_ctx *c);
 
 // The frame's per-cell records and cell-lookup grid.  h == nullptr (the product path): from the device columns c->hcol,
 // on the device -- stage_cells_kernel (ingest.hip) + grid_build.hip; the host only plans the bucket grid from the mesh
@@ -703,14 +704,15 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
 // struct hydro_dataframe's columns on the device: 16 arrays of M doubles
 static int ensure_hcol(mcrat_hip_ctx *c, int M)
 {
-    const size_t stride = align_up(sizeof(double) * (size_t)M, 256), total = 16 * stride;
+    const size_t stride = align_up(sizeof(double) * (size_t)M, 256), total = 19 * stride;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->hcol_buf && c->hcol_bytes < total) { HIPCHK(c, hipFree(c->hcol_buf)); c->hcol_buf = nullptr; c->hcol_bytes = 0; }
     if (!c->hcol_buf) { HIPCHK(c, hipMalloc(&c->hcol_buf, total)); c->hcol_bytes = total; }
     char *b = static_cast<char *>(c->hcol_buf);
-    double **cols[16] = {&c->hcol.r0, &c->hcol.r1, &c->hcol.r2, &c->hcol.s0, &c->hcol.s1, &c->hcol.s2, &c->hcol.v0, &c->hcol.v1, &c->hcol.v2,
-                         &c->hcol.dens, &c->hcol.dens_lab, &c->hcol.pres, &c->hcol.temp, &c->hcol.gamma, &c->hcol.r, &c->hcol.theta};
-    for (int k = 0; k < 16; ++k) *cols[k] = reinterpret_cast<double *>(b + k * stride);
+    double **cols[19] = {&c->hcol.r0, &c->hcol.r1, &c->hcol.r2, &c->hcol.s0, &c->hcol.s1, &c->hcol.s2, &c->hcol.v0, &c->hcol.v1, &c->hcol.v2,
+                         &c->hcol.dens, &c->hcol.dens_lab, &c->hcol.pres, &c->hcol.temp, &c->hcol.gamma, &c->hcol.r, &c->hcol.theta,
+                         &c->hcol.B0, &c->hcol.B1, &c->hcol.B2};
+    for (int k = 0; k < 19; ++k) *cols[k] = reinterpret_cast<double *>(b + k * stride);
     c->hcol_M = M;
     return MCRAT_HIP_OK;
 }
@@ -1004,6 +1006,42 @@ extern "C" int mcrat_hip_ingest_chombo(mcrat_hip_ctx *c, const mcrat_hip_chombo 
                        [&](const SlabDev &sd, const int *start) { return ingest_write_chombo(d, sd, start, c->hcol, c->stream); });
     if (rc == MCRAT_HIP_OK && result) result->cells_read = cells;
     return rc;
+}
+
+extern "C" int mcrat_hip_set_hydro_extras(mcrat_hip_ctx *c, const double *dens, const double *B0, const double *B1, const double *B2)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro || !c->hcol_buf) return MCRAT_HIP_ESTATE;
+    const size_t bytes = sizeof(double) * (size_t)c->hcol_M;
+    const struct { double *dst; const double *src; } copy[4] = {{c->hcol.dens, dens}, {c->hcol.B0, B0}, {c->hcol.B1, B1}, {c->hcol.B2, B2}};
+    for (const auto &cp : copy)
+        if (cp.src) HIPCHK(c, hipMemcpyAsync(cp.dst, cp.src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_absorb_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, int *num_abs_ph, int *scatt_cyclosynch_num_ph,
+                                           double *abs_weight)
+{
+    if (!c || !cs || cs->b_field_calc < 0 || cs->b_field_calc > 2) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro || !c->have_photons || !c->hcol_buf) return MCRAT_HIP_ESTATE;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    const int nblk = cs_absorb_blocks(c->ph.n);
+    if ((rc = ensure_aos(c, sizeof(CsAbsPartial) * (size_t)nblk))) return rc;
+    CsParams p{c->kc.dimensions, cs->b_field_calc, cs->epsilon_b};
+    HIPCHK(c, launch_cs_absorb(p, c->ph, c->hy.temp, c->hcol, static_cast<CsAbsPartial *>(c->aos_buf), c->stream));
+    std::vector<CsAbsPartial> part((size_t)nblk);
+    HIPCHK(c, hipMemcpyAsync(part.data(), c->aos_buf, sizeof(CsAbsPartial) * (size_t)nblk, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double w = 0;
+    long long a = 0, s = 0;
+    for (const auto &q : part) { w += q.abs_weight; a += q.abs_count; s += q.scatt_count; }
+    if (num_abs_ph) *num_abs_ph = (int)a;
+    if (scatt_cyclosynch_num_ph) *scatt_cyclosynch_num_ph = (int)s;
+    if (abs_weight) *abs_weight = w;
+    drop_graph(c);
+    return MCRAT_HIP_OK;
 }
 
 extern "C" int mcrat_hip_get_hydro(mcrat_hip_ctx *c, mcrat_hip_hydro_columns *out)

@@ -82,6 +82,7 @@ struct HydroCols {          // struct hydro_dataframe's columns (mcrat.h:194-244
     double *v0, *v1, *v2;
     double *dens, *dens_lab, *pres, *temp, *gamma;
     double *r, *theta;
+    double *B0, *B1, *B2;   // magnetic field (B_FIELD_CALC == SIMULATION; mcrat_hip_set_hydro_extras)
 };
 struct SlabDev {
     int dimensions, geometry, ph_inj_switch;
@@ -124,6 +125,15 @@ hipError_t ingest_count_chombo(const ChomboDev &h, const SlabDev &slab, unsigned
 hipError_t ingest_write_chombo(const ChomboDev &h, const SlabDev &slab, const int *block_start, const HydroCols &out, hipStream_t stream);
 // marks the cells of boxes [c0, c1) that a box of [f0, f1) (the next finer level) covers
 hipError_t launch_chombo_mask(const ChomboBox *boxes, int c0, int c1, int f0, int f1, int ref_ratio, int three, unsigned char *covered, hipStream_t stream);
+// phAbsCyclosynch (mc_cyclosynch.c:1571-1623) on the device (staging.hip): photons at or below their cell's cyclotron frequency and
+// all pool photons become null slots (setNullPhoton, photons.c:210-250)
+struct CsParams {
+    int dimensions, b_field_calc;
+    double epsilon_b;
+};
+struct CsAbsPartial { double abs_weight; int abs_count, scatt_count; };      // one per workgroup
+int cs_absorb_blocks(int n);
+hipError_t launch_cs_absorb(const CsParams &p, const PhotonDev &ph, const double *temp, const HydroCols &h, CsAbsPartial *partials, hipStream_t stream);
 struct OutflowDev {
     int simulation_type;
     double gamma_infinity, lumi, r00, t_comov, ddensity, theta_j, p;

@@ -106,6 +106,69 @@ __global__ __launch_bounds__(256) void output_write_kernel(PhotonDev ph, int n, 
     out.type[j] = ph.type[i];
 }
 
+constexpr double CHARGE_EL = 4.8032068e-10;      // Src/mclib.c:4-5
+
+// phAbsCyclosynch, mc_cyclosynch.c:1571-1623; calcB :54-76, calcCyclotronFreq :30-33, getMagneticFieldMagnitude :78-92
+__global__ __launch_bounds__(256) void cs_absorb_kernel(CsParams p, PhotonDev ph, const double *__restrict__ temp, HydroCols h,
+                                                        CsAbsPartial *__restrict__ partials)
+{
+    __shared__ double s_w[4];
+    __shared__ int s_a[4], s_s[4];
+    double abs_weight = 0;
+    int abs_count = 0, scatt_count = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ph.n; i += gridDim.x * 256) {
+        const double weight = ph.weight[i];
+        const int cell = ph.idx[i];
+        if (!((weight != 0) && (cell != -1))) continue;
+        double b_field;
+        if (p.b_field_calc == 0 || p.b_field_calc == 1) {
+            const double el_dens = h.dens[cell] / M_P, T = temp[cell];
+            if (p.b_field_calc == 0) b_field = sqrt(p.epsilon_b * 8 * M_PI * 3 * el_dens * K_B * T / 2);
+            else b_field = sqrt(8 * M_PI * p.epsilon_b * (el_dens * M_P * C_LIGHT * C_LIGHT + 4 * A_RAD * T * T * T * T / 3));
+        } else if (p.dimensions == DIM_TWO) {
+            b_field = sqrt(h.B0[cell] * h.B0[cell] + h.B1[cell] * h.B1[cell]);
+        } else {
+            b_field = sqrt(h.B0[cell] * h.B0[cell] + h.B1[cell] * h.B1[cell] + h.B2[cell] * h.B2[cell]);
+        }
+        const double nu_c = CHARGE_EL * b_field / (2 * M_PI * M_EL * C_LIGHT);
+        const char type = ph.type[i];
+        if ((ph.c0[i] * C_LIGHT / PL_CONST <= nu_c) || (type == 'p')) {
+            abs_count += 1;
+            if (type == 'i' || type == 'c') abs_weight += weight;
+            // setNullPhoton, photons.c:210-250 (time_to_scatter is left as it is)
+            ph.type[i] = 'N';
+            ph.weight[i] = 0;
+            ph.idx[i] = -1;
+            ph.flags[i] = (unsigned char)FLAG_VALID;
+            ph.p0[i] = 0; ph.p1[i] = 0; ph.p2[i] = 0; ph.p3[i] = 0;
+            ph.c0[i] = 0; ph.c1[i] = 0; ph.c2[i] = 0; ph.c3[i] = 0;
+            ph.r0[i] = 0; ph.r1[i] = 0; ph.r2[i] = 0;
+            ph.s0[i] = 0; ph.s1[i] = 0; ph.s2[i] = 0; ph.s3[i] = 0;
+            ph.num_scatt[i] = 0;
+            ph.tau[i] = 0;
+            ph.u0[i] = 0; ph.u1[i] = 0; ph.u2[i] = 0;
+            ph.ntau[i] = -1.0 / 0.0;
+            ph.tau_next[i] = 0;
+        } else if (type == 'k' || type == 'c') {
+            scatt_count += 1;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        abs_weight += __shfl_down(abs_weight, off);
+        abs_count += __shfl_down(abs_count, off);
+        scatt_count += __shfl_down(scatt_count, off);
+    }
+    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = abs_weight; s_a[threadIdx.x >> 6] = abs_count; s_s[threadIdx.x >> 6] = scatt_count; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        CsAbsPartial o;
+        o.abs_weight = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        o.abs_count = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        o.scatt_count = s_s[0] + s_s[1] + s_s[2] + s_s[3];
+        partials[blockIdx.x] = o;
+    }
+}
+
 // the loop state of a new frame (mcrat.c:754-758): one record for the single list, one per virtual rank with the forced
 // re-location pending.  The record travels as a kernel argument, so opening a frame needs no host buffer and no wait.
 __global__ __launch_bounds__(256) void init_states_kernel(LoopState *__restrict__ single, LoopState *__restrict__ ranks, int n_ranks, LoopState v)
@@ -137,6 +200,14 @@ hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStr
 hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int first, int n, hipStream_t stream)
 {
     soa_to_aos_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(ph, static_cast<mcrat_hip_photon *>(aos), first, n);
+    return hipGetLastError();
+}
+
+int cs_absorb_blocks(int n) { const int b = (n + 255) / 256; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
+
+hipError_t launch_cs_absorb(const CsParams &p, const PhotonDev &ph, const double *temp, const HydroCols &h, CsAbsPartial *partials, hipStream_t stream)
+{
+    cs_absorb_kernel<<<dim3(cs_absorb_blocks(ph.n)), dim3(256), 0, stream>>>(p, ph, temp, h, partials);
     return hipGetLastError();
 }
 

@@ -119,6 +119,12 @@ class Chombo(C.Structure):
                 ("data", _dp), ("l_scale", C.c_double), ("d_scale", C.c_double), ("p_scale", C.c_double)]
 
 
+class Cyclosynch(C.Structure):
+    """mcrat_hip_cyclosynch: B_FIELD_CALC (0 INTERNAL_E, 1 TOTAL_E, 2 SIMULATION), EPSILON_B and the rebinning / frame fields"""
+    _fields_ = [("b_field_calc", C.c_int), ("epsilon_b", C.c_double), ("rebin_e_perc", C.c_double), ("rebin_ang", C.c_double),
+                ("rebin_ang_phi", C.c_double), ("scatt_frame_number", C.c_int), ("inj_frame_number", C.c_int)]
+
+
 class Outflow(C.Structure):
     _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
                 ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
@@ -157,6 +163,8 @@ SYMBOLS = {
     "mcrat_hip_ingest_flash": (C.c_int, [_ctx, C.POINTER(FlashBlocks), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_ingest_pluto": (C.c_int, [_ctx, C.POINTER(PlutoGrid), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_ingest_chombo": (C.c_int, [_ctx, C.POINTER(Chombo), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
+    "mcrat_hip_set_hydro_extras": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
+    "mcrat_hip_absorb_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), _ip, _ip, _dp]),
     "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
     "mcrat_hip_get_output": (C.c_int, [_ctx, C.POINTER(OutputColumns)]),
     "mcrat_hip_get_photons_range": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
@@ -350,6 +358,17 @@ class Engine:
             self._check(self.lib.mcrat_hip_ingest_pluto(self.ctx, C.byref(g), C.byref(s), op, C.byref(res)), "ingest_pluto")
         self.num_elements = res.num_elements
         return res.num_elements, res.elem_factor, res.cells_read
+
+    def set_hydro_extras(self, dens=None, B0=None, B1=None, B2=None):
+        keep = [None if a is None else _f8(a) for a in (dens, B0, B1, B2)]
+        self._check(self.lib.mcrat_hip_set_hydro_extras(self.ctx, *[None if a is None else a.ctypes.data_as(_dp) for a in keep]), "set_hydro_extras")
+
+    def absorb_cyclosynch(self, b_field_calc=1, epsilon_b=0.5):
+        """phAbsCyclosynch (mc_cyclosynch.c:1571-1623) -> (num_abs_ph, scatt_cyclosynch_num_ph, absorbed weight)"""
+        cs = Cyclosynch(int(b_field_calc), float(epsilon_b), 0.1, 0.5, 10.0, 0, 0)
+        a, s, w = C.c_int(), C.c_int(), C.c_double()
+        self._check(self.lib.mcrat_hip_absorb_cyclosynch(self.ctx, C.byref(cs), C.byref(a), C.byref(s), C.byref(w)), "absorb_cyclosynch")
+        return a.value, s.value, w.value
 
     def get_hydro(self, num_elements=None):
         """the staged frame's columns (struct hydro_dataframe) as a dict of numpy arrays"""

@@ -1,0 +1,73 @@
+"""GPU parity for the cyclo-synchrotron row as far as it is on the device: the absorption at the end of a
+scatter frame (mcrat_hip_absorb_cyclosynch = phAbsCyclosynch, Src/mc_cyclosynch.c:1571-1623) against oracle/oracle_cyclosynch.c."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+
+pytestmark = pytest.mark.gpu
+PL_CONST = 6.6260755e-27
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mcrat_amd import engine
+    engine.load_library()
+    return engine
+
+
+@pytest.mark.parametrize("b_field_calc", [0, 1, 2])
+@pytest.mark.parametrize("dims", ["2d", "3d"])
+def test_absorption_matches_the_oracle(hip, oracle, b_field_calc, dims):
+    L = oracle.lib()
+    if dims == "2d":
+        frame, ph, cfg = synth.config2(n_photons=4000, nzc=8, stokes=1, lumi=1e53)
+    else:
+        frame, ph, cfg = synth.config_3d_cartesian(n_photons=3000, n=(16, 16, 16))
+    rng = np.random.default_rng(8)
+    m = frame["num_elements"]
+    dens = np.ascontiguousarray(frame["dens"]) if "dens" in frame else np.ascontiguousarray(frame["dens_lab"] / frame["gamma"])
+    B = [np.ascontiguousarray(10 ** rng.uniform(2, 7, m)) for _ in range(3)]
+    # locate the photons on the device, then give the list every type and a spread of comoving energies around nu_c
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    e.begin_frame(3, 0.0, 0.2)
+    e.run(40)
+    aos = e.get_photons_aos()
+    n = len(aos)
+    aos["type"] = rng.choice([b"i", b"k", b"c", b"p", b"N"], size=n, p=[0.4, 0.2, 0.2, 0.15, 0.05])
+    aos["weight"] = np.where(aos["type"] == b"N", 0.0, 10 ** rng.uniform(45, 47, n))
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    H = oracle.OracleHydro(frame)
+    cs = oracle.CS(b_field_calc, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), *[b.ctypes.data_as(C.POINTER(C.c_double)) for b in B], 200, 200, 0.5, 10.0)
+    cell = np.maximum(aos["nearest_block_index"], 0)
+    nu_c = np.array([L.orc_calcCyclotronFreq(L.orc_getMagneticFieldMagnitude(C.byref(c), C.byref(cs), C.byref(H.c), int(k))) for k in cell])
+    factor = np.where(rng.random(n) < 0.5, 10 ** rng.uniform(-2, -0.01, n), 10 ** rng.uniform(0.01, 2, n))
+    factor[::50] = 1.0                                                  # exactly at the cyclotron frequency: absorbed (<=)
+    aos["comv_p0"] = factor * nu_c * PL_CONST / synth.C_LIGHT
+    aos["nearest_block_index"][5::97] = -1                              # outside the frame: never absorbed
+    # oracle
+    l = oracle.PhotonList()
+    L.orc_list_init(C.byref(l))
+    ref = aos.copy()
+    assert L.orc_list_set(C.byref(l), ref.ctypes.data, n) == 0
+    n_abs, n_scatt = C.c_int(), C.c_int()
+    w_ref = L.orc_phAbsCyclosynch(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(n_abs), C.byref(n_scatt))
+    buf = (C.c_char * (n * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    want = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    L.orc_list_free(C.byref(l))
+    # device
+    e.set_photons_aos(aos)
+    e.set_hydro_extras(dens, *B)
+    a, s, w = e.absorb_cyclosynch(b_field_calc, 0.5)
+    got = e.get_photons_aos()
+    e.close()
+    assert (a, s) == (n_abs.value, n_scatt.value) and a > 0.3 * n and s > 0
+    assert w == pytest.approx(w_ref, rel=1e-12)
+    assert (got["type"][got["nearest_block_index"] != -1] == b"p").sum() == 0          # pool photons outside the frame are left alone (:1586)
+    for f in ("type", "weight", "nearest_block_index", "recalc_properties", "p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3",
+              "r0", "r1", "r2", "s0", "s1", "s2", "s3", "num_scatt", "total_optical_depth"):
+        assert np.array_equal(got[f], want[f], equal_nan=got[f].dtype.kind == "f"), f
