@@ -306,6 +306,19 @@ typedef struct mcrat_hip_cyclosynch {
     int    scatt_frame_number, inj_frame_number;     /* hydro_data->scatt_frame_number / ->inj_frame_number; unused by the absorption */
 } mcrat_hip_cyclosynch;
 int mcrat_hip_set_hydro_extras(mcrat_hip_ctx *ctx, const double *dens, const double *B0, const double *B1, const double *B2);
+/*   mcrat_hip_emit_cyclosynch_pool  photonEmitCyclosynch with inject_single_switch == 0 (mc_cyclosynch.c:1200-1460, mcrat.c:741) on the staged
+ *                                frame: pool photons (type 'p') at the centres of the cells of the shell the injected photons occupy
+ *                                (calcCyclosynchRLimits with cs->scatt_frame_number / inj_frame_number), each at its cell's cyclotron
+ *                                frequency, the common weight adjusted until 1 <= N <= rebin_e_perc * maximum_photons; they go into
+ *                                the list's null slots in slot order, the list doubling first when it has none (addToPhotonList,
+ *                                photons.c:108-208; MCRAT_HIP_EINVAL where the reference exits with "Adding to the photon list has
+ *                                failed").  The Poisson mean is gsl_integration_qags of the Planck photon density from 10 Hz to the
+ *                                cyclotron frequency: QUADPACK's first 21-point rule, which is where QAGS stops for this integrand;
+ *                                *integrals_not_converged counts cells where it would not have (weak field in a very hot cell). */
+int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, double r_inj, double ph_weight, int maximum_photons,
+                                   double theta_min, double theta_max, double fps, uint64_t seed, int *num_emitted, double *ph_weight_adjusted,
+                                   int *integrals_not_converged);
+int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *ctx);   /* photon_list->list_capacity as the device holds it (it grows when the pool does not fit) */
 int mcrat_hip_absorb_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, int *num_abs_ph, int *scatt_cyclosynch_num_ph,
                                 double *abs_weight);
 

@@ -1239,6 +1239,126 @@ extern "C" int mcrat_hip_inject_photons(mcrat_hip_ctx *c, double r_inj, double p
     return MCRAT_HIP_OK;
 }
 
+// reallocatePhotonListMemory (photons.c:37-80) on the device: a larger set of columns, the old slots copied, the new ones null
+static int grow_photons(mcrat_hip_ctx *c, int new_n)
+{
+    const PhotonDev old = c->ph;
+    void *old_buf = c->ph_buf;
+    const int old_n = old.n;
+    if (new_n <= old_n) return MCRAT_HIP_EINVAL;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->ph_buf = nullptr; c->ph_bytes = 0;                     // a fresh, zeroed allocation
+    int rc = alloc_photons(c, new_n);
+    if (rc) { if (c->ph_buf) (void)hipFree(c->ph_buf); c->ph_buf = old_buf; c->ph = old; return rc; }
+    const double *src[24] = {old.r0, old.r1, old.r2, old.p0, old.p1, old.p2, old.p3, old.c0, old.c1, old.c2, old.c3, old.s0, old.s1, old.s2, old.s3,
+                             old.num_scatt, old.weight, old.tau, old.tts, old.u0, old.u1, old.u2, old.ntau, old.tau_next};
+    double *dst[24] = {c->ph.r0, c->ph.r1, c->ph.r2, c->ph.p0, c->ph.p1, c->ph.p2, c->ph.p3, c->ph.c0, c->ph.c1, c->ph.c2, c->ph.c3, c->ph.s0, c->ph.s1,
+                       c->ph.s2, c->ph.s3, c->ph.num_scatt, c->ph.weight, c->ph.tau, c->ph.tts, c->ph.u0, c->ph.u1, c->ph.u2, c->ph.ntau, c->ph.tau_next};
+    for (int k = 0; k < 24; ++k) HIPCHK(c, hipMemcpyAsync(dst[k], src[k], sizeof(double) * (size_t)old_n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ph.idx, old.idx, sizeof(int) * (size_t)old_n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ph.flags, old.flags, (size_t)old_n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ph.type, old.type, (size_t)old_n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, launch_null_fill(c->ph, old_n, new_n - old_n, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(old_buf));
+    if (c->ph_snap) { HIPCHK(c, hipFree(c->ph_snap)); c->ph_snap = nullptr; c->ph_snap_bytes = 0; }     // a snapshot of the smaller list
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, double r_inj, double ph_weight, int maximum_photons,
+                                              double theta_min, double theta_max, double fps, uint64_t seed, int *num_emitted,
+                                              double *ph_weight_adjusted, int *integrals_not_converged)
+{
+    if (!c || !cs || cs->b_field_calc < 0 || cs->b_field_calc > 2 || !(ph_weight > 0) || !(fps > 0) || maximum_photons < 0) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro || !c->hcol_buf || !c->have_photons) return MCRAT_HIP_ESTATE;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    const int M = c->hy.M;
+    CsEmitParams p{};
+    p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry; p.b_field_calc = cs->b_field_calc; p.epsilon_b = cs->epsilon_b;
+    p.rmin = r_inj + (C_LIGHT * (cs->scatt_frame_number - cs->inj_frame_number) / fps - 0.5 * C_LIGHT / fps);      // calcCyclosynchRLimits :225-244
+    p.rmax = r_inj + (C_LIGHT * (cs->scatt_frame_number - cs->inj_frame_number) / fps + 0.5 * C_LIGHT / fps);
+    p.theta_min = theta_min; p.theta_max = theta_max;
+    RngKey key = c->key;
+    key.seed = seed;
+    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+    const size_t need_counts = (size_t)std::max(M, (c->ph.n + 255) / 256 + 8);
+    if (c->grid_count_cap < need_counts) {
+        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
+        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * need_counts));
+        c->grid_count_cap = need_counts;
+    }
+    unsigned *d_flags = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_flags, 2 * sizeof(unsigned)));
+    auto fail = [&](int code) { (void)hipFree(d_flags); return code; };
+    // :1244-1296: the weight loop on the device's totals
+    const double max_photons = cs->rebin_e_perc * maximum_photons;
+    double weight = ph_weight;
+    unsigned long long total = 0;
+    unsigned flags[2] = {0, 0};
+    bool ok = false;
+    for (unsigned long long attempt = 0; attempt <= 400 && !ok; ++attempt) {
+        if (hipMemsetAsync(d_flags, 0, 2 * sizeof(unsigned), c->stream) != hipSuccess) return fail(MCRAT_HIP_EHIP);
+        if (launch_cs_emit_count(p, c->hy, c->hcol, weight, attempt, key, c->grid_count, c->d_grid_total, d_flags, c->stream) != hipSuccess ||
+            hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { c->last_error = "cyclo-synchrotron emission: count pass failed"; return fail(MCRAT_HIP_EHIP); }
+        const int min_photons = flags[1] ? 1 : 0;                                   // no cell in the shell: nothing to emit (:1236-1239)
+        if ((double)total > max_photons) weight *= 10;
+        else if ((long long)total < min_photons) weight *= 0.5;
+        else ok = true;
+    }
+    if (!ok) { c->last_error = "cyclo-synchrotron emission: no weight gives between 1 and rebin_e_perc * maximum_photons photons"; return fail(MCRAT_HIP_EINVAL); }
+    const int n_emit = (int)total;
+    if (num_emitted) *num_emitted = n_emit;
+    if (ph_weight_adjusted) *ph_weight_adjusted = weight;
+    if (integrals_not_converged) *integrals_not_converged = (int)flags[0];
+    if (n_emit == 0) return fail(MCRAT_HIP_OK);
+    // cell -> first pool photon (the counts live in grid_count[0..M)); keep them while the list may be re-allocated
+    const size_t scan_ints = (size_t)M + 1 + grid_scan_scratch_ints(M);
+    int *d_start = nullptr;
+    if (hipMalloc((void **)&d_start, sizeof(int) * scan_ints) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
+    auto fail2 = [&](int code) { (void)hipFree(d_start); return fail(code); };
+    if (launch_exclusive_scan(c->grid_count, M, d_start, d_start + M + 1, (long long)total, c->stream) != hipSuccess) return fail2(MCRAT_HIP_EHIP);
+    // addToPhotonList (photons.c:108-208): the null slots, the list doubled first when it has none
+    unsigned long long n_null = 0;
+    auto count_nulls = [&]() -> int {
+        if (launch_null_count(c->ph, c->grid_count, c->d_grid_total, c->stream) != hipSuccess ||
+            hipMemcpyAsync(&n_null, c->d_grid_total, sizeof n_null, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) return MCRAT_HIP_EHIP;
+        return MCRAT_HIP_OK;
+    };
+    if ((rc = count_nulls())) return fail2(rc);
+    if (n_null == 0) {                                                              // num_photons >= list_capacity && num_null_photons <= num (:112)
+        const long long cap = c->ph.n;
+        const long long new_cap = (cap * 2 > cap + n_emit) ? cap * 2 : cap * (n_emit / cap);
+        if (new_cap > 0x7fffffffLL) return fail2(MCRAT_HIP_EINVAL);
+        if ((rc = grow_photons(c, (int)new_cap))) return fail2(rc);
+        if (c->grid_count_cap < (size_t)((c->ph.n + 255) / 256 + 8)) {
+            HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0;
+            const size_t cap2 = (size_t)((c->ph.n + 255) / 256 + 8);
+            if (hipMalloc((void **)&c->grid_count, sizeof(unsigned) * cap2) != hipSuccess) return fail2(MCRAT_HIP_ENOMEM);
+            c->grid_count_cap = cap2;
+        }
+        if ((rc = count_nulls())) return fail2(rc);
+    }
+    if ((unsigned long long)n_emit > n_null) {
+        c->last_error = "cyclo-synchrotron emission: fewer null slots than photons to add (the reference exits with \"Adding to the photon list has failed\")";
+        return fail2(MCRAT_HIP_EINVAL);
+    }
+    const long long nblk = (c->ph.n + 255) / 256;
+    const size_t null_bytes = sizeof(int) * ((size_t)nblk + 1 + grid_scan_scratch_ints(nblk) + (size_t)n_null);
+    if ((rc = ensure_aos(c, null_bytes))) return fail2(rc);
+    int *blk_start = static_cast<int *>(c->aos_buf), *scratch = blk_start + nblk + 1, *null_slots = scratch + grid_scan_scratch_ints(nblk);
+    if (launch_exclusive_scan(c->grid_count, nblk, blk_start, scratch, (long long)n_null, c->stream) != hipSuccess ||
+        launch_null_write(c->ph, blk_start, null_slots, c->stream) != hipSuccess ||
+        launch_cs_emit_generate(p, c->hy, c->hcol, weight, key, d_start, n_emit, null_slots, c->ph, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { c->last_error = "cyclo-synchrotron emission: generate pass failed"; return fail2(MCRAT_HIP_EHIP); }
+    c->frame_open = false;
+    drop_graph(c);
+    return fail2(MCRAT_HIP_OK);
+}
+
 extern "C" int mcrat_hip_set_photons_soa(mcrat_hip_ctx *c, const mcrat_hip_photon_soa *s)
 {
     if (!c || !s || s->n <= 0) return MCRAT_HIP_EINVAL;

@@ -243,7 +243,270 @@ __global__ __launch_bounds__(256) void inject_generate_kernel(InjectParams p, Hy
     ph.type[k] = 'i';                                                        // INJECTED_PHOTON, mcrat.h
 }
 
+// ---------------------------------------------------------------------------------------------- cyclo-synchrotron pool emission
+constexpr uint32_t RNG_CS_COUNT = 5u;
+constexpr uint32_t RNG_CS_PHOTON = 6u;
+constexpr double CHARGE_EL = 4.8032068e-10;      // Src/mclib.c:4-5
+
+// getMagneticFieldMagnitude + calcCyclotronFreq, mc_cyclosynch.c:30-33,54-92
+__device__ __forceinline__ double cs_nu_c(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, int i)
+{
+    double b_field;
+    if (p.b_field_calc == 0 || p.b_field_calc == 1) {
+        const double el_dens = h.dens[i] / M_P, T = hy.temp[i];
+        if (p.b_field_calc == 0) b_field = sqrt(p.epsilon_b * 8 * M_PI * 3 * el_dens * K_B * T / 2);
+        else b_field = sqrt(8 * M_PI * p.epsilon_b * (el_dens * M_P * C_LIGHT * C_LIGHT + 4 * A_RAD * T * T * T * T / 3));
+    } else if (p.dimensions == DIM_TWO) {
+        b_field = sqrt(h.B0[i] * h.B0[i] + h.B1[i] * h.B1[i]);
+    } else {
+        b_field = sqrt(h.B0[i] * h.B0[i] + h.B1[i] * h.B1[i] + h.B2[i] * h.B2[i]);
+    }
+    return CHARGE_EL * b_field / (2 * M_PI * M_EL * C_LIGHT);
+}
+
+// mc_cyclosynch.c:1215-1226 (note the strict upper bounds, unlike the injection's slab)
+__device__ __forceinline__ bool in_emission_slab(const CsEmitParams &p, const CellRec &c)
+{
+    double r_in, th_in, r_out, th_out;
+    if (p.dimensions == DIM_THREE) {
+        hydro_to_spherical(p.dimensions, p.geometry, fabs(c.c0) - 0.5 * c.s0, fabs(c.c1) - 0.5 * c.s1, fabs(c.c2) - 0.5 * c.s2, r_in, th_in);
+        hydro_to_spherical(p.dimensions, p.geometry, fabs(c.c0) + 0.5 * c.s0, fabs(c.c1) + 0.5 * c.s1, fabs(c.c2) + 0.5 * c.s2, r_out, th_out);
+    } else {
+        hydro_to_spherical(p.dimensions, p.geometry, c.c0 - 0.5 * c.s0, c.c1 - 0.5 * c.s1, 0, r_in, th_in);
+        hydro_to_spherical(p.dimensions, p.geometry, c.c0 + 0.5 * c.s0, c.c1 + 0.5 * c.s1, 0, r_out, th_out);
+    }
+    return (p.rmin <= r_out) && (r_in < p.rmax) && (th_out >= p.theta_min) && (th_in < p.theta_max);
+}
+
+// blackbody_ph_spect, mc_cyclosynch.c:185-196
+__device__ __forceinline__ double planck_tail(double nu, double temp)
+{
+    return (8 * M_PI * nu * nu) / (exp(PL_CONST * nu / (K_B * temp)) - 1) / (C_LIGHT * C_LIGHT * C_LIGHT);
+}
+
+// gsl_integration_qags(blackbody_ph_spect, 10, nu_c, 0, 1e-2, ...) (:1276): QUADPACK's 21-point Gauss-Kronrod rule and QAGS' first-step
+// test, as oracle/oracle_cyclosynch.c restates them; `converged` tells whether QAGS would have returned after this one rule
+__device__ double qk21_planck(double a, double b, double temp, bool &converged)
+{
+    const double XGK[11] = {0.995657163025808080735527280689003, 0.973906528517171720077964012084452, 0.930157491355708226001207180059508,
+                            0.865063366688984510732096688423493, 0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
+                            0.562757134668604683339000099272694, 0.433395394129247190799265943165784, 0.294392862701460198131126603103866,
+                            0.148874338981631210884826001129720, 0.0};
+    const double WGK[11] = {0.011694638867371874278064396062192, 0.032558162307964727478818972459390, 0.054755896574351996031381300244580,
+                            0.075039674810919952767043140916190, 0.093125454583697605535065465083366, 0.109387158802297641899210590325805,
+                            0.123491976262065851077958109585166, 0.134709217311473325928054001771707, 0.142775938577060080797094273138717,
+                            0.147739104901338491374841515972068, 0.149445554002916905664936468389821};
+    const double WG[5] = {0.066671344308688137593568809893332, 0.149451349150580593145776339657697, 0.219086362515982043995534934228163,
+                          0.269266719309996355091226921569469, 0.295524224714752870173815619188769};
+    const double centr = 0.5 * (a + b), hlgth = 0.5 * (b - a), dhlgth = fabs(hlgth);
+    const double fc = planck_tail(centr, temp);
+    double fv1[10], fv2[10], resg = 0, resk = WGK[10] * fc, rabs = fabs(resk);
+    for (int j = 0; j < 5; j++) {
+        const int jtw = 2 * j + 1;
+        const double absc = hlgth * XGK[jtw], f1 = planck_tail(centr - absc, temp), f2 = planck_tail(centr + absc, temp);
+        fv1[jtw] = f1; fv2[jtw] = f2;
+        resg += WG[j] * (f1 + f2);
+        resk += WGK[jtw] * (f1 + f2);
+        rabs += WGK[jtw] * (fabs(f1) + fabs(f2));
+    }
+    for (int j = 0; j < 5; j++) {
+        const int jtwm1 = 2 * j;
+        const double absc = hlgth * XGK[jtwm1], f1 = planck_tail(centr - absc, temp), f2 = planck_tail(centr + absc, temp);
+        fv1[jtwm1] = f1; fv2[jtwm1] = f2;
+        resk += WGK[jtwm1] * (f1 + f2);
+        rabs += WGK[jtwm1] * (fabs(f1) + fabs(f2));
+    }
+    const double reskh = resk * 0.5;
+    double rasc = WGK[10] * fabs(fc - reskh);
+    for (int j = 0; j < 10; j++) rasc += WGK[j] * (fabs(fv1[j] - reskh) + fabs(fv2[j] - reskh));
+    double err = fabs((resk - resg) * hlgth);
+    const double result = resk * hlgth;
+    rabs *= dhlgth; rasc *= dhlgth;
+    if (rasc != 0 && err != 0) { const double s = pow(200 * err / rasc, 1.5); err = (s < 1) ? rasc * s : rasc; }
+    if (rabs > 2.2250738585072014e-308 / (50 * 2.220446049250313e-16)) { const double m = 50 * 2.220446049250313e-16 * rabs; if (m > err) err = m; }
+    const double tol = fmax(0.0, 1e-2 * fabs(result));
+    converged = !(err <= 100 * 2.220446049250313e-16 * rabs && err > tol) && ((err <= tol && err != rasc) || err == 0.0);
+    return result;
+}
+
+// mc_cyclosynch.c:1244-1296, one weight: the Poisson count of every cell of the shell; flags[0] counts cells whose integral
+// would have needed more than QAGS' first rule (the oracle then bisects; the device keeps the first rule's value)
+__global__ __launch_bounds__(256) void cs_emit_count_kernel(CsEmitParams p, HydroDev hy, HydroCols h, double weight, unsigned long long attempt, RngKey key,
+                                                            unsigned *__restrict__ count, unsigned long long *__restrict__ total, unsigned *__restrict__ flags)
+{
+    __shared__ unsigned long long s_sum[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long mine = 0;
+    if (i < hy.M) {
+        const CellRec c = load_cell(hy, p.dimensions, i);
+        unsigned n = 0;
+        if (in_emission_slab(p, c)) {
+            if (attempt == 0) atomicAdd(flags + 1, 1u);
+            const double nu_c = cs_nu_c(p, hy, h, i);
+            bool converged;
+            double ph_dens_calc = qk21_planck(10, nu_c, hy.temp[i], converged);
+            if (!converged) atomicAdd(flags, 1u);
+            ph_dens_calc *= element_volume(p.dimensions, p.geometry, c) / weight;                    // :1277
+            EventStream rng = keyed_stream(key, attempt, (uint32_t)i, RNG_CS_COUNT);
+            const long long k = poisson(rng, ph_dens_calc);
+            n = (unsigned)(k < 0 ? 0 : (k > 0x7fffffffll ? 0x7fffffffll : k));
+        }
+        count[i] = n;
+        mine = n;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+
+// mc_cyclosynch.c:1340-1455: pool photon k, at the centre of its cell with the cell's cyclotron frequency, into null slot null_slots[k]
+__global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, HydroDev hy, HydroCols h, double weight, RngKey key,
+                                                               const int *__restrict__ start, int n_emit, const int *__restrict__ null_slots, PhotonDev ph)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_emit) return;
+    int lo = 0, hi = hy.M;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= k) lo = mid; else hi = mid;
+    }
+    const int i = lo;
+    const CellRec c = load_cell(hy, p.dimensions, i);
+    const double fr_dum = cs_nu_c(p, hy, h, i);
+    EventStream rng = keyed_stream(key, 0ull, (uint32_t)k, RNG_CS_PHOTON);
+    double position_phi = 0;
+    if (p.dimensions != DIM_THREE) position_phi = rng.uniform() * 2 * M_PI;
+    const double com_v_phi = rng.uniform() * 2 * M_PI;
+    const double com_v_theta = rng.uniform() * M_PI;                           // uniform in the angle, as the reference has it (:1388)
+    double p_comv[4];
+    p_comv[0] = PL_CONST * fr_dum / C_LIGHT;
+    p_comv[1] = (PL_CONST * fr_dum / C_LIGHT) * sin(com_v_theta) * cos(com_v_phi);
+    p_comv[2] = (PL_CONST * fr_dum / C_LIGHT) * sin(com_v_theta) * sin(com_v_phi);
+    p_comv[3] = (PL_CONST * fr_dum / C_LIGHT) * cos(com_v_theta);
+    const CellFluid f = hy.fluid[i];
+    const double fcv = hy.fluid_c ? hy.fluid_c[i] : 0.0;
+    const double cphi = cos(position_phi), sphi = sin(position_phi);
+    double boost[3];
+    if (p.dimensions == DIM_TWO) phys::beta_from_record<DIM_TWO>(f.a, f.b, fcv, cphi, sphi, boost);
+    else if (p.dimensions == DIM_TWO_POINT_FIVE) phys::beta_from_record<DIM_TWO_POINT_FIVE>(f.a, f.b, fcv, cphi, sphi, boost);
+    else phys::beta_from_record<DIM_THREE>(f.a, f.b, fcv, cphi, sphi, boost);
+    boost[0] *= -1; boost[1] *= -1; boost[2] *= -1;
+    double l_boost[4];
+    phys::lorentz_boost(boost, p_comv, l_boost, true);
+    double xyz[3];
+    if (p.dimensions == DIM_THREE) hydro_to_mcrat(p.dimensions, p.geometry, c.c0, c.c1, c.c2, xyz);
+    else hydro_to_mcrat(p.dimensions, p.geometry, c.c0, c.c1, position_phi, xyz);
+    const int s = null_slots[k];
+    ph.r0[s] = xyz[0]; ph.r1[s] = xyz[1]; ph.r2[s] = xyz[2];
+    ph.p0[s] = l_boost[0]; ph.p1[s] = l_boost[1]; ph.p2[s] = l_boost[2]; ph.p3[s] = l_boost[3];
+    ph.c0[s] = p_comv[0]; ph.c1[s] = p_comv[1]; ph.c2[s] = p_comv[2]; ph.c3[s] = p_comv[3];
+    ph.s0[s] = 1; ph.s1[s] = 0; ph.s2[s] = 0; ph.s3[s] = 0;
+    ph.num_scatt[s] = 0;
+    ph.weight[s] = weight;
+    ph.tau[s] = 0; ph.tts[s] = 0; ph.tau_next[s] = 0;
+    double u0 = 0, u1 = 0, u2 = 0;
+    if (l_boost[0] != 0) {
+        const double d = 1.0 / l_boost[0];
+        u0 = l_boost[1] * d * C_LIGHT; u1 = l_boost[2] * d * C_LIGHT; u2 = l_boost[3] * d * C_LIGHT;
+    }
+    ph.u0[s] = u0; ph.u1[s] = u1; ph.u2[s] = u2;
+    ph.ntau[s] = -INFINITY;
+    ph.idx[s] = 0;                                                              // nearest_block_index = 0 (:1436)
+    ph.flags[s] = (unsigned char)(FLAG_VALID | FLAG_RECALC);                    // a pool photon does not move (mclib.c:1070)
+    ph.type[s] = 'p';
+}
+
+// the null slots of the list, ascending (photons.c:181-189)
+constexpr int NULL_CHUNKS = 8;
+__global__ __launch_bounds__(256) void null_count_kernel(PhotonDev ph, unsigned *__restrict__ block_count, unsigned long long *__restrict__ total)
+{
+    __shared__ unsigned s_w[NULL_CHUNKS][4];
+    const int chunks = (ph.n + 255) / 256;
+    for (int c = 0; c < NULL_CHUNKS; ++c) {
+        const int i = (blockIdx.x * NULL_CHUNKS + c) * 256 + threadIdx.x;
+        const bool is_null = i < ph.n && ph.type[i] == 'N';
+        const unsigned long long m = __ballot(is_null);
+        if ((threadIdx.x & 63) == 0) s_w[c][threadIdx.x >> 6] = (unsigned)__popcll(m);
+    }
+    __syncthreads();
+    unsigned cnt = 0;
+    if (threadIdx.x < NULL_CHUNKS) {
+        const int chunk = blockIdx.x * NULL_CHUNKS + threadIdx.x;
+        cnt = s_w[threadIdx.x][0] + s_w[threadIdx.x][1] + s_w[threadIdx.x][2] + s_w[threadIdx.x][3];
+        if (chunk < chunks) block_count[chunk] = cnt;
+    }
+    for (int off = NULL_CHUNKS / 2; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if (threadIdx.x == 0 && cnt) atomicAdd(total, (unsigned long long)cnt);
+}
+
+__global__ __launch_bounds__(256) void null_write_kernel(PhotonDev ph, const int *__restrict__ block_start, int *__restrict__ null_slots)
+{
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool is_null = i < ph.n && ph.type[i] == 'N';
+    const unsigned long long m = __ballot(is_null);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (!is_null) return;
+    unsigned pos = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) pos += s_w[w];
+    null_slots[block_start[blockIdx.x] + pos] = i;
+}
+
+// setNullPhoton (photons.c:210-250) on fresh slots
+__global__ __launch_bounds__(256) void null_fill_kernel(PhotonDev ph, int first, int count)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const int i = first + k;
+    ph.type[i] = 'N';
+    ph.idx[i] = -1;
+    ph.flags[i] = (unsigned char)FLAG_VALID;
+    ph.ntau[i] = -INFINITY;            // -1 / total_optical_depth with 0; every other column is zero already
+}
+
 }  // namespace
+
+hipError_t launch_cs_emit_count(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, unsigned long long attempt,
+                                RngKey key, unsigned *count, unsigned long long *d_total, unsigned *d_flags, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    cs_emit_count_kernel<<<dim3((hy.M + 255) / 256), dim3(256), 0, stream>>>(p, hy, h, ph_weight_adjusted, attempt, key, count, d_total, d_flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_cs_emit_generate(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, RngKey key, const int *start,
+                                   int n_emit, const int *null_slots, const PhotonDev &ph, hipStream_t stream)
+{
+    if (n_emit <= 0) return hipSuccess;
+    cs_emit_generate_kernel<<<dim3((n_emit + 255) / 256), dim3(256), 0, stream>>>(p, hy, h, ph_weight_adjusted, key, start, n_emit, null_slots, ph);
+    return hipGetLastError();
+}
+
+hipError_t launch_null_count(const PhotonDev &ph, unsigned *block_count, unsigned long long *d_total, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    const int chunks = (ph.n + 255) / 256;
+    null_count_kernel<<<dim3((chunks + NULL_CHUNKS - 1) / NULL_CHUNKS), dim3(256), 0, stream>>>(ph, block_count, d_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_null_write(const PhotonDev &ph, const int *block_start, int *null_slots, hipStream_t stream)
+{
+    null_write_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(ph, block_start, null_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_null_fill(const PhotonDev &ph, int first, int count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    null_fill_kernel<<<dim3((count + 255) / 256), dim3(256), 0, stream>>>(ph, first, count);
+    return hipGetLastError();
+}
 
 hipError_t launch_inject_count(const InjectParams &p, const HydroDev &hy, double ph_weight_adjusted, unsigned long long attempt, RngKey key,
                                unsigned *count, unsigned long long *d_total, hipStream_t stream)

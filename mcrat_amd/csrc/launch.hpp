@@ -161,6 +161,21 @@ struct HotTableParams {
     unsigned long long seed;
 };
 hipError_t launch_hot_table(const HotTableParams &p, double *table, hipStream_t stream);
+// photonEmitCyclosynch, inject_single_switch == 0, on the device (inject.hip; mc_cyclosynch.c:1200-1460)
+struct CsEmitParams {
+    int dimensions, geometry, b_field_calc;
+    double epsilon_b;
+    double rmin, rmax, theta_min, theta_max;        // the shell of :1203-1204 and the thread's angle range
+};
+hipError_t launch_cs_emit_count(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, unsigned long long attempt,
+                                RngKey key, unsigned *count, unsigned long long *d_total, unsigned *d_flags, hipStream_t stream);
+hipError_t launch_cs_emit_generate(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, RngKey key, const int *start,
+                                   int n_emit, const int *null_slots, const PhotonDev &ph, hipStream_t stream);
+// the list's null slots in ascending order (addToPhotonList's null_ph_indexes, photons.c:181-189): count per 256 slots, then write
+hipError_t launch_null_count(const PhotonDev &ph, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
+hipError_t launch_null_write(const PhotonDev &ph, const int *block_start, int *null_slots, hipStream_t stream);
+// slots [first, first + count) become null photons (reallocatePhotonListMemory, photons.c:72-78)
+hipError_t launch_null_fill(const PhotonDev &ph, int first, int count, hipStream_t stream);
 hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
                       unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
                       long long total, hipStream_t stream);

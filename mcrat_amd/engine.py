@@ -164,6 +164,9 @@ SYMBOLS = {
     "mcrat_hip_ingest_pluto": (C.c_int, [_ctx, C.POINTER(PlutoGrid), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_ingest_chombo": (C.c_int, [_ctx, C.POINTER(Chombo), C.POINTER(Slab), C.POINTER(Outflow), C.POINTER(IngestResult)]),
     "mcrat_hip_set_hydro_extras": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
+    "mcrat_hip_emit_cyclosynch_pool": (C.c_int, [_ctx, C.POINTER(Cyclosynch), C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
+                                                 C.c_uint64, _ip, _dp, _ip]),
+    "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_absorb_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), _ip, _ip, _dp]),
     "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
     "mcrat_hip_get_output": (C.c_int, [_ctx, C.POINTER(OutputColumns)]),
@@ -362,6 +365,17 @@ class Engine:
     def set_hydro_extras(self, dens=None, B0=None, B1=None, B2=None):
         keep = [None if a is None else _f8(a) for a in (dens, B0, B1, B2)]
         self._check(self.lib.mcrat_hip_set_hydro_extras(self.ctx, *[None if a is None else a.ctypes.data_as(_dp) for a in keep]), "set_hydro_extras")
+
+    def emit_cyclosynch_pool(self, r_inj, ph_weight, maximum_photons, theta_min, theta_max, fps, seed, b_field_calc=1, epsilon_b=0.5,
+                             rebin_e_perc=0.1, scatt_frame_number=0, inj_frame_number=0):
+        """photonEmitCyclosynch, inject_single_switch = 0 (mc_cyclosynch.c:1200-1460) -> (photons emitted, adjusted weight, integrals not converged)"""
+        cs = Cyclosynch(int(b_field_calc), float(epsilon_b), float(rebin_e_perc), 0.5, 10.0, int(scatt_frame_number), int(inj_frame_number))
+        n, w, bad = C.c_int(), C.c_double(), C.c_int()
+        self._check(self.lib.mcrat_hip_emit_cyclosynch_pool(self.ctx, C.byref(cs), float(r_inj), float(ph_weight), int(maximum_photons), float(theta_min),
+                                                            float(theta_max), float(fps), int(seed), C.byref(n), C.byref(w), C.byref(bad)),
+                    "emit_cyclosynch_pool")
+        self.n = int(self.lib.mcrat_hip_num_photon_slots(self.ctx))          # the list doubles when the pool does not fit
+        return n.value, w.value, bad.value
 
     def absorb_cyclosynch(self, b_field_calc=1, epsilon_b=0.5):
         """phAbsCyclosynch (mc_cyclosynch.c:1571-1623) -> (num_abs_ph, scatt_cyclosynch_num_ph, absorbed weight)"""

@@ -71,3 +71,68 @@ def test_absorption_matches_the_oracle(hip, oracle, b_field_calc, dims):
     for f in ("type", "weight", "nearest_block_index", "recalc_properties", "p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3",
               "r0", "r1", "r2", "s0", "s1", "s2", "s3", "num_scatt", "total_optical_depth"):
         assert np.array_equal(got[f], want[f], equal_nan=got[f].dtype.kind == "f"), f
+
+
+def _oracle_pool(oracle, frame, cfg, aos, null_slots, dens, b_field_calc, seed, maximum_photons, frames=(200, 200)):
+    """-> (photons emitted, weight, fallback flag, the list before the emission, the list after it)"""
+    L = oracle.lib()
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    H = oracle.OracleHydro(frame)
+    cs = oracle.CS(b_field_calc, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, frames[0], frames[1], 0.5, 10.0)
+    l = oracle.PhotonList()
+    L.orc_list_init(C.byref(l))
+    a = aos.copy()
+    assert L.orc_list_set(C.byref(l), a.ctypes.data, len(a)) == 0
+    for i in null_slots:
+        assert L.orc_list_set_null(C.byref(l), int(i)) == 0
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    before = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), seed, 0)
+    w, fb = C.c_double(), C.c_int()
+    n = L.orc_photonEmitCyclosynch(C.byref(c), C.byref(cs), C.byref(l), 1e12, 1e40, maximum_photons, 0.0, 0.05, C.byref(H.c), C.byref(rng), 0, 0,
+                                   C.byref(w), C.byref(fb))
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    out = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    L.orc_list_free(C.byref(l))
+    return n, w.value, fb.value, before, out
+
+
+@pytest.mark.parametrize("case", ["null-slots", "full-list-doubles", "no-cell-in-shell"])
+def test_pool_emission_matches_the_oracle(hip, oracle, case):
+    """mcrat_hip_emit_cyclosynch_pool against orc_photonEmitCyclosynch (inject_single_switch = 0): the same number of pool photons, the
+    same adjusted weight, in the same slots; directions and positions to 1e-11 (the device boosts with the staged cell records)"""
+    frame, ph, cfg = synth.config2(n_photons=600, nzc=8, stokes=1, lumi=1e53)
+    dens = np.ascontiguousarray(frame["dens"])
+    aos = synth.photons_to_aos(ph, hip.PHOTON_DTYPE)
+    nulls = range(1, 600, 2) if case != "full-list-doubles" else ()
+    frames = (100000, 200) if case == "no-cell-in-shell" else (200, 200)
+    maximum = 1500 if case != "full-list-doubles" else 9000       # no null slot: the list doubles (photons.c:112-121)
+    n_ref, w_ref, fb_ref, aos, want = _oracle_pool(oracle, frame, cfg, aos, nulls, dens, 1, 77, maximum, frames)
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    e.set_hydro(frame)
+    e.set_hydro_extras(dens)
+    e.set_photons_aos(aos)
+    n, w, bad = e.emit_cyclosynch_pool(1e12, 1e40, maximum, 0.0, 0.05, frame["fps"], 77, b_field_calc=1, scatt_frame_number=frames[0], inj_frame_number=frames[1])
+    assert (n, w, bad) == (n_ref, w_ref, 0) and fb_ref == 0
+    assert e.n == len(want)
+    got = e.get_photons_aos()
+    e.close()
+    if case == "no-cell-in-shell":
+        assert n == 0
+    elif case == "full-list-doubles":
+        assert len(got) == 1200 and n > 0
+    else:
+        assert 1 <= n <= 150
+    assert np.array_equal(got["type"], want["type"]) and np.array_equal(got["weight"], want["weight"])
+    assert np.array_equal(got["nearest_block_index"], want["nearest_block_index"]) and np.array_equal(got["recalc_properties"], want["recalc_properties"])
+    pool = got["type"] == b"p"
+    assert pool.sum() == n
+    for f in ("comv_p0",):
+        assert np.allclose(got[f][pool], want[f][pool], rtol=1e-14)
+    for f in ("p0", "p1", "p2", "p3", "comv_p1", "comv_p2", "comv_p3", "r0", "r1", "r2"):
+        scale = np.abs(want["p0"][pool]) if f.startswith("p") else (np.abs(want["comv_p0"][pool]) if f.startswith("comv") else 1e12)
+        assert np.all(np.abs(got[f][pool] - want[f][pool]) <= 1e-11 * scale), f
+    rest = ~pool
+    for f in ("p0", "r0", "num_scatt", "s0"):
+        assert np.array_equal(got[f][rest], want[f][rest], equal_nan=True), f
