@@ -318,6 +318,14 @@ int mcrat_hip_set_hydro_extras(mcrat_hip_ctx *ctx, const double *dens, const dou
 int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, double r_inj, double ph_weight, int maximum_photons,
                                    double theta_min, double theta_max, double fps, uint64_t seed, int *num_emitted, double *ph_weight_adjusted,
                                    int *integrals_not_converged);
+/*   mcrat_hip_rebin_cyclosynch   rebinCyclosynchCompPhotons (mc_cyclosynch.c:246-712): every photon that is neither null, pool nor injected is
+ *                                replaced by one 'k' photon per non-empty (log10 energy, polar angle of the position[, azimuth]) bin with the
+ *                                bin's weight and weighted averages (bins filled in slot order, so the sums are the reference's sums);
+ *                                returns the number of empty bins in *empty_bins and the two counters the reference updates
+ *                                (:689-690).  MCRAT_HIP_EINVAL on the reference's error paths: nothing to rebin, more bins than
+ *                                max_photons, zero bins along an axis, a photon outside the histograms, too few null slots. */
+int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, int max_photons, int *empty_bins, int *num_cyclosynch_ph_emit,
+                               int *scatt_cyclosynch_num_ph);
 int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *ctx);   /* photon_list->list_capacity as the device holds it (it grows when the pool does not fit) */
 int mcrat_hip_absorb_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, int *num_abs_ph, int *scatt_cyclosynch_num_ph,
                                 double *abs_weight);

@@ -1400,6 +1400,106 @@ extern "C" int mcrat_hip_restore_photons(mcrat_hip_ctx *c)
     return MCRAT_HIP_OK;
 }
 
+extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, int max_photons, int *empty_bins_out,
+                                          int *num_cyclosynch_ph_emit, int *scatt_cyclosynch_num_ph)
+{
+    if (!c || !cs || max_photons <= 0) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    const int n = c->ph.n, three = c->kc.dimensions == DIM_THREE;
+    // collect_photon_statistics :273-322
+    const int rblk = rebin_range_blocks(n);
+    if ((rc = ensure_aos(c, sizeof(RebinRange) * (size_t)rblk))) return rc;
+    HIPCHK(c, launch_rebin_range(c->ph, three, static_cast<RebinRange *>(c->aos_buf), c->stream));
+    std::vector<RebinRange> part((size_t)rblk);
+    HIPCHK(c, hipMemcpyAsync(part.data(), c->aos_buf, sizeof(RebinRange) * (size_t)rblk, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    RebinRange q = part[0];
+    for (int k = 1; k < rblk; ++k) {
+        q.p0_min = std::fmin(q.p0_min, part[k].p0_min); q.p0_max = std::fmax(q.p0_max, part[k].p0_max);
+        q.theta_min = std::fmin(q.theta_min, part[k].theta_min); q.theta_max = std::fmax(q.theta_max, part[k].theta_max);
+        q.phi_min = std::fmin(q.phi_min, part[k].phi_min); q.phi_max = std::fmax(q.phi_max, part[k].phi_max);
+        q.valid += part[k].valid; q.synch += part[k].synch;
+    }
+    if (q.valid == 0) { c->last_error = "rebinning: no valid photons found for rebinning"; return MCRAT_HIP_EINVAL; }
+    const double log_p0_min = (q.p0_min > 0 && q.p0_max > 0) ? std::log10(q.p0_min) : 0.0, log_p0_max = (q.p0_min > 0 && q.p0_max > 0) ? std::log10(q.p0_max) : 1.0;
+    // calculate_binning_params :324-347, allocate_histograms :351-391
+    RebinAxes ax{};
+    ax.three = three;
+    ax.num_bins = (int)(cs->rebin_e_perc * max_photons);
+    ax.num_bins_theta = (int)std::ceil((q.theta_max - q.theta_min) / (cs->rebin_ang * (M_PI / 180.0)));
+    ax.num_bins_phi = three ? (int)std::ceil((q.phi_max - q.phi_min) / cs->rebin_ang_phi) : 1;
+    const long long total_ll = (long long)ax.num_bins_theta * ax.num_bins * (three ? ax.num_bins_phi : 1);
+    if (total_ll > max_photons) { c->last_error = "rebinning would create more photons than max_photons"; return MCRAT_HIP_EINVAL; }
+    if (ax.num_bins <= 0 || ax.num_bins_theta <= 0 || ax.num_bins_phi <= 0) { c->last_error = "rebinning: invalid histogram dimensions"; return MCRAT_HIP_EINVAL; }
+    ax.total_bins = (int)total_ll;
+    ax.e_lo = log_p0_min; ax.e_hi = log_p0_max + (log_p0_max - log_p0_min) * 1e-6;
+    ax.t_lo = q.theta_min; ax.t_hi = q.theta_max + (q.theta_max - q.theta_min) * 1e-6;
+    ax.p_lo = q.phi_min; ax.p_hi = q.phi_max + (q.phi_max - q.phi_min) * 1e-6;
+    // scratch: bin of every slot, per-bin counts / cursors / starts, the member lists, the records, the null-slot list
+    const int B = ax.total_bins;
+    const long long nblk = (n + 255) / 256;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_bin = take(sizeof(int) * (size_t)n), o_cnt = take(sizeof(unsigned) * (size_t)(B + 2)), o_cur = take(sizeof(unsigned) * (size_t)B);
+    const size_t o_start = take(sizeof(int) * ((size_t)B + 1 + grid_scan_scratch_ints(B))), o_mem = take(sizeof(int) * (size_t)n);
+    const size_t o_rec = take(sizeof(RebinRec) * (size_t)B);
+    const size_t o_nblk = take(sizeof(unsigned) * (size_t)(nblk + 8)), o_nstart = take(sizeof(int) * ((size_t)nblk + 1 + grid_scan_scratch_ints(nblk)));
+    const size_t o_null = take(sizeof(int) * (size_t)n);
+    if ((rc = ensure_aos(c, off))) return rc;
+    char *b = static_cast<char *>(c->aos_buf);
+    int *bin_of = reinterpret_cast<int *>(b + o_bin), *bin_start = reinterpret_cast<int *>(b + o_start), *members = reinterpret_cast<int *>(b + o_mem);
+    unsigned *bin_count = reinterpret_cast<unsigned *>(b + o_cnt), *cursor = reinterpret_cast<unsigned *>(b + o_cur);
+    unsigned *empty = bin_count + B;                              // [B]: empty bins, [B + 1]: photons outside the histograms
+    RebinRec *recs = reinterpret_cast<RebinRec *>(b + o_rec);
+    unsigned *null_cnt = reinterpret_cast<unsigned *>(b + o_nblk);
+    int *null_start = reinterpret_cast<int *>(b + o_nstart), *null_slots = reinterpret_cast<int *>(b + o_null);
+    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+    HIPCHK(c, launch_rebin_assign(c->ph, ax, bin_of, bin_count, c->stream));
+    HIPCHK(c, hipMemsetAsync(empty, 0, 2 * sizeof(unsigned), c->stream));
+    HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned) * (size_t)B, c->stream));
+    // how many photons take part (= the scan's total): eligible photons are all binned or the call fails
+    std::vector<unsigned> h_cnt((size_t)B);
+    HIPCHK(c, hipMemcpyAsync(h_cnt.data(), bin_count, sizeof(unsigned) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
+    std::vector<int> h_bin((size_t)n);
+    HIPCHK(c, hipMemcpyAsync(h_bin.data(), bin_of, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    long long members_total = 0;
+    for (unsigned v : h_cnt) members_total += v;
+    for (int v : h_bin)
+        if (v == -2) { c->last_error = "rebinning: a photon maps to an invalid bin index (the reference exits)"; return MCRAT_HIP_EINVAL; }
+    HIPCHK(c, launch_exclusive_scan(bin_count, B, bin_start, bin_start + B + 1, members_total, c->stream));
+    HIPCHK(c, launch_rebin_fill(c->ph, bin_of, bin_start, cursor, members, c->stream));
+    HIPCHK(c, launch_rebin_create(c->ph, ax, bin_start, members, recs, empty, c->stream));
+    HIPCHK(c, launch_rebin_nullify(c->ph, c->stream));                                            // :573-581
+    // addToPhotonList(rebin_ph, total_bins), photons.c:108-208
+    unsigned long long n_null = 0;
+    HIPCHK(c, launch_null_count(c->ph, null_cnt, c->d_grid_total, c->stream));
+    unsigned h_empty[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(&n_null, c->d_grid_total, sizeof n_null, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(h_empty, empty, sizeof h_empty, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((unsigned long long)B > n_null) {
+        c->last_error = "rebinning: fewer null slots than rebinned photons (the reference exits with \"Adding to the photon list has failed\")";
+        return MCRAT_HIP_EINVAL;
+    }
+    HIPCHK(c, launch_exclusive_scan(null_cnt, nblk, null_start, null_start + nblk + 1, (long long)n_null, c->stream));
+    HIPCHK(c, launch_null_write(c->ph, null_start, null_slots, c->stream));
+    HIPCHK(c, launch_rebin_place(c->ph, recs, B, null_slots, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const int null_count = (int)h_empty[0];
+    if ((long long)n - (long long)n_null + (B - null_count) < B) {                                // :676-681
+        c->last_error = "rebinning: fewer photons in the list than bins after the rebinning";
+        return MCRAT_HIP_EINVAL;
+    }
+    if (empty_bins_out) *empty_bins_out = null_count;
+    if (scatt_cyclosynch_num_ph) *scatt_cyclosynch_num_ph = B - null_count;                       // :689-690
+    if (num_cyclosynch_ph_emit) *num_cyclosynch_ph_emit = B + q.synch - null_count;
+    drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *c) { return (c && c->have_photons) ? c->ph.n : 0; }
 
 static int flush_pending(mcrat_hip_ctx *c)

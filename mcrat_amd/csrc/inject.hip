@@ -467,7 +467,251 @@ __global__ __launch_bounds__(256) void null_fill_kernel(PhotonDev ph, int first,
     ph.ntau[i] = -INFINITY;            // -1 / total_optical_depth with 0; every other column is zero already
 }
 
+// ---------------------------------------------------------------------------------------------- rebinCyclosynchCompPhotons
+__device__ __forceinline__ bool rebin_eligible(char type) { return type != 'N' && type != 'p' && type != 'i'; }   // :284,:453
+
+// calculate_photon_position :246-270
+__device__ __forceinline__ void rebin_position(const PhotonDev &ph, int i, int three, double &r, double &theta, double &phi)
+{
+    const double x = ph.r0[i], y = ph.r1[i], z = ph.r2[i];
+    r = sqrt(x * x + y * y + z * z);
+    phi = 0;
+    if (r < 2.2250738585072014e-308) { theta = 0.0; return; }
+    theta = acos(z / r);
+    if (three) phi = fmod(atan2(y, x) * (180.0 / M_PI) + 360.0, 360.0);
+}
+
+__global__ __launch_bounds__(256) void rebin_range_kernel(PhotonDev ph, int three, RebinRange *__restrict__ partials)
+{
+    __shared__ RebinRange s_p[4];
+    RebinRange q;
+    q.p0_min = 1.7976931348623157e308; q.p0_max = 0; q.theta_min = 1.7976931348623157e308; q.theta_max = 0;
+    q.phi_min = 1.7976931348623157e308; q.phi_max = 0; q.valid = 0; q.synch = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ph.n; i += gridDim.x * 256) {
+        const char type = ph.type[i];
+        if (rebin_eligible(type)) {
+            const double p0 = ph.p0[i];
+            if (p0 > 0) { q.p0_min = fmin(q.p0_min, p0); q.p0_max = fmax(q.p0_max, p0); q.valid += 1; }
+            double r, theta, phi;
+            rebin_position(ph, i, three, r, theta, phi);
+            q.theta_min = fmin(q.theta_min, theta); q.theta_max = fmax(q.theta_max, theta);
+            if (three) { q.phi_min = fmin(q.phi_min, phi); q.phi_max = fmax(q.phi_max, phi); }
+        }
+        if (type == 'p') q.synch += 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        q.p0_min = fmin(q.p0_min, __shfl_xor(q.p0_min, off)); q.p0_max = fmax(q.p0_max, __shfl_xor(q.p0_max, off));
+        q.theta_min = fmin(q.theta_min, __shfl_xor(q.theta_min, off)); q.theta_max = fmax(q.theta_max, __shfl_xor(q.theta_max, off));
+        q.phi_min = fmin(q.phi_min, __shfl_xor(q.phi_min, off)); q.phi_max = fmax(q.phi_max, __shfl_xor(q.phi_max, off));
+        q.valid += __shfl_xor(q.valid, off); q.synch += __shfl_xor(q.synch, off);
+    }
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            const RebinRange &o = s_p[w];
+            q.p0_min = fmin(q.p0_min, o.p0_min); q.p0_max = fmax(q.p0_max, o.p0_max);
+            q.theta_min = fmin(q.theta_min, o.theta_min); q.theta_max = fmax(q.theta_max, o.theta_max);
+            q.phi_min = fmin(q.phi_min, o.phi_min); q.phi_max = fmax(q.phi_max, o.phi_max);
+            q.valid += o.valid; q.synch += o.synch;
+        }
+        partials[blockIdx.x] = q;
+    }
+}
+
+// gsl_histogram2d_set_ranges_uniform's edges and gsl_histogram2d_find (see oracle/oracle_cyclosynch.c)
+__device__ __forceinline__ double axis_edge(double lo, double hi, int n, int i)
+{
+    const double f1 = ((double)(n - i)) / (double)n, f2 = ((double)i) / (double)n;
+    return f1 * lo + f2 * hi;
+}
+__device__ __forceinline__ int axis_find(double lo, double hi, int n, double x)
+{
+    if (!(x >= axis_edge(lo, hi, n, 0)) || !(x < axis_edge(lo, hi, n, n))) return -1;
+    int a = 0, b = n;
+    while (b - a > 1) {
+        const int mid = (a + b) / 2;
+        if (x >= axis_edge(lo, hi, n, mid)) a = mid; else b = mid;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void rebin_assign_kernel(PhotonDev ph, RebinAxes ax, int *__restrict__ bin_of, unsigned *__restrict__ bin_count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ph.n) return;
+    int bin = -1;
+    if (rebin_eligible(ph.type[i])) {                                               // accumulate_bin_statistics :450-466
+        double r, theta, phi;
+        rebin_position(ph, i, ax.three, r, theta, phi);
+        const double le = log10(ph.p0[i]);
+        int idx_x = axis_find(ax.e_lo, ax.e_hi, ax.num_bins, le), idx_y = axis_find(ax.t_lo, ax.t_hi, ax.num_bins_theta, theta), idx_z = 0;
+        if (idx_x < 0 || idx_y < 0) { idx_x = 0; idx_y = 0; }                       // gsl_histogram2d_find: both untouched on a domain error
+        if (ax.three) {
+            const int pz = axis_find(ax.p_lo, ax.p_hi, ax.num_bins_phi, phi);
+            const int ex = axis_find(ax.e_lo, ax.e_hi, ax.num_bins, le), ty = axis_find(ax.t_lo, ax.t_hi, ax.num_bins_theta, theta);
+            if (ex >= 0 && pz >= 0) { idx_x = ex; idx_z = pz; }
+            if (ty >= 0 && pz >= 0) { idx_y = ty; idx_z = pz; }
+        }
+        if (idx_x < 0 || idx_x >= ax.num_bins || idx_y < 0 || idx_y >= ax.num_bins_theta || (ax.three && (idx_z < 0 || idx_z >= ax.num_bins_phi))) bin = -2;
+        else bin = ax.three ? idx_z * ax.num_bins * ax.num_bins_theta + idx_x * ax.num_bins_theta + idx_y : idx_x * ax.num_bins_theta + idx_y;
+        if (bin >= ax.total_bins) bin = -2;
+        if (bin >= 0) atomicAdd(bin_count + bin, 1u);
+    }
+    bin_of[i] = bin;
+}
+
+__global__ __launch_bounds__(256) void rebin_fill_kernel(PhotonDev ph, const int *__restrict__ bin_of, const int *__restrict__ bin_start,
+                                                         unsigned *__restrict__ cursor, int *__restrict__ members)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ph.n) return;
+    const int b = bin_of[i];
+    if (b >= 0) members[bin_start[b] + (int)atomicAdd(cursor + b, 1u)] = i;
+}
+
+// create_rebinned_photons :504-607, with accumulate_bin_statistics' sums (:467-497) formed in slot order as the reference forms them
+__global__ __launch_bounds__(256) void rebin_create_kernel(PhotonDev ph, RebinAxes ax, const int *__restrict__ bin_start, int *__restrict__ members,
+                                                           RebinRec *__restrict__ recs, unsigned *__restrict__ empty_bins)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= ax.total_bins) return;
+    const int m0 = bin_start[b], m = bin_start[b + 1] - m0;
+    for (int a = 1; a < m; ++a) {                       // the fill is unordered: sort the few members by slot
+        const int key = members[m0 + a];
+        int j = a - 1;
+        while (j >= 0 && members[m0 + j] > key) { members[m0 + j + 1] = members[m0 + j]; --j; }
+        members[m0 + j + 1] = key;
+    }
+    double w_r = 0, w_theta = 0, w_phi_offset = 0, w_s0 = 0, w_s1 = 0, w_s2 = 0, w_s3 = 0, w_scatt = 0, total_weight = 0;
+    double w_phi_dir = 0, w_theta_dir = 0, w_energy = 0, w_phi_pos = 0;
+    const double RAD_TO_DEG = 180.0 / M_PI, DEG_TO_RAD = M_PI / 180.0;
+    for (int k = 0; k < m; ++k) {
+        const int i = members[m0 + k];
+        double r, theta, phi;
+        rebin_position(ph, i, ax.three, r, theta, phi);
+        const double w = ph.weight[i], p0 = ph.p0[i], p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
+        w_r += r * w;
+        w_theta += theta * w;
+        w_phi_offset += (atan2(p2, p1) - atan2(ph.r1[i], ph.r0[i])) * RAD_TO_DEG * w;
+        w_s0 += ph.s0[i] * w; w_s1 += ph.s1[i] * w; w_s2 += ph.s2[i] * w; w_s3 += ph.s3[i] * w;
+        w_scatt += ph.num_scatt[i] * w;
+        total_weight += w;
+        const double phi_dir = fmod(atan2(p2, p1) * RAD_TO_DEG + 360.0, 360.0);
+        const double theta_dir = acos(p3 / p0) * RAD_TO_DEG;
+        w_phi_dir += phi_dir * w;
+        w_theta_dir += theta_dir * w;
+        w_energy += p0 * w;
+        if (ax.three) w_phi_pos += phi * w;
+    }
+    RebinRec o;
+    o.valid = 0; o.pad = 0;
+    o.weight = o.p0 = o.p1 = o.p2 = o.p3 = o.r0 = o.r1 = o.r2 = o.s0 = o.s1 = o.s2 = o.s3 = o.num_scatt = 0;
+    if (!(total_weight > 0)) { atomicAdd(empty_bins, 1u); recs[b] = o; return; }
+    const double avg_energy = w_energy / total_weight, avg_phi_dir = w_phi_dir / total_weight, avg_theta_dir = w_theta_dir / total_weight;
+    const double avg_r = w_r / total_weight, avg_theta_pos = w_theta / total_weight;
+    o.valid = 1;
+    o.weight = total_weight;
+    o.p0 = avg_energy;
+    o.p1 = avg_energy * sin(avg_theta_dir * DEG_TO_RAD) * cos(avg_phi_dir * DEG_TO_RAD);
+    o.p2 = avg_energy * sin(avg_theta_dir * DEG_TO_RAD) * sin(avg_phi_dir * DEG_TO_RAD);
+    o.p3 = avg_energy * cos(avg_theta_dir * DEG_TO_RAD);
+    double pos_phi;
+    if (ax.three) pos_phi = (w_phi_pos / total_weight) * DEG_TO_RAD;
+    else pos_phi = (avg_phi_dir - w_phi_offset / total_weight) * DEG_TO_RAD;
+    o.r0 = avg_r * sin(avg_theta_pos) * cos(pos_phi);
+    o.r1 = avg_r * sin(avg_theta_pos) * sin(pos_phi);
+    o.r2 = avg_r * cos(avg_theta_pos);
+    o.s0 = w_s0 / total_weight; o.s1 = w_s1 / total_weight; o.s2 = w_s2 / total_weight; o.s3 = w_s3 / total_weight;
+    o.num_scatt = (double)(int)(w_scatt / total_weight + 0.5);
+    recs[b] = o;
+}
+
+__global__ __launch_bounds__(256) void rebin_place_kernel(PhotonDev ph, const RebinRec *__restrict__ recs, int total_bins, const int *__restrict__ null_slots)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= total_bins) return;
+    const RebinRec o = recs[b];
+    if (!o.valid) return;                                // a null rebinned photon is not copied (photons.c:192)
+    const int s = null_slots[b];
+    ph.type[s] = 'k';
+    ph.weight[s] = o.weight;
+    ph.p0[s] = o.p0; ph.p1[s] = o.p1; ph.p2[s] = o.p2; ph.p3[s] = o.p3;
+    ph.c0[s] = 0; ph.c1[s] = 0; ph.c2[s] = 0; ph.c3[s] = 0;
+    ph.r0[s] = o.r0; ph.r1[s] = o.r1; ph.r2[s] = o.r2;
+    ph.s0[s] = o.s0; ph.s1[s] = o.s1; ph.s2[s] = o.s2; ph.s3[s] = o.s3;
+    ph.num_scatt[s] = o.num_scatt;
+    ph.idx[s] = 0;
+    ph.tau[s] = 0; ph.tau_next[s] = 0; ph.tts[s] = 0;    // calloc'ed in the reference
+    double u0 = 0, u1 = 0, u2 = 0;
+    if (o.p0 != 0) { const double d = 1.0 / o.p0; u0 = o.p1 * d * C_LIGHT; u1 = o.p2 * d * C_LIGHT; u2 = o.p3 * d * C_LIGHT; }
+    ph.u0[s] = u0; ph.u1[s] = u1; ph.u2[s] = u2;
+    ph.ntau[s] = -INFINITY;
+    ph.flags[s] = (unsigned char)(FLAG_VALID | FLAG_RECALC | (o.weight != 0 ? FLAG_MOVES : 0u));
+}
+
+__global__ __launch_bounds__(256) void rebin_nullify_kernel(PhotonDev ph)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ph.n) return;
+    const char type = ph.type[i];
+    if (type != 'c' && type != 'k') return;
+    ph.type[i] = 'N';
+    ph.weight[i] = 0;
+    ph.idx[i] = -1;
+    ph.flags[i] = (unsigned char)FLAG_VALID;
+    ph.p0[i] = 0; ph.p1[i] = 0; ph.p2[i] = 0; ph.p3[i] = 0;
+    ph.c0[i] = 0; ph.c1[i] = 0; ph.c2[i] = 0; ph.c3[i] = 0;
+    ph.r0[i] = 0; ph.r1[i] = 0; ph.r2[i] = 0;
+    ph.s0[i] = 0; ph.s1[i] = 0; ph.s2[i] = 0; ph.s3[i] = 0;
+    ph.num_scatt[i] = 0;
+    ph.tau[i] = 0; ph.tau_next[i] = 0;
+    ph.u0[i] = 0; ph.u1[i] = 0; ph.u2[i] = 0;
+    ph.ntau[i] = -INFINITY;
+}
+
 }  // namespace
+
+int rebin_range_blocks(int n) { const int b = (n + 255) / 256; return b < 1 ? 1 : (b > 512 ? 512 : b); }
+
+hipError_t launch_rebin_range(const PhotonDev &ph, int three, RebinRange *partials, hipStream_t stream)
+{
+    rebin_range_kernel<<<dim3(rebin_range_blocks(ph.n)), dim3(256), 0, stream>>>(ph, three, partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebin_assign(const PhotonDev &ph, const RebinAxes &ax, int *bin_of, unsigned *bin_count, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(bin_count, 0, sizeof(unsigned) * (size_t)ax.total_bins, stream);
+    if (e != hipSuccess) return e;
+    rebin_assign_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(ph, ax, bin_of, bin_count);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebin_fill(const PhotonDev &ph, const int *bin_of, const int *bin_start, unsigned *cursor, int *members, hipStream_t stream)
+{
+    rebin_fill_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(ph, bin_of, bin_start, cursor, members);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebin_create(const PhotonDev &ph, const RebinAxes &ax, const int *bin_start, int *members, RebinRec *recs,
+                               unsigned *empty_bins, hipStream_t stream)
+{
+    rebin_create_kernel<<<dim3((ax.total_bins + 255) / 256), dim3(256), 0, stream>>>(ph, ax, bin_start, members, recs, empty_bins);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebin_place(const PhotonDev &ph, const RebinRec *recs, int total_bins, const int *null_slots, hipStream_t stream)
+{
+    rebin_place_kernel<<<dim3((total_bins + 255) / 256), dim3(256), 0, stream>>>(ph, recs, total_bins, null_slots);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebin_nullify(const PhotonDev &ph, hipStream_t stream)
+{
+    rebin_nullify_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(ph);
+    return hipGetLastError();
+}
 
 hipError_t launch_cs_emit_count(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, unsigned long long attempt,
                                 RngKey key, unsigned *count, unsigned long long *d_total, unsigned *d_flags, hipStream_t stream)

@@ -176,6 +176,32 @@ hipError_t launch_null_count(const PhotonDev &ph, unsigned *block_count, unsigne
 hipError_t launch_null_write(const PhotonDev &ph, const int *block_start, int *null_slots, hipStream_t stream);
 // slots [first, first + count) become null photons (reallocatePhotonListMemory, photons.c:72-78)
 hipError_t launch_null_fill(const PhotonDev &ph, int first, int count, hipStream_t stream);
+// rebinCyclosynchCompPhotons on the device (inject.hip; mc_cyclosynch.c:246-712)
+struct RebinRange {            // collect_photon_statistics :273-322, one per workgroup, finished on the host
+    double p0_min, p0_max, theta_min, theta_max, phi_min, phi_max;
+    int valid, synch;
+};
+struct RebinAxes {             // the three uniform histograms' ranges (:360-391) and the bin counts (:324-347)
+    double e_lo, e_hi, t_lo, t_hi, p_lo, p_hi;
+    int num_bins, num_bins_theta, num_bins_phi, total_bins, three;
+};
+int rebin_range_blocks(int n);
+hipError_t launch_rebin_range(const PhotonDev &ph, int three, RebinRange *partials, hipStream_t stream);
+// bin of every slot (-1: not rebinned; -2: outside the histograms, the reference's exit(1)) and the number of slots per bin
+hipError_t launch_rebin_assign(const PhotonDev &ph, const RebinAxes &ax, int *bin_of, unsigned *bin_count, hipStream_t stream);
+// slots of each bin (bin_start from the scan of bin_count); then one thread per bin: the weighted sums in slot order and the
+// rebinned photon as a record (create_rebinned_photons :504-607)
+hipError_t launch_rebin_fill(const PhotonDev &ph, const int *bin_of, const int *bin_start, unsigned *cursor, int *members, hipStream_t stream);
+struct RebinRec {              // one rebinned photon (or an empty bin: valid == 0)
+    double weight, p0, p1, p2, p3, r0, r1, r2, s0, s1, s2, s3, num_scatt;
+    int valid, pad;
+};
+hipError_t launch_rebin_create(const PhotonDev &ph, const RebinAxes &ax, const int *bin_start, int *members, RebinRec *recs,
+                               unsigned *empty_bins, hipStream_t stream);
+// after the old photons are nullified: record b into the b-th null slot (addToPhotonList, photons.c:190-199)
+hipError_t launch_rebin_place(const PhotonDev &ph, const RebinRec *recs, int total_bins, const int *null_slots, hipStream_t stream);
+// setNullPhoton for every 'k' and 'c' photon (:573-581)
+hipError_t launch_rebin_nullify(const PhotonDev &ph, hipStream_t stream);
 hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
                       unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
                       long long total, hipStream_t stream);

@@ -166,6 +166,7 @@ SYMBOLS = {
     "mcrat_hip_set_hydro_extras": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
     "mcrat_hip_emit_cyclosynch_pool": (C.c_int, [_ctx, C.POINTER(Cyclosynch), C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
                                                  C.c_uint64, _ip, _dp, _ip]),
+    "mcrat_hip_rebin_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), C.c_int, _ip, _ip, _ip]),
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_absorb_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), _ip, _ip, _dp]),
     "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
@@ -376,6 +377,13 @@ class Engine:
                     "emit_cyclosynch_pool")
         self.n = int(self.lib.mcrat_hip_num_photon_slots(self.ctx))          # the list doubles when the pool does not fit
         return n.value, w.value, bad.value
+
+    def rebin_cyclosynch(self, max_photons, rebin_e_perc=0.1, rebin_ang=0.5, rebin_ang_phi=10.0):
+        """rebinCyclosynchCompPhotons (mc_cyclosynch.c:246-712) -> (empty bins, num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph)"""
+        cs = Cyclosynch(1, 0.5, float(rebin_e_perc), float(rebin_ang), float(rebin_ang_phi), 0, 0)
+        e, a, s = C.c_int(), C.c_int(), C.c_int()
+        self._check(self.lib.mcrat_hip_rebin_cyclosynch(self.ctx, C.byref(cs), int(max_photons), C.byref(e), C.byref(a), C.byref(s)), "rebin_cyclosynch")
+        return e.value, a.value, s.value
 
     def absorb_cyclosynch(self, b_field_calc=1, epsilon_b=0.5):
         """phAbsCyclosynch (mc_cyclosynch.c:1571-1623) -> (num_abs_ph, scatt_cyclosynch_num_ph, absorbed weight)"""

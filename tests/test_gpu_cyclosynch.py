@@ -136,3 +136,79 @@ def test_pool_emission_matches_the_oracle(hip, oracle, case):
     rest = ~pool
     for f in ("p0", "r0", "num_scatt", "s0"):
         assert np.array_equal(got[f][rest], want[f][rest], equal_nan=True), f
+
+
+def _rebin_input(dtype, n, seed, null_every=0):
+    rng = np.random.default_rng(seed)
+    aos = np.zeros(n, dtype=dtype)
+    kind = rng.choice([b"k", b"c", b"i", b"p"], size=n, p=[0.5, 0.3, 0.15, 0.05])
+    aos["type"] = kind
+    th_pos, phi_pos, r = rng.uniform(0.01, 0.04, n), rng.uniform(0, 2 * np.pi, n), rng.uniform(1.0e12, 1.1e12, n)
+    aos["r0"], aos["r1"], aos["r2"] = r * np.sin(th_pos) * np.cos(phi_pos), r * np.sin(th_pos) * np.sin(phi_pos), r * np.cos(th_pos)
+    e = 10 ** rng.uniform(-18, -15, n)
+    th_d, ph_d = rng.uniform(0.0, 0.05, n), phi_pos + rng.normal(0, 0.01, n)
+    aos["p0"], aos["p1"], aos["p2"], aos["p3"] = e, e * np.sin(th_d) * np.cos(ph_d), e * np.sin(th_d) * np.sin(ph_d), e * np.cos(th_d)
+    aos["s0"], aos["s1"], aos["s2"] = 1.0, rng.uniform(-0.3, 0.3, n), rng.uniform(-0.3, 0.3, n)
+    aos["weight"] = 10 ** rng.uniform(45, 47, n)
+    aos["num_scatt"] = rng.integers(1, 40, n)
+    aos["nearest_block_index"] = 5
+    return aos
+
+
+@pytest.mark.parametrize("dims,max_photons,e_perc,ang_phi", [("2d", 2000, 0.1, 10.0), ("3d", 5000, 0.01, 45.0)])
+def test_rebinning_matches_the_oracle(hip, oracle, dims, max_photons, e_perc, ang_phi):
+    """mcrat_hip_rebin_cyclosynch against orc_rebinCyclosynchCompPhotons (mc_cyclosynch.c:246-712): the same bins, the same empty-bin
+    count and counters, every rebinned photon in the same slot; the sums are formed in slot order on both sides so weights agree to the
+    last bit and the trigonometric fields to 1e-13"""
+    L = oracle.lib()
+    D = synth.TWO if dims == "2d" else synth.THREE
+    n = 3000
+    aos = _rebin_input(oracle.PHOTON_DTYPE, n, 4)
+    c = oracle.make_config(D, synth.CYLINDRICAL if dims == "2d" else synth.CARTESIAN, 1)
+    cs = oracle.CS(1, 0.5, e_perc, None, None, None, None, 200, 200, 0.5, ang_phi)
+    l = oracle.PhotonList()
+    L.orc_list_init(C.byref(l))
+    a = aos.copy()
+    assert L.orc_list_set(C.byref(l), a.ctypes.data, len(a)) == 0
+    for i in range(0, n, 7):                                    # some null slots to start with
+        assert L.orc_list_set_null(C.byref(l), int(i)) == 0
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    before = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    emit, scatt = C.c_int(), C.c_int()
+    nulls = L.orc_rebinCyclosynchCompPhotons(C.byref(c), C.byref(cs), C.byref(l), C.byref(emit), C.byref(scatt), max_photons)
+    assert nulls >= 0
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    want = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    L.orc_list_free(C.byref(l))
+
+    e = hip.Engine(D, synth.CYLINDRICAL if dims == "2d" else synth.CARTESIAN, 1)
+    e.set_photons_aos(before.astype(hip.PHOTON_DTYPE))
+    got_nulls, got_emit, got_scatt = e.rebin_cyclosynch(max_photons, e_perc, 0.5, ang_phi)
+    got = e.get_photons_aos()
+    e.close()
+    assert (got_nulls, got_emit, got_scatt) == (nulls, emit.value, scatt.value)
+    assert scatt.value > 100
+    assert np.array_equal(got["type"], want["type"])
+    for f in ("weight", "num_scatt", "nearest_block_index", "recalc_properties", "comv_p0", "comv_p1", "comv_p2", "comv_p3"):
+        assert np.array_equal(got[f], want[f]), f
+    k = want["type"] == b"k"
+    for f in ("p0", "p1", "p2", "p3", "r0", "r1", "r2", "s0", "s1", "s2", "s3"):
+        scale = np.abs(want["p0"]) if f.startswith("p") else (1e12 if f.startswith("r") else 1.0)
+        assert np.all(np.abs(got[f] - want[f]) <= 1e-13 * scale), (f, np.max(np.abs(got[f] - want[f]) / scale))
+        assert np.array_equal(got[f][~k], want[f][~k]), f
+
+
+def test_rebinning_refusals(hip, oracle):
+    """the reference's error paths: more bins than max_photons (:649-654), nothing to rebin (:640-645)"""
+    aos = _rebin_input(hip.PHOTON_DTYPE, 500, 9)
+    e = hip.Engine(synth.TWO, synth.CYLINDRICAL, 1)
+    e.set_photons_aos(aos)
+    with pytest.raises(hip.McratHipError):
+        e.rebin_cyclosynch(10, 0.5, 0.01, 10.0)                 # 5 energy bins x hundreds of angle bins > 10
+    only = aos.copy()
+    only["type"] = b"i"
+    e.set_photons_aos(only)
+    with pytest.raises(hip.McratHipError):
+        e.rebin_cyclosynch(2000)
+    assert np.array_equal(e.get_photons_aos()["p0"], only["p0"])
+    e.close()
