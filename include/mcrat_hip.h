@@ -66,7 +66,7 @@ typedef struct mcrat_hip_config {
     int geometry;                /* GEOMETRY                                                  */
     int stokes_switch;           /* STOKES_SWITCH   (0/1)                                     */
     int tau_calculation;         /* TAU_CALCULATION: MCRAT_HIP_TAU_DIRECT or MCRAT_HIP_TAU_TABLE */
-    int cyclosynchrotron_switch; /* CYCLOSYNCHROTRON_SWITCH (only 0)                          */
+    int cyclosynchrotron_switch; /* CYCLOSYNCHROTRON_SWITCH; 1 needs virtual_rank_photons = 0  */
     int device;                  /* HIP device ordinal                                        */
     void *stream;                /* hipStream_t to launch on, or NULL for a private stream    */
     uint32_t rng_stream;         /* virtual-rank id mixed into every RNG counter (rank id)    */
@@ -326,6 +326,26 @@ int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosync
  *                                max_photons, zero bins along an axis, a photon outside the histograms, too few null slots. */
 int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, int max_photons, int *empty_bins, int *num_cyclosynch_ph_emit,
                                int *scatt_cyclosynch_num_ph);
+/*   mcrat_hip_scatter_frame_cyclosynch   the scatter-frame body of main() with CYCLOSYNCHROTRON_SWITCH on (mcrat.c:706-878, from the pool emission
+ *                                to the absorption; the hydro frame is staged and the extras set): emit_pool is the condition
+ *                                `(scatt_frame != scatt_framestart) || (restrt == CONTINUE)` of :707,:727,:855; inside the loop a pool
+ *                                photon that photonEvent reports becomes a comptonised one and is replaced by a new pool photon of its
+ *                                weight in its cell (:786-795; photonEmitCyclosynch with inject_single_switch = 1, the list doubling
+ *                                when it has no null slot), and every 1000 scatterings the comptonised photons are rebinned once there
+ *                                are more than max_photons of them (:797-808).  Needs a context created with
+ *                                cyclosynchrotron_switch = 1 (one list per context: no virtual ranks, no shared clock; mcrat_hip_run
+ *                                and mcrat_hip_propagate_frame refuse such a context).  max_iterations <= 0: until the frame is over. */
+typedef struct mcrat_hip_cyclosynch_counts {
+    int    num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph, frame_abs_cnt;   /* the counters of mcrat.c:735-878 */
+    int    rebins;                        /* successful rebinCyclosynchCompPhotons calls */
+    int    integrals_not_converged;       /* see mcrat_hip_emit_cyclosynch_pool */
+    int    pad;
+    double n_comptonized;                 /* mcrat.c:788,871 */
+    double pool_weight;                   /* ph_weight_adjusted of the pool emission */
+} mcrat_hip_cyclosynch_counts;
+int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, double *time_now, double remaining_time, uint64_t seed,
+                                       double r_inj, double ph_weight_suggest, int max_photons, double theta_min, double theta_max, double fps,
+                                       int emit_pool, long long max_iterations, mcrat_hip_frame_stats *stats, mcrat_hip_cyclosynch_counts *counts);
 int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *ctx);   /* photon_list->list_capacity as the device holds it (it grows when the pool does not fit) */
 int mcrat_hip_absorb_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, int *num_abs_ph, int *scatt_cyclosynch_num_ph,
                                 double *abs_weight);

@@ -159,7 +159,7 @@ struct alignas(256) LoopState {
     double t_cut;                        // free times below this go on the shortlist (speed only, never results)
     double t_est;                        // running estimate of the smallest free time per iteration
     int force_relocate;                  // virtual-rank mode: the next pass is the forced re-location pass of a new frame
-    int pad0;
+    int photon_event_called;             // this pass took the photonEvent branch of mcrat.c:777 (the cyclo-synchrotron hook of :786 looks at it)
     long long stamps[8];                 // diagnostic build only (-DMCRAT_DIAG): s_memtime at points of the event walk
 };
 

@@ -57,6 +57,7 @@ struct mcrat_hip_ctx {
     unsigned *grid_count = nullptr;    // per-bucket counters of the device build
     size_t grid_count_cap = 0;
     unsigned long long *d_grid_total = nullptr;
+    void *d_cs_hook = nullptr;                 // CsHook of the cyclo-synchrotron frame driver
     HydroCols hcol{};                  // the frame as struct hydro_dataframe's columns (set_hydro / ingest), kept for get_hydro
     void *hcol_buf = nullptr;
     size_t hcol_bytes = 0;
@@ -160,8 +161,10 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
     if (cfg->abi_version != MCRAT_HIP_ABI_VERSION) return MCRAT_HIP_EINVAL;
     if (!geometry_supported(cfg->dimensions, cfg->geometry)) return MCRAT_HIP_EINVAL;
     if (cfg->tau_calculation != MCRAT_HIP_TAU_DIRECT && cfg->tau_calculation != MCRAT_HIP_TAU_TABLE) return MCRAT_HIP_EINVAL;
-    if (cfg->cyclosynchrotron_switch != 0) return MCRAT_HIP_EINVAL;
     if (cfg->virtual_rank_photons < 0) return MCRAT_HIP_EINVAL;
+    // with the switch on the list changes length inside the loop; one list per context, driven by
+    // mcrat_hip_scatter_frame_cyclosynch
+    if (cfg->cyclosynchrotron_switch != 0 && (cfg->cyclosynchrotron_switch != 1 || cfg->virtual_rank_photons != 0)) return MCRAT_HIP_EINVAL;
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device < 0 || cfg->device >= ndev) return MCRAT_HIP_ENODEV;
@@ -214,6 +217,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->raw_buf) (void)hipFree(c->raw_buf);
     if (c->grid_count) (void)hipFree(c->grid_count);
     if (c->d_grid_total) (void)hipFree(c->d_grid_total);
+    if (c->d_cs_hook) (void)hipFree(c->d_cs_hook);
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
     if (c->d_hot_table) (void)hipFree(c->d_hot_table);
@@ -1848,6 +1852,10 @@ extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_h
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->frame_open) return MCRAT_HIP_ESTATE;
     if (c->sc_world > 0) { c->last_error = "shared clock attached: drive the frame with mcrat_hip_shared_clock_*"; return MCRAT_HIP_ESTATE; }
+    if (c->cfg.cyclosynchrotron_switch) {
+        c->last_error = "CYCLOSYNCHROTRON_SWITCH is on: drive the frame with mcrat_hip_scatter_frame_cyclosynch (the loop has the hook of mcrat.c:786-808)";
+        return MCRAT_HIP_ESTATE;
+    }
     if (c->n_ranks > 0) return run_ranks(c, max_iterations, stats);
     const int per_sync = c->cfg.iterations_per_sync;
     long long it = 0;
@@ -1915,6 +1923,87 @@ extern "C" int mcrat_hip_propagate_frame(mcrat_hip_ctx *c, double *time_now, dou
     if (rc) return rc;
     *time_now = local.time_now;
     if (stats) *stats = local;
+    return MCRAT_HIP_OK;
+}
+
+// The scatter-frame body of main() with CYCLOSYNCHROTRON_SWITCH on (mcrat.c:706-878, between getHydroData and saveCheckpoint): pool
+// emission, the loop with the replacement of scattered pool photons (:786-795) and the rebinning trigger (:797-808), the rebinning
+// and absorption at the end of the frame (:853-878).  The hook needs the list current after every pass, so a pass here is
+// step + event + flush + cs_replace and the host reads the pass's outcome back (list growth and the rebinning are host-driven);
+// a device-resident hook is DESIGN.md section 8's next step for this row.
+extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, double *time_now, double remaining_time, uint64_t seed,
+                                                  double r_inj, double ph_weight_suggest, int max_photons, double theta_min, double theta_max, double fps,
+                                                  int emit_pool, long long max_iterations, mcrat_hip_frame_stats *stats, mcrat_hip_cyclosynch_counts *cnt)
+{
+    if (!c || !cs || !time_now || !cnt || cs->b_field_calc < 0 || cs->b_field_calc > 2 || max_photons <= 0) return MCRAT_HIP_EINVAL;
+    if (!c->cfg.cyclosynchrotron_switch) { c->last_error = "the context was created with cyclosynchrotron_switch = 0"; return MCRAT_HIP_ESTATE; }
+    if (c->n_ranks > 0 || c->sc_world > 0) return MCRAT_HIP_ESTATE;
+    if (!c->have_hydro || !c->hcol_buf || !c->have_photons) return MCRAT_HIP_ESTATE;
+    memset(cnt, 0, sizeof *cnt);
+    int rc;
+    if (emit_pool) {                                                                              // :727-744
+        int n = 0, bad = 0;
+        double w = 0;
+        if ((rc = mcrat_hip_emit_cyclosynch_pool(c, cs, r_inj, ph_weight_suggest, max_photons, theta_min, theta_max, fps, seed, &n, &w, &bad))) return rc;
+        cnt->num_cyclosynch_ph_emit = n;
+        cnt->pool_weight = w;
+        cnt->integrals_not_converged = bad;
+    }
+    if ((rc = mcrat_hip_begin_frame(c, seed, *time_now, remaining_time))) return rc;
+    CsEmitParams p{};
+    p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry; p.b_field_calc = cs->b_field_calc; p.epsilon_b = cs->epsilon_b;
+    if (!c->d_cs_hook) HIPCHK(c, hipMalloc((void **)&c->d_cs_hook, sizeof(CsHook)));
+    CsHook hook;
+    long long it = 0;
+    while (!c->h_state->done && (max_iterations <= 0 || it < max_iterations)) {                  // :761-851
+        HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+        c->find_switch = 0;
+        HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+        HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
+        HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, static_cast<CsHook *>(c->d_cs_hook), c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&hook, c->d_cs_hook, sizeof hook, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (hook.need_grow) {                                                                     // photons.c:112-121: the list doubles
+            if (c->ph.n > 0x3fffffff) { c->last_error = "photon list too long to double"; return MCRAT_HIP_ENOMEM; }
+            if ((rc = grow_photons(c, 2 * c->ph.n))) return rc;
+            HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, static_cast<CsHook *>(c->d_cs_hook), c->stream));
+            HIPCHK(c, hipMemcpyAsync(&hook, c->d_cs_hook, sizeof hook, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!hook.fired) { c->last_error = "the replacement of a scattered pool photon failed after the list was doubled"; return MCRAT_HIP_ENOMEM; }
+        }
+        if (hook.fired) {                                                                         // :788-794
+            cnt->n_comptonized += hook.weight;
+            cnt->num_cyclosynch_ph_emit += 1;
+            cnt->scatt_cyclosynch_num_ph += 1;
+        }
+        const LoopState &h = *c->h_state;
+        if (h.photon_event_called && (h.frame_scatt_cnt % 1000 == 0) && h.frame_scatt_cnt != 0 && cnt->scatt_cyclosynch_num_ph > max_photons) {   // :797-808
+            int empty = 0;
+            rc = mcrat_hip_rebin_cyclosynch(c, cs, max_photons, &empty, &cnt->num_cyclosynch_ph_emit, &cnt->scatt_cyclosynch_num_ph);
+            if (rc == MCRAT_HIP_OK) cnt->rebins += 1;
+            else if (rc != MCRAT_HIP_EINVAL) return rc;          // EINVAL: one of the reference's refusals, the list is as it was
+        }
+        it += 1;
+    }
+    c->pending_applied = false;
+    if (emit_pool) {                                                                              // :853-878
+        if (cnt->scatt_cyclosynch_num_ph > max_photons) {
+            int empty = 0;
+            rc = mcrat_hip_rebin_cyclosynch(c, cs, max_photons, &empty, &cnt->num_cyclosynch_ph_emit, &cnt->scatt_cyclosynch_num_ph);
+            if (rc == MCRAT_HIP_OK) cnt->rebins += 1;
+            else if (rc != MCRAT_HIP_EINVAL) return rc;
+        }
+        if (cnt->num_cyclosynch_ph_emit > 0) {
+            double w = 0;
+            if ((rc = mcrat_hip_absorb_cyclosynch(c, cs, &cnt->frame_abs_cnt, &cnt->scatt_cyclosynch_num_ph, &w))) return rc;
+            cnt->n_comptonized -= w;
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *time_now = c->h_state->time_now;
+    fill_stats(c, stats);
     return MCRAT_HIP_OK;
 }
 

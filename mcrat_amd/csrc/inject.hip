@@ -246,6 +246,7 @@ __global__ __launch_bounds__(256) void inject_generate_kernel(InjectParams p, Hy
 // ---------------------------------------------------------------------------------------------- cyclo-synchrotron pool emission
 constexpr uint32_t RNG_CS_COUNT = 5u;
 constexpr uint32_t RNG_CS_PHOTON = 6u;
+constexpr uint32_t RNG_CS_SINGLE = 7u;
 constexpr double CHARGE_EL = 4.8032068e-10;      // Src/mclib.c:4-5
 
 // getMagneticFieldMagnitude + calcCyclotronFreq, mc_cyclosynch.c:30-33,54-92
@@ -360,21 +361,13 @@ __global__ __launch_bounds__(256) void cs_emit_count_kernel(CsEmitParams p, Hydr
     if (threadIdx.x == 0) atomicAdd(total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
-// mc_cyclosynch.c:1340-1455: pool photon k, at the centre of its cell with the cell's cyclotron frequency, into null slot null_slots[k]
-__global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, HydroDev hy, HydroCols h, double weight, RngKey key,
-                                                               const int *__restrict__ start, int n_emit, const int *__restrict__ null_slots, PhotonDev ph)
+// one cyclo-synchrotron photon at the centre of cell i with the cell's cyclotron frequency into slot s (:1380-1440); the direction
+// takes three uniform draws (two in 3-D).  Returns the azimuth drawn for the position.
+__device__ double cs_emit_one(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, int i, double weight, int block_index, EventStream &rng,
+                              const PhotonDev &ph, int s)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_emit) return;
-    int lo = 0, hi = hy.M;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (start[mid] <= k) lo = mid; else hi = mid;
-    }
-    const int i = lo;
     const CellRec c = load_cell(hy, p.dimensions, i);
     const double fr_dum = cs_nu_c(p, hy, h, i);
-    EventStream rng = keyed_stream(key, 0ull, (uint32_t)k, RNG_CS_PHOTON);
     double position_phi = 0;
     if (p.dimensions != DIM_THREE) position_phi = rng.uniform() * 2 * M_PI;
     const double com_v_phi = rng.uniform() * 2 * M_PI;
@@ -397,7 +390,6 @@ __global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, H
     double xyz[3];
     if (p.dimensions == DIM_THREE) hydro_to_mcrat(p.dimensions, p.geometry, c.c0, c.c1, c.c2, xyz);
     else hydro_to_mcrat(p.dimensions, p.geometry, c.c0, c.c1, position_phi, xyz);
-    const int s = null_slots[k];
     ph.r0[s] = xyz[0]; ph.r1[s] = xyz[1]; ph.r2[s] = xyz[2];
     ph.p0[s] = l_boost[0]; ph.p1[s] = l_boost[1]; ph.p2[s] = l_boost[2]; ph.p3[s] = l_boost[3];
     ph.c0[s] = p_comv[0]; ph.c1[s] = p_comv[1]; ph.c2[s] = p_comv[2]; ph.c3[s] = p_comv[3];
@@ -412,9 +404,73 @@ __global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, H
     }
     ph.u0[s] = u0; ph.u1[s] = u1; ph.u2[s] = u2;
     ph.ntau[s] = -INFINITY;
-    ph.idx[s] = 0;                                                              // nearest_block_index = 0 (:1436)
+    ph.idx[s] = block_index;
     ph.flags[s] = (unsigned char)(FLAG_VALID | FLAG_RECALC);                    // a pool photon does not move (mclib.c:1070)
     ph.type[s] = 'p';
+    return position_phi;
+}
+
+// mc_cyclosynch.c:1340-1455: pool photon k into null slot null_slots[k], nearest_block_index = 0 (:1436)
+__global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, HydroDev hy, HydroCols h, double weight, RngKey key,
+                                                               const int *__restrict__ start, int n_emit, const int *__restrict__ null_slots, PhotonDev ph)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_emit) return;
+    int lo = 0, hi = hy.M;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= k) lo = mid; else hi = mid;
+    }
+    EventStream rng = keyed_stream(key, 0ull, (uint32_t)k, RNG_CS_PHOTON);
+    (void)cs_emit_one(p, hy, h, lo, weight, 0, rng, ph, null_slots[k]);
+}
+
+// The hook of mcrat.c:786-795 after a pass that called photonEvent: if the photon photonEvent reports is a pool photon it
+// becomes a comptonised one and is replaced by a fresh pool photon of its weight in its cell (photonEmitCyclosynch with
+// inject_single_switch = 1, mc_cyclosynch.c:1467-1558, into the list's first null slot, photons.c:139-160), and it is itself
+// moved to a random place in that cell (:1540-1556).  One workgroup; the pending advance must have been applied
+// (flush_kernel) so that the positions are current.  out->need_grow: the list has no null slot, nothing was done.
+__global__ __launch_bounds__(256) void cs_replace_kernel(CsEmitParams p, HydroDev hy, HydroCols h, RngKey key, const LoopState *__restrict__ st,
+                                                         PhotonDev ph, CsHook *__restrict__ out)
+{
+    __shared__ int s_min[4];
+    const int tid = threadIdx.x;
+    const int sidx = st->last_scattered_index;
+    const bool fire = st->photon_event_called && sidx >= 0 && sidx < ph.n && ph.type[sidx] == 'p';
+    if (!fire) {
+        if (tid == 0) { out->fired = 0; out->need_grow = 0; out->slot = -1; out->weight = 0; }
+        return;
+    }
+    int mine = INT_MAX;
+    for (int i = tid; i < ph.n; i += 256)
+        if (ph.type[i] == 'N') { mine = i; break; }
+    for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off));
+    if ((tid & 63) == 0) s_min[tid >> 6] = mine;
+    __syncthreads();
+    if (tid != 0) return;
+    const int slot = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+    if (slot == INT_MAX) { out->fired = 0; out->need_grow = 1; out->slot = -1; out->weight = 0; return; }
+    const int i = ph.idx[sidx];
+    const double weight = ph.weight[sidx];
+    ph.type[sidx] = 'k';                                                        // mcrat.c:789
+    EventStream rng = keyed_stream(key, st->iteration - 1ull, (uint32_t)sidx, RNG_CS_SINGLE);
+    const double position_phi = cs_emit_one(p, hy, h, i, weight, i, rng, ph, slot);
+    const CellRec c = load_cell(hy, p.dimensions, i);
+    const double position_rand = rng.uniform_pos() * c.s0 - c.s0 / 2.0;
+    const double position2_rand = rng.uniform_pos() * c.s1 - c.s1 / 2.0;
+    double xyz[3];
+    if (p.dimensions == DIM_THREE) {
+        const double position3_rand = rng.uniform_pos() * c.s2 - c.s2 / 2.0;
+        hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, c.c2 + position3_rand, xyz);
+    } else {
+        hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, position_phi, xyz);
+    }
+    ph.r0[sidx] = xyz[0]; ph.r1[sidx] = xyz[1]; ph.r2[sidx] = xyz[2];
+    // it moves from now on (mclib.c:1070); a tau stored at scatter time belonged to the old azimuth
+    unsigned f = ph.flags[sidx] & ~FLAG_TAU_FRESH;
+    if (weight != 0) f |= FLAG_MOVES;
+    ph.flags[sidx] = (unsigned char)f;
+    out->fired = 1; out->need_grow = 0; out->slot = slot; out->weight = weight;
 }
 
 // the null slots of the list, ascending (photons.c:181-189)
@@ -710,6 +766,13 @@ hipError_t launch_rebin_place(const PhotonDev &ph, const RebinRec *recs, int tot
 hipError_t launch_rebin_nullify(const PhotonDev &ph, hipStream_t stream)
 {
     rebin_nullify_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(ph);
+    return hipGetLastError();
+}
+
+hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, const LoopState *st, const PhotonDev &ph,
+                             CsHook *out, hipStream_t stream)
+{
+    cs_replace_kernel<<<dim3(1), dim3(256), 0, stream>>>(p, hy, h, key, st, ph, out);
     return hipGetLastError();
 }
 

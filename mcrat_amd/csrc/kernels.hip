@@ -495,6 +495,7 @@ struct EventWalk {
     int nseg, skip, last_idx;
     long long rej;
     bool first;           // the next candidate is the head of the sorted list
+    bool called;          // the head lies inside the frame: main() calls photonEvent (mcrat.c:777)
 };
 
 // the physics of one candidate between mclib.c:1144 and :1322: fluid frame at the photon's azimuth, Stokes rotation
@@ -564,6 +565,7 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     // photonEvent at all when even the first free time exceeds the frame (mcrat.c:777,834)
     const bool in_frame = scatt_time < w.dt_max;
     if (!(w.first && !in_frame)) w.last_idx = i;
+    if (w.first) w.called = in_frame;
     w.first = false;
     if (!in_frame) {                                       // mclib.c:1327-1335
         const double this_seg = w.dt_max - w.old_scatt_time;
@@ -651,7 +653,7 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
     EventWalk w;
     w.dt_max = dt_max;
     w.seg = sh.seg;
-    w.old_scatt_time = 0; w.dt = 0; w.nseg = 0; w.skip = -1; w.rej = 0; w.first = true;
+    w.old_scatt_time = 0; w.dt = 0; w.nseg = 0; w.skip = -1; w.rej = 0; w.first = true; w.called = false;
     w.last_idx = last_idx;
     long long rescans = 0;
     const double t_first = (n_list > 0) ? sh.list[0].t : INFINITY;
@@ -708,6 +710,7 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
         st->skip_idx = w.skip;
         st->last_scattered_index = w.last_idx;
         st->kn_rejections += w.rej;
+        st->photon_event_called = w.called ? 1 : 0;
         st->rescans += rescans;
         // shortlist threshold for the next pass: ~8 expected entries (speed only)
         if (t_first < INFINITY) {

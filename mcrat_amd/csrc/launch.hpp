@@ -171,6 +171,16 @@ hipError_t launch_cs_emit_count(const CsEmitParams &p, const HydroDev &hy, const
                                 RngKey key, unsigned *count, unsigned long long *d_total, unsigned *d_flags, hipStream_t stream);
 hipError_t launch_cs_emit_generate(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, RngKey key, const int *start,
                                    int n_emit, const int *null_slots, const PhotonDev &ph, hipStream_t stream);
+// the replacement of a scattered pool photon inside the loop (mcrat.c:786-795), one workgroup on the context's stream
+struct CsHook {
+    int fired;          // the reported photon was a pool photon and has been replaced
+    int need_grow;      // ... but the list has no null slot: nothing was done, grow the list and launch again
+    int slot;           // where the new pool photon went
+    int pad;
+    double weight;      // the weight of the comptonised photon (n_comptonized, mcrat.c:788)
+};
+hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, const LoopState *st, const PhotonDev &ph,
+                             CsHook *out, hipStream_t stream);
 // the list's null slots in ascending order (addToPhotonList's null_ph_indexes, photons.c:181-189): count per 256 slots, then write
 hipError_t launch_null_count(const PhotonDev &ph, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
 hipError_t launch_null_write(const PhotonDev &ph, const int *block_start, int *null_slots, hipStream_t stream);

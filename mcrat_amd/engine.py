@@ -125,6 +125,12 @@ class Cyclosynch(C.Structure):
                 ("rebin_ang_phi", C.c_double), ("scatt_frame_number", C.c_int), ("inj_frame_number", C.c_int)]
 
 
+class CyclosynchCounts(C.Structure):
+    """mcrat_hip_cyclosynch_counts: the counters of mcrat.c:735-878 for one scatter frame"""
+    _fields_ = [("num_cyclosynch_ph_emit", C.c_int), ("scatt_cyclosynch_num_ph", C.c_int), ("frame_abs_cnt", C.c_int), ("rebins", C.c_int),
+                ("integrals_not_converged", C.c_int), ("pad", C.c_int), ("n_comptonized", C.c_double), ("pool_weight", C.c_double)]
+
+
 class Outflow(C.Structure):
     _fields_ = [("simulation_type", C.c_int), ("gamma_infinity", C.c_double), ("lumi", C.c_double), ("r00", C.c_double),
                 ("t_comov", C.c_double), ("ddensity", C.c_double), ("theta_j", C.c_double), ("p", C.c_double)]
@@ -167,6 +173,9 @@ SYMBOLS = {
     "mcrat_hip_emit_cyclosynch_pool": (C.c_int, [_ctx, C.POINTER(Cyclosynch), C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double,
                                                  C.c_uint64, _ip, _dp, _ip]),
     "mcrat_hip_rebin_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), C.c_int, _ip, _ip, _ip]),
+    "mcrat_hip_scatter_frame_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), _dp, C.c_double, C.c_uint64, C.c_double, C.c_double, C.c_int,
+                                                     C.c_double, C.c_double, C.c_double, C.c_int, C.c_longlong, C.POINTER(FrameStats),
+                                                     C.POINTER(CyclosynchCounts)]),
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_absorb_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), _ip, _ip, _dp]),
     "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
@@ -246,9 +255,10 @@ class Engine:
     """One context of the HIP photon-loop engine (one per rank / GPU)."""
 
     def __init__(self, dimensions, geometry, stokes=0, device=0, stream=None, rng_stream=0,
-                 iterations_per_sync=0, use_graph=False, profile=False, virtual_rank_photons=0, tau_calculation=TAU_DIRECT):
+                 iterations_per_sync=0, use_graph=False, profile=False, virtual_rank_photons=0, tau_calculation=TAU_DIRECT,
+                 cyclosynchrotron=0):
         self.lib = load_library()
-        self.cfg = Config(ABI_VERSION, int(dimensions), int(geometry), int(bool(stokes)), int(tau_calculation), 0,
+        self.cfg = Config(ABI_VERSION, int(dimensions), int(geometry), int(bool(stokes)), int(tau_calculation), int(cyclosynchrotron),
                           int(device), C.c_void_p(stream) if stream else None, int(rng_stream),
                           int(iterations_per_sync), int(bool(use_graph)), int(bool(profile)), int(virtual_rank_photons))
         self.ctx = _ctx()
@@ -377,6 +387,20 @@ class Engine:
                     "emit_cyclosynch_pool")
         self.n = int(self.lib.mcrat_hip_num_photon_slots(self.ctx))          # the list doubles when the pool does not fit
         return n.value, w.value, bad.value
+
+    def scatter_frame_cyclosynch(self, time_now, remaining_time, seed, r_inj, ph_weight_suggest, max_photons, theta_min, theta_max, fps, emit_pool=1,
+                                 max_iterations=0, b_field_calc=1, epsilon_b=0.5, rebin_e_perc=0.1, rebin_ang=0.5, rebin_ang_phi=10.0,
+                                 scatt_frame_number=0, inj_frame_number=0):
+        """main()'s scatter-frame body with CYCLOSYNCHROTRON_SWITCH on (mcrat.c:706-878) -> (time_now, FrameStats, CyclosynchCounts)"""
+        cs = Cyclosynch(int(b_field_calc), float(epsilon_b), float(rebin_e_perc), float(rebin_ang), float(rebin_ang_phi), int(scatt_frame_number),
+                        int(inj_frame_number))
+        st, cnt, tn = FrameStats(), CyclosynchCounts(), C.c_double(time_now)
+        self._check(self.lib.mcrat_hip_scatter_frame_cyclosynch(self.ctx, C.byref(cs), C.byref(tn), float(remaining_time), int(seed), float(r_inj),
+                                                                float(ph_weight_suggest), int(max_photons), float(theta_min), float(theta_max), float(fps),
+                                                                int(emit_pool), int(max_iterations), C.byref(st), C.byref(cnt)),
+                    "scatter_frame_cyclosynch")
+        self.n = int(self.lib.mcrat_hip_num_photon_slots(self.ctx))
+        return tn.value, st, cnt
 
     def rebin_cyclosynch(self, max_photons, rebin_e_perc=0.1, rebin_ang=0.5, rebin_ang_phi=10.0):
         """rebinCyclosynchCompPhotons (mc_cyclosynch.c:246-712) -> (empty bins, num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph)"""

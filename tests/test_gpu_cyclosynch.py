@@ -212,3 +212,62 @@ def test_rebinning_refusals(hip, oracle):
         e.rebin_cyclosynch(2000)
     assert np.array_equal(e.get_photons_aos()["p0"], only["p0"])
     e.close()
+
+
+@pytest.mark.parametrize("case,max_photons,remaining,max_iterations", [("pool-replace-grow", 2000, 0.2, 600), ("rebin-in-the-loop", 200, 3.0, 0)])
+def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case, max_photons, remaining, max_iterations):
+    """mcrat_hip_scatter_frame_cyclosynch against orc_scatter_frame_cs (mcrat.c:706-878): pool emission, the loop in which every scattered
+    pool photon becomes a comptonised one and is replaced (the list doubling when its null slots run out), the rebinning every 1000
+    scatterings once there are more comptonised photons than max_photons, the absorption at the end.  Same passes, scatterings,
+    counters, list length, types, slots and weights; doubles to 1e-9 as for the plain loop (tests/test_gpu_parity.py)."""
+    L = oracle.lib()
+    frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
+    dens = np.ascontiguousarray(frame["dens"])
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 1)
+    H = oracle.OracleHydro(frame)
+    cs = oracle.CS(1, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, 200, 200, 0.5, 10.0)
+    aos = synth.photons_to_aos(ph, oracle.PHOTON_DTYPE)
+    l = oracle.PhotonList()
+    L.orc_list_init(C.byref(l))
+    both = np.concatenate([aos, aos])                          # the second half becomes the null slots the pool goes into
+    assert L.orc_list_set(C.byref(l), both.ctypes.data, len(both)) == 0
+    for i in range(300, 600):
+        assert L.orc_list_set_null(C.byref(l), i) == 0
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    before = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), 31, 0)
+    st, cnt, t = oracle.Stats(), oracle.CSCounts(), C.c_double(0.0)
+    L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), remaining, 1e12, 1e40, max_photons, 0.0, 0.05, 1,
+                           max_iterations, C.byref(st), C.byref(cnt))
+    assert cnt.error == 0
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    want = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    L.orc_list_free(C.byref(l))
+    assert len(want) == 1200 and cnt.scatt_cyclosynch_num_ph > 0 and cnt.frame_abs_cnt > 0       # the list doubled inside the loop
+    if case == "rebin-in-the-loop":
+        assert cnt.rebins >= 1 and st.remaining_time == 0.0
+
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+    e.set_hydro(frame)
+    e.set_hydro_extras(dens)
+    e.set_photons_aos(before.astype(hip.PHOTON_DTYPE))
+    with pytest.raises(hip.McratHipError):                     # the plain loop has no hook: refused with the switch on
+        e.propagate_frame(0.0, remaining, 31)
+    tn, gst, gcnt = e.scatter_frame_cyclosynch(0.0, remaining, 31, 1e12, 1e40, max_photons, 0.0, 0.05, frame["fps"], emit_pool=1,
+                                               max_iterations=max_iterations, b_field_calc=1, scatt_frame_number=200, inj_frame_number=200)
+    got = e.get_photons_aos()
+    e.close()
+    assert (gst.iterations, gst.frame_scatt_cnt, gst.kn_rejections) == (st.iterations, st.frame_scatt_cnt, st.kn_rejections)
+    assert (gcnt.num_cyclosynch_ph_emit, gcnt.scatt_cyclosynch_num_ph, gcnt.frame_abs_cnt, gcnt.rebins) == \
+        (cnt.num_cyclosynch_ph_emit, cnt.scatt_cyclosynch_num_ph, cnt.frame_abs_cnt, cnt.rebins)
+    assert gcnt.pool_weight == cnt.pool_weight and gcnt.n_comptonized == pytest.approx(cnt.n_comptonized, rel=1e-12)
+    assert tn == pytest.approx(t.value, rel=1e-12) and len(got) == len(want)
+    assert np.array_equal(got["type"], want["type"])
+    for f in ("weight", "num_scatt", "nearest_block_index", "recalc_properties"):
+        assert np.array_equal(got[f], want[f]), f
+    for f in ("p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3", "r0", "r1", "r2", "s0", "s1", "s2", "s3"):
+        scale = np.maximum(np.abs(want["p0"]), 1e-300) if f.startswith("p") else (
+            np.maximum(np.abs(want["comv_p0"]), 1e-300) if f.startswith("comv") else (np.maximum(np.abs(want[f]), 1e9) if f.startswith("r") else 1.0))
+        err = np.abs(got[f] - want[f]) / scale
+        assert np.all(err <= 1e-9), (f, float(err.max()), int(err.argmax()))
