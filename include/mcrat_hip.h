@@ -289,9 +289,9 @@ typedef struct mcrat_hip_output_columns {
 int mcrat_hip_get_output(mcrat_hip_ctx *ctx, mcrat_hip_output_columns *out);
 int mcrat_hip_get_photons_range(mcrat_hip_ctx *ctx, int first, int count, mcrat_hip_photon *records);
 
-/* Cyclo-synchrotron, first device piece: the absorption at the end of a scatter frame.  The rest of the row
- * (pool emission, the replacement hook inside the loop, rebinning) is not on the device yet and mcrat_hip_init still refuses
- * cyclosynchrotron_switch != 0; this call works on whatever photon types the list holds.
+/* Cyclo-synchrotron: the stages of a scatter frame with CYCLOSYNCHROTRON_SWITCH on.  They work on whatever photon
+ * types the list holds; mcrat_hip_scatter_frame_cyclosynch (below) chains them as mcrat.c:706-878 does and needs a context created
+ * with cyclosynchrotron_switch = 1.
  *   mcrat_hip_set_hydro_extras   the columns of struct hydro_dataframe the magnetic field needs and mcrat_hip_hydro does not carry:
  *                                dens (comoving density; B_FIELD_CALC INTERNAL_E / TOTAL_E, mc_cyclosynch.c:82-83) and B0-2
  *                                (B_FIELD_CALC == SIMULATION).  NULL pointers are skipped; after mcrat_hip_ingest_* dens is there already.
@@ -383,7 +383,9 @@ int mcrat_hip_create_hot_cross_section(mcrat_hip_ctx *ctx, double *thermal_table
 
 /* photons host -> device (after photonInjection mcrat.c:645 / readCheckpoint) and back
  * (before saveCheckpoint mcrat.c:902 / printPhotons mcrat.c:907).  NULL-photon slots
- * (type 'N', weight 0, index -1: photons.c:208) are carried through unchanged. */
+ * (type 'N', weight 0, index -1: photons.c:208) are carried through unchanged.  list_capacity must equal
+ * mcrat_hip_num_photon_slots on get; a context with cyclosynchrotron_switch on also sets num_photons and num_null_photons
+ * from what the list holds now (photons.c:252-275). */
 int mcrat_hip_set_photons(mcrat_hip_ctx *ctx, const mcrat_hip_photon_list *list);
 int mcrat_hip_get_photons(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list);
 int mcrat_hip_set_photons_soa(mcrat_hip_ctx *ctx, const mcrat_hip_photon_soa *soa);

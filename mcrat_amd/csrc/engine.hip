@@ -1558,6 +1558,12 @@ extern "C" int mcrat_hip_get_photons(mcrat_hip_ctx *c, mcrat_hip_photon_list *l)
     HIPCHK(c, launch_soa_to_aos(c->ph, c->aos_buf, 0, n, c->stream));
     HIPCHK(c, hipMemcpyAsync(l->photons, c->aos_buf, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->cfg.cyclosynchrotron_switch) {          // the list changed inside the frame: the counts of photons.c:252-275
+        int nulls = 0;
+        for (int i = 0; i < n; ++i) nulls += l->photons[i].type == 'N';
+        l->num_null_photons = nulls;
+        l->num_photons = n - nulls;
+    }
     return MCRAT_HIP_OK;
 }
 

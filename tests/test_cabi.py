@@ -83,8 +83,11 @@ def test_no_cpu_fallback(engine):
     assert lib.mcrat_hip_init(C.byref(ctx), C.byref(bad)) == -1
     unknown_tau = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, 7, 0, 0, None, 0, 0, 0, 0, 0)   # no such TAU_CALCULATION
     assert lib.mcrat_hip_init(C.byref(ctx), C.byref(unknown_tau)) == -1
-    cyclo = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 1, 0, None, 0, 0, 0, 0, 0)   # CYCLOSYNCHROTRON_SWITCH ON
+    # CYCLOSYNCHROTRON_SWITCH ON is one list per context: refused together with virtual ranks
+    cyclo = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 1, 0, None, 0, 0, 0, 0, 1000)
     assert lib.mcrat_hip_init(C.byref(ctx), C.byref(cyclo)) == -1
+    cyclo2 = engine.Config(engine.ABI_VERSION, engine.TWO, engine.CYLINDRICAL, 0, engine.TAU_DIRECT, 2, 0, None, 0, 0, 0, 0, 0)      # no such value
+    assert lib.mcrat_hip_init(C.byref(ctx), C.byref(cyclo2)) == -1
     assert lib.mcrat_hip_init(None, C.byref(cfg)) == -1
 
 
