@@ -214,18 +214,35 @@ def test_rebinning_refusals(hip, oracle):
     e.close()
 
 
-@pytest.mark.parametrize("case,max_photons,remaining,max_iterations", [("pool-replace-grow", 2000, 0.2, 600), ("rebin-in-the-loop", 200, 3.0, 0)])
-def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case, max_photons, remaining, max_iterations):
+CS_FRAMES = {
+    # name: (mesh, B_FIELD_CALC, max_photons, remaining_time, max_iterations, emit_pool, theta_max, rebin_ang_phi)
+    "2d-pool-replace-grow": ("2d", 1, 2000, 0.2, 600, 1, 0.05, 10.0),
+    "2d-rebin-in-the-loop": ("2d", 1, 200, 3.0, 0, 1, 0.05, 10.0),
+    "2d-internal-energy-field": ("2d", 0, 2000, 0.2, 800, 1, 0.05, 10.0),
+    "2d-first-frame-no-pool": ("2d", 1, 2000, 0.2, 800, 0, 0.05, 10.0),
+    "3d-pool-replace-grow": ("3d", 1, 2000, 0.2, 0, 1, 0.06, 45.0),
+    "3d-internal-energy-field": ("3d", 0, 2000, 0.2, 0, 1, 0.06, 45.0),
+    "3d-rebin-refused": ("3d", 1, 150, 1.0, 0, 1, 0.06, 45.0),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CS_FRAMES))
+def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case):
     """mcrat_hip_scatter_frame_cyclosynch against orc_scatter_frame_cs (mcrat.c:706-878): pool emission, the loop in which every scattered
     pool photon becomes a comptonised one and is replaced (the list doubling when its null slots run out), the rebinning every 1000
-    scatterings once there are more comptonised photons than max_photons, the absorption at the end.  Same passes, scatterings,
-    counters, list length, types, slots and weights; doubles to 1e-9 as for the plain loop (tests/test_gpu_parity.py)."""
+    scatterings once there are more comptonised photons than max_photons (refused, as in the reference, when it would need more bins
+    than max_photons), the absorption at the end.  Same passes, scatterings, counters, list length, types, slots and weights; doubles
+    to 1e-9 as for the plain loop (tests/test_gpu_parity.py)."""
+    mesh, b_field_calc, max_photons, remaining, max_iterations, emit_pool, theta_max, ang_phi = CS_FRAMES[case]
     L = oracle.lib()
-    frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
+    if mesh == "2d":
+        frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
+    else:
+        frame, ph, cfg = synth.config_3d_cartesian(n_photons=300, n=(8, 8, 8))
     dens = np.ascontiguousarray(frame["dens"])
     c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 1)
     H = oracle.OracleHydro(frame)
-    cs = oracle.CS(1, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, 200, 200, 0.5, 10.0)
+    cs = oracle.CS(b_field_calc, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, 200, 200, 0.5, ang_phi)
     aos = synth.photons_to_aos(ph, oracle.PHOTON_DTYPE)
     l = oracle.PhotonList()
     L.orc_list_init(C.byref(l))
@@ -238,15 +255,20 @@ def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case, 
     rng = oracle.Rng()
     L.orc_rng_init(C.byref(rng), 31, 0)
     st, cnt, t = oracle.Stats(), oracle.CSCounts(), C.c_double(0.0)
-    L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), remaining, 1e12, 1e40, max_photons, 0.0, 0.05, 1,
-                           max_iterations, C.byref(st), C.byref(cnt))
-    assert cnt.error == 0
+    L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), remaining, 1e12, 1e40, max_photons, 0.0, theta_max,
+                           emit_pool, max_iterations, C.byref(st), C.byref(cnt))
+    assert cnt.error == 0 and st.frame_scatt_cnt > 500
     buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
     want = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
     L.orc_list_free(C.byref(l))
-    assert len(want) == 1200 and cnt.scatt_cyclosynch_num_ph > 0 and cnt.frame_abs_cnt > 0       # the list doubled inside the loop
-    if case == "rebin-in-the-loop":
-        assert cnt.rebins >= 1 and st.remaining_time == 0.0
+    if case.endswith("pool-replace-grow"):
+        assert len(want) == 1200 and cnt.scatt_cyclosynch_num_ph > 0 and cnt.frame_abs_cnt > 0   # the list doubled inside the loop
+    if case == "2d-rebin-in-the-loop":
+        assert cnt.rebins >= 1 and st.remaining_time == 0.0 and len(want) == 1200
+    if case == "3d-rebin-refused":
+        assert cnt.rebins == 0 and cnt.num_cyclosynch_ph_emit > max_photons
+    if not emit_pool:
+        assert cnt.num_cyclosynch_ph_emit == 0 and (want["type"] == b"p").sum() == 0
 
     e = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
     e.set_hydro(frame)
@@ -254,8 +276,9 @@ def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case, 
     e.set_photons_aos(before.astype(hip.PHOTON_DTYPE))
     with pytest.raises(hip.McratHipError):                     # the plain loop has no hook: refused with the switch on
         e.propagate_frame(0.0, remaining, 31)
-    tn, gst, gcnt = e.scatter_frame_cyclosynch(0.0, remaining, 31, 1e12, 1e40, max_photons, 0.0, 0.05, frame["fps"], emit_pool=1,
-                                               max_iterations=max_iterations, b_field_calc=1, scatt_frame_number=200, inj_frame_number=200)
+    tn, gst, gcnt = e.scatter_frame_cyclosynch(0.0, remaining, 31, 1e12, 1e40, max_photons, 0.0, theta_max, frame["fps"], emit_pool=emit_pool,
+                                               max_iterations=max_iterations, b_field_calc=b_field_calc, rebin_ang_phi=ang_phi,
+                                               scatt_frame_number=200, inj_frame_number=200)
     got = e.get_photons_aos()
     e.close()
     assert (gst.iterations, gst.frame_scatt_cnt, gst.kn_rejections) == (st.iterations, st.frame_scatt_cnt, st.kn_rejections)
