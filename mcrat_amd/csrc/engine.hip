@@ -57,7 +57,7 @@ struct mcrat_hip_ctx {
     unsigned *grid_count = nullptr;    // per-bucket counters of the device build
     size_t grid_count_cap = 0;
     unsigned long long *d_grid_total = nullptr;
-    void *d_cs_hook = nullptr;                 // CsHook of the cyclo-synchrotron frame driver
+    void *d_cs_hook = nullptr;                 // CsFrame of the cyclo-synchrotron frame driver
     HydroCols hcol{};                  // the frame as struct hydro_dataframe's columns (set_hydro / ingest), kept for get_hydro
     void *hcol_buf = nullptr;
     size_t hcol_bytes = 0;
@@ -1935,8 +1935,8 @@ extern "C" int mcrat_hip_propagate_frame(mcrat_hip_ctx *c, double *time_now, dou
 // The scatter-frame body of main() with CYCLOSYNCHROTRON_SWITCH on (mcrat.c:706-878, between getHydroData and saveCheckpoint): pool
 // emission, the loop with the replacement of scattered pool photons (:786-795) and the rebinning trigger (:797-808), the rebinning
 // and absorption at the end of the frame (:853-878).  The hook needs the list current after every pass, so a pass here is
-// step + event + flush + cs_replace and the host reads the pass's outcome back (list growth and the rebinning are host-driven);
-// a device-resident hook is DESIGN.md section 8's next step for this row.
+// step + event + flush + cs_replace; the hook keeps the frame's counters on the device and parks the loop when it needs the host
+// (list growth, the rebinning), so the host reads back once per batch of passes (CsFrame, launch.hpp).
 extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, double *time_now, double remaining_time, uint64_t seed,
                                                   double r_inj, double ph_weight_suggest, int max_photons, double theta_min, double theta_max, double fps,
                                                   int emit_pool, long long max_iterations, mcrat_hip_frame_stats *stats, mcrat_hip_cyclosynch_counts *cnt)
@@ -1958,40 +1958,63 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
     if ((rc = mcrat_hip_begin_frame(c, seed, *time_now, remaining_time))) return rc;
     CsEmitParams p{};
     p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry; p.b_field_calc = cs->b_field_calc; p.epsilon_b = cs->epsilon_b;
-    if (!c->d_cs_hook) HIPCHK(c, hipMalloc((void **)&c->d_cs_hook, sizeof(CsHook)));
-    CsHook hook;
-    long long it = 0;
-    while (!c->h_state->done && (max_iterations <= 0 || it < max_iterations)) {                  // :761-851
-        HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
-        c->find_switch = 0;
-        HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
-        HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
-        HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, static_cast<CsHook *>(c->d_cs_hook), c->stream));
+    if (!c->d_cs_hook) HIPCHK(c, hipMalloc((void **)&c->d_cs_hook, sizeof(CsFrame)));
+    CsFrame *d_cf = static_cast<CsFrame *>(c->d_cs_hook);
+    CsFrame cf{};
+    cf.max_photons = max_photons;
+    cf.last_iteration = ~0ull;
+    HIPCHK(c, hipMemcpyAsync(d_cf, &cf, sizeof cf, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                                                  // cf is on the stack
+    const int emit_pool_count = cnt->num_cyclosynch_ph_emit;
+    int emit_base = emit_pool_count;               // num_cyclosynch_ph_emit = emit_base + replacements since (the rebinning overwrites it)
+    const long long per_sync = 32;                 // passes queued per read-back; a parked loop makes the rest of a batch no-ops
+    while (!c->h_state->done && (max_iterations <= 0 || c->h_state->iterations < max_iterations)) {   // :761-851
+        long long batch = per_sync;
+        if (max_iterations > 0 && batch > max_iterations - c->h_state->iterations) batch = max_iterations - c->h_state->iterations;
+        for (long long b = 0; b < batch; ++b) {
+            HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+            c->find_switch = 0;
+            HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+            HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
+            HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, d_cf, 0, c->stream));
+        }
         HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&hook, c->d_cs_hook, sizeof hook, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&cf, d_cf, sizeof cf, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (hook.need_grow) {                                                                     // photons.c:112-121: the list doubles
-            if (c->ph.n > 0x3fffffff) { c->last_error = "photon list too long to double"; return MCRAT_HIP_ENOMEM; }
-            if ((rc = grow_photons(c, 2 * c->ph.n))) return rc;
-            HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, static_cast<CsHook *>(c->d_cs_hook), c->stream));
-            HIPCHK(c, hipMemcpyAsync(&hook, c->d_cs_hook, sizeof hook, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if (!hook.fired) { c->last_error = "the replacement of a scattered pool photon failed after the list was doubled"; return MCRAT_HIP_ENOMEM; }
+        while (cf.halt) {                          // the loop is parked: do what the hook asked for, then let it go on
+            const int why = cf.halt;
+            cf.halt = 0;
+            c->h_state->done = cf.saved_done;
+            HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(c->d_state) + offsetof(LoopState, done), &cf.saved_done, sizeof(int), hipMemcpyHostToDevice,
+                                     c->stream));
+            if (why == CS_HALT_GROW) {                                                            // photons.c:112-121: the list doubles
+                if (c->ph.n > 0x3fffffff) { c->last_error = "photon list too long to double"; return MCRAT_HIP_ENOMEM; }
+                HIPCHK(c, hipMemcpyAsync(d_cf, &cf, sizeof cf, hipMemcpyHostToDevice, c->stream));
+                if ((rc = grow_photons(c, 2 * c->ph.n))) return rc;
+                HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, d_cf, 1, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipMemcpyAsync(&cf, d_cf, sizeof cf, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (cf.halt == CS_HALT_GROW) { c->last_error = "the replacement of a scattered pool photon failed after the list was doubled"; return MCRAT_HIP_ENOMEM; }
+            } else {                                                                              // :797-808
+                int empty = 0, emit_total = emit_base + cf.emitted, scatt = cf.scatt_num;
+                rc = mcrat_hip_rebin_cyclosynch(c, cs, max_photons, &empty, &emit_total, &scatt);
+                if (rc == MCRAT_HIP_OK) {
+                    cnt->rebins += 1;
+                    emit_base = emit_total;
+                    cf.emitted = 0;
+                    cf.scatt_num = scatt;
+                } else if (rc != MCRAT_HIP_EINVAL) {
+                    return rc;                     // EINVAL: one of the reference's refusals, the list is as it was
+                }
+                HIPCHK(c, hipMemcpyAsync(d_cf, &cf, sizeof cf, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
         }
-        if (hook.fired) {                                                                         // :788-794
-            cnt->n_comptonized += hook.weight;
-            cnt->num_cyclosynch_ph_emit += 1;
-            cnt->scatt_cyclosynch_num_ph += 1;
-        }
-        const LoopState &h = *c->h_state;
-        if (h.photon_event_called && (h.frame_scatt_cnt % 1000 == 0) && h.frame_scatt_cnt != 0 && cnt->scatt_cyclosynch_num_ph > max_photons) {   // :797-808
-            int empty = 0;
-            rc = mcrat_hip_rebin_cyclosynch(c, cs, max_photons, &empty, &cnt->num_cyclosynch_ph_emit, &cnt->scatt_cyclosynch_num_ph);
-            if (rc == MCRAT_HIP_OK) cnt->rebins += 1;
-            else if (rc != MCRAT_HIP_EINVAL) return rc;          // EINVAL: one of the reference's refusals, the list is as it was
-        }
-        it += 1;
     }
+    cnt->num_cyclosynch_ph_emit = emit_base + cf.emitted;
+    cnt->scatt_cyclosynch_num_ph = cf.scatt_num;
+    cnt->n_comptonized = cf.n_comptonized;
     c->pending_applied = false;
     if (emit_pool) {                                                                              // :853-878
         if (cnt->scatt_cyclosynch_num_ph > max_photons) {

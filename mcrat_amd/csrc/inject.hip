@@ -425,52 +425,69 @@ __global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, H
     (void)cs_emit_one(p, hy, h, lo, weight, 0, rng, ph, null_slots[k]);
 }
 
-// The hook of mcrat.c:786-795 after a pass that called photonEvent: if the photon photonEvent reports is a pool photon it
+// The hook of mcrat.c:786-808 after a pass.  If the pass called photonEvent and the photon it reports is a pool photon, that photon
 // becomes a comptonised one and is replaced by a fresh pool photon of its weight in its cell (photonEmitCyclosynch with
-// inject_single_switch = 1, mc_cyclosynch.c:1467-1558, into the list's first null slot, photons.c:139-160), and it is itself
-// moved to a random place in that cell (:1540-1556).  One workgroup; the pending advance must have been applied
-// (flush_kernel) so that the positions are current.  out->need_grow: the list has no null slot, nothing was done.
-__global__ __launch_bounds__(256) void cs_replace_kernel(CsEmitParams p, HydroDev hy, HydroCols h, RngKey key, const LoopState *__restrict__ st,
-                                                         PhotonDev ph, CsHook *__restrict__ out)
+// inject_single_switch = 1, mc_cyclosynch.c:1467-1558, into the list's first null slot, photons.c:139-160), and it is itself moved to
+// a random place in that cell (:1540-1556); then the rebinning trigger of :797-808.  One workgroup; the pending advance must have
+// been applied (flush_kernel) so that the positions are current.  See CsFrame (launch.hpp) for how it parks the loop.
+__global__ __launch_bounds__(256) void cs_replace_kernel(CsEmitParams p, HydroDev hy, HydroCols h, RngKey key, LoopState *st, PhotonDev ph, CsFrame *cf,
+                                                         int resume)
 {
     __shared__ int s_min[4];
     const int tid = threadIdx.x;
+    const unsigned long long it = st->iteration;
+    if (!resume && (cf->halt != 0 || it == cf->last_iteration)) return;        // parked, or a queued pass that did nothing
     const int sidx = st->last_scattered_index;
-    const bool fire = st->photon_event_called && sidx >= 0 && sidx < ph.n && ph.type[sidx] == 'p';
-    if (!fire) {
-        if (tid == 0) { out->fired = 0; out->need_grow = 0; out->slot = -1; out->weight = 0; }
-        return;
+    const int called = st->photon_event_called;
+    const bool fire = called && sidx >= 0 && sidx < ph.n && ph.type[sidx] == 'p';
+    if (fire) {
+        int mine = INT_MAX;
+        for (int i = tid; i < ph.n; i += 256)
+            if (ph.type[i] == 'N') { mine = i; break; }
+        for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off));
+        if ((tid & 63) == 0) s_min[tid >> 6] = mine;
+        __syncthreads();
     }
-    int mine = INT_MAX;
-    for (int i = tid; i < ph.n; i += 256)
-        if (ph.type[i] == 'N') { mine = i; break; }
-    for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off));
-    if ((tid & 63) == 0) s_min[tid >> 6] = mine;
-    __syncthreads();
     if (tid != 0) return;
-    const int slot = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
-    if (slot == INT_MAX) { out->fired = 0; out->need_grow = 1; out->slot = -1; out->weight = 0; return; }
-    const int i = ph.idx[sidx];
-    const double weight = ph.weight[sidx];
-    ph.type[sidx] = 'k';                                                        // mcrat.c:789
-    EventStream rng = keyed_stream(key, st->iteration - 1ull, (uint32_t)sidx, RNG_CS_SINGLE);
-    const double position_phi = cs_emit_one(p, hy, h, i, weight, i, rng, ph, slot);
-    const CellRec c = load_cell(hy, p.dimensions, i);
-    const double position_rand = rng.uniform_pos() * c.s0 - c.s0 / 2.0;
-    const double position2_rand = rng.uniform_pos() * c.s1 - c.s1 / 2.0;
-    double xyz[3];
-    if (p.dimensions == DIM_THREE) {
-        const double position3_rand = rng.uniform_pos() * c.s2 - c.s2 / 2.0;
-        hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, c.c2 + position3_rand, xyz);
-    } else {
-        hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, position_phi, xyz);
+    if (fire) {
+        const int slot = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        if (slot == INT_MAX) {                                                  // photons.c:112-121: the host doubles the list
+            cf->halt = CS_HALT_GROW;
+            cf->saved_done = st->done;
+            st->done = LOOP_CS_HALT;
+            return;
+        }
+        const int i = ph.idx[sidx];
+        const double weight = ph.weight[sidx];
+        ph.type[sidx] = 'k';                                                    // mcrat.c:789
+        EventStream rng = keyed_stream(key, it - 1ull, (uint32_t)sidx, RNG_CS_SINGLE);
+        const double position_phi = cs_emit_one(p, hy, h, i, weight, i, rng, ph, slot);
+        const CellRec c = load_cell(hy, p.dimensions, i);
+        const double position_rand = rng.uniform_pos() * c.s0 - c.s0 / 2.0;
+        const double position2_rand = rng.uniform_pos() * c.s1 - c.s1 / 2.0;
+        double xyz[3];
+        if (p.dimensions == DIM_THREE) {
+            const double position3_rand = rng.uniform_pos() * c.s2 - c.s2 / 2.0;
+            hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, c.c2 + position3_rand, xyz);
+        } else {
+            hydro_to_mcrat(p.dimensions, p.geometry, c.c0 + position_rand, c.c1 + position2_rand, position_phi, xyz);
+        }
+        ph.r0[sidx] = xyz[0]; ph.r1[sidx] = xyz[1]; ph.r2[sidx] = xyz[2];
+        // it moves from now on (mclib.c:1070); a tau stored at scatter time belonged to the old azimuth
+        unsigned f = ph.flags[sidx] & ~FLAG_TAU_FRESH;
+        if (weight != 0) f |= FLAG_MOVES;
+        ph.flags[sidx] = (unsigned char)f;
+        cf->n_comptonized += weight;                                            // mcrat.c:788-794
+        cf->emitted += 1;
+        cf->scatt_num += 1;
     }
-    ph.r0[sidx] = xyz[0]; ph.r1[sidx] = xyz[1]; ph.r2[sidx] = xyz[2];
-    // it moves from now on (mclib.c:1070); a tau stored at scatter time belonged to the old azimuth
-    unsigned f = ph.flags[sidx] & ~FLAG_TAU_FRESH;
-    if (weight != 0) f |= FLAG_MOVES;
-    ph.flags[sidx] = (unsigned char)f;
-    out->fired = 1; out->need_grow = 0; out->slot = slot; out->weight = weight;
+    cf->last_iteration = it;
+    const long long fsc = st->frame_scatt_cnt;
+    if (called && (fsc % 1000 == 0) && fsc != 0 && cf->scatt_num > cf->max_photons) {       // mcrat.c:797-808
+        cf->halt = CS_HALT_REBIN;
+        cf->saved_done = st->done;
+        st->done = LOOP_CS_HALT;
+    }
 }
 
 // the null slots of the list, ascending (photons.c:181-189)
@@ -769,10 +786,10 @@ hipError_t launch_rebin_nullify(const PhotonDev &ph, hipStream_t stream)
     return hipGetLastError();
 }
 
-hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, const LoopState *st, const PhotonDev &ph,
-                             CsHook *out, hipStream_t stream)
+hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, LoopState *st, const PhotonDev &ph,
+                             CsFrame *frame, int resume, hipStream_t stream)
 {
-    cs_replace_kernel<<<dim3(1), dim3(256), 0, stream>>>(p, hy, h, key, st, ph, out);
+    cs_replace_kernel<<<dim3(1), dim3(256), 0, stream>>>(p, hy, h, key, st, ph, frame, resume);
     return hipGetLastError();
 }
 

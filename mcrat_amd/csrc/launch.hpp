@@ -171,16 +171,25 @@ hipError_t launch_cs_emit_count(const CsEmitParams &p, const HydroDev &hy, const
                                 RngKey key, unsigned *count, unsigned long long *d_total, unsigned *d_flags, hipStream_t stream);
 hipError_t launch_cs_emit_generate(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, RngKey key, const int *start,
                                    int n_emit, const int *null_slots, const PhotonDev &ph, hipStream_t stream);
-// the replacement of a scattered pool photon inside the loop (mcrat.c:786-795), one workgroup on the context's stream
-struct CsHook {
-    int fired;          // the reported photon was a pool photon and has been replaced
-    int need_grow;      // ... but the list has no null slot: nothing was done, grow the list and launch again
-    int slot;           // where the new pool photon went
+// the hook of mcrat.c:786-808 after every pass of a cyclo-synchrotron frame (one workgroup on the context's stream) and the state it
+// keeps on the device, so that the host reads a frame's progress back once per batch of passes: when the hook needs the host (the list
+// has no null slot left; the rebinning is due) it parks the loop -- LoopState::done = LOOP_CS_HALT makes the step and event kernels of
+// the passes already queued return at once -- and says why in `halt`
+constexpr int LOOP_CS_HALT = 3;      // LoopState::done value
+constexpr int CS_HALT_GROW = 1;      // nothing was done for this pass: double the list, launch the hook again with resume = 1
+constexpr int CS_HALT_REBIN = 2;     // the pass is complete; rebinCyclosynchCompPhotons is due (mcrat.c:797-808)
+struct CsFrame {
+    int halt;
+    int saved_done;                  // LoopState::done as the pass left it
+    int emitted;                     // replacements since the host last looked (num_cyclosynch_ph_emit)
+    int scatt_num;                   // scatt_cyclosynch_num_ph
+    int max_photons;
     int pad;
-    double weight;      // the weight of the comptonised photon (n_comptonized, mcrat.c:788)
+    unsigned long long last_iteration;   // LoopState::iteration of the last pass the hook handled (queued passes after `done` are no-ops)
+    double n_comptonized;            // mcrat.c:788, summed in pass order
 };
-hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, const LoopState *st, const PhotonDev &ph,
-                             CsHook *out, hipStream_t stream);
+hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, LoopState *st, const PhotonDev &ph,
+                             CsFrame *frame, int resume, hipStream_t stream);
 // the list's null slots in ascending order (addToPhotonList's null_ph_indexes, photons.c:181-189): count per 256 slots, then write
 hipError_t launch_null_count(const PhotonDev &ph, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
 hipError_t launch_null_write(const PhotonDev &ph, const int *block_start, int *null_slots, hipStream_t stream);

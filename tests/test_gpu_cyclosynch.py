@@ -223,6 +223,8 @@ CS_FRAMES = {
     "3d-pool-replace-grow": ("3d", 1, 2000, 0.2, 0, 1, 0.06, 45.0),
     "3d-internal-energy-field": ("3d", 0, 2000, 0.2, 0, 1, 0.06, 45.0),
     "3d-rebin-refused": ("3d", 1, 150, 1.0, 0, 1, 0.06, 45.0),
+    # BASELINE.json configs[4]'s switches at test size: THREE / SPHERICAL, B_FIELD_CALC == SIMULATION, STOKES on; the list doubles twice
+    "3d-spherical-simulation-field": ("3ds", 2, 2000, 0.2, 0, 1, 0.2, 45.0),
 }
 
 
@@ -237,12 +239,19 @@ def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case):
     L = oracle.lib()
     if mesh == "2d":
         frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
-    else:
+    elif mesh == "3d":
         frame, ph, cfg = synth.config_3d_cartesian(n_photons=300, n=(8, 8, 8))
+    else:
+        frame, ph, cfg = synth.config_3d(synth.SPHERICAL, n_photons=300)
     dens = np.ascontiguousarray(frame["dens"])
     c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 1)
     H = oracle.OracleHydro(frame)
-    cs = oracle.CS(b_field_calc, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, 200, 200, 0.5, ang_phi)
+    B = [None, None, None]
+    if b_field_calc == 2:
+        g = np.random.default_rng(5)
+        B = [np.ascontiguousarray(g.uniform(1e3, 1e5, frame["num_elements"])) for _ in range(3)]
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+    cs = oracle.CS(b_field_calc, 0.5, 0.1, ptr(dens), ptr(B[0]), ptr(B[1]), ptr(B[2]), 200, 200, 0.5, ang_phi)
     aos = synth.photons_to_aos(ph, oracle.PHOTON_DTYPE)
     l = oracle.PhotonList()
     L.orc_list_init(C.byref(l))
@@ -261,6 +270,8 @@ def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case):
     buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
     want = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
     L.orc_list_free(C.byref(l))
+    if case == "3d-spherical-simulation-field":
+        assert len(want) == 2400
     if case.endswith("pool-replace-grow"):
         assert len(want) == 1200 and cnt.scatt_cyclosynch_num_ph > 0 and cnt.frame_abs_cnt > 0   # the list doubled inside the loop
     if case == "2d-rebin-in-the-loop":
@@ -272,7 +283,7 @@ def test_scatter_frame_with_the_switch_on_matches_the_oracle(hip, oracle, case):
 
     e = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
     e.set_hydro(frame)
-    e.set_hydro_extras(dens)
+    e.set_hydro_extras(dens, *B)
     e.set_photons_aos(before.astype(hip.PHOTON_DTYPE))
     with pytest.raises(hip.McratHipError):                     # the plain loop has no hook: refused with the switch on
         e.propagate_frame(0.0, remaining, 31)
