@@ -134,8 +134,56 @@ def ingest_vectors():
 
 HOT_GRID = (-5.0, 1.5, -2.5, 1.0)
 
+# cyclo-synchrotron scatter frame (mcrat.c:706-878): cfg2-like frame, 300 injected photons and 300 null slots, a pool,
+# 1500 passes with replacements and a list doubling, the absorption at the end
+CS_FRAME = dict(n_photons=300, nzc=8, lumi=3e53, seed=31, remaining=0.2, max_photons=2000, theta_max=0.05, iterations=1500,
+                b_field_calc=1, epsilon_b=0.5, rebin_e_perc=0.1, rebin_ang=0.5, rebin_ang_phi=10.0, frames=(200, 200))
+CS_FIELDS = ("p0", "p1", "p2", "p3", "comv_p0", "r0", "r1", "r2", "s0", "s1", "s2", "weight", "num_scatt", "nearest_block_index")
+
+
+def cs_frame_inputs():
+    k = CS_FRAME
+    frame, ph, cfg = synth.config2(n_photons=k["n_photons"], nzc=k["nzc"], lumi=k["lumi"])
+    aos = synth.photons_to_aos(ph, O.PHOTON_DTYPE)
+    L = O.lib()
+    l = O.PhotonList()
+    L.orc_list_init(C.byref(l))
+    both = np.concatenate([aos, aos])
+    assert L.orc_list_set(C.byref(l), both.ctypes.data, len(both)) == 0
+    for i in range(k["n_photons"], 2 * k["n_photons"]):
+        assert L.orc_list_set_null(C.byref(l), i) == 0
+    return frame, cfg, l
+
+
+def cs_frame_vector():
+    k = CS_FRAME
+    frame, cfg, l = cs_frame_inputs()
+    L = O.lib()
+    H = O.OracleHydro(frame)
+    c = O.make_config(cfg["dimensions"], cfg["geometry"], 1)
+    dens = np.ascontiguousarray(frame["dens"])
+    cs = O.CS(k["b_field_calc"], k["epsilon_b"], k["rebin_e_perc"], dp(dens), None, None, None, k["frames"][0], k["frames"][1], k["rebin_ang"],
+              k["rebin_ang_phi"])
+    rng = O.Rng()
+    L.orc_rng_init(C.byref(rng), k["seed"], 0)
+    st, cnt, t = O.Stats(), O.CSCounts(), C.c_double(0.0)
+    L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), k["remaining"], 1e12, 1e40, k["max_photons"], 0.0,
+                           k["theta_max"], 1, k["iterations"], C.byref(st), C.byref(cnt))
+    buf = (C.c_char * (l.list_capacity * O.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    v = np.frombuffer(buf, dtype=O.PHOTON_DTYPE).copy()
+    out = {f: np.ascontiguousarray(v[f]) for f in CS_FIELDS}
+    out["type"] = np.frombuffer(v["type"].tobytes(), dtype=np.uint8).copy()
+    out["stats"] = np.array([st.iterations, st.frame_scatt_cnt, st.kn_rejections, cnt.num_cyclosynch_ph_emit, cnt.scatt_cyclosynch_num_ph, cnt.frame_abs_cnt,
+                             cnt.rebins, cnt.error, l.list_capacity, l.num_photons, l.num_null_photons], dtype=np.int64)
+    out["times"] = np.array([t.value, cnt.n_comptonized, cnt.pool_weight])
+    L.orc_list_free(C.byref(l))
+    return out
+
 
 if __name__ == "__main__":
+    np.savez_compressed(os.path.join(HERE, "cs_frame.npz"), **cs_frame_vector())
+    if "--cs-only" in sys.argv:
+        sys.exit(0)
     np.savez_compressed(os.path.join(HERE, "ingest.npz"), **ingest_vectors())
     if "--ingest-only" in sys.argv:
         sys.exit(0)

@@ -121,3 +121,53 @@ def test_hip_engine_reproduces_hot_table_vector():
     got = e.create_hot_cross_section(4, 3, mg.HOT_GRID, calls=4000, seed=123)
     assert np.allclose(got, want, rtol=0, atol=1e-9)
     e.close()
+
+
+def test_oracle_reproduces_cyclosynch_frame_vector(oracle):
+    want = np.load(os.path.join(GOLD, "cs_frame.npz"))
+    got = mg.cs_frame_vector()
+    assert np.array_equal(got["stats"], want["stats"]) and np.array_equal(got["type"], want["type"])
+    assert want["stats"][3] > 100 and want["stats"][4] > 10 and want["stats"][8] == 1200     # replacements happened, the list doubled
+    for k in ("weight", "num_scatt", "nearest_block_index"):
+        assert np.array_equal(got[k], want[k]), k
+    for k in mg.CS_FIELDS:
+        assert np.allclose(got[k], want[k], rtol=1e-11, atol=1e-300), k
+    assert np.allclose(got["times"], want["times"], rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_engine_reproduces_cyclosynch_frame_vector():
+    """the committed cyclo-synchrotron frame without the oracle in the loop: inputs from seeds, expected list from tests/golden"""
+    from mcrat_amd import engine
+    want = np.load(os.path.join(GOLD, "cs_frame.npz"))
+    k = mg.CS_FRAME
+    frame, ph, cfg = synth.config2(n_photons=k["n_photons"], nzc=k["nzc"], lumi=k["lumi"])
+    aos = synth.photons_to_aos(ph, engine.PHOTON_DTYPE)
+    nulls = np.zeros(k["n_photons"], dtype=engine.PHOTON_DTYPE)               # setNullPhoton, photons.c:210-250
+    nulls["type"], nulls["nearest_block_index"] = b"N", -1
+    e = engine.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+    e.set_hydro(frame)
+    e.set_hydro_extras(np.ascontiguousarray(frame["dens"]))
+    e.set_photons_aos(np.concatenate([aos, nulls]))
+    tn, st, cnt = e.scatter_frame_cyclosynch(0.0, k["remaining"], k["seed"], 1e12, 1e40, k["max_photons"], 0.0, k["theta_max"], frame["fps"], emit_pool=1,
+                                             max_iterations=k["iterations"], b_field_calc=k["b_field_calc"], epsilon_b=k["epsilon_b"],
+                                             rebin_e_perc=k["rebin_e_perc"], rebin_ang=k["rebin_ang"], rebin_ang_phi=k["rebin_ang_phi"],
+                                             scatt_frame_number=k["frames"][0], inj_frame_number=k["frames"][1])
+    out = e.get_photons_aos()
+    e.close()
+    nn = int((out["type"] == b"N").sum())
+    assert [st.iterations, st.frame_scatt_cnt, st.kn_rejections, cnt.num_cyclosynch_ph_emit, cnt.scatt_cyclosynch_num_ph, cnt.frame_abs_cnt, cnt.rebins, 0,
+            len(out), len(out) - nn, nn] == list(want["stats"])
+    assert np.array_equal(np.frombuffer(out["type"].tobytes(), dtype=np.uint8), want["type"])
+    for f in ("weight", "num_scatt", "nearest_block_index"):
+        assert np.array_equal(out[f], want[f]), f
+    assert tn == pytest.approx(want["times"][0], rel=1e-12) and cnt.n_comptonized == pytest.approx(want["times"][1], rel=1e-12)
+    assert cnt.pool_weight == want["times"][2]
+    p0 = np.abs(want["p0"])
+    for f in ("p0", "p1", "p2", "p3"):
+        assert _close(out[f], want[f], 1e-9, np.maximum(p0, 1e-300)), f
+    assert _close(out["comv_p0"], want["comv_p0"], 1e-9, np.maximum(np.abs(want["comv_p0"]), 1e-300))
+    for f in ("r0", "r1", "r2"):
+        assert _close(out[f], want[f], 1e-9, np.maximum(np.abs(want[f]), 1e9)), f
+    for f in ("s0", "s1", "s2"):
+        assert _close(out[f], want[f], 1e-9, np.ones_like(want[f])), f
