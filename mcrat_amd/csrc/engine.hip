@@ -1460,19 +1460,15 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
     unsigned *null_cnt = reinterpret_cast<unsigned *>(b + o_nblk);
     int *null_start = reinterpret_cast<int *>(b + o_nstart), *null_slots = reinterpret_cast<int *>(b + o_null);
     if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
-    HIPCHK(c, launch_rebin_assign(c->ph, ax, bin_of, bin_count, c->stream));
-    HIPCHK(c, hipMemsetAsync(empty, 0, 2 * sizeof(unsigned), c->stream));
+    HIPCHK(c, launch_rebin_assign(c->ph, ax, bin_of, bin_count, c->stream));           // zeroes bin_count[0 .. B + 1] first
     HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned) * (size_t)B, c->stream));
     // how many photons take part (= the scan's total): eligible photons are all binned or the call fails
-    std::vector<unsigned> h_cnt((size_t)B);
-    HIPCHK(c, hipMemcpyAsync(h_cnt.data(), bin_count, sizeof(unsigned) * (size_t)B, hipMemcpyDeviceToHost, c->stream));
-    std::vector<int> h_bin((size_t)n);
-    HIPCHK(c, hipMemcpyAsync(h_bin.data(), bin_of, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned> h_cnt((size_t)B + 2);
+    HIPCHK(c, hipMemcpyAsync(h_cnt.data(), bin_count, sizeof(unsigned) * ((size_t)B + 2), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     long long members_total = 0;
-    for (unsigned v : h_cnt) members_total += v;
-    for (int v : h_bin)
-        if (v == -2) { c->last_error = "rebinning: a photon maps to an invalid bin index (the reference exits)"; return MCRAT_HIP_EINVAL; }
+    for (int k = 0; k < B; ++k) members_total += h_cnt[(size_t)k];
+    if (h_cnt[(size_t)B + 1] != 0) { c->last_error = "rebinning: a photon maps to an invalid bin index (the reference exits)"; return MCRAT_HIP_EINVAL; }
     HIPCHK(c, launch_exclusive_scan(bin_count, B, bin_start, bin_start + B + 1, members_total, c->stream));
     HIPCHK(c, launch_rebin_fill(c->ph, bin_of, bin_start, cursor, members, c->stream));
     HIPCHK(c, launch_rebin_create(c->ph, ax, bin_start, members, recs, empty, c->stream));

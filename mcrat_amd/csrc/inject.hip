@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256) void rebin_assign_kernel(PhotonDev ph, RebinAx
         if (idx_x < 0 || idx_x >= ax.num_bins || idx_y < 0 || idx_y >= ax.num_bins_theta || (ax.three && (idx_z < 0 || idx_z >= ax.num_bins_phi))) bin = -2;
         else bin = ax.three ? idx_z * ax.num_bins * ax.num_bins_theta + idx_x * ax.num_bins_theta + idx_y : idx_x * ax.num_bins_theta + idx_y;
         if (bin >= ax.total_bins) bin = -2;
-        if (bin >= 0) atomicAdd(bin_count + bin, 1u);
+        atomicAdd(bin_count + (bin >= 0 ? bin : ax.total_bins + 1), 1u);          // [total_bins + 1]: photons outside the histograms
     }
     bin_of[i] = bin;
 }
@@ -755,7 +755,7 @@ hipError_t launch_rebin_range(const PhotonDev &ph, int three, RebinRange *partia
 
 hipError_t launch_rebin_assign(const PhotonDev &ph, const RebinAxes &ax, int *bin_of, unsigned *bin_count, hipStream_t stream)
 {
-    hipError_t e = hipMemsetAsync(bin_count, 0, sizeof(unsigned) * (size_t)ax.total_bins, stream);
+    hipError_t e = hipMemsetAsync(bin_count, 0, sizeof(unsigned) * ((size_t)ax.total_bins + 2), stream);     // + empty bins, photons outside
     if (e != hipSuccess) return e;
     rebin_assign_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(ph, ax, bin_of, bin_count);
     return hipGetLastError();

@@ -257,9 +257,11 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
 // slow path of one queued slot: mclib.c:528-586 (re-location, comoving momentum, optical depth) or the
 // recalc_properties branch of calcMeanFreePath (mclib.c:668-673), then its free-time draw.  Two dependent load
 // rounds: {photon columns, bucket range} then {bucket entries | the cell's fluid record}.
+// `bits` is the slot's free-path draw of this pass: phase 1 has computed the pair's Philox block anyway (one block serves two
+// slots) and hands the 64 bits over -- for queued slots through the slot's time_to_scatter entry, which this function overwrites.
 template <int DIMS, int GEOM>
 __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, bool relocate, int bucket, bool count_it,
-                                           unsigned long long iter, const RngKey &key, int rng_slot, int &relocated, int &not_found)
+                                           uint64_t bits, int &relocated, int &not_found)
 {
     const int h = i - ph.hot_bias;               // index into the hot columns
     const double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
@@ -324,10 +326,6 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         } else {
             ntau = ph.ntau[h];
         }
-        const uint32_t gslot = (uint32_t)rng_slot + key.slot_base;
-        const Philox4 blk = keyed_block(key.seed, iter, gslot >> 1, RNG_FREEPATH, key.stream);
-        const uint64_t bits = (gslot & 1) ? ((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))
-                                             : ((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32));
         t = sample_free_time(ntau, bits);
     } else {
         t = 1e12 / C_LIGHT;
@@ -420,8 +418,8 @@ __global__ __launch_bounds__(STEP_BLOCK, 3) void step_kernel(PhotonDev ph, Hydro
         T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0, b0);
         T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1, b1);
         if constexpr (FORCE) {
-            if (q0) T.x = slow_one<DIMS, GEOM>(ph, hy, i0, true, b0, false, iter, key, i0, relocated, not_found);
-            if (q1) T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, true, b1, false, iter, key, i0 + 1, relocated, not_found);
+            if (q0) T.x = slow_one<DIMS, GEOM>(ph, hy, i0, true, b0, false, bits0, relocated, not_found);
+            if (q1) T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, true, b1, false, bits1, relocated, not_found);
             q0 = q1 = 0;
         } else {
             // ballot-compact the slots that need the slow path into the workgroup's LDS queue (one LDS atomic
@@ -437,12 +435,14 @@ __global__ __launch_bounds__(STEP_BLOCK, 3) void step_kernel(PhotonDev ph, Hydro
                     if (q0) { const int e = base + __popcll(m0 & below); s_q[e] = i0 | (q0 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b0; }
                     if (q1) { const int e = base + c0 + __popcll(m1 & below); s_q[e] = (i0 + 1) | (q1 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b1; }
                 } else {
-                    if (q0) { T.x = slow_one<DIMS, GEOM>(ph, hy, i0, q0 == 1, b0, true, iter, key, i0, relocated, not_found); q0 = 0; }
-                    if (q1) { T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, q1 == 1, b1, true, iter, key, i0 + 1, relocated, not_found); q1 = 0; }
+                    if (q0) { T.x = slow_one<DIMS, GEOM>(ph, hy, i0, q0 == 1, b0, true, bits0, relocated, not_found); q0 = 0; }
+                    if (q1) { T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, q1 == 1, b1, true, bits1, relocated, not_found); q1 = 0; }
                 }
             }
         }
-        *reinterpret_cast<double2 *>(ph.tts + i0) = T;      // queued slots: placeholder, rewritten in phase 2
+        if (q0) T.x = __longlong_as_double((long long)bits0);   // queued slots: the draw, for phase 2 (which stores the free time)
+        if (q1) T.y = __longlong_as_double((long long)bits1);
+        *reinterpret_cast<double2 *>(ph.tts + i0) = T;
         if ((in.FL.x & FLAG_VALID) && !q0) { best.offer(T.x, i0); if (T.x < t_cut) shortlist_push(sl, T.x, i0); }
         if ((in.FL.y & FLAG_VALID) && !q1) { best.offer(T.y, i0 + 1); if (T.y < t_cut) shortlist_push(sl, T.y, i0 + 1); }
     };
@@ -462,7 +462,8 @@ __global__ __launch_bounds__(STEP_BLOCK, 3) void step_kernel(PhotonDev ph, Hydro
             const int entry = s_q[e];
             if (entry == -1) continue;
             const int i = entry & ~Q_RECALC_ONLY;
-            const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(entry & Q_RECALC_ONLY), s_qb[e], true, iter, key, i, relocated, not_found);
+            const uint64_t bits = (uint64_t)__double_as_longlong(ph.tts[i]);
+            const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(entry & Q_RECALC_ONLY), s_qb[e], true, bits, relocated, not_found);
             best.offer(t, i);
             if (t < t_cut) shortlist_push(sl, t, i);
         }
@@ -970,6 +971,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                             const int e = atomicAdd(&s_qn, 1);                    // < RANK_QCAP: a chunk has no more slots than that
                             s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0);
                             s_qb[e] = bucket;
+                            ph.tts[i] = __longlong_as_double((long long)bits[k]);   // the draw, for phase 2 (which stores the free time)
                             continue;
                         } else {
                             t = tf[k];
@@ -992,7 +994,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             for (int e = tid; e < qn; e += EVENT_BLOCK) {
                 const int il = s_q[e] & ~Q_RECALC_ONLY;
                 const int i = base + il;
-                const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, iter, rk, il, relocated, not_found);
+                const uint64_t qbits = (uint64_t)__double_as_longlong(ph.tts[i]);
+                const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, qbits, relocated, not_found);
                 best.offer(t, i);
                 if (t < t_cut) shortlist_lds(t, i);
             }

@@ -56,6 +56,25 @@ def main():
     timed("chombo ingest 3-D, injection frame", lambda: e.ingest(raw, inj, None))
     timed("chombo ingest 3-D, slab", lambda: e.ingest(raw, dict(slab, min_theta=0.0, max_theta=0.2), None))
     e.close()
+    # a scatter frame with CYCLOSYNCHROTRON_SWITCH on (mcrat.c:706-878): a rank-sized list (3000 injected photons + room for the pool)
+    frame, ph, cfg = synth.config2(n_photons=3000, nzc=8, lumi=3e53)
+    aos = synth.photons_to_aos(ph, engine.PHOTON_DTYPE)
+    nulls = np.zeros(3000, dtype=engine.PHOTON_DTYPE)
+    nulls["type"], nulls["nearest_block_index"] = b"N", -1
+    both = np.concatenate([aos, nulls])
+    e = engine.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+    e.set_hydro(frame)
+    e.set_hydro_extras(np.ascontiguousarray(frame["dens"]))
+
+    def cs_frame():
+        e.set_photons_aos(both)
+        t0 = time.perf_counter()
+        _, st, cnt = e.scatter_frame_cyclosynch(0.0, 0.2, 31, 1e12, 1e40, 20000, 0.0, 0.05, frame["fps"], emit_pool=1, scatt_frame_number=200, inj_frame_number=200)
+        dt = time.perf_counter() - t0
+        return "%d passes, %d scatterings, %d emitted, %d absorbed, %d slots, %.1f us/pass" % (
+            st.iterations, st.frame_scatt_cnt, cnt.num_cyclosynch_ph_emit, cnt.frame_abs_cnt, e.n, dt * 1e6 / max(st.iterations, 1))
+    timed("cyclo-synchrotron frame, 3000+pool", cs_frame)
+    e.close()
 
 
 if __name__ == "__main__":
