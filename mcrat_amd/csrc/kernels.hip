@@ -503,7 +503,8 @@ struct EventWalk {
 // into the comoving frame, electron draw, singleScatter, boost back.  r is the candidate's position at the event.
 // Returns false on a Klein-Nishina rejection (p, pc, s are then unspecified, nothing was stored).  tau_new is the
 // optical depth of the new momentum in the cached cell (see commit_scatter).
-template <int DIMS, int GEOM, bool STOKES>
+// WAVE: called by all 64 lanes of a wavefront with the same arguments (event_block's walk); see phys::sample_thermal_electron.
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
 __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter,
                                              uint32_t rng_slot, int cell, const double r[3], double p[4], double pc[4], double s[4],
                                              double &fluid_temp, double &tau_new)
@@ -519,7 +520,7 @@ __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, 
     const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
     double el[4];
     MC_STAMP(st, 3);
-    phys::single_thermal_electron(el, fluid_temp, k2e, pc, rng);       // mclib.c:1234
+    phys::single_thermal_electron<WAVE>(el, fluid_temp, k2e, pc, rng); // mclib.c:1234
     MC_STAMP(st, 4);
     if (!phys::single_scatter<STOKES>(el, pc, s, rng)) return false;   // mclib.c:1245
     MC_STAMP(st, 5);
@@ -531,7 +532,7 @@ __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, 
     // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
     const CellFluid f = hy.fluid[cell];
     double norm = 1.0;
-    if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], fluid_temp);          // optical_depth.c:58
+    if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], fluid_temp, !WAVE || (threadIdx.x & 63) == 0);   // optical_depth.c:58
     tau_new = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p[1], p[2], p[3], norm);
     return true;
 }
@@ -558,7 +559,7 @@ __device__ __forceinline__ void commit_scatter(const PhotonDev &ph, int i, const
 }
 
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
-template <int DIMS, int GEOM, bool STOKES>
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
 __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
                                              unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base)
 {
@@ -599,7 +600,7 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
         }
     }
     double fluid_temp, tau_new;
-    if (!scatter_core<DIMS, GEOM, STOKES>(hy, st, key, iter, (uint32_t)(i - slot_base) + key.slot_base, cell, r, p, pc, s, fluid_temp, tau_new)) {
+    if (!scatter_core<DIMS, GEOM, STOKES, WAVE>(hy, st, key, iter, (uint32_t)(i - slot_base) + key.slot_base, cell, r, p, pc, s, fluid_temp, tau_new)) {
         w.rej += 1;
         return EV_RUNNING;
     }
@@ -661,15 +662,24 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
 
     const Cand *list = sh.list;
     const int max_rounds = n / TOPK + 3;
+    // The walk runs on the whole first wavefront, all 64 lanes with the same values (a wave instruction costs the same for one lane
+    // as for 64, and every store below then writes one value to one address from every lane), so that the one loop of the scatter
+    // with a long trip count -- the hot electron's rejection sampling -- can try 64 attempts at a time (physics.hpp).
+    // (-DMCRAT_NO_WAVE_WALK=1 builds the one-lane walk for A/B runs, tools/hot_bench.py.)
+#ifdef MCRAT_NO_WAVE_WALK
+    constexpr bool WAVE_WALK = false;
+#else
+    constexpr bool WAVE_WALK = true;
+#endif
     for (int round = 0; round < max_rounds; ++round) {
-        if (tid == 0) {
+        if (WAVE_WALK ? tid < 64 : tid == 0) {
             int status = EV_NEED_MORE;
             if (n_list == 0) {                             // every slot was tried (or there is none): mclib.c:1128 loop ends
                 w.dt = (round == 0) ? w.dt_max : w.old_scatt_time;
                 status = EV_DONE;
             }
             for (int c = 0; c < n_list && status == EV_NEED_MORE; ++c) {
-                if (try_candidate<DIMS, GEOM, STOKES>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base) == EV_DONE)
+                if (try_candidate<DIMS, GEOM, STOKES, WAVE_WALK>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base) == EV_DONE)
                     status = EV_DONE;
             }
             if (status == EV_NEED_MORE) {

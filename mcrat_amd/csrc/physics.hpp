@@ -262,7 +262,7 @@ __device__ __forceinline__ int table_cell(double x0, double dx, int n_cells, dou
     return i;
 }
 
-__device__ __forceinline__ double thermal_cross_section(const HydroDev &h, double photon_comv_e, double fluid_temp)
+__device__ __forceinline__ double thermal_cross_section(const HydroDev &h, double photon_comv_e, double fluid_temp, bool count = true)
 {
     if (!h.hot_table) return 1.0;
     const double normalized_photon_comv_e = photon_comv_e / (M_EL * C_LIGHT);
@@ -274,7 +274,7 @@ __device__ __forceinline__ double thermal_cross_section(const HydroDev &h, doubl
     if (x > x_hi) { x = x_hi; out = true; }
     if (!(y >= h.hot_t0)) { y = h.hot_t0; out = true; }
     if (y > y_hi) { y = y_hi; out = true; }
-    if (out) atomicAdd(h.table_misses, 1);
+    if (out && count) atomicAdd(h.table_misses, 1);
     const int xi = table_cell(h.hot_e0, h.hot_de, h.hot_n_ph_e, x);
     const int yi = table_cell(h.hot_t0, h.hot_dt, h.hot_n_t, y);
     const double xmin = h.hot_e0 + xi * h.hot_de, xmax = h.hot_e0 + (xi + 1) * h.hot_de;
@@ -403,19 +403,53 @@ __device__ __forceinline__ double gaussian(EventStream &rng, double sigma)
 // electron.c:202-237.  k2e = exp(1/Theta) K_2(1/Theta) of the cell (HydroDev::k2e): the reference's
 // x^2 beta exp(-x/Theta) / K_2(1/Theta) is evaluated as x^2 beta exp(-(x-1)/Theta) / k2e, the same number
 // without the e^-600 intermediate.
+// WAVE: the caller is a full wavefront whose 64 lanes hold the same arguments and the same stream (the event walk).  The
+// Maxwell-Juettner rejection loop accepts one attempt in 50 to 300 (the envelope is the reference's: x uniform up to 1 + 100 Theta,
+// y uniform up to 1/2), and every attempt takes exactly two numbers of the stream, so lane k tries attempt 64 j + k of round j --
+// the stream is a counter, any position is one addition away -- and the first accepted attempt in attempt order wins: the same
+// gamma and the same stream position as the one-lane loop, in a sixty-fourth of its trips.
+template <bool WAVE = false>
 __device__ __forceinline__ double sample_thermal_electron(double temp, double k2e, EventStream &rng)
 {
     double gamma = 1;
     if (temp >= 1e7) {
         const double factor = K_B * temp / (M_EL * C_LIGHT * C_LIGHT);
-        double x_dum = 1, y_dum = 1, f_x_dum = 0;
-        for (int it = 0; it < REJECTION_CAP && ((f_x_dum != f_x_dum) || (y_dum > f_x_dum)); ++it) {
-            x_dum = rng.uniform_pos() * (1 + 100 * factor);
-            const double beta_x_dum = sqrt(1 - (1 / (x_dum * x_dum)));
-            y_dum = rng.uniform() / 2.0;
-            f_x_dum = x_dum * x_dum * (beta_x_dum / k2e) * exp(-1 * (x_dum - 1.0) / factor);
+        if constexpr (WAVE) {
+            static_assert(REJECTION_CAP % 64 == 0, "whole rounds");
+            const int lane = (int)(threadIdx.x & 63);
+            const uint64_t base = rng.state;
+            double x_dum = 1;
+            bool accepted = false;
+            for (int it0 = 0; it0 < REJECTION_CAP && !accepted; it0 += 64) {
+                EventStream r;
+                r.state = base + 0x9E3779B97F4A7C15ull * (uint64_t)(2 * (it0 + lane));
+                x_dum = r.uniform_pos() * (1 + 100 * factor);
+                const double beta_x_dum = sqrt(1 - (1 / (x_dum * x_dum)));
+                const double y_dum = r.uniform() / 2.0;
+                const double f_x_dum = x_dum * x_dum * (beta_x_dum / k2e) * exp(-1 * (x_dum - 1.0) / factor);
+                const unsigned long long ok = __ballot(!((f_x_dum != f_x_dum) || (y_dum > f_x_dum)));
+                if (ok) {
+                    const int first = __ffsll((long long)ok) - 1;
+                    x_dum = __shfl(x_dum, first);
+                    rng.state = base + 0x9E3779B97F4A7C15ull * (uint64_t)(2 * (it0 + first + 1));
+                    accepted = true;
+                }
+            }
+            if (!accepted) {                                   // the bounded loop ran out: its last attempt stands
+                x_dum = __shfl(x_dum, 63);
+                rng.state = base + 0x9E3779B97F4A7C15ull * (uint64_t)(2ull * REJECTION_CAP);
+            }
+            gamma = x_dum;
+        } else {
+            double x_dum = 1, y_dum = 1, f_x_dum = 0;
+            for (int it = 0; it < REJECTION_CAP && ((f_x_dum != f_x_dum) || (y_dum > f_x_dum)); ++it) {
+                x_dum = rng.uniform_pos() * (1 + 100 * factor);
+                const double beta_x_dum = sqrt(1 - (1 / (x_dum * x_dum)));
+                y_dum = rng.uniform() / 2.0;
+                f_x_dum = x_dum * x_dum * (beta_x_dum / k2e) * exp(-1 * (x_dum - 1.0) / factor);
+            }
+            gamma = x_dum;
         }
-        gamma = x_dum;
     } else {
         const double factor = sqrt(K_B * temp / M_EL);
         const double g1 = gaussian(rng, factor) / C_LIGHT;
@@ -427,9 +461,10 @@ __device__ __forceinline__ double sample_thermal_electron(double temp, double k2
 }
 
 // electron.c:70-94 with sampleElectronTheta (:177-200) and rotateElectron (:126-175) in line
+template <bool WAVE = false>
 __device__ __forceinline__ void single_thermal_electron(double el_p[4], double temp, double k2e, const double ph_p[4], EventStream &rng)
 {
-    const double gamma = sample_thermal_electron(temp, k2e, rng);
+    const double gamma = sample_thermal_electron<WAVE>(temp, k2e, rng);
     const double beta = sqrt(1 - (1 / (gamma * gamma)));
     const double phi = rng.uniform() * 2 * M_PI;
     // theta = acos(ct): only cos(theta) = ct and sin(theta) = sqrt(1 - ct^2) are used

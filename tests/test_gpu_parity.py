@@ -167,6 +167,9 @@ CASES = {
     "cfg2-cylindrical-jet-stokes": (synth.config2, dict(n_photons=1500, nzc=8, stokes=1, lumi=1e54), 1000),
     "cfg3-spherical-jet-stokes": (synth.config3, dict(n_photons=2000, nr=256, nth=128, lumi=1e54), 1000),
     "cfg2-cylindrical-jet-thin": (synth.config2, dict(n_photons=2000, nzc=8), 0),
+    # ten times closer to the engine the jet is at 3e7 K: the Maxwell-Juttner branch (electron.c:207-226), whose rejection loop takes
+    # ~150 attempts per electron -- several 64-attempt rounds of the event walk's wavefront (physics.hpp, sample_thermal_electron)
+    "cfg2-hot-inner-jet-stokes": (synth.config2, dict(n_photons=2000, nzc=8, stokes=1, lumi=1e54, r_inj=1e11, block_side=2.5e7), 1000),
     "3d-cartesian-wind-stokes": (synth.config_3d_cartesian, dict(n_photons=1500), 800),
     # every (DIMENSIONS, GEOMETRY) pair the reference supports (mcrat.h:196-204)
     "2.5d-cylindrical-toroidal-flow-stokes": (synth.config_25d, dict(geometry=synth.CYLINDRICAL), 700),
@@ -341,13 +344,16 @@ def test_errors_are_reported_not_fatal(hip):
 
 
 # ------------------------------------------------------------------ virtual ranks
-@pytest.mark.parametrize("case", ["cfg1", "cfg2-stokes", "cfg3-stokes"])
+@pytest.mark.parametrize("case", ["cfg1", "cfg2-hot", "cfg2-stokes", "cfg3-stokes"])
 def test_virtual_ranks_equal_independent_lists(hip, oracle, case):
     """virtual_rank_photons = n: every block of n consecutive slots is an independent photon list with its own
     clock and RNG stream rng_stream + r -- the reference's many-ranks run shape.  Each must equal the oracle run
     on that sub-list alone (slot indices restart at 0, stream = first_stream + r), including the short last rank."""
     if case == "cfg1":
         frame, ph, cfg = synth.config1(n_photons=3000, n0=32, n1=32)
+    elif case == "cfg2-hot":
+        frame, ph, cfg = synth.config2(n_photons=3000, nzc=8, lumi=1e54, r_inj=1e11, block_side=2.5e7)
+        assert frame["temp"].min() > 1e7
     elif case == "cfg2-stokes":
         frame, ph, cfg = synth.config2(n_photons=3000, nzc=8, stokes=1, lumi=1e54)
     else:
