@@ -1750,6 +1750,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     *c->h_state = h;                               // the host's view until the next read-back (every read-back is followed by a wait)
     HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     if (c->sc_world > 0) HIPCHK(c, hipMemsetAsync(c->d_sc, 0, sizeof(ScState), c->stream));
+    if (c->graph_exec && c->key.seed != seed) drop_graph(c);      // the captured launches carry the key by value
     c->key.seed = seed;
     c->find_switch = 1;           // mcrat.c:756
     c->pending_applied = false;
@@ -1967,12 +1968,16 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
     while (!c->h_state->done && (max_iterations <= 0 || c->h_state->iterations < max_iterations)) {   // :761-851
         long long batch = per_sync;
         if (max_iterations > 0 && batch > max_iterations - c->h_state->iterations) batch = max_iterations - c->h_state->iterations;
-        for (long long b = 0; b < batch; ++b) {
-            HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
-            c->find_switch = 0;
+        auto one_pass = [&](bool force) -> int {
+            HIPCHK(c, launch_step(c->kc, force, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
             HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
             HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
             HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, d_cf, 0, c->stream));
+            return MCRAT_HIP_OK;
+        };
+        for (long long b = 0; b < batch; ++b) {       // (a batch as one hipGraph launch was measured: 33.7 against 34.6 us per pass, not kept)
+            if ((rc = one_pass(c->find_switch != 0))) return rc;
+            c->find_switch = 0;
         }
         HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(&cf, d_cf, sizeof cf, hipMemcpyDeviceToHost, c->stream));

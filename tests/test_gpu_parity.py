@@ -259,6 +259,22 @@ def test_split_runs_graph_and_profile_modes_are_bitwise_identical(hip):
             assert np.array_equal(out[k], base[k]), (name, k)
         if name == "profile":
             assert st.step_kernel_launches == iters and st.step_kernel_ms > 0 and st.event_kernel_ms > 0
+    # a captured graph carries the frame's key: a second frame on the same context with another seed must not replay the first one's
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], use_graph=True, iterations_per_sync=50)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    e.snapshot_photons()
+    e.begin_frame(seed + 1, t0, rem)
+    e.run(iters)
+    other = e.get_photons()
+    e.restore_photons()
+    e.begin_frame(seed, t0, rem)
+    e.run(iters)
+    again = e.get_photons()
+    e.close()
+    assert not np.array_equal(other["p0"], base["p0"])
+    for k in FLOAT_FIELDS + INT_FIELDS:
+        assert np.array_equal(again[k], base[k]), ("graph after a seed change", k)
     # the same frame in three calls
     e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
     e.set_hydro(frame)
