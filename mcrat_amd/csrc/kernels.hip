@@ -366,7 +366,10 @@ __device__ __forceinline__ PairIn load_pair(const PhotonDev &ph, int i0, bool ne
 // LDS queue the few slots that need the slow path, then finishes those with dense lanes (phase 2) and
 // publishes its minimum.  On the forced pass of a new frame every slot takes the slow path, in line.
 template <int DIMS, int GEOM, bool FORCE>
-__global__ __launch_bounds__(STEP_BLOCK, 3) void step_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
+#ifndef STEP_WAVES_PER_SIMD
+#define STEP_WAVES_PER_SIMD 3
+#endif
+__global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
                                                           Cand *__restrict__ block_min, Shortlist *sl)
 {
     __shared__ int s_qn;
