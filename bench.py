@@ -478,6 +478,41 @@ def main():
         except Exception as ex:
             ingest = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
+    def measure_hot():
+        """the same jet ten times closer to the engine: every cell above 1e7 K, where the reference's Maxwell-Juttner sampler accepts one
+        attempt in ~150 and the event walk's wavefront tries 64 at a time; 300 passes per list"""
+        hframe, hph, hcfg = synth.config2(n_photons=args.photons, seed=SEED + rank, nzc=args.nzc, stokes=args.stokes, lumi=1e54, r_inj=1e11,
+                                          block_side=2.5e7)
+        e = engine.Engine(hcfg["dimensions"], hcfg["geometry"], hcfg["stokes"], device=local_rank, stream=stream, rng_stream=first_stream,
+                          virtual_rank_photons=args.rank_photons)
+        e.set_hydro(hframe)
+        e.set_photons(hph)
+        e.snapshot_photons()
+        best = None
+        for _ in range(3):
+            e.restore_photons()
+            e.begin_frame(SEED, 0.0, 1.0 / hframe["fps"])
+            e.run(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = e.run(300)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, int(st.frame_scatt_cnt), int(st.iterations))
+        e.close()
+        return {"workload": "cfg2 jet at r_inj = 1e11 cm, L = 1e54 erg/s: T' = %.1e .. %.1e K; %d lists x %d photons, 300 passes each"
+                            % (float(hframe["temp"].min()), float(hframe["temp"].max()), (args.photons + args.rank_photons - 1) // args.rank_photons,
+                               args.rank_photons),
+                "scatter_events_per_s": best[1] / best[0], "ms": best[0] * 1e3, "scatter_events": best[1], "loop_passes": best[2]}
+
+    hot = None
+    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode:
+        try:
+            hot = measure_hot()
+        except Exception as ex:
+            hot = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -531,6 +566,7 @@ def main():
             "other_mode": other,
             "pcie_inclusive": pcie,
             "ingest": ingest,
+            "hot_frame": hot,
             "cpu_baseline": cpu,
             "cpu_optimised": cpu_opt,
         }

@@ -491,6 +491,11 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
 
 // ------------------------------------------------------------------ event kernel
 enum { EV_RUNNING = 0, EV_DONE = 1, EV_NEED_MORE = 2 };
+#ifdef MCRAT_NO_WAVE_WALK
+constexpr bool WAVE_WALK = false;    // photonEvent's walk on one lane
+#else
+constexpr bool WAVE_WALK = true;     // ... on a whole wavefront with the same values in every lane (event_block)
+#endif
 
 // thread 0's state while it walks the sorted candidates, photonEvent mclib.c:1128-1339
 struct EventWalk {
@@ -669,11 +674,6 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
     // as for 64, and every store below then writes one value to one address from every lane), so that the one loop of the scatter
     // with a long trip count -- the hot electron's rejection sampling -- can try 64 attempts at a time (physics.hpp).
     // (-DMCRAT_NO_WAVE_WALK=1 builds the one-lane walk for A/B runs, tools/hot_bench.py.)
-#ifdef MCRAT_NO_WAVE_WALK
-    constexpr bool WAVE_WALK = false;
-#else
-    constexpr bool WAVE_WALK = true;
-#endif
     for (int round = 0; round < max_rounds; ++round) {
         if (WAVE_WALK ? tid < 64 : tid == 0) {
             int status = EV_NEED_MORE;
@@ -1249,7 +1249,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void sc_resolve_kernel(PhotonDev ph, H
         s_order[rank] = tid;
     }
     __syncthreads();
-    if (tid != 0) return;
+    if (WAVE_WALK ? tid >= 64 : tid != 0) return;         // the walk: one wavefront, every lane the same values (see event_block)
 
     double hor_t = INFINITY;
     long long hor_g = LLONG_MAX;
@@ -1301,7 +1301,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void sc_resolve_kernel(PhotonDev ph, H
         double pc[4] = {c.pc[0], c.pc[1], c.pc[2], c.pc[3]};
         double s[4] = {c.s[0], c.s[1], c.s[2], c.s[3]};
         double fluid_temp, tau_new;
-        if (!scatter_core<DIMS, GEOM, STOKES>(hy, st, key, iter, (uint32_t)c.gid, c.cell, r, p, pc, s, fluid_temp, tau_new)) {
+        if (!scatter_core<DIMS, GEOM, STOKES, WAVE_WALK>(hy, st, key, iter, (uint32_t)c.gid, c.cell, r, p, pc, s, fluid_temp, tau_new)) {
             rej += 1;
             continue;
         }
