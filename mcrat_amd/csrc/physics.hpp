@@ -463,9 +463,40 @@ __device__ __forceinline__ double sample_thermal_electron(double temp, double k2
         }
     } else {
         const double factor = sqrt(K_B * temp / M_EL);
-        const double g1 = gaussian(rng, factor) / C_LIGHT;
-        const double g2 = gaussian(rng, factor) / C_LIGHT;
-        const double g3 = gaussian(rng, factor) / C_LIGHT;
+        double g1, g2, g3;
+        if constexpr (WAVE) {
+            // The three Gaussians (Marsaglia's polar method, 79 % of its attempts accepted) draw from one sequence of attempts, two
+            // numbers each: the first, second and third accepted attempt are the three values.  Lane k evaluates attempt k.
+            const int lane = (int)(threadIdx.x & 63);
+            double v0 = 0, v1 = 0, v2 = 0;
+            int found = 0;
+            uint64_t base = rng.state;
+            for (int round = 0; round < REJECTION_CAP / 64 && found < 3; ++round) {
+                EventStream r;
+                r.state = base + 0x9E3779B97F4A7C15ull * (uint64_t)(2 * lane);
+                const double x = -1.0 + 2.0 * r.uniform_pos();
+                const double y = -1.0 + 2.0 * r.uniform_pos();
+                const double r2 = x * x + y * y;
+                const double v = factor * y * sqrt(-2.0 * log(r2) / r2);
+                unsigned long long ok = __ballot(!(r2 > 1.0 || r2 == 0.0));
+                int used = 64;                                     // attempts of this round the serial loops would have made
+                while (ok && found < 3) {
+                    const int a = __ffsll((long long)ok) - 1;
+                    const double picked = __shfl(v, a);
+                    if (found == 0) v0 = picked; else if (found == 1) v1 = picked; else v2 = picked;
+                    ++found;
+                    ok &= ok - 1;
+                    if (found == 3) used = a + 1;
+                }
+                base += 0x9E3779B97F4A7C15ull * (uint64_t)(2 * used);
+            }
+            rng.state = base;
+            g1 = v0 / C_LIGHT; g2 = v1 / C_LIGHT; g3 = v2 / C_LIGHT;
+        } else {
+            g1 = gaussian(rng, factor) / C_LIGHT;
+            g2 = gaussian(rng, factor) / C_LIGHT;
+            g3 = gaussian(rng, factor) / C_LIGHT;
+        }
         gamma = 1.0 / sqrt(1 - ((g1 * g1 + g2 * g2) + g3 * g3));
     }
     return gamma;
