@@ -170,6 +170,8 @@ CASES = {
     # ten times closer to the engine the jet is at 3e7 K: the Maxwell-Juttner branch (electron.c:207-226), whose rejection loop takes
     # ~150 attempts per electron -- several 64-attempt rounds of the event walk's wavefront (physics.hpp, sample_thermal_electron)
     "cfg2-hot-inner-jet-stokes": (synth.config2, dict(n_photons=2000, nzc=8, stokes=1, lumi=1e54, r_inj=1e11, block_side=2.5e7), 1000),
+    # just above the 1e7 K switch (1.7e7 K) the sampler accepts one attempt in ~250: four or five rounds per electron
+    "cfg2-warm-inner-jet": (synth.config2, dict(n_photons=2000, nzc=8, lumi=1e53, r_inj=1e11, block_side=2.5e7), 800),
     "3d-cartesian-wind-stokes": (synth.config_3d_cartesian, dict(n_photons=1500), 800),
     # every (DIMENSIONS, GEOMETRY) pair the reference supports (mcrat.h:196-204)
     "2.5d-cylindrical-toroidal-flow-stokes": (synth.config_25d, dict(geometry=synth.CYLINDRICAL), 700),
