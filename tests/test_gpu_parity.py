@@ -452,8 +452,13 @@ def test_virtual_ranks_are_deterministic_and_equal_single_list_contexts_at_scale
     frame, ph, cfg = synth.config2(n_photons=n)
     rem = 1.0 / frame["fps"]
     runs = []
-    for split, block in ((False, "256"), (True, "256"), (False, "128")):       # 128: four lists per CU, same arithmetic
+    # 128: four lists per CU, same arithmetic; the last run keeps the lists' columns in HBM/L2 instead of LDS (the path long lists take)
+    for split, block, no_lds in ((False, "256", False), (True, "256", False), (False, "128", False), (False, "256", True)):
         monkeypatch.setenv("MCRAT_HIP_RANK_BLOCK", block)
+        if no_lds:
+            monkeypatch.setenv("MCRAT_HIP_NO_LDS_LISTS", "1")
+        else:
+            monkeypatch.delenv("MCRAT_HIP_NO_LDS_LISTS", raising=False)
         e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=per)
         e.set_hydro(frame)
         e.set_photons(ph)
