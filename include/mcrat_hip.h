@@ -414,6 +414,39 @@ int mcrat_hip_restore_photons(mcrat_hip_ctx *ctx);
 int mcrat_hip_num_virtual_ranks(const mcrat_hip_ctx *ctx);
 int mcrat_hip_rank_stats(mcrat_hip_ctx *ctx, int rank, mcrat_hip_frame_stats *stats);
 
+/* Rank pool: the reference's run shape on one GPU ------------------------------------------------------------------
+ * MCRaT is run as 150-600 MPI ranks of 10^3 - 5*10^3 photons (Doc/mcrat_doc.tex:165-166,222): every rank owns an
+ * (angle bin, injection-frame range) of mcrat.c:139-164,457-479, a Poisson-sized photon list (mclib.c:87-136), its own
+ * generator (mcrat.c:99-103,701), its own clock, and its own mc_proc_<rank>.h5 / mc_chkpt_<rank>.dat
+ * (mcrat_io.c:199-200,871-903); ranks never talk inside the loop.  A pool lets ONE process per GPU adopt R such ranks:
+ *   mcrat_hip_pool_create   turns `pool` into R lists of up to slots_per_rank slots each (slots_per_rank >= the longest list
+ *                           a rank will ever hold: max_photons, times the doublings cyclo-synchrotron emission may need)
+ *   mcrat_hip_pool_rank     the *view* of list `rank`: a context whose photons, loop state and clock are that list's and
+ *                           whose hydro frame is the pool's.  Every per-list entry point of this header works on a view
+ *                           exactly as on a context of its own holding only that list with rng_stream `rng_stream`:
+ *                           mcrat_hip_set_photons / _inject_photons (the rank joins), _begin_frame (its seed and clock),
+ *                           _ph_minmax, _scatt_stats, _get_output, _get_photons_range, _get_photons ... A view is
+ *                           destroyed with mcrat_hip_destroy or with its pool; set_hydro / ingest go to the pool.
+ *   mcrat_hip_run(pool)     the loop of mcrat.c:761-851 for every list whose view has an open frame (mcrat_hip_begin_frame
+ *                           on the view), all lists in ONE launch, one workgroup per list (rank_loop_kernel) -- each list
+ *                           sees exactly the arithmetic and the random numbers of a context of its own.  The stats are the
+ *                           totals; mcrat_hip_frame_statistics(view) gives a list's own.  mcrat_hip_begin_frame(pool)
+ *                           opens a frame for all lists at once with one seed and clock.
+ *   mcrat_hip_pool_summaries  phMinMax, phScattStats, averagePhotonEnergy and printPhotons' photon count for every list in
+ *                           one launch (lists that do not exist: list_capacity 0).
+ * mcrat_host_run_ranks (mcrat_amd/host) is main()'s rank logic on top of this; INTEGRATION.md shows the edit. */
+typedef struct mcrat_hip_rank_summary {
+    double min_r, max_r, min_theta, max_theta;   /* phMinMax, mclib.c:1465 */
+    double avg_scatt, avg_r;                     /* phScattStats, mclib.c:1385 */
+    double avg_energy;                           /* averagePhotonEnergy, mclib.c:1358 */
+    int    max_scatt, min_scatt;
+    int    num_output;                           /* photons with weight != 0: what printPhotons writes (mcrat_io.c:137-181) */
+    int    list_capacity;                        /* photon_list->list_capacity of this rank (0: no list) */
+} mcrat_hip_rank_summary;
+int mcrat_hip_pool_create(mcrat_hip_ctx *pool, int n_ranks, int slots_per_rank);
+int mcrat_hip_pool_rank(mcrat_hip_ctx *pool, int rank, uint32_t rng_stream, mcrat_hip_ctx **view);
+int mcrat_hip_pool_summaries(mcrat_hip_ctx *pool, mcrat_hip_rank_summary *out /* [n_ranks] */);
+
 /* function-granular A/B entry points (one kernel each, for parity tests against the
  * reference functions): the findContainingHydroCell + calcMeanFreePath half of an
  * iteration and the photonEvent half.  mcrat_amd/host/mcrat_hip_host.h wraps them in shims with the reference's

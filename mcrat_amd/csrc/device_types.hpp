@@ -173,6 +173,13 @@ struct alignas(16) Shortlist {
     Cand items[SHORTLIST_CAP];
 };
 
+// one list of a rank pool (kernels.hip, RankLayout)
+struct alignas(16) RankDesc {
+    int len;                     // list_capacity of this rank's list (0: the rank sits this launch out)
+    uint32_t stream;             // its random stream (RngKey::stream of a single-list context holding only its photons)
+    uint64_t seed;               // its per-frame seed
+};
+
 struct RngKey {
     uint64_t seed;
     uint32_t stream;

@@ -89,6 +89,19 @@ struct mcrat_hip_ctx {
     LoopState *h_rstates = nullptr;   // pinned
     int rstates_cap = 0;
 
+    // rank pool (mcrat_hip_pool_*): the photon arrays hold n_ranks lists of up to rank_stride slots, each with its own length,
+    // seed, stream and clock -- the reference's MPI ranks, adopted by one GPU.  List r is reached through a *view*: a context
+    // whose columns, LoopState and scratch are windows into this one, so that every per-list entry point (injection, reductions,
+    // output columns, checkpoint records, ...) works on one rank's list unchanged.
+    bool is_pool = false;
+    int rank_stride = 0;              // slots reserved per list (pool), or cfg.virtual_rank_photons
+    std::vector<mcrat_hip_ctx *> views;
+    RankDesc *d_desc = nullptr;
+    RankDesc *h_desc = nullptr;       // pinned
+    mcrat_hip_ctx *parent = nullptr;  // this context is the view of list view_rank of `parent`
+    int view_rank = -1;
+    uint32_t view_stream = 0;
+
     // one list over several GPUs, one clock (mcrat_hip_shared_clock_*)
     int sc_world = 0, sc_rank = 0;
     ScState *d_sc = nullptr;
@@ -128,6 +141,9 @@ static void drop_graph(mcrat_hip_ctx *c)
     if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
     c->graph_batch = 0;
 }
+
+static void sync_views(mcrat_hip_ctx *c);
+static int view_refuses(mcrat_hip_ctx *c, const char *what);
 
 extern "C" const char *mcrat_hip_version(void) { return "mcrat_hip 0.1 (gfx950, abi 1)"; }
 
@@ -202,12 +218,33 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
     return MCRAT_HIP_OK;
 }
 
+static void destroy_view(mcrat_hip_ctx *v)
+{
+    // a view owns nothing but the scratch it allocated itself
+    if (v->stream) (void)hipStreamSynchronize(v->stream);
+    if (v->aos_buf) (void)hipFree(v->aos_buf);
+    if (v->grid_count) (void)hipFree(v->grid_count);
+    if (v->d_grid_total) (void)hipFree(v->d_grid_total);
+    if (v->d_cs_hook) (void)hipFree(v->d_cs_hook);
+    if (v->ph_snap) (void)hipFree(v->ph_snap);
+    for (hipEvent_t e : v->ev) (void)hipEventDestroy(e);
+    if (v->parent && v->view_rank >= 0 && v->view_rank < (int)v->parent->views.size() && v->parent->views[v->view_rank] == v)
+        v->parent->views[v->view_rank] = nullptr;
+    delete v;
+}
+
 extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
 {
     if (!c) return;
+    if (c->parent) { destroy_view(c); return; }
+    for (mcrat_hip_ctx *v : c->views)
+        if (v) { v->parent = nullptr; destroy_view(v); }
+    c->views.clear();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    if (c->d_desc) (void)hipFree(c->d_desc);
+    if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->ph_buf) (void)hipFree(c->ph_buf);
     if (c->ph_snap) (void)hipFree(c->ph_snap);
     if (c->aos_buf) (void)hipFree(c->aos_buf);
@@ -481,6 +518,7 @@ extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *t
                                                double log_ph_e_min, double log_ph_e_max, double log_t_min, double log_t_max)
 {
     if (!c || !thermal_table || n_ph_e < 1 || n_t < 1 || !(log_ph_e_max > log_ph_e_min) || !(log_t_max > log_t_min)) return MCRAT_HIP_EINVAL;
+    if (c->parent) return view_refuses(c, "set_hot_cross_section");
     if (c->cfg.tau_calculation != MCRAT_HIP_TAU_TABLE) { c->last_error = "the context was created with TAU_CALCULATION == DIRECT"; return MCRAT_HIP_ESTATE; }
     const size_t count = (size_t)(n_ph_e + 1) * (size_t)(n_t + 1);
     for (size_t k = 0; k < count; ++k)
@@ -493,11 +531,32 @@ extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *t
     c->hot_grid[0] = log_ph_e_min; c->hot_grid[1] = log_ph_e_max; c->hot_grid[2] = log_t_min; c->hot_grid[3] = log_t_max;
     apply_hot_table(c);
     drop_graph(c);
+    sync_views(c);
     return MCRAT_HIP_OK;
 }
 
 static int ensure_aos(mcrat_hip_ctx *c, size_t bytes);
 static int flush_pending(mcrat_hip_ctx *c);
+
+// rank pool: the views read the pool's hydro frame (and cross-section table) through copies of its descriptors
+static void sync_views(mcrat_hip_ctx *c)
+{
+    for (mcrat_hip_ctx *v : c->views) {
+        if (!v) continue;
+        v->hy = c->hy;
+        v->hcol = c->hcol; v->hcol_buf = c->hcol_buf; v->hcol_M = c->hcol_M;
+        v->have_hydro = c->have_hydro;
+        v->d_hot_table = c->d_hot_table; v->hot_n_ph_e = c->hot_n_ph_e; v->hot_n_t = c->hot_n_t;
+        for (int k = 0; k < 4; ++k) v->hot_grid[k] = c->hot_grid[k];
+        drop_graph(v);
+    }
+}
+
+static int view_refuses(mcrat_hip_ctx *c, const char *what)
+{
+    c->last_error = std::string(what) + ": a rank view shares its pool's hydro frame; call this on the pool context";
+    return MCRAT_HIP_ESTATE;
+}
 
 // The frame's per-cell records and cell-lookup grid.  h == nullptr (the product path): from the device columns c->hcol,
 // on the device -- stage_cells_kernel (ingest.hip) + grid_build.hip; the host only plans the bucket grid from the mesh
@@ -702,6 +761,7 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
     }
     c->have_hydro = true;
     drop_graph(c);
+    sync_views(c);
     return MCRAT_HIP_OK;
 }
 
@@ -724,12 +784,14 @@ static int ensure_hcol(mcrat_hip_ctx *c, int M)
 extern "C" int mcrat_hip_set_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h)
 {
     if (!c || !h || h->num_elements <= 0) return MCRAT_HIP_EINVAL;
+    if (c->parent) return view_refuses(c, "set_hydro");
     const int M = h->num_elements;
     const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
     if (!h->r0 || !h->r1 || !h->r0_size || !h->r1_size || !h->v0 || !h->v1 || !h->dens_lab || !h->temp || !h->gamma) return MCRAT_HIP_EINVAL;
     if (three && (!h->r2 || !h->r2_size)) return MCRAT_HIP_EINVAL;
     if (!two && !h->v2) return MCRAT_HIP_EINVAL;
     c->have_hydro = false;
+    sync_views(c);
     // the columns cross PCIe as they lie in the caller's memory; per-cell records and the cell-lookup grid are produced on
     // the device (stage_hydro)
     int rc = ensure_hcol(c, M);
@@ -848,11 +910,13 @@ extern "C" int mcrat_hip_ingest_flash(mcrat_hip_ctx *c, const mcrat_hip_flash_bl
                                       mcrat_hip_ingest_result *result)
 {
     if (!c || !b || !slab_ok(slab) || !outflow_ok(outflow)) return MCRAT_HIP_EINVAL;
+    if (c->parent) return view_refuses(c, "ingest_flash");
     if (b->n_blocks <= 0 || b->coord_stride < 2 || b->bsize_stride < 2 || !b->coordinates || !b->block_size || !b->node_type || !b->velx || !b->vely ||
         !b->dens || !b->pres)
         return MCRAT_HIP_EINVAL;
     if (c->kc.dimensions != DIM_TWO) { c->last_error = "FLASH frames are two-dimensional (mcrat_io.c:1938: 3D FLASH is not supported)"; return MCRAT_HIP_EINVAL; }
     c->have_hydro = false;
+    sync_views(c);
     const size_t nb = (size_t)b->n_blocks;
     RawPacker pk{c};
     const size_t o_coord = pk.add(b->coordinates, sizeof(double) * nb * b->coord_stride), o_bs = pk.add(b->block_size, sizeof(double) * nb * b->bsize_stride);
@@ -882,6 +946,7 @@ extern "C" int mcrat_hip_ingest_pluto(mcrat_hip_ctx *c, const mcrat_hip_pluto_gr
                                       mcrat_hip_ingest_result *result)
 {
     if (!c || !g || !slab_ok(slab) || !outflow_ok(outflow)) return MCRAT_HIP_EINVAL;
+    if (c->parent) return view_refuses(c, "ingest_pluto");
     const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
     if (g->nx <= 0 || g->ny <= 0 || (three && g->nz <= 0) || !g->x1 || !g->dx1 || !g->x2 || !g->dx2 || !g->rho || !g->vx1 || !g->vx2 || !g->prs)
         return MCRAT_HIP_EINVAL;
@@ -891,6 +956,7 @@ extern "C" int mcrat_hip_ingest_pluto(mcrat_hip_ctx *c, const mcrat_hip_pluto_gr
     const size_t cells = (size_t)g->nx * g->ny * nz;
     if (cells > 0x7fffffffull) return MCRAT_HIP_EINVAL;            // the reference's grid_size is an int (mclib_pluto.c:1061)
     c->have_hydro = false;
+    sync_views(c);
     RawPacker pk{c};
     const size_t o_x1 = pk.add(g->x1, sizeof(double) * g->nx), o_dx1 = pk.add(g->dx1, sizeof(double) * g->nx);
     const size_t o_x2 = pk.add(g->x2, sizeof(double) * g->ny), o_dx2 = pk.add(g->dx2, sizeof(double) * g->ny);
@@ -918,6 +984,7 @@ extern "C" int mcrat_hip_ingest_chombo(mcrat_hip_ctx *c, const mcrat_hip_chombo 
                                        mcrat_hip_ingest_result *result)
 {
     if (!c || !h || !slab_ok(slab) || !outflow_ok(outflow)) return MCRAT_HIP_EINVAL;
+    if (c->parent) return view_refuses(c, "ingest_chombo");
     if (h->num_levels <= 0 || h->num_vars <= 0 || !h->levels || !h->var_names || !h->data) return MCRAT_HIP_EINVAL;
     const bool three = c->kc.dimensions == DIM_THREE;
     const int nd = three ? 3 : 2, bi = 2 * nd, nl = h->num_levels, nv = h->num_vars;
@@ -981,6 +1048,7 @@ extern "C" int mcrat_hip_ingest_chombo(mcrat_hip_ctx *c, const mcrat_hip_chombo 
     if (kv[0] < 0 || kv[1] < 0 || kv[2] < 0 || kv[4] < 0 || (c->kc.dimensions != DIM_TWO && kv[3] < 0)) { c->last_error = "PLUTO-Chombo ingest: a component (rho, vx1, vx2, [vx3], prs) is missing"; return MCRAT_HIP_EINVAL; }
 
     c->have_hydro = false;
+    sync_views(c);
     const bool masked = slab->ph_inj_switch != 0;
     RawPacker pk{c};
     const size_t o_box = pk.add(boxes.data(), sizeof(ChomboBox) * boxes.size());
@@ -1015,6 +1083,7 @@ extern "C" int mcrat_hip_ingest_chombo(mcrat_hip_ctx *c, const mcrat_hip_chombo 
 extern "C" int mcrat_hip_set_hydro_extras(mcrat_hip_ctx *c, const double *dens, const double *B0, const double *B1, const double *B2)
 {
     if (!c) return MCRAT_HIP_EINVAL;
+    if (c->parent) return view_refuses(c, "set_hydro_extras");
     if (!c->have_hydro || !c->hcol_buf) return MCRAT_HIP_ESTATE;
     const size_t bytes = sizeof(double) * (size_t)c->hcol_M;
     const struct { double *dst; const double *src; } copy[4] = {{c->hcol.dens, dens}, {c->hcol.B0, B0}, {c->hcol.B1, B1}, {c->hcol.B2, B2}};
@@ -1067,8 +1136,42 @@ extern "C" int mcrat_hip_get_hydro(mcrat_hip_ctx *c, mcrat_hip_hydro_columns *ou
 }
 
 // ---------------------------------------------------------------------------------------------- photons
+// a view's list: a window of `n` slots into the pool's columns (the window spans the pool's slots per rank; slots beyond n stay invalid)
+static int alloc_view_photons(mcrat_hip_ctx *c, int n)
+{
+    mcrat_hip_ctx *P = c->parent;
+    if (n > P->rank_stride) {
+        c->last_error = "the list is longer than the pool's slots per rank (mcrat_hip_pool_create)";
+        return MCRAT_HIP_ENOMEM;
+    }
+    const size_t o = (size_t)c->view_rank * (size_t)P->rank_stride;
+    PhotonDev p = P->ph;
+    double **cols[24] = {&p.r0, &p.r1, &p.r2, &p.p0, &p.p1, &p.p2, &p.p3, &p.c0, &p.c1, &p.c2, &p.c3, &p.s0, &p.s1, &p.s2, &p.s3,
+                         &p.num_scatt, &p.weight, &p.tau, &p.tts, &p.u0, &p.u1, &p.u2, &p.ntau, &p.tau_next};
+    for (int k = 0; k < 24; ++k) *cols[k] += o;
+    p.idx += o; p.flags += o; p.type += o;
+    p.n = n;
+    p.n_pad = P->rank_stride;
+    p.hot_bias = p.if_bias = p.u_bias = 0;
+    c->ph = p;
+    HIPCHK(c, launch_clear_slots(c->ph, 0, P->rank_stride, c->stream));
+    c->step_blocks = step_grid_blocks(p.n_pad);
+    c->partials = P->partials;                // list-mode scratch is the pool's: one stream, one list at a time
+    c->partials_cap = P->partials_cap;
+    c->shortlist = P->shortlist;
+    HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
+    c->n_ranks = 0;
+    drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
 static int alloc_photons(mcrat_hip_ctx *c, int n)
 {
+    if (c->parent) return alloc_view_photons(c, n);
+    if (c->is_pool) {
+        c->last_error = "this context is a rank pool: its photons are set through the views (mcrat_hip_pool_rank)";
+        return MCRAT_HIP_ESTATE;
+    }
     const int n_pad = (int)align_up((size_t)std::max(n, 1), 2 * STEP_BLOCK);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
@@ -1097,7 +1200,7 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     p.type = b + o_type;
     p.n = n;
     p.n_pad = n_pad;
-    p.hot_bias = 0;
+    p.hot_bias = p.if_bias = p.u_bias = 0;
     c->step_blocks = step_grid_blocks(n_pad);
     const int need = c->step_blocks;                          // one candidate per workgroup of the step kernel
     if (c->partials_cap < need) {
@@ -1108,6 +1211,7 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     }
     c->n_ranks = 0;
     if (c->cfg.virtual_rank_photons > 0) {
+        c->rank_stride = c->cfg.virtual_rank_photons;
         c->n_ranks = (n + c->cfg.virtual_rank_photons - 1) / c->cfg.virtual_rank_photons;
         if (c->rstates_cap < c->n_ranks) {
             if (c->d_rstates) HIPCHK(c, hipFree(c->d_rstates));
@@ -1250,6 +1354,15 @@ static int grow_photons(mcrat_hip_ctx *c, int new_n)
     void *old_buf = c->ph_buf;
     const int old_n = old.n;
     if (new_n <= old_n) return MCRAT_HIP_EINVAL;
+    if (c->parent) {                                           // a view grows inside its window of the pool
+        if (new_n > c->parent->rank_stride) {
+            c->last_error = "the list cannot double: it would outgrow the pool's slots per rank (mcrat_hip_pool_create)";
+            return MCRAT_HIP_ENOMEM;
+        }
+        HIPCHK(c, launch_null_fill(c->ph, old_n, new_n - old_n, c->stream));
+        c->ph.n = new_n;
+        return MCRAT_HIP_OK;
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->ph_buf = nullptr; c->ph_bytes = 0;                     // a fresh, zeroed allocation
     int rc = alloc_photons(c, new_n);
@@ -1385,6 +1498,7 @@ extern "C" int mcrat_hip_snapshot_photons(mcrat_hip_ctx *c)
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    if (c->parent) { c->last_error = "snapshot the pool, not one of its views"; return MCRAT_HIP_ESTATE; }
     int rc = MCRAT_HIP_OK;
     if (c->frame_open && c->n_ranks == 0) { HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream)); }
     (void)rc;
@@ -1398,9 +1512,11 @@ extern "C" int mcrat_hip_snapshot_photons(mcrat_hip_ctx *c)
 extern "C" int mcrat_hip_restore_photons(mcrat_hip_ctx *c)
 {
     if (!c) return MCRAT_HIP_EINVAL;
-    if (!c->have_photons || !c->ph_snap || c->ph_snap_bytes < c->ph_bytes) return MCRAT_HIP_ESTATE;
+    if (c->parent || !c->have_photons || !c->ph_snap || c->ph_snap_bytes < c->ph_bytes) return MCRAT_HIP_ESTATE;
     HIPCHK(c, hipMemcpyAsync(c->ph_buf, c->ph_snap, c->ph_bytes, hipMemcpyDeviceToDevice, c->stream));
     c->frame_open = false;        // the loop state no longer matches the photons: begin_frame comes next
+    for (mcrat_hip_ctx *v : c->views)
+        if (v) v->frame_open = false;
     return MCRAT_HIP_OK;
 }
 
@@ -1674,8 +1790,17 @@ static void state_to_stats(const LoopState &h, long long slots, mcrat_hip_frame_
 
 static int rank_slots(const mcrat_hip_ctx *c, int r)
 {
+    if (c->is_pool) return c->h_desc[r].len;
     const int per = c->cfg.virtual_rank_photons;
     return std::min(per, c->ph.n - r * per);
+}
+
+static int longest_rank_list(const mcrat_hip_ctx *c)
+{
+    if (!c->is_pool) return std::min(c->cfg.virtual_rank_photons, c->ph.n);
+    int m = 0;
+    for (int r = 0; r < c->n_ranks; ++r) m = std::max(m, c->h_desc[r].len);
+    return m;
 }
 
 // whole-job view of the virtual ranks: counters add up; the clock shown is that of the rank furthest behind
@@ -1729,6 +1854,109 @@ extern "C" int mcrat_hip_rank_stats(mcrat_hip_ctx *c, int rank, mcrat_hip_frame_
     return MCRAT_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- rank pool
+extern "C" int mcrat_hip_pool_create(mcrat_hip_ctx *c, int n_ranks, int slots_per_rank)
+{
+    if (!c || n_ranks <= 0 || slots_per_rank <= 0) return MCRAT_HIP_EINVAL;
+    if (c->parent) { c->last_error = "a rank view cannot hold a pool"; return MCRAT_HIP_ESTATE; }
+    if (c->sc_world > 0) { c->last_error = "shared clock and rank pool exclude each other"; return MCRAT_HIP_ESTATE; }
+    const size_t stride = align_up((size_t)slots_per_rank, 2 * STEP_BLOCK);
+    if (stride * (size_t)n_ranks > 0x7fffffffull - 2 * STEP_BLOCK) { c->last_error = "rank pool: more than 2^31 slots"; return MCRAT_HIP_EINVAL; }
+    for (mcrat_hip_ctx *v : c->views)
+        if (v) { v->parent = nullptr; destroy_view(v); }
+    c->views.clear();
+    c->is_pool = false;
+    c->cfg.virtual_rank_photons = (int)stride;
+    int rc = alloc_photons(c, (int)(stride * (size_t)n_ranks));       // zeroed: no slot belongs to a list yet
+    if (rc) return rc;
+    c->is_pool = true;
+    c->views.assign((size_t)n_ranks, nullptr);
+    if (c->d_desc) { HIPCHK(c, hipFree(c->d_desc)); c->d_desc = nullptr; }
+    if (c->h_desc) { HIPCHK(c, hipHostFree(c->h_desc)); c->h_desc = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->d_desc, sizeof(RankDesc) * (size_t)n_ranks));
+    HIPCHK(c, hipHostMalloc((void **)&c->h_desc, sizeof(RankDesc) * (size_t)n_ranks, hipHostMallocDefault));
+    memset(c->h_desc, 0, sizeof(RankDesc) * (size_t)n_ranks);
+    HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)n_ranks, hipMemcpyHostToDevice, c->stream));
+    memset(c->h_rstates, 0, sizeof(LoopState) * (size_t)n_ranks);
+    for (int r = 0; r < n_ranks; ++r) { c->h_rstates[r].done = 1; c->h_rstates[r].skip_idx = -1; c->h_rstates[r].last_scattered_index = -1; }
+    HIPCHK(c, hipMemcpyAsync(c->d_rstates, c->h_rstates, sizeof(LoopState) * (size_t)n_ranks, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->have_photons = true;
+    c->frame_open = false;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_pool_rank(mcrat_hip_ctx *c, int rank, uint32_t rng_stream, mcrat_hip_ctx **view)
+{
+    if (!c || !view) return MCRAT_HIP_EINVAL;
+    *view = nullptr;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    if (rank < 0 || rank >= c->n_ranks) return MCRAT_HIP_EINVAL;
+    mcrat_hip_ctx *v = c->views[rank];
+    if (!v) {
+        v = new (std::nothrow) mcrat_hip_ctx();
+        if (!v) return MCRAT_HIP_ENOMEM;
+        v->cfg = c->cfg;
+        v->cfg.virtual_rank_photons = 0;
+        v->cfg.stream = c->stream;
+        v->kc = c->kc;
+        v->stream = c->stream;
+        v->own_stream = false;
+        v->parent = c;
+        v->view_rank = rank;
+        v->d_state = c->d_rstates + rank;         // windows into the pool's blocks; nothing here is owned by the view
+        v->h_state = c->h_rstates + rank;
+        v->d_red = c->d_red; v->h_red = c->h_red;
+        v->d_table_misses = c->d_table_misses;
+        c->views[rank] = v;
+        sync_views(c);
+    }
+    v->cfg.rng_stream = rng_stream;
+    v->key.stream = rng_stream & 0xffffffu;
+    v->view_stream = v->key.stream;
+    *view = v;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_pool_summaries(mcrat_hip_ctx *c, mcrat_hip_rank_summary *out)
+{
+    if (!c || !out) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    const int R = c->n_ranks;
+    for (int r = 0; r < R; ++r) {                  // every list that exists, whether or not it is in a frame
+        const mcrat_hip_ctx *v = c->views[r];
+        RankDesc d{};
+        if (v && v->have_photons) { d.len = v->ph.n; d.stream = v->key.stream; d.seed = v->key.seed; }
+        c->h_desc[r] = d;
+    }
+    const size_t bytes = (sizeof(ReducePartial) + sizeof(int)) * (size_t)R + sizeof(RankDesc) * (size_t)R;
+    int rc = ensure_aos(c, bytes);
+    if (rc) return rc;
+    ReducePartial *d_part = static_cast<ReducePartial *>(c->aos_buf);
+    RankDesc *d_desc = reinterpret_cast<RankDesc *>(d_part + R);
+    int *d_nout = reinterpret_cast<int *>(d_desc + R);
+    HIPCHK(c, hipMemcpyAsync(d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rank_reduce(c->ph, c->rank_stride, R, d_desc, d_part, d_nout, c->stream));
+    std::vector<ReducePartial> part((size_t)R);
+    std::vector<int> nout((size_t)R);
+    HIPCHK(c, hipMemcpyAsync(part.data(), d_part, sizeof(ReducePartial) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(nout.data(), d_nout, sizeof(int) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < R; ++r) {
+        const ReducePartial &t = part[(size_t)r];
+        mcrat_hip_rank_summary &o = out[r];
+        memset(&o, 0, sizeof o);
+        o.list_capacity = c->h_desc[r].len;
+        if (o.list_capacity <= 0) continue;
+        o.min_r = t.r_min; o.max_r = t.r_max; o.min_theta = t.th_min; o.max_theta = t.th_max;
+        o.max_scatt = (int)t.max_scatt; o.min_scatt = (int)t.min_scatt;
+        o.avg_scatt = t.sum_scatt / (double)t.count; o.avg_r = t.sum_r / (double)t.count;
+        o.avg_energy = (t.e_sum * C_LIGHT) / t.w_sum;
+        o.num_output = nout[(size_t)r];
+    }
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double time_now, double remaining_time)
 {
     if (!c) return MCRAT_HIP_EINVAL;
@@ -1746,7 +1974,11 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     h.done = !(remaining_time > 0);
     h.skip_idx = -1;
     h.last_scattered_index = -1;
+    if (c->parent) h.force_relocate = 1;           // a view's LoopState is the pool's for this list (rank_loop_kernel looks at the flag)
     HIPCHK(c, launch_init_states(c->d_state, c->d_rstates, c->n_ranks, h, c->stream));     // per list: force_relocate = 1, mcrat.c:756
+    if (c->is_pool)                                // the pool's own begin_frame: every list, the same seed and clock
+        for (mcrat_hip_ctx *v : c->views)
+            if (v && v->have_photons) { v->key.seed = seed; v->frame_open = true; v->find_switch = 1; v->pending_applied = false; }
     *c->h_state = h;                               // the host's view until the next read-back (every read-back is followed by a wait)
     HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     if (c->sc_world > 0) HIPCHK(c, hipMemsetAsync(c->d_sc, 0, sizeof(ScState), c->stream));
@@ -1806,12 +2038,27 @@ static void choose_rank_block(mcrat_hip_ctx *c)
     if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) { c->rank_block = (atoi(e) == 128) ? 128 : 256; return; }
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const bool many = c->n_ranks > 2 * cus && c->cfg.virtual_rank_photons <= 1024;
+    const bool many = c->n_ranks > 2 * cus && longest_rank_list(c) <= 1024;
     c->rank_block = (many && c->rank_passes_per_list >= 48.0) ? 128 : 256;
+}
+
+// rank pool: what the kernel needs to know about every list, from its view
+static int pool_describe(mcrat_hip_ctx *c)
+{
+    for (int r = 0; r < c->n_ranks; ++r) {
+        const mcrat_hip_ctx *v = r < (int)c->views.size() ? c->views[r] : nullptr;
+        RankDesc d{};
+        if (v && v->have_photons && v->frame_open) { d.len = v->ph.n; d.stream = v->key.stream; d.seed = v->key.seed; }
+        c->h_desc[r] = d;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)c->n_ranks, hipMemcpyHostToDevice, c->stream));
+    return MCRAT_HIP_OK;
 }
 
 static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame_stats *stats)
 {
+    if (c->is_pool) { int rc = pool_describe(c); if (rc) return rc; }
+    const int longest = longest_rank_list(c);
     if (!c->rank_block_fixed) { choose_rank_block(c); c->rank_block_fixed = true; }    // one choice per frame (begin_frame resets)
     const long long per_launch_cap = 4096;      // bounds one launch to seconds even for the densest lists
     long long it = 0;
@@ -1823,7 +2070,8 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
             if (rc) return rc;
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
-        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->cfg.virtual_rank_photons, batch, c->rank_block, c->stream));
+        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, batch,
+                                   c->rank_block, c->stream));
         if (c->cfg.profile) {
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
             HIPCHK(c, hipEventSynchronize(c->ev[1]));
@@ -1853,6 +2101,12 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
 extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame_stats *stats)
 {
     if (!c) return MCRAT_HIP_EINVAL;
+    if (c->is_pool) {                              // every list whose view has opened a frame (or the pool's own begin_frame: all)
+        if (!c->have_hydro) return MCRAT_HIP_ESTATE;
+        if (c->cfg.cyclosynchrotron_switch) { c->last_error = "CYCLOSYNCHROTRON_SWITCH is on: run the views one by one (mcrat_hip_scatter_frame_cyclosynch)"; return MCRAT_HIP_ESTATE; }
+        c->frame_open = true;
+        return run_ranks(c, max_iterations, stats);
+    }
     if (!c->frame_open) return MCRAT_HIP_ESTATE;
     if (c->sc_world > 0) { c->last_error = "shared clock attached: drive the frame with mcrat_hip_shared_clock_*"; return MCRAT_HIP_ESTATE; }
     if (c->cfg.cyclosynchrotron_switch) {

@@ -776,10 +776,15 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
 // the per-pass state lives in LDS, and no pass costs a kernel launch or an N-wide sweep of HBM.  Every list sees
 // exactly the arithmetic and random numbers of a single-list context holding only its photons with
 // rng_stream = first_stream + r.
+// Two layouts.  desc == nullptr: the list is cut into ranks of `stride` consecutive slots (the last may hold fewer), all with the
+// launch's seed and the streams key.stream + rank.  desc != nullptr (rank pool, mcrat_hip_pool_*): rank r owns the slots
+// [r * stride, r * stride + desc[r].len) -- the reference's ranks hold Poisson-sized lists (mclib.c:87-136) -- and has its own
+// seed and stream, as every MPI rank has its own generator (mcrat.c:99-103,701).
 struct RankLayout {
     int n_ranks;
-    int rank_photons;     // slots per rank (the last rank may hold fewer)
+    int stride;           // slots reserved per rank
     int n_total;
+    const RankDesc *desc;
 };
 
 // Four lists per CU.  Measured by varying the number of lists on a dense jet: a workgroup alone on its CU needs 25 us per
@@ -811,12 +816,23 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     int *const s_q = reinterpret_cast<int *>(sh.list);
     const int tid = threadIdx.x, lane = tid & 63;
     const int rank = blockIdx.x;
-    const int base = rank * lay.rank_photons;
-    const int n = min(lay.rank_photons, lay.n_total - base);
-    if (tid == 0) st = states[rank];
+    const int base = rank * lay.stride;
+    int n = min(lay.stride, lay.n_total - base);
+    RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
+    if (lay.desc) {
+        const RankDesc d = lay.desc[rank];
+        n = min(n, d.len);
+        rk.seed = d.seed;
+        rk.stream = d.stream;
+    }
+    // a pool list's *scattered_ph_index is list-local between launches (its view reads it like a context of its own)
+    const int idx_shift = lay.desc ? base : 0;
+    if (tid == 0) {
+        st = states[rank];
+        if (st.last_scattered_index >= 0) st.last_scattered_index += idx_shift;
+    }
     __syncthreads();
     if (st.done || n <= 0) return;
-    const RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
 #ifdef MCRAT_DIAG
     long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ticks: load, forced step, step, event, store; [5] passes
     long long dg_t = (long long)__builtin_amdgcn_s_memtime();
@@ -1071,7 +1087,11 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         RANK_TICK(4);
         if (tid == 0) for (int k = 0; k < 8; ++k) st.stamps[k] = dg[k];
 #endif
-        if (tid == 0) { st.nseg = 0; st.skip_idx = -1; states[rank] = st; }
+        if (tid == 0) {
+            st.nseg = 0; st.skip_idx = -1;
+            if (st.last_scattered_index >= 0) st.last_scattered_index -= idx_shift;
+            states[rank] = st;
+        }
     }
 }
 
@@ -1420,6 +1440,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(PhotonDev ph, ReducePartial
     double sum_scatt = 0, sum_r = 0, e_sum = 0, w_sum = 0, max_s = 0, min_s = 2147483647.0;
     long long count = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < ph.n; i += gridDim.x * 256) {
+        if (!(ph.flags[i] & FLAG_VALID)) continue;                      // a rank pool's unused slots belong to no list
         const double x = ph.r0[i], y = ph.r1[i], z = ph.r2[i], w = ph.weight[i];
         const double r = sqrt(x * x + y * y + z * z);
         if (w != 0) {                                                   // mclib.c:1479
@@ -1538,12 +1559,12 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 }
 
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_photons, long long max_passes, int block, hipStream_t stream)
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, long long max_passes, int block, hipStream_t stream)
 {
-    RankLayout lay = {n_ranks, rank_photons, ph.n};
+    RankLayout lay = {n_ranks, rank_stride, ph.n, desc};
     // per-pass columns in LDS (32 B per slot with 128 threads, 61 B with 256: rank_loop_kernel) for lists of up to 1024 photons
     int lds_slots = 0;
-    if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && rank_photons <= 1024) lds_slots = (rank_photons + 15) & ~15;
+    if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && longest_list <= 1024) lds_slots = (longest_list + 15) & ~15;
     size_t dyn = (size_t)lds_slots * rank_lds_bytes_per_slot(block == 128 ? 128 : 256);
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;

@@ -27,9 +27,10 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 // candidate selection + photonEvent + loop bookkeeping
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
-// virtual ranks: every workgroup (of `block` = 128 or 256 threads) runs the whole loop of one independent photon list of `rank_photons` slots
+// virtual ranks: every workgroup (of `block` = 128 or 256 threads) runs the whole loop of one independent photon list: the slots
+// [r * rank_stride, ...) -- rank_stride of them, or desc[r].len with the list's own seed and stream (rank pool); longest_list sizes the LDS copy
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_photons, long long max_passes, int block, hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, long long max_passes, int block, hipStream_t stream);
 // one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
@@ -42,6 +43,9 @@ hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream
 hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream);
 // struct photon records <-> SoA columns on the device (staging.hip); `aos` is a device buffer of n 176-B records
 hipError_t launch_init_states(LoopState *single, LoopState *ranks, int n_ranks, const LoopState &v, hipStream_t stream);
+hipError_t launch_clear_slots(const PhotonDev &ph, int first, int count, hipStream_t stream);   // every column zeroed: no list's slots
+// rank pool: the per-frame reductions and printPhotons' count for every list (desc[r].len slots from r * stride), one launch
+hipError_t launch_rank_reduce(const PhotonDev &ph, int stride, int n_ranks, const RankDesc *desc, ReducePartial *out, int *n_out, hipStream_t stream);
 hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream);
 hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int first, int n, hipStream_t stream);   // record k = slot first + k
 // printPhotons' arrays (mcrat_io.c:137-181): photons with weight != 0, slot order; col: p0-3, comv_p0-3, r0-2, s0-3, num_scatt, weight

@@ -182,7 +182,94 @@ __global__ __launch_bounds__(256) void init_states_kernel(LoopState *__restrict_
     }
 }
 
+// slots [first, first + count) of every column zeroed: not part of any list (flag byte 0: not FLAG_VALID)
+__global__ __launch_bounds__(256) void clear_slots_kernel(PhotonDev ph, int first, int count)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const int i = first + k;
+    double *cols[24] = {ph.r0, ph.r1, ph.r2, ph.p0, ph.p1, ph.p2, ph.p3, ph.c0, ph.c1, ph.c2, ph.c3, ph.s0, ph.s1, ph.s2, ph.s3,
+                        ph.num_scatt, ph.weight, ph.tau, ph.tts, ph.u0, ph.u1, ph.u2, ph.ntau, ph.tau_next};
+#pragma unroll
+    for (int c = 0; c < 24; ++c) cols[c][i] = 0.0;
+    ph.idx[i] = 0;
+    ph.flags[i] = 0;
+    ph.type[i] = 0;
+}
+
+// rank pool: phMinMax (mclib.c:1465), phScattStats (mclib.c:1385), averagePhotonEnergy (mclib.c:1358) and printPhotons' count of
+// photons with weight != 0 (mcrat_io.c:137-181) for every list in one launch, one workgroup per list
+__global__ __launch_bounds__(256) void rank_reduce_kernel(PhotonDev ph, int stride, const RankDesc *__restrict__ desc, ReducePartial *__restrict__ out,
+                                                          int *__restrict__ n_out)
+{
+    __shared__ double s[4][10];
+    __shared__ long long s_cnt[4][2];
+    const int rank = blockIdx.x, base = rank * stride, n = desc[rank].len;
+    double r_min = 1.7976931348623157e308, r_max = 0, th_min = 1.7976931348623157e308, th_max = 0;
+    double sum_scatt = 0, sum_r = 0, e_sum = 0, w_sum = 0, max_s = 0, min_s = 2147483647.0;
+    long long count = 0, kept = 0;
+    for (int il = threadIdx.x; il < n; il += 256) {
+        const int i = base + il;
+        const double x = ph.r0[i], y = ph.r1[i], z = ph.r2[i], w = ph.weight[i];
+        const double r = sqrt(x * x + y * y + z * z);
+        if (w != 0) {
+            const double th = acos(z / r);
+            r_max = fmax(r_max, r); r_min = fmin(r_min, r);
+            th_max = fmax(th_max, th); th_min = fmin(th_min, th);
+            kept += 1;
+        }
+        const double ns = ph.num_scatt[i];
+        sum_scatt += ns; sum_r += r;
+        max_s = fmax(max_s, ns); min_s = fmin(min_s, ns);
+        e_sum += ph.p0[i] * w; w_sum += w;
+        count += 1;
+    }
+    auto wsum = [](double v) { for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64); return v; };
+    auto wmin = [](double v) { for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64)); return v; };
+    auto wmax = [](double v) { for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64)); return v; };
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    r_min = wmin(r_min); r_max = wmax(r_max); th_min = wmin(th_min); th_max = wmax(th_max);
+    sum_scatt = wsum(sum_scatt); sum_r = wsum(sum_r); e_sum = wsum(e_sum); w_sum = wsum(w_sum);
+    max_s = wmax(max_s); min_s = wmin(min_s);
+    const double cd = wsum((double)count), kd = wsum((double)kept);
+    if (lane == 0) {
+        s[wv][0] = r_min; s[wv][1] = r_max; s[wv][2] = th_min; s[wv][3] = th_max; s[wv][4] = sum_scatt;
+        s[wv][5] = sum_r; s[wv][6] = e_sum; s[wv][7] = w_sum; s[wv][8] = max_s; s[wv][9] = min_s;
+        s_cnt[wv][0] = (long long)cd; s_cnt[wv][1] = (long long)kd;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ReducePartial p;
+        p.r_min = fmin(fmin(s[0][0], s[1][0]), fmin(s[2][0], s[3][0]));
+        p.r_max = fmax(fmax(s[0][1], s[1][1]), fmax(s[2][1], s[3][1]));
+        p.th_min = fmin(fmin(s[0][2], s[1][2]), fmin(s[2][2], s[3][2]));
+        p.th_max = fmax(fmax(s[0][3], s[1][3]), fmax(s[2][3], s[3][3]));
+        p.sum_scatt = (s[0][4] + s[1][4]) + (s[2][4] + s[3][4]);
+        p.sum_r = (s[0][5] + s[1][5]) + (s[2][5] + s[3][5]);
+        p.e_sum = (s[0][6] + s[1][6]) + (s[2][6] + s[3][6]);
+        p.w_sum = (s[0][7] + s[1][7]) + (s[2][7] + s[3][7]);
+        p.max_scatt = fmax(fmax(s[0][8], s[1][8]), fmax(s[2][8], s[3][8]));
+        p.min_scatt = fmin(fmin(s[0][9], s[1][9]), fmin(s[2][9], s[3][9]));
+        p.count = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+        out[rank] = p;
+        n_out[rank] = (int)(s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1]);
+    }
+}
+
 }  // namespace
+
+hipError_t launch_clear_slots(const PhotonDev &ph, int first, int count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    clear_slots_kernel<<<dim3((count + 255) / 256), dim3(256), 0, stream>>>(ph, first, count);
+    return hipGetLastError();
+}
+
+hipError_t launch_rank_reduce(const PhotonDev &ph, int stride, int n_ranks, const RankDesc *desc, ReducePartial *out, int *n_out, hipStream_t stream)
+{
+    rank_reduce_kernel<<<dim3(n_ranks), dim3(256), 0, stream>>>(ph, stride, desc, out, n_out);
+    return hipGetLastError();
+}
 
 hipError_t launch_init_states(LoopState *single, LoopState *ranks, int n_ranks, const LoopState &v, hipStream_t stream)
 {

@@ -154,6 +154,13 @@ class OutputColumns(C.Structure):
     _fields_ = [("count", C.c_int)] + [(f, _dp) for f in OUTPUT_COLUMNS] + [("type", C.c_char_p)]
 
 
+class RankSummary(C.Structure):
+    """mcrat_hip_rank_summary: the per-frame reductions and printPhotons' count of one list of a rank pool"""
+    _fields_ = [("min_r", C.c_double), ("max_r", C.c_double), ("min_theta", C.c_double), ("max_theta", C.c_double),
+                ("avg_scatt", C.c_double), ("avg_r", C.c_double), ("avg_energy", C.c_double),
+                ("max_scatt", C.c_int), ("min_scatt", C.c_int), ("num_output", C.c_int), ("list_capacity", C.c_int)]
+
+
 SCIENCE, CYLINDRICAL_OUTFLOW, SPHERICAL_OUTFLOW, STRUCTURED_SPHERICAL_OUTFLOW = 0, 1, 2, 3    # SIMULATION_TYPE, mcrat.h:30-33
 
 # every symbol include/mcrat_hip.h declares: (restype, argtypes)
@@ -198,6 +205,9 @@ SYMBOLS = {
     "mcrat_hip_restore_photons": (C.c_int, [_ctx]),
     "mcrat_hip_num_virtual_ranks": (C.c_int, [_ctx]),
     "mcrat_hip_rank_stats": (C.c_int, [_ctx, C.c_int, C.POINTER(FrameStats)]),
+    "mcrat_hip_pool_create": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "mcrat_hip_pool_rank": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.POINTER(_ctx)]),
+    "mcrat_hip_pool_summaries": (C.c_int, [_ctx, C.POINTER(RankSummary)]),
     "mcrat_hip_step_locate_sample": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_step_event": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_update_photon_position": (C.c_int, [_ctx, C.c_double]),
@@ -270,8 +280,36 @@ class Engine:
 
     def close(self):
         if getattr(self, "ctx", None):
-            self.lib.mcrat_hip_destroy(self.ctx)
+            if getattr(self, "pool", None) is None:      # a view goes with its pool
+                self.lib.mcrat_hip_destroy(self.ctx)
             self.ctx = _ctx()
+            for v in getattr(self, "views", {}).values():
+                v.ctx = _ctx()
+
+    # ---- rank pool: R independent lists (the reference's MPI ranks) in one context
+    def pool_create(self, n_ranks, slots_per_rank):
+        self._check(self.lib.mcrat_hip_pool_create(self.ctx, int(n_ranks), int(slots_per_rank)), "pool_create")
+        for v in getattr(self, "views", {}).values():
+            v.ctx = _ctx()
+        self.views = {}
+        self.n_pool_ranks = int(n_ranks)
+        self.n = int(self.lib.mcrat_hip_num_photon_slots(self.ctx))
+
+    def pool_rank(self, rank, rng_stream=0):
+        """the view of list `rank`: an Engine whose photons, clock and loop state are that list's"""
+        ctx = _ctx()
+        self._check(self.lib.mcrat_hip_pool_rank(self.ctx, int(rank), int(rng_stream), C.byref(ctx)), "pool_rank")
+        v = self.views.get(rank)
+        if v is None or v.ctx.value != ctx.value:
+            v = Engine.__new__(Engine)
+            v.lib, v.cfg, v.ctx, v.n, v.pool = self.lib, self.cfg, ctx, 0, self
+            self.views[rank] = v
+        return v
+
+    def pool_summaries(self):
+        out = (RankSummary * self.n_pool_ranks)()
+        self._check(self.lib.mcrat_hip_pool_summaries(self.ctx, out), "pool_summaries")
+        return list(out)
 
     def __del__(self):
         try:

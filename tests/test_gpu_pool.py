@@ -1,0 +1,209 @@
+"""Rank pool (mcrat_hip_pool_*): R independent photon lists of different lengths -- the reference's MPI ranks, each with its
+own Poisson-sized list, generator and clock (mcrat.c:99-103,139-164,457-479,701; mclib.c:87-136) -- in ONE context, all lists
+propagated by one launch.  Every list must equal the oracle run on that list alone (its own seed, stream, clock), and the
+view of a list must behave like a context of its own for the per-list entry points.  Through the C ABI."""
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+from tests.test_gpu_parity import FLOAT_FIELDS, INT_FIELDS, _compare
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mcrat_amd import engine
+    engine.load_library()
+    return engine
+
+
+def _cut(ph, lo, hi, n):
+    return {k: (v[lo:hi].copy() if isinstance(v, np.ndarray) and len(v) == n else v) for k, v in ph.items()}
+
+
+def _lists(ph, lens):
+    n, out, lo = len(ph["p0"]), [], 0
+    for m in lens:
+        out.append(_cut(ph, lo, lo + m, n))
+        lo += m
+    assert lo <= n
+    return out
+
+
+@pytest.mark.parametrize("case", ["cfg2-stokes", "cfg3-stokes-long", "cfg1-global"])
+def test_unequal_lists_equal_independent_oracle_runs(hip, oracle, case, monkeypatch):
+    lens = [137, 1000, 512, 999, 3, 64, 700, 1024]
+    if case == "cfg2-stokes":
+        frame, ph, cfg = synth.config2(n_photons=sum(lens), nzc=8, stokes=1, lumi=1e54)
+    elif case == "cfg3-stokes-long":
+        lens[5] = 1500                                 # one list beyond what is kept in LDS: every list takes the HBM/L2 path
+        frame, ph, cfg = synth.config3(n_photons=sum(lens), nr=256, nth=128, lumi=1e54)
+    else:
+        frame, ph, cfg = synth.config1(n_photons=sum(lens), n0=32, n1=32)
+        monkeypatch.setenv("MCRAT_HIP_NO_LDS_LISTS", "1")
+    subs = _lists(ph, lens)
+    R = len(lens)
+    seeds = [1000 + 17 * r for r in range(R)]
+    streams = [3, 99, 4, 4, 7, 0, 12345, 8][:R]        # two ranks may even share a stream: their seeds differ
+    t0 = [2.0 + 0.01 * r for r in range(R)]            # every rank its own clock
+    rem = [0.2 - 0.01 * r for r in range(R)]
+    passes = 250
+
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(R, 1600)
+    views = []
+    for r in range(R):
+        if r == 4:
+            continue                                   # rank 4 joins late (below)
+        v = pool.pool_rank(r, streams[r])
+        v.set_photons(subs[r])
+        v.begin_frame(seeds[r], t0[r], rem[r])
+        views.append(v)
+    tot = pool.run(passes)
+
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    sums = dict(it=0, sc=0)
+    for r in range(R):
+        if r == 4:
+            continue
+        P = oracle.OraclePhotons(synth.photons_to_aos(subs[r], oracle.PHOTON_DTYPE))
+        rst, rtn, rrem, _ = oracle.photon_loop(c, P, H, seed=seeds[r], time_now=t0[r], remaining_time=rem[r], max_iterations=passes,
+                                               stream=streams[r])
+        v = pool.pool_rank(r, streams[r])
+        st = v.frame_statistics()
+        assert st.iterations == rst.iterations
+        assert st.frame_scatt_cnt == rst.frame_scatt_cnt
+        assert st.kn_rejections == rst.kn_rejections
+        assert st.num_photons_find_new_element == rst.num_photons_find_new_element
+        assert st.last_scattered_index == rst.last_scattered_index          # list-local, as in a context of its own
+        assert st.time_now == pytest.approx(rtn, rel=1e-12) and st.remaining_time == pytest.approx(rrem, rel=1e-9, abs=1e-300)
+        _compare(v.get_photons(), P.aos)
+        sums["it"] += rst.iterations
+        sums["sc"] += rst.frame_scatt_cnt
+    assert (tot.iterations, tot.frame_scatt_cnt) == (sums["it"], sums["sc"])
+    assert sums["sc"] > 0
+
+    # a rank that joins later (its own injection frame): only its list runs now, the others are untouched
+    before = {r: pool.pool_rank(r, streams[r]).get_photons() for r in (0, 7)}
+    v4 = pool.pool_rank(4, streams[4])
+    v4.set_photons(subs[4])
+    v4.begin_frame(seeds[4], t0[4], rem[4])
+    pool.run(passes)
+    P = oracle.OraclePhotons(synth.photons_to_aos(subs[4], oracle.PHOTON_DTYPE))
+    rst, _, _, _ = oracle.photon_loop(c, P, H, seed=seeds[4], time_now=t0[4], remaining_time=rem[4], max_iterations=passes, stream=streams[4])
+    assert v4.frame_statistics().iterations == rst.iterations
+    _compare(v4.get_photons(), P.aos)
+    for r in (0, 7):
+        st = pool.pool_rank(r, streams[r]).frame_statistics()
+        if st.remaining_time > 0:
+            continue                                   # unfinished lists went on: not comparable
+        after = pool.pool_rank(r, streams[r]).get_photons()
+        for k in FLOAT_FIELDS + INT_FIELDS:
+            assert np.array_equal(before[r][k], after[k], equal_nan=True), (r, k)
+    pool.close()
+
+
+def test_pool_lists_are_bitwise_single_list_contexts_in_rank_mode(hip):
+    """whole frames: list r of a pool == list r of a fixed-size virtual-rank context == bitwise, when lengths, seed and streams agree"""
+    n, per, R = 6000, 1000, 6
+    frame, ph, cfg = synth.config2(n_photons=n, nzc=8, lumi=1e53)
+    rem = 1.0 / frame["fps"]
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=10, virtual_rank_photons=per)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    e.begin_frame(77, 0.0, rem)
+    st = e.run(0)
+    ref = e.get_photons()
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(R, per)
+    for r in range(R):
+        v = pool.pool_rank(r, 10 + r)
+        v.set_photons(_cut(ph, r * per, (r + 1) * per, n))
+    pool.begin_frame(77, 0.0, rem)                     # the pool's own begin_frame: every list, one seed and clock
+    tot = pool.run(0)
+    assert (tot.iterations, tot.frame_scatt_cnt, tot.num_photons_find_new_element) == (st.iterations, st.frame_scatt_cnt, st.num_photons_find_new_element)
+    assert tot.frame_scatt_cnt > 0 and tot.remaining_time == 0.0
+    for r in range(R):
+        out = pool.pool_rank(r, 10 + r).get_photons()
+        for k in FLOAT_FIELDS + INT_FIELDS:
+            assert np.array_equal(out[k], np.asarray(ref[k])[r * per:(r + 1) * per], equal_nan=True), (r, k)
+    e.close()
+    pool.close()
+
+
+def test_view_entry_points_and_summaries(hip, oracle):
+    """a view is a context of its own for the per-list entry points: reductions, printPhotons' columns, checkpoint records;
+    mcrat_hip_pool_summaries gives the same numbers for every list in one launch"""
+    lens = [300, 1100, 17]
+    frame, ph, cfg = synth.config2(n_photons=sum(lens), nzc=8, stokes=1, lumi=1e54)
+    ph["weight"][5] = 0.0                              # a photon printPhotons skips
+    subs = _lists(ph, lens)
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(4, 1200)                          # rank 3 never gets a list
+    for r in range(3):
+        v = pool.pool_rank(r, r)
+        v.set_photons(subs[r])
+        v.begin_frame(5 + r, 0.0, 0.05)
+    pool.run(0)
+    summ = pool.pool_summaries()
+    assert summ[3].list_capacity == 0
+    for r in range(3):
+        v = pool.pool_rank(r, r)
+        single = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=r, virtual_rank_photons=lens[r])
+        single.set_hydro(frame)
+        single.set_photons(subs[r])
+        single.begin_frame(5 + r, 0.0, 0.05)
+        single.run(0)
+        a, b = v.get_photons(), single.get_photons()
+        for k in FLOAT_FIELDS + INT_FIELDS:
+            assert np.array_equal(a[k], b[k], equal_nan=True), (r, k)
+        assert v.ph_minmax() == single.ph_minmax()
+        assert v.scatt_stats() == single.scatt_stats()
+        assert v.avg_energy() == single.avg_energy()
+        oa, ob = v.get_output(), single.get_output()
+        assert len(oa["p0"]) == lens[r] - (1 if r == 0 else 0)
+        for k in oa:
+            assert np.array_equal(oa[k], ob[k]), (r, k)
+        assert np.array_equal(v.get_photons_range(0, lens[r]), single.get_photons_range(0, lens[r]))
+        s = summ[r]
+        mm, ss = v.ph_minmax(), v.scatt_stats()
+        assert (s.min_r, s.max_r, s.min_theta, s.max_theta) == mm
+        assert (s.max_scatt, s.min_scatt) == ss[:2]
+        assert s.avg_scatt == pytest.approx(ss[2], rel=1e-13) and s.avg_r == pytest.approx(ss[3], rel=1e-13)
+        assert s.avg_energy == pytest.approx(v.avg_energy(), rel=1e-13)
+        assert s.num_output == len(oa["p0"]) and s.list_capacity == lens[r]
+        single.close()
+    # the pool context itself sees all lists: printPhotons' columns of the lists one after the other
+    allout = pool.get_output()
+    assert len(allout["p0"]) == sum(lens) - 1
+    cat = np.concatenate([pool.pool_rank(r, r).get_output()["r0"] for r in range(3)])
+    assert np.array_equal(allout["r0"], cat)
+    mm = pool.ph_minmax()
+    assert mm[0] == min(s.min_r for s in summ[:3]) and mm[1] == max(s.max_r for s in summ[:3])
+    pool.close()
+
+
+def test_pool_refusals(hip):
+    frame, ph, cfg = synth.config1(n_photons=600, n0=8, n1=8)
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(2, 64)                            # slots per rank are rounded up to 512
+    v = pool.pool_rank(0, 0)
+    with pytest.raises(hip.McratHipError, match="slots per rank"):
+        v.set_photons(ph)                              # 600 photons do not fit
+    with pytest.raises(hip.McratHipError, match="pool"):
+        v.set_hydro(frame)                             # the hydro frame is the pool's
+    with pytest.raises(hip.McratHipError, match="views"):
+        pool.set_photons(ph)                           # photons go in through the views
+    with pytest.raises(hip.McratHipError):
+        pool.pool_rank(2, 0)
+    v.set_photons(_cut(ph, 0, 400, 600))
+    assert v.get_photons()["p0"].shape == (400,)
+    pool.pool_create(3, 1000)                          # re-creating drops the lists
+    assert pool.pool_summaries()[0].list_capacity == 0
+    pool.close()
