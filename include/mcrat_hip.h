@@ -287,6 +287,11 @@ typedef struct mcrat_hip_output_columns {
     char   *type;
 } mcrat_hip_output_columns;
 int mcrat_hip_get_output(mcrat_hip_ctx *ctx, mcrat_hip_output_columns *out);
+/* saveCheckpoint's in-place type conversion in CYCLOSYNCHROTRON_SWITCH builds (mcrat_io.c:896-900, :951-955, :991-995), on the resident
+ * list: every comptonised photon 'k' with weight != 0 becomes an unabsorbed one 'c' -- before the records are streamed out, and for
+ * good, so that the next frame's phAbsCyclosynch (mc_cyclosynch.c:1607) and printPhotons' PT see what the reference's would.
+ * mcrat_host_save_checkpoint calls it when its cyclosynchrotron_switch argument is on.  *num_converted may be NULL. */
+int mcrat_hip_convert_comptonized(mcrat_hip_ctx *ctx, int *num_converted);
 int mcrat_hip_get_photons_range(mcrat_hip_ctx *ctx, int first, int count, mcrat_hip_photon *records);
 
 /* Cyclo-synchrotron: the stages of a scatter frame with CYCLOSYNCHROTRON_SWITCH on.  They work on whatever photon

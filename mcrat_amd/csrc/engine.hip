@@ -144,6 +144,7 @@ static void drop_graph(mcrat_hip_ctx *c)
 
 static void sync_views(mcrat_hip_ctx *c);
 static int view_refuses(mcrat_hip_ctx *c, const char *what);
+static int ensure_counts(mcrat_hip_ctx *c, size_t n);
 
 extern "C" const char *mcrat_hip_version(void) { return "mcrat_hip 0.1 (gfx950, abi 1)"; }
 
@@ -220,11 +221,8 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
 
 static void destroy_view(mcrat_hip_ctx *v)
 {
-    // a view owns nothing but the scratch it allocated itself
+    // a view owns nothing but its cyclo-synchrotron hook state, a snapshot and its events; the rest are windows into the pool
     if (v->stream) (void)hipStreamSynchronize(v->stream);
-    if (v->aos_buf) (void)hipFree(v->aos_buf);
-    if (v->grid_count) (void)hipFree(v->grid_count);
-    if (v->d_grid_total) (void)hipFree(v->d_grid_total);
     if (v->d_cs_hook) (void)hipFree(v->d_cs_hook);
     if (v->ph_snap) (void)hipFree(v->ph_snap);
     for (hipEvent_t e : v->ev) (void)hipEventDestroy(e);
@@ -552,6 +550,24 @@ static void sync_views(mcrat_hip_ctx *c)
     }
 }
 
+// per-context scratch: `n` counters and the 8-byte total.  A view borrows its pool's (one stream, one call at a time): a thousand
+// views must not hold a thousand cell-sized arrays.
+static int ensure_counts(mcrat_hip_ctx *c, size_t n)
+{
+    if (c->parent) {
+        int rc = ensure_counts(c->parent, n);
+        c->grid_count = c->parent->grid_count; c->grid_count_cap = c->parent->grid_count_cap; c->d_grid_total = c->parent->d_grid_total;
+        return rc;
+    }
+    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+    if (c->grid_count_cap < n) {
+        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
+        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * n));
+        c->grid_count_cap = n;
+    }
+    return MCRAT_HIP_OK;
+}
+
 static int view_refuses(mcrat_hip_ctx *c, const char *what)
 {
     c->last_error = std::string(what) + ": a rank view shares its pool's hydro frame; call this on the pool context";
@@ -683,17 +699,13 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
         nb = (long long)g.start.size() - 1;
         entries_total = (long long)g.cells.size();
     } else {
-        if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+        { int rc = ensure_counts(c, 1); if (rc) return rc; }
         double f = g.f0;
         bool ok = false;
         for (int attempt = 0; attempt < 12 && !ok; ++attempt, f *= 0.5) {
             nb = grid_dims(g, naxes, f);
             if (nb > (long long)GRID_CODE_BUCKET_MASK) continue;              // bucket codes keep 27 bits for the index
-            if (c->grid_count_cap < (size_t)nb) {
-                if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
-                HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)nb));
-                c->grid_count_cap = (size_t)nb;
-            }
+            { int rc = ensure_counts(c, (size_t)nb); if (rc) return rc; }
             GridPlan plan;
             for (int k = 0; k < 3; ++k) { plan.org[k] = g.org[k]; plan.inv[k] = g.inv[k]; plan.dim[k] = g.dim[k]; plan.logmap[k] = g.logmap[k]; }
             plan.naxes = naxes;
@@ -860,12 +872,7 @@ int ingest_common(mcrat_hip_ctx *c, long long n_virtual, const mcrat_hip_slab *s
 {
     const long long nblk = ingest_blocks(n_virtual);
     if (nblk <= 0 || nblk > 0x7fffffffLL) return MCRAT_HIP_EINVAL;
-    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
-    if (c->grid_count_cap < (size_t)nblk) {
-        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
-        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)nblk));
-        c->grid_count_cap = (size_t)nblk;
-    }
+    { int rc_ = ensure_counts(c, (size_t)nblk); if (rc_) return rc_; }
     // CYCLOSYNCHROTRON_SWITCH is OFF in this engine (mcrat_hip_init refuses it): elem_factor starts at 0 (mclib_flash.c:275-279)
     int elem_factor = 0;
     unsigned long long total = 0;
@@ -1272,6 +1279,11 @@ static int upload_columns(mcrat_hip_ctx *c, int n, const std::vector<const doubl
 
 static int ensure_aos(mcrat_hip_ctx *c, size_t bytes)
 {
+    if (c->parent) {                               // a view borrows its pool's staging buffer (ensure_counts)
+        int rc = ensure_aos(c->parent, bytes);
+        c->aos_buf = c->parent->aos_buf; c->aos_bytes = c->parent->aos_bytes;
+        return rc;
+    }
     if (c->aos_buf && c->aos_bytes < bytes) { HIPCHK(c, hipFree(c->aos_buf)); c->aos_buf = nullptr; c->aos_bytes = 0; }
     if (!c->aos_buf) { HIPCHK(c, hipMalloc(&c->aos_buf, bytes)); c->aos_bytes = bytes; }
     return MCRAT_HIP_OK;
@@ -1310,12 +1322,7 @@ extern "C" int mcrat_hip_inject_photons(mcrat_hip_ctx *c, double r_inj, double p
     p.wien = spect == 'w';
     RngKey key = c->key;
     key.seed = seed;
-    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
-    if (c->grid_count_cap < (size_t)M) {
-        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
-        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)M));
-        c->grid_count_cap = (size_t)M;
-    }
+    { int rc_ = ensure_counts(c, (size_t)M); if (rc_) return rc_; }
     // mclib.c:87-136: draw the per-cell counts; too many photons -> weight x 10, too few -> weight x 0.5, draw again
     double weight = ph_weight;
     unsigned long long total = 0;
@@ -1398,13 +1405,8 @@ extern "C" int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *c, const mcrat_hip_
     p.theta_min = theta_min; p.theta_max = theta_max;
     RngKey key = c->key;
     key.seed = seed;
-    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
     const size_t need_counts = (size_t)std::max(M, (c->ph.n + 255) / 256 + 8);
-    if (c->grid_count_cap < need_counts) {
-        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
-        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * need_counts));
-        c->grid_count_cap = need_counts;
-    }
+    { int rc_ = ensure_counts(c, need_counts); if (rc_) return rc_; }
     unsigned *d_flags = nullptr;
     HIPCHK(c, hipMalloc((void **)&d_flags, 2 * sizeof(unsigned)));
     auto fail = [&](int code) { (void)hipFree(d_flags); return code; };
@@ -1451,12 +1453,7 @@ extern "C" int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *c, const mcrat_hip_
         const long long new_cap = (cap * 2 > cap + n_emit) ? cap * 2 : cap * (n_emit / cap);
         if (new_cap > 0x7fffffffLL) return fail2(MCRAT_HIP_EINVAL);
         if ((rc = grow_photons(c, (int)new_cap))) return fail2(rc);
-        if (c->grid_count_cap < (size_t)((c->ph.n + 255) / 256 + 8)) {
-            HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0;
-            const size_t cap2 = (size_t)((c->ph.n + 255) / 256 + 8);
-            if (hipMalloc((void **)&c->grid_count, sizeof(unsigned) * cap2) != hipSuccess) return fail2(MCRAT_HIP_ENOMEM);
-            c->grid_count_cap = cap2;
-        }
+        if ((rc = ensure_counts(c, (size_t)((c->ph.n + 255) / 256 + 8)))) return fail2(rc);
         if ((rc = count_nulls())) return fail2(rc);
     }
     if ((unsigned long long)n_emit > n_null) {
@@ -1575,7 +1572,7 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
     RebinRec *recs = reinterpret_cast<RebinRec *>(b + o_rec);
     unsigned *null_cnt = reinterpret_cast<unsigned *>(b + o_nblk);
     int *null_start = reinterpret_cast<int *>(b + o_nstart), *null_slots = reinterpret_cast<int *>(b + o_null);
-    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
+    if ((rc = ensure_counts(c, 1))) return rc;
     HIPCHK(c, launch_rebin_assign(c->ph, ax, bin_of, bin_count, c->stream));           // zeroes bin_count[0 .. B + 1] first
     HIPCHK(c, hipMemsetAsync(cursor, 0, sizeof(unsigned) * (size_t)B, c->stream));
     // how many photons take part (= the scan's total): eligible photons are all binned or the call fails
@@ -1663,7 +1660,7 @@ extern "C" int mcrat_hip_get_photons(mcrat_hip_ctx *c, mcrat_hip_photon_list *l)
     int rc = flush_pending(c);
     if (rc) return rc;
     const size_t bytes = sizeof(mcrat_hip_photon) * (size_t)n;
-    const bool fresh = !c->aos_buf || c->aos_bytes < bytes;
+    const bool fresh = !c->aos_buf || c->aos_bytes < bytes || c->parent;     // (a view's staging buffer is its pool's)
     if ((rc = ensure_aos(c, bytes))) return rc;
     // photons that came in as SoA columns have no uploaded records: the bytes between the members are the caller's
     if (fresh) HIPCHK(c, hipMemcpyAsync(c->aos_buf, l->photons, bytes, hipMemcpyHostToDevice, c->stream));
@@ -1695,6 +1692,21 @@ extern "C" int mcrat_hip_get_photons_range(mcrat_hip_ctx *c, int first, int coun
     return MCRAT_HIP_OK;
 }
 
+extern "C" int mcrat_hip_convert_comptonized(mcrat_hip_ctx *c, int *num_converted)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    int rc = ensure_aos(c, sizeof(unsigned));
+    if (rc) return rc;
+    unsigned n = 0;
+    HIPCHK(c, hipMemsetAsync(c->aos_buf, 0, sizeof(unsigned), c->stream));
+    HIPCHK(c, launch_convert_comptonized(c->ph, static_cast<unsigned *>(c->aos_buf), c->stream));
+    HIPCHK(c, hipMemcpyAsync(&n, c->aos_buf, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (num_converted) *num_converted = (int)n;
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_get_output(mcrat_hip_ctx *c, mcrat_hip_output_columns *out)
 {
     if (!c || !out) return MCRAT_HIP_EINVAL;
@@ -1703,12 +1715,7 @@ extern "C" int mcrat_hip_get_output(mcrat_hip_ctx *c, mcrat_hip_output_columns *
     int rc = flush_pending(c);
     if (rc) return rc;
     const long long nblk = (n + 255) / 256;
-    if (!c->d_grid_total) HIPCHK(c, hipMalloc((void **)&c->d_grid_total, sizeof(unsigned long long)));
-    if (c->grid_count_cap < (size_t)nblk) {
-        if (c->grid_count) { HIPCHK(c, hipFree(c->grid_count)); c->grid_count = nullptr; c->grid_count_cap = 0; }
-        HIPCHK(c, hipMalloc((void **)&c->grid_count, sizeof(unsigned) * (size_t)nblk));
-        c->grid_count_cap = (size_t)nblk;
-    }
+    { int rc_ = ensure_counts(c, (size_t)nblk); if (rc_) return rc_; }
     unsigned long long total = 0;
     HIPCHK(c, launch_output_count(c->ph, n, c->grid_count, c->d_grid_total, c->stream));
     HIPCHK(c, hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream));

@@ -43,6 +43,7 @@ hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream
 hipError_t launch_reduce(const PhotonDev &ph, ReducePartial *out, int blocks, hipStream_t stream);
 // struct photon records <-> SoA columns on the device (staging.hip); `aos` is a device buffer of n 176-B records
 hipError_t launch_init_states(LoopState *single, LoopState *ranks, int n_ranks, const LoopState &v, hipStream_t stream);
+hipError_t launch_convert_comptonized(const PhotonDev &ph, unsigned *converted, hipStream_t stream);   // 'k' with weight != 0 -> 'c' (mcrat_io.c:896-900)
 hipError_t launch_clear_slots(const PhotonDev &ph, int first, int count, hipStream_t stream);   // every column zeroed: no list's slots
 // rank pool: the per-frame reductions and printPhotons' count for every list (desc[r].len slots from r * stride), one launch
 hipError_t launch_rank_reduce(const PhotonDev &ph, int stride, int n_ranks, const RankDesc *desc, ReducePartial *out, int *n_out, hipStream_t stream);

@@ -182,6 +182,17 @@ __global__ __launch_bounds__(256) void init_states_kernel(LoopState *__restrict_
     }
 }
 
+// saveCheckpoint's in-place conversion with CYCLOSYNCHROTRON_SWITCH on (mcrat_io.c:896-900, :951-955, :991-995): a comptonised photon
+// 'k' with weight != 0 becomes an unabsorbed one 'c'
+__global__ __launch_bounds__(256) void convert_comptonized_kernel(PhotonDev ph, unsigned *__restrict__ converted)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool hit = i < ph.n && ph.type[i] == 'k' && ph.weight[i] != 0;
+    if (hit) ph.type[i] = 'c';
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(converted, (unsigned)__popcll(m));
+}
+
 // slots [first, first + count) of every column zeroed: not part of any list (flag byte 0: not FLAG_VALID)
 __global__ __launch_bounds__(256) void clear_slots_kernel(PhotonDev ph, int first, int count)
 {
@@ -257,6 +268,12 @@ __global__ __launch_bounds__(256) void rank_reduce_kernel(PhotonDev ph, int stri
 }
 
 }  // namespace
+
+hipError_t launch_convert_comptonized(const PhotonDev &ph, unsigned *converted, hipStream_t stream)
+{
+    convert_comptonized_kernel<<<dim3((ph.n + 255) / 256), dim3(256), 0, stream>>>(ph, converted);
+    return hipGetLastError();
+}
 
 hipError_t launch_clear_slots(const PhotonDev &ph, int first, int count, hipStream_t stream)
 {

@@ -187,6 +187,7 @@ SYMBOLS = {
     "mcrat_hip_absorb_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), _ip, _ip, _dp]),
     "mcrat_hip_get_hydro": (C.c_int, [_ctx, C.POINTER(HydroColumns)]),
     "mcrat_hip_get_output": (C.c_int, [_ctx, C.POINTER(OutputColumns)]),
+    "mcrat_hip_convert_comptonized": (C.c_int, [_ctx, _ip]),
     "mcrat_hip_get_photons_range": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
     "mcrat_hip_inject_photons": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char, C.c_double, C.c_double, C.c_double,
                                            C.c_uint64, _ip, _dp]),
@@ -299,11 +300,16 @@ class Engine:
         """the view of list `rank`: an Engine whose photons, clock and loop state are that list's"""
         ctx = _ctx()
         self._check(self.lib.mcrat_hip_pool_rank(self.ctx, int(rank), int(rng_stream), C.byref(ctx)), "pool_rank")
+        if not hasattr(self, "views"):
+            self.views = {}                                      # the pool was laid out from C (mcrat_host_run_ranks)
         v = self.views.get(rank)
         if v is None or v.ctx.value != ctx.value:
             v = Engine.__new__(Engine)
             v.lib, v.cfg, v.ctx, v.n, v.pool = self.lib, self.cfg, ctx, 0, self
             self.views[rank] = v
+        v.n = int(self.lib.mcrat_hip_num_photon_slots(ctx))      # the list may have been set from C (mcrat_host_run_ranks)
+        if getattr(self, "num_elements", None) is not None:
+            v.num_elements = self.num_elements
         return v
 
     def pool_summaries(self):
@@ -540,6 +546,12 @@ class Engine:
         self._check(self.lib.mcrat_hip_get_output(self.ctx, C.byref(o)), "get_output")
         assert o.count == m
         return out
+
+    def convert_comptonized(self):
+        """saveCheckpoint's 'k' -> 'c' conversion (mcrat_io.c:896-900) on the resident list; returns the number converted"""
+        n = C.c_int()
+        self._check(self.lib.mcrat_hip_convert_comptonized(self.ctx, C.byref(n)), "convert_comptonized")
+        return n.value
 
     def get_photons_range(self, first, count):
         a = np.zeros(count, dtype=PHOTON_DTYPE)

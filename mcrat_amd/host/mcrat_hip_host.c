@@ -2,9 +2,11 @@
 #include "mcrat_hip_host.h"
 
 #include <ctype.h>
+#include <limits.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* next line that carries values: skips blank lines and "[Block]" headers, cuts the trailing "# comment" */
 static int next_value_line(FILE *f, char *buf, size_t n)
@@ -297,7 +299,8 @@ static int copy_file(const char *from, const char *to)        /* "exec cp file f
 }
 
 int mcrat_host_save_checkpoint(const char *dir, int frame, int frame2, int scatt_frame, double time_now, mcrat_hip_ctx *ctx,
-                               const mcrat_hip_photon_list *list, int list_capacity, int last_frame, int angle_rank, int angle_size)
+                               mcrat_hip_photon_list *list, int list_capacity, int last_frame, int angle_rank, int angle_size,
+                               int cyclosynchrotron_switch)
 {
     char file[2000], old[2100];
     if (!dir || list_capacity < 0 || (!ctx && list_capacity > 0 && (!list || !list->photons))) return 1;
@@ -315,6 +318,14 @@ int mcrat_host_save_checkpoint(const char *dir, int frame, int frame2, int scatt
         int ph_num = list_capacity;
         ok = fwrite(&scatt_frame, sizeof(int), 1, f) == 1 && fwrite(&time_now, sizeof(double), 1, f) == 1 &&
              fwrite(&ph_num, sizeof(int), 1, f) == 1;
+    }
+    if (ok && list_capacity > 0 && cyclosynchrotron_switch) {  /* :896-900, :951-955, :991-995: 'k' with weight != 0 -> 'c', in place */
+        if (ctx) {
+            ok = mcrat_hip_convert_comptonized(ctx, NULL) == 0;
+        } else {
+            for (int i = 0; i < list_capacity; i++)
+                if (list->photons[i].type == 'k' && list->photons[i].weight != 0) list->photons[i].type = 'c';
+        }
     }
     if (ok && list_capacity > 0) {
         if (ctx) {
@@ -446,6 +457,214 @@ int mcrat_host_scatter_frame_resident(mcrat_hip_ctx *ctx, mcrat_host_get_hydro_f
     log_frame(fPtr, &st, *time_now, max_scatt, min_scatt, avg_scatt, avg_r);
     if (stats) *stats = st;
     return MCRAT_HIP_OK;
+}
+
+/* ------------------------------------------------------------------ rank pool (mcrat_hip_host.h) */
+uint64_t mcrat_host_rank_seed(uint64_t rng_seed, long long k)
+{
+    uint64_t z = rng_seed + 0x9E3779B97F4A7C15ull * (uint64_t)(k + 1);       /* SplitMix64 */
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int mcrat_host_split_ranks(const mcrat_host_mcpar *par, int numprocs, int first_rank, int n_adopt, const char *base_dir,
+                           double ph_weight_default, uint64_t base_seed, mcrat_host_rank *out)
+{
+    if (!par || !out || !base_dir || numprocs <= 0 || first_rank < 0 || n_adopt <= 0 || first_rank + n_adopt > numprocs) return -1;
+    const int num_angles = par->n_theta_j;
+    if (num_angles <= 0 || numprocs % num_angles != 0) return -1;
+    const double delta_theta = (par->theta_j - par->theta_jmin) / num_angles;                     /* degrees, mcrat.c:125 */
+    const int procs_per_angle = numprocs / num_angles;                                            /* :139 */
+    for (int k = 0; k < n_adopt; k++) {
+        mcrat_host_rank *r = &out[k];
+        memset(r, 0, sizeof *r);
+        const int myid = first_rank + k, color = myid / procs_per_angle;                          /* MPI_Comm_split(color, key = myid), :146 */
+        double thread_theta = par->theta_jmin;
+        for (int j = 1; j <= color; j++) thread_theta = thread_theta + delta_theta;               /* :129-133 */
+        r->myid = myid;
+        r->angle_id = myid - color * procs_per_angle;
+        r->angle_procs = procs_per_angle;
+        r->theta_jmin_thread = thread_theta * (M_PI / 180);                                       /* :152-153 */
+        r->theta_jmax_thread = r->theta_jmin_thread + (delta_theta * (M_PI / 180));
+        snprintf(r->mc_dir, sizeof r->mc_dir, "%s%0.1lf-%0.1lf/", base_dir, r->theta_jmin_thread * 180 / M_PI, r->theta_jmax_thread * 180 / M_PI);
+        r->inj_radius = par->inj_radius[color];
+        r->ph_weight_suggest = ph_weight_default;
+        const int frm0 = par->frm0[color], frm2 = par->frm2[color];
+        const int proc_frame_size = (int)ceil((frm2 - frm0) / (float)r->angle_procs);             /* :457 */
+        r->framestart = frm0 + r->angle_id * proc_frame_size;                                     /* :472 */
+        r->frm2 = (r->angle_id != r->angle_procs - 1) ? frm0 + r->angle_id * proc_frame_size + proc_frame_size - 1 : frm2;   /* :475-482 */
+        r->rng_seed = base_seed;
+        r->rng_stream = (uint32_t)myid;
+    }
+    return 0;
+}
+
+static double wall_ms(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
+
+#define RANK_DEG(r) (r)->theta_jmin_thread * 180 / M_PI, (r)->theta_jmax_thread * 180 / M_PI
+
+int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_ranks, mcrat_host_pool_config *cfg)
+{
+    if (!pool || !ranks || n_ranks <= 0 || !cfg || !cfg->get_hydro || !(cfg->fps > 0) || cfg->max_photons <= 0) return MCRAT_HIP_EINVAL;
+    int rc = mcrat_hip_pool_create(pool, n_ranks, cfg->slots_per_rank > 0 ? cfg->slots_per_rank : cfg->max_photons);
+    if (rc) return rc;
+    mcrat_hip_rank_summary *summ = (mcrat_hip_rank_summary *)calloc((size_t)n_ranks, sizeof *summ);
+    if (!summ) return MCRAT_HIP_ENOMEM;
+    cfg->hydro_frames_read = cfg->launches = 0;
+    cfg->ms_propagate = cfg->ms_hydro = cfg->ms_output = 0;
+    for (int r = 0; r < n_ranks && rc == 0; r++) {
+        mcrat_host_rank *k = &ranks[r];
+        rc = mcrat_hip_pool_rank(pool, r, k->rng_stream, &k->view);
+        k->frame = k->framestart;
+        k->state = 0;
+        k->seeds_drawn = 0;
+        k->frame_scatt_cnt_total = 0;
+        if (rc == 0 && k->restrt == 'c') {                                                        /* readCheckpoint's photons, mcrat.c:487 */
+            if (!k->restart_list) { rc = MCRAT_HIP_EINVAL; break; }
+            rc = mcrat_hip_set_photons(k->view, k->restart_list);
+            k->state = 4;
+            k->scatt_frame = k->scatt_framestart;
+            k->time_now = k->time_now_start;
+            k->num_photons = k->restart_list->num_photons;
+        }
+        if (k->fPtr) {                                                                            /* mcrat.c:560 */
+            fprintf(k->fPtr, "Im Proc %d with angles %0.1lf-%0.1lf  Starting on Frame: %d scatt_framestart: %d\n", k->angle_id, RANK_DEG(k),
+                    k->framestart, k->framestart);
+            fflush(k->fPtr);
+        }
+    }
+    mcrat_hip_slab slab;
+    memset(&slab, 0, sizeof slab);
+    slab.fps = cfg->fps;
+    memcpy(slab.r0_domain, cfg->r0_domain, sizeof slab.r0_domain);
+    memcpy(slab.r1_domain, cfg->r1_domain, sizeof slab.r1_domain);
+    memcpy(slab.r2_domain, cfg->r2_domain, sizeof slab.r2_domain);
+    long long frames_done = 0;
+    int stop = 0;
+    while (rc == 0 && !stop) {                     /* one turn: every rank's next injection batch (the outer loop of mcrat.c:609) */
+        int first = INT_MAX;
+        for (int r = 0; r < n_ranks; r++)
+            if (ranks[r].state == 4) { if (ranks[r].scatt_frame < first) first = ranks[r].scatt_frame; }
+            else if (ranks[r].frame <= ranks[r].frm2) { ranks[r].state = 0; if (ranks[r].frame < first) first = ranks[r].frame; }
+            else ranks[r].state = 3;
+        if (first == INT_MAX) break;
+        for (int F = first; F <= cfg->last_frm && rc == 0 && !stop; F++) {                         /* the hydro frames, read once for all ranks */
+            /* ranks whose injection frame this is (mcrat.c:626-647) */
+            double staged_r_inj = -1;
+            for (int r = 0; r < n_ranks && rc == 0; r++) {
+                mcrat_host_rank *k = &ranks[r];
+                if (k->state != 0 || k->frame != F) continue;
+                k->time_now = F / cfg->fps;                                                       /* :628 */
+                if (k->fPtr) fprintf(k->fPtr, ">> Im Proc: %d with angles %0.1lf - %0.1lf Working on Frame: %d\n", k->angle_id, RANK_DEG(k), F);
+                if (staged_r_inj != k->inj_radius) {                                              /* getHydroData(..., inj_radius, 1, ...), :638 */
+                    slab.r_inj = k->inj_radius; slab.ph_inj_switch = 1;
+                    slab.min_r = slab.max_r = slab.min_theta = slab.max_theta = 0;
+                    const double t0 = wall_ms();
+                    rc = cfg->get_hydro(cfg->user, pool, F, &slab);
+                    cfg->ms_hydro += wall_ms() - t0;
+                    cfg->hydro_frames_read += 1;
+                    if (rc) break;
+                    staged_r_inj = k->inj_radius;
+                }
+                if (k->fPtr) fprintf(k->fPtr, ">>  Proc: %d with angles %0.1lf-%0.1lf: Injecting photons\n", k->angle_id, RANK_DEG(k));
+                rc = mcrat_hip_inject_photons(k->view, k->inj_radius, k->ph_weight_suggest, cfg->min_photons, cfg->max_photons, cfg->spect,
+                                              k->theta_jmin_thread, k->theta_jmax_thread, cfg->fps, mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++),
+                                              &k->num_photons, &k->ph_weight);                   /* photonInjection, :645 */
+                if (rc) break;
+                k->state = 1;
+                k->scatt_frame = F;                                                               /* scatt_framestart = frame, :660 */
+            }
+            if (rc) break;
+            int n_active = 0;
+            for (int r = 0; r < n_ranks; r++) {
+                if (ranks[r].state == 4 && ranks[r].scatt_frame == F) ranks[r].state = 1;        /* a restarted rank picks up at its scatt_framestart */
+                n_active += ranks[r].state == 1;
+            }
+            if (!n_active) continue;
+            /* phMinMax of every list (mcrat.c:704) -> the slab all of them fit in -> getHydroData once (:721) */
+            if ((rc = mcrat_hip_pool_summaries(pool, summ))) break;
+            slab.ph_inj_switch = 0;
+            slab.min_r = slab.min_theta = HUGE_VAL; slab.max_r = slab.max_theta = 0;
+            for (int r = 0; r < n_ranks; r++) {
+                if (ranks[r].state != 1) continue;
+                if (summ[r].min_r < slab.min_r) slab.min_r = summ[r].min_r;
+                if (summ[r].max_r > slab.max_r) slab.max_r = summ[r].max_r;
+                if (summ[r].min_theta < slab.min_theta) slab.min_theta = summ[r].min_theta;
+                if (summ[r].max_theta > slab.max_theta) slab.max_theta = summ[r].max_theta;
+                slab.r_inj = ranks[r].inj_radius;
+            }
+            {
+                const double t0 = wall_ms();
+                rc = cfg->get_hydro(cfg->user, pool, F, &slab);
+                cfg->ms_hydro += wall_ms() - t0;
+                cfg->hydro_frames_read += 1;
+                if (rc) break;
+            }
+            const double t_prop = wall_ms();
+            for (int r = 0; r < n_ranks && rc == 0; r++) {
+                mcrat_host_rank *k = &ranks[r];
+                if (k->state != 1) continue;
+                if (k->fPtr) {
+                    fprintf(k->fPtr, ">>\n>> Proc %d with angles %0.1lf-%0.1lf: Working on photons injected at frame: %d out of %d\n", k->angle_id, RANK_DEG(k),
+                            k->frame, k->frm2);
+                    fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: propagating and scattering %d photons\n", k->angle_id, RANK_DEG(k), k->num_photons);
+                }
+                /* the rank's per-frame seed (gsl_rng_set(rng, gsl_rng_get(rng)), :701) and its own clock (:758) */
+                const double remaining_time = ((F + 1) / cfg->fps) - k->time_now;
+                rc = mcrat_hip_begin_frame(k->view, mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++), k->time_now, remaining_time);
+            }
+            if (rc) break;
+            mcrat_hip_frame_stats tot;
+            if ((rc = mcrat_hip_run(pool, 0, &tot))) break;                                       /* mcrat.c:761-851 for every list */
+            cfg->launches += 1;
+            if ((rc = mcrat_hip_pool_summaries(pool, summ))) break;                               /* phScattStats, :881 */
+            cfg->ms_propagate += wall_ms() - t_prop;
+            const double t_out = wall_ms();
+            for (int r = 0; r < n_ranks && rc == 0; r++) {
+                mcrat_host_rank *k = &ranks[r];
+                if (k->state != 1) continue;
+                mcrat_hip_frame_stats st;
+                if ((rc = mcrat_hip_frame_statistics(k->view, &st))) break;
+                k->time_now = st.time_now;
+                k->frame_scatt_cnt_total += st.frame_scatt_cnt;
+                log_frame(k->fPtr, &st, k->time_now, summ[r].max_scatt, summ[r].min_scatt, summ[r].avg_scatt, summ[r].avg_r);
+                if (cfg->write_checkpoints) {
+                    if (k->fPtr) fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: Making checkpoint file\n", k->angle_id, RANK_DEG(k));
+                    if (mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, F, k->time_now, k->view, NULL, summ[r].list_capacity, cfg->last_frm,
+                                                   k->angle_id, k->angle_procs, 0) != 0) {       /* :902-915 */
+                        if (k->fPtr) fprintf(k->fPtr, "There is an issue with opening and saving the chkpt file therefore MCRaT is not saving data to the checkpoint or mc_proc files to prevent corruption of those data.\n");
+                        rc = 1;
+                        break;
+                    }
+                }
+                if (cfg->print_photons)                                                           /* :907 */
+                    rc = cfg->print_photons(k->view, F, k->mc_dir, k->angle_id, cfg->comv_switch, cfg->stokes_switch, cfg->save_type, k->fPtr);
+                k->scatt_frame = F + 1;
+            }
+            cfg->ms_output += wall_ms() - t_out;
+            frames_done += 1;
+            if (cfg->max_frames > 0 && frames_done >= cfg->max_frames) stop = 1;
+        }
+        /* the batch is through its last hydro frame (mcrat.c:920-922): restrt = INITALIZE, freePhotonList, next injection frame */
+        for (int r = 0; r < n_ranks && !stop; r++)
+            if (ranks[r].state == 1) { ranks[r].state = 2; ranks[r].frame += 1; }
+            else if (ranks[r].state == 0 || ranks[r].state == 4) { ranks[r].state = 2; ranks[r].frame += 1; }      /* its injection frame lies beyond last_frm: nothing to scatter in */
+    }
+    if (rc == 0 && !stop && cfg->write_checkpoints)
+        for (int r = 0; r < n_ranks; r++) {                                                       /* the closing saveCheckpoint of :924, list freed */
+            mcrat_host_rank *k = &ranks[r];
+            (void)mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, cfg->last_frm + 1, k->time_now, NULL, NULL, 0, cfg->last_frm, k->angle_id,
+                                             k->angle_procs, 0);
+            if (k->fPtr) { fprintf(k->fPtr, "Process %d has completed the MC calculation.\n", k->angle_id); fflush(k->fPtr); }
+        }
+    free(summ);
+    return rc;
 }
 
 /* ------------------------------------------------------------------ A/B shims (mcrat_hip_host.h) */

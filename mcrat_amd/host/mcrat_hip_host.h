@@ -80,9 +80,13 @@ void mcrat_host_pluto_name(char *out, size_t n, const char *prefix, int frame);
  * scatt_frame (int), time_now (double), list_capacity (int) -- followed by the struct photon records (176 B each).  The
  * previous file is kept as <file>_old except when scatt_frame == frame, where it is removed first (:849,:901,:951).
  * With ctx != NULL the records stream from the device in pieces (mcrat_hip_get_photons_range): no host copy of the list;
- * with ctx == NULL they are `list`'s.  Returns 0, or 1 if the file cannot be written (as the reference). */
+ * with ctx == NULL they are `list`'s.  cyclosynchrotron_switch (CYCLOSYNCHROTRON_SWITCH of mcrat_input.h) on: every comptonised
+ * photon 'k' with weight != 0 becomes an unabsorbed one 'c' before its record is written, and stays so in the list -- on the
+ * device (mcrat_hip_convert_comptonized) or in `list` -- as the reference converts it in place (:896-900, :951-955, :991-995).
+ * Returns 0, or 1 if the file cannot be written (as the reference). */
 int mcrat_host_save_checkpoint(const char *dir, int frame, int frame2, int scatt_frame, double time_now, mcrat_hip_ctx *ctx,
-                               const mcrat_hip_photon_list *list, int list_capacity, int last_frame, int angle_rank, int angle_size);
+                               mcrat_hip_photon_list *list, int list_capacity, int last_frame, int angle_rank, int angle_size,
+                               int cyclosynchrotron_switch);
 /* readCheckpoint (mcrat_io.c:1011-1134): fills the scalars with the reference's "+1" conventions; for a 'c' file
  * list->photons is malloc'ed with list_capacity records (free() it) ready for mcrat_hip_set_photons.  A missing file is
  * not an error (restart = 'i', scatt_framestart = framestart, :1127-1131).  Returns 0, -2 on a truncated file. */
@@ -143,6 +147,84 @@ int mcrat_host_scatter_frame_resident(mcrat_hip_ctx *ctx, mcrat_host_get_hydro_f
                                       const double r0_domain[2], const double r1_domain[2], const double r2_domain[2],
                                       double *time_now, int scatt_frame, int increment_scatt_frame, double fps, uint64_t seed,
                                       FILE *fPtr, mcrat_hip_frame_stats *stats);
+
+/* ---- rank pool: one process per GPU adopts R of the reference's MPI ranks (mcrat_hip_pool_*, include/mcrat_hip.h) ----
+ * What main() decides per MPI rank between mcrat.c:116 and :483 -- its angle bin (:139-164), its block of injection frames
+ * (:457-479), its directory, log file and generator -- lives in one mcrat_host_rank per adopted rank; mcrat_host_split_ranks
+ * fills them for an 'i' run the way MPI_Comm_split and the frame arithmetic would.  mcrat_host_run_ranks is then the rest of
+ * main() (:609-924) for all of them at once: for every rank the outer loop over its injection frames and the inner loop
+ * over the scatter frames, with the SAME per-rank results and files -- mc_proc_<angle_id>.h5, mc_chkpt_<angle_id>.dat and
+ * mc_output_<angle_id>.log in the rank's mc_dir -- but scheduled by hydro frame: ranks are independent (they never talk
+ * inside the loop), so the driver takes every rank's k-th injection batch together, walks the hydro frames
+ * once per batch, lets each rank join at its own injection frame, reads every hydro frame once for all ranks that are in
+ * it (the slab is the union of the ranks' phMinMax slabs, mcrat.c:704-721) and propagates all their lists in one launch.
+ * The photons stay on the device from injection to the last frame; what crosses PCIe per frame is what the reference
+ * writes per frame (checkpoint records, printPhotons' columns). */
+typedef struct mcrat_host_rank {
+    /* what the rank is (filled by mcrat_host_split_ranks, or by hand) */
+    int      myid;                       /* world rank this entry stands for (log lines only) */
+    int      angle_id, angle_procs;      /* rank and size in its angle communicator (mcrat.c:147-148); angle_procs is saveCheckpoint's angle_size */
+    char     mc_dir[1024];               /* mcrat.c:155 */
+    double   theta_jmin_thread, theta_jmax_thread;   /* radians, mcrat.c:152-153 */
+    double   inj_radius;                 /* mcrat.c:159 */
+    double   ph_weight_suggest;          /* mcrat.c:162 (ph_weight_default) */
+    int      framestart, frm2;           /* first and last injection frame of this rank, mcrat.c:472-483 */
+    uint64_t rng_seed;                   /* the rank's generator: seed k of the rank is mcrat_host_rank_seed(rng_seed, k), standing for the
+                                            k-th gsl_rng_get of mcrat.c:701 (and of photonInjection's draws) */
+    uint32_t rng_stream;                 /* its stream id in the engine's keyed source */
+    FILE    *fPtr;                       /* mc_output_<angle_id>.log, may be NULL */
+    /* a CONTINUE run (mc.par 'c'): what mcrat_host_read_checkpoint returned for this rank (mcrat.c:487) -- restrt 'c', the list (uploaded
+     * at the start; the caller keeps ownership), scatt_framestart and time_now_start; framestart / frm2 as the checkpoint gives them.
+     * restrt 0 or 'i': the rank starts by injecting at framestart */
+    char     restrt;
+    int      scatt_framestart;
+    double   time_now_start;
+    const mcrat_hip_photon_list *restart_list;
+    /* progress (driver-owned; zero it before the first call) */
+    mcrat_hip_ctx *view;
+    int      frame, scatt_frame;         /* the loop variables of mcrat.c:609,:664 */
+    double   time_now;
+    int      num_photons;                /* photon_list.num_photons after the injection */
+    double   ph_weight;                  /* the adjusted weight of the injection */
+    long long seeds_drawn;
+    long long frame_scatt_cnt_total;     /* scatterings over all frames (for callers' accounting) */
+    int      state;                      /* 0 waiting for its injection frame, 1 scattering, 2 batch finished, 3 all batches done,
+                                            4 restarted from a checkpoint, waiting for scatt_framestart */
+} mcrat_host_rank;
+
+uint64_t mcrat_host_rank_seed(uint64_t rng_seed, long long k);
+
+/* the rank/angle split of an INITALIZE run for the world ranks first_rank .. first_rank + n_adopt - 1 of numprocs
+ * (mcrat.c:116-164,457-483): numprocs must be a multiple of par->n_theta_j.  base_dir is FILEPATH MC_PATH.  rng_seed /
+ * rng_stream are set to (base_seed, myid): every rank its own stream (the reference gives all ranks GSL's default seed,
+ * SURVEY.md section 0 fact 7; distinct streams are what a user wants and what the engine's virtual ranks always used).
+ * 0, or -1 on a bad split. */
+int mcrat_host_split_ranks(const mcrat_host_mcpar *par, int numprocs, int first_rank, int n_adopt, const char *base_dir,
+                           double ph_weight_default, uint64_t base_seed, mcrat_host_rank *out);
+
+typedef int (*mcrat_host_print_photons_fn)(mcrat_hip_ctx *ctx, int frame, const char *dir, int angle_rank, int comv_switch,
+                                           int stokes_switch, int save_type, FILE *fPtr);
+typedef struct mcrat_host_pool_config {
+    double fps;                          /* mc.par */
+    int    last_frm;
+    double r0_domain[2], r1_domain[2], r2_domain[2];
+    char   spect;
+    int    min_photons, max_photons;
+    int    slots_per_rank;               /* 0: max_photons */
+    mcrat_host_get_hydro_fn get_hydro;   /* the reader: stages hydro frame `scatt_frame` for `slab` on the POOL context (getHydroData) */
+    void  *user;
+    int    write_checkpoints;            /* saveCheckpoint per rank and frame, mcrat.c:902 (0: skip -- benchmarks) */
+    mcrat_host_print_photons_fn print_photons;   /* mcrat_host_print_photons (needs the HDF5 build), or NULL to skip printPhotons */
+    int    comv_switch, stokes_switch, save_type;
+    int    max_frames;                   /* > 0: stop after this many hydro frames in total (tests, benchmarks) */
+    /* out */
+    long long hydro_frames_read;         /* get_hydro calls */
+    long long launches;                  /* mcrat_hip_run calls */
+    double ms_propagate, ms_hydro, ms_output;   /* wall time spent in the loop, in the reader callback, in checkpoint + printPhotons */
+} mcrat_host_pool_config;
+/* pool: a context of the run's DIMENSIONS / GEOMETRY / STOKES_SWITCH; the driver creates the pool layout and the views.
+ * Returns 0 or the first negative MCRAT_HIP_E* code (1: a checkpoint could not be written, as saveCheckpoint). */
+int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_ranks, mcrat_host_pool_config *cfg);
 
 /* ---- A/B shims: the reference's loop functions with their own argument order (Src/mclib.h:8-29) ----------------
  * For checking the engine against the CPU functions one call at a time inside MCRaT's own loop (mcrat.c:761-851):

@@ -80,14 +80,14 @@ def test_checkpoint_streamed_from_the_device_equals_the_one_written_from_host_re
     host = C.CDLL(build_host.build())
     host.mcrat_host_save_checkpoint.restype = C.c_int
     host.mcrat_host_save_checkpoint.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(PhotonList), C.c_int,
-                                                C.c_int, C.c_int, C.c_int]
+                                                C.c_int, C.c_int, C.c_int, C.c_int]
     e, _ = _engine_after_a_frame(hip, n=7000)
     (tmp_path / "a").mkdir()
     (tmp_path / "b").mkdir()
-    assert host.mcrat_host_save_checkpoint((str(tmp_path / "a") + "/").encode(), 200, 203, 257, 51.4, e.ctx, None, 7000, 3000, 0, 4) == 0
+    assert host.mcrat_host_save_checkpoint((str(tmp_path / "a") + "/").encode(), 200, 203, 257, 51.4, e.ctx, None, 7000, 3000, 0, 4, 0) == 0
     aos = e.get_photons_range(0, 7000)
     l = PhotonList(aos.ctypes.data, None, 7000, 0, 7000)
-    assert host.mcrat_host_save_checkpoint((str(tmp_path / "b") + "/").encode(), 200, 203, 257, 51.4, None, C.byref(l), 7000, 3000, 0, 4) == 0
+    assert host.mcrat_host_save_checkpoint((str(tmp_path / "b") + "/").encode(), 200, 203, 257, 51.4, None, C.byref(l), 7000, 3000, 0, 4, 0) == 0
     a, b = (tmp_path / "a" / "mc_chkpt_0.dat").read_bytes(), (tmp_path / "b" / "mc_chkpt_0.dat").read_bytes()
     assert a == b and len(a) == 4 + 1 + 12 + 8 + 4 + 176 * 7000
     assert a[:5] == struct.pack("=i", 4) + b"c"

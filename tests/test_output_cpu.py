@@ -23,7 +23,7 @@ def host():
     lib = C.CDLL(build_host.build())
     lib.mcrat_host_save_checkpoint.restype = C.c_int
     lib.mcrat_host_save_checkpoint.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(PhotonList), C.c_int,
-                                               C.c_int, C.c_int, C.c_int]
+                                               C.c_int, C.c_int, C.c_int, C.c_int]
     lib.mcrat_host_read_checkpoint.restype = C.c_int
     lib.mcrat_host_read_checkpoint.argtypes = [C.c_char_p, C.POINTER(PhotonList), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                C.c_char_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]
@@ -41,7 +41,7 @@ def _records(engine, n=300, seed=5):
 
 def _save(host, d, aos, frame, frame2, scatt_frame, t, last_frame, rank=3, size=8):
     l = PhotonList(aos.ctypes.data, None, len(aos), 0, len(aos))
-    return host.mcrat_host_save_checkpoint((str(d) + "/").encode(), frame, frame2, scatt_frame, t, None, C.byref(l), len(aos), last_frame, rank, size)
+    return host.mcrat_host_save_checkpoint((str(d) + "/").encode(), frame, frame2, scatt_frame, t, None, C.byref(l), len(aos), last_frame, rank, size, 0)
 
 
 def test_checkpoint_bytes_are_the_references_layout(host, tmp_path):
