@@ -70,9 +70,22 @@ struct alignas(32) CellGeom {    // one 32-B sector per in-cell test (geometry.c
 struct alignas(16) CellGeom2 {   // third axis, 3-D only
     double c2, s2;
 };
+// the per-cell operands of calculateOpticalDepth, as optical_depth.c:52,57 computes them (host and device: -ffp-contract=off both)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void cell_tau_operands(double gamma_cell, double dens_lab, double &beta_g, double &n_dens)
+{
+    beta_g = __builtin_sqrt(1.0 - 1.0 / (gamma_cell * gamma_cell));
+    n_dens = dens_lab / M_P;
+}
+
 struct alignas(32) CellFluid {   // gathered when tau or the comoving momentum is recomputed
     double a, b;                 // velocity with the per-cell part of geometry.c:189-253 applied (physics.hpp, cell_beta)
-    double gamma, dens_lab;
+    // what calculateOpticalDepth makes of the cell alone (optical_depth.c:52-57), computed once per frame instead of once per
+    // re-location -- the same operations on the same operands, so the same bits:
+    double beta_g;               // sqrt(1.0 - 1.0 / (gamma * gamma))
+    double n_dens;               // dens_lab / M_P
 };
 
 // exact accelerator for findContainingBlock (geometry.c:350-391): uniform buckets (optionally in
@@ -82,7 +95,7 @@ struct alignas(32) CellFluid {   // gathered when tau or the comoving momentum i
 // re-location costs two dependent load rounds (list range, then up to four entries) instead of five
 struct alignas(32) FatCell {
     double c0, c1, s0, s1;       // CellGeom
-    double a, b, gamma, dens_lab;   // CellFluid
+    double a, b, beta_g, n_dens;    // CellFluid
     double c2, s2;               // CellGeom2 (3-D)
     double fc;                   // HydroDev::fluid_c
     int cell;
@@ -120,6 +133,7 @@ struct HydroDev {
     const CellFluid *fluid;
     const double *temp;
     const double *fluid_c;       // third velocity component (2.5-D: v2; 3-D: Cartesian z), absent in 2-D
+    const double *gamma;         // the cells' Lorentz factor (photonInjection's count, mclib.c:95; the loop reads CellFluid::beta_g)
     const double *k2e;           // exp(x) K_2(x), x = m_e c^2 / k T, for cells with T >= 1e7 K (else 0)
     int M;
     double dom0[2], dom1[2], dom2[2];

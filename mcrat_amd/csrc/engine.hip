@@ -597,6 +597,7 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
     const size_t o_temp = take(sizeof(double) * M);
     const size_t o_fc = !two ? take(sizeof(double) * M) : 0;
     const size_t o_k2e = (any_hot || !host_grid) ? take(sizeof(double) * M) : 0;     // device path: known only after staging
+    const size_t o_gamma = take(sizeof(double) * M);
     const size_t total = off;
 
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -614,7 +615,7 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
         HIPCHK(c, launch_stage_cells(c->kc.dimensions, c->kc.geometry, c->hcol, M, reinterpret_cast<CellGeom *>(base + o_geom),
                                      three ? reinterpret_cast<CellGeom2 *>(base + o_geom2) : nullptr, reinterpret_cast<CellFluid *>(base + o_fluid),
                                      !two ? reinterpret_cast<double *>(base + o_fc) : nullptr, reinterpret_cast<double *>(base + o_temp),
-                                     d_part, d_samp, stride, nsamp, c->stream));
+                                     reinterpret_cast<double *>(base + o_gamma), d_part, d_samp, stride, nsamp, c->stream));
         std::vector<char> hs(scratch_bytes);
         HIPCHK(c, hipMemcpyAsync(hs.data(), c->aos_buf, scratch_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -646,7 +647,7 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
     const int geomv = c->kc.geometry;
     for (int i = 0; host_grid && i < M; ++i) {
         geom[i].c0 = h->r0[i]; geom[i].c1 = h->r1[i]; geom[i].s0 = h->r0_size[i]; geom[i].s1 = h->r1_size[i];
-        fluid[i].gamma = h->gamma[i]; fluid[i].dens_lab = h->dens_lab[i];
+        cell_tau_operands(h->gamma[i], h->dens_lab[i], fluid[i].beta_g, fluid[i].n_dens);
         const double v0 = h->v0[i], v1 = h->v1[i], v2 = two ? 0.0 : h->v2[i];
         if (!three) {
             if (geomv == GEOM_SPHERICAL) {
@@ -678,6 +679,7 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
             for (int i = 0; i < M; ++i) { g2[i].c2 = h->r2[i]; g2[i].s2 = h->r2_size[i]; }
         }
         memcpy(host.data() + o_temp, h->temp, sizeof(double) * M);
+        memcpy(host.data() + o_gamma, h->gamma, sizeof(double) * M);
         HIPCHK(c, hipMemcpy(c->hy_buf, host.data(), total, hipMemcpyHostToDevice));
     }
 
@@ -688,6 +690,7 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
     hy.temp = reinterpret_cast<const double *>(base + o_temp);
     hy.fluid_c = !two ? reinterpret_cast<const double *>(base + o_fc) : nullptr;
     hy.k2e = any_hot ? reinterpret_cast<const double *>(base + o_k2e) : nullptr;
+    hy.gamma = reinterpret_cast<const double *>(base + o_gamma);
     hy.M = M;
     hy.dom0[0] = dom0[0]; hy.dom0[1] = dom0[1];
     hy.dom1[0] = dom1[0]; hy.dom1[1] = dom1[1];
@@ -745,7 +748,7 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
             const int ci = g.cells[e];
             FatCell &f = fat[e];
             f.c0 = geom[ci].c0; f.c1 = geom[ci].c1; f.s0 = geom[ci].s0; f.s1 = geom[ci].s1;
-            f.a = fluid[ci].a; f.b = fluid[ci].b; f.gamma = fluid[ci].gamma; f.dens_lab = fluid[ci].dens_lab;
+            f.a = fluid[ci].a; f.b = fluid[ci].b; f.beta_g = fluid[ci].beta_g; f.n_dens = fluid[ci].n_dens;
             f.c2 = three ? h->r2[ci] : 0.0; f.s2 = three ? h->r2_size[ci] : 0.0;
             f.fc = fc ? fc[ci] : 0.0;
             f.cell = ci; f.pad = 0;

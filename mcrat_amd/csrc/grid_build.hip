@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void grid_records_kernel(int naxes, long long 
     const CellFluid f = fluid[ci];
     FatCell fc;
     fc.c0 = g.c0; fc.c1 = g.c1; fc.s0 = g.s0; fc.s1 = g.s1;
-    fc.a = f.a; fc.b = f.b; fc.gamma = f.gamma; fc.dens_lab = f.dens_lab;
+    fc.a = f.a; fc.b = f.b; fc.beta_g = f.beta_g; fc.n_dens = f.n_dens;
     fc.c2 = 0; fc.s2 = 0;
     if (naxes == 3) { const CellGeom2 g2 = geom2[ci]; fc.c2 = g2.c2; fc.s2 = g2.s2; }
     fc.fc = fluid_c ? fluid_c[ci] : 0.0;

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(IB) void outflow_prep_kernel(int dims, int geom, Ou
 // largest width per axis) and whether any cell is hot enough for the Maxwell-Juttner sampler (electron.c:208).
 __global__ __launch_bounds__(IB) void stage_cells_kernel(int dims, int geom, HydroCols h, int M, CellGeom *__restrict__ og, CellGeom2 *__restrict__ og2,
                                                          CellFluid *__restrict__ of, double *__restrict__ ofc, double *__restrict__ otemp,
-                                                         StagePartial *__restrict__ partials)
+                                                         double *__restrict__ ogamma, StagePartial *__restrict__ partials)
 {
     __shared__ StagePartial s_p[IB / 64];
     StagePartial p;
@@ -384,7 +384,8 @@ __global__ __launch_bounds__(IB) void stage_cells_kernel(int dims, int geom, Hyd
         if (three) { CellGeom2 g2; g2.c2 = c2; g2.s2 = s2; og2[i] = g2; }
         const double v0 = h.v0[i], v1 = h.v1[i], v2 = two ? 0.0 : h.v2[i];
         CellFluid f;
-        f.gamma = h.gamma[i]; f.dens_lab = h.dens_lab[i];
+        cell_tau_operands(h.gamma[i], h.dens_lab[i], f.beta_g, f.n_dens);
+        ogamma[i] = h.gamma[i];
         double fc = 0;
         if (!three) {
             if (geom == GEOM_SPHERICAL) {
@@ -564,9 +565,9 @@ hipError_t launch_outflow_prep(int dims, int geom, const OutflowDev &o, const Hy
 int stage_cells_blocks(int M) { const int b = (M + IB - 1) / IB; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
 
 hipError_t launch_stage_cells(int dims, int geom, const HydroCols &h, int M, CellGeom *og, CellGeom2 *og2, CellFluid *of, double *ofc, double *otemp,
-                              StagePartial *partials, double *samples, int stride, int nsamp, hipStream_t stream)
+                              double *ogamma, StagePartial *partials, double *samples, int stride, int nsamp, hipStream_t stream)
 {
-    hipLaunchKernelGGL(stage_cells_kernel, dim3(stage_cells_blocks(M)), dim3(IB), 0, stream, dims, geom, h, M, og, og2, of, ofc, otemp, partials);
+    hipLaunchKernelGGL(stage_cells_kernel, dim3(stage_cells_blocks(M)), dim3(IB), 0, stream, dims, geom, h, M, og, og2, of, ofc, otemp, ogamma, partials);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sample_cells_kernel, dim3((nsamp + IB - 1) / IB), dim3(IB), 0, stream, h, M, stride, nsamp, (dims == DIM_THREE) ? 3 : 2, samples);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void inject_count_kernel(InjectParams p, Hydro
         unsigned n = 0;
         if (in_injection_slab(p, c)) {
             const double T = hy.temp[i];
-            const double gamma = hy.fluid[i].gamma;
+            const double gamma = hy.gamma[i];
             const double ph_dens_calc = (4.0 / 3.0) * element_volume(p.dimensions, p.geometry, c) * ((gamma * p.num_dens_coeff * T * T * T) / weight);   // mclib.c:110
             EventStream rng = keyed_stream(key, attempt, (uint32_t)i, RNG_INJECT_COUNT);
             const long long k = poisson(rng, ph_dens_calc);

@@ -271,7 +271,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
     int cell;
     bool need_tau = (fl & FLAG_RECALC) != 0;
     bool new_cell = false;
-    double fa = 0, fb = 0, fc = 0, fgamma = 1, fdens = 0;
+    double fa = 0, fb = 0, fc = 0, fbeta_g = 0, fdens = 0;
     if (MC_DIAG(DIAG_SLOW_EMPTY)) { ph.tts[i] = 1e-3 + i * 1e-12; return 1e-3 + i * 1e-12; }
     if (MC_DIAG(DIAG_SLOW_NO_SEARCH)) relocate = false;
     if (relocate) {
@@ -281,7 +281,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         cell = phys::find_in_bucket<DIMS>(hy.grid, bucket, a0, a1, a2, hit);     // mclib.c:534
         ph.idx[hf] = cell;                                                       // mclib.c:536
         if (cell != -1) {
-            fa = hit.a; fb = hit.b; fc = hit.fc; fgamma = hit.gamma; fdens = hit.dens_lab;
+            fa = hit.a; fb = hit.b; fc = hit.fc; fbeta_g = hit.beta_g; fdens = hit.n_dens;
             new_cell = true;
             need_tau = true;                                                     // mclib.c:570
             if (count_it) relocated += 1;                                        // mclib.c:579,608-611
@@ -292,7 +292,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         cell = ph.idx[hf];
         if (cell != -1) {
             const CellFluid f = hy.fluid[cell];
-            fa = f.a; fb = f.b; fgamma = f.gamma; fdens = f.dens_lab;
+            fa = f.a; fb = f.b; fbeta_g = f.beta_g; fdens = f.n_dens;
             if constexpr (DIMS != DIM_TWO) fc = hy.fluid_c[cell];
         }
     }
@@ -318,7 +318,7 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
                 if (!new_cell) comv0 = ph.c0[i];
                 norm = phys::thermal_cross_section(hy, comv0, hy.temp[cell]);
             }
-            const double tau = phys::optical_depth_direct(beta, fgamma, fdens, p1, p2, p3, norm);
+            const double tau = phys::optical_depth_direct(beta, fbeta_g, fdens, p1, p2, p3, norm);
             ntau = -1.0 / tau;
             ph.tau[i] = tau;
             ph.ntau[h] = ntau;
@@ -541,7 +541,7 @@ __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, 
     const CellFluid f = hy.fluid[cell];
     double norm = 1.0;
     if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], fluid_temp, !WAVE || (threadIdx.x & 63) == 0);   // optical_depth.c:58
-    tau_new = phys::optical_depth_direct(beta, f.gamma, f.dens_lab, p[1], p[2], p[3], norm);
+    tau_new = phys::optical_depth_direct(beta, f.beta_g, f.n_dens, p[1], p[2], p[3], norm);
     return true;
 }
 

@@ -156,7 +156,7 @@ hipError_t launch_fill_spherical(int dims, int geom, const HydroCols &h, int M, 
 hipError_t launch_outflow_prep(int dims, int geom, const OutflowDev &o, const HydroCols &h, int M, hipStream_t stream);
 int stage_cells_blocks(int M);
 hipError_t launch_stage_cells(int dims, int geom, const HydroCols &h, int M, CellGeom *og, CellGeom2 *og2, CellFluid *of, double *ofc, double *otemp,
-                              StagePartial *partials, double *samples, int stride, int nsamp, hipStream_t stream);
+                              double *ogamma, StagePartial *partials, double *samples, int stride, int nsamp, hipStream_t stream);
 // createHotCrossSection on the device (hot_table.hip; hot_x_section.c:82-133,324-400)
 constexpr int HOT_TABLE_SUBSTREAMS = 256;   // sample k of an entry belongs to substream k % 256 (part of the table's definition)
 struct HotTableParams {

@@ -246,17 +246,17 @@ __device__ __forceinline__ void lorentz_boost(const double b[3], const double p[
 
 // ---------------------------------------------------------------- optical depth
 // optical_depth.c:7-59 (TAU_CALCULATION == DIRECT): tau' = n_lab sigma_T (1 - beta cos(angle to the flow)) [1/cm]
-__device__ __forceinline__ double optical_depth_direct(const double fluid_beta[3], double gamma_cell, double dens_lab,
+// beta_g = sqrt(1 - 1/gamma^2) (:52) and n_dens = dens_lab / M_P (:57) depend on the cell alone and come staged (CellFluid).
+__device__ __forceinline__ double optical_depth_direct(const double fluid_beta[3], double beta_g, double n_dens,
                                                        double p1, double p2, double p3, double norm_cross_section = 1.0)
 {
     const double fl_v_norm = sqrt(fluid_beta[0] * fluid_beta[0] + fluid_beta[1] * fluid_beta[1] + fluid_beta[2] * fluid_beta[2]);
     const double ph_v_norm = sqrt(p1 * p1 + p2 * p2 + p3 * p3);
     const double n_cosangle = ((fluid_beta[0] * p1) + (fluid_beta[1] * p2) + (fluid_beta[2] * p3)) / (fl_v_norm * ph_v_norm);
-    const double beta = sqrt(1.0 - 1.0 / (gamma_cell * gamma_cell));
-    const double fluid_factor = (1.0 - beta * n_cosangle);
-    const double thermal_n_dens_lab = dens_lab / M_P;
-    return (thermal_n_dens_lab) * (THOM_X_SECT * norm_cross_section) * fluid_factor;
+    const double fluid_factor = (1.0 - beta_g * n_cosangle);
+    return (n_dens) * (THOM_X_SECT * norm_cross_section) * fluid_factor;
 }
+
 
 // getCrossSection / getThermalCrossSection, optical_depth.c:117-149: 1 in DIRECT; in TABLE
 // 10^interp(log10(h nu'/m_e c^2), log10(kT/m_e c^2)) with GSL's bilinear interp2d scheme on the uniform grid of
