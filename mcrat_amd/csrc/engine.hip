@@ -83,6 +83,7 @@ struct mcrat_hip_ctx {
     // virtual ranks (cfg.virtual_rank_photons > 0): one LoopState per list
     int n_ranks = 0;
     int rank_block = 256;             // threads per list of the next launches (choose_rank_block)
+    bool rank_fuse = true;            // ... and whether they use the build with the fused pass
     bool rank_block_fixed = false;
     double rank_passes_per_list = 0;  // of the last completed frame
     LoopState *d_rstates = nullptr;
@@ -2045,11 +2046,20 @@ static int ensure_events(mcrat_hip_ctx *c, size_t n);
 // optical depth before it has run a frame; it looks at the previous one (passes per list).
 static void choose_rank_block(mcrat_hip_ctx *c)
 {
-    if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) { c->rank_block = (atoi(e) == 128) ? 128 : 256; return; }
+    if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) {
+        c->rank_block = (atoi(e) == 128) ? 128 : 256;
+        c->rank_fuse = c->rank_block == 256 && c->rank_passes_per_list < 48.0;
+        if (const char *f = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = c->rank_block == 256 && atoi(f) != 0;
+        return;
+    }
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const bool many = c->n_ranks > 2 * cus && longest_rank_list(c) <= 1024;
     c->rank_block = (many && c->rank_passes_per_list >= 48.0) ? 128 : 256;
+    // the build with the fused pass (kernels.hip, rank_loop_kernel<.., FUSE>) for frames that looked optically thin last time (or
+    // have not been seen yet): there most slots change cell between two events
+    c->rank_fuse = c->rank_block == 256 && c->rank_passes_per_list < 48.0;
+    if (const char *e = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = c->rank_block == 256 && atoi(e) != 0;
 }
 
 // rank pool: what the kernel needs to know about every list, from its view
@@ -2081,7 +2091,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
         HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, batch,
-                                   c->rank_block, c->stream));
+                                   c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
         if (c->cfg.profile) {
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
             HIPCHK(c, hipEventSynchronize(c->ev[1]));

@@ -222,12 +222,13 @@ constexpr int Q_RECALC_ONLY = (int)0x80000000;   // queue entry flag: the slot i
 // 2: recalc tau only) when the slot must go through the slow path; the time returned then is a placeholder.
 template <int DIMS, int GEOM, bool FORCE>
 __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned fl, int cell,
-                                           double r0, double r1, double r2, double ntau, uint64_t bits, int &queue, int &bucket)
+                                           double r0, double r1, double r2, double ntau, uint64_t bits, int &queue, int &bucket,
+                                           double &a0, double &a1, double &a2)
 {
     queue = 0;
     bucket = -1;
+    a0 = a1 = a2 = 0;
     if (!(fl & FLAG_VALID)) return INFINITY;
-    double a0, a1, a2;
     if (MC_DIAG(DIAG_SKIP_COORDS)) { a0 = r0 + r1; a1 = r2; a2 = 0; }
     else phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
     if (phys::in_domain<DIMS>(hy, a0, a1, a2) && (cell != -1)) {               // mclib.c:492-505
@@ -334,6 +335,69 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
     return t;
 }
 
+// K slots of one thread through the re-location branch of the slow path AT ONCE: the same loads, the same arithmetic in the same
+// order as slow_one -- the same bits -- but written as one straight-line block over the K slots (no branch between the stages:
+// physics.hpp's helpers select instead of branching), so that the K dependent chains (two gathers, six square roots, sixteen
+// divisions, a logarithm each) interleave in the issue slots one chain leaves empty.  Where most photons change cell between two
+// events -- optically thin frames, and the forced pass of every frame (mcrat.c:756) -- a pass is this function for every slot, and
+// two waves per SIMD hide little of one chain's latency.
+// Takes a slot only when the bucket's hint settles it (one 96-B entry, the cell provably the only one that holds the point:
+// find_in_bucket); todo[k] stays set for the others -- list walks, points outside every cell -- and the caller falls back to slow_one.
+// (DIRECT optical depths only: the TABLE build keeps slow_one.)
+template <int DIMS, int GEOM, int K>
+__device__ __forceinline__ void relocate_lockstep(const PhotonDev &ph, const HydroDev &hy, const int (&slot)[K], bool (&todo)[K],
+                                                  const double (&r0)[K], const double (&r1)[K], const double (&a0)[K], const double (&a1)[K],
+                                                  const double (&a2)[K], const int (&code)[K], const uint64_t (&bits)[K], const unsigned (&fl)[K],
+                                                  bool count_it, double (&t)[K], int &relocated)
+{
+    static_assert(!TABLE_MODE, "DIRECT optical depths");
+    const GridDev &g = hy.grid;
+    BucketDir d[K];
+    double p0[K], p1[K], p2[K], p3[K];
+    bool take[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        take[k] = todo[k] && code[k] >= 0;
+        d[k] = g.dir[take[k] ? (code[k] & GRID_CODE_BUCKET_MASK) : 0];
+        const int i = slot[k];
+        p0[k] = ph.p0[i]; p1[k] = ph.p1[i]; p2[k] = ph.p2[i]; p3[k] = ph.p3[i];
+    }
+    FatCell f[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const unsigned hint = (d[k].hints >> (4 * ((code[k] >> GRID_CODE_OCT_SHIFT) & 7))) & 15u;
+        take[k] = take[k] && d[k].n > 0 && (code[k] & GRID_CODE_HINT_OK) && hint != GRID_NO_HINT;
+        f[k] = g.cells[take[k] ? d[k].e0 + (int)hint : 0];
+    }
+    double comv[K][4], tau[K], ntau[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        take[k] = take[k] && phys::well_in_fat_cell<DIMS>(f[k], a0[k], a1[k], a2[k]);
+        double cphi, sphi;
+        phys::cos_sin_of_atan2(r1[k], r0[k], cphi, sphi);                        // photon azimuth, mclib.c:549-552
+        double beta[3];
+        phys::beta_from_record<DIMS>(f[k].a, f[k].b, f[k].fc, cphi, sphi, beta);
+        const double lab[4] = {p0[k], p1[k], p2[k], p3[k]};
+        phys::lorentz_boost(beta, lab, comv[k], true);                           // mclib.c:558
+        tau[k] = phys::optical_depth_direct(beta, f[k].beta_g, f[k].n_dens, p1[k], p2[k], p3[k], 1.0);
+        ntau[k] = -1.0 / tau[k];
+        t[k] = sample_free_time(ntau[k], bits[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (!take[k]) continue;
+        const int i = slot[k], h = i - ph.hot_bias, hf = i - ph.if_bias;
+        ph.idx[hf] = f[k].cell;                                                  // mclib.c:536
+        ph.c0[i] = comv[k][0]; ph.c1[i] = comv[k][1]; ph.c2[i] = comv[k][2]; ph.c3[i] = comv[k][3];
+        ph.tau[i] = tau[k];
+        ph.ntau[h] = ntau[k];
+        if (fl[k] & FLAG_RECALC) ph.flags[hf] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));   // mclib.c:571-576
+        ph.tts[i] = t[k];
+        if (count_it) relocated += 1;                                            // mclib.c:579,608-611
+        todo[k] = false;
+    }
+}
+
 // the streaming loads of one slot pair
 struct PairIn {
     double2 R0, R1, R2, U0, U1, U2, NTAU;
@@ -418,9 +482,24 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
 
         int q0, q1, b0, b1;
         double2 T;
-        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0, b0);
-        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1, b1);
+        double A0[2], A1[2], A2[2];
+        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0, b0, A0[0], A1[0], A2[0]);
+        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1, b1, A0[1], A1[1], A2[1]);
         if constexpr (FORCE) {
+            if constexpr (!TABLE_MODE) {             // both slots of the pair in lockstep; what the hints do not settle goes on below
+                const int slot[2] = {i0, i0 + 1}, code[2] = {b0, b1};
+                bool todo[2] = {q0 != 0, q1 != 0};
+                const double R0[2] = {in.R0.x, in.R0.y}, R1[2] = {in.R1.x, in.R1.y};
+                const uint64_t bits[2] = {bits0, bits1};
+                const unsigned fl[2] = {in.FL.x, in.FL.y};
+                double tt[2];
+                int dummy = 0;
+                if (todo[0] || todo[1]) {
+                    relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, R0, R1, A0, A1, A2, code, bits, fl, false, tt, dummy);
+                    if (q0 && !todo[0]) { T.x = tt[0]; q0 = 0; }
+                    if (q1 && !todo[1]) { T.y = tt[1]; q1 = 0; }
+                }
+            }
             if (q0) T.x = slow_one<DIMS, GEOM>(ph, hy, i0, true, b0, false, bits0, relocated, not_found);
             if (q1) T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, true, b1, false, bits1, relocated, not_found);
             q0 = q1 = 0;
@@ -799,8 +878,13 @@ constexpr int rank_lds_bytes_per_slot(int block) { return block >= 256 ? 7 * (in
 #ifndef RANK_WAVES_PER_SIMD
 #define RANK_WAVES_PER_SIMD 2
 #endif
+#ifndef RANK_FUSE_DEN
+#define RANK_FUSE_DEN 2      // a pass takes the fused form when more than 1/RANK_FUSE_DEN of the slots changed cell in the previous one
+#endif
 
-template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK>
+// FUSE: the kernel also holds the fused form of a pass (below).  It pays in optically thin frames and costs dense ones code they never
+// run (instruction cache, registers), so it is a build of its own and engine.hip picks per frame, as it picks the workgroup size.
+template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK, bool FUSE>
 __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
@@ -809,7 +893,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's r and -1/tau columns when it fits (lds_slots >= n)
     __shared__ LoopState st;
     __shared__ EventSharedT<RANK_BLOCK> sh;
-    __shared__ int s_qn, s_sln;
+    __shared__ int s_qn, s_sln, s_nrel;
     __shared__ int s_qb[RANK_QCAP];
     // the slow-path queue shares memory with the event walk's sorted list: the queue is empty before the list is written
     static_assert(sizeof(sh.list) >= sizeof(int) * RANK_QCAP, "queue fits into the sorted-list storage");
@@ -875,14 +959,21 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     }
     RANK_TICK(0);
 
+    int prev_rel = 0;                                        // slots that changed cell in the previous pass
     for (long long pass = 0; pass < max_passes; ++pass) {
         const int nseg = st.nseg;
         const int skip = st.skip_idx;
         const unsigned long long iter = st.iteration;
         const double t_cut = st.t_cut;
         const bool force = st.force_relocate != 0;          // first pass of a frame, mcrat.c:756
-        if (tid == 0) { s_qn = 0; s_sln = 0; }
+        // Where most slots change cell from one event to the next (the forced pass; optically thin frames, whose events lie many
+        // cells' light-crossing times apart) a thread takes its own slots through the re-location in lockstep (relocate_lockstep)
+        // instead of queueing them: no hand-over through LDS, and the chains of its slots overlap.  Where few do (dense frames), the
+        // queue keeps the lanes of the slow path dense.  Same arithmetic either way.
+        const bool fused = FUSE && !TABLE_MODE && (force || RANK_FUSE_DEN * prev_rel > n);
+        if (tid == 0) { s_qn = 0; s_sln = 0; s_nrel = 0; }
         __syncthreads();
+        int n_rel = 0;
 
         MinCand best;
         best.init();
@@ -901,121 +992,181 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                 if (tid == 0) s_qn = 0;
                 __syncthreads();
             }
-            // Two slot pairs per thread per trip, every stage written over all four slots before the next stage:
-            // with two lists per CU a SIMD holds two waves, and four independent chains (LDS loads -> sqrt -> cell-record
-            // gather -> Philox -> log) in flight hide part of each other's latency.  Same arithmetic per slot as fast_one;
-            // on the forced pass of a new frame (mcrat.c:756) every located slot goes to the queue (mclib.c:528).
-            constexpr int NS = 4;
+            // Queue form: two slot pairs per thread per trip, every stage written over all four slots before the next stage: with
+            // two lists per CU a SIMD holds two waves, and four independent chains (LDS loads -> sqrt -> cell-record gather ->
+            // Philox -> log) in flight hide part of each other's latency; slots that need the slow path go to the LDS queue.
+            // Fused form: one slot pair per trip, its re-locations in lockstep right here (relocate_lockstep); only what the hints
+            // do not settle is queued.  Same arithmetic per slot as fast_one / slow_one in both.
             const int hoff = base - ph.hot_bias;
-            for (int pair = (c0 >> 1) + tid; 2 * pair < c1; pair += 2 * EVENT_BLOCK) {
-                int il[NS];
-                bool live[NS];
-                il[0] = 2 * pair; il[1] = 2 * pair + 1; il[2] = 2 * (pair + EVENT_BLOCK); il[3] = il[2] + 1;
+            auto phase1 = [&](auto ns_c, auto fused_c) {
+                constexpr int NS = decltype(ns_c)::value;
+                constexpr bool FUSED = decltype(fused_c)::value;
+                constexpr int PAIRS = NS / 2;
+                for (int pair = (c0 >> 1) + tid; 2 * pair < c1; pair += PAIRS * EVENT_BLOCK) {
+                    int il[NS];
+                    bool live[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) { live[k] = il[k] < c1; if (!live[k]) il[k] = c0; }
-                double r0[NS], r1[NS], r2[NS], ntau[NS];
-                int cell[NS];
-                unsigned fl[NS];
+                    for (int j = 0; j < PAIRS; ++j) { il[2 * j] = 2 * (pair + j * EVENT_BLOCK); il[2 * j + 1] = il[2 * j] + 1; }
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const int h = il[k] + hoff;
-                    r0[k] = ph.r0[h]; r1[k] = ph.r1[h]; r2[k] = ph.r2[h];
-                    const int hf = base + il[k] - ph.if_bias;
-                    ntau[k] = ph.ntau[h]; cell[k] = ph.idx[hf]; fl[k] = ph.flags[hf];
-                }
-                if (nseg > 0) {                                  // pending updatePhotonPosition, mclib.c:1067-1095
-                    double u0[NS], u1[NS], u2[NS];
-                    bool mv[NS];
+                    for (int k = 0; k < NS; ++k) { live[k] = il[k] < c1; if (!live[k]) il[k] = c0; }
+                    double r0[NS], r1[NS], r2[NS], ntau[NS];
+                    int cell[NS];
+                    unsigned fl[NS];
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
                         const int h = il[k] + hoff;
-                        const int hu = base + il[k] - ph.u_bias;
-                        u0[k] = ph.u0[hu]; u1[k] = ph.u1[hu]; u2[k] = ph.u2[hu];
-                        mv[k] = live[k] && (fl[k] & FLAG_MOVES) && (base + il[k] != skip);
+                        r0[k] = ph.r0[h]; r1[k] = ph.r1[h]; r2[k] = ph.r2[h];
+                        const int hf = base + il[k] - ph.if_bias;
+                        ntau[k] = ph.ntau[h]; cell[k] = ph.idx[hf]; fl[k] = ph.flags[hf];
                     }
-                    for (int sg = 0; sg < nseg; ++sg) {
-                        const double t = st.seg[sg];
+                    if (nseg > 0) {                                  // pending updatePhotonPosition, mclib.c:1067-1095
+                        double u0[NS], u1[NS], u2[NS];
+                        bool mv[NS];
 #pragma unroll
                         for (int k = 0; k < NS; ++k) {
-                            const double n0 = r0[k] + u0[k] * t, n1 = r1[k] + u1[k] * t, n2 = r2[k] + u2[k] * t;
-                            r0[k] = mv[k] ? n0 : r0[k]; r1[k] = mv[k] ? n1 : r1[k]; r2[k] = mv[k] ? n2 : r2[k];
+                            const int hu = base + il[k] - ph.u_bias;
+                            u0[k] = ph.u0[hu]; u1[k] = ph.u1[hu]; u2[k] = ph.u2[hu];
+                            mv[k] = live[k] && (fl[k] & FLAG_MOVES) && (base + il[k] != skip);
                         }
+                        for (int sg = 0; sg < nseg; ++sg) {
+                            const double t = st.seg[sg];
+#pragma unroll
+                            for (int k = 0; k < NS; ++k) {
+                                const double n0 = r0[k] + u0[k] * t, n1 = r1[k] + u1[k] * t, n2 = r2[k] + u2[k] * t;
+                                r0[k] = mv[k] ? n0 : r0[k]; r1[k] = mv[k] ? n1 : r1[k]; r2[k] = mv[k] ? n2 : r2[k];
+                            }
+                        }
+#pragma unroll
+                        for (int k = 0; k < NS; ++k)
+                            if (mv[k]) { const int h = il[k] + hoff; ph.r0[h] = r0[k]; ph.r1[h] = r1[k]; ph.r2[h] = r2[k]; }
+                    }
+                    double a0[NS], a1[NS], a2[NS], tf[NS];
+                    bool dom[NS], inb[NS];
+                    CellGeom cg[NS];
+                    CellGeom2 cg2[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        const int cc = (cell[k] < 0 || MC_DIAG(DIAG_SKIP_INCELL)) ? 0 : cell[k];
+                        cg[k] = hy.geom[cc];                                         // geometry.c:394-417 operands
+                        if constexpr (DIMS == DIM_THREE) cg2[k] = hy.geom2[cc];
                     }
 #pragma unroll
-                    for (int k = 0; k < NS; ++k)
-                        if (mv[k]) { const int h = il[k] + hoff; ph.r0[h] = r0[k]; ph.r1[h] = r1[k]; ph.r2[h] = r2[k]; }
-                }
-                double a0[NS], a1[NS], a2[NS], tf[NS];
-                bool dom[NS], inb[NS];
-                CellGeom cg[NS];
-                CellGeom2 cg2[NS];
+                    for (int k = 0; k < NS; ++k) {
+                        if (MC_DIAG(DIAG_SKIP_COORDS)) { a0[k] = r0[k] + r1[k]; a1[k] = r2[k]; a2[k] = 0; }
+                        else phys::hydro_coords<DIMS, GEOM>(r0[k], r1[k], r2[k], a0[k], a1[k], a2[k]);
+                        dom[k] = phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);      // mclib.c:492-505
+                    }
+                    uint64_t bits[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const int cc = (cell[k] < 0 || MC_DIAG(DIAG_SKIP_INCELL)) ? 0 : cell[k];
-                    cg[k] = hy.geom[cc];                                         // geometry.c:394-417 operands
-                    if constexpr (DIMS == DIM_THREE) cg2[k] = hy.geom2[cc];
-                }
+                    for (int j = 0; j < PAIRS; ++j) {
+                        Philox4 blk;
+                        const uint32_t pj = (uint32_t)(pair + j * EVENT_BLOCK);
+                        if (MC_DIAG(DIAG_SKIP_PHILOX)) { blk.w[0] = pj * 2654435761u + (uint32_t)iter; blk.w[1] = pj ^ 0x9e3779b9u; blk.w[2] = ~blk.w[0]; blk.w[3] = blk.w[1] + 7u; }
+                        else blk = keyed_block(rk.seed, iter, pj, RNG_FREEPATH, rk.stream);
+                        bits[2 * j] = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
+                        bits[2 * j + 1] = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
+                    }
+                    // decisions, slot by slot
+                    int qd[NS], code[NS];
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    if (MC_DIAG(DIAG_SKIP_COORDS)) { a0[k] = r0[k] + r1[k]; a1[k] = r2[k]; a2[k] = 0; }
-                    else phys::hydro_coords<DIMS, GEOM>(r0[k], r1[k], r2[k], a0[k], a1[k], a2[k]);
-                    dom[k] = phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);      // mclib.c:492-505
-                }
-                Philox4 ba, bb;
-                if (MC_DIAG(DIAG_SKIP_PHILOX)) {
-                    ba.w[0] = pair * 2654435761u + (uint32_t)iter; ba.w[1] = pair ^ 0x9e3779b9u; ba.w[2] = ~ba.w[0]; ba.w[3] = ba.w[1] + 7u;
-                    bb = ba; bb.w[1] ^= 0x5bd1e995u; bb.w[3] += 77u;
-                } else {
-                    ba = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
-                    bb = keyed_block(rk.seed, iter, (uint32_t)(pair + EVENT_BLOCK), RNG_FREEPATH, rk.stream);
-                }
-                const uint64_t bits[NS] = {(uint64_t)ba.w[0] | ((uint64_t)ba.w[1] << 32), (uint64_t)ba.w[2] | ((uint64_t)ba.w[3] << 32),
-                                           (uint64_t)bb.w[0] | ((uint64_t)bb.w[1] << 32), (uint64_t)bb.w[2] | ((uint64_t)bb.w[3] << 32)};
+                    for (int k = 0; k < NS; ++k) {
+                        inb[k] = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) && (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
+                        if constexpr (DIMS == DIM_THREE) inb[k] = inb[k] && (2 * fabs(a2[k] - cg2[k].c2) - cg2[k].s2 <= 0);
+                        if (MC_DIAG(DIAG_SKIP_INCELL)) inb[k] = true;
+                        qd[k] = 0; code[k] = -1;
+                        if (!live[k] || !(fl[k] & FLAG_VALID) || !(dom[k] && cell[k] != -1)) continue;
+                        if (force || !inb[k]) qd[k] = 1;                              // mclib.c:507,528
+                        else if ((fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;   // mclib.c:668
+                        if (qd[k] == 1) { code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]); n_rel += 1; }
+                    }
+                    if constexpr (FUSED) {                           // the draws of the slots that stay in their cells, if there are any
+                        bool any = false;
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    inb[k] = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) && (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
-                    if constexpr (DIMS == DIM_THREE) inb[k] = inb[k] && (2 * fabs(a2[k] - cg2[k].c2) - cg2[k].s2 <= 0);
-                    tf[k] = sample_free_time(ntau[k], bits[k]);                   // mclib.c:675-687
-                    if (MC_DIAG(DIAG_SKIP_SAMPLE)) tf[k] = 1e-7 * (1.0 + (double)(bits[k] >> 40) * 1e-3) + ntau[k] * 0.0;
-                    if (MC_DIAG(DIAG_SKIP_INCELL)) inb[k] = true;
-                }
-                // decisions, slot by slot (rarely anything but the first branch)
+                        for (int k = 0; k < NS; ++k) any = any || (live[k] && (fl[k] & FLAG_VALID) && dom[k] && cell[k] != -1 && qd[k] == 0);
+                        if (any) {
 #pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    if (!live[k]) continue;
-                    const int i = base + il[k], h = il[k] + hoff;
-                    double t;
-                    if (!(fl[k] & FLAG_VALID)) { ph.tts[i] = INFINITY; continue; }
-                    if (dom[k] && cell[k] != -1) {
-                        int q = 0;
-                        if (force || !inb[k]) q = 1;                              // mclib.c:507,528
-                        else if (fl[k] & FLAG_RECALC) {                           // mclib.c:668
-                            if (fl[k] & FLAG_TAU_FRESH) {
-                                ph.flags[i - ph.if_bias] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
-                                ph.tau[i] = ph.tau_next[i];
-                            } else q = 2;
-                        }
-                        if (q) {
-                            const int bucket = (q == 1) ? phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]) : -1;
-                            const int e = atomicAdd(&s_qn, 1);                    // < RANK_QCAP: a chunk has no more slots than that
-                            s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0);
-                            s_qb[e] = bucket;
-                            ph.tts[i] = __longlong_as_double((long long)bits[k]);   // the draw, for phase 2 (which stores the free time)
-                            continue;
-                        } else {
-                            t = tf[k];
-                            ph.tts[i] = t;
+                            for (int k = 0; k < NS; ++k) tf[k] = sample_free_time(ntau[k], bits[k]);
                         }
                     } else {
-                        if (cell[k] != -1) ph.idx[i - ph.if_bias] = -1;           // mclib.c:592
-                        t = 1e12 / C_LIGHT;                                       // mclib.c:620,684
-                        ph.tts[i] = t;
+#pragma unroll
+                        for (int k = 0; k < NS; ++k) {
+                            tf[k] = sample_free_time(ntau[k], bits[k]);               // mclib.c:675-687
+                            if (MC_DIAG(DIAG_SKIP_SAMPLE)) tf[k] = 1e-7 * (1.0 + (double)(bits[k] >> 40) * 1e-3) + ntau[k] * 0.0;
+                        }
                     }
-                    best.offer(t, i);
-                    if (t < t_cut) shortlist_lds(t, i);
+                    bool settled[NS];
+                    double tl[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) { settled[k] = false; tl[k] = 0; }
+                    if constexpr (FUSED && !TABLE_MODE) {
+#pragma unroll
+                        for (int k0 = 0; k0 < NS; k0 += 2) {
+                            bool todo[2] = {qd[k0] == 1, qd[k0 + 1] == 1};
+                            if (!(todo[0] || todo[1])) continue;
+                            const int slot[2] = {base + il[k0], base + il[k0 + 1]}, cd[2] = {code[k0], code[k0 + 1]};
+                            const double R0[2] = {r0[k0], r0[k0 + 1]}, R1[2] = {r1[k0], r1[k0 + 1]};
+                            const double A0[2] = {a0[k0], a0[k0 + 1]}, A1[2] = {a1[k0], a1[k0 + 1]}, A2[2] = {a2[k0], a2[k0 + 1]};
+                            const uint64_t bt[2] = {bits[k0], bits[k0 + 1]};
+                            const unsigned fk[2] = {fl[k0], fl[k0 + 1]};
+                            double tt[2];
+                            relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, R0, R1, A0, A1, A2, cd, bt, fk, !force, tt, relocated);
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+                                if (qd[k0 + j] == 1 && !todo[j]) { settled[k0 + j] = true; tl[k0 + j] = tt[j]; }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        if (!live[k]) continue;
+                        const int i = base + il[k];
+                        double t;
+                        if (!(fl[k] & FLAG_VALID)) { ph.tts[i] = INFINITY; continue; }
+                        if (settled[k]) {                                             // re-located in lockstep above; everything is stored
+                            best.offer(tl[k], i);
+                            if (tl[k] < t_cut) shortlist_lds(tl[k], i);
+                            continue;
+                        }
+                        if (dom[k] && cell[k] != -1) {
+                            const int q = qd[k];
+                            if (!q && (fl[k] & FLAG_RECALC)) {                        // mclib.c:668, tau of the new momentum is at hand
+                                ph.flags[i - ph.if_bias] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                                ph.tau[i] = ph.tau_next[i];
+                            }
+                            if (q) {
+                                const int e = atomicAdd(&s_qn, 1);                    // < RANK_QCAP: a chunk has no more slots than that
+                                s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0);
+                                s_qb[e] = code[k];
+                                ph.tts[i] = __longlong_as_double((long long)bits[k]);   // the draw, for phase 2 (which stores the free time)
+                                continue;
+                            } else {
+                                t = tf[k];
+                                ph.tts[i] = t;
+                            }
+                        } else {
+                            if (cell[k] != -1) ph.idx[i - ph.if_bias] = -1;           // mclib.c:592
+                            t = 1e12 / C_LIGHT;                                       // mclib.c:620,684
+                            ph.tts[i] = t;
+                        }
+                        best.offer(t, i);
+                        if (t < t_cut) shortlist_lds(t, i);
+                    }
                 }
+            };
+            if constexpr (FUSE && !TABLE_MODE) {
+                if (fused) phase1(std::integral_constant<int, 2>{}, std::true_type{});
+                else phase1(std::integral_constant<int, 4>{}, std::false_type{});
+            } else {
+                phase1(std::integral_constant<int, 4>{}, std::false_type{});
             }
             if (!force) RANK_TICK(6);
+            if constexpr (FUSE) {                            // how many slots changed cell this pass: the next pass's form
+                if (c0 + RANK_QCAP >= n) {
+                    int w = n_rel;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+                    if (lane == 0 && w) atomicAdd(&s_nrel, w);
+                }
+            }
             __syncthreads();
             if (!force) RANK_TICK(7);
             // ---- phase 2: the queued slots, dense
@@ -1034,6 +1185,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if (relocated) atomicAdd(reinterpret_cast<unsigned long long *>(&st.n_relocated), (unsigned long long)relocated);
         if (not_found) atomicAdd(reinterpret_cast<unsigned long long *>(&st.not_found), (unsigned long long)not_found);
         __syncthreads();
+        prev_rel = s_nrel;                                   // (complete since the barrier after phase 1; reset after the next ones)
         MinCand g;
         g.init();
 #pragma unroll
@@ -1561,6 +1713,8 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, long long max_passes, int block, hipStream_t stream)
 {
+    const bool fuse = block >= 1000;               // block: 128 or 256 threads per list, + 1000 for the build with the fused pass (256 threads)
+    if (fuse) block -= 1000;
     RankLayout lay = {n_ranks, rank_stride, ph.n, desc};
     // per-pass columns in LDS (32 B per slot with 128 threads, 61 B with 256: rank_loop_kernel) for lists of up to 1024 photons
     int lds_slots = 0;
@@ -1580,11 +1734,14 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
             }
         };
         if (block == 128) {
-            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 128>, rank_loop_kernel<DV, GV, true, false, 128>, 128);
-            else launch(rank_loop_kernel<DV, GV, false, true, 128>, rank_loop_kernel<DV, GV, false, false, 128>, 128);
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 128, false>, rank_loop_kernel<DV, GV, true, false, 128, false>, 128);
+            else launch(rank_loop_kernel<DV, GV, false, true, 128, false>, rank_loop_kernel<DV, GV, false, false, 128, false>, 128);
+        } else if (fuse && !TABLE_MODE) {
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256, true>, rank_loop_kernel<DV, GV, true, false, 256, true>, 256);
+            else launch(rank_loop_kernel<DV, GV, false, true, 256, true>, rank_loop_kernel<DV, GV, false, false, 256, true>, 256);
         } else {
-            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256>, rank_loop_kernel<DV, GV, true, false, 256>, 256);
-            else launch(rank_loop_kernel<DV, GV, false, true, 256>, rank_loop_kernel<DV, GV, false, false, 256>, 256);
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256, false>, rank_loop_kernel<DV, GV, true, false, 256, false>, 256);
+            else launch(rank_loop_kernel<DV, GV, false, true, 256, false>, rank_loop_kernel<DV, GV, false, false, 256, false>, 256);
         }
     });
 }

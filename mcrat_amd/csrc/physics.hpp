@@ -184,11 +184,15 @@ __device__ __forceinline__ void beta_from_record(double a, double b, double c, d
 }
 
 // cos and sin of atan2(y, x) without the angle (atan2(0,0) = 0 -> (1,0))
+// (written with selects, not branches, like zero_norm and lorentz_boost below: the values are the same, and a thread that takes several
+// photons through these functions in lockstep -- relocate_lockstep, kernels.hip -- gets one straight-line block to interleave)
 __device__ __forceinline__ void cos_sin_of_atan2(double y, double x, double &c, double &s)
 {
     const double h = sqrt(x * x + y * y);
-    if (h > 0) { c = x / h; s = y / h; }
-    else { c = (x < 0 || (x == 0 && signbit(x))) ? -1.0 : 1.0; s = 0.0; }
+    const double ch = x / h, sh = y / h;
+    const bool pos = h > 0;
+    c = pos ? ch : ((x < 0 || (x == 0 && signbit(x))) ? -1.0 : 1.0);
+    s = pos ? sh : 0.0;
 }
 
 // geometry.c:189-253: fluid velocity of a cell (hydro basis) -> Cartesian, for a photon at azimuth
@@ -211,11 +215,11 @@ __device__ __forceinline__ void cell_beta(const HydroDev &h, int cell, double cp
 __device__ __forceinline__ void zero_norm(double p[4])
 {
     const double nrm = sqrt(p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
-    if (p[0] != nrm) {
-        p[1] = (p[1] / nrm) * p[0];
-        p[2] = (p[2] / nrm) * p[0];
-        p[3] = (p[3] / nrm) * p[0];
-    }
+    const double q1 = (p[1] / nrm) * p[0], q2 = (p[2] / nrm) * p[0], q3 = (p[3] / nrm) * p[0];
+    const bool fix = p[0] != nrm;
+    p[1] = fix ? q1 : p[1];
+    p[2] = fix ? q2 : p[2];
+    p[3] = fix ? q3 : p[3];
 }
 
 // mclib.c:302-407
@@ -223,7 +227,7 @@ __device__ __forceinline__ void lorentz_boost(const double b[3], const double p[
 {
     const double beta = sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
     double r[4];
-    if (beta > 0) {
+    {
         const double gamma = 1.0 / sqrt(1 - beta * beta);
         const double b2 = beta * beta, g1 = gamma - 1;
         const double L01 = -1 * b[0] * gamma, L02 = -1 * b[1] * gamma, L03 = -1 * b[2] * gamma;
@@ -233,12 +237,12 @@ __device__ __forceinline__ void lorentz_boost(const double b[3], const double p[
         const double L22 = 1 + ((g1 * (b[1] * b[1])) / b2);
         const double L23 = (g1 * (b[1] * b[2])) / b2;
         const double L33 = 1 + ((g1 * (b[2] * b[2])) / b2);
-        r[0] = ((p[0] * gamma + p[1] * L01) + p[2] * L02) + p[3] * L03;
-        r[1] = ((p[0] * L01 + p[1] * L11) + p[2] * L12) + p[3] * L13;
-        r[2] = ((p[0] * L02 + p[1] * L12) + p[2] * L22) + p[3] * L23;
-        r[3] = ((p[0] * L03 + p[1] * L13) + p[2] * L23) + p[3] * L33;
-    } else {
-        r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; r[3] = p[3];
+        const double m0 = ((p[0] * gamma + p[1] * L01) + p[2] * L02) + p[3] * L03;
+        const double m1 = ((p[0] * L01 + p[1] * L11) + p[2] * L12) + p[3] * L13;
+        const double m2 = ((p[0] * L02 + p[1] * L12) + p[2] * L22) + p[3] * L23;
+        const double m3 = ((p[0] * L03 + p[1] * L13) + p[2] * L23) + p[3] * L33;
+        const bool moving = beta > 0;                   // a fluid at rest: the identity (mclib.c:313)
+        r[0] = moving ? m0 : p[0]; r[1] = moving ? m1 : p[1]; r[2] = moving ? m2 : p[2]; r[3] = moving ? m3 : p[3];
     }
     if (photon) zero_norm(r);
     out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];

@@ -7,6 +7,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcrat_amd import engine, synth  # noqa: E402
 
+if os.environ.get("MCRAT_HIP_LIB"):
+    engine.LIB_PATH = os.environ["MCRAT_HIP_LIB"]
+
 REPS = int(os.environ.get("REPS", "5"))
 cases = os.environ.get("CASES", "thin,dense,stokes,cfg3").split(",")
 n, per = int(os.environ.get("N", "1000000")), int(os.environ.get("PER", "1000"))
@@ -34,8 +37,10 @@ for case in cases:
         t0 = time.perf_counter()
         st = e.run(0)
         dt = time.perf_counter() - t0
+        if k == 1:
+            first = (st.frame_scatt_cnt, st.photon_steps, st.iterations)        # counters of a fixed seed; the time is the best of REPS
         if k and (best is None or dt < best[0]):
-            best = (dt, st.frame_scatt_cnt, st.photon_steps, st.iterations)
+            best = (dt,) + first
     e.close()
     print("%-7s %8.3f ms  events %8d  photon-steps %.3e  passes/list %.1f  -> %.3e events/s  frac %.3f"
           % (case, best[0] * 1e3, best[1], best[2], best[3] / (n / per), best[1] / best[0], 110 * best[2] / best[0] / 8e12), flush=True)
