@@ -37,6 +37,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: these declarations are its whole surface */
+#endif
 
 #define MCRAT_HIP_ABI_VERSION 1
 
@@ -47,6 +50,7 @@ extern "C" {
 #define MCRAT_HIP_ENOMEM   (-3)  /* device or host allocation failed                      */
 #define MCRAT_HIP_EHIP     (-4)  /* a HIP runtime call failed (see mcrat_hip_last_error)  */
 #define MCRAT_HIP_ESTATE   (-5)  /* call out of order (e.g. run before set_hydro)         */
+#define MCRAT_HIP_EREFUSED (-6)  /* the reference refuses this too and goes on (rebinCyclosynchCompPhotons' early returns); nothing changed */
 
 /* switch values: identical to Src/mcrat.h:36-44,64-65 so a -D of mcrat_input.h maps 1:1 */
 #define MCRAT_HIP_CARTESIAN        0
@@ -327,8 +331,9 @@ int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosync
  *                                replaced by one 'k' photon per non-empty (log10 energy, polar angle of the position[, azimuth]) bin with the
  *                                bin's weight and weighted averages (bins filled in slot order, so the sums are the reference's sums);
  *                                returns the number of empty bins in *empty_bins and the two counters the reference updates
- *                                (:689-690).  MCRAT_HIP_EINVAL on the reference's error paths: nothing to rebin, more bins than
- *                                max_photons, zero bins along an axis, a photon outside the histograms, too few null slots. */
+ *                                (:689-690).  MCRAT_HIP_EREFUSED on the reference's own refusals, which leave the list as it was: nothing to
+ *                                rebin, more bins than max_photons, zero bins along an axis, a photon outside the histograms, too few null
+ *                                slots (MCRAT_HIP_EINVAL is a bad argument). */
 int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, int max_photons, int *empty_bins, int *num_cyclosynch_ph_emit,
                                int *scatt_cyclosynch_num_ph);
 /*   mcrat_hip_scatter_frame_cyclosynch   the scatter-frame body of main() with CYCLOSYNCHROTRON_SWITCH on (mcrat.c:706-878, from the pool emission
@@ -392,6 +397,11 @@ int mcrat_hip_create_hot_cross_section(mcrat_hip_ctx *ctx, double *thermal_table
  * mcrat_hip_num_photon_slots on get; a context with cyclosynchrotron_switch on also sets num_photons and num_null_photons
  * from what the list holds now (photons.c:252-275). */
 int mcrat_hip_set_photons(mcrat_hip_ctx *ctx, const mcrat_hip_photon_list *list);
+/* Optional, once per allocation (after allocatePhotonListMemory, photons.c:28 / reallocatePhotonListMemory): page-lock the caller's
+ * array so that set_photons / get_photons move it by direct DMA at the link's rate -- pageable memory goes through the runtime's
+ * staging buffers at a third of that.  Unregister before free()/realloc(). */
+int mcrat_hip_register_host(mcrat_hip_ctx *ctx, void *ptr, size_t bytes);
+int mcrat_hip_unregister_host(mcrat_hip_ctx *ctx, void *ptr);
 int mcrat_hip_get_photons(mcrat_hip_ctx *ctx, mcrat_hip_photon_list *list);
 int mcrat_hip_set_photons_soa(mcrat_hip_ctx *ctx, const mcrat_hip_photon_soa *soa);
 int mcrat_hip_get_photons_soa(mcrat_hip_ctx *ctx, const mcrat_hip_photon_soa *soa);
@@ -500,6 +510,9 @@ int mcrat_hip_synchronize(mcrat_hip_ctx *ctx);
 size_t mcrat_hip_device_bytes(const mcrat_hip_ctx *ctx);   /* HBM held by the context */
 int mcrat_hip_lookup_cell(mcrat_hip_ctx *ctx, int n, const double *a0, const double *a1, const double *a2, int *cell_out); /* device cell search == findContainingBlock geometry.c:350 */
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "libmcrat_hip.so")
 KERNEL_TUS = ["kernels%s_d%d.hip" % (m, d) for m in ("", "_table") for d in (0, 1, 2)]   # kernels.hip per TAU_CALCULATION x DIMENSIONS
 SOURCES = KERNEL_TUS + ["launchers.hip", "grid_build.hip", "staging.hip", "inject.hip", "ingest.hip", "hot_table.hip", "engine.hip"]
 HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden"]
 OBJDIR = os.path.join(HERE, "_obj")
 _KERNEL_DEPS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"]
 DEPS = {"launchers.hip": ["launchers.hip", "device_types.hpp", "launch.hpp"],

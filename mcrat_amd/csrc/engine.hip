@@ -158,6 +158,7 @@ extern "C" const char *mcrat_hip_strerror(int code)
     case MCRAT_HIP_ENOMEM: return "out of memory";
     case MCRAT_HIP_EHIP: return "HIP runtime error";
     case MCRAT_HIP_ESTATE: return "call out of order";
+    case MCRAT_HIP_EREFUSED: return "refused as the reference refuses it (nothing was changed)";
     default: return "unknown error";
     }
 }
@@ -1293,6 +1294,22 @@ static int ensure_aos(mcrat_hip_ctx *c, size_t bytes)
     return MCRAT_HIP_OK;
 }
 
+// Page-lock the caller's memory (its struct photon array, its hydro columns) so that the copies of set_photons / get_photons /
+// set_hydro run as direct DMA at the link's rate instead of through the runtime's staging of pageable memory.
+extern "C" int mcrat_hip_register_host(mcrat_hip_ctx *c, void *ptr, size_t bytes)
+{
+    if (!c || !ptr || bytes == 0) return MCRAT_HIP_EINVAL;
+    HIPCHK(c, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_unregister_host(mcrat_hip_ctx *c, void *ptr)
+{
+    if (!c || !ptr) return MCRAT_HIP_EINVAL;
+    HIPCHK(c, hipHostUnregister(ptr));
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_set_photons(mcrat_hip_ctx *c, const mcrat_hip_photon_list *l)
 {
     if (!c || !l || !l->photons || l->list_capacity <= 0) return MCRAT_HIP_EINVAL;
@@ -1543,7 +1560,7 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
         q.phi_min = std::fmin(q.phi_min, part[k].phi_min); q.phi_max = std::fmax(q.phi_max, part[k].phi_max);
         q.valid += part[k].valid; q.synch += part[k].synch;
     }
-    if (q.valid == 0) { c->last_error = "rebinning: no valid photons found for rebinning"; return MCRAT_HIP_EINVAL; }
+    if (q.valid == 0) { c->last_error = "rebinning: no valid photons found for rebinning"; return MCRAT_HIP_EREFUSED; }
     const double log_p0_min = (q.p0_min > 0 && q.p0_max > 0) ? std::log10(q.p0_min) : 0.0, log_p0_max = (q.p0_min > 0 && q.p0_max > 0) ? std::log10(q.p0_max) : 1.0;
     // calculate_binning_params :324-347, allocate_histograms :351-391
     RebinAxes ax{};
@@ -1552,8 +1569,8 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
     ax.num_bins_theta = (int)std::ceil((q.theta_max - q.theta_min) / (cs->rebin_ang * (M_PI / 180.0)));
     ax.num_bins_phi = three ? (int)std::ceil((q.phi_max - q.phi_min) / cs->rebin_ang_phi) : 1;
     const long long total_ll = (long long)ax.num_bins_theta * ax.num_bins * (three ? ax.num_bins_phi : 1);
-    if (total_ll > max_photons) { c->last_error = "rebinning would create more photons than max_photons"; return MCRAT_HIP_EINVAL; }
-    if (ax.num_bins <= 0 || ax.num_bins_theta <= 0 || ax.num_bins_phi <= 0) { c->last_error = "rebinning: invalid histogram dimensions"; return MCRAT_HIP_EINVAL; }
+    if (total_ll > max_photons) { c->last_error = "rebinning would create more photons than max_photons"; return MCRAT_HIP_EREFUSED; }
+    if (ax.num_bins <= 0 || ax.num_bins_theta <= 0 || ax.num_bins_phi <= 0) { c->last_error = "rebinning: invalid histogram dimensions"; return MCRAT_HIP_EREFUSED; }
     ax.total_bins = (int)total_ll;
     ax.e_lo = log_p0_min; ax.e_hi = log_p0_max + (log_p0_max - log_p0_min) * 1e-6;
     ax.t_lo = q.theta_min; ax.t_hi = q.theta_max + (q.theta_max - q.theta_min) * 1e-6;
@@ -1585,7 +1602,7 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
     HIPCHK(c, hipStreamSynchronize(c->stream));
     long long members_total = 0;
     for (int k = 0; k < B; ++k) members_total += h_cnt[(size_t)k];
-    if (h_cnt[(size_t)B + 1] != 0) { c->last_error = "rebinning: a photon maps to an invalid bin index (the reference exits)"; return MCRAT_HIP_EINVAL; }
+    if (h_cnt[(size_t)B + 1] != 0) { c->last_error = "rebinning: a photon maps to an invalid bin index (the reference exits)"; return MCRAT_HIP_EREFUSED; }
     HIPCHK(c, launch_exclusive_scan(bin_count, B, bin_start, bin_start + B + 1, members_total, c->stream));
     HIPCHK(c, launch_rebin_fill(c->ph, bin_of, bin_start, cursor, members, c->stream));
     HIPCHK(c, launch_rebin_create(c->ph, ax, bin_start, members, recs, empty, c->stream));
@@ -1599,7 +1616,7 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if ((unsigned long long)B > n_null) {
         c->last_error = "rebinning: fewer null slots than rebinned photons (the reference exits with \"Adding to the photon list has failed\")";
-        return MCRAT_HIP_EINVAL;
+        return MCRAT_HIP_EREFUSED;
     }
     HIPCHK(c, launch_exclusive_scan(null_cnt, nblk, null_start, null_start + nblk + 1, (long long)n_null, c->stream));
     HIPCHK(c, launch_null_write(c->ph, null_start, null_slots, c->stream));
@@ -1608,7 +1625,7 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
     const int null_count = (int)h_empty[0];
     if ((long long)n - (long long)n_null + (B - null_count) < B) {                                // :676-681
         c->last_error = "rebinning: fewer photons in the list than bins after the rebinning";
-        return MCRAT_HIP_EINVAL;
+        return MCRAT_HIP_EREFUSED;
     }
     if (empty_bins_out) *empty_bins_out = null_count;
     if (scatt_cyclosynch_num_ph) *scatt_cyclosynch_num_ph = B - null_count;                       // :689-690
@@ -1834,7 +1851,7 @@ static void fill_rank_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
 }
 
 #ifdef MCRAT_DIAG
-extern "C" int mcrat_hip_diag_rank_stamps(mcrat_hip_ctx *c, int rank, long long out[8])
+extern "C" __attribute__((visibility("default"))) int mcrat_hip_diag_rank_stamps(mcrat_hip_ctx *c, int rank, long long out[8])
 {
     if (!c || !out || rank < 0 || rank >= c->n_ranks) return -1;
     LoopState h;
@@ -1843,7 +1860,7 @@ extern "C" int mcrat_hip_diag_rank_stamps(mcrat_hip_ctx *c, int rank, long long 
     return 0;
 }
 
-extern "C" int mcrat_hip_diag_stamps(mcrat_hip_ctx *c, long long out[8])
+extern "C" __attribute__((visibility("default"))) int mcrat_hip_diag_stamps(mcrat_hip_ctx *c, long long out[8])
 {
     if (!c || !out) return -1;
     if (hipMemcpy(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost) != hipSuccess) return -1;
@@ -2048,8 +2065,8 @@ static void choose_rank_block(mcrat_hip_ctx *c)
 {
     if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) {
         c->rank_block = (atoi(e) == 128) ? 128 : 256;
-        c->rank_fuse = c->rank_block == 256 && c->rank_passes_per_list < 48.0;
-        if (const char *f = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = c->rank_block == 256 && atoi(f) != 0;
+        c->rank_fuse = c->rank_passes_per_list < 48.0;
+        if (const char *f = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = atoi(f) != 0;
         return;
     }
     int cus = 256, dev = 0;
@@ -2262,9 +2279,11 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
             c->h_state->done = cf.saved_done;
             HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(c->d_state) + offsetof(LoopState, done), &cf.saved_done, sizeof(int), hipMemcpyHostToDevice,
                                      c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));          // cf lives on the stack and changes below: the copy must have read it
             if (why == CS_HALT_GROW) {                                                            // photons.c:112-121: the list doubles
                 if (c->ph.n > 0x3fffffff) { c->last_error = "photon list too long to double"; return MCRAT_HIP_ENOMEM; }
                 HIPCHK(c, hipMemcpyAsync(d_cf, &cf, sizeof cf, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
                 if ((rc = grow_photons(c, 2 * c->ph.n))) return rc;
                 HIPCHK(c, launch_cs_replace(p, c->hy, c->hcol, c->key, c->d_state, c->ph, d_cf, 1, c->stream));
                 HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
@@ -2279,8 +2298,8 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
                     emit_base = emit_total;
                     cf.emitted = 0;
                     cf.scatt_num = scatt;
-                } else if (rc != MCRAT_HIP_EINVAL) {
-                    return rc;                     // EINVAL: one of the reference's refusals, the list is as it was
+                } else if (rc != MCRAT_HIP_EREFUSED) {
+                    return rc;                     // EREFUSED: one of the reference's refusals, the list is as it was
                 }
                 HIPCHK(c, hipMemcpyAsync(d_cf, &cf, sizeof cf, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2296,7 +2315,7 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
             int empty = 0;
             rc = mcrat_hip_rebin_cyclosynch(c, cs, max_photons, &empty, &cnt->num_cyclosynch_ph_emit, &cnt->scatt_cyclosynch_num_ph);
             if (rc == MCRAT_HIP_OK) cnt->rebins += 1;
-            else if (rc != MCRAT_HIP_EINVAL) return rc;
+            else if (rc != MCRAT_HIP_EREFUSED) return rc;
         }
         if (cnt->num_cyclosynch_ph_emit > 0) {
             double w = 0;

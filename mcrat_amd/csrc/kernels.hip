@@ -1733,7 +1733,10 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                 kernel_global<<<dim3(n_ranks), dim3(threads), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
             }
         };
-        if (block == 128) {
+        if (block == 128 && fuse && !TABLE_MODE) {
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 128, true>, rank_loop_kernel<DV, GV, true, false, 128, true>, 128);
+            else launch(rank_loop_kernel<DV, GV, false, true, 128, true>, rank_loop_kernel<DV, GV, false, false, 128, true>, 128);
+        } else if (block == 128) {
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 128, false>, rank_loop_kernel<DV, GV, true, false, 128, false>, 128);
             else launch(rank_loop_kernel<DV, GV, false, true, 128, false>, rank_loop_kernel<DV, GV, false, false, 128, false>, 128);
         } else if (fuse && !TABLE_MODE) {
@@ -1768,7 +1771,7 @@ hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const 
 }
 
 #if defined(MCRAT_DIAG) && !MCRAT_TAU_TABLE_TU && MCRAT_TU_DIMS == 0
-extern "C" int mcrat_hip_diag_set(int bits)
+extern "C" __attribute__((visibility("default"))) int mcrat_hip_diag_set(int bits)
 {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_diag), &bits, sizeof(int)) == hipSuccess ? 0 : -1;
 }

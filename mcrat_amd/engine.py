@@ -195,6 +195,8 @@ SYMBOLS = {
     "mcrat_hip_create_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
                                                      C.c_uint64]),
     "mcrat_hip_set_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
+    "mcrat_hip_register_host": (C.c_int, [_ctx, C.c_void_p, C.c_size_t]),
+    "mcrat_hip_unregister_host": (C.c_int, [_ctx, C.c_void_p]),
     "mcrat_hip_get_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
     "mcrat_hip_set_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_get_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
@@ -558,19 +560,26 @@ class Engine:
         self._check(self.lib.mcrat_hip_get_photons_range(self.ctx, int(first), int(count), a.ctypes.data), "get_photons_range")
         return a
 
-    def set_photons_aos(self, aos):
-        """aos: numpy array of PHOTON_DTYPE (the reference's struct photon records)."""
+    def set_photons_aos(self, aos, num_null=None):
+        """aos: numpy array of PHOTON_DTYPE (the reference's struct photon records); num_null: photon_list->num_null_photons if known"""
         a = np.ascontiguousarray(aos, dtype=PHOTON_DTYPE)
-        l = PhotonList(a.ctypes.data, None, len(a) - int(np.count_nonzero(a["type"] == b"N")),
-                       int(np.count_nonzero(a["type"] == b"N")), len(a))
+        nulls = int(np.count_nonzero(a["type"] == b"N")) if num_null is None else int(num_null)
+        l = PhotonList(a.ctypes.data, None, len(a) - nulls, nulls, len(a))
         self._check(self.lib.mcrat_hip_set_photons(self.ctx, C.byref(l)), "set_photons")
         self.n = len(a)
 
-    def get_photons_aos(self):
-        a = np.zeros(self.n, dtype=PHOTON_DTYPE)
+    def get_photons_aos(self, out=None):
+        a = np.zeros(self.n, dtype=PHOTON_DTYPE) if out is None else out
         l = PhotonList(a.ctypes.data, None, self.n, 0, self.n)
         self._check(self.lib.mcrat_hip_get_photons(self.ctx, C.byref(l)), "get_photons")
         return a
+
+    def register_host(self, array):
+        """page-lock a numpy array the caller hands to set_photons_aos / get_photons_aos(out=...) repeatedly"""
+        self._check(self.lib.mcrat_hip_register_host(self.ctx, array.ctypes.data, array.nbytes), "register_host")
+
+    def unregister_host(self, array):
+        self._check(self.lib.mcrat_hip_unregister_host(self.ctx, array.ctypes.data), "unregister_host")
 
     # ---- the loop
     def begin_frame(self, seed, time_now, remaining_time):

@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mcrat_amd import build, engine, synth  # noqa: E402
 
 diag_lib = os.path.join(os.path.dirname(build.LIB), "libmcrat_hip_diag.so")
-build.build(force=True, extra_flags=["-DMCRAT_DIAG=1"], lib=diag_lib, objdir=os.path.join(os.path.dirname(build.LIB), "_obj_diag"))
+if not (os.environ.get("MCRAT_DIAG_PREBUILT") and os.path.exists(diag_lib)):     # (built here beforehand: the library travels with the snapshot)
+    build.build(force=True, extra_flags=["-DMCRAT_DIAG=1"], lib=diag_lib, objdir=os.path.join(os.path.dirname(build.LIB), "_obj_diag"))
 engine.LIB_PATH = diag_lib
 lib = engine.load_library()
 lib.mcrat_hip_diag_rank_stamps.restype, lib.mcrat_hip_diag_rank_stamps.argtypes = C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
