@@ -111,7 +111,7 @@ def cpu_optimised_ranks(frame, ph, cfg, per, cores, seconds=8.0):
     t_grid = time.perf_counter()
     O.lib().orc_grid_attach(C.byref(c), C.byref(H.c))
     t_grid = time.perf_counter() - t_grid
-    n_lists = int(ph["p0"].size) // per
+    n_lists = min(int(ph["p0"].size) // per, 128 * cores)      # more than the cores get through in `seconds`
     # the lists are prepared before the clock starts: only the C loop (which runs outside the GIL) is timed
     lists = [O.OraclePhotons(synth.photons_to_aos(sub_photons(ph, r * per, (r + 1) * per), O.PHOTON_DTYPE)) for r in range(n_lists)]
     nxt, lock, tot = [0], threading.Lock(), [0, 0, 0]
@@ -173,8 +173,12 @@ def main():
     ap.add_argument("--mode", choices=("ranks", "list", "shared-clock"), default="ranks")
     ap.add_argument("--steps", type=int, default=0, help="ranks: frames (default 20); list: loop passes (default 2000)")
     ap.add_argument("--warmup", type=int, default=-1, help="ranks: frames (default 2); list: passes (default 50)")
-    ap.add_argument("--photons", type=int, default=1_000_000, help="photon slots per GPU")
-    ap.add_argument("--rank-photons", type=int, default=1000, help="photons per virtual rank (ranks mode)")
+    ap.add_argument("--photons", type=int, default=0, help="photon slots per GPU (default: 1e6 for cfg2, 1e7 for cfg3)")
+    ap.add_argument("--config", choices=("cfg2", "cfg3"), default="cfg2",
+                    help="BASELINE.json configs[1] (2D FLASH-like cylindrical jet, 1e6 photons: the headline) or configs[2] (2D PLUTO-like "
+                         "spherical jet, 1e7 photons, Stokes on)")
+    ap.add_argument("--rank-photons", type=int, default=976, help="mean photons per adopted rank (ranks mode); the lists differ in length")
+    ap.add_argument("--host-driver", type=int, default=1, help="also time the host-C rank-pool driver with its outputs (ranks mode, 1 GPU)")
     ap.add_argument("--nzc", type=int, default=64, help="mesh scale: 64 -> 1 048 576 cells")
     ap.add_argument("--stokes", type=int, default=0)
     ap.add_argument("--graph", type=int, default=1)
@@ -186,8 +190,12 @@ def main():
     args = ap.parse_args()
     steps = args.steps if args.steps > 0 else (20 if args.mode == "ranks" else 2000)
     warmup = args.warmup if args.warmup >= 0 else (2 if args.mode == "ranks" else 50)
+    if args.photons <= 0:
+        args.photons = 1_000_000 if args.config == "cfg2" else 10_000_000
     if args.photons % 2:
         raise SystemExit("--photons must be even")
+    if args.config == "cfg3":
+        args.stokes = 1
 
     import torch
     from mcrat_amd import engine, synth
@@ -218,8 +226,22 @@ def main():
 
     # every GPU owns an independent photon set on a replica of the frame (weak scaling): the reference's ranks own
     # disjoint photons and never talk during the loop -- no data-path collective
-    frame, ph, cfg = synth.config2(n_photons=args.photons, seed=SEED + rank, nzc=args.nzc, stokes=args.stokes)
+    if args.config == "cfg3":
+        frame, ph, cfg = synth.config3(n_photons=args.photons, seed=SEED + rank, nr=32 * args.nzc, nth=8 * args.nzc, stokes=1)
+    else:
+        frame, ph, cfg = synth.config2(n_photons=args.photons, seed=SEED + rank, nzc=args.nzc, stokes=args.stokes)
     n = int(ph["p0"].size)
+    # the adopted ranks' lists (mcrat_hip_pool_*): the reference's ranks hold Poisson-sized lists (mclib.c:87-136), so the lengths
+    # differ -- here by up to +-40 around the mean, adding up to n exactly
+    n_lists = max(1, int(round(n / float(args.rank_photons))))
+    lens = np.full(n_lists, n // n_lists, dtype=np.int64)
+    lens[: n - int(lens.sum())] += 1
+    if n_lists > 1 and lens.min() > 80:
+        d = np.random.default_rng(SEED).integers(-40, 41, n_lists // 2)
+        lens[: 2 * (n_lists // 2) : 2] += d
+        lens[1 : 2 * (n_lists // 2) : 2] -= d
+    assert int(lens.sum()) == n and lens.min() > 0
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     remaining = 1.0 / frame["fps"]
     stream = torch.cuda.current_stream().cuda_stream
     first_stream = rank * 100000           # RNG streams of this GPU's virtual ranks
@@ -232,12 +254,17 @@ def main():
 
     def make_engine(mode, profile=False, per_sync=None):
         if mode == "ranks":
+            # a rank pool: every list its own length, stream and clock, all lists propagated by one launch (mcrat_hip_pool_*)
             e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
-                              rng_stream=first_stream, virtual_rank_photons=args.rank_photons, profile=profile)
-        else:
-            e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
-                              rng_stream=first_stream, iterations_per_sync=per_sync or 500, use_graph=bool(args.graph),
-                              profile=profile)
+                              rng_stream=first_stream, profile=profile)
+            e.set_hydro(frame)
+            e.pool_create(n_lists, int(lens.max()))
+            for r in range(n_lists):
+                e.pool_rank(r, first_stream + r).set_photons(sub_photons(ph, int(offs[r]), int(offs[r + 1])))
+            return e
+        e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
+                          rng_stream=first_stream, iterations_per_sync=per_sync or 500, use_graph=bool(args.graph),
+                          profile=profile)
         e.set_hydro(frame)
         e.set_photons(ph)
         return e
@@ -263,7 +290,7 @@ def main():
         ev, ps, it = run_ranks(e, k_frames, SEED)
         sync()
         dt = time.perf_counter() - t0
-        nr = e.num_virtual_ranks()
+        nr = n_lists
         e.close()
         roof = None
         if with_roofline:
@@ -283,7 +310,7 @@ def main():
             launch_ms = ms / max(1, launches)
             bytes_per_launch = ALGORITHMIC_BYTES_PER_PHOTON_STEP * psteps / max(1, launches)
             achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
-            full = (n == 1_000_000 and args.nzc == 64 and args.rank_photons == 1000)
+            full = (n == 1_000_000 and args.nzc == 64 and args.config == "cfg2")
             traffic, src = committed_traffic("*_rank_loop_kernel_pmc.json") if full else (None, None)
             roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
@@ -411,29 +438,104 @@ def main():
 
     # what a drop-in caller pays per hydro frame around the loop: staging the frame (the lookup grid is built on the
     # device), the photons in as struct photon records, one frame of propagation, the photons out
+    def plain_engine():
+        return engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream, rng_stream=first_stream,
+                             virtual_rank_photons=1000)
+
     def measure_pcie():
+        """(a) the drop-in of INTEGRATION.md's first section: the caller's struct photon array and hydro columns in host memory, one
+        context, one hydro frame = set_hydro + set_photons + propagate_frame + get_photons (buffers allocated once, as MCRaT's are).
+        (b) the rank-pool driver of the host C (mcrat_host_run_ranks): the ranks' lists resident from device-side injection to the last
+        frame; per frame the reader's buffers go in (ingest) and what the reference writes per frame comes out (checkpoint records,
+        printPhotons' columns)."""
         aos = synth.photons_to_aos(ph, engine.PHOTON_DTYPE)
-        e = make_engine("ranks")
+        out_buf = aos.copy()
+        e = plain_engine()
         t = {"set_hydro": 0.0, "set_photons": 0.0, "propagate": 0.0, "get_photons": 0.0}
         reps, ev = 3, 0
         for k in range(reps + 1):
             t0 = time.perf_counter(); e.set_hydro(frame)
-            t1 = time.perf_counter(); e.set_photons_aos(aos)
+            t1 = time.perf_counter(); e.set_photons_aos(aos, num_null=0)
             t2 = time.perf_counter(); _, st = e.propagate_frame(0.0, remaining, SEED + 9000 + k)
-            t3 = time.perf_counter(); e.get_photons_aos()
+            t3 = time.perf_counter(); e.get_photons_aos(out=out_buf)
             t4 = time.perf_counter()
             if k:                                             # the first round pays the allocations
                 t["set_hydro"] += t1 - t0; t["set_photons"] += t2 - t1; t["propagate"] += t3 - t2; t["get_photons"] += t4 - t3
                 ev += st.frame_scatt_cnt
         e.close()
         tot = sum(t.values())
-        pcie = {"note": "per hydro frame through the C ABI with host-resident inputs and outputs (pageable memory): "
-                        "mcrat_hip_set_hydro + set_photons + propagate_frame + get_photons, %d photons as struct photon records" % n,
-                "ms": {k: v * 1e3 / reps for k, v in t.items()}, "ms_per_frame": tot * 1e3 / reps, "scatter_events_per_s": ev / tot}
+        pcie = {"host_list": {"note": "per hydro frame through the C ABI with host-resident inputs and outputs: mcrat_hip_set_hydro + set_photons + "
+                                      "propagate_frame (1000-photon virtual ranks) + get_photons, %d photons as struct photon records (176 MB each way)" % n,
+                              "ms": {k: v * 1e3 / reps for k, v in t.items()}, "ms_per_frame": tot * 1e3 / reps,
+                              "scatter_events_per_s": ev / tot}}
+        if args.host_driver:
+            try:
+                pcie["rank_pool_driver"] = measure_host_driver()
+            except Exception as ex:
+                pcie["rank_pool_driver"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         return pcie
 
+    def measure_host_driver():
+        import ctypes as C
+        import shutil
+        import tempfile
+        from mcrat_amd.host import binding as B
+        host, h5 = B.host(), B.host_h5()
+        side = 2.5e8 * (64 // args.nzc)
+        raw = synth.flash_raw_blocks(side, args.nzc, 2 * args.nzc, args.nzc, 1e12 - args.nzc * side, seed=1)
+        jet = engine.Engine.outflow(engine.STRUCTURED_SPHERICAL_OUTFLOW, lumi=3e50, theta_j=0.1)
+        R, frames = 1024, 3
+        res = {"note": "mcrat_host_run_ranks (host C): %d adopted ranks, each injecting 500-1000 photons on the device at frame 0 and scattering "
+                       "through %d hydro frames of the cfg2 mesh read as a FLASH checkpoint (host buffers -> mcrat_hip_ingest_flash, once per frame "
+                       "for all ranks); photons resident throughout.  ms per hydro frame, by what is written per rank and frame" % (R, frames),
+               "ranks": R, "hydro_frames": frames}
+        for label, chk, hdf in (("no_output", 0, 0), ("checkpoints", 1, 0), ("checkpoints_and_hdf5", 1, 1)):
+            if hdf and h5 is None:
+                continue
+            tmp = tempfile.mkdtemp(prefix="mcrat_bench_")
+            try:
+                pool = engine.Engine(synth.TWO, synth.CYLINDRICAL, 0, device=local_rank, stream=stream)
+                ranks = (B.HostRank * R)()
+                for r, k in enumerate(ranks):
+                    k.myid, k.angle_id, k.angle_procs = r, r, R
+                    k.mc_dir = (tmp + "/").encode()
+                    k.theta_jmin_thread, k.theta_jmax_thread, k.inj_radius, k.ph_weight_suggest = 0.0, 3.0 * np.pi / 180, 1e12, 1e50
+                    k.framestart, k.frm2, k.rng_seed, k.rng_stream = 0, 0, SEED, 7000 + r
+                pc = B.PoolConfig()
+                pc.fps, pc.last_frm = float(frame["fps"]), frames - 1
+                pc.r0_domain[0], pc.r0_domain[1] = frame["r0_domain"]
+                pc.r1_domain[0], pc.r1_domain[1] = frame["r1_domain"]
+                pc.spect, pc.min_photons, pc.max_photons = b"b", 500, 1000
+
+                def reader(user, ctx, f, slab, pool=pool):
+                    sl = slab.contents
+                    pool.ingest(raw, dict(r_inj=sl.r_inj, ph_inj_switch=sl.ph_inj_switch, min_r=sl.min_r, max_r=sl.max_r, min_theta=sl.min_theta,
+                                          max_theta=sl.max_theta, fps=sl.fps, r0_domain=tuple(sl.r0_domain), r1_domain=tuple(sl.r1_domain),
+                                          r2_domain=tuple(sl.r2_domain)), jet)
+                    return 0
+                pc.get_hydro = B.GET_HYDRO(reader)
+                pc.write_checkpoints = chk
+                if hdf:
+                    pc.print_photons = C.cast(h5.mcrat_host_print_photon_arrays, C.c_void_p).value
+                pc.comv_switch, pc.stokes_switch, pc.save_type = 1, 0, 0
+                t0 = time.perf_counter()
+                rc = host.mcrat_host_run_ranks(pool.ctx, ranks, R, C.byref(pc))
+                wall = time.perf_counter() - t0
+                if rc != 0:
+                    raise RuntimeError("mcrat_host_run_ranks: %d" % rc)
+                photons = sum(k.num_photons for k in ranks)
+                events = sum(k.frame_scatt_cnt_total for k in ranks)
+                res[label] = {"photons": int(photons), "scatter_events": int(events), "wall_ms_total": wall * 1e3,
+                              "ms_per_frame": {"propagate_and_statistics": pc.ms_propagate / frames, "output": pc.ms_output / frames,
+                                               "hydro_reader_and_ingest": pc.ms_hydro / pc.hydro_frames_read},
+                              "scatter_events_per_s_inclusive": events / ((pc.ms_propagate + pc.ms_output + pc.ms_hydro) * 1e-3)}
+                pool.close()
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        return res
+
     pcie = None
-    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode:
+    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode and args.config == "cfg2":
         try:                                    # an extra must never cost the bench line
             pcie = measure_pcie()
         except Exception as ex:
@@ -447,7 +549,7 @@ def main():
         slab = dict(r_inj=1e12, ph_inj_switch=1, min_r=0.0, max_r=0.0, min_theta=0.0, max_theta=0.0, fps=float(frame["fps"]),
                     r0_domain=frame["r0_domain"], r1_domain=frame["r1_domain"], r2_domain=(0.0, 0.0))
         jet = engine.Engine.outflow(engine.STRUCTURED_SPHERICAL_OUTFLOW, lumi=3e50, theta_j=0.1)
-        e = make_engine("ranks")
+        e = plain_engine()
         t_in, t_inj, reps = 0.0, 0.0, 3
         for k in range(reps + 1):
             t0 = time.perf_counter(); m, ef, cells = e.ingest(raw, slab, jet)
@@ -472,7 +574,7 @@ def main():
         return ingest
 
     ingest = None
-    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode:
+    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode and args.config == "cfg2":
         try:                                    # an extra must never cost the bench line
             ingest = measure_ingest()
         except Exception as ex:
@@ -484,7 +586,7 @@ def main():
         hframe, hph, hcfg = synth.config2(n_photons=args.photons, seed=SEED + rank, nzc=args.nzc, stokes=args.stokes, lumi=1e54, r_inj=1e11,
                                           block_side=2.5e7)
         e = engine.Engine(hcfg["dimensions"], hcfg["geometry"], hcfg["stokes"], device=local_rank, stream=stream, rng_stream=first_stream,
-                          virtual_rank_photons=args.rank_photons)
+                          virtual_rank_photons=1000)
         e.set_hydro(hframe)
         e.set_photons(hph)
         e.snapshot_photons()
@@ -502,12 +604,11 @@ def main():
                 best = (dt, int(st.frame_scatt_cnt), int(st.iterations))
         e.close()
         return {"workload": "cfg2 jet at r_inj = 1e11 cm, L = 1e54 erg/s: T' = %.1e .. %.1e K; %d lists x %d photons, 300 passes each"
-                            % (float(hframe["temp"].min()), float(hframe["temp"].max()), (args.photons + args.rank_photons - 1) // args.rank_photons,
-                               args.rank_photons),
+                            % (float(hframe["temp"].min()), float(hframe["temp"].max()), (args.photons + 999) // 1000, 1000),
                 "scatter_events_per_s": best[1] / best[0], "ms": best[0] * 1e3, "scatter_events": best[1], "loop_passes": best[2]}
 
     hot = None
-    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode:
+    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode and args.config == "cfg2":
         try:
             hot = measure_hot()
         except Exception as ex:
@@ -531,16 +632,18 @@ def main():
 
     if rank == 0:
         if args.mode == "ranks":
-            shape = ("%d virtual ranks x %d photons (independent lists, own clock and RNG stream each; one workgroup per list); "
-                     "step = one hydro frame (1/fps = %.2f s) for all lists, restarted from the resident snapshot"
-                     % (main_res.get("ranks", 0), args.rank_photons, remaining))
+            shape = ("a rank pool of %d adopted ranks with lists of %d-%d photons (independent lists, own clock and RNG stream each: the "
+                     "reference's MPI ranks; one workgroup per list, all lists in one launch); step = one hydro frame (1/fps = %.2f s) for "
+                     "all lists, restarted from the resident snapshot"
+                     % (main_res.get("ranks", 0), int(lens.min()), int(lens.max()), remaining))
         elif args.mode == "list":
             shape = "one list, one clock; step = one loop pass over all photons"
         else:
             shape = ("ONE list of %d photons with one clock, its slots spread over %d GPU(s); step = one round: own slots "
                      "stepped, 736-B proposals all-gathered (RCCL), merged candidates walked on every GPU" % (n * world, world))
         out = {
-            "metric": "photon-scatter-events/sec at 1e6 photons, 2D FLASH jet",
+            "metric": "photon-scatter-events/sec at 1e6 photons, 2D FLASH jet" if args.config == "cfg2" else
+                      "photon-scatter-events/sec at 1e7 photons, 2D PLUTO spherical jet, Stokes on",
             "value": events_all / t_max,
             "unit": "scatter-events/s",
             "n_gpus": world,
@@ -552,9 +655,11 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: 2D FLASH-like cylindrical GRB-jet frame (%d cells, Lundman structured "
+            "config": {"workload": "BASELINE.json %s (%d cells, Lundman structured "
                                    "jet), %d photons per GPU, Compton+KN, STOKES %s; %s"
-                                   % (frame["num_elements"], n, "on" if args.stokes else "off", shape),
+                                   % ("configs[1]: 2D FLASH-like cylindrical GRB-jet frame" if args.config == "cfg2" else
+                                      "configs[2]: 2D PLUTO-like spherical (log r, theta) jet frame", frame["num_elements"], n,
+                                      "on" if args.stokes else "off", shape),
                        "mode": args.mode, "photons_per_gpu": n, "cells": int(frame["num_elements"]),
                        "rank_photons": args.rank_photons if args.mode == "ranks" else None,
                        "parallelism": ("one list, slots sharded x%d, all-gather per round" % world) if args.mode == "shared-clock"

@@ -461,6 +461,15 @@ typedef struct mcrat_hip_rank_summary {
 int mcrat_hip_pool_create(mcrat_hip_ctx *pool, int n_ranks, int slots_per_rank);
 int mcrat_hip_pool_rank(mcrat_hip_ctx *pool, int rank, uint32_t rng_stream, mcrat_hip_ctx **view);
 int mcrat_hip_pool_summaries(mcrat_hip_ctx *pool, mcrat_hip_rank_summary *out /* [n_ranks] */);
+/* the same for hundreds of lists at once, so that a frame of the pool costs a handful of launches, not a handful per list:
+ *   mcrat_hip_pool_begin_frames  mcrat_hip_begin_frame for every list with open[r] != 0, each with its own seed and clock ([n_ranks] arrays)
+ *   mcrat_hip_pool_frame_stats   mcrat_hip_frame_statistics of every list ([n_ranks]; lists without a frame: what they last had)
+ *   mcrat_hip_pool_layout        the lists' places in the pool's own slot numbering: list r occupies the slots r * slots_per_rank ...,
+ *                                which mcrat_hip_get_photons_range / mcrat_hip_get_output on the POOL context address (slots beyond a
+ *                                list's length hold no photon: type 0, weight 0) -- one transfer for all lists' records or columns */
+int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *pool, const int *open, const uint64_t *seeds, const double *time_now, const double *remaining_time);
+int mcrat_hip_pool_frame_stats(mcrat_hip_ctx *pool, mcrat_hip_frame_stats *out /* [n_ranks] */);
+int mcrat_hip_pool_layout(const mcrat_hip_ctx *pool, int *n_ranks, int *slots_per_rank);
 
 /* function-granular A/B entry points (one kernel each, for parity tests against the
  * reference functions): the findContainingHydroCell + calcMeanFreePath half of an

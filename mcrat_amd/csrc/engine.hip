@@ -1946,6 +1946,76 @@ extern "C" int mcrat_hip_pool_rank(mcrat_hip_ctx *c, int rank, uint32_t rng_stre
     return MCRAT_HIP_OK;
 }
 
+extern "C" int mcrat_hip_pool_layout(const mcrat_hip_ctx *c, int *n_ranks, int *slots_per_rank)
+{
+    if (!c || !c->is_pool) return MCRAT_HIP_ESTATE;
+    if (n_ranks) *n_ranks = c->n_ranks;
+    if (slots_per_rank) *slots_per_rank = c->rank_stride;
+    return MCRAT_HIP_OK;
+}
+
+// mcrat_hip_begin_frame for many views in one launch: every list with open[r] != 0 gets its own seed and clock
+extern "C" int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *c, const int *open, const uint64_t *seeds, const double *time_now, const double *remaining_time)
+{
+    if (!c || !open || !seeds || !time_now || !remaining_time) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    if (!c->have_hydro) return MCRAT_HIP_ESTATE;
+    if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && !c->d_hot_table) {
+        c->last_error = "TAU_CALCULATION == TABLE needs mcrat_hip_set_hot_cross_section first";
+        return MCRAT_HIP_ESTATE;
+    }
+    const int R = c->n_ranks;
+    std::vector<int> op((size_t)R, 0);
+    for (int r = 0; r < R; ++r) {
+        mcrat_hip_ctx *v = c->views[r];
+        if (!open[r]) continue;
+        if (!v || !v->have_photons) { c->last_error = "pool_begin_frames: a list that does not exist was asked to open a frame"; return MCRAT_HIP_ESTATE; }
+        op[(size_t)r] = 1;
+    }
+    const size_t bytes = (sizeof(int) + 2 * sizeof(double)) * (size_t)R;
+    int rc = ensure_aos(c, bytes + 64);
+    if (rc) return rc;
+    double *d_t = static_cast<double *>(c->aos_buf), *d_rem = d_t + R;
+    int *d_open = reinterpret_cast<int *>(d_rem + R);
+    HIPCHK(c, hipMemcpyAsync(d_t, time_now, sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rem, remaining_time, sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_open, op.data(), sizeof(int) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
+    HIPCHK(c, launch_init_states_multi(c->d_rstates, R, d_open, d_t, d_rem, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));        // the arrays above are the caller's and `op`
+    for (int r = 0; r < R; ++r) {
+        if (!op[(size_t)r]) continue;
+        mcrat_hip_ctx *v = c->views[r];
+        if (v->graph_exec && v->key.seed != seeds[r]) drop_graph(v);
+        v->key.seed = seeds[r];
+        v->find_switch = 1;
+        v->pending_applied = false;
+        v->frame_open = true;
+        v->prof_step_ms = v->prof_event_ms = 0;
+        v->prof_launches = 0;
+        LoopState &h = *v->h_state;
+        memset(&h, 0, sizeof h);
+        h.remaining_time = remaining_time[r]; h.time_now = time_now[r]; h.done = !(remaining_time[r] > 0);
+        h.skip_idx = -1; h.last_scattered_index = -1; h.force_relocate = 1;
+    }
+    c->rank_block_fixed = false;
+    return MCRAT_HIP_OK;
+}
+
+// the loop statistics of every list (what mcrat_hip_frame_statistics gives for one view), one read-back
+extern "C" int mcrat_hip_pool_frame_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *out)
+{
+    if (!c || !out) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * (size_t)c->n_ranks, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int r = 0; r < c->n_ranks; ++r) {
+        const mcrat_hip_ctx *v = c->views[r];
+        state_to_stats(c->h_rstates[r], (v && v->have_photons) ? v->ph.n : 0, &out[r]);
+    }
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_pool_summaries(mcrat_hip_ctx *c, mcrat_hip_rank_summary *out)
 {
     if (!c || !out) return MCRAT_HIP_EINVAL;

@@ -267,7 +267,29 @@ __global__ __launch_bounds__(256) void rank_reduce_kernel(PhotonDev ph, int stri
     }
 }
 
+// rank pool: a new frame for the lists with open[r] != 0 -- their own clocks -- in one launch (cf. init_states_kernel)
+__global__ __launch_bounds__(256) void init_states_multi_kernel(LoopState *__restrict__ ranks, int n_ranks, const int *__restrict__ open,
+                                                                const double *__restrict__ time_now, const double *__restrict__ remaining)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_ranks || !open[r]) return;
+    LoopState w = {};
+    w.remaining_time = remaining[r];
+    w.time_now = time_now[r];
+    w.done = !(remaining[r] > 0);
+    w.skip_idx = -1;
+    w.last_scattered_index = -1;
+    w.force_relocate = 1;                          // mcrat.c:756
+    ranks[r] = w;
+}
+
 }  // namespace
+
+hipError_t launch_init_states_multi(LoopState *ranks, int n_ranks, const int *open, const double *time_now, const double *remaining, hipStream_t stream)
+{
+    init_states_multi_kernel<<<dim3((n_ranks + 255) / 256), dim3(256), 0, stream>>>(ranks, n_ranks, open, time_now, remaining);
+    return hipGetLastError();
+}
 
 hipError_t launch_convert_comptonized(const PhotonDev &ph, unsigned *converted, hipStream_t stream)
 {

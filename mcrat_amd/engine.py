@@ -211,6 +211,9 @@ SYMBOLS = {
     "mcrat_hip_pool_create": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "mcrat_hip_pool_rank": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.POINTER(_ctx)]),
     "mcrat_hip_pool_summaries": (C.c_int, [_ctx, C.POINTER(RankSummary)]),
+    "mcrat_hip_pool_begin_frames": (C.c_int, [_ctx, _ip, C.POINTER(C.c_uint64), _dp, _dp]),
+    "mcrat_hip_pool_frame_stats": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
+    "mcrat_hip_pool_layout": (C.c_int, [_ctx, _ip, _ip]),
     "mcrat_hip_step_locate_sample": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_step_event": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_update_photon_position": (C.c_int, [_ctx, C.c_double]),

@@ -27,7 +27,6 @@ class HostRank(C.Structure):
 
 
 GET_HYDRO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(engine.Slab))
-PRINT_PHOTONS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p)
 
 
 class PoolConfig(C.Structure):
@@ -82,6 +81,8 @@ def host_h5():
         lib = C.CDLL(path)
         lib.mcrat_host_print_photons.restype = C.c_int
         lib.mcrat_host_print_photons.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.mcrat_host_print_photon_arrays.restype = C.c_int
+        lib.mcrat_host_print_photon_arrays.argtypes = [C.POINTER(engine.OutputColumns), C.c_int, C.c_char_p, C.c_int, C.c_void_p]
         lib.mcrat_host_h5_read.restype = C.c_int
         lib.mcrat_host_h5_read.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         _h5 = lib

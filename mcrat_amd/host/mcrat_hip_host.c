@@ -307,8 +307,10 @@ int mcrat_host_save_checkpoint(const char *dir, int frame, int frame2, int scatt
     snprintf(file, sizeof file, "%s%s%d%s", dir, "mc_chkpt_", angle_rank, ".dat");
     snprintf(old, sizeof old, "%s_old", file);
     const int continuing = (scatt_frame != last_frame) || (scatt_frame == frame);       /* the three cases of :846,:898,:947 */
+    /* "exec cp file file_old" and then fopen(file, "wb"), which truncates the original: the same files result from a rename, without
+     * reading and writing the old checkpoint once more per frame (copy_file is the fallback across file systems) */
     if (scatt_frame == frame) remove(file);
-    else (void)copy_file(file, old);
+    else if (rename(file, old) != 0) (void)copy_file(file, old);
     FILE *f = fopen(file, "wb");
     if (!f) { printf("Cannot open %s to save checkpoint\n", file); return 1; }
     char restart = continuing ? 'c' : 'i';                     /* CONTINUE / INITALIZE, mcrat.h */
@@ -515,7 +517,19 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     int rc = mcrat_hip_pool_create(pool, n_ranks, cfg->slots_per_rank > 0 ? cfg->slots_per_rank : cfg->max_photons);
     if (rc) return rc;
     mcrat_hip_rank_summary *summ = (mcrat_hip_rank_summary *)calloc((size_t)n_ranks, sizeof *summ);
-    if (!summ) return MCRAT_HIP_ENOMEM;
+    mcrat_hip_frame_stats *stats = (mcrat_hip_frame_stats *)calloc((size_t)n_ranks, sizeof *stats);
+    int *open = (int *)calloc((size_t)n_ranks, sizeof(int));
+    uint64_t *seeds = (uint64_t *)calloc((size_t)n_ranks, sizeof(uint64_t));
+    double *t_now = (double *)calloc((size_t)n_ranks, sizeof(double)), *t_rem = (double *)calloc((size_t)n_ranks, sizeof(double));
+    mcrat_hip_photon *rec_buf = NULL;
+    double *out_buf = NULL;
+    char *out_type = NULL;
+    size_t out_cap = 0;
+    int stride = 0;
+    if (!summ || !stats || !open || !seeds || !t_now || !t_rem || mcrat_hip_pool_layout(pool, NULL, &stride) != 0) {
+        free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem);
+        return MCRAT_HIP_ENOMEM;
+    }
     cfg->hydro_frames_read = cfg->launches = 0;
     cfg->ms_propagate = cfg->ms_hydro = cfg->ms_output = 0;
     for (int r = 0; r < n_ranks && rc == 0; r++) {
@@ -607,46 +621,105 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 if (rc) break;
             }
             const double t_prop = wall_ms();
-            for (int r = 0; r < n_ranks && rc == 0; r++) {
+            for (int r = 0; r < n_ranks; r++) {
                 mcrat_host_rank *k = &ranks[r];
-                if (k->state != 1) continue;
+                open[r] = k->state == 1;
+                if (!open[r]) continue;
                 if (k->fPtr) {
                     fprintf(k->fPtr, ">>\n>> Proc %d with angles %0.1lf-%0.1lf: Working on photons injected at frame: %d out of %d\n", k->angle_id, RANK_DEG(k),
                             k->frame, k->frm2);
                     fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: propagating and scattering %d photons\n", k->angle_id, RANK_DEG(k), k->num_photons);
                 }
                 /* the rank's per-frame seed (gsl_rng_set(rng, gsl_rng_get(rng)), :701) and its own clock (:758) */
-                const double remaining_time = ((F + 1) / cfg->fps) - k->time_now;
-                rc = mcrat_hip_begin_frame(k->view, mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++), k->time_now, remaining_time);
+                seeds[r] = mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++);
+                t_now[r] = k->time_now;
+                t_rem[r] = ((F + 1) / cfg->fps) - k->time_now;
             }
-            if (rc) break;
+            if ((rc = mcrat_hip_pool_begin_frames(pool, open, seeds, t_now, t_rem))) break;      /* every list's begin_frame, one launch */
             mcrat_hip_frame_stats tot;
             if ((rc = mcrat_hip_run(pool, 0, &tot))) break;                                       /* mcrat.c:761-851 for every list */
             cfg->launches += 1;
             if ((rc = mcrat_hip_pool_summaries(pool, summ))) break;                               /* phScattStats, :881 */
+            if ((rc = mcrat_hip_pool_frame_stats(pool, stats))) break;
             cfg->ms_propagate += wall_ms() - t_prop;
             const double t_out = wall_ms();
-            for (int r = 0; r < n_ranks && rc == 0; r++) {
+            for (int r = 0; r < n_ranks; r++) {
                 mcrat_host_rank *k = &ranks[r];
                 if (k->state != 1) continue;
-                mcrat_hip_frame_stats st;
-                if ((rc = mcrat_hip_frame_statistics(k->view, &st))) break;
-                k->time_now = st.time_now;
-                k->frame_scatt_cnt_total += st.frame_scatt_cnt;
-                log_frame(k->fPtr, &st, k->time_now, summ[r].max_scatt, summ[r].min_scatt, summ[r].avg_scatt, summ[r].avg_r);
-                if (cfg->write_checkpoints) {
-                    if (k->fPtr) fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: Making checkpoint file\n", k->angle_id, RANK_DEG(k));
-                    if (mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, F, k->time_now, k->view, NULL, summ[r].list_capacity, cfg->last_frm,
-                                                   k->angle_id, k->angle_procs, 0) != 0) {       /* :902-915 */
-                        if (k->fPtr) fprintf(k->fPtr, "There is an issue with opening and saving the chkpt file therefore MCRaT is not saving data to the checkpoint or mc_proc files to prevent corruption of those data.\n");
-                        rc = 1;
-                        break;
+                k->time_now = stats[r].time_now;
+                k->frame_scatt_cnt_total += stats[r].frame_scatt_cnt;
+                log_frame(k->fPtr, &stats[r], k->time_now, summ[r].max_scatt, summ[r].min_scatt, summ[r].avg_scatt, summ[r].avg_r);
+            }
+            /* saveCheckpoint (:902-915): the records of all lists come over in pieces of whole lists, one transfer per piece */
+            if (cfg->write_checkpoints) {
+                const int per_piece = (1 << 20) / stride > 0 ? (1 << 20) / stride : 1;
+                if (!rec_buf) rec_buf = (mcrat_hip_photon *)malloc(sizeof(mcrat_hip_photon) * (size_t)per_piece * (size_t)stride);
+                if (!rec_buf) { rc = MCRAT_HIP_ENOMEM; break; }
+                for (int r0 = 0; r0 < n_ranks && rc == 0; r0 += per_piece) {
+                    const int r1 = r0 + per_piece < n_ranks ? r0 + per_piece : n_ranks;
+                    int any = 0;
+                    for (int r = r0; r < r1; r++) any |= ranks[r].state == 1;
+                    if (!any) continue;
+                    if ((rc = mcrat_hip_get_photons_range(pool, r0 * stride, (r1 - r0) * stride, rec_buf))) break;
+                    for (int r = r0; r < r1; r++) {
+                        mcrat_host_rank *k = &ranks[r];
+                        if (k->state != 1) continue;
+                        mcrat_hip_photon_list l;
+                        memset(&l, 0, sizeof l);
+                        l.photons = rec_buf + (size_t)(r - r0) * (size_t)stride;
+                        l.list_capacity = summ[r].list_capacity;
+                        if (k->fPtr) fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: Making checkpoint file\n", k->angle_id, RANK_DEG(k));
+                        if (mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, F, k->time_now, NULL, &l, l.list_capacity, cfg->last_frm, k->angle_id,
+                                                       k->angle_procs, 0) != 0) {
+                            if (k->fPtr) fprintf(k->fPtr, "There is an issue with opening and saving the chkpt file therefore MCRaT is not saving data to the checkpoint or mc_proc files to prevent corruption of those data.\n");
+                            rc = 1;
+                            break;
+                        }
                     }
                 }
-                if (cfg->print_photons)                                                           /* :907 */
-                    rc = cfg->print_photons(k->view, F, k->mc_dir, k->angle_id, cfg->comv_switch, cfg->stokes_switch, cfg->save_type, k->fPtr);
-                k->scatt_frame = F + 1;
+                if (rc) break;
             }
+            /* printPhotons (:907): the pool's compacted columns in one transfer (photons with weight != 0 in slot order, i.e. list after list) */
+            if (cfg->print_photons) {
+                mcrat_hip_output_columns all;
+                memset(&all, 0, sizeof all);
+                if ((rc = mcrat_hip_get_output(pool, &all))) break;                               /* the count */
+                const size_t cnt = (size_t)all.count;
+                if (cnt > out_cap) {
+                    free(out_buf); free(out_type);
+                    out_buf = (double *)malloc(sizeof(double) * 17 * (cnt ? cnt : 1));
+                    out_type = (char *)malloc(cnt ? cnt : 1);
+                    out_cap = cnt;
+                    if (!out_buf || !out_type) { rc = MCRAT_HIP_ENOMEM; break; }
+                }
+                double **slot[17] = {&all.p0, &all.p1, &all.p2, &all.p3, &all.comv_p0, &all.comv_p1, &all.comv_p2, &all.comv_p3, &all.r0, &all.r1, &all.r2,
+                                     &all.s0, &all.s1, &all.s2, &all.s3, &all.num_scatt, &all.weight};
+                for (int c = 0; c < 17; c++) {
+                    const int is_comv = c >= 4 && c < 8, is_stokes = c >= 11 && c < 15;
+                    *slot[c] = ((is_comv && !cfg->comv_switch) || (is_stokes && !cfg->stokes_switch)) ? NULL : out_buf + (size_t)c * cnt;
+                }
+                all.type = cfg->save_type ? out_type : NULL;
+                if (cnt && (rc = mcrat_hip_get_output(pool, &all))) break;
+                size_t first = 0;
+                for (int r = 0; r < n_ranks && rc == 0; r++) {
+                    mcrat_host_rank *k = &ranks[r];
+                    const size_t m = (size_t)summ[r].num_output;
+                    if (k->state == 1 && m > 0) {
+                        mcrat_hip_output_columns one = all;
+                        double **os[17] = {&one.p0, &one.p1, &one.p2, &one.p3, &one.comv_p0, &one.comv_p1, &one.comv_p2, &one.comv_p3, &one.r0, &one.r1, &one.r2,
+                                           &one.s0, &one.s1, &one.s2, &one.s3, &one.num_scatt, &one.weight};
+                        for (int c = 0; c < 17; c++)
+                            if (*os[c]) *os[c] += first;
+                        if (one.type) one.type += first;
+                        one.count = (int)m;
+                        rc = cfg->print_photons(&one, F, k->mc_dir, k->angle_id, k->fPtr);
+                    }
+                    first += m;
+                }
+                if (rc) break;
+            }
+            for (int r = 0; r < n_ranks; r++)
+                if (ranks[r].state == 1) ranks[r].scatt_frame = F + 1;
             cfg->ms_output += wall_ms() - t_out;
             frames_done += 1;
             if (cfg->max_frames > 0 && frames_done >= cfg->max_frames) stop = 1;
@@ -663,7 +736,8 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                                              k->angle_procs, 0);
             if (k->fPtr) { fprintf(k->fPtr, "Process %d has completed the MC calculation.\n", k->angle_id); fflush(k->fPtr); }
         }
-    free(summ);
+    free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem);
+    free(rec_buf); free(out_buf); free(out_type);
     return rc;
 }
 

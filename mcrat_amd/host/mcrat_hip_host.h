@@ -101,6 +101,9 @@ int mcrat_host_read_checkpoint(const char *dir, mcrat_hip_photon_list *list, int
 int mcrat_host_print_photons(mcrat_hip_ctx *ctx, int frame, const char *dir, int angle_rank, int comv_switch, int stokes_switch,
                              int save_type, FILE *fPtr);
 int mcrat_host_h5_read(const char *file, const char *group, const char *name, int is_char, void *data, int cap, int *n);
+/* the HDF5 half alone, on arrays the caller holds (cols->count photons, NULL columns skipped): what mcrat_host_run_ranks calls per rank
+ * with slices of ONE mcrat_hip_get_output of the whole pool */
+int mcrat_host_print_photon_arrays(const mcrat_hip_output_columns *cols, int frame, const char *dir, int angle_rank, FILE *fPtr);
 
 /* The HDF5 reads of the two HDF5-based readers, and nothing else of them (same file, mcrat_hip_host_h5.c):
  *   mcrat_host_read_flash    readAndDecimate's H5Dread calls (mclib_flash.c:95-197): "coordinates", "block size", "node type",
@@ -202,8 +205,7 @@ uint64_t mcrat_host_rank_seed(uint64_t rng_seed, long long k);
 int mcrat_host_split_ranks(const mcrat_host_mcpar *par, int numprocs, int first_rank, int n_adopt, const char *base_dir,
                            double ph_weight_default, uint64_t base_seed, mcrat_host_rank *out);
 
-typedef int (*mcrat_host_print_photons_fn)(mcrat_hip_ctx *ctx, int frame, const char *dir, int angle_rank, int comv_switch,
-                                           int stokes_switch, int save_type, FILE *fPtr);
+typedef int (*mcrat_host_print_arrays_fn)(const mcrat_hip_output_columns *cols, int frame, const char *dir, int angle_rank, FILE *fPtr);
 typedef struct mcrat_host_pool_config {
     double fps;                          /* mc.par */
     int    last_frm;
@@ -214,7 +216,7 @@ typedef struct mcrat_host_pool_config {
     mcrat_host_get_hydro_fn get_hydro;   /* the reader: stages hydro frame `scatt_frame` for `slab` on the POOL context (getHydroData) */
     void  *user;
     int    write_checkpoints;            /* saveCheckpoint per rank and frame, mcrat.c:902 (0: skip -- benchmarks) */
-    mcrat_host_print_photons_fn print_photons;   /* mcrat_host_print_photons (needs the HDF5 build), or NULL to skip printPhotons */
+    mcrat_host_print_arrays_fn print_photons;    /* mcrat_host_print_photon_arrays (the HDF5 build), or NULL to skip printPhotons */
     int    comv_switch, stokes_switch, save_type;
     int    max_frames;                   /* > 0: stop after this many hydro frames in total (tests, benchmarks) */
     /* out */

@@ -45,6 +45,34 @@ static int put(hid_t group, const char *name, hid_t type, const void *data, hsiz
     return st < 0 ? -1 : 0;
 }
 
+/* the HDF5 half of printPhotons (mcrat_io.c:183-836) on arrays the caller holds: cols->count photons; NULL columns are not written */
+int mcrat_host_print_photon_arrays(const mcrat_hip_output_columns *cols, int frame, const char *dir, int angle_rank, FILE *fPtr)
+{
+    if (!cols || !dir || cols->count < 0) return MCRAT_HIP_EINVAL;
+    const int n = cols->count;
+    if (n == 0) return MCRAT_HIP_OK;                              /* an empty H5Dcreate with chunk 0 is an error; nothing to write */
+    if (fPtr) fprintf(fPtr, "num_ph %d\nAllocated weight to be %d values large and other arrays to be %d\n", n, n, n);
+    char file[2000], group[64];
+    snprintf(file, sizeof file, "%s%s%d%s", dir, "mc_proc_", angle_rank, ".h5");
+    snprintf(group, sizeof group, "%d", frame);
+    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
+    hid_t f = H5Fcreate(file, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT);           /* :199-206 */
+    if (f < 0) f = H5Fopen(file, H5F_ACC_RDWR, H5P_DEFAULT);
+    if (f < 0) return MCRAT_HIP_EINVAL;
+    hid_t g = (H5Lexists(f, group, H5P_DEFAULT) > 0) ? H5Gopen2(f, group, H5P_DEFAULT) : H5Gcreate2(f, group, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+    int bad = g < 0;
+    static const char *names[17] = {"P0", "P1", "P2", "P3", "COMV_P0", "COMV_P1", "COMV_P2", "COMV_P3", "R0", "R1", "R2",
+                                    "S0", "S1", "S2", "S3", "NS", "PW"};
+    const double *col[17] = {cols->p0, cols->p1, cols->p2, cols->p3, cols->comv_p0, cols->comv_p1, cols->comv_p2, cols->comv_p3,
+                             cols->r0, cols->r1, cols->r2, cols->s0, cols->s1, cols->s2, cols->s3, cols->num_scatt, cols->weight};
+    for (int k = 0; !bad && k < 17; k++)
+        if (col[k]) bad = put(g, names[k], H5T_NATIVE_DOUBLE, col[k], (hsize_t)n) != 0;
+    if (!bad && cols->type) bad = put(g, "PT", H5T_NATIVE_CHAR, cols->type, (hsize_t)n) != 0;
+    if (g >= 0) H5Gclose(g);
+    H5Fclose(f);
+    return bad ? MCRAT_HIP_EINVAL : MCRAT_HIP_OK;
+}
+
 int mcrat_host_print_photons(mcrat_hip_ctx *ctx, int frame, const char *dir, int angle_rank, int comv_switch, int stokes_switch,
                              int save_type, FILE *fPtr)
 {
@@ -69,27 +97,10 @@ int mcrat_host_print_photons(mcrat_hip_ctx *ctx, int frame, const char *dir, int
     o.count = n;
     rc = mcrat_hip_get_output(ctx, &o);
     if (rc) { free(buf); free(type); return rc; }
-    if (fPtr) fprintf(fPtr, "num_ph %d\nAllocated weight to be %d values large and other arrays to be %d\n", n, n, n);
-
-    char file[2000], group[64];
-    snprintf(file, sizeof file, "%s%s%d%s", dir, "mc_proc_", angle_rank, ".h5");
-    snprintf(group, sizeof group, "%d", frame);
-    H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
-    hid_t f = H5Fcreate(file, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT);           /* :199-206 */
-    if (f < 0) f = H5Fopen(file, H5F_ACC_RDWR, H5P_DEFAULT);
-    if (f < 0) { free(buf); free(type); return MCRAT_HIP_EINVAL; }
-    hid_t g = (H5Lexists(f, group, H5P_DEFAULT) > 0) ? H5Gopen2(f, group, H5P_DEFAULT) : H5Gcreate2(f, group, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
-    int bad = g < 0;
-    static const char *names[17] = {"P0", "P1", "P2", "P3", "COMV_P0", "COMV_P1", "COMV_P2", "COMV_P3", "R0", "R1", "R2",
-                                    "S0", "S1", "S2", "S3", "NS", "PW"};
-    for (int k = 0; !bad && k < ncol; k++)
-        if (*slot[k]) bad = put(g, names[k], H5T_NATIVE_DOUBLE, *slot[k], (hsize_t)n) != 0;
-    if (!bad && save_type) bad = put(g, "PT", H5T_NATIVE_CHAR, type, (hsize_t)n) != 0;
-    if (g >= 0) H5Gclose(g);
-    H5Fclose(f);
+    rc = mcrat_host_print_photon_arrays(&o, frame, dir, angle_rank, fPtr);
     free(buf);
     free(type);
-    return bad ? MCRAT_HIP_EINVAL : MCRAT_HIP_OK;
+    return rc;
 }
 
 /* a dataset of a frame back into memory (what dirFileMerge does per dataset, mcrat_io.c:1500-1560); *n receives its length;

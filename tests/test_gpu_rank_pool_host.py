@@ -84,7 +84,7 @@ def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, orac
     cfg.get_hydro = B.GET_HYDRO(reader)
     cfg.write_checkpoints = 1
     if h5 is not None:
-        cfg.print_photons = C.cast(h5.mcrat_host_print_photons, C.c_void_p).value
+        cfg.print_photons = C.cast(h5.mcrat_host_print_photon_arrays, C.c_void_p).value
     cfg.comv_switch, cfg.stokes_switch, cfg.save_type = 1, 1, 1
     assert host.mcrat_host_run_ranks(pool.ctx, ranks, R, C.byref(cfg)) == 0
     for f in logs:
