@@ -509,6 +509,26 @@ int mcrat_hip_shared_clock_resolve(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_poll(mcrat_hip_ctx *ctx, int *frame_done, mcrat_hip_frame_stats *stats);   /* synchronises the stream */
 int mcrat_hip_shared_clock_finish(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);   /* apply the pending advance, final stats */
 
+/* The device functions of the path, one at a time, on arrays -- for function-level parity tests against the reference functions
+ * (tests/test_gpu_functions.py; the loop does not use this entry).  in / out: n rows of doubles, row layouts:
+ *   KN_CROSS_SECTION       in  energy_ratio                          out sigma / sigma_T        kleinNishinaCrossSection, mcrat_scattering.c:597
+ *   LORENTZ_BOOST_PHOTON   in  beta[3], p[4]                         out p'[4]                  lorentzBoost(.., 'p'), mclib.c:302 (zeroNorm'ed)
+ *   LORENTZ_BOOST_ELECTRON in  beta[3], p[4]                         out p'[4]                  lorentzBoost(.., 'e')
+ *   STOKES_ROTATION        in  v[3], v_ph[3], v_ph_boosted[3], s[4]  out s[4]                   stokesRotation, mcrat_scattering.c:103
+ *   THERMAL_ELECTRON       in  temp, ph[4]                           out el[4]                  singleThermalElectron, electron.c:70
+ *   THERMAL_ELECTRON_WAVE  the same through the wavefront-wide sampler the event walk uses (one wavefront per row)
+ *   ELECTRON_AND_SCATTER   in  temp, ph[4], s[4]                     out el[4], ph'[4], s'[4], occurred    singleThermalElectron then
+ *                                                                    singleScatter (mcrat_scattering.c:151) on one stream; STOKES as the context's
+ * Random numbers of row i: the engine's event stream {seed, iteration i, slot 0, the context's rng_stream} (rng.hpp). */
+#define MCRAT_HIP_FN_KN_CROSS_SECTION       1
+#define MCRAT_HIP_FN_LORENTZ_BOOST_PHOTON   2
+#define MCRAT_HIP_FN_LORENTZ_BOOST_ELECTRON 3
+#define MCRAT_HIP_FN_STOKES_ROTATION        4
+#define MCRAT_HIP_FN_THERMAL_ELECTRON       5
+#define MCRAT_HIP_FN_THERMAL_ELECTRON_WAVE  6
+#define MCRAT_HIP_FN_ELECTRON_AND_SCATTER   7
+int mcrat_hip_eval_function(mcrat_hip_ctx *ctx, int fn, int n, const double *in, double *out, uint64_t seed);
+
 /* per-frame reductions on the resident photons ------------------------------- */
 int mcrat_hip_ph_minmax(mcrat_hip_ctx *ctx, double *min_r, double *max_r, double *min_theta, double *max_theta); /* mclib.c:1465 */
 int mcrat_hip_scatt_stats(mcrat_hip_ctx *ctx, int *max_scatt, int *min_scatt, double *avg_scatt, double *avg_r); /* mclib.c:1385 */

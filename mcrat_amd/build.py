@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcrat_hip.so")
 KERNEL_TUS = ["kernels%s_d%d.hip" % (m, d) for m in ("", "_table") for d in (0, 1, 2)]   # kernels.hip per TAU_CALCULATION x DIMENSIONS
-SOURCES = KERNEL_TUS + ["launchers.hip", "grid_build.hip", "staging.hip", "inject.hip", "ingest.hip", "hot_table.hip", "engine.hip"]
+SOURCES = KERNEL_TUS + ["launchers.hip", "grid_build.hip", "staging.hip", "inject.hip", "ingest.hip", "hot_table.hip", "functions.hip", "engine.hip"]
 HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden"]
 OBJDIR = os.path.join(HERE, "_obj")
@@ -25,6 +25,7 @@ DEPS = {"launchers.hip": ["launchers.hip", "device_types.hpp", "launch.hpp"],
         "inject.hip": ["inject.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"],
         "ingest.hip": ["ingest.hip", "device_types.hpp", "launch.hpp"],
         "hot_table.hip": ["hot_table.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"],
+        "functions.hip": ["functions.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")],
         "engine.hip": ["engine.hip", "device_types.hpp", "launch.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]}
 for _tu in KERNEL_TUS:
     DEPS[_tu] = _KERNEL_DEPS + [_tu]

@@ -2583,6 +2583,24 @@ extern "C" int mcrat_hip_avg_energy(mcrat_hip_ctx *c, double *erg)
     return MCRAT_HIP_OK;
 }
 
+extern "C" int mcrat_hip_eval_function(mcrat_hip_ctx *c, int fn, int n, const double *in, double *out, uint64_t seed)
+{
+    static const int in_w[8] = {0, 1, 7, 7, 13, 5, 5, 9}, out_w[8] = {0, 1, 4, 4, 4, 4, 4, 13};
+    if (!c || n <= 0 || !in || !out || fn < 1 || fn > 7) return MCRAT_HIP_EINVAL;
+    const size_t bi = sizeof(double) * (size_t)in_w[fn] * (size_t)n, bo = sizeof(double) * (size_t)out_w[fn] * (size_t)n;
+    double *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_in, bi));
+    if (hipMalloc((void **)&d_out, bo) != hipSuccess) { (void)hipFree(d_in); return MCRAT_HIP_ENOMEM; }
+    hipError_t e = hipMemcpyAsync(d_in, in, bi, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = launch_eval_function(fn, c->kc.stokes, n, d_in, d_out, seed, c->key.stream, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, bo, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    HIPCHK(c, e);
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_lookup_cell(mcrat_hip_ctx *c, int n, const double *a0, const double *a1, const double *a2, int *out)
 {
     if (!c || n <= 0 || !a0 || !a1 || !out) return MCRAT_HIP_EINVAL;

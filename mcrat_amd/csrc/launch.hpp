@@ -232,5 +232,7 @@ hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *
                       long long total, hipStream_t stream);
 hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, const double *a0, const double *a1,
                          const double *a2, int *out, hipStream_t stream);
+// physics.hpp's functions on arrays (functions.hip; mcrat_hip_eval_function)
+hipError_t launch_eval_function(int fn, int stokes, int n, const double *in, double *out, uint64_t seed, uint32_t stream_id, hipStream_t stream);
 
 }  // namespace mcrat

@@ -230,6 +230,7 @@ SYMBOLS = {
     "mcrat_hip_avg_energy": (C.c_int, [_ctx, _dp]),
     "mcrat_hip_synchronize": (C.c_int, [_ctx]),
     "mcrat_hip_device_bytes": (C.c_size_t, [_ctx]),
+    "mcrat_hip_eval_function": (C.c_int, [_ctx, C.c_int, C.c_int, _dp, _dp, C.c_uint64]),
     "mcrat_hip_lookup_cell": (C.c_int, [_ctx, C.c_int, _dp, _dp, _dp, _ip]),
 }
 
@@ -677,6 +678,17 @@ class Engine:
 
     def device_bytes(self):
         return int(self.lib.mcrat_hip_device_bytes(self.ctx))
+
+    FN = dict(kn_cross_section=(1, 1, 1), lorentz_boost_photon=(2, 7, 4), lorentz_boost_electron=(3, 7, 4), stokes_rotation=(4, 13, 4),
+              thermal_electron=(5, 5, 4), thermal_electron_wave=(6, 5, 4), electron_and_scatter=(7, 9, 13))
+
+    def eval_function(self, name, rows, seed=0):
+        """one device function of physics.hpp on an array of argument rows (mcrat_hip_eval_function); returns the result rows"""
+        fn, wi, wo = self.FN[name]
+        a = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, wi)
+        out = np.empty((a.shape[0], wo))
+        self._check(self.lib.mcrat_hip_eval_function(self.ctx, fn, a.shape[0], a.ctypes.data_as(_dp), out.ctypes.data_as(_dp), int(seed)), "eval_function")
+        return out
 
     def lookup_cell(self, a0, a1, a2=None):
         a0, a1 = _f8(a0), _f8(a1)

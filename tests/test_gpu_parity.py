@@ -149,12 +149,20 @@ def test_locate_and_sample_step(hip, oracle, make):
     out = e.get_photons()
     assert (P.aos["nearest_block_index"] >= 0).all()
     _compare(out, P.aos, rtol=1e-10)
-    # the event half picks the same photon and time as the head of the oracle's sorted list
+    # the event half walks the candidates exactly as the oracle's photonEvent does on its sorted list: the same photon reported,
+    # the same time step, the same number of Klein-Nishina rejections on the way, and the same photons afterwards
     s = e.step_event()
-    first = P.sorted[0]
+    idx, scatt = C.c_int(-1), C.c_longlong(0)
+    ost = oracle.Stats()
+    o_dt = L.orc_photonEvent(C.byref(c), C.byref(P.c), 0.2, C.byref(H.c), C.byref(idx), C.byref(scatt), C.byref(rng), C.byref(ost))
     assert s.iterations == 1
-    assert s.last_scattered_index == first or s.kn_rejections > 0
-    assert s.last_time_step == pytest.approx(P.aos["time_to_scatter"][first], rel=1e-12) or s.kn_rejections > 0
+    assert s.last_scattered_index == idx.value
+    assert s.frame_scatt_cnt == scatt.value
+    assert s.kn_rejections == ost.kn_rejections
+    assert s.last_time_step == pytest.approx(o_dt, rel=1e-12)
+    if ost.kn_rejections == 0 and scatt.value == 1:
+        assert idx.value == P.sorted[0]                  # the head of the argsort (mclib.c:702-712) scattered
+    _compare(e.get_photons(), P.aos, rtol=1e-9)          # (the read-back applies the advance the walk left pending)
 
 
 # ------------------------------------------------------------------ trajectories
