@@ -133,3 +133,38 @@ def test_hdf5_frame_datasets_like_printPhotons(hip, tmp_path):
     for absent in (b"COMV_P0", b"S0", b"PT"):
         assert h5.mcrat_host_h5_read(file, b"258", absent, 0, None, 0, C.byref(n)) != 0
     e.close()
+
+
+def test_device_streamed_checkpoint_headers_in_the_three_cases_of_saveCheckpoint(hip, tmp_path):
+    """the file streamed from the device (ctx branch) against bytes assembled here from the reference's write sequence
+    (Src/mcrat_io.c:871-903 CONTINUE in the middle of a run, :918-961 the injection frame itself, :963-1000 after the last hydro frame:
+    INITALIZE header without scatt_frame / time / count) -- not against the host-list writer"""
+    from mcrat_amd.host import binding as B
+    host = B.host()
+    e, _ = _engine_after_a_frame(hip, n=3000)
+    rec = e.get_photons_range(0, 3000)
+    d = str(tmp_path) + "/"
+    path, old = tmp_path / "mc_chkpt_5.dat", tmp_path / "mc_chkpt_5.dat_old"
+    body = rec.tobytes()
+    assert len(body) == 176 * 3000
+
+    def save(frame, frame2, scatt_frame, t, last):
+        return host.mcrat_host_save_checkpoint(d.encode(), frame, frame2, scatt_frame, t, e.ctx, None, 3000, last, 5, 16, 0)
+    # (1) scatt_frame != last_frame, != frame: angle_size, 'c', frame, frame2, scatt_frame, time_now, ph_num, records
+    assert save(200, 203, 257, 51.4, 3000) == 0
+    first = path.read_bytes()
+    assert first == struct.pack("=i", 16) + b"c" + struct.pack("=iii", 200, 203, 257) + struct.pack("=d", 51.4) + struct.pack("=i", 3000) + body
+    assert not old.exists()                                                  # "cp" of a file that did not exist yet
+    assert save(200, 203, 258, 51.6, 3000) == 0
+    assert old.read_bytes() == first and path.read_bytes()[9:21] == struct.pack("=iii", 200, 203, 258)
+    # (2) scatt_frame == frame: the previous file is removed ("rm"), no _old is made; same CONTINUE header
+    os.remove(old)
+    assert save(300, 303, 300, 60.0, 3000) == 0
+    assert not old.exists()
+    assert path.read_bytes() == struct.pack("=i", 16) + b"c" + struct.pack("=iii", 300, 303, 300) + struct.pack("=d", 60.0) + struct.pack("=i", 3000) + body
+    # (3) scatt_frame == last_frame: 'i', frame, frame2, then the records with no count in front; the previous file kept as _old
+    before = path.read_bytes()
+    assert save(300, 303, 3000, 600.0, 3000) == 0
+    assert old.read_bytes() == before
+    assert path.read_bytes() == struct.pack("=i", 16) + b"i" + struct.pack("=ii", 300, 303) + body
+    e.close()
