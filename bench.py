@@ -252,15 +252,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def make_engine(mode, profile=False, per_sync=None):
+    def make_engine(mode, profile=False, per_sync=None, photons=None, lists=None, stream_base=None):
         if mode == "ranks":
             # a rank pool: every list its own length, stream and clock, all lists propagated by one launch (mcrat_hip_pool_*)
+            src = ph if photons is None else photons
+            lo, hi = (0, n_lists) if lists is None else lists
+            sb = first_stream if stream_base is None else stream_base
             e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
-                              rng_stream=first_stream, profile=profile)
+                              rng_stream=sb, profile=profile)
             e.set_hydro(frame)
-            e.pool_create(n_lists, int(lens.max()))
-            for r in range(n_lists):
-                e.pool_rank(r, first_stream + r).set_photons(sub_photons(ph, int(offs[r]), int(offs[r + 1])))
+            e.pool_create(max(1, hi - lo), int(lens.max()))
+            for r in range(lo, hi):
+                e.pool_rank(r - lo, sb + r).set_photons(sub_photons(src, int(offs[r]), int(offs[r + 1])))
             return e
         e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
                           rng_stream=first_stream, iterations_per_sync=per_sync or 500, use_graph=bool(args.graph),
@@ -319,6 +322,28 @@ def main():
                             "re-location pass of the new frame is inside the launch); the HBM-bound kernel of this path is "
                             "step_kernel, see other_mode.roofline"}
         return dict(events=ev, photon_steps=ps, passes=it, seconds=dt, ranks=nr, roofline=roof)
+
+    def measure_strong(k_frames, k_warm):
+        """strong scaling beside the weak line: ONE set of n photons (the set rank 0 holds in the weak run), its lists dealt out to the
+        GPUs in contiguous blocks (sharding.shard_bounds), no data-path collective; at N = 1 this is the weak line's own workload"""
+        from mcrat_amd import sharding
+        if world == 1:
+            common = ph
+        elif args.config == "cfg3":
+            _, common, _ = synth.config3(n_photons=args.photons, seed=SEED, nr=32 * args.nzc, nth=8 * args.nzc, stokes=1)
+        else:
+            _, common, _ = synth.config2(n_photons=args.photons, seed=SEED, nzc=args.nzc, stokes=args.stokes)
+        lo, hi = sharding.shard_bounds(n_lists, world, rank)
+        e = make_engine("ranks", photons=common, lists=(lo, hi), stream_base=0)
+        e.snapshot_photons()
+        run_ranks(e, k_warm, SEED + 1000)
+        sync()
+        t0 = time.perf_counter()
+        ev, ps, it = run_ranks(e, k_frames, SEED)
+        sync()
+        dt = time.perf_counter() - t0
+        e.close()
+        return ev, ps, dt, hi - lo
 
     def measure_list(k_steps, k_warm, prof_steps):
         e = make_engine("list", per_sync=max(50, min(500, k_steps)))
@@ -403,6 +428,23 @@ def main():
         t_max, events_all, steps_all = float(t.item()), float(c[0].item()), float(c[1].item())
         if args.mode == "shared-clock":
             events_all = float(main_res["events"])       # one list: every GPU counts the same events
+
+    strong = None
+    if args.mode == "ranks" and args.other_mode:
+        try:
+            ev_s, ps_s, dt_s, my_lists = measure_strong(steps, warmup)
+            if dist is not None:
+                tt = torch.tensor([dt_s], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                cc = torch.tensor([float(ev_s), float(ps_s)], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+                dt_s, ev_s, ps_s = float(tt.item()), float(cc[0].item()), float(cc[1].item())
+            strong = {"scaling": "strong", "note": "one set of %d photons (%d lists) dealt out to the %d GPU(s) in contiguous blocks of lists, frame "
+                                                   "replicated, no data-path collective; at n_gpus = 1 this is the weak line's own workload" % (n, n_lists, world),
+                      "value": ev_s / dt_s, "unit": "scatter-events/s", "n_gpus": world, "photons_total": n, "lists_per_gpu": int(my_lists),
+                      "ms_per_step": dt_s * 1e3 / steps, "photon_steps_per_s": ps_s / dt_s}
+        except Exception as ex:
+            strong = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     other = None
     if rank == 0 and world == 1 and args.other_mode:
@@ -668,6 +710,7 @@ def main():
             "scatter_events": events_all,
             "loop_passes": main_res["passes"],
             "roofline": main_res["roofline"],
+            "strong": strong,
             "other_mode": other,
             "pcie_inclusive": pcie,
             "ingest": ingest,

@@ -65,6 +65,9 @@ def host():
         lib.mcrat_host_rank_seed.argtypes = [C.c_uint64, C.c_longlong]
         lib.mcrat_host_split_ranks.restype = C.c_int
         lib.mcrat_host_split_ranks.argtypes = [C.POINTER(McPar), C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_double, C.c_uint64, C.POINTER(HostRank)]
+        lib.mcrat_host_shared_clock_frame.restype = C.c_int
+        lib.mcrat_host_shared_clock_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                      C.POINTER(C.c_double), C.c_double, C.c_uint64, C.c_int, C.POINTER(engine.FrameStats)]
         lib.mcrat_host_run_ranks.restype = C.c_int
         lib.mcrat_host_run_ranks.argtypes = [C.c_void_p, C.POINTER(HostRank), C.c_int, C.POINTER(PoolConfig)]
         _host = lib
@@ -87,6 +90,29 @@ def host_h5():
         lib.mcrat_host_h5_read.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         _h5 = lib
     return _h5
+
+
+ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+_rccl = None
+
+
+def host_rccl():
+    """libmcrat_hip_host_rccl.so (the shared-clock exchange over RCCL, its rounds in a hipGraph), or None without ROCm's RCCL"""
+    global _rccl
+    if _rccl is None:
+        host()
+        path = build_host.build_rccl()
+        if path is None:
+            return None
+        lib = C.CDLL(path)
+        lib.mcrat_host_shared_clock_frame_graph.restype = C.c_int
+        lib.mcrat_host_shared_clock_frame_graph.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.POINTER(C.c_double),
+                                                            C.c_double, C.c_uint64, C.c_int, C.POINTER(engine.FrameStats)]
+        lib.mcrat_host_rccl_comm_single.restype = C.c_int
+        lib.mcrat_host_rccl_comm_single.argtypes = [C.POINTER(C.c_void_p)]
+        lib.mcrat_host_rccl_comm_destroy.argtypes = [C.c_void_p]
+        _rccl = lib
+    return _rccl
 
 
 def rank_seed(rng_seed, k):

@@ -47,6 +47,26 @@ def build_h5(force=False):
     return H5_LIB
 
 
+RCCL_LIB = os.path.join(HERE, "libmcrat_hip_host_rccl.so")
+RCCL_SRC = os.path.join(HERE, "mcrat_hip_host_rccl.c")
+
+
+def build_rccl(force=False):
+    """the shared-clock exchange over RCCL and its hipGraph (mcrat_hip_host_rccl.c); None where ROCm's RCCL headers are not installed"""
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if not (os.path.exists(os.path.join(rocm, "include", "rccl", "rccl.h")) and os.path.exists(os.path.join(rocm, "lib", "librccl.so"))):
+        return None
+    deps = [RCCL_SRC, os.path.join(HERE, "mcrat_hip_host.h"), os.path.join(ROOT, "include", "mcrat_hip.h")]
+    if not force and os.path.exists(RCCL_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(RCCL_LIB) for d in deps):
+        return RCCL_LIB
+    cmd = ["gcc", "-std=gnu99", "-O2", "-Wall", "-Wextra", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
+           RCCL_SRC, "-o", RCCL_LIB, "-L", os.path.dirname(HERE), "-lmcrat_hip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN/..", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+    subprocess.run(cmd, check=True)
+    return RCCL_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True))
     print(build_h5(force=True))
+    print(build_rccl(force=True))

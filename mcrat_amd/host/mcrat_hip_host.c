@@ -741,6 +741,37 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     return rc;
 }
 
+/* ------------------------------------------------------------------ shared clock: the host loop (mcrat_hip_host.h) */
+int mcrat_host_shared_clock_frame(mcrat_hip_ctx *ctx, int world, int rank, long long slot_base, mcrat_host_allgather_fn exchange, void *user,
+                                  void *stream, double *time_now, double remaining_time, uint64_t seed, int rounds_per_poll,
+                                  mcrat_hip_frame_stats *stats)
+{
+    if (!ctx || !time_now || world < 1 || (world > 1 && !exchange)) return MCRAT_HIP_EINVAL;
+    if (rounds_per_poll < 1) rounds_per_poll = 32;
+    void *send = NULL, *recv = NULL;
+    int rc;
+    if (mcrat_hip_shared_clock_buffers(ctx, &send, &recv) != 0 &&
+        (rc = mcrat_hip_shared_clock_attach(ctx, world, rank, slot_base, NULL, NULL)) != 0)
+        return rc;
+    if ((rc = mcrat_hip_shared_clock_buffers(ctx, &send, &recv)) != 0) return rc;
+    const size_t nb = mcrat_hip_shared_clock_bytes_per_rank();
+    if ((rc = mcrat_hip_begin_frame(ctx, seed, *time_now, remaining_time)) != 0) return rc;
+    mcrat_hip_frame_stats st;
+    int done = 0;
+    while (!done) {
+        for (int k = 0; k < rounds_per_poll; k++) {
+            if ((rc = mcrat_hip_shared_clock_propose(ctx)) != 0) return rc;
+            if (world > 1 && (rc = exchange(user, send, recv, nb, stream)) != 0) return rc;
+            if ((rc = mcrat_hip_shared_clock_resolve(ctx)) != 0) return rc;
+        }
+        if ((rc = mcrat_hip_shared_clock_poll(ctx, &done, &st)) != 0) return rc;      /* identical on every rank: the loops stay in step */
+    }
+    if ((rc = mcrat_hip_shared_clock_finish(ctx, &st)) != 0) return rc;
+    *time_now = st.time_now;
+    if (stats) *stats = st;
+    return MCRAT_HIP_OK;
+}
+
 /* ------------------------------------------------------------------ A/B shims (mcrat_hip_host.h) */
 int mcrat_ab_begin_frame(mcrat_ab_rng *rng, mcrat_hip_ctx *ctx, const mcrat_hip_photon_list *ph, const mcrat_hip_hydro *hydro,
                          uint64_t seed, double time_now, double remaining_time)

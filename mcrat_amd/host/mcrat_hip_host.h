@@ -228,6 +228,28 @@ typedef struct mcrat_host_pool_config {
  * Returns 0 or the first negative MCRAT_HIP_E* code (1: a checkpoint could not be written, as saveCheckpoint). */
 int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_ranks, mcrat_host_pool_config *cfg);
 
+/* ---- one list over several GPUs, one clock (mcrat_hip_shared_clock_*, include/mcrat_hip.h): the host loop in C ----------------
+ * One process per GPU; every process calls this with the same seed, time_now and remaining_time and its own rank / slot_base
+ * (the number of slots on the lower ranks, even).  A round is propose -> exchange -> resolve; `exchange` is the all-gather of the
+ * round's proposals (bytes_per_rank from every rank, in rank order, into recv) ON THE CONTEXT'S STREAM -- mcrat_host_allgather_rccl
+ * (mcrat_hip_host_rccl.c) is ncclAllGather; an MPI build passes MPI_Allgather on device pointers after a stream synchronise.  The
+ * state is polled every rounds_per_poll rounds (rounds after the frame's end are no-ops).  The context must have its photons and
+ * hydro frame set; it is attached on the first call (library-owned exchange buffers).  0 or a negative MCRAT_HIP_E* code. */
+typedef int (*mcrat_host_allgather_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+int mcrat_host_shared_clock_frame(mcrat_hip_ctx *ctx, int world, int rank, long long slot_base, mcrat_host_allgather_fn exchange, void *user,
+                                  void *stream, double *time_now, double remaining_time, uint64_t seed, int rounds_per_poll,
+                                  mcrat_hip_frame_stats *stats);
+/* mcrat_hip_host_rccl.c (libmcrat_hip_host_rccl.so, links librccl): the exchange as ncclAllGather -- `user` points at the caller's
+ * ncclComm_t --, and the same frame with its rounds captured in a hipGraph (the forced first round is launched eagerly, then
+ * rounds_per_graph rounds of {propose kernels, ncclAllGather, resolve kernel} replay as one graph launch between two polls).
+ * mcrat_host_rccl_comm_single makes a one-rank communicator on the current device (tests, one-GPU runs). */
+int mcrat_host_allgather_rccl(void *user, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+int mcrat_host_shared_clock_frame_graph(mcrat_hip_ctx *ctx, int world, int rank, long long slot_base, void *nccl_comm, void *stream,
+                                        double *time_now, double remaining_time, uint64_t seed, int rounds_per_graph,
+                                        mcrat_hip_frame_stats *stats);
+int  mcrat_host_rccl_comm_single(void **nccl_comm);
+void mcrat_host_rccl_comm_destroy(void *nccl_comm);
+
 /* ---- A/B shims: the reference's loop functions with their own argument order (Src/mclib.h:8-29) ----------------
  * For checking the engine against the CPU functions one call at a time inside MCRaT's own loop (mcrat.c:761-851):
  * replace `findContainingHydroCell(&photon_list, &hydrodata, sw, rng, fPtr)` by
