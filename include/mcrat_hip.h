@@ -467,6 +467,22 @@ int mcrat_hip_pool_summaries(mcrat_hip_ctx *pool, mcrat_hip_rank_summary *out /*
  *   mcrat_hip_pool_layout        the lists' places in the pool's own slot numbering: list r occupies the slots r * slots_per_rank ...,
  *                                which mcrat_hip_get_photons_range / mcrat_hip_get_output on the POOL context address (slots beyond a
  *                                list's length hold no photon: type 0, weight 0) -- one transfer for all lists' records or columns */
+/* CYCLOSYNCHROTRON_SWITCH on (the pool created from a context with cyclosynchrotron_switch = 1): mcrat_hip_scatter_frame_cyclosynch for
+ * every list with lists[r].open != 0 -- pool emission per list, then the loops of ALL lists in the same launches (a list leaves the loop only
+ * for the hook of mcrat.c:786-808: its scattered pool photon converted and replaced, the list doubling inside its window of the pool when
+ * it has no null slot left, the rebinning trigger), rebinning and absorption at the end.  cs carries the build's switches (b_field_calc,
+ * epsilon_b, rebin_*); the frame numbers come per list.  slots_per_rank of mcrat_hip_pool_create must allow for the doublings
+ * (MCRAT_HIP_ENOMEM otherwise).  stats / counts: [n_ranks], per list; stats may be NULL. */
+typedef struct mcrat_hip_pool_cs_list {
+    int      open;
+    int      emit_pool;                   /* (scatt_frame != scatt_framestart) || (restrt == CONTINUE), mcrat.c:707 */
+    int      scatt_frame_number, inj_frame_number;
+    uint64_t seed;
+    double   time_now, remaining_time;
+    double   r_inj, ph_weight_suggest, theta_min, theta_max;
+} mcrat_hip_pool_cs_list;
+int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *pool, const mcrat_hip_cyclosynch *cs, int max_photons, double fps,
+                                             const mcrat_hip_pool_cs_list *lists, mcrat_hip_frame_stats *stats, mcrat_hip_cyclosynch_counts *counts);
 int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *pool, const int *open, const uint64_t *seeds, const double *time_now, const double *remaining_time);
 int mcrat_hip_pool_frame_stats(mcrat_hip_ctx *pool, mcrat_hip_frame_stats *out /* [n_ranks] */);
 int mcrat_hip_pool_layout(const mcrat_hip_ctx *pool, int *n_ranks, int *slots_per_rank);

@@ -2177,7 +2177,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
             if (rc) return rc;
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
-        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, batch,
+        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, nullptr, batch,
                                    c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
         if (c->cfg.profile) {
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -2397,6 +2397,134 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
     HIPCHK(c, hipStreamSynchronize(c->stream));
     *time_now = c->h_state->time_now;
     fill_stats(c, stats);
+    return MCRAT_HIP_OK;
+}
+
+// The scatter frame of mcrat.c:706-878 with CYCLOSYNCHROTRON_SWITCH on for the lists of a rank pool: what mcrat_hip_scatter_frame_cyclosynch
+// does for one list, for every open list -- the loop of all of them in the same launches.  rank_loop_kernel runs every list until a pass
+// the hook of :786-808 must look at (photonEvent reported a pool photon; a thousand scatterings are full) and parks it there;
+// cs_replace_pool_kernel, one workgroup per parked list, converts and replaces the pool photon (doubling the list inside its window
+// of the pool when it has no null slot left), evaluates the rebinning trigger and lets the list go on; the two launches alternate,
+// several pairs per read-back.  Only the rebinning itself needs the host (the view's mcrat_hip_rebin_cyclosynch).
+extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, int max_photons, double fps,
+                                                        const mcrat_hip_pool_cs_list *lists, mcrat_hip_frame_stats *stats,
+                                                        mcrat_hip_cyclosynch_counts *counts)
+{
+    if (!c || !cs || !lists || !counts || cs->b_field_calc < 0 || cs->b_field_calc > 2 || max_photons <= 0 || !(fps > 0)) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    if (!c->cfg.cyclosynchrotron_switch) { c->last_error = "the pool was created with cyclosynchrotron_switch = 0"; return MCRAT_HIP_ESTATE; }
+    if (!c->have_hydro || !c->hcol_buf) return MCRAT_HIP_ESTATE;
+    const int R = c->n_ranks;
+    int rc;
+    std::vector<int> open((size_t)R, 0), emit_base((size_t)R, 0);
+    std::vector<uint64_t> seeds((size_t)R, 0);
+    std::vector<double> t_now((size_t)R, 0.0), t_rem((size_t)R, 0.0);
+    std::vector<mcrat_hip_cyclosynch> csr((size_t)R, *cs);
+    for (int r = 0; r < R; ++r) {
+        memset(&counts[r], 0, sizeof counts[r]);
+        if (!lists[r].open) continue;
+        mcrat_hip_ctx *v = c->views[r];
+        if (!v || !v->have_photons) { c->last_error = "pool_scatter_frames_cyclosynch: an open list does not exist"; return MCRAT_HIP_ESTATE; }
+        open[(size_t)r] = 1;
+        seeds[(size_t)r] = lists[r].seed; t_now[(size_t)r] = lists[r].time_now; t_rem[(size_t)r] = lists[r].remaining_time;
+        csr[(size_t)r].scatt_frame_number = lists[r].scatt_frame_number;
+        csr[(size_t)r].inj_frame_number = lists[r].inj_frame_number;
+        if (lists[r].emit_pool) {                                                                 // :727-744
+            int n = 0, bad = 0;
+            double w = 0;
+            if ((rc = mcrat_hip_emit_cyclosynch_pool(v, &csr[(size_t)r], lists[r].r_inj, lists[r].ph_weight_suggest, max_photons, lists[r].theta_min,
+                                                     lists[r].theta_max, fps, lists[r].seed, &n, &w, &bad))) {
+                c->last_error = v->last_error;
+                return rc;
+            }
+            counts[r].num_cyclosynch_ph_emit = n;
+            counts[r].pool_weight = w;
+            counts[r].integrals_not_converged = bad;
+            emit_base[(size_t)r] = n;
+        }
+    }
+    if ((rc = mcrat_hip_pool_begin_frames(c, open.data(), seeds.data(), t_now.data(), t_rem.data()))) return rc;
+    // the hooks' state, one CsFrame per list
+    if (c->d_cs_hook) { HIPCHK(c, hipFree(c->d_cs_hook)); c->d_cs_hook = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->d_cs_hook, sizeof(CsFrame) * (size_t)R));
+    CsFrame *d_cf = static_cast<CsFrame *>(c->d_cs_hook);
+    std::vector<CsFrame> cf((size_t)R);
+    for (int r = 0; r < R; ++r) { cf[(size_t)r] = CsFrame{}; cf[(size_t)r].max_photons = max_photons; cf[(size_t)r].last_iteration = ~0ull; }
+    HIPCHK(c, hipMemcpyAsync(d_cf, cf.data(), sizeof(CsFrame) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    if ((rc = pool_describe(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    CsEmitParams p{};
+    p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry; p.b_field_calc = cs->b_field_calc; p.epsilon_b = cs->epsilon_b;
+    c->rank_block = 256; c->rank_fuse = false;         // lists that change length: columns stay in HBM/L2 (longest = the window)
+    const int pairs_per_sync = 8;
+    for (;;) {
+        for (int k = 0; k < pairs_per_sync; ++k) {
+            HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, 1 << 30, c->d_desc, d_cf, 4096, 256, c->stream));
+            HIPCHK(c, launch_cs_replace_pool(p, c->hy, c->hcol, c->d_rstates, c->ph, c->rank_stride, R, c->d_desc, d_cf, c->stream));
+        }
+        HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(cf.data(), d_cf, sizeof(CsFrame) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bool all_done = true;
+        for (int r = 0; r < R; ++r) {
+            if (!open[(size_t)r]) continue;
+            mcrat_hip_ctx *v = c->views[r];
+            v->ph.n = c->h_desc[r].len;                                                           // the list may have doubled in the hook
+            CsFrame &f = cf[(size_t)r];
+            if (f.halt == CS_HALT_GROW) {
+                c->last_error = "a cyclo-synchrotron list outgrew the pool's slots per rank (mcrat_hip_pool_create: allow for the doublings)";
+                return MCRAT_HIP_ENOMEM;
+            }
+            if (f.halt == CS_HALT_REBIN) {                                                        // :797-808, on the list's view
+                int empty = 0, emit_total = emit_base[(size_t)r] + f.emitted, scatt = f.scatt_num;
+                rc = mcrat_hip_rebin_cyclosynch(v, &csr[(size_t)r], max_photons, &empty, &emit_total, &scatt);
+                if (rc == MCRAT_HIP_OK) {
+                    counts[r].rebins += 1;
+                    emit_base[(size_t)r] = emit_total;
+                    f.emitted = 0;
+                    f.scatt_num = scatt;
+                } else if (rc != MCRAT_HIP_EREFUSED) {
+                    c->last_error = v->last_error;
+                    return rc;
+                }
+                f.halt = 0;
+                c->h_rstates[r].done = f.saved_done;
+                HIPCHK(c, hipMemcpyAsync(d_cf + r, &f, sizeof f, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(c->d_rstates + r) + offsetof(LoopState, done), &c->h_rstates[r].done, sizeof(int),
+                                         hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+            if (c->h_rstates[r].done != LOOP_DONE) all_done = false;
+        }
+        if (all_done) break;
+    }
+    for (int r = 0; r < R; ++r) {
+        if (!open[(size_t)r]) continue;
+        mcrat_hip_ctx *v = c->views[r];
+        const CsFrame &f = cf[(size_t)r];
+        counts[r].num_cyclosynch_ph_emit = emit_base[(size_t)r] + f.emitted;
+        counts[r].scatt_cyclosynch_num_ph = f.scatt_num;
+        counts[r].n_comptonized = f.n_comptonized;
+        v->pending_applied = false;
+        if (lists[r].emit_pool) {                                                                 // :853-878
+            if (counts[r].scatt_cyclosynch_num_ph > max_photons) {
+                int empty = 0;
+                rc = mcrat_hip_rebin_cyclosynch(v, &csr[(size_t)r], max_photons, &empty, &counts[r].num_cyclosynch_ph_emit, &counts[r].scatt_cyclosynch_num_ph);
+                if (rc == MCRAT_HIP_OK) counts[r].rebins += 1;
+                else if (rc != MCRAT_HIP_EREFUSED) { c->last_error = v->last_error; return rc; }
+            }
+            if (counts[r].num_cyclosynch_ph_emit > 0) {
+                double w = 0;
+                if ((rc = mcrat_hip_absorb_cyclosynch(v, &csr[(size_t)r], &counts[r].frame_abs_cnt, &counts[r].scatt_cyclosynch_num_ph, &w))) {
+                    c->last_error = v->last_error;
+                    return rc;
+                }
+                counts[r].n_comptonized -= w;
+            }
+        }
+        if (stats) state_to_stats(c->h_rstates[r], v->ph.n, &stats[r]);
+    }
     return MCRAT_HIP_OK;
 }
 

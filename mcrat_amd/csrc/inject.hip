@@ -430,16 +430,18 @@ __global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, H
 // inject_single_switch = 1, mc_cyclosynch.c:1467-1558, into the list's first null slot, photons.c:139-160), and it is itself moved to
 // a random place in that cell (:1540-1556); then the rebinning trigger of :797-808.  One workgroup; the pending advance must have
 // been applied (flush_kernel) so that the positions are current.  See CsFrame (launch.hpp) for how it parks the loop.
-__global__ __launch_bounds__(256) void cs_replace_kernel(CsEmitParams p, HydroDev hy, HydroCols h, RngKey key, LoopState *st, PhotonDev ph, CsFrame *cf,
-                                                         int resume)
+// (body shared by the single-list hook and the rank pool's; all 256 threads call it.  grow_cap: the list may double in place up to
+// this many slots -- the pool's slots per rank -- instead of parking for the host; *len_out receives the new length.)
+__device__ __forceinline__ void cs_hook_body(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, const RngKey &key, LoopState *st, PhotonDev ph,
+                                             CsFrame *cf, int resume, int *s_min, int grow_cap, int *len_out)
 {
-    __shared__ int s_min[4];
     const int tid = threadIdx.x;
     const unsigned long long it = st->iteration;
-    if (!resume && (cf->halt != 0 || it == cf->last_iteration)) return;        // parked, or a queued pass that did nothing
+    if (!resume && ((cf->halt != 0 && cf->halt != CS_HALT_HOOK) || it == cf->last_iteration)) return;   // parked for the host, or a queued pass that did nothing
     const int sidx = st->last_scattered_index;
     const int called = st->photon_event_called;
     const bool fire = called && sidx >= 0 && sidx < ph.n && ph.type[sidx] == 'p';
+    int slot = INT_MAX;
     if (fire) {
         int mine = INT_MAX;
         for (int i = tid; i < ph.n; i += 256)
@@ -447,14 +449,24 @@ __global__ __launch_bounds__(256) void cs_replace_kernel(CsEmitParams p, HydroDe
         for (int off = 32; off > 0; off >>= 1) mine = min(mine, __shfl_xor(mine, off));
         if ((tid & 63) == 0) s_min[tid >> 6] = mine;
         __syncthreads();
+        slot = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
+        if (slot == INT_MAX && 2 * ph.n <= grow_cap) {                          // photons.c:112-121 inside the pool's window: the list doubles
+            const int old_n = ph.n;
+            for (int i = old_n + tid; i < 2 * old_n; i += 256) {                // (reallocatePhotonListMemory, photons.c:72-78; the columns are zero)
+                ph.type[i] = 'N'; ph.idx[i] = -1; ph.flags[i] = (unsigned char)FLAG_VALID; ph.ntau[i] = -INFINITY;
+            }
+            ph.n = 2 * old_n;
+            slot = old_n;
+            if (tid == 0 && len_out) *len_out = ph.n;
+            __threadfence_block();
+            __syncthreads();
+        }
     }
     if (tid != 0) return;
     if (fire) {
-        const int slot = min(min(s_min[0], s_min[1]), min(s_min[2], s_min[3]));
         if (slot == INT_MAX) {                                                  // photons.c:112-121: the host doubles the list
             cf->halt = CS_HALT_GROW;
-            cf->saved_done = st->done;
-            st->done = LOOP_CS_HALT;
+            if (st->done != LOOP_CS_HALT) { cf->saved_done = st->done; st->done = LOOP_CS_HALT; }
             return;
         }
         const int i = ph.idx[sidx];
@@ -485,9 +497,40 @@ __global__ __launch_bounds__(256) void cs_replace_kernel(CsEmitParams p, HydroDe
     const long long fsc = st->frame_scatt_cnt;
     if (called && (fsc % 1000 == 0) && fsc != 0 && cf->scatt_num > cf->max_photons) {       // mcrat.c:797-808
         cf->halt = CS_HALT_REBIN;
-        cf->saved_done = st->done;
-        st->done = LOOP_CS_HALT;
+        if (st->done != LOOP_CS_HALT) { cf->saved_done = st->done; st->done = LOOP_CS_HALT; }
+    } else if (cf->halt == CS_HALT_HOOK) {                                      // the pool's loop parked for this hook: let it go on
+        cf->halt = 0;
+        st->done = cf->saved_done;
     }
+}
+
+__global__ __launch_bounds__(256) void cs_replace_kernel(CsEmitParams p, HydroDev hy, HydroCols h, RngKey key, LoopState *st, PhotonDev ph, CsFrame *cf,
+                                                         int resume)
+{
+    __shared__ int s_min[4];
+    cs_hook_body(p, hy, h, key, st, ph, cf, resume, s_min, 0, nullptr);
+}
+
+// the same hook for the lists of a rank pool, one workgroup per list: the lists rank_loop_kernel has parked because the pass they just
+// finished has something for the hook (LOOP_CS_HALT with CsFrame::halt == CS_HALT_HOOK; the kernel leaves the photons current)
+__global__ __launch_bounds__(256) void cs_replace_pool_kernel(CsEmitParams p, HydroDev hy, HydroCols h, LoopState *states, PhotonDev pool, int stride,
+                                                              RankDesc *desc, CsFrame *frames)
+{
+    __shared__ int s_min[4];
+    const int r = blockIdx.x;
+    LoopState *st = states + r;
+    CsFrame *cf = frames + r;
+    if (st->done != LOOP_CS_HALT || cf->halt != CS_HALT_HOOK) return;
+    const RankDesc d = desc[r];
+    const size_t o = (size_t)r * (size_t)stride;
+    PhotonDev ph = pool;
+    double **cols[24] = {&ph.r0, &ph.r1, &ph.r2, &ph.p0, &ph.p1, &ph.p2, &ph.p3, &ph.c0, &ph.c1, &ph.c2, &ph.c3, &ph.s0, &ph.s1, &ph.s2, &ph.s3,
+                         &ph.num_scatt, &ph.weight, &ph.tau, &ph.tts, &ph.u0, &ph.u1, &ph.u2, &ph.ntau, &ph.tau_next};
+    for (int k = 0; k < 24; ++k) *cols[k] += o;
+    ph.idx += o; ph.flags += o; ph.type += o;
+    ph.n = d.len;
+    const RngKey key = {d.seed, d.stream, 0u};
+    cs_hook_body(p, hy, h, key, st, ph, cf, 0, s_min, stride, &desc[r].len);
 }
 
 // the null slots of the list, ascending (photons.c:181-189)
@@ -790,6 +833,13 @@ hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const Hy
                              CsFrame *frame, int resume, hipStream_t stream)
 {
     cs_replace_kernel<<<dim3(1), dim3(256), 0, stream>>>(p, hy, h, key, st, ph, frame, resume);
+    return hipGetLastError();
+}
+
+hipError_t launch_cs_replace_pool(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, LoopState *states, const PhotonDev &pool, int stride,
+                                  int n_ranks, RankDesc *desc, CsFrame *frames, hipStream_t stream)
+{
+    cs_replace_pool_kernel<<<dim3(n_ranks), dim3(256), 0, stream>>>(p, hy, h, states, pool, stride, desc, frames);
     return hipGetLastError();
 }
 

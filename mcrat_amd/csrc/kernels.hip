@@ -864,6 +864,7 @@ struct RankLayout {
     int stride;           // slots reserved per rank
     int n_total;
     const RankDesc *desc;
+    CsFrame *cs;          // CYCLOSYNCHROTRON_SWITCH on: per list, where a pass the hook of mcrat.c:786-808 must look at parks the list
 };
 
 // Four lists per CU.  Measured by varying the number of lists on a dense jet: a workgroup alone on its CU needs 25 us per
@@ -1195,7 +1196,22 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if (force) RANK_TICK(1); else RANK_TICK(2);
         // ---- the event half and the bookkeeping
         event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n, iter, st.remaining_time, st.last_scattered_index, st.t_est);
-        if (tid == 0) st.force_relocate = 0;
+        if (tid == 0) {
+            st.force_relocate = 0;
+            // cyclo-synchrotron lists: if photonEvent reported a pool photon (it becomes a comptonised one and is replaced, mcrat.c:786-795)
+            // or the rebinning is to be looked at (every 1000 scatterings, :797), the list leaves the loop here -- its photons made
+            // current below -- for cs_replace_pool_kernel, which lets it go on in the next launch
+            if (lay.cs && st.photon_event_called) {
+                const int sidx = st.last_scattered_index;
+                const bool pool_photon = sidx >= 0 && gph.type[sidx] == 'p';
+                const bool thousand = (st.frame_scatt_cnt % 1000 == 0) && st.frame_scatt_cnt != 0;
+                if (pool_photon || thousand) {
+                    lay.cs[rank].halt = CS_HALT_HOOK;
+                    lay.cs[rank].saved_done = st.done;
+                    st.done = LOOP_CS_HALT;
+                }
+            }
+        }
         __syncthreads();
         RANK_TICK(3);
 #ifdef MCRAT_DIAG
@@ -1711,11 +1727,12 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 }
 
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, long long max_passes, int block, hipStream_t stream)
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
+                            hipStream_t stream)
 {
     const bool fuse = block >= 1000;               // block: 128 or 256 threads per list, + 1000 for the build with the fused pass (256 threads)
     if (fuse) block -= 1000;
-    RankLayout lay = {n_ranks, rank_stride, ph.n, desc};
+    RankLayout lay = {n_ranks, rank_stride, ph.n, desc, cs};
     // per-pass columns in LDS (32 B per slot with 128 threads, 61 B with 256: rank_loop_kernel) for lists of up to 1024 photons
     int lds_slots = 0;
     if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && longest_list <= 1024) lds_slots = (longest_list + 15) & ~15;

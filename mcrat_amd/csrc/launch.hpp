@@ -30,7 +30,8 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 // virtual ranks: every workgroup (of `block` = 128 or 256 threads) runs the whole loop of one independent photon list: the slots
 // [r * rank_stride, ...) -- rank_stride of them, or desc[r].len with the list's own seed and stream (rank pool); longest_list sizes the LDS copy
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, long long max_passes, int block, hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, struct CsFrame *cs, long long max_passes, int block,
+                            hipStream_t stream);
 // one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
@@ -184,6 +185,7 @@ hipError_t launch_cs_emit_generate(const CsEmitParams &p, const HydroDev &hy, co
 constexpr int LOOP_CS_HALT = 3;      // LoopState::done value
 constexpr int CS_HALT_GROW = 1;      // nothing was done for this pass: double the list, launch the hook again with resume = 1
 constexpr int CS_HALT_REBIN = 2;     // the pass is complete; rebinCyclosynchCompPhotons is due (mcrat.c:797-808)
+constexpr int CS_HALT_HOOK = 3;      // rank pool: rank_loop_kernel parked the list after a pass the hook has to look at (cs_replace_pool_kernel)
 struct CsFrame {
     int halt;
     int saved_done;                  // LoopState::done as the pass left it
@@ -196,6 +198,9 @@ struct CsFrame {
 };
 hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, LoopState *st, const PhotonDev &ph,
                              CsFrame *frame, int resume, hipStream_t stream);
+// the hook for every parked list of a rank pool (one workgroup per list; a list out of null slots doubles inside its window of the pool)
+hipError_t launch_cs_replace_pool(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, LoopState *states, const PhotonDev &pool, int stride,
+                                  int n_ranks, RankDesc *desc, CsFrame *frames, hipStream_t stream);
 // the list's null slots in ascending order (addToPhotonList's null_ph_indexes, photons.c:181-189): count per 256 slots, then write
 hipError_t launch_null_count(const PhotonDev &ph, unsigned *block_count, unsigned long long *d_total, hipStream_t stream);
 hipError_t launch_null_write(const PhotonDev &ph, const int *block_start, int *null_slots, hipStream_t stream);

@@ -161,6 +161,13 @@ class RankSummary(C.Structure):
                 ("max_scatt", C.c_int), ("min_scatt", C.c_int), ("num_output", C.c_int), ("list_capacity", C.c_int)]
 
 
+class PoolCsList(C.Structure):
+    """mcrat_hip_pool_cs_list: one list's arguments of a cyclo-synchrotron scatter frame of a rank pool"""
+    _fields_ = [("open", C.c_int), ("emit_pool", C.c_int), ("scatt_frame_number", C.c_int), ("inj_frame_number", C.c_int), ("seed", C.c_uint64),
+                ("time_now", C.c_double), ("remaining_time", C.c_double), ("r_inj", C.c_double), ("ph_weight_suggest", C.c_double),
+                ("theta_min", C.c_double), ("theta_max", C.c_double)]
+
+
 SCIENCE, CYLINDRICAL_OUTFLOW, SPHERICAL_OUTFLOW, STRUCTURED_SPHERICAL_OUTFLOW = 0, 1, 2, 3    # SIMULATION_TYPE, mcrat.h:30-33
 
 # every symbol include/mcrat_hip.h declares: (restype, argtypes)
@@ -211,6 +218,8 @@ SYMBOLS = {
     "mcrat_hip_pool_create": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "mcrat_hip_pool_rank": (C.c_int, [_ctx, C.c_int, C.c_uint32, C.POINTER(_ctx)]),
     "mcrat_hip_pool_summaries": (C.c_int, [_ctx, C.POINTER(RankSummary)]),
+    "mcrat_hip_pool_scatter_frames_cyclosynch": (C.c_int, [_ctx, C.POINTER(Cyclosynch), C.c_int, C.c_double, C.POINTER(PoolCsList), C.POINTER(FrameStats),
+                                                           C.POINTER(CyclosynchCounts)]),
     "mcrat_hip_pool_begin_frames": (C.c_int, [_ctx, _ip, C.POINTER(C.c_uint64), _dp, _dp]),
     "mcrat_hip_pool_frame_stats": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_pool_layout": (C.c_int, [_ctx, _ip, _ip]),
@@ -317,6 +326,23 @@ class Engine:
         if getattr(self, "num_elements", None) is not None:
             v.num_elements = self.num_elements
         return v
+
+    def pool_scatter_frames_cyclosynch(self, lists, max_photons, fps, b_field_calc=1, epsilon_b=0.5, rebin_e_perc=0.1, rebin_ang=0.5, rebin_ang_phi=10.0):
+        """lists: one dict per list (None: the list sits the frame out) with seed, time_now, remaining_time, r_inj, ph_weight_suggest, theta_min,
+        theta_max, emit_pool, scatt_frame_number, inj_frame_number -> ([FrameStats], [CyclosynchCounts])"""
+        R = self.n_pool_ranks
+        arr = (PoolCsList * R)()
+        for r, d in enumerate(lists):
+            if d is None:
+                continue
+            arr[r] = PoolCsList(1, int(d.get("emit_pool", 1)), int(d.get("scatt_frame_number", 0)), int(d.get("inj_frame_number", 0)), int(d["seed"]),
+                                float(d["time_now"]), float(d["remaining_time"]), float(d["r_inj"]), float(d["ph_weight_suggest"]), float(d["theta_min"]),
+                                float(d["theta_max"]))
+        cs = Cyclosynch(int(b_field_calc), float(epsilon_b), float(rebin_e_perc), float(rebin_ang), float(rebin_ang_phi), 0, 0)
+        st, cnt = (FrameStats * R)(), (CyclosynchCounts * R)()
+        self._check(self.lib.mcrat_hip_pool_scatter_frames_cyclosynch(self.ctx, C.byref(cs), int(max_photons), float(fps), arr, st, cnt),
+                    "pool_scatter_frames_cyclosynch")
+        return list(st), list(cnt)
 
     def pool_summaries(self):
         out = (RankSummary * self.n_pool_ranks)()

@@ -1,0 +1,152 @@
+"""CYCLOSYNCHROTRON_SWITCH on inside the rank pool (mcrat_hip_pool_scatter_frames_cyclosynch): several lists of one pool go through the
+scatter frame of mcrat.c:706-878 in the same launches -- pool emission, the loop in which a scattered pool photon becomes a comptonised
+one and is replaced (the list doubling inside its window of the pool), the rebinning trigger, rebinning and absorption -- and every
+list must come out as orc_scatter_frame_cs leaves it when run on that list alone: same passes, scatterings, counters, list length,
+types, slots and weights; doubles to 1e-9."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mcrat_amd import engine
+    engine.load_library()
+    return engine
+
+
+def _oracle_frame(oracle, cfg, frame, dens, B, before, seed, stream, remaining, max_photons, theta_max, emit_pool, b_field_calc, ang_phi):
+    L = oracle.lib()
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 1)
+    H = oracle.OracleHydro(frame)
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+    cs = oracle.CS(b_field_calc, 0.5, 0.1, ptr(dens), ptr(B[0]), ptr(B[1]), ptr(B[2]), 200, 200, 0.5, ang_phi)
+    l = oracle.PhotonList()
+    L.orc_list_init(C.byref(l))
+    # as tests/test_gpu_cyclosynch.py builds its list: every slot a photon first (setPhotonList counts all of them in num_photons), then the
+    # null slots by setNullPhoton, so that the list's counters are consistent (verifyPhotonNum)
+    nulls = np.flatnonzero(before["type"] == b"N")
+    full = before.copy()
+    full[nulls] = before[0]
+    assert L.orc_list_set(C.byref(l), full.ctypes.data, len(full)) == 0
+    for i in nulls:
+        assert L.orc_list_set_null(C.byref(l), int(i)) == 0
+    rng = oracle.Rng()
+    L.orc_rng_init(C.byref(rng), seed, stream)
+    st, cnt, t = oracle.Stats(), oracle.CSCounts(), C.c_double(0.0)
+    L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), remaining, 1e12, 1e40, max_photons, 0.0, theta_max,
+                           emit_pool, 0, C.byref(st), C.byref(cnt))
+    assert cnt.error == 0
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    want = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    L.orc_list_free(C.byref(l))
+    return want, st, cnt, t.value
+
+
+def _start_list(oracle, ph, shift):
+    """300 photons + 300 null slots, as tests/test_gpu_cyclosynch.py sets its lists up; `shift` rotates the photons so that the lists differ"""
+    aos = np.roll(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE), shift)
+    L = oracle.lib()
+    l = oracle.PhotonList()
+    L.orc_list_init(C.byref(l))
+    both = np.concatenate([aos, aos])
+    assert L.orc_list_set(C.byref(l), both.ctypes.data, len(both)) == 0
+    for i in range(300, 600):
+        assert L.orc_list_set_null(C.byref(l), i) == 0
+    buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+    before = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
+    L.orc_list_free(C.byref(l))
+    return before
+
+
+POOLS = {
+    # mesh, B_FIELD_CALC, max_photons, theta_max, rebin_ang_phi, per list: (seed, remaining_time, emit_pool)
+    "2d-rebinning-lists": ("2d", 1, 200, 0.05, 10.0, [(31, 3.0, 1), (32, 1.0, 1), (33, 0.7, 0), None, (35, 0.05, 1)]),
+    "3d-growing-lists": ("3d", 1, 2000, 0.06, 45.0, [(31, 0.2, 1), (41, 0.2, 1), (42, 0.1, 0)]),
+    # BASELINE.json configs[4]'s switches at test size: THREE / SPHERICAL, B_FIELD_CALC == SIMULATION, STOKES on
+    "3d-spherical-simulation-field": ("3ds", 2, 2000, 0.2, 45.0, [(31, 0.2, 1), (51, 0.15, 1)]),
+}
+
+
+@pytest.mark.parametrize("case", sorted(POOLS))
+def test_pool_lists_with_the_switch_on_match_the_oracle_list_by_list(hip, oracle, case):
+    mesh, b_field_calc, max_photons, theta_max, ang_phi, lists = POOLS[case]
+    if mesh == "2d":
+        frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
+    elif mesh == "3d":
+        frame, ph, cfg = synth.config_3d_cartesian(n_photons=300, n=(8, 8, 8))
+    else:
+        frame, ph, cfg = synth.config_3d(synth.SPHERICAL, n_photons=300)
+    dens = np.ascontiguousarray(frame["dens"])
+    B = [None, None, None]
+    if b_field_calc == 2:
+        g = np.random.default_rng(5)
+        B = [np.ascontiguousarray(g.uniform(1e3, 1e5, frame["num_elements"])) for _ in range(3)]
+    R = len(lists)
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+    pool.set_hydro(frame)
+    pool.set_hydro_extras(dens, *B)
+    pool.pool_create(R, 4800)                              # 600 slots to start with, room for three doublings
+    starts, args = [], []
+    for r, spec in enumerate(lists):
+        if spec is None:
+            starts.append(None); args.append(None)
+            continue
+        seed, remaining, emit_pool = spec
+        before = _start_list(oracle, ph, 7 * r)
+        starts.append(before)
+        pool.pool_rank(r, r).set_photons_aos(before.astype(hip.PHOTON_DTYPE))
+        args.append(dict(seed=seed, time_now=0.0, remaining_time=remaining, r_inj=1e12, ph_weight_suggest=1e40, theta_min=0.0, theta_max=theta_max,
+                         emit_pool=emit_pool, scatt_frame_number=200, inj_frame_number=200))
+    with pytest.raises(hip.McratHipError):
+        pool.run(0)                                        # the plain loop has no hook: refused with the switch on
+    sts, cnts = pool.pool_scatter_frames_cyclosynch(args, max_photons, frame["fps"], b_field_calc=b_field_calc, rebin_ang_phi=ang_phi)
+    grew = rebinned = 0
+    for r, spec in enumerate(lists):
+        if spec is None:
+            assert cnts[r].num_cyclosynch_ph_emit == 0 and sts[r].iterations == 0
+            continue
+        seed, remaining, emit_pool = spec
+        want, st, cnt, t = _oracle_frame(oracle, cfg, frame, dens, B, starts[r], seed, r, remaining, max_photons, theta_max, emit_pool, b_field_calc, ang_phi)
+        g, gc = sts[r], cnts[r]
+        assert (g.iterations, g.frame_scatt_cnt, g.kn_rejections) == (st.iterations, st.frame_scatt_cnt, st.kn_rejections), (case, r)
+        assert (gc.num_cyclosynch_ph_emit, gc.scatt_cyclosynch_num_ph, gc.frame_abs_cnt, gc.rebins) == \
+            (cnt.num_cyclosynch_ph_emit, cnt.scatt_cyclosynch_num_ph, cnt.frame_abs_cnt, cnt.rebins), (case, r)
+        assert gc.pool_weight == cnt.pool_weight and gc.n_comptonized == pytest.approx(cnt.n_comptonized, rel=1e-12)
+        assert g.time_now == pytest.approx(t, rel=1e-12) and g.remaining_time == 0.0
+        got = pool.pool_rank(r, r).get_photons_aos()
+        assert len(got) == len(want), (case, r)
+        assert np.array_equal(got["type"], want["type"])
+        for f in ("weight", "num_scatt", "nearest_block_index", "recalc_properties"):
+            assert np.array_equal(got[f], want[f]), (r, f)
+        for f in ("p0", "p1", "p2", "p3", "comv_p0", "comv_p1", "comv_p2", "comv_p3", "r0", "r1", "r2", "s0", "s1", "s2", "s3"):
+            scale = np.maximum(np.abs(want["p0"]), 1e-300) if f.startswith("p") else (
+                np.maximum(np.abs(want["comv_p0"]), 1e-300) if f.startswith("comv") else (np.maximum(np.abs(want[f]), 1e9) if f.startswith("r") else 1.0))
+            err = np.abs(got[f] - want[f]) / scale
+            assert np.all(err <= 1e-9), (r, f, float(err.max()), int(err.argmax()))
+        grew += len(want) > 600
+        rebinned += cnt.rebins
+        assert st.frame_scatt_cnt > (100 if remaining >= 0.1 else 0)
+    assert grew >= 1                                        # at least one list doubled inside the loop, in its window of the pool
+    if case == "2d-rebinning-lists":
+        assert rebinned >= 1                                # ... and the rebinning trigger parked a list for the host at least once
+    pool.close()
+
+
+def test_a_pool_too_small_for_the_doublings_says_so(hip, oracle):
+    frame, ph, cfg = synth.config_3d_cartesian(n_photons=300, n=(8, 8, 8))
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+    pool.set_hydro(frame)
+    pool.set_hydro_extras(np.ascontiguousarray(frame["dens"]), None, None, None)
+    pool.pool_create(1, 1000)                              # 1024 slots: one doubling of 600 does not fit
+    pool.pool_rank(0, 0).set_photons_aos(_start_list(oracle, ph, 0).astype(hip.PHOTON_DTYPE))
+    with pytest.raises(hip.McratHipError, match="slots per rank|doubl"):
+        pool.pool_scatter_frames_cyclosynch([dict(seed=31, time_now=0.0, remaining_time=0.2, r_inj=1e12, ph_weight_suggest=1e40, theta_min=0.0,
+                                                  theta_max=0.06, emit_pool=1, scatt_frame_number=200, inj_frame_number=200)], 2000, frame["fps"],
+                                            rebin_ang_phi=45.0)
+    pool.close()
