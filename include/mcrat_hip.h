@@ -346,7 +346,9 @@ int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *c
  *                                cyclosynchrotron_switch = 1 (one list per context: no virtual ranks, no shared clock; mcrat_hip_run
  *                                and mcrat_hip_propagate_frame refuse such a context).  max_iterations <= 0: until the frame is over. */
 typedef struct mcrat_hip_cyclosynch_counts {
-    int    num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph, frame_abs_cnt;   /* the counters of mcrat.c:735-878 */
+    int    num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph, frame_abs_cnt;   /* the counters of mcrat.c:735-878.  scatt_cyclosynch_num_ph is IN/OUT:
+                                             main() carries it from one scatter frame of an injection to the next (set at mcrat.c:873, reset at
+                                             :921) -- pass the previous frame's value in (0 for the first frame; zero the struct before use) */
     int    rebins;                        /* successful rebinCyclosynchCompPhotons calls */
     int    integrals_not_converged;       /* see mcrat_hip_emit_cyclosynch_pool */
     int    pad;

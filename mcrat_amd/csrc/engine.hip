@@ -2303,6 +2303,7 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
     if (!c->cfg.cyclosynchrotron_switch) { c->last_error = "the context was created with cyclosynchrotron_switch = 0"; return MCRAT_HIP_ESTATE; }
     if (c->n_ranks > 0 || c->sc_world > 0) return MCRAT_HIP_ESTATE;
     if (!c->have_hydro || !c->hcol_buf || !c->have_photons) return MCRAT_HIP_ESTATE;
+    const int carried = cnt->scatt_cyclosynch_num_ph;        // main()'s counter lives across the scatter frames of an injection (mcrat.c:873,921)
     memset(cnt, 0, sizeof *cnt);
     int rc;
     if (emit_pool) {                                                                              // :727-744
@@ -2321,6 +2322,7 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
     CsFrame cf{};
     cf.max_photons = max_photons;
     cf.last_iteration = ~0ull;
+    cf.scatt_num = carried;
     HIPCHK(c, hipMemcpyAsync(d_cf, &cf, sizeof cf, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));                                                  // cf is on the stack
     const int emit_pool_count = cnt->num_cyclosynch_ph_emit;
@@ -2420,7 +2422,9 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
     std::vector<uint64_t> seeds((size_t)R, 0);
     std::vector<double> t_now((size_t)R, 0.0), t_rem((size_t)R, 0.0);
     std::vector<mcrat_hip_cyclosynch> csr((size_t)R, *cs);
+    std::vector<int> carried((size_t)R, 0);
     for (int r = 0; r < R; ++r) {
+        carried[(size_t)r] = counts[r].scatt_cyclosynch_num_ph;      // in: the counter main() carries from the previous frame (mcrat.c:873,921)
         memset(&counts[r], 0, sizeof counts[r]);
         if (!lists[r].open) continue;
         mcrat_hip_ctx *v = c->views[r];
@@ -2449,7 +2453,10 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
     HIPCHK(c, hipMalloc((void **)&c->d_cs_hook, sizeof(CsFrame) * (size_t)R));
     CsFrame *d_cf = static_cast<CsFrame *>(c->d_cs_hook);
     std::vector<CsFrame> cf((size_t)R);
-    for (int r = 0; r < R; ++r) { cf[(size_t)r] = CsFrame{}; cf[(size_t)r].max_photons = max_photons; cf[(size_t)r].last_iteration = ~0ull; }
+    for (int r = 0; r < R; ++r) {
+        cf[(size_t)r] = CsFrame{};
+        cf[(size_t)r].max_photons = max_photons; cf[(size_t)r].last_iteration = ~0ull; cf[(size_t)r].scatt_num = carried[(size_t)r];
+    }
     HIPCHK(c, hipMemcpyAsync(d_cf, cf.data(), sizeof(CsFrame) * (size_t)R, hipMemcpyHostToDevice, c->stream));
     if ((rc = pool_describe(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));

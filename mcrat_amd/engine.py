@@ -340,6 +340,9 @@ class Engine:
                                 float(d["theta_max"]))
         cs = Cyclosynch(int(b_field_calc), float(epsilon_b), float(rebin_e_perc), float(rebin_ang), float(rebin_ang_phi), 0, 0)
         st, cnt = (FrameStats * R)(), (CyclosynchCounts * R)()
+        for r, d in enumerate(lists):
+            if d is not None:
+                cnt[r].scatt_cyclosynch_num_ph = int(d.get("scatt_cyclosynch_num_ph", 0))
         self._check(self.lib.mcrat_hip_pool_scatter_frames_cyclosynch(self.ctx, C.byref(cs), int(max_photons), float(fps), arr, st, cnt),
                     "pool_scatter_frames_cyclosynch")
         return list(st), list(cnt)
@@ -466,11 +469,12 @@ class Engine:
 
     def scatter_frame_cyclosynch(self, time_now, remaining_time, seed, r_inj, ph_weight_suggest, max_photons, theta_min, theta_max, fps, emit_pool=1,
                                  max_iterations=0, b_field_calc=1, epsilon_b=0.5, rebin_e_perc=0.1, rebin_ang=0.5, rebin_ang_phi=10.0,
-                                 scatt_frame_number=0, inj_frame_number=0):
+                                 scatt_frame_number=0, inj_frame_number=0, scatt_cyclosynch_num_ph=0):
         """main()'s scatter-frame body with CYCLOSYNCHROTRON_SWITCH on (mcrat.c:706-878) -> (time_now, FrameStats, CyclosynchCounts)"""
         cs = Cyclosynch(int(b_field_calc), float(epsilon_b), float(rebin_e_perc), float(rebin_ang), float(rebin_ang_phi), int(scatt_frame_number),
                         int(inj_frame_number))
         st, cnt, tn = FrameStats(), CyclosynchCounts(), C.c_double(time_now)
+        cnt.scatt_cyclosynch_num_ph = int(scatt_cyclosynch_num_ph)       # main()'s counter, carried from the previous frame
         self._check(self.lib.mcrat_hip_scatter_frame_cyclosynch(self.ctx, C.byref(cs), C.byref(tn), float(remaining_time), int(seed), float(r_inj),
                                                                 float(ph_weight_suggest), int(max_photons), float(theta_min), float(theta_max), float(fps),
                                                                 int(emit_pool), int(max_iterations), C.byref(st), C.byref(cnt)),

@@ -317,6 +317,7 @@ typedef struct orc_cs_counts {          /* main()'s cyclo-synchrotron counters f
 void   orc_scatter_frame_cs(const orc_config *c, orc_cs *cs, orc_photon_list *l, const orc_hydro *h, orc_rng *rng, double *time_now,
                             double remaining_time, double r_inj, double ph_weight_suggest, int max_photons, double theta_jmin_thread,
                             double theta_jmax_thread, int emit_pool, long long max_iterations, orc_stats *st, orc_cs_counts *cnt);   /* mcrat.c:706-878 */
+int    orc_saveCheckpoint_convert(orc_photon_list *l);                            /* mcrat_io.c:896-900: 'k' with weight -> 'c' */
 double orc_phAbsCyclosynch(const orc_config *c, const orc_cs *cs, orc_photon_list *l, const orc_hydro *h, int *num_abs_ph,
                            int *scatt_cyclosynch_num_ph);                        /* :1571 */
 

@@ -569,11 +569,26 @@ int orc_rebinCyclosynchCompPhotons(const orc_config *c, const orc_cs *cs, orc_ph
  * Reference behaviour kept: the photon photonEvent reports (:781,:786) is turned from a pool photon into a comptonised one and
  * replaced even when every candidate of the pass was Klein-Nishina-rejected, because *scattered_ph_index then names the last
  * candidate tried (mclib.c:1128,1337-1355). */
+/* saveCheckpoint's in-place conversion with the switch on (mcrat_io.c:896-900, :951-955, :991-995): every comptonised photon with weight
+ * becomes an unabsorbed one before its record is written -- and stays so for printPhotons (mcrat.c:907) and the next frame.  Returns the
+ * number converted. */
+int orc_saveCheckpoint_convert(orc_photon_list *l)
+{
+    int n = 0;
+    for (int i = 0; i < l->list_capacity; i++)
+        if (l->photons[i].type == ORC_COMPTONIZED_PHOTON && l->photons[i].weight != 0) { l->photons[i].type = ORC_UNABSORBED_CS_PHOTON; n++; }
+    return n;
+}
+
 void orc_scatter_frame_cs(const orc_config *c, orc_cs *cs, orc_photon_list *l, const orc_hydro *h, orc_rng *rng, double *time_now,
                           double remaining_time, double r_inj, double ph_weight_suggest, int max_photons, double theta_jmin_thread,
                           double theta_jmax_thread, int emit_pool, long long max_iterations, orc_stats *st, orc_cs_counts *cnt)
 {
+    /* scatt_cyclosynch_num_ph is main()'s own counter: it lives from one scatter frame of an injection to the next (set at :873 by
+     * phAbsCyclosynch or the rebinning, reset at :921 only) -- the caller hands the previous frame's value in through cnt */
+    const int carried = cnt->scatt_cyclosynch_num_ph;
     memset(cnt, 0, sizeof *cnt);
+    cnt->scatt_cyclosynch_num_ph = carried;
     if (emit_pool) {                                                                      /* :727-744 */
         const int n = orc_photonEmitCyclosynch(c, cs, l, r_inj, ph_weight_suggest, max_photons, theta_jmin_thread, theta_jmax_thread, h, rng, 0, 0,
                                                &cnt->pool_weight, NULL);

@@ -225,6 +225,7 @@ def lib():
             "orc_qags": (i, [C.c_void_p, p, d, d, d, d, i, _dp, _dp, C.POINTER(i)]),
             "orc_photonEmitCyclosynch": (i, [cfgp, C.POINTER(CS), lp, d, d, i, d, d, hp, rp, i, i, _dp, C.POINTER(i)]),
             "orc_phAbsCyclosynch": (d, [cfgp, C.POINTER(CS), lp, hp, C.POINTER(i), C.POINTER(i)]),
+            "orc_saveCheckpoint_convert": (i, [lp]),
             "orc_scatter_frame_cs": (None, [cfgp, C.POINTER(CS), lp, hp, rp, _dp, d, d, d, i, d, d, i, C.c_longlong, sp, C.POINTER(CSCounts)]),
             "orc_rebinCyclosynchCompPhotons": (i, [cfgp, C.POINTER(CS), lp, C.POINTER(i), C.POINTER(i), i]),
             "orc_table_misses": (C.c_longlong, []),

@@ -150,3 +150,86 @@ def test_a_pool_too_small_for_the_doublings_says_so(hip, oracle):
                                                   theta_max=0.06, emit_pool=1, scatt_frame_number=200, inj_frame_number=200)], 2000, frame["fps"],
                                             rebin_ang_phi=45.0)
     pool.close()
+
+
+@pytest.mark.parametrize("shape", ["one-list-context", "pool-views"])
+def test_two_frames_with_the_checkpoint_conversion_between_them(hip, oracle, shape):
+    """emit -> loop -> rebin/absorb -> saveCheckpoint (every live comptonised photon 'k' becomes an unabsorbed one 'c' in the list,
+    mcrat_io.c:896-900) -> printPhotons' PT column -> the next frame, whose absorption counts those 'c' photons (mc_cyclosynch.c:1607) and
+    whose rebinning trigger starts from the counter main() carries over (mcrat.c:873): against the oracle doing the same two frames"""
+    frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
+    dens = np.ascontiguousarray(frame["dens"])
+    L = oracle.lib()
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], 1)
+    H = oracle.OracleHydro(frame)
+    max_photons, theta_max = 2000, 0.05
+    lists = {"one-list-context": [(31, 0)], "pool-views": [(31, 0), (77, 1)]}[shape]
+
+    def oracle_two_frames(before, seed, stream):
+        cs = oracle.CS(1, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, 200, 200, 0.5, 10.0)
+        l = oracle.PhotonList()
+        L.orc_list_init(C.byref(l))
+        nulls = np.flatnonzero(before["type"] == b"N")
+        full = before.copy()
+        full[nulls] = before[0]
+        assert L.orc_list_set(C.byref(l), full.ctypes.data, len(full)) == 0
+        for i in nulls:
+            assert L.orc_list_set_null(C.byref(l), int(i)) == 0
+        out, t, carry = [], C.c_double(0.0), 0
+        for k, rem in enumerate((0.1, 0.1)):
+            rng = oracle.Rng()
+            L.orc_rng_init(C.byref(rng), seed + k, stream)
+            st, cnt = oracle.Stats(), oracle.CSCounts()
+            cnt.scatt_cyclosynch_num_ph = carry
+            L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), rem, 1e12, 1e40, max_photons, 0.0, theta_max,
+                                   1, 0, C.byref(st), C.byref(cnt))
+            assert cnt.error == 0
+            converted = L.orc_saveCheckpoint_convert(C.byref(l))
+            carry = cnt.scatt_cyclosynch_num_ph
+            buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
+            out.append((np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy(), st.frame_scatt_cnt, cnt.frame_abs_cnt, cnt.scatt_cyclosynch_num_ph,
+                        cnt.num_cyclosynch_ph_emit, converted, t.value))
+        L.orc_list_free(C.byref(l))
+        return out
+    starts = [_start_list(oracle, ph, 11 * r) for r in range(len(lists))]
+    wants = [oracle_two_frames(starts[r], seed, stream) for r, (seed, stream) in enumerate(lists)]
+    assert wants[0][0][5] > 0 and wants[0][1][2] > 0              # the first frame leaves 'k' photons to convert; the second absorbs
+
+    if shape == "one-list-context":
+        e = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+        e.set_hydro(frame)
+        e.set_hydro_extras(dens, None, None, None)
+        e.set_photons_aos(starts[0].astype(hip.PHOTON_DTYPE))
+        views = [e]
+    else:
+        e = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+        e.set_hydro(frame)
+        e.set_hydro_extras(dens, None, None, None)
+        e.pool_create(len(lists), 4800)
+        views = [e.pool_rank(r, stream) for r, (seed, stream) in enumerate(lists)]
+        for r, v in enumerate(views):
+            v.set_photons_aos(starts[r].astype(hip.PHOTON_DTYPE))
+    t, carry = [0.0] * len(lists), [0] * len(lists)
+    for k, rem in enumerate((0.1, 0.1)):
+        if shape == "one-list-context":
+            tn, st, cnt = e.scatter_frame_cyclosynch(t[0], rem, lists[0][0] + k, 1e12, 1e40, max_photons, 0.0, theta_max, frame["fps"], emit_pool=1,
+                                                     scatt_frame_number=200, inj_frame_number=200, scatt_cyclosynch_num_ph=carry[0])
+            sts, cnts = [st], [cnt]
+        else:
+            args = [dict(seed=seed + k, time_now=t[r], remaining_time=rem, r_inj=1e12, ph_weight_suggest=1e40, theta_min=0.0, theta_max=theta_max, emit_pool=1,
+                         scatt_frame_number=200, inj_frame_number=200, scatt_cyclosynch_num_ph=carry[r]) for r, (seed, stream) in enumerate(lists)]
+            sts, cnts = e.pool_scatter_frames_cyclosynch(args, max_photons, frame["fps"])
+        for r, v in enumerate(views):
+            want, scatt, absd, carry_w, emit_w, conv_w, t_w = wants[r][k]
+            assert (sts[r].frame_scatt_cnt, cnts[r].frame_abs_cnt, cnts[r].scatt_cyclosynch_num_ph, cnts[r].num_cyclosynch_ph_emit) == (scatt, absd, carry_w, emit_w), (k, r)
+            assert v.convert_comptonized() == conv_w                                   # what saveCheckpoint does to the list
+            v.n = int(v.lib.mcrat_hip_num_photon_slots(v.ctx))
+            got = v.get_photons_aos()
+            assert len(got) == len(want) and np.array_equal(got["type"], want["type"]), (k, r)
+            assert np.array_equal(got["weight"], want["weight"]) and np.array_equal(got["num_scatt"], want["num_scatt"])
+            out = v.get_output()                                                        # printPhotons' PT after the checkpoint (mcrat.c:902-907)
+            assert np.array_equal(out["type"], want["type"][want["weight"] != 0])
+            assert b"k" not in set(out["type"].tolist()) and (k == 0 or b"c" in set(out["type"].tolist()))
+            t[r], carry[r] = sts[r].time_now, cnts[r].scatt_cyclosynch_num_ph
+            assert t[r] == pytest.approx(t_w, rel=1e-12)
+    e.close()
