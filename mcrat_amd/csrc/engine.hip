@@ -1435,7 +1435,7 @@ extern "C" int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *c, const mcrat_hip_
     const double max_photons = cs->rebin_e_perc * maximum_photons;
     double weight = ph_weight;
     unsigned long long total = 0;
-    unsigned flags[2] = {0, 0};
+    unsigned flags[2] = {0, 0}, cells_in_shell = 0;
     bool ok = false;
     for (unsigned long long attempt = 0; attempt <= 400 && !ok; ++attempt) {
         if (hipMemsetAsync(d_flags, 0, 2 * sizeof(unsigned), c->stream) != hipSuccess) return fail(MCRAT_HIP_EHIP);
@@ -1443,7 +1443,8 @@ extern "C" int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *c, const mcrat_hip_
             hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { c->last_error = "cyclo-synchrotron emission: count pass failed"; return fail(MCRAT_HIP_EHIP); }
-        const int min_photons = flags[1] ? 1 : 0;                                   // no cell in the shell: nothing to emit (:1236-1239)
+        if (attempt == 0) cells_in_shell = flags[1];                                // (the kernel counts them on its first pass only)
+        const int min_photons = cells_in_shell ? 1 : 0;                             // no cell in the shell: nothing to emit (:1236-1239)
         if ((double)total > max_photons) weight *= 10;
         else if ((long long)total < min_photons) weight *= 0.5;
         else ok = true;

@@ -23,7 +23,8 @@ class HostRank(C.Structure):
                 ("restrt", C.c_char), ("scatt_framestart", C.c_int), ("time_now_start", C.c_double), ("restart_list", C.POINTER(engine.PhotonList)),
                 ("view", C.c_void_p), ("frame", C.c_int), ("scatt_frame", C.c_int), ("time_now", C.c_double),
                 ("num_photons", C.c_int), ("ph_weight", C.c_double), ("seeds_drawn", C.c_longlong),
-                ("frame_scatt_cnt_total", C.c_longlong), ("state", C.c_int)]
+                ("frame_scatt_cnt_total", C.c_longlong), ("scatt_cyclosynch_num_ph", C.c_int), ("first_scatt_frame", C.c_int),
+                ("cyclosynch_emitted_total", C.c_longlong), ("cyclosynch_absorbed_total", C.c_longlong), ("state", C.c_int)]
 
 
 GET_HYDRO = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(engine.Slab))
@@ -36,7 +37,7 @@ class PoolConfig(C.Structure):
                 ("spect", C.c_char), ("min_photons", C.c_int), ("max_photons", C.c_int), ("slots_per_rank", C.c_int),
                 ("get_hydro", GET_HYDRO), ("user", C.c_void_p), ("write_checkpoints", C.c_int),
                 ("print_photons", C.c_void_p), ("comv_switch", C.c_int), ("stokes_switch", C.c_int), ("save_type", C.c_int),
-                ("max_frames", C.c_int),
+                ("max_frames", C.c_int), ("cyclosynchrotron_switch", C.c_int), ("cs", engine.Cyclosynch),
                 ("hydro_frames_read", C.c_longlong), ("launches", C.c_longlong),
                 ("ms_propagate", C.c_double), ("ms_hydro", C.c_double), ("ms_output", C.c_double)]
 

@@ -502,6 +502,8 @@ int mcrat_host_split_ranks(const mcrat_host_mcpar *par, int numprocs, int first_
     return 0;
 }
 
+#define MCRAT_C_LIGHT 2.99792458e10       /* C_LIGHT, Src/mclib.c:4 */
+
 static double wall_ms(void)
 {
     struct timespec t;
@@ -521,13 +523,15 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     int *open = (int *)calloc((size_t)n_ranks, sizeof(int));
     uint64_t *seeds = (uint64_t *)calloc((size_t)n_ranks, sizeof(uint64_t));
     double *t_now = (double *)calloc((size_t)n_ranks, sizeof(double)), *t_rem = (double *)calloc((size_t)n_ranks, sizeof(double));
+    mcrat_hip_pool_cs_list *cs_lists = (mcrat_hip_pool_cs_list *)calloc((size_t)n_ranks, sizeof *cs_lists);
+    mcrat_hip_cyclosynch_counts *cs_counts = (mcrat_hip_cyclosynch_counts *)calloc((size_t)n_ranks, sizeof *cs_counts);
     mcrat_hip_photon *rec_buf = NULL;
     double *out_buf = NULL;
     char *out_type = NULL;
     size_t out_cap = 0;
     int stride = 0;
-    if (!summ || !stats || !open || !seeds || !t_now || !t_rem || mcrat_hip_pool_layout(pool, NULL, &stride) != 0) {
-        free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem);
+    if (!summ || !stats || !open || !seeds || !t_now || !t_rem || !cs_lists || !cs_counts || mcrat_hip_pool_layout(pool, NULL, &stride) != 0) {
+        free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
         return MCRAT_HIP_ENOMEM;
     }
     cfg->hydro_frames_read = cfg->launches = 0;
@@ -593,11 +597,14 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 if (rc) break;
                 k->state = 1;
                 k->scatt_frame = F;                                                               /* scatt_framestart = frame, :660 */
+                k->first_scatt_frame = F;
+                k->scatt_cyclosynch_num_ph = 0;                                                   /* :921 */
             }
             if (rc) break;
             int n_active = 0;
             for (int r = 0; r < n_ranks; r++) {
-                if (ranks[r].state == 4 && ranks[r].scatt_frame == F) ranks[r].state = 1;        /* a restarted rank picks up at its scatt_framestart */
+                if (ranks[r].state == 4 && ranks[r].scatt_frame == F) { ranks[r].state = 1; ranks[r].first_scatt_frame = -1; }   /* a restarted rank picks up at
+                                                                                                     its scatt_framestart; restrt == CONTINUE emits (:707) */
                 n_active += ranks[r].state == 1;
             }
             if (!n_active) continue;
@@ -612,6 +619,12 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 if (summ[r].min_theta < slab.min_theta) slab.min_theta = summ[r].min_theta;
                 if (summ[r].max_theta > slab.max_theta) slab.max_theta = summ[r].max_theta;
                 slab.r_inj = ranks[r].inj_radius;
+                if (cfg->cyclosynchrotron_switch && F != ranks[r].first_scatt_frame) {           /* calcCyclosynchRLimits, mcrat.c:708-720 */
+                    const double lo = ranks[r].inj_radius + (MCRAT_C_LIGHT * (F - ranks[r].frame) / cfg->fps - 0.5 * MCRAT_C_LIGHT / cfg->fps);
+                    const double hi = ranks[r].inj_radius + (MCRAT_C_LIGHT * (F - ranks[r].frame) / cfg->fps + 0.5 * MCRAT_C_LIGHT / cfg->fps);
+                    if (lo < slab.min_r) slab.min_r = lo;
+                    if (hi > slab.max_r) slab.max_r = hi;
+                }
             }
             {
                 const double t0 = wall_ms();
@@ -635,12 +648,37 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 t_now[r] = k->time_now;
                 t_rem[r] = ((F + 1) / cfg->fps) - k->time_now;
             }
-            if ((rc = mcrat_hip_pool_begin_frames(pool, open, seeds, t_now, t_rem))) break;      /* every list's begin_frame, one launch */
-            mcrat_hip_frame_stats tot;
-            if ((rc = mcrat_hip_run(pool, 0, &tot))) break;                                       /* mcrat.c:761-851 for every list */
+            if (!cfg->cyclosynchrotron_switch) {
+                if ((rc = mcrat_hip_pool_begin_frames(pool, open, seeds, t_now, t_rem))) break;  /* every list's begin_frame, one launch */
+                mcrat_hip_frame_stats tot;
+                if ((rc = mcrat_hip_run(pool, 0, &tot))) break;                                   /* mcrat.c:761-851 for every list */
+                if ((rc = mcrat_hip_pool_frame_stats(pool, stats))) break;
+            } else {                                                                              /* mcrat.c:706-878 for every list */
+                for (int r = 0; r < n_ranks; r++) {
+                    mcrat_host_rank *k = &ranks[r];
+                    memset(&cs_lists[r], 0, sizeof cs_lists[r]);
+                    memset(&cs_counts[r], 0, sizeof cs_counts[r]);
+                    if (!open[r]) continue;
+                    cs_lists[r].open = 1;
+                    cs_lists[r].emit_pool = F != k->first_scatt_frame;                            /* (scatt_frame != scatt_framestart) || CONTINUE, :707 */
+                    cs_lists[r].scatt_frame_number = F; cs_lists[r].inj_frame_number = k->frame;
+                    cs_lists[r].seed = seeds[r]; cs_lists[r].time_now = t_now[r]; cs_lists[r].remaining_time = t_rem[r];
+                    cs_lists[r].r_inj = k->inj_radius; cs_lists[r].ph_weight_suggest = k->ph_weight_suggest;
+                    cs_lists[r].theta_min = k->theta_jmin_thread; cs_lists[r].theta_max = k->theta_jmax_thread;
+                    cs_counts[r].scatt_cyclosynch_num_ph = k->scatt_cyclosynch_num_ph;
+                    if (cs_lists[r].emit_pool && k->fPtr) fprintf(k->fPtr, "Emitting Cyclosynchrotron Photons in frame %d\n", F);
+                }
+                if ((rc = mcrat_hip_pool_scatter_frames_cyclosynch(pool, &cfg->cs, cfg->max_photons, cfg->fps, cs_lists, stats, cs_counts))) break;
+                for (int r = 0; r < n_ranks; r++) {
+                    if (!open[r]) continue;
+                    ranks[r].scatt_cyclosynch_num_ph = cs_counts[r].scatt_cyclosynch_num_ph;
+                    ranks[r].cyclosynch_emitted_total += cs_counts[r].num_cyclosynch_ph_emit;
+                    ranks[r].cyclosynch_absorbed_total += cs_counts[r].frame_abs_cnt;
+                    if (ranks[r].fPtr) fprintf(ranks[r].fPtr, "The number of cyclosynchrotron photons absorbed in this frame is: %d\n", cs_counts[r].frame_abs_cnt);
+                }
+            }
             cfg->launches += 1;
             if ((rc = mcrat_hip_pool_summaries(pool, summ))) break;                               /* phScattStats, :881 */
-            if ((rc = mcrat_hip_pool_frame_stats(pool, stats))) break;
             cfg->ms_propagate += wall_ms() - t_prop;
             const double t_out = wall_ms();
             for (int r = 0; r < n_ranks; r++) {
@@ -651,6 +689,8 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 log_frame(k->fPtr, &stats[r], k->time_now, summ[r].max_scatt, summ[r].min_scatt, summ[r].avg_scatt, summ[r].avg_r);
             }
             /* saveCheckpoint (:902-915): the records of all lists come over in pieces of whole lists, one transfer per piece */
+            if (cfg->cyclosynchrotron_switch && (rc = mcrat_hip_convert_comptonized(pool, NULL))) break;   /* its 'k' -> 'c', on every list at once
+                                                                                                     (the reference converts whether or not the file opens) */
             if (cfg->write_checkpoints) {
                 const int per_piece = (1 << 20) / stride > 0 ? (1 << 20) / stride : 1;
                 if (!rec_buf) rec_buf = (mcrat_hip_photon *)malloc(sizeof(mcrat_hip_photon) * (size_t)per_piece * (size_t)stride);
@@ -736,7 +776,7 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                                              k->angle_procs, 0);
             if (k->fPtr) { fprintf(k->fPtr, "Process %d has completed the MC calculation.\n", k->angle_id); fflush(k->fPtr); }
         }
-    free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem);
+    free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
     free(rec_buf); free(out_buf); free(out_type);
     return rc;
 }

@@ -191,6 +191,9 @@ typedef struct mcrat_host_rank {
     double   ph_weight;                  /* the adjusted weight of the injection */
     long long seeds_drawn;
     long long frame_scatt_cnt_total;     /* scatterings over all frames (for callers' accounting) */
+    int      scatt_cyclosynch_num_ph;    /* main()'s counter of comptonised photons, carried over the scatter frames of an injection (mcrat.c:873,921) */
+    int      first_scatt_frame;          /* scatt_framestart of the running batch: no pool emission in that frame (mcrat.c:707) */
+    long long cyclosynch_emitted_total, cyclosynch_absorbed_total;
     int      state;                      /* 0 waiting for its injection frame, 1 scattering, 2 batch finished, 3 all batches done,
                                             4 restarted from a checkpoint, waiting for scatt_framestart */
 } mcrat_host_rank;
@@ -219,6 +222,13 @@ typedef struct mcrat_host_pool_config {
     mcrat_host_print_arrays_fn print_photons;    /* mcrat_host_print_photon_arrays (the HDF5 build), or NULL to skip printPhotons */
     int    comv_switch, stokes_switch, save_type;
     int    max_frames;                   /* > 0: stop after this many hydro frames in total (tests, benchmarks) */
+    /* CYCLOSYNCHROTRON_SWITCH ON (the pool context created with cyclosynchrotron_switch = 1): the frame is mcrat.c:706-878 per rank --
+     * pool emission from a rank's second scatter frame on (:707), the hook inside the loop, rebinning, absorption -- through
+     * mcrat_hip_pool_scatter_frames_cyclosynch; the slab read for a frame also covers the emission shell (calcCyclosynchRLimits,
+     * :708-720); saveCheckpoint converts 'k' -> 'c' on the device.  The reader callback must hand the magnetic-field columns over
+     * (mcrat_hip_set_hydro_extras) when B_FIELD_CALC needs them.  slots_per_rank must allow for the lists' doublings. */
+    int    cyclosynchrotron_switch;
+    mcrat_hip_cyclosynch cs;             /* B_FIELD_CALC, EPSILON_B, CYCLOSYNCHROTRON_REBIN_* (the frame numbers are filled per rank) */
     /* out */
     long long hydro_frames_read;         /* get_hydro calls */
     long long launches;                  /* mcrat_hip_run calls */
