@@ -167,6 +167,154 @@ def cpu_baseline_ranks(frame, ph, cfg, per, cores):
                        "all ranks / wall time" % (cores, per, frame["num_elements"]))}
 
 
+def bench_cfg5(args):
+    """BASELINE.json configs[4] on one GPU: a 3-D PLUTO-Chombo AMR frame in spherical coordinates (three levels, ~4e6 cells read), the
+    magnetic field from the simulation, cyclo-synchrotron emission and absorption, Compton scattering with Stokes parameters; ~1e7
+    photons as the lists of a rank pool (~1000 photons per adopted rank).  A step is one scatter frame of mcrat.c:706-878 for all lists --
+    pool emission, the loop with the replacement of scattered pool photons, rebinning, absorption -- from a resident snapshot taken
+    after the injection frame's own scatter frame."""
+    import ctypes as C
+    import torch
+    from mcrat_amd import engine, synth
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--config cfg5 is a one-GPU line (the reference's ranks do not communicate: N GPUs run N such pools)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the photon loop")
+    steps = args.steps if args.steps > 0 else 3
+    warmup = args.warmup if args.warmup >= 0 else 1
+    n_target = args.photons if args.photons > 0 else 10_000_000
+    scale = max(1, args.nzc // 16)                     # --nzc 64: the full mesh; smaller values shrink it for rehearsals
+    fps, r_inj, th_max = 5.0, 1e12, 0.12
+    dom = dict(r0_domain=(1e11, 3e12), r1_domain=(0.0, 0.5), r2_domain=(0.0, 2 * np.pi))
+    raw = synth.chombo_raw(synth.THREE, synth.SPHERICAL, (1e11, 0.0, 0.0), (3e12, 0.5, 2 * np.pi), (24 * scale, 12 * scale, 12 * scale), seed=5, logr=True)
+    cells_read = int(sum(len(lv["data"]) for lv in raw["levels"]) // len(raw["var_names"]))
+    jet = engine.Engine.outflow(engine.STRUCTURED_SPHERICAL_OUTFLOW, lumi=1e52, theta_j=0.1)
+
+    def field(cols):
+        r, th = np.asarray(cols["r0"]), np.asarray(cols["r1"])
+        b = 3e4 * (1e12 / r) * (1.0 + 0.3 * np.sin(3 * th))
+        return [np.ascontiguousarray(0.2 * b), np.ascontiguousarray(0.1 * b), np.ascontiguousarray(b)]
+    R = max(1, int(round(n_target / float(args.rank_photons))))
+    max_photons = 2 * args.rank_photons
+    pool = engine.Engine(synth.THREE, synth.SPHERICAL, 1, cyclosynchrotron=1)
+    t0 = time.perf_counter()
+    m_inj, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **dom), jet)
+    pool.pool_create(R, 4 * max_photons)
+    n = 0
+    for r in range(R):
+        k, _ = pool.pool_rank(r, r).inject_photons(r_inj, 1e50, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2, "b", 0.0, th_max, fps, SEED + r)
+        n += k
+    setup_inject = time.perf_counter() - t0
+
+    def stage(F):
+        mm = pool.ph_minmax()
+        lo = min(mm[0], r_inj + synth.C_LIGHT * (F / fps - 0.5 / fps))
+        hi = max(mm[1], r_inj + synth.C_LIGHT * (F / fps + 0.5 / fps))
+        m, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=0, min_r=lo, max_r=hi, min_theta=mm[2], max_theta=mm[3], fps=fps, **dom), jet)
+        pool.set_hydro_extras(None, *field(pool.get_hydro()))
+        return m
+
+    def frame_args(F, t_now, seed0, emit):
+        return [dict(seed=seed0 + r, time_now=t_now, remaining_time=(F + 1) / fps - t_now, r_inj=r_inj, ph_weight_suggest=1e50, theta_min=0.0, theta_max=th_max,
+                     emit_pool=emit, scatt_frame_number=F, inj_frame_number=0) for r in range(R)]
+    stage(0)
+    sts, cnts = pool.pool_scatter_frames_cyclosynch(frame_args(0, 0.0, SEED, 0), max_photons, fps, b_field_calc=2, rebin_ang_phi=45.0)   # the injection frame's own scatter frame: no pool yet
+    m_cells = stage(1)
+    pool.snapshot_photons()
+    t1 = 1.0 / fps
+
+    def one(seed0):
+        pool.restore_photons()
+        st, cn = pool.pool_scatter_frames_cyclosynch(frame_args(1, t1, seed0, 1), max_photons, fps, b_field_calc=2, rebin_ang_phi=45.0)
+        slots = sum(int(pool.lib.mcrat_hip_num_photon_slots(pool.pool_rank(r, r).ctx)) for r in range(0, R, max(1, R // 64))) * max(1, R // 64)
+        return (sum(x.frame_scatt_cnt for x in st), sum(x.photon_steps for x in st), sum(x.iterations for x in st), sum(x.num_cyclosynch_ph_emit for x in cn),
+                sum(x.frame_abs_cnt for x in cn), sum(x.rebins for x in cn), slots)
+    for k in range(warmup):
+        one(SEED + 100000 * (k + 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    tot = [0] * 7
+    for k in range(steps):
+        got = one(SEED + 7 + 1000 * k)
+        tot = [a + b for a, b in zip(tot, got)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[1] / dt / 1e9
+    cpu = None
+    if not args.no_cpu_baseline:
+        try:
+            cpu = cfg5_cpu_baseline(pool, field, R, max_photons, fps, r_inj, th_max, host_cores())
+        except Exception as ex:
+            cpu = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    pool.close()
+    out = {"metric": "photon-scatter-events/sec at 1e7 photons, 3D PLUTO-Chombo MHD jet with cyclo-synchrotron emission/absorption",
+           "value": tot[0] / dt, "unit": "scatter-events/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3 / steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "BASELINE.json configs[4] on one GPU: 3-D PLUTO-Chombo AMR frame in spherical coordinates (%d cells read, %d in the photons' "
+                                  "slab), B_FIELD_CALC == SIMULATION, cyclo-synchrotron emission and absorption, Compton+KN, Stokes on; %d injected photons "
+                                  "as a rank pool of %d adopted ranks (lists of %d-%d photons that grow with their pool photons); step = one scatter frame "
+                                  "(mcrat.c:706-878: pool emission, loop with replacement of scattered pool photons, rebinning, absorption) for all lists, "
+                                  "from a resident snapshot" % (cells_read, m_cells, n, R, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2),
+                      "mode": "ranks", "photons_per_gpu": n, "cells": int(m_cells), "parallelism": "independent photon shards x1"},
+           "photon_steps_per_s": tot[1] / dt, "scatter_events": tot[0], "loop_passes": tot[2],
+           "cyclosynchrotron": {"pool_photons_emitted_per_frame": tot[3] / steps, "photons_absorbed_per_frame": tot[4] / steps, "rebinnings_per_frame": tot[5] / steps,
+                                "list_slots_after_a_frame": tot[6] // steps, "setup_s_ingest_and_injection": setup_inject},
+           "roofline": {"kernel": "rank_loop_kernel + cs_replace_pool_kernel (whole frame)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "note": "110 B x photon-steps over the WALL time of the timed frames (pool emission, rebinning and absorption included), not over "
+                                "one kernel's launches: a lower bound of the loop kernel's own figure"},
+           "cpu_baseline": cpu}
+    print(json.dumps(out), flush=True)
+
+
+def cfg5_cpu_baseline(pool, field, R, max_photons, fps, r_inj, th_max, cores):
+    """the oracle's cyclo-synchrotron scatter frame (faithful port, one list per host core, all cores at once) on the frame the device holds and on
+    the device's own lists, 150 loop passes each after the pool emission"""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from mcrat_amd import synth
+    from oracle import oracle_py as O
+    cols = pool.get_hydro()
+    Bf = field(cols)
+    dens = np.ascontiguousarray(cols["dens"])
+    dom = dict(r0_domain=(1e11, 3e12), r1_domain=(0.0, 0.5), r2_domain=(0.0, 2 * np.pi))
+    H = O.OracleHydro(dict(cols, **dom, fps=fps))
+    c = O.make_config(synth.THREE, synth.SPHERICAL, 1)
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    lists = [pool.pool_rank(r, r).get_photons_aos().astype(O.PHOTON_DTYPE) for r in range(min(cores, R))]
+    L = O.lib()
+
+    def one(r):
+        cs = O.CS(2, 0.5, 0.1, ptr(dens), ptr(Bf[0]), ptr(Bf[1]), ptr(Bf[2]), 1, 0, 0.5, 45.0)
+        l = O.PhotonList()
+        L.orc_list_init(C.byref(l))
+        a = lists[r]
+        nulls = np.flatnonzero(a["type"] == b"N")
+        full = a.copy()
+        if len(nulls):
+            full[nulls] = a[np.flatnonzero(a["type"] != b"N")[0]]
+        L.orc_list_set(C.byref(l), full.ctypes.data, len(full))
+        for i in nulls:
+            L.orc_list_set_null(C.byref(l), int(i))
+        rng = O.Rng()
+        L.orc_rng_init(C.byref(rng), SEED + r, r)
+        st, cnt, t = O.Stats(), O.CSCounts(), C.c_double(1.0 / fps)
+        t0 = time.perf_counter()
+        L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), 1.0 / fps, r_inj, 1e50, max_photons, 0.0, th_max, 1, 150,
+                               C.byref(st), C.byref(cnt))
+        dt = time.perf_counter() - t0
+        L.orc_list_free(C.byref(l))
+        return st.frame_scatt_cnt, st.photon_steps, dt
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(len(lists)) as ex:
+        res = list(ex.map(one, range(len(lists))))
+    dt = time.perf_counter() - t0
+    return {"value": sum(x[0] for x in res) / dt, "unit": "scatter-events/s", "cores": len(lists), "kind": "port",
+            "photon_steps_per_s": sum(x[1] for x in res) / dt, "wall_s": dt,
+            "sample": "oracle/ (faithful C restatement of mcrat.c:706-878 with the switch on) on %d host cores at once, one of the device's lists per core on the "
+                      "frame the device holds (%d cells): pool emission, then 150 loop passes each" % (len(lists), int(cols["num_elements"]))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +322,7 @@ def main():
     ap.add_argument("--steps", type=int, default=0, help="ranks: frames (default 20); list: loop passes (default 2000)")
     ap.add_argument("--warmup", type=int, default=-1, help="ranks: frames (default 2); list: passes (default 50)")
     ap.add_argument("--photons", type=int, default=0, help="photon slots per GPU (default: 1e6 for cfg2, 1e7 for cfg3)")
-    ap.add_argument("--config", choices=("cfg2", "cfg3"), default="cfg2",
+    ap.add_argument("--config", choices=("cfg2", "cfg3", "cfg5"), default="cfg2",
                     help="BASELINE.json configs[1] (2D FLASH-like cylindrical jet, 1e6 photons: the headline) or configs[2] (2D PLUTO-like "
                          "spherical jet, 1e7 photons, Stokes on)")
     ap.add_argument("--rank-photons", type=int, default=976, help="mean photons per adopted rank (ranks mode); the lists differ in length")
@@ -190,6 +338,8 @@ def main():
     args = ap.parse_args()
     steps = args.steps if args.steps > 0 else (20 if args.mode == "ranks" else 2000)
     warmup = args.warmup if args.warmup >= 0 else (2 if args.mode == "ranks" else 50)
+    if args.config == "cfg5":
+        return bench_cfg5(args)
     if args.photons <= 0:
         args.photons = 1_000_000 if args.config == "cfg2" else 10_000_000
     if args.photons % 2:

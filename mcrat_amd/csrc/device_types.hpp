@@ -1,5 +1,6 @@
 // device_types.hpp -- HBM layouts shared by the kernels and the host-side engine.
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace mcrat {
@@ -63,6 +64,17 @@ struct PhotonDev {
     int if_bias;
     int u_bias;
 };
+// the columns from slot `first` on: a list of a rank pool as a list of its own (the biases stay 0)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline void offset_photons(PhotonDev &ph, size_t first)
+{
+    double **cols[24] = {&ph.r0, &ph.r1, &ph.r2, &ph.p0, &ph.p1, &ph.p2, &ph.p3, &ph.c0, &ph.c1, &ph.c2, &ph.c3, &ph.s0, &ph.s1, &ph.s2, &ph.s3,
+                         &ph.num_scatt, &ph.weight, &ph.tau, &ph.tts, &ph.u0, &ph.u1, &ph.u2, &ph.ntau, &ph.tau_next};
+    for (int k = 0; k < 24; ++k) *cols[k] += first;
+    ph.idx += first; ph.flags += first; ph.type += first;
+}
 
 struct alignas(32) CellGeom {    // one 32-B sector per in-cell test (geometry.c:394-417)
     double c0, c1, s0, s1;       // centre and full size on axes 0,1

@@ -97,6 +97,7 @@ struct mcrat_hip_ctx {
     bool is_pool = false;
     int rank_stride = 0;              // slots reserved per list (pool), or cfg.virtual_rank_photons
     std::vector<mcrat_hip_ctx *> views;
+    std::vector<int> snap_lens;       // the lists' lengths when mcrat_hip_snapshot_photons was taken
     RankDesc *d_desc = nullptr;
     RankDesc *h_desc = nullptr;       // pinned
     mcrat_hip_ctx *parent = nullptr;  // this context is the view of list view_rank of `parent`
@@ -1525,6 +1526,8 @@ extern "C" int mcrat_hip_snapshot_photons(mcrat_hip_ctx *c)
     if (!c->ph_snap) { HIPCHK(c, hipMalloc(&c->ph_snap, c->ph_bytes)); c->ph_snap_bytes = c->ph_bytes; }
     HIPCHK(c, hipMemcpyAsync(c->ph_snap, c->ph_buf, c->ph_bytes, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->snap_lens.clear();
+    for (mcrat_hip_ctx *v : c->views) c->snap_lens.push_back((v && v->have_photons) ? v->ph.n : -1);    // lists change length (cyclo-synchrotron)
     return MCRAT_HIP_OK;
 }
 
@@ -1534,8 +1537,12 @@ extern "C" int mcrat_hip_restore_photons(mcrat_hip_ctx *c)
     if (c->parent || !c->have_photons || !c->ph_snap || c->ph_snap_bytes < c->ph_bytes) return MCRAT_HIP_ESTATE;
     HIPCHK(c, hipMemcpyAsync(c->ph_buf, c->ph_snap, c->ph_bytes, hipMemcpyDeviceToDevice, c->stream));
     c->frame_open = false;        // the loop state no longer matches the photons: begin_frame comes next
-    for (mcrat_hip_ctx *v : c->views)
-        if (v) v->frame_open = false;
+    for (size_t r = 0; r < c->views.size(); ++r) {
+        mcrat_hip_ctx *v = c->views[r];
+        if (!v) continue;
+        v->frame_open = false;
+        if (r < c->snap_lens.size() && c->snap_lens[r] >= 0) v->ph.n = c->snap_lens[r];
+    }
     return MCRAT_HIP_OK;
 }
 
@@ -2403,6 +2410,109 @@ extern "C" int mcrat_hip_scatter_frame_cyclosynch(mcrat_hip_ctx *c, const mcrat_
     return MCRAT_HIP_OK;
 }
 
+// photonEmitCyclosynch (mc_cyclosynch.c:1219-1460, inject_single_switch = 0) for the lists of a rank pool that ask for it: the emission
+// shell of each group of lists that share one (same radii and angles) is found and integrated once, then one workgroup per list runs the
+// list's weight loop and places its photons (inject.hip).  A list with more photons than that kernel's tables hold takes the one-list
+// path (mcrat_hip_emit_cyclosynch_pool on its view); both give the same photons.
+static int pool_emit_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, const std::vector<mcrat_hip_cyclosynch> &csr, int max_photons, double fps,
+                                const mcrat_hip_pool_cs_list *lists, mcrat_hip_cyclosynch_counts *counts, std::vector<int> &emit_base)
+{
+    const int R = c->n_ranks, M = c->hy.M;
+    struct Shell { double rmin, rmax, tmin, tmax; };
+    std::vector<Shell> shells;
+    std::vector<CsPoolEmit> pe((size_t)R);
+    bool any = false;
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        pe[(size_t)r] = CsPoolEmit{};
+        c->h_desc[r] = RankDesc{};
+        if (!lists[r].open || !lists[r].emit_pool) continue;
+        if (!(lists[r].ph_weight_suggest > 0)) return MCRAT_HIP_EINVAL;
+        mcrat_hip_ctx *v = c->views[r];
+        if ((rc = flush_pending(v))) return rc;
+        const mcrat_hip_cyclosynch &q = csr[(size_t)r];
+        Shell sh;
+        sh.rmin = lists[r].r_inj + (C_LIGHT * (q.scatt_frame_number - q.inj_frame_number) / fps - 0.5 * C_LIGHT / fps);    // calcCyclosynchRLimits :225-244
+        sh.rmax = lists[r].r_inj + (C_LIGHT * (q.scatt_frame_number - q.inj_frame_number) / fps + 0.5 * C_LIGHT / fps);
+        sh.tmin = lists[r].theta_min; sh.tmax = lists[r].theta_max;
+        int g = -1;
+        for (size_t k = 0; k < shells.size(); ++k)
+            if (shells[k].rmin == sh.rmin && shells[k].rmax == sh.rmax && shells[k].tmin == sh.tmin && shells[k].tmax == sh.tmax) { g = (int)k; break; }
+        if (g < 0) { g = (int)shells.size(); shells.push_back(sh); }
+        CsPoolEmit &e = pe[(size_t)r];
+        e.open = 1; e.group = g; e.seed = lists[r].seed; e.weight_in = lists[r].ph_weight_suggest; e.max_photons = cs->rebin_e_perc * max_photons;
+        c->h_desc[r].len = v->ph.n; c->h_desc[r].stream = v->key.stream; c->h_desc[r].seed = lists[r].seed;
+        any = true;
+    }
+    if (!any) return MCRAT_HIP_OK;
+    if ((rc = ensure_counts(c, (size_t)M + 8))) return rc;
+    const size_t scan_ints = (size_t)M + 1 + grid_scan_scratch_ints(M);
+    int *d_start = nullptr;
+    CsPoolEmit *d_pe = nullptr;
+    CsShellCell *d_shell = nullptr;
+    unsigned *d_bad = nullptr;
+    size_t shell_cap = 0;
+    auto done = [&](int code) { (void)hipFree(d_start); (void)hipFree(d_pe); (void)hipFree(d_shell); (void)hipFree(d_bad); return code; };
+    if (hipMalloc((void **)&d_start, sizeof(int) * scan_ints) != hipSuccess || hipMalloc((void **)&d_pe, sizeof(CsPoolEmit) * (size_t)R) != hipSuccess ||
+        hipMalloc((void **)&d_bad, sizeof(unsigned)) != hipSuccess) return done(MCRAT_HIP_ENOMEM);
+    if (hipMemcpyAsync(d_pe, pe.data(), sizeof(CsPoolEmit) * (size_t)R, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+    CsEmitParams p{};
+    p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry; p.b_field_calc = cs->b_field_calc; p.epsilon_b = cs->epsilon_b;
+    std::vector<unsigned> bad(shells.size(), 0);
+    for (size_t g = 0; g < shells.size(); ++g) {
+        p.rmin = shells[g].rmin; p.rmax = shells[g].rmax; p.theta_min = shells[g].tmin; p.theta_max = shells[g].tmax;
+        int n_shell = 0;
+        if (launch_cs_shell_flag(p, c->hy, c->grid_count, c->d_grid_total, &n_shell, c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+        if ((size_t)n_shell > shell_cap) {
+            (void)hipFree(d_shell); d_shell = nullptr;
+            if (hipMalloc((void **)&d_shell, sizeof(CsShellCell) * (size_t)n_shell) != hipSuccess) return done(MCRAT_HIP_ENOMEM);
+            shell_cap = (size_t)n_shell;
+        }
+        if (n_shell > 0 && launch_cs_shell_write(p, c->hy, c->hcol, c->grid_count, n_shell, d_start, d_start + M + 1, d_shell, d_bad, c->stream) != hipSuccess)
+            return done(MCRAT_HIP_EHIP);
+        if (n_shell == 0 && hipMemsetAsync(d_bad, 0, sizeof(unsigned), c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+        if (launch_cs_emit_pool(p, c->hy, c->hcol, c->ph, c->rank_stride, R, c->d_desc, d_shell, n_shell, d_pe, (int)g, c->stream) != hipSuccess ||
+            hipMemcpyAsync(&bad[g], d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { c->last_error = "cyclo-synchrotron emission of the pool's lists failed"; return done(MCRAT_HIP_EHIP); }
+    }
+    if (hipMemcpyAsync(pe.data(), d_pe, sizeof(CsPoolEmit) * (size_t)R, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipMemcpyAsync(c->h_desc, c->d_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+    (void)done(0);
+    for (int r = 0; r < R; ++r) {
+        const CsPoolEmit &e = pe[(size_t)r];
+        if (!e.open) continue;
+        mcrat_hip_ctx *v = c->views[r];
+        int n = e.n_emit, nbad = (int)bad[(size_t)e.group];
+        double w = e.weight_out;
+        switch (e.error) {
+        case 0:
+            v->ph.n = c->h_desc[r].len;                                                           // the list may have grown inside its window
+            if (n > 0) { v->frame_open = false; drop_graph(v); }
+            break;
+        case 4:                                                                                   // more photons than the kernel's tables hold
+            if ((rc = mcrat_hip_emit_cyclosynch_pool(v, &csr[(size_t)r], lists[r].r_inj, lists[r].ph_weight_suggest, max_photons, lists[r].theta_min,
+                                                     lists[r].theta_max, fps, lists[r].seed, &n, &w, &nbad))) { c->last_error = v->last_error; return rc; }
+            break;
+        case 1:
+            c->last_error = "cyclo-synchrotron emission: no weight gives between 1 and rebin_e_perc * maximum_photons photons";
+            return MCRAT_HIP_EINVAL;
+        case 2:
+            c->last_error = "cyclo-synchrotron emission: fewer null slots than photons to add (the reference exits with \"Adding to the photon list has failed\")";
+            return MCRAT_HIP_EINVAL;
+        default:
+            c->last_error = "the list is longer than the pool's slots per rank (mcrat_hip_pool_create)";
+            return MCRAT_HIP_ENOMEM;
+        }
+        counts[r].num_cyclosynch_ph_emit = n;
+        counts[r].pool_weight = w;
+        counts[r].integrals_not_converged = nbad;
+        emit_base[(size_t)r] = n;
+    }
+    return MCRAT_HIP_OK;
+}
+
 // The scatter frame of mcrat.c:706-878 with CYCLOSYNCHROTRON_SWITCH on for the lists of a rank pool: what mcrat_hip_scatter_frame_cyclosynch
 // does for one list, for every open list -- the loop of all of them in the same launches.  rank_loop_kernel runs every list until a pass
 // the hook of :786-808 must look at (photonEvent reported a pool photon; a thousand scatterings are full) and parks it there;
@@ -2434,20 +2544,8 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
         seeds[(size_t)r] = lists[r].seed; t_now[(size_t)r] = lists[r].time_now; t_rem[(size_t)r] = lists[r].remaining_time;
         csr[(size_t)r].scatt_frame_number = lists[r].scatt_frame_number;
         csr[(size_t)r].inj_frame_number = lists[r].inj_frame_number;
-        if (lists[r].emit_pool) {                                                                 // :727-744
-            int n = 0, bad = 0;
-            double w = 0;
-            if ((rc = mcrat_hip_emit_cyclosynch_pool(v, &csr[(size_t)r], lists[r].r_inj, lists[r].ph_weight_suggest, max_photons, lists[r].theta_min,
-                                                     lists[r].theta_max, fps, lists[r].seed, &n, &w, &bad))) {
-                c->last_error = v->last_error;
-                return rc;
-            }
-            counts[r].num_cyclosynch_ph_emit = n;
-            counts[r].pool_weight = w;
-            counts[r].integrals_not_converged = bad;
-            emit_base[(size_t)r] = n;
-        }
     }
+    if ((rc = pool_emit_cyclosynch(c, cs, csr, max_photons, fps, lists, counts, emit_base))) return rc;                // :727-744
     if ((rc = mcrat_hip_pool_begin_frames(c, open.data(), seeds.data(), t_now.data(), t_rem.data()))) return rc;
     // the hooks' state, one CsFrame per list
     if (c->d_cs_hook) { HIPCHK(c, hipFree(c->d_cs_hook)); c->d_cs_hook = nullptr; }
@@ -2507,6 +2605,8 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
         }
         if (all_done) break;
     }
+    std::vector<int> absorb((size_t)R, 0);
+    bool any_absorb = false;
     for (int r = 0; r < R; ++r) {
         if (!open[(size_t)r]) continue;
         mcrat_hip_ctx *v = c->views[r];
@@ -2522,16 +2622,32 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
                 if (rc == MCRAT_HIP_OK) counts[r].rebins += 1;
                 else if (rc != MCRAT_HIP_EREFUSED) { c->last_error = v->last_error; return rc; }
             }
-            if (counts[r].num_cyclosynch_ph_emit > 0) {
-                double w = 0;
-                if ((rc = mcrat_hip_absorb_cyclosynch(v, &csr[(size_t)r], &counts[r].frame_abs_cnt, &counts[r].scatt_cyclosynch_num_ph, &w))) {
-                    c->last_error = v->last_error;
-                    return rc;
-                }
-                counts[r].n_comptonized -= w;
-            }
+            if (counts[r].num_cyclosynch_ph_emit > 0) { absorb[(size_t)r] = 1; any_absorb = true; }
         }
         if (stats) state_to_stats(c->h_rstates[r], v->ph.n, &stats[r]);
+    }
+    if (any_absorb) {                                                                             // phAbsCyclosynch of every such list, one launch
+        for (int r = 0; r < R; ++r)
+            if (absorb[(size_t)r] && (rc = flush_pending(c->views[r]))) return rc;
+        for (int r = 0; r < R; ++r) { c->h_desc[r].len = open[(size_t)r] ? c->views[r]->ph.n : 0; }
+        const size_t bytes = (sizeof(CsAbsPartial) + sizeof(int)) * (size_t)R;
+        if ((rc = ensure_aos(c, bytes + 64))) return rc;
+        CsAbsPartial *d_part = static_cast<CsAbsPartial *>(c->aos_buf);
+        int *d_sel = reinterpret_cast<int *>(d_part + R);
+        std::vector<CsAbsPartial> part((size_t)R);
+        HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(d_sel, absorb.data(), sizeof(int) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+        CsParams ap{c->kc.dimensions, cs->b_field_calc, cs->epsilon_b};
+        HIPCHK(c, launch_cs_absorb_pool(ap, c->ph, c->rank_stride, R, c->d_desc, d_sel, c->hy.temp, c->hcol, d_part, c->stream));
+        HIPCHK(c, hipMemcpyAsync(part.data(), d_part, sizeof(CsAbsPartial) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int r = 0; r < R; ++r) {
+            if (!absorb[(size_t)r]) continue;
+            counts[r].frame_abs_cnt = (int)part[(size_t)r].abs_count;
+            counts[r].scatt_cyclosynch_num_ph = (int)part[(size_t)r].scatt_count;
+            counts[r].n_comptonized -= part[(size_t)r].abs_weight;
+            drop_graph(c->views[r]);
+        }
     }
     return MCRAT_HIP_OK;
 }

@@ -430,6 +430,157 @@ __global__ __launch_bounds__(256) void cs_emit_generate_kernel(CsEmitParams p, H
 // inject_single_switch = 1, mc_cyclosynch.c:1467-1558, into the list's first null slot, photons.c:139-160), and it is itself moved to
 // a random place in that cell (:1540-1556); then the rebinning trigger of :797-808.  One workgroup; the pending advance must have
 // been applied (flush_kernel) so that the positions are current.  See CsFrame (launch.hpp) for how it parks the loop.
+// ---- pool emission for many lists at once (rank pool).  What photonEmitCyclosynch computes per cell -- whether the cell lies in the
+// emission shell, the Planck integral below its cyclotron frequency, its volume -- does not depend on the list; lists that emit into the
+// same shell (same injection radius, frame numbers and angle range: the ranks of an angle bin) share it.  cs_shell_*: the shell's cells
+// in ascending order with those per-cell values; cs_emit_pool_kernel: one workgroup per list runs that list's weight loop on its own
+// Poisson streams (the streams of the one-list path: {seed, attempt, cell, RNG_CS_COUNT}), places the photons in its null slots in
+// slot order (the list doubling inside its window of the pool when it has none), and generates them ({seed, 0, k, RNG_CS_PHOTON}).
+__global__ __launch_bounds__(256) void cs_shell_flag_kernel(CsEmitParams p, HydroDev hy, unsigned *__restrict__ flag, unsigned long long *__restrict__ total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned in = 0;
+    if (i < hy.M) {
+        in = in_emission_slab(p, load_cell(hy, p.dimensions, i)) ? 1u : 0u;
+        flag[i] = in;
+    }
+    const unsigned long long m = __ballot(in != 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, (unsigned long long)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void cs_shell_write_kernel(CsEmitParams p, HydroDev hy, HydroCols h, const unsigned *__restrict__ flag,
+                                                             const int *__restrict__ start, CsShellCell *__restrict__ out, unsigned *__restrict__ not_converged)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hy.M || !flag[i]) return;
+    const CellRec c = load_cell(hy, p.dimensions, i);
+    bool converged;
+    CsShellCell s;
+    s.cell = i; s.pad = 0;
+    s.integral = qk21_planck(10, cs_nu_c(p, hy, h, i), hy.temp[i], converged);                         // :1276
+    s.volume = element_volume(p.dimensions, p.geometry, c);
+    if (!converged) atomicAdd(not_converged, 1u);
+    out[start[i]] = s;
+}
+
+// exclusive scan of one value per thread over the workgroup (256 threads); returns the thread's offset, *total the sum
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int *s_w, int *total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    __syncthreads();
+    if (lane == 63) s_w[w] = x;
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < w; ++k) before += s_w[k];
+    *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return before + x - v;
+}
+
+constexpr int CS_POOL_EMIT_CAP = 4096;       // pool photons one list may receive in one emission (LDS tables of cells and slots)
+
+__global__ __launch_bounds__(256) void cs_emit_pool_kernel(CsEmitParams p, HydroDev hy, HydroCols h, PhotonDev pool, int stride, RankDesc *desc,
+                                                           const CsShellCell *__restrict__ shell, int n_shell, CsPoolEmit *lists, int group)
+{
+    __shared__ unsigned long long s_sum[4];
+    __shared__ int s_w[4];
+    __shared__ int s_cell[CS_POOL_EMIT_CAP], s_slot[CS_POOL_EMIT_CAP];
+    __shared__ double s_weight;
+    __shared__ int s_ok, s_attempt;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    CsPoolEmit &L = lists[r];
+    if (!L.open || L.group != group) return;
+    const RankDesc d = desc[r];
+    PhotonDev ph = pool;
+    offset_photons(ph, (size_t)r * (size_t)stride);
+    ph.n = d.len;
+    const RngKey key = {L.seed, d.stream, 0u};
+    // ---- :1244-1296: the weight loop
+    if (tid == 0) { s_weight = L.weight_in; s_ok = 0; s_attempt = 0; }
+    __syncthreads();
+    const int min_photons = n_shell > 0 ? 1 : 0;                                          // no cell in the shell: nothing to emit (:1236-1239)
+    unsigned long long total = 0;
+    for (int attempt = 0; attempt <= 400; ++attempt) {
+        const double weight = s_weight;
+        unsigned long long mine = 0;
+        for (int s = tid; s < n_shell; s += 256) {
+            double ph_dens_calc = shell[s].integral;
+            ph_dens_calc *= shell[s].volume / weight;                                      // :1277
+            EventStream rng = keyed_stream(key, (unsigned long long)attempt, (uint32_t)shell[s].cell, RNG_CS_COUNT);
+            const long long k = poisson(rng, ph_dens_calc);
+            mine += (unsigned long long)(k < 0 ? 0 : (k > 0x7fffffffll ? 0x7fffffffll : k));
+        }
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) s_sum[tid >> 6] = mine;
+        __syncthreads();
+        total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        if (tid == 0) {
+            if ((double)total > L.max_photons) s_weight = weight * 10;
+            else if ((long long)total < min_photons) s_weight = weight * 0.5;
+            else { s_ok = 1; s_attempt = attempt; }
+        }
+        __syncthreads();
+        if (s_ok) break;
+    }
+    if (!s_ok) { if (tid == 0) { L.error = 1; L.n_emit = 0; } return; }
+    const double weight = s_weight;
+    const int attempt = s_attempt, n_emit = (int)total;
+    if (tid == 0) { L.n_emit = n_emit; L.weight_out = weight; L.error = 0; }
+    if (n_emit == 0) return;
+    if (n_emit > CS_POOL_EMIT_CAP) { if (tid == 0) L.error = 4; return; }
+    // ---- photon k -> its cell: the counts of the accepted attempt again, in cell order (:1340-1455)
+    int base = 0;
+    for (int c0 = 0; c0 < n_shell; c0 += 256) {
+        const int s = c0 + tid;
+        int cnt = 0, cell = -1;
+        if (s < n_shell) {
+            double ph_dens_calc = shell[s].integral;
+            ph_dens_calc *= shell[s].volume / weight;
+            EventStream rng = keyed_stream(key, (unsigned long long)attempt, (uint32_t)shell[s].cell, RNG_CS_COUNT);
+            const long long k = poisson(rng, ph_dens_calc);
+            cnt = (int)(k < 0 ? 0 : (k > 0x7fffffffll ? 0x7fffffffll : k));
+            cell = shell[s].cell;
+        }
+        int chunk_total;
+        const int off = block_exclusive_scan_256(cnt, s_w, &chunk_total);
+        for (int j = 0; j < cnt; ++j) s_cell[base + off + j] = cell;
+        base += chunk_total;
+        __syncthreads();
+    }
+    // ---- addToPhotonList (photons.c:108-208): the null slots in slot order, the list doubled first when it has none
+    int n = ph.n, n_null = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        n_null = 0;
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            const int i = c0 + tid;
+            const int isn = (i < n && ph.type[i] == 'N') ? 1 : 0;
+            int chunk_total;
+            const int off = block_exclusive_scan_256(isn, s_w, &chunk_total);
+            if (isn && n_null + off < n_emit) s_slot[n_null + off] = i;
+            n_null += chunk_total;
+            __syncthreads();
+        }
+        if (n_null != 0 || pass == 1) break;
+        const long long cap = n;                                                           // photons.c:112-121
+        const long long new_cap = (cap * 2 > cap + n_emit) ? cap * 2 : cap * (n_emit / cap);
+        if (new_cap > stride) { if (tid == 0) L.error = 3; return; }
+        for (int i = n + tid; i < (int)new_cap; i += 256) { ph.type[i] = 'N'; ph.idx[i] = -1; ph.flags[i] = (unsigned char)FLAG_VALID; ph.ntau[i] = -INFINITY; }
+        n = (int)new_cap;
+        ph.n = n;
+        if (tid == 0) desc[r].len = n;
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (n_emit > n_null) { if (tid == 0) L.error = 2; return; }                            // "Adding to the photon list has failed"
+    __syncthreads();
+    for (int k = tid; k < n_emit; k += 256) {
+        EventStream rng = keyed_stream(key, 0ull, (uint32_t)k, RNG_CS_PHOTON);
+        (void)cs_emit_one(p, hy, h, s_cell[k], weight, 0, rng, ph, s_slot[k]);
+    }
+}
+
 // (body shared by the single-list hook and the rank pool's; all 256 threads call it.  grow_cap: the list may double in place up to
 // this many slots -- the pool's slots per rank -- instead of parking for the host; *len_out receives the new length.)
 __device__ __forceinline__ void cs_hook_body(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, const RngKey &key, LoopState *st, PhotonDev ph,
@@ -522,12 +673,8 @@ __global__ __launch_bounds__(256) void cs_replace_pool_kernel(CsEmitParams p, Hy
     CsFrame *cf = frames + r;
     if (st->done != LOOP_CS_HALT || cf->halt != CS_HALT_HOOK) return;
     const RankDesc d = desc[r];
-    const size_t o = (size_t)r * (size_t)stride;
     PhotonDev ph = pool;
-    double **cols[24] = {&ph.r0, &ph.r1, &ph.r2, &ph.p0, &ph.p1, &ph.p2, &ph.p3, &ph.c0, &ph.c1, &ph.c2, &ph.c3, &ph.s0, &ph.s1, &ph.s2, &ph.s3,
-                         &ph.num_scatt, &ph.weight, &ph.tau, &ph.tts, &ph.u0, &ph.u1, &ph.u2, &ph.ntau, &ph.tau_next};
-    for (int k = 0; k < 24; ++k) *cols[k] += o;
-    ph.idx += o; ph.flags += o; ph.type += o;
+    offset_photons(ph, (size_t)r * (size_t)stride);
     ph.n = d.len;
     const RngKey key = {d.seed, d.stream, 0u};
     cs_hook_body(p, hy, h, key, st, ph, cf, 0, s_min, stride, &desc[r].len);
@@ -833,6 +980,35 @@ hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const Hy
                              CsFrame *frame, int resume, hipStream_t stream)
 {
     cs_replace_kernel<<<dim3(1), dim3(256), 0, stream>>>(p, hy, h, key, st, ph, frame, resume);
+    return hipGetLastError();
+}
+
+hipError_t launch_cs_shell_flag(const CsEmitParams &p, const HydroDev &hy, unsigned *flag, unsigned long long *d_total, int *n_shell, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    cs_shell_flag_kernel<<<dim3((hy.M + 255) / 256), dim3(256), 0, stream>>>(p, hy, flag, d_total);
+    unsigned long long total = 0;
+    if ((e = hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    *n_shell = (int)total;
+    return hipGetLastError();
+}
+
+hipError_t launch_cs_shell_write(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, const unsigned *flag, int n_shell, int *start, int *scratch,
+                                 CsShellCell *out, unsigned *not_converged, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(not_converged, 0, sizeof(unsigned), stream);
+    if (e != hipSuccess) return e;
+    if ((e = launch_exclusive_scan(flag, hy.M, start, scratch, (long long)n_shell, stream)) != hipSuccess) return e;
+    cs_shell_write_kernel<<<dim3((hy.M + 255) / 256), dim3(256), 0, stream>>>(p, hy, h, flag, start, out, not_converged);
+    return hipGetLastError();
+}
+
+hipError_t launch_cs_emit_pool(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, const PhotonDev &pool, int stride, int n_ranks, RankDesc *desc,
+                               const CsShellCell *shell, int n_shell, CsPoolEmit *lists, int group, hipStream_t stream)
+{
+    cs_emit_pool_kernel<<<dim3(n_ranks), dim3(256), 0, stream>>>(p, hy, h, pool, stride, desc, shell, n_shell, lists, group);
     return hipGetLastError();
 }
 

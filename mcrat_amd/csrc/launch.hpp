@@ -198,6 +198,25 @@ struct CsFrame {
 };
 hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, RngKey key, LoopState *st, const PhotonDev &ph,
                              CsFrame *frame, int resume, hipStream_t stream);
+// pool emission for the lists of a rank pool (inject.hip): the emission shell's cells with what photonEmitCyclosynch computes per cell, once per
+// group of lists that share the shell, then one workgroup per list
+struct alignas(8) CsShellCell { int cell; int pad; double integral; double volume; };
+struct alignas(8) CsPoolEmit {
+    int open, group;                 // in: takes part; which shell it emits into
+    unsigned long long seed;         // in: the list's emission seed
+    double weight_in, max_photons;   // in: ph_weight_suggest; rebin_e_perc * maximum_photons
+    double weight_out;               // out: the adjusted weight
+    int n_emit, error;               // out: photons emitted; 0 ok, 1 no weight fits, 2 fewer null slots than photons, 3 the list would outgrow its
+                                     //      window of the pool, 4 more photons than the kernel's tables hold
+};
+hipError_t launch_cs_shell_flag(const CsEmitParams &p, const HydroDev &hy, unsigned *flag, unsigned long long *d_total, int *n_shell, hipStream_t stream);   // waits
+hipError_t launch_cs_shell_write(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, const unsigned *flag, int n_shell, int *start, int *scratch,
+                                 CsShellCell *out, unsigned *not_converged, hipStream_t stream);
+hipError_t launch_cs_emit_pool(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, const PhotonDev &pool, int stride, int n_ranks, RankDesc *desc,
+                               const CsShellCell *shell, int n_shell, CsPoolEmit *lists, int group, hipStream_t stream);
+// phAbsCyclosynch for the open lists of a rank pool, one workgroup per list (staging.hip)
+hipError_t launch_cs_absorb_pool(const CsParams &p, const PhotonDev &pool, int stride, int n_ranks, const RankDesc *desc, const int *open, const double *temp,
+                                 const HydroCols &h, CsAbsPartial *per_list, hipStream_t stream);
 // the hook for every parked list of a rank pool (one workgroup per list; a list out of null slots doubles inside its window of the pool)
 hipError_t launch_cs_replace_pool(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, LoopState *states, const PhotonDev &pool, int stride,
                                   int n_ranks, RankDesc *desc, CsFrame *frames, hipStream_t stream);

@@ -108,7 +108,65 @@ __global__ __launch_bounds__(256) void output_write_kernel(PhotonDev ph, int n, 
 
 constexpr double CHARGE_EL = 4.8032068e-10;      // Src/mclib.c:4-5
 
-// phAbsCyclosynch, mc_cyclosynch.c:1571-1623; calcB :54-76, calcCyclotronFreq :30-33, getMagneticFieldMagnitude :78-92
+// phAbsCyclosynch, mc_cyclosynch.c:1571-1623; calcB :54-76, calcCyclotronFreq :30-33, getMagneticFieldMagnitude :78-92: photon i
+__device__ __forceinline__ void cs_absorb_slot(const CsParams &p, const PhotonDev &ph, const double *__restrict__ temp, const HydroCols &h, int i,
+                                               double &abs_weight, int &abs_count, int &scatt_count)
+{
+    const double weight = ph.weight[i];
+    const int cell = ph.idx[i];
+    if (!((weight != 0) && (cell != -1))) return;
+    double b_field;
+    if (p.b_field_calc == 0 || p.b_field_calc == 1) {
+        const double el_dens = h.dens[cell] / M_P, T = temp[cell];
+        if (p.b_field_calc == 0) b_field = sqrt(p.epsilon_b * 8 * M_PI * 3 * el_dens * K_B * T / 2);
+        else b_field = sqrt(8 * M_PI * p.epsilon_b * (el_dens * M_P * C_LIGHT * C_LIGHT + 4 * A_RAD * T * T * T * T / 3));
+    } else if (p.dimensions == DIM_TWO) {
+        b_field = sqrt(h.B0[cell] * h.B0[cell] + h.B1[cell] * h.B1[cell]);
+    } else {
+        b_field = sqrt(h.B0[cell] * h.B0[cell] + h.B1[cell] * h.B1[cell] + h.B2[cell] * h.B2[cell]);
+    }
+    const double nu_c = CHARGE_EL * b_field / (2 * M_PI * M_EL * C_LIGHT);
+    const char type = ph.type[i];
+    if ((ph.c0[i] * C_LIGHT / PL_CONST <= nu_c) || (type == 'p')) {
+        abs_count += 1;
+        if (type == 'i' || type == 'c') abs_weight += weight;
+        // setNullPhoton, photons.c:210-250 (time_to_scatter is left as it is)
+        ph.type[i] = 'N';
+        ph.weight[i] = 0;
+        ph.idx[i] = -1;
+        ph.flags[i] = (unsigned char)FLAG_VALID;
+        ph.p0[i] = 0; ph.p1[i] = 0; ph.p2[i] = 0; ph.p3[i] = 0;
+        ph.c0[i] = 0; ph.c1[i] = 0; ph.c2[i] = 0; ph.c3[i] = 0;
+        ph.r0[i] = 0; ph.r1[i] = 0; ph.r2[i] = 0;
+        ph.s0[i] = 0; ph.s1[i] = 0; ph.s2[i] = 0; ph.s3[i] = 0;
+        ph.num_scatt[i] = 0;
+        ph.tau[i] = 0;
+        ph.u0[i] = 0; ph.u1[i] = 0; ph.u2[i] = 0;
+        ph.ntau[i] = -1.0 / 0.0;
+        ph.tau_next[i] = 0;
+    } else if (type == 'k' || type == 'c') {
+        scatt_count += 1;
+    }
+}
+
+// the workgroup's sums of what its threads counted
+__device__ __forceinline__ CsAbsPartial cs_absorb_reduce(double abs_weight, int abs_count, int scatt_count, double *s_w, int *s_a, int *s_s)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        abs_weight += __shfl_down(abs_weight, off);
+        abs_count += __shfl_down(abs_count, off);
+        scatt_count += __shfl_down(scatt_count, off);
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = abs_weight; s_a[threadIdx.x >> 6] = abs_count; s_s[threadIdx.x >> 6] = scatt_count; }
+    __syncthreads();
+    CsAbsPartial o;
+    o.abs_weight = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    o.abs_count = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+    o.scatt_count = s_s[0] + s_s[1] + s_s[2] + s_s[3];
+    return o;
+}
+
 __global__ __launch_bounds__(256) void cs_absorb_kernel(CsParams p, PhotonDev ph, const double *__restrict__ temp, HydroCols h,
                                                         CsAbsPartial *__restrict__ partials)
 {
@@ -116,57 +174,35 @@ __global__ __launch_bounds__(256) void cs_absorb_kernel(CsParams p, PhotonDev ph
     __shared__ int s_a[4], s_s[4];
     double abs_weight = 0;
     int abs_count = 0, scatt_count = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < ph.n; i += gridDim.x * 256) {
-        const double weight = ph.weight[i];
-        const int cell = ph.idx[i];
-        if (!((weight != 0) && (cell != -1))) continue;
-        double b_field;
-        if (p.b_field_calc == 0 || p.b_field_calc == 1) {
-            const double el_dens = h.dens[cell] / M_P, T = temp[cell];
-            if (p.b_field_calc == 0) b_field = sqrt(p.epsilon_b * 8 * M_PI * 3 * el_dens * K_B * T / 2);
-            else b_field = sqrt(8 * M_PI * p.epsilon_b * (el_dens * M_P * C_LIGHT * C_LIGHT + 4 * A_RAD * T * T * T * T / 3));
-        } else if (p.dimensions == DIM_TWO) {
-            b_field = sqrt(h.B0[cell] * h.B0[cell] + h.B1[cell] * h.B1[cell]);
-        } else {
-            b_field = sqrt(h.B0[cell] * h.B0[cell] + h.B1[cell] * h.B1[cell] + h.B2[cell] * h.B2[cell]);
-        }
-        const double nu_c = CHARGE_EL * b_field / (2 * M_PI * M_EL * C_LIGHT);
-        const char type = ph.type[i];
-        if ((ph.c0[i] * C_LIGHT / PL_CONST <= nu_c) || (type == 'p')) {
-            abs_count += 1;
-            if (type == 'i' || type == 'c') abs_weight += weight;
-            // setNullPhoton, photons.c:210-250 (time_to_scatter is left as it is)
-            ph.type[i] = 'N';
-            ph.weight[i] = 0;
-            ph.idx[i] = -1;
-            ph.flags[i] = (unsigned char)FLAG_VALID;
-            ph.p0[i] = 0; ph.p1[i] = 0; ph.p2[i] = 0; ph.p3[i] = 0;
-            ph.c0[i] = 0; ph.c1[i] = 0; ph.c2[i] = 0; ph.c3[i] = 0;
-            ph.r0[i] = 0; ph.r1[i] = 0; ph.r2[i] = 0;
-            ph.s0[i] = 0; ph.s1[i] = 0; ph.s2[i] = 0; ph.s3[i] = 0;
-            ph.num_scatt[i] = 0;
-            ph.tau[i] = 0;
-            ph.u0[i] = 0; ph.u1[i] = 0; ph.u2[i] = 0;
-            ph.ntau[i] = -1.0 / 0.0;
-            ph.tau_next[i] = 0;
-        } else if (type == 'k' || type == 'c') {
-            scatt_count += 1;
-        }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ph.n; i += gridDim.x * 256) cs_absorb_slot(p, ph, temp, h, i, abs_weight, abs_count, scatt_count);
+    const CsAbsPartial o = cs_absorb_reduce(abs_weight, abs_count, scatt_count, s_w, s_a, s_s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = o;
+}
+
+// the same for the open lists of a rank pool, one workgroup per list.  The workgroup plays the cs_absorb_blocks(len) workgroups the list
+// would have had alone one after the other and adds their sums in that order, so the absorbed weight is the one-list path's to the bit.
+__global__ __launch_bounds__(256) void cs_absorb_pool_kernel(CsParams p, PhotonDev pool, int stride, const RankDesc *__restrict__ desc,
+                                                             const int *__restrict__ open, const double *__restrict__ temp, HydroCols h,
+                                                             CsAbsPartial *__restrict__ per_list)
+{
+    __shared__ double s_w[4];
+    __shared__ int s_a[4], s_s[4];
+    const int r = blockIdx.x;
+    if (!open[r]) return;
+    PhotonDev ph = pool;
+    offset_photons(ph, (size_t)r * (size_t)stride);
+    ph.n = desc[r].len;
+    const int b = (ph.n + 255) / 256, nblk = b < 1 ? 1 : (b > 1024 ? 1024 : b);
+    CsAbsPartial sum;
+    sum.abs_weight = 0; sum.abs_count = 0; sum.scatt_count = 0;
+    for (int vb = 0; vb < nblk; ++vb) {
+        double abs_weight = 0;
+        int abs_count = 0, scatt_count = 0;
+        for (int i = vb * 256 + threadIdx.x; i < ph.n; i += nblk * 256) cs_absorb_slot(p, ph, temp, h, i, abs_weight, abs_count, scatt_count);
+        const CsAbsPartial o = cs_absorb_reduce(abs_weight, abs_count, scatt_count, s_w, s_a, s_s);
+        sum.abs_weight += o.abs_weight; sum.abs_count += o.abs_count; sum.scatt_count += o.scatt_count;
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        abs_weight += __shfl_down(abs_weight, off);
-        abs_count += __shfl_down(abs_count, off);
-        scatt_count += __shfl_down(scatt_count, off);
-    }
-    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = abs_weight; s_a[threadIdx.x >> 6] = abs_count; s_s[threadIdx.x >> 6] = scatt_count; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        CsAbsPartial o;
-        o.abs_weight = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        o.abs_count = s_a[0] + s_a[1] + s_a[2] + s_a[3];
-        o.scatt_count = s_s[0] + s_s[1] + s_s[2] + s_s[3];
-        partials[blockIdx.x] = o;
-    }
+    if (threadIdx.x == 0) per_list[r] = sum;
 }
 
 // the loop state of a new frame (mcrat.c:754-758): one record for the single list, one per virtual rank with the forced
@@ -334,6 +370,13 @@ int cs_absorb_blocks(int n) { const int b = (n + 255) / 256; return b < 1 ? 1 : 
 hipError_t launch_cs_absorb(const CsParams &p, const PhotonDev &ph, const double *temp, const HydroCols &h, CsAbsPartial *partials, hipStream_t stream)
 {
     cs_absorb_kernel<<<dim3(cs_absorb_blocks(ph.n)), dim3(256), 0, stream>>>(p, ph, temp, h, partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_cs_absorb_pool(const CsParams &p, const PhotonDev &pool, int stride, int n_ranks, const RankDesc *desc, const int *open, const double *temp,
+                                 const HydroCols &h, CsAbsPartial *per_list, hipStream_t stream)
+{
+    cs_absorb_pool_kernel<<<dim3(n_ranks), dim3(256), 0, stream>>>(p, pool, stride, desc, open, temp, h, per_list);
     return hipGetLastError();
 }
 
