@@ -79,6 +79,7 @@ struct mcrat_hip_ctx {
     RngKey key{0, 0, 0};
     long long frame_photon_steps = 0;
     bool pending_applied = false;     // step_locate_sample has applied the pending advance that LoopState still lists
+    bool rank_current = false;        // a view whose frame rank_loop_kernel has run: it leaves no pending advance (until the next begin_frame)
 
     // virtual ranks (cfg.virtual_rank_photons > 0): one LoopState per list
     int n_ranks = 0;
@@ -1646,7 +1647,7 @@ extern "C" int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *c) { return (c &&
 
 static int flush_pending(mcrat_hip_ctx *c)
 {
-    if (c->n_ranks > 0) return MCRAT_HIP_OK;      // rank_loop_kernel leaves the photons current
+    if (c->n_ranks > 0 || (c->parent && c->rank_current)) return MCRAT_HIP_OK;      // rank_loop_kernel leaves the photons current
     if (c->pending_applied) return MCRAT_HIP_OK;  // between the two halves of a pass: the step kernel has applied it, the event kernel will replace it
     HIPCHK(c, launch_flush(c->ph, c->d_state, c->step_blocks, c->stream));
     return MCRAT_HIP_OK;
@@ -1998,6 +1999,7 @@ extern "C" int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *c, const int *open, co
         v->key.seed = seeds[r];
         v->find_switch = 1;
         v->pending_applied = false;
+        v->rank_current = false;
         v->frame_open = true;
         v->prof_step_ms = v->prof_event_ms = 0;
         v->prof_launches = 0;
@@ -2084,7 +2086,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     HIPCHK(c, launch_init_states(c->d_state, c->d_rstates, c->n_ranks, h, c->stream));     // per list: force_relocate = 1, mcrat.c:756
     if (c->is_pool)                                // the pool's own begin_frame: every list, the same seed and clock
         for (mcrat_hip_ctx *v : c->views)
-            if (v && v->have_photons) { v->key.seed = seed; v->frame_open = true; v->find_switch = 1; v->pending_applied = false; }
+            if (v && v->have_photons) { v->key.seed = seed; v->frame_open = true; v->find_switch = 1; v->pending_applied = false; v->rank_current = false; }
     *c->h_state = h;                               // the host's view until the next read-back (every read-back is followed by a wait)
     HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     if (c->sc_world > 0) HIPCHK(c, hipMemsetAsync(c->d_sc, 0, sizeof(ScState), c->stream));
@@ -2092,6 +2094,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     c->key.seed = seed;
     c->find_switch = 1;           // mcrat.c:756
     c->pending_applied = false;
+    c->rank_current = false;
     c->rank_block_fixed = false;
     c->frame_open = true;
     c->prof_step_ms = c->prof_event_ms = 0;
@@ -2200,7 +2203,12 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all_done = true;
         for (int r = 0; r < c->n_ranks && all_done; ++r) all_done = c->h_rstates[r].done != 0;
-        if (all_done) break;
+        if (all_done) {
+            if (c->is_pool)
+                for (mcrat_hip_ctx *v : c->views)
+                    if (v && v->frame_open) v->rank_current = true;
+            break;
+        }
     }
     fill_rank_stats(c, stats);
     {   // what the next frame's choice of workgroup size looks at
@@ -2561,11 +2569,19 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
     HIPCHK(c, hipStreamSynchronize(c->stream));
     CsEmitParams p{};
     p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry; p.b_field_calc = cs->b_field_calc; p.epsilon_b = cs->epsilon_b;
-    c->rank_block = 256; c->rank_fuse = false;         // lists that change length: columns stay in HBM/L2 (longest = the window)
+    // lists that change length: columns stay in HBM/L2 (longest = the window), so LDS does not limit the lists per CU; with more than
+    // two lists per CU the 128-thread workgroups put four on one (cfg5 at 1e7 photons: 420 -> 380 ms per frame)
+    {
+        int cus = 256, dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        c->rank_block = R > 2 * cus ? 128 : 256;
+        c->rank_fuse = false;
+        if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) c->rank_block = (atoi(e) == 128) ? 128 : 256;
+    }
     const int pairs_per_sync = 8;
     for (;;) {
         for (int k = 0; k < pairs_per_sync; ++k) {
-            HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, 1 << 30, c->d_desc, d_cf, 4096, 256, c->stream));
+            HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, 1 << 30, c->d_desc, d_cf, 4096, c->rank_block, c->stream));
             HIPCHK(c, launch_cs_replace_pool(p, c->hy, c->hcol, c->d_rstates, c->ph, c->rank_stride, R, c->d_desc, d_cf, c->stream));
         }
         HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
@@ -2615,6 +2631,7 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
         counts[r].scatt_cyclosynch_num_ph = f.scatt_num;
         counts[r].n_comptonized = f.n_comptonized;
         v->pending_applied = false;
+        v->rank_current = true;
         if (lists[r].emit_pool) {                                                                 // :853-878
             if (counts[r].scatt_cyclosynch_num_ph > max_photons) {
                 int empty = 0;

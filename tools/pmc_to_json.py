@@ -69,7 +69,8 @@ for sub, want, bytes_note in (("pmc_ranks", "rank_loop_kernel", "ranks"), ("pmc_
     json.dump(out[want], open(os.path.join(dst, "%s_%s_pmc.json" % (tag, want)), "w"), indent=1)
 open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
 for sub, name in (("kt_default", "%s_kernel_stats.csv" % tag), ("kt_list", "%s_list_kernel_stats.csv" % tag),
-                  ("kt_ingest", "%s_ingest_kernel_stats.csv" % tag)):
+                  ("kt_ingest", "%s_ingest_kernel_stats.csv" % tag), ("kt_cfg3", "%s_cfg3_kernel_stats.csv" % tag),
+                  ("kt_cfg5", "%s_cfg5_kernel_stats.csv" % tag)):
     f = stats_file(sub)
     if f:
         shutil.copy(f, os.path.join(dst, name))
@@ -80,4 +81,8 @@ if os.path.exists(t) and os.path.getsize(t) > 0:
 b = os.path.join(src, "bench.json")
 if os.path.exists(b) and os.path.getsize(b) > 0:
     shutil.copy(b, os.path.join(dst, "%s_bench.json" % tag))
+for name in ("bench_cfg3", "kt_cfg5", "kt_default"):
+    b = os.path.join(src, name + ".json")
+    if os.path.exists(b) and os.path.getsize(b) > 0:
+        shutil.copy(b, os.path.join(dst, "%s_%s.json" % (tag, name.replace("kt_cfg5", "bench_cfg5_traced").replace("kt_default", "bench_traced"))))
 print(json.dumps({k: v["traffic_bytes_per_launch"] for k, v in out.items()}))
