@@ -38,6 +38,21 @@ def test_library_exports_every_declared_symbol(engine):
     assert lib.mcrat_hip_strerror(-2) == b"no usable HIP device"
 
 
+def test_library_exports_nothing_the_header_does_not_declare(engine):
+    """-fvisibility=hidden + the header's visibility push: the product library's dynamic symbols are the C ABI and nothing else
+    (the diagnostic entry points exist in the -DMCRAT_DIAG build only)"""
+    import shutil
+    import subprocess
+    from mcrat_amd import build
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("no nm in this image")
+    out = subprocess.run([nm, "-D", "--defined-only", build.LIB], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    extra = {n for n in exported if not n.startswith(("_init", "_fini"))} - set(declared_symbols())
+    assert not extra, sorted(extra)
+
+
 def test_header_is_plain_c_and_layouts_match_binding(engine, tmp_path):
     src = tmp_path / "layout.c"
     src.write_text(r'''
