@@ -417,6 +417,20 @@ int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *ctx);
 int mcrat_hip_propagate_frame(mcrat_hip_ctx *ctx, double *time_now, double remaining_time,
                               uint64_t seed, mcrat_hip_frame_stats *stats);
 
+/* SURVEY.md 8(b)'s `mode` argument.  MCRAT_HIP_MODE_EXACT is mcrat_hip_propagate_frame: the event-driven loop of mcrat.c:761-851,
+ * one scattering per pass per list, comparable pass by pass with the reference.  MCRAT_HIP_MODE_FAST runs every photon through the
+ * frame on its own clock with per-photon keyed random numbers (photons are independent within a frozen frame and exponential free
+ * paths are memoryless): statistically equivalent, NOT sequence-equivalent -- spectra, scattering counts and polarisation agree with
+ * the exact mode within Monte-Carlo error (tests/test_gpu_fast_mode.py), single photons do not.  fast_windows (<= 0: 8) is how often
+ * per frame a photon's cell and optical depth are refreshed besides after its own scatterings; the reference refreshes them whenever
+ * any photon of the rank scatters.  Works on a single list, virtual ranks or a rank pool alike (the lists do not matter to it);
+ * refuses cyclo-synchrotron contexts and an attached shared clock.  stats: iterations = passes of the longest-running workgroup,
+ * photon_steps = free-path draws, frame_scatt_cnt, kn_rejections, num_photons_find_new_element, not_found. */
+#define MCRAT_HIP_MODE_EXACT 0
+#define MCRAT_HIP_MODE_FAST  1
+int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *ctx, double *time_now, double remaining_time, uint64_t seed, int mode, int fast_windows,
+                                   mcrat_hip_frame_stats *stats);
+
 /* the same loop in pieces, for bounded runs (benchmarks, tests, progress logging):
  * begin_frame resets the per-frame state; each run executes at most max_iterations
  * passes (<= 0: until the frame time is used up) and is synchronous on return. */

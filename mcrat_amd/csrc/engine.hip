@@ -78,6 +78,7 @@ struct mcrat_hip_ctx {
     int find_switch = 1;
     RngKey key{0, 0, 0};
     long long frame_photon_steps = 0;
+    void *d_fast = nullptr;           // FAST mode's counters (FastCounts)
     bool pending_applied = false;     // step_locate_sample has applied the pending advance that LoopState still lists
     bool rank_current = false;        // a view whose frame rank_loop_kernel has run: it leaves no pending advance (until the next begin_frame)
 
@@ -228,6 +229,7 @@ static void destroy_view(mcrat_hip_ctx *v)
     // a view owns nothing but its cyclo-synchrotron hook state, a snapshot and its events; the rest are windows into the pool
     if (v->stream) (void)hipStreamSynchronize(v->stream);
     if (v->d_cs_hook) (void)hipFree(v->d_cs_hook);
+    if (v->d_fast) (void)hipFree(v->d_fast);
     if (v->ph_snap) (void)hipFree(v->ph_snap);
     for (hipEvent_t e : v->ev) (void)hipEventDestroy(e);
     if (v->parent && v->view_rank >= 0 && v->view_rank < (int)v->parent->views.size() && v->parent->views[v->view_rank] == v)
@@ -257,6 +259,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->grid_count) (void)hipFree(c->grid_count);
     if (c->d_grid_total) (void)hipFree(c->d_grid_total);
     if (c->d_cs_hook) (void)hipFree(c->d_cs_hook);
+    if (c->d_fast) (void)hipFree(c->d_fast);
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
     if (c->d_hot_table) (void)hipFree(c->d_hot_table);
@@ -2303,6 +2306,53 @@ extern "C" int mcrat_hip_propagate_frame(mcrat_hip_ctx *c, double *time_now, dou
     if (rc) return rc;
     *time_now = local.time_now;
     if (stats) *stats = local;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *c, double *time_now, double remaining_time, uint64_t seed, int mode, int fast_windows,
+                                              mcrat_hip_frame_stats *stats)
+{
+    if (!c || !time_now) return MCRAT_HIP_EINVAL;
+    if (mode == MCRAT_HIP_MODE_EXACT) return mcrat_hip_propagate_frame(c, time_now, remaining_time, seed, stats);
+    if (mode != MCRAT_HIP_MODE_FAST) return MCRAT_HIP_EINVAL;
+    if (!c->have_hydro || !c->have_photons) return MCRAT_HIP_ESTATE;
+    if (c->cfg.cyclosynchrotron_switch) { c->last_error = "FAST mode has no cyclo-synchrotron hooks: use the exact scatter frame"; return MCRAT_HIP_ESTATE; }
+    if (c->sc_world > 0) { c->last_error = "shared clock attached: drive the frame with mcrat_hip_shared_clock_*"; return MCRAT_HIP_ESTATE; }
+    if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && !c->d_hot_table) {
+        c->last_error = "TAU_CALCULATION == TABLE needs mcrat_hip_set_hot_cross_section first";
+        return MCRAT_HIP_ESTATE;
+    }
+    int rc;
+    if (c->frame_open && c->n_ranks == 0 && (rc = flush_pending(c))) return rc;       // what a list-mode run still owes the photons
+    if (!c->d_fast) HIPCHK(c, hipMalloc(&c->d_fast, sizeof(FastCounts)));
+    HIPCHK(c, hipMemsetAsync(c->d_fast, 0, sizeof(FastCounts), c->stream));
+    RngKey key = c->key;
+    key.seed = seed;
+    const int windows = fast_windows > 0 ? fast_windows : 8;
+    FastCounts fc{};
+    if (remaining_time > 0) {
+        HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, key, remaining_time, windows, 1 << 22, static_cast<FastCounts *>(c->d_fast), c->stream));
+        HIPCHK(c, hipMemcpyAsync(&fc, c->d_fast, sizeof fc, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->frame_open = false;
+    c->pending_applied = false;
+    for (mcrat_hip_ctx *v : c->views)
+        if (v) { v->frame_open = false; v->pending_applied = false; v->rank_current = true; }
+    if (fc.unfinished) { c->last_error = "FAST mode: photons left with frame time after 2^22 passes (an optical depth of infinity?)"; return MCRAT_HIP_ESTATE; }
+    if (remaining_time > 0) *time_now += remaining_time;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->iterations = (long long)fc.passes;
+        stats->photon_steps = (long long)fc.photon_steps;
+        stats->frame_scatt_cnt = (long long)fc.scatterings;
+        stats->kn_rejections = (long long)fc.kn_rejections;
+        stats->num_photons_find_new_element = (long long)fc.relocated;
+        stats->not_found = (long long)fc.not_found;
+        stats->last_scattered_index = -1;
+        stats->remaining_time = 0;
+        stats->time_now = *time_now;
+    }
     return MCRAT_HIP_OK;
 }
 

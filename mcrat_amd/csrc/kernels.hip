@@ -1263,6 +1263,134 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     }
 }
 
+// ------------------------------------------------------------------ FAST mode (SURVEY.md section 7, 8b `mode`)
+// Within a frozen hydro frame the photons are mutually independent and exponential free paths are memoryless, so the frame can be run
+// photon by photon instead of event by event: every lane takes ONE photon through the whole frame on its own clock -- locate, optical
+// depth, free-path draw, advance, scatter, again -- with per-photon keyed random numbers.  Statistically equivalent to the loop of
+// mcrat.c:761-851, not sequence-equivalent: which photon scatters when is no longer a property of the list.  What the reference does to
+// a photon between its own scatterings is kept in distribution: it re-locates the photon and redraws its free path whenever ANY photon
+// of the rank scatters, i.e. the cell and optical depth a flight uses are refreshed a number of times per frame; here they are
+// refreshed at every boundary of `windows` equal time windows (and after each own scattering).  The same device functions as the
+// exact loop do the work (fast_one, slow_one, scatter_core, commit_scatter), so the physics is the exact mode's line for line.
+// A pass of the workgroup: phase A, every lane its own photon (streaming, like step_kernel's phase 1 + slow path); the lanes whose
+// photon scatters in this pass queue it in LDS (ballot-free: one LDS atomic each, few per pass); phase B, the queue worked off with dense
+// lanes -- lane j scatters queue entry j -- so that the 3 500-instruction event code runs with full lanes where there are many events.
+constexpr int FAST_BLOCK = 256;
+constexpr uint32_t RNG_FAST_FREEPATH = 8u;
+
+template <int DIMS, int GEOM, bool STOKES>
+__global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph, HydroDev hy, RngKey key, double remaining_time, int windows,
+                                                                int max_passes, FastCounts *__restrict__ counts)
+{
+    __shared__ int s_q[FAST_BLOCK];
+    __shared__ int s_nq;
+    __shared__ unsigned long long s_cnt[6];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * FAST_BLOCK + tid;
+    const bool have = i < ph.n;
+    const unsigned fl0 = have ? (unsigned)ph.flags[i] : 0u;
+    const bool valid = have && (fl0 & FLAG_VALID);
+    const bool moves = (fl0 & FLAG_MOVES) != 0;
+    const double window = remaining_time / (double)windows;
+    double t_left = remaining_time, w_left = window;
+    bool done = !valid || !(remaining_time > 0);
+    int relocated = 0, not_found = 0;
+    unsigned steps = 0, scatt = 0, rej = 0;
+    if (tid < 6) s_cnt[tid] = 0;
+    int pass = 0;
+    for (; pass < max_passes; ++pass) {
+        if (tid == 0) s_nq = 0;
+        __syncthreads();
+        if (!done) {
+            // the photon's state lives in the columns between passes (61 B in, 24 B out per pass, like step_kernel): nothing but the
+            // two clocks stays in registers across phase B, whose event code needs them all
+            const unsigned fl = ph.flags[i];
+            int cell = ph.idx[i];
+            double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
+            const double ntau = ph.ntau[i];
+            const Philox4 blk = keyed_block(key.seed, (uint64_t)pass, (uint32_t)i + key.slot_base, RNG_FAST_FREEPATH, key.stream);
+            const uint64_t bits = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
+            int queue, bucket;
+            double a0, a1, a2;
+            double t = fast_one<DIMS, GEOM, false>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, queue, bucket, a0, a1, a2);
+            const bool inside = (cell != -1) && phys::in_domain<DIMS>(hy, a0, a1, a2);
+            if (pass == 0 && inside && queue != 1) {                      // find_nearest_grid_switch = 1 on a new frame (mcrat.c:756)
+                queue = 1;
+                bucket = phys::grid_bucket(hy.grid, a0, a1, a2);
+            }
+            if (!inside) cell = -1;                                       // (fast_one has stored it, mclib.c:592)
+            if (queue) {
+                t = slow_one<DIMS, GEOM>(ph, hy, i, queue == 1, bucket, true, bits, relocated, not_found);
+                cell = ph.idx[i];
+            }
+            steps += 1;
+            double adv;
+            if (cell == -1) {                                             // outside the frame's cells: streams to the end of the frame
+                adv = t_left;
+                t_left = 0;
+                done = true;
+            } else {
+                const double limit = fmin(t_left, w_left);
+                if (t < limit) {
+                    adv = t;
+                    t_left -= adv; w_left -= adv;
+                    s_q[atomicAdd(&s_nq, 1)] = i;                         // scatters at the end of this flight: phase B
+                } else if (limit == t_left) {
+                    adv = limit;
+                    t_left = 0;
+                    done = true;
+                } else {
+                    adv = limit;
+                    t_left -= adv;
+                    w_left = window;                                      // a window boundary: the next pass re-locates and redraws
+                }
+            }
+            if (moves) {
+                const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
+                ph.r0[i] = r0 + u0 * adv; ph.r1[i] = r1 + u1 * adv; ph.r2[i] = r2 + u2 * adv;
+            }
+        }
+        __syncthreads();
+        const int nq = s_nq;
+        for (int j = tid; j < nq; j += FAST_BLOCK) {                      // phase B: one queued photon per lane
+            const int k = s_q[j];
+            const int kc = ph.idx[k];
+            double p[4] = {ph.p0[k], ph.p1[k], ph.p2[k], ph.p3[k]};
+            double pc[4] = {ph.c0[k], ph.c1[k], ph.c2[k], ph.c3[k]};
+            const double r[3] = {ph.r0[k], ph.r1[k], ph.r2[k]};
+            double s[4] = {1, 0, 0, 0};
+            if constexpr (STOKES) { s[0] = ph.s0[k]; s[1] = ph.s1[k]; s[2] = ph.s2[k]; s[3] = ph.s3[k]; }
+            const unsigned kf = ph.flags[k];
+            double fluid_temp, tau_new;
+            if (scatter_core<DIMS, GEOM, STOKES, false>(hy, (LoopState *)nullptr, key, (unsigned long long)pass, (uint32_t)k + key.slot_base, kc, r, p, pc, s,
+                                                        fluid_temp, tau_new)) {
+                commit_scatter<STOKES>(ph, k, p, pc, s, r, tau_new, kf);
+                scatt += 1;
+            } else {
+                rej += 1;
+            }
+        }
+        if (!__syncthreads_or(!done)) { pass += 1; break; }
+    }
+    // the workgroup's counters
+    unsigned long long v[6] = {(unsigned long long)steps, (unsigned long long)scatt, (unsigned long long)rej, (unsigned long long)relocated, (unsigned long long)not_found, (valid && !done) ? 1ull : 0ull};
+    for (int c = 0; c < 6; ++c) {
+        unsigned long long x = v[c];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+        if ((tid & 63) == 0 && x) atomicAdd(&s_cnt[c], x);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&counts->photon_steps, s_cnt[0]);
+        atomicAdd(&counts->scatterings, s_cnt[1]);
+        atomicAdd(&counts->kn_rejections, s_cnt[2]);
+        atomicAdd(&counts->relocated, s_cnt[3]);
+        atomicAdd(&counts->not_found, s_cnt[4]);
+        atomicAdd(&counts->unfinished, s_cnt[5]);
+        atomicMax(&counts->passes, (unsigned long long)pass);
+    }
+}
+
 // ------------------------------------------------------------------ one list over several GPUs, one clock
 // (device_types.hpp, "ScProposal").  A round is: step_kernel (returns at once in a midpass round) ->
 // sc_midpass_kernel (returns at once unless midpass) -> sc_propose_kernel -> all-gather of the proposals (host:
@@ -1763,6 +1891,17 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256, false>, rank_loop_kernel<DV, GV, true, false, 256, false>, 256);
             else launch(rank_loop_kernel<DV, GV, false, true, 256, false>, rank_loop_kernel<DV, GV, false, false, 256, false>, 256);
         }
+    });
+}
+
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream)
+{
+    const int blocks = (ph.n + FAST_BLOCK - 1) / FAST_BLOCK;
+    return dispatch(kc, [&](auto D, auto G) {
+        constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
+        if (kc.stokes) fast_frame_kernel<DV, GV, true><<<dim3(blocks), dim3(FAST_BLOCK), 0, stream>>>(ph, hy, key, remaining_time, windows, max_passes, counts);
+        else fast_frame_kernel<DV, GV, false><<<dim3(blocks), dim3(FAST_BLOCK), 0, stream>>>(ph, hy, key, remaining_time, windows, max_passes, counts);
     });
 }
 

@@ -32,6 +32,10 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, struct CsFrame *cs, long long max_passes, int block,
                             hipStream_t stream);
+// FAST mode: every photon through the whole frame on its own clock (kernels.hip, fast_frame_kernel); the counters add up over launches
+struct FastCounts { unsigned long long photon_steps, scatterings, kn_rejections, relocated, not_found, unfinished, passes; };
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream);
 // one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);

@@ -18,6 +18,8 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream);
 int step_grid_blocks(int n_pad);
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);
@@ -38,6 +40,8 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream);
 }  // namespace tau_direct_d1
 
 namespace tau_direct_d2 {
@@ -52,6 +56,8 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream);
 }  // namespace tau_direct_d2
 
 namespace tau_table_d0 {
@@ -66,6 +72,8 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream);
 }  // namespace tau_table_d0
 
 namespace tau_table_d1 {
@@ -80,6 +88,8 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream);
 }  // namespace tau_table_d1
 
 namespace tau_table_d2 {
@@ -94,6 +104,8 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream);
 }  // namespace tau_table_d2
 
 #define MCRAT_ROUTE(fn, ...)                                                                     \
@@ -150,6 +162,12 @@ hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, cons
                          hipStream_t stream)
 {
     return tau_direct_d0::launch_lookup(kc, hy, n, a0, a1, a2, out, stream);
+}
+
+hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
+                             int max_passes, FastCounts *counts, hipStream_t stream)
+{
+    MCRAT_ROUTE(launch_fast_frame, kc, ph, hy, key, remaining_time, windows, max_passes, counts, stream);
 }
 
 }  // namespace mcrat

@@ -172,6 +172,7 @@ SCIENCE, CYLINDRICAL_OUTFLOW, SPHERICAL_OUTFLOW, STRUCTURED_SPHERICAL_OUTFLOW = 
 
 # every symbol include/mcrat_hip.h declares: (restype, argtypes)
 _ctx = C.c_void_p
+MODE_EXACT, MODE_FAST = 0, 1
 SYMBOLS = {
     "mcrat_hip_init": (C.c_int, [C.POINTER(_ctx), C.POINTER(Config)]),
     "mcrat_hip_destroy": (None, [_ctx]),
@@ -209,6 +210,7 @@ SYMBOLS = {
     "mcrat_hip_get_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
+    "mcrat_hip_propagate_frame_mode": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.c_int, C.c_int, C.POINTER(FrameStats)]),
     "mcrat_hip_begin_frame": (C.c_int, [_ctx, C.c_uint64, C.c_double, C.c_double]),
     "mcrat_hip_run": (C.c_int, [_ctx, C.c_longlong, C.POINTER(FrameStats)]),
     "mcrat_hip_snapshot_photons": (C.c_int, [_ctx]),
@@ -629,6 +631,14 @@ class Engine:
         tn = C.c_double(time_now)
         self._check(self.lib.mcrat_hip_propagate_frame(self.ctx, C.byref(tn), float(remaining_time), int(seed), C.byref(st)),
                     "propagate_frame")
+        return tn.value, st
+
+    def propagate_frame_fast(self, time_now, remaining_time, seed, windows=0):
+        """MCRAT_HIP_MODE_FAST: every photon through the frame on its own clock (statistically, not sequence-, equivalent)"""
+        st = FrameStats()
+        tn = C.c_double(time_now)
+        self._check(self.lib.mcrat_hip_propagate_frame_mode(self.ctx, C.byref(tn), float(remaining_time), int(seed), MODE_FAST, int(windows),
+                                                            C.byref(st)), "propagate_frame_mode")
         return tn.value, st
 
     def snapshot_photons(self):

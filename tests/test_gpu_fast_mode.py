@@ -1,0 +1,153 @@
+"""MCRAT_HIP_MODE_FAST (mcrat_hip_propagate_frame_mode): every photon through the frame on
+its own clock with per-photon keyed random numbers.  It is statistically, not sequence-, equivalent to the event-driven loop of
+mcrat.c:761-851, so it is held against the EXACT mode (itself parity-tested against the oracle) through the distribution gates
+BASELINE.md names -- scatterings per photon, the energy spectrum, the Stokes parameters Q and U -- within Monte-Carlo error, and through
+what must hold exactly: the clock, conservation, null slots, determinism."""
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mcrat_amd import engine
+    engine.load_library()
+    return engine
+
+
+def _run(hip, frame, ph, cfg, mode, seed, windows=0, **kw):
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], **kw)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    rem = 1.0 / frame["fps"]
+    if mode == "exact":
+        tn, st = e.propagate_frame(3.0, rem, seed)
+    else:
+        tn, st = e.propagate_frame_fast(3.0, rem, seed, windows)
+    out = e.get_photons()
+    e.close()
+    return tn, st, out
+
+
+def _moments(ph0, o):
+    n = len(o["p0"])
+    ns = o["num_scatt"] - ph0["num_scatt"]
+    loge = np.log(o["p0"])
+    return dict(ns=(ns.mean(), ns.std() / np.sqrt(n)), loge=(loge.mean(), loge.std() / np.sqrt(n)),
+                q=(o["s1"].mean(), o["s1"].std() / np.sqrt(n)), u=(o["s2"].mean(), o["s2"].std() / np.sqrt(n)))
+
+
+def _spectrum_chi2(ph0, a, b, bins=24):
+    """chi^2 per bin between the energy spectra of the photons that scattered"""
+    la, lb = np.log(a["p0"][a["num_scatt"] > ph0["num_scatt"]]), np.log(b["p0"][b["num_scatt"] > ph0["num_scatt"]])
+    lo, hi = min(la.min(), lb.min()), max(la.max(), lb.max())
+    ha, _ = np.histogram(la, bins=bins, range=(lo, hi))
+    hb, _ = np.histogram(lb, bins=bins, range=(lo, hi))
+    ok = (ha + hb) >= 20
+    assert ok.sum() >= 6
+    return (((ha - hb) ** 2) / np.maximum(1, ha + hb))[ok].sum() / ok.sum()
+
+
+@pytest.mark.parametrize("case", ["cfg2-cylindrical-stokes", "cfg3-spherical-stokes", "cfg2-cylindrical-hot"])
+def test_fast_mode_agrees_with_exact_mode_in_distribution(hip, case):
+    if case == "cfg2-cylindrical-stokes":
+        frame, ph, cfg = synth.config2(n_photons=200_000, nzc=32, stokes=1, lumi=3e52)
+    elif case == "cfg3-spherical-stokes":
+        frame, ph, cfg = synth.config3(n_photons=150_000, nr=1024, nth=256, stokes=1, lumi=3e52)
+    else:                                                         # T' > 1e7 K: the Maxwell-Juettner sampler, Klein-Nishina rejections
+        frame, ph, cfg = synth.config2(n_photons=100_000, nzc=32, stokes=0, lumi=1e54, r_inj=1e11)
+    _, st_e, ex = _run(hip, frame, ph, cfg, "exact", 777, virtual_rank_photons=1000)
+    _, st_f, fa = _run(hip, frame, ph, cfg, "fast", 778)
+    n = len(ph["p0"])
+    assert st_e.frame_scatt_cnt > 0.1 * n                          # a frame in which the gates mean something
+    assert int((fa["num_scatt"] - ph["num_scatt"]).sum()) == st_f.frame_scatt_cnt
+    me, mf = _moments(ph, ex), _moments(ph, fa)
+    for k in ("ns", "loge") + (("q", "u") if cfg["stokes"] else ()):
+        z = (me[k][0] - mf[k][0]) / np.hypot(me[k][1], mf[k][1])
+        assert abs(z) < 4.0, (case, k, me[k], mf[k], z)            # within Monte-Carlo error
+    assert _spectrum_chi2(ph, ex, fa) < 2.0
+    # the rejection rate of the Klein-Nishina test is a property of the frame, not of the mode
+    re, rf = st_e.kn_rejections / st_e.frame_scatt_cnt, st_f.kn_rejections / st_f.frame_scatt_cnt
+    assert abs(re - rf) < 4 * np.sqrt((re + rf + 1e-9) / st_e.frame_scatt_cnt) + 1e-4
+    # and an exact run with another seed is as far from the first as FAST is (the gates are not vacuous)
+    _, _, ex2 = _run(hip, frame, ph, cfg, "exact", 999, virtual_rank_photons=1000)
+    assert not np.array_equal(ex2["p0"], ex["p0"])
+    assert _spectrum_chi2(ph, ex, ex2) < 2.0
+
+
+def test_fast_mode_bookkeeping(hip):
+    frame, ph, cfg = synth.config2(n_photons=60_000, nzc=16, stokes=1, lumi=1e52)
+    n = len(ph["p0"])
+    ph = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in ph.items()}
+    null = np.arange(0, n, 97)
+    ph["weight"][null] = 0.0                                        # null slots (setNullPhoton, photons.c:210-250): no weight, no cell
+    ph["type"][null] = b"N"
+    ph["nearest_block_index"][null] = -1
+    far = np.arange(5, n, 211)                                      # photons about to leave the domain
+    ph["r2"][far] = 2.49999e13
+    ph["p3"][far] = np.abs(ph["p0"][far]); ph["p1"][far] = 0; ph["p2"][far] = 0
+    tn, st, out = _run(hip, frame, ph, cfg, "fast", 5, windows=4)
+    rem = 1.0 / frame["fps"]
+    assert tn == 3.0 + rem and st.remaining_time == 0.0 and st.time_now == tn
+    assert np.array_equal(out["weight"], ph["weight"]) and np.array_equal(out["type"], ph["type"])
+    for k in ("r0", "r1", "r2", "p0", "p1", "p2", "p3"):
+        assert np.array_equal(out[k][null], ph[k][null]), k        # untouched
+    assert (out["num_scatt"] >= ph["num_scatt"]).all()
+    assert int((out["num_scatt"] - ph["num_scatt"]).sum()) == st.frame_scatt_cnt > 1000
+    nrm = np.sqrt(out["p1"] ** 2 + out["p2"] ** 2 + out["p3"] ** 2)
+    assert np.allclose(nrm, out["p0"], rtol=1e-12, atol=0)
+    assert (out["s0"] == 1).all() and (out["s1"] ** 2 + out["s2"] ** 2 + out["s3"] ** 2 <= 1 + 1e-9).all()
+    gone = np.setdiff1d(far, null)
+    assert (out["nearest_block_index"][gone] == -1).all()           # mclib.c:592
+    # a photon that never scattered flew straight for the whole frame
+    same = (out["num_scatt"] == ph["num_scatt"]) & (ph["weight"] != 0)
+    d = synth.C_LIGHT * rem
+    for r, p in (("r0", "p1"), ("r1", "p2"), ("r2", "p3")):
+        assert np.allclose(out[r][same], ph[r][same] + d * ph[p][same] / ph["p0"][same], rtol=1e-12, atol=1e-3)
+    assert st.photon_steps >= int((ph["weight"] != 0).sum()) and st.iterations >= 4
+
+
+def test_fast_mode_is_deterministic_and_ignores_the_list_structure(hip):
+    frame, ph, cfg = synth.config3(n_photons=40_000, nr=512, nth=128, stokes=1, lumi=3e52)
+    a = _run(hip, frame, ph, cfg, "fast", 11, windows=8)
+    b = _run(hip, frame, ph, cfg, "fast", 11, windows=8)
+    c = _run(hip, frame, ph, cfg, "fast", 11, windows=8, virtual_rank_photons=1000)      # the lists do not matter to it
+    d = _run(hip, frame, ph, cfg, "fast", 12, windows=8)
+    for k in a[2]:
+        assert np.array_equal(a[2][k], b[2][k]) and np.array_equal(a[2][k], c[2][k]), k
+    assert a[1].frame_scatt_cnt == b[1].frame_scatt_cnt == c[1].frame_scatt_cnt
+    assert not np.array_equal(a[2]["p0"], d[2]["p0"])
+    # more windows: more re-locations and draws, the same physics
+    e = _run(hip, frame, ph, cfg, "fast", 11, windows=32)
+    assert e[1].photon_steps > a[1].photon_steps
+    me, mf = _moments(ph, a[2]), _moments(ph, e[2])
+    assert abs(me["ns"][0] - mf["ns"][0]) < 4 * np.hypot(me["ns"][1], mf["ns"][1])
+
+
+def test_mode_argument(hip):
+    import ctypes as C
+    frame, ph, cfg = synth.config1(n_photons=3000)
+    rem = 1.0 / frame["fps"]
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    tn, st = C.c_double(0.0), hip.FrameStats()
+    assert e.lib.mcrat_hip_propagate_frame_mode(e.ctx, C.byref(tn), rem, 42, hip.MODE_EXACT, 0, C.byref(st)) == 0
+    via_mode = e.get_photons()
+    e.set_photons(ph)
+    tn2, st2 = e.propagate_frame(0.0, rem, 42)
+    plain = e.get_photons()
+    assert tn.value == tn2 and st.frame_scatt_cnt == st2.frame_scatt_cnt
+    for k in plain:
+        assert np.array_equal(plain[k], via_mode[k]), k            # MODE_EXACT is mcrat_hip_propagate_frame
+    assert e.lib.mcrat_hip_propagate_frame_mode(e.ctx, C.byref(tn), rem, 42, 7, 0, C.byref(st)) == -1      # MCRAT_HIP_EINVAL
+    e.close()
+    cs = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], cyclosynchrotron=1)
+    cs.set_hydro(frame)
+    cs.set_photons(ph)
+    with pytest.raises(hip.McratHipError, match="cyclo-synchrotron"):
+        cs.propagate_frame_fast(0.0, rem, 1)
+    cs.close()
