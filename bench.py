@@ -342,6 +342,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=300, help="list-mode passes bracketed by HIP events for the roofline")
     ap.add_argument("--other-mode", type=int, default=1, help="also measure the other run shape briefly")
+    ap.add_argument("--fast-windows", type=int, default=8, help="FAST mode beside the exact headline: refreshes per frame (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shared-clock-rounds", type=int, default=300,
                     help="also time this many rounds of the one-list-over-all-GPUs mode (0: skip)")
@@ -605,6 +606,70 @@ def main():
                       "ms_per_step": dt_s * 1e3 / steps, "photon_steps_per_s": ps_s / dt_s}
         except Exception as ex:
             strong = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+    # FAST mode beside the exact headline, never instead of it (mcrat_hip_propagate_frame_mode): the same photons and
+    # frame, every photon on its own clock.  Statistically equivalent to the exact loop (tests/test_gpu_fast_mode.py), not sequence-equivalent.
+    fast = None
+    if args.mode == "ranks" and args.other_mode and args.fast_windows > 0:
+        try:
+            def run_fast(e, k, seed0):
+                ev = ps = 0
+                for j in range(k):
+                    e.restore_photons()
+                    _, st = e.propagate_frame_fast(0.0, remaining, seed0 + j, args.fast_windows)
+                    ev += st.frame_scatt_cnt
+                    ps += st.photon_steps
+                return ev, ps
+            e = make_engine("list")
+            e.snapshot_photons()
+            run_fast(e, warmup, SEED + 7000)
+            sync()
+            t0 = time.perf_counter()
+            ev_f, ps_f = run_fast(e, steps, SEED + 8000)
+            sync()
+            dt_f = time.perf_counter() - t0
+            e.close()
+            if dist is not None:
+                tt = torch.tensor([dt_f], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                cc = torch.tensor([float(ev_f), float(ps_f)], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+                dt_f, ev_f, ps_f = float(tt.item()), float(cc[0].item()), float(cc[1].item())
+            fast = {"mode": "FAST", "note": "the headline's photons and frame with MCRAT_HIP_MODE_FAST: one lane per photon through the whole frame on its "
+                                            "own clock, per-photon keyed random numbers, cell and optical depth refreshed %d times per frame and after each own "
+                                            "scattering; statistically (not sequence-) equivalent to the exact loop: scatterings per photon, spectrum, Q/U agree "
+                                            "within Monte-Carlo error (tests/test_gpu_fast_mode.py).  Reported beside the exact headline, not instead of it"
+                                            % args.fast_windows,
+                    "windows": args.fast_windows, "value": ev_f / dt_f, "unit": "scatter-events/s", "n_gpus": world, "steps": steps,
+                    "ms_per_step": dt_f * 1e3 / steps, "photon_steps_per_s": ps_f / dt_f, "scatter_events": ev_f}
+            if rank == 0 and world == 1 and args.config == "cfg2":
+                dframe, dph, dcfg = synth.config2(n_photons=n, seed=SEED, nzc=args.nzc, stokes=args.stokes, lumi=3.6e52)
+                res = {}
+                for which in ("exact", "fast"):
+                    d = engine.Engine(dcfg["dimensions"], dcfg["geometry"], dcfg["stokes"], device=local_rank, stream=stream, rng_stream=first_stream,
+                                      virtual_rank_photons=1000 if which == "exact" else 0)
+                    d.set_hydro(dframe)
+                    d.set_photons(dph)
+                    d.snapshot_photons()
+                    best = None
+                    for j in range(3):
+                        d.restore_photons()
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        if which == "exact":
+                            _, st = d.propagate_frame(0.0, remaining, SEED + j)
+                        else:
+                            _, st = d.propagate_frame_fast(0.0, remaining, SEED + j, args.fast_windows)
+                        torch.cuda.synchronize()
+                        dtd = time.perf_counter() - t0
+                        if best is None or dtd < best[0]:
+                            best = (dtd, int(st.frame_scatt_cnt))
+                    d.close()
+                    res[which] = {"ms_per_frame": best[0] * 1e3, "scatter_events": best[1], "scatter_events_per_s": best[1] / best[0]}
+                fast["dense_frame"] = {"workload": "the same mesh and photons with L = 3.6e52 erg/s (120 x denser): ~0.4 scatterings per photon and frame",
+                                       "exact": res["exact"], "fast": res["fast"]}
+        except Exception as ex:
+            fast = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     other = None
     if rank == 0 and world == 1 and args.other_mode:
@@ -871,6 +936,7 @@ def main():
             "loop_passes": main_res["passes"],
             "roofline": main_res["roofline"],
             "strong": strong,
+            "fast_mode": fast,
             "other_mode": other,
             "pcie_inclusive": pcie,
             "ingest": ingest,

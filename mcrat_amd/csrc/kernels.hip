@@ -1275,11 +1275,14 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
 // A pass of the workgroup: phase A, every lane its own photon (streaming, like step_kernel's phase 1 + slow path); the lanes whose
 // photon scatters in this pass queue it in LDS (ballot-free: one LDS atomic each, few per pass); phase B, the queue worked off with dense
 // lanes -- lane j scatters queue entry j -- so that the 3 500-instruction event code runs with full lanes where there are many events.
-constexpr int FAST_BLOCK = 256;
+#ifndef FAST_BLOCK_THREADS
+#define FAST_BLOCK_THREADS 256
+#endif
+constexpr int FAST_BLOCK = FAST_BLOCK_THREADS;
 constexpr uint32_t RNG_FAST_FREEPATH = 8u;
 
 template <int DIMS, int GEOM, bool STOKES>
-__global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph, HydroDev hy, RngKey key, double remaining_time, int windows,
+__global__ __launch_bounds__(FAST_BLOCK, FAST_BLOCK >= 512 ? 2 : 2) void fast_frame_kernel(PhotonDev ph, HydroDev hy, RngKey key, double remaining_time, int windows,
                                                                 int max_passes, FastCounts *__restrict__ counts)
 {
     __shared__ int s_q[FAST_BLOCK];
