@@ -151,3 +151,31 @@ def test_mode_argument(hip):
     with pytest.raises(hip.McratHipError, match="cyclo-synchrotron"):
         cs.propagate_frame_fast(0.0, rem, 1)
     cs.close()
+
+
+def test_fast_mode_on_a_rank_pool(hip):
+    """the lists of a rank pool in one launch: every list's photons advance by the frame, closed windows stay empty"""
+    frame, ph, cfg = synth.config2(n_photons=30_000, nzc=16, stokes=0, lumi=3e52)
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(4, 12_000)
+    cuts = [(0, 9_000), (9_000, 20_500), (20_500, 30_000)]                  # list 3 stays empty
+    views = [pool.pool_rank(r, 40 + r) for r in range(4)]
+    for v, (lo, hi) in zip(views, cuts):
+        v.set_photons({k: (a[lo:hi].copy() if isinstance(a, np.ndarray) else a) for k, a in ph.items()})
+    rem = 1.0 / frame["fps"]
+    tn, st = pool.propagate_frame_fast(1.0, rem, 21)
+    assert tn == 1.0 + rem and st.frame_scatt_cnt > 3000
+    total = 0
+    for v, (lo, hi) in zip(views, cuts):
+        out = v.get_photons()
+        assert len(out["p0"]) == hi - lo
+        assert np.array_equal(out["weight"], ph["weight"][lo:hi])
+        ns = out["num_scatt"] - ph["num_scatt"][lo:hi]
+        assert (ns >= 0).all()
+        total += int(ns.sum())
+        moved = np.sqrt((out["r0"] - ph["r0"][lo:hi]) ** 2 + (out["r1"] - ph["r1"][lo:hi]) ** 2 + (out["r2"] - ph["r2"][lo:hi]) ** 2)
+        assert np.allclose(moved[ns == 0], synth.C_LIGHT * rem, rtol=1e-9)
+    assert total == st.frame_scatt_cnt
+    assert pool.pool_summaries()[3].list_capacity == 0
+    pool.close()

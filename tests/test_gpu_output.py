@@ -156,7 +156,7 @@ def test_device_streamed_checkpoint_headers_in_the_three_cases_of_saveCheckpoint
     assert first == struct.pack("=i", 16) + b"c" + struct.pack("=iii", 200, 203, 257) + struct.pack("=d", 51.4) + struct.pack("=i", 3000) + body
     assert not old.exists()                                                  # "cp" of a file that did not exist yet
     assert save(200, 203, 258, 51.6, 3000) == 0
-    assert old.read_bytes() == first and path.read_bytes()[9:21] == struct.pack("=iii", 200, 203, 258)
+    assert old.read_bytes() == first and path.read_bytes()[5:17] == struct.pack("=iii", 200, 203, 258)
     # (2) scatt_frame == frame: the previous file is removed ("rm"), no _old is made; same CONTINUE header
     os.remove(old)
     assert save(300, 303, 300, 60.0, 3000) == 0
