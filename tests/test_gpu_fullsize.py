@@ -148,3 +148,66 @@ def test_one_list_full_size(hip):
     r.run(1)
     assert np.array_equal(r.get_photons()["nearest_block_index"], loc)
     assert first.iterations == 1
+
+
+def test_cfg3_at_its_full_ten_million_photons_as_a_rank_pool(hip):
+    """BASELINE.json configs[2] at full size: 10^7 photons on the 1 048 576-cell spherical frame, Stokes on, as the rank pool bench.py --config cfg3
+    runs (10 246 adopted ranks of ~976 photons, each with its own stream and seed): the invariants of this file on every list's photons, the
+    per-list statistics adding up, and FAST mode on the same pool within Monte-Carlo error of the exact frame"""
+    n = 10_000_000
+    frame, ph, cfg = synth.config3(n_photons=n)
+    assert frame["num_elements"] == 1048576 and len(ph["p0"]) == n
+    rem = 1.0 / frame["fps"]
+    per = 976
+    n_lists = int(round(n / per))
+    rng = np.random.default_rng(3)
+    lens = np.full(n_lists, per) + rng.integers(-40, 41, n_lists)
+    lens[-1] += n - int(lens.sum())
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    assert offs[-1] == n and lens.min() > 0
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(n_lists, int(lens.max()))
+    views = []
+    for r in range(n_lists):
+        v = pool.pool_rank(r, 1000 + r)
+        v.set_photons({k: (a[offs[r]:offs[r + 1]] if isinstance(a, np.ndarray) else a) for k, a in ph.items()})
+        views.append(v)
+    pool.snapshot_photons()
+    pool.begin_frame(20261004, 2.0, rem)
+    st = pool.run(0)
+    assert st.remaining_time == 0.0 and st.not_found == 0 and st.frame_scatt_cnt > 50_000
+    summ = pool.pool_summaries()
+    assert sum(s.list_capacity for s in summ) == n
+    # the pool's photons, list by list, in the order they went in
+    cols = {k: [] for k in ("p0", "p1", "p2", "p3", "r0", "r1", "r2", "s0", "s1", "s2", "s3", "num_scatt", "weight", "type", "comv_p0")}
+    for v in views[:: max(1, n_lists // 400)]:                        # every 25th list in full (the copies are what takes time here)
+        o = v.get_photons()
+        for k in cols:
+            cols[k].append(o[k])
+    sel = np.concatenate([np.arange(offs[r], offs[r + 1]) for r in range(0, n_lists, max(1, n_lists // 400))])
+    got = {k: np.concatenate(v) for k, v in cols.items()}
+    assert np.array_equal(got["weight"], ph["weight"][sel]) and np.array_equal(got["type"], ph["type"][sel])
+    for k in ("p0", "p1", "p2", "p3", "r0", "r1", "r2", "comv_p0"):
+        assert np.isfinite(got[k]).all(), k
+    nrm = np.sqrt(got["p1"] ** 2 + got["p2"] ** 2 + got["p3"] ** 2)
+    assert np.allclose(nrm, got["p0"], rtol=1e-12, atol=0)
+    assert (got["num_scatt"] >= ph["num_scatt"][sel]).all()
+    assert (got["s0"] == 1).all() and (got["s1"] ** 2 + got["s2"] ** 2 + got["s3"] ** 2 <= 1 + 1e-9).all()
+    per_list = np.array([pool.rank_stats(r).frame_scatt_cnt for r in range(0, n_lists, max(1, n_lists // 400))])
+    ns_exact = got["num_scatt"] - ph["num_scatt"][sel]
+    assert int(ns_exact.sum()) == int(per_list.sum())
+    # deterministic: the same frame again from the snapshot, bit for bit
+    pool.restore_photons()
+    pool.begin_frame(20261004, 2.0, rem)
+    st2 = pool.run(0)
+    assert (st2.iterations, st2.frame_scatt_cnt, st2.num_photons_find_new_element) == (st.iterations, st.frame_scatt_cnt, st.num_photons_find_new_element)
+    again = views[0].get_photons()
+    first = {k: got[k][: lens[0]] for k in ("p0", "r0", "s1")}
+    for k in first:
+        assert np.array_equal(again[k], first[k]), k
+    # FAST mode on the same 10^7 photons: the same number of scatterings within Monte-Carlo error
+    pool.restore_photons()
+    _, stf = pool.propagate_frame_fast(2.0, rem, 77)
+    assert abs(stf.frame_scatt_cnt - st.frame_scatt_cnt) < 6 * np.sqrt(st.frame_scatt_cnt) + 1e-3 * st.frame_scatt_cnt
+    pool.close()
