@@ -3,7 +3,9 @@ Gamma_0 = 100, L = 3e50 erg/s, p = 4) run end to end on the device: a PLUTO-like
 analytic jet every hydro frame (SIMULATION_TYPE = STRUCTURED_SPHERICAL_OUTFLOW), photons injected deep below the photosphere,
 propagated frame by frame (phMinMax -> slab ingest -> loop) until they stream freely, then the polarisation degree against
 the viewing angle.  A stress run of every stage, and a physics sanity check: Pi ~ 0 inside the core, a few per cent around
-theta_v ~ theta_j, sum(U) ~ 0.      python3 tools/lundman_run.py [photons] [frames]"""
+theta_v ~ theta_j, sum(U) ~ 0.      python3 tools/lundman_run.py [photons] [frames]
+MODE=fast in the environment runs every frame with MCRAT_HIP_MODE_FAST (WINDOWS refreshes per frame, default 8): the same table within its
+errors is the FAST mode's global check (profiles/r02_lundman_fast.txt beside profiles/r02_lundman_exact.txt)."""
 import os
 import sys
 import time
@@ -16,6 +18,7 @@ from mcrat_amd import engine, synth  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 FRAMES = int(sys.argv[2]) if len(sys.argv) > 2 else 420
 FPS, THETA_J, LUMI = 5.0, 0.1, 3e50
+FAST, WINDOWS = os.environ.get("MODE", "exact") == "fast", int(os.environ.get("WINDOWS", "8"))
 # the photosphere of the flow line at angle theta is r_ph = L sigma_T / (8 pi m_p c^3 eta^3), eta = Gamma_0 / sqrt(1 + (theta/theta_j)^2p):
 # 1.8e11 cm on the axis, 5e12 cm at 1.3 theta_j, beyond the 2.5e13 cm domain from 1.6 theta_j on (the manual's remark, :566).  The
 # slow, dense wings cost ~1e3-1e4 scatterings per photon, so the run injects within THETA_MAX and above every flow line's saturation radius
@@ -35,7 +38,10 @@ time_now, events, steps, quiet = 0.0, 0, 0, 0
 for k in range(FRAMES):
     mm = e.ph_minmax()
     cells, ef, _ = e.ingest(raw, dict(r_inj=R_INJ, ph_inj_switch=0, min_r=mm[0], max_r=mm[1], min_theta=mm[2], max_theta=mm[3], fps=FPS, **DOM), jet)
-    time_now, st = e.propagate_frame(time_now, (k + 1) / FPS - time_now, 5000 + k)
+    if FAST:
+        time_now, st = e.propagate_frame_fast(time_now, (k + 1) / FPS - time_now, 5000 + k, WINDOWS)
+    else:
+        time_now, st = e.propagate_frame(time_now, (k + 1) / FPS - time_now, 5000 + k)
     events += st.frame_scatt_cnt
     steps += st.photon_steps
     quiet = quiet + 1 if st.frame_scatt_cnt == 0 else 0
@@ -48,6 +54,7 @@ for k in range(FRAMES):
 wall = time.perf_counter() - t0
 out = e.get_output()
 e.close()
+print("mode: %s" % ("FAST, %d windows per frame" % WINDOWS if FAST else "EXACT (1000-photon lists)"))
 print("total: %d scatterings, %.3e photon-steps, %d frames in %.1f s wall (ingest + loop + statistics per frame)" % (events, steps, k + 1, wall), flush=True)
 
 # polarisation against the viewing angle (the direction the photon finally travels in)
