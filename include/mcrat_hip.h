@@ -430,6 +430,13 @@ int mcrat_hip_propagate_frame(mcrat_hip_ctx *ctx, double *time_now, double remai
 #define MCRAT_HIP_MODE_FAST  1
 int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *ctx, double *time_now, double remaining_time, uint64_t seed, int mode, int fast_windows,
                                    mcrat_hip_frame_stats *stats);
+/* FAST mode for the lists of a rank pool in one launch ([n_ranks] arrays, as mcrat_hip_pool_begin_frames): list r with open[r] != 0 runs its
+ * frame of remaining_time[r] with its own seed, stream and list-local slot numbers in its keys -- exactly what
+ * mcrat_hip_propagate_frame_mode(view r, ..., seeds[r], MCRAT_HIP_MODE_FAST, ...) gives, so a list's photons do not depend on which other
+ * lists share the pool; stats[r]: the list's counters, time_now[r] + remaining_time[r].  mcrat_hip_propagate_frame_mode(pool, FAST) is this
+ * for every list that holds photons with one seed and one frame time. */
+int mcrat_hip_pool_propagate_frames_fast(mcrat_hip_ctx *pool, const int *open, const uint64_t *seeds, const double *time_now,
+                                         const double *remaining_time, int fast_windows, mcrat_hip_frame_stats *stats);
 
 /* the same loop in pieces, for bounded runs (benchmarks, tests, progress logging):
  * begin_frame resets the per-frame state; each run executes at most max_iterations

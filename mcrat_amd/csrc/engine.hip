@@ -2309,50 +2309,129 @@ extern "C" int mcrat_hip_propagate_frame(mcrat_hip_ctx *c, double *time_now, dou
     return MCRAT_HIP_OK;
 }
 
-extern "C" int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *c, double *time_now, double remaining_time, uint64_t seed, int mode, int fast_windows,
-                                              mcrat_hip_frame_stats *stats)
+static int fast_refusals(mcrat_hip_ctx *c)
 {
-    if (!c || !time_now) return MCRAT_HIP_EINVAL;
-    if (mode == MCRAT_HIP_MODE_EXACT) return mcrat_hip_propagate_frame(c, time_now, remaining_time, seed, stats);
-    if (mode != MCRAT_HIP_MODE_FAST) return MCRAT_HIP_EINVAL;
-    if (!c->have_hydro || !c->have_photons) return MCRAT_HIP_ESTATE;
+    if (!c->have_hydro) return MCRAT_HIP_ESTATE;
     if (c->cfg.cyclosynchrotron_switch) { c->last_error = "FAST mode has no cyclo-synchrotron hooks: use the exact scatter frame"; return MCRAT_HIP_ESTATE; }
     if (c->sc_world > 0) { c->last_error = "shared clock attached: drive the frame with mcrat_hip_shared_clock_*"; return MCRAT_HIP_ESTATE; }
     if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && !c->d_hot_table) {
         c->last_error = "TAU_CALCULATION == TABLE needs mcrat_hip_set_hot_cross_section first";
         return MCRAT_HIP_ESTATE;
     }
-    int rc;
+    return MCRAT_HIP_OK;
+}
+
+static void fast_stats(const FastCounts &fc, double time_now, mcrat_hip_frame_stats *stats)
+{
+    memset(stats, 0, sizeof *stats);
+    stats->iterations = (long long)fc.passes;
+    stats->photon_steps = (long long)fc.photon_steps;
+    stats->frame_scatt_cnt = (long long)fc.scatterings;
+    stats->kn_rejections = (long long)fc.kn_rejections;
+    stats->num_photons_find_new_element = (long long)fc.relocated;
+    stats->not_found = (long long)fc.not_found;
+    stats->last_scattered_index = -1;
+    stats->remaining_time = 0;
+    stats->time_now = time_now;
+}
+
+// MCRAT_HIP_MODE_FAST for the lists of a rank pool, one launch: list r (open[r] != 0) runs its frame of remaining_time[r] with its own seed
+// and stream and list-local slot numbers in its keys -- bit for bit what mcrat_hip_propagate_frame_mode(view r, ..., seeds[r], FAST, ...) gives
+extern "C" int mcrat_hip_pool_propagate_frames_fast(mcrat_hip_ctx *c, const int *open, const uint64_t *seeds, const double *time_now,
+                                                    const double *remaining_time, int fast_windows, mcrat_hip_frame_stats *stats)
+{
+    if (!c || !open || !seeds || !time_now || !remaining_time) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    int rc = fast_refusals(c);
+    if (rc) return rc;
+    const int R = c->n_ranks;
+    std::vector<double> rem((size_t)R, 0.0);
+    for (int r = 0; r < R; ++r) {
+        mcrat_hip_ctx *v = c->views[r];
+        c->h_desc[r] = RankDesc{};
+        if (!open[r]) continue;
+        if (!v || !v->have_photons) { c->last_error = "pool_propagate_frames_fast: a list that does not exist was asked to run a frame"; return MCRAT_HIP_ESTATE; }
+        if ((rc = flush_pending(v))) return rc;
+        c->h_desc[r].len = v->ph.n; c->h_desc[r].stream = v->key.stream; c->h_desc[r].seed = seeds[r];
+        rem[(size_t)r] = remaining_time[r] > 0 ? remaining_time[r] : 0.0;
+    }
+    const size_t bytes = (sizeof(FastCounts) + sizeof(double)) * (size_t)R;
+    if ((rc = ensure_aos(c, bytes + 64))) return rc;
+    FastCounts *d_cnt = static_cast<FastCounts *>(c->aos_buf);
+    double *d_rem = reinterpret_cast<double *>(d_cnt + R);
+    HIPCHK(c, hipMemsetAsync(d_cnt, 0, sizeof(FastCounts) * (size_t)R, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_rem, rem.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    const FastLists lists{c->rank_stride, c->d_desc, d_rem};
+    HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, c->key, 0.0, fast_windows > 0 ? fast_windows : 8, 1 << 22, d_cnt, lists, c->stream));
+    std::vector<FastCounts> cnt((size_t)R);
+    HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(FastCounts) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->frame_open = false;
+    unsigned long long unfinished = 0;
+    for (int r = 0; r < R; ++r) {
+        if (!open[r]) continue;
+        mcrat_hip_ctx *v = c->views[r];
+        v->frame_open = false; v->pending_applied = false; v->rank_current = true;
+        unfinished += cnt[(size_t)r].unfinished;
+        if (stats) fast_stats(cnt[(size_t)r], time_now[r] + rem[(size_t)r], &stats[r]);
+    }
+    if (unfinished) { c->last_error = "FAST mode: photons left with frame time after 2^22 passes (an optical depth of infinity?)"; return MCRAT_HIP_ESTATE; }
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *c, double *time_now, double remaining_time, uint64_t seed, int mode, int fast_windows,
+                                              mcrat_hip_frame_stats *stats)
+{
+    if (!c || !time_now) return MCRAT_HIP_EINVAL;
+    if (mode == MCRAT_HIP_MODE_EXACT) return mcrat_hip_propagate_frame(c, time_now, remaining_time, seed, stats);
+    if (mode != MCRAT_HIP_MODE_FAST) return MCRAT_HIP_EINVAL;
+    int rc = fast_refusals(c);
+    if (rc) return rc;
+    if (c->is_pool) {                                                  // every list that holds photons, the same seed and frame time
+        const int R = c->n_ranks;
+        std::vector<int> open((size_t)R, 0);
+        std::vector<uint64_t> seeds((size_t)R, seed);
+        std::vector<double> t((size_t)R, *time_now), rem((size_t)R, remaining_time);
+        std::vector<mcrat_hip_frame_stats> per((size_t)R);
+        bool any = false;
+        for (int r = 0; r < R; ++r) { open[(size_t)r] = c->views[r] && c->views[r]->have_photons; any = any || open[(size_t)r]; }
+        if (!any) return MCRAT_HIP_ESTATE;
+        if ((rc = mcrat_hip_pool_propagate_frames_fast(c, open.data(), seeds.data(), t.data(), rem.data(), fast_windows, per.data()))) return rc;
+        if (remaining_time > 0) *time_now += remaining_time;
+        if (stats) {
+            FastCounts sum{};
+            for (int r = 0; r < R; ++r) {
+                if (!open[(size_t)r]) continue;
+                const mcrat_hip_frame_stats &q = per[(size_t)r];
+                sum.passes = std::max<unsigned long long>(sum.passes, (unsigned long long)q.iterations);
+                sum.photon_steps += (unsigned long long)q.photon_steps; sum.scatterings += (unsigned long long)q.frame_scatt_cnt;
+                sum.kn_rejections += (unsigned long long)q.kn_rejections; sum.relocated += (unsigned long long)q.num_photons_find_new_element;
+                sum.not_found += (unsigned long long)q.not_found;
+            }
+            fast_stats(sum, *time_now, stats);
+        }
+        return MCRAT_HIP_OK;
+    }
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
     if (c->frame_open && c->n_ranks == 0 && (rc = flush_pending(c))) return rc;       // what a list-mode run still owes the photons
     if (!c->d_fast) HIPCHK(c, hipMalloc(&c->d_fast, sizeof(FastCounts)));
     HIPCHK(c, hipMemsetAsync(c->d_fast, 0, sizeof(FastCounts), c->stream));
     RngKey key = c->key;
     key.seed = seed;
-    const int windows = fast_windows > 0 ? fast_windows : 8;
     FastCounts fc{};
     if (remaining_time > 0) {
-        HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, key, remaining_time, windows, 1 << 22, static_cast<FastCounts *>(c->d_fast), c->stream));
+        HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, key, remaining_time, fast_windows > 0 ? fast_windows : 8, 1 << 22,
+                                    static_cast<FastCounts *>(c->d_fast), FastLists{0, nullptr, nullptr}, c->stream));
         HIPCHK(c, hipMemcpyAsync(&fc, c->d_fast, sizeof fc, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->frame_open = false;
     c->pending_applied = false;
-    for (mcrat_hip_ctx *v : c->views)
-        if (v) { v->frame_open = false; v->pending_applied = false; v->rank_current = true; }
+    if (c->parent) c->rank_current = true;
     if (fc.unfinished) { c->last_error = "FAST mode: photons left with frame time after 2^22 passes (an optical depth of infinity?)"; return MCRAT_HIP_ESTATE; }
     if (remaining_time > 0) *time_now += remaining_time;
-    if (stats) {
-        memset(stats, 0, sizeof *stats);
-        stats->iterations = (long long)fc.passes;
-        stats->photon_steps = (long long)fc.photon_steps;
-        stats->frame_scatt_cnt = (long long)fc.scatterings;
-        stats->kn_rejections = (long long)fc.kn_rejections;
-        stats->num_photons_find_new_element = (long long)fc.relocated;
-        stats->not_found = (long long)fc.not_found;
-        stats->last_scattered_index = -1;
-        stats->remaining_time = 0;
-        stats->time_now = *time_now;
-    }
+    if (stats) fast_stats(fc, *time_now, stats);
     return MCRAT_HIP_OK;
 }
 

@@ -1282,15 +1282,30 @@ constexpr int FAST_BLOCK = FAST_BLOCK_THREADS;
 constexpr uint32_t RNG_FAST_FREEPATH = 8u;
 
 template <int DIMS, int GEOM, bool STOKES>
-__global__ __launch_bounds__(FAST_BLOCK, FAST_BLOCK >= 512 ? 2 : 2) void fast_frame_kernel(PhotonDev ph, HydroDev hy, RngKey key, double remaining_time, int windows,
-                                                                int max_passes, FastCounts *__restrict__ counts)
+__global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph, HydroDev hy, RngKey key, double remaining_time, int windows,
+                                                                   int max_passes, FastCounts *__restrict__ counts, FastLists lists)
 {
     __shared__ int s_q[FAST_BLOCK];
     __shared__ int s_nq;
     __shared__ unsigned long long s_cnt[6];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * FAST_BLOCK + tid;
-    const bool have = i < ph.n;
+    int first = 0, len = ph.n;
+    if (lists.desc) {
+        // the lists of a rank pool (windows of lists.stride slots, a multiple of 512: a workgroup lies within one list): each list with
+        // its own seed, stream and frame time and list-local slot numbers in its keys -- the photons a list ends up with do not depend
+        // on which other lists share the pool, as in the exact mode
+        const int r = (blockIdx.x * FAST_BLOCK) / lists.stride;
+        const RankDesc d = lists.desc[r];
+        first = r * lists.stride;
+        len = d.len;
+        remaining_time = lists.remaining_time[r];
+        if (len <= 0 || !(remaining_time > 0)) return;
+        key.seed = d.seed; key.stream = d.stream; key.slot_base = 0;
+        counts += r;
+    }
+    const uint32_t rng_first = key.slot_base - (uint32_t)first;       // key slot of photon i: i + rng_first
+    const bool have = i - first < len && i < ph.n;
     const unsigned fl0 = have ? (unsigned)ph.flags[i] : 0u;
     const bool valid = have && (fl0 & FLAG_VALID);
     const bool moves = (fl0 & FLAG_MOVES) != 0;
@@ -1311,7 +1326,7 @@ __global__ __launch_bounds__(FAST_BLOCK, FAST_BLOCK >= 512 ? 2 : 2) void fast_fr
             int cell = ph.idx[i];
             double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
             const double ntau = ph.ntau[i];
-            const Philox4 blk = keyed_block(key.seed, (uint64_t)pass, (uint32_t)i + key.slot_base, RNG_FAST_FREEPATH, key.stream);
+            const Philox4 blk = keyed_block(key.seed, (uint64_t)pass, (uint32_t)i + rng_first, RNG_FAST_FREEPATH, key.stream);
             const uint64_t bits = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
             int queue, bucket;
             double a0, a1, a2;
@@ -1365,7 +1380,7 @@ __global__ __launch_bounds__(FAST_BLOCK, FAST_BLOCK >= 512 ? 2 : 2) void fast_fr
             if constexpr (STOKES) { s[0] = ph.s0[k]; s[1] = ph.s1[k]; s[2] = ph.s2[k]; s[3] = ph.s3[k]; }
             const unsigned kf = ph.flags[k];
             double fluid_temp, tau_new;
-            if (scatter_core<DIMS, GEOM, STOKES, false>(hy, (LoopState *)nullptr, key, (unsigned long long)pass, (uint32_t)k + key.slot_base, kc, r, p, pc, s,
+            if (scatter_core<DIMS, GEOM, STOKES, false>(hy, (LoopState *)nullptr, key, (unsigned long long)pass, (uint32_t)k + rng_first, kc, r, p, pc, s,
                                                         fluid_temp, tau_new)) {
                 commit_scatter<STOKES>(ph, k, p, pc, s, r, tau_new, kf);
                 scatt += 1;
@@ -1898,13 +1913,14 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
 }
 
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream)
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream)
 {
+    if (lists.desc && (lists.stride <= 0 || lists.stride % FAST_BLOCK != 0)) return hipErrorInvalidValue;
     const int blocks = (ph.n + FAST_BLOCK - 1) / FAST_BLOCK;
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
-        if (kc.stokes) fast_frame_kernel<DV, GV, true><<<dim3(blocks), dim3(FAST_BLOCK), 0, stream>>>(ph, hy, key, remaining_time, windows, max_passes, counts);
-        else fast_frame_kernel<DV, GV, false><<<dim3(blocks), dim3(FAST_BLOCK), 0, stream>>>(ph, hy, key, remaining_time, windows, max_passes, counts);
+        if (kc.stokes) fast_frame_kernel<DV, GV, true><<<dim3(blocks), dim3(FAST_BLOCK), 0, stream>>>(ph, hy, key, remaining_time, windows, max_passes, counts, lists);
+        else fast_frame_kernel<DV, GV, false><<<dim3(blocks), dim3(FAST_BLOCK), 0, stream>>>(ph, hy, key, remaining_time, windows, max_passes, counts, lists);
     });
 }
 

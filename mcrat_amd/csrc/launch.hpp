@@ -34,8 +34,11 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             hipStream_t stream);
 // FAST mode: every photon through the whole frame on its own clock (kernels.hip, fast_frame_kernel); the counters add up over launches
 struct FastCounts { unsigned long long photon_steps, scatterings, kn_rejections, relocated, not_found, unfinished, passes; };
+// desc != nullptr: the photons are the lists of a rank pool (list r in slots [r * stride, r * stride + desc[r].len), stride a multiple of 256);
+// every list then has its own seed and stream (desc), its own frame time and its own counters (counts[r]); lists with len 0 or no time stand still
+struct FastLists { int stride; const RankDesc *desc; const double *remaining_time; };
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream);
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 // one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);

@@ -19,7 +19,7 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream);
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 int step_grid_blocks(int n_pad);
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);
@@ -41,7 +41,7 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream);
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_direct_d1
 
 namespace tau_direct_d2 {
@@ -57,7 +57,7 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream);
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_direct_d2
 
 namespace tau_table_d0 {
@@ -73,7 +73,7 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream);
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_table_d0
 
 namespace tau_table_d1 {
@@ -89,7 +89,7 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream);
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_table_d1
 
 namespace tau_table_d2 {
@@ -105,7 +105,7 @@ hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
                              const ScProposal *all, int world, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream);
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_table_d2
 
 #define MCRAT_ROUTE(fn, ...)                                                                     \
@@ -165,9 +165,9 @@ hipError_t launch_lookup(const KernelConfig &kc, const HydroDev &hy, int n, cons
 }
 
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
-                             int max_passes, FastCounts *counts, hipStream_t stream)
+                             int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream)
 {
-    MCRAT_ROUTE(launch_fast_frame, kc, ph, hy, key, remaining_time, windows, max_passes, counts, stream);
+    MCRAT_ROUTE(launch_fast_frame, kc, ph, hy, key, remaining_time, windows, max_passes, counts, lists, stream);
 }
 
 }  // namespace mcrat

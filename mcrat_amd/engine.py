@@ -211,6 +211,7 @@ SYMBOLS = {
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
     "mcrat_hip_propagate_frame_mode": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.c_int, C.c_int, C.POINTER(FrameStats)]),
+    "mcrat_hip_pool_propagate_frames_fast": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_uint64), _dp, _dp, C.c_int, C.POINTER(FrameStats)]),
     "mcrat_hip_begin_frame": (C.c_int, [_ctx, C.c_uint64, C.c_double, C.c_double]),
     "mcrat_hip_run": (C.c_int, [_ctx, C.c_longlong, C.POINTER(FrameStats)]),
     "mcrat_hip_snapshot_photons": (C.c_int, [_ctx]),
@@ -640,6 +641,17 @@ class Engine:
         self._check(self.lib.mcrat_hip_propagate_frame_mode(self.ctx, C.byref(tn), float(remaining_time), int(seed), MODE_FAST, int(windows),
                                                             C.byref(st)), "propagate_frame_mode")
         return tn.value, st
+
+    def pool_propagate_frames_fast(self, open_, seeds, time_now, remaining_time, windows=0):
+        """FAST mode for the lists of the pool, each with its own seed and frame time -> per-list FrameStats"""
+        R = self.n_pool_ranks
+        o = (C.c_int * R)(*[int(x) for x in open_])
+        sd = (C.c_uint64 * R)(*[int(x) for x in seeds])
+        t = (C.c_double * R)(*[float(x) for x in time_now])
+        rem = (C.c_double * R)(*[float(x) for x in remaining_time])
+        st = (FrameStats * R)()
+        self._check(self.lib.mcrat_hip_pool_propagate_frames_fast(self.ctx, o, sd, t, rem, int(windows), st), "pool_propagate_frames_fast")
+        return list(st)
 
     def snapshot_photons(self):
         self._check(self.lib.mcrat_hip_snapshot_photons(self.ctx), "snapshot_photons")

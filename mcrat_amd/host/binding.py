@@ -37,7 +37,7 @@ class PoolConfig(C.Structure):
                 ("spect", C.c_char), ("min_photons", C.c_int), ("max_photons", C.c_int), ("slots_per_rank", C.c_int),
                 ("get_hydro", GET_HYDRO), ("user", C.c_void_p), ("write_checkpoints", C.c_int),
                 ("print_photons", C.c_void_p), ("comv_switch", C.c_int), ("stokes_switch", C.c_int), ("save_type", C.c_int),
-                ("max_frames", C.c_int), ("cyclosynchrotron_switch", C.c_int), ("cs", engine.Cyclosynch),
+                ("max_frames", C.c_int), ("cyclosynchrotron_switch", C.c_int), ("cs", engine.Cyclosynch), ("mode", C.c_int), ("fast_windows", C.c_int),
                 ("hydro_frames_read", C.c_longlong), ("launches", C.c_longlong),
                 ("ms_propagate", C.c_double), ("ms_hydro", C.c_double), ("ms_output", C.c_double)]
 

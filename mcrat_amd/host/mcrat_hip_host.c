@@ -516,6 +516,7 @@ static double wall_ms(void)
 int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_ranks, mcrat_host_pool_config *cfg)
 {
     if (!pool || !ranks || n_ranks <= 0 || !cfg || !cfg->get_hydro || !(cfg->fps > 0) || cfg->max_photons <= 0) return MCRAT_HIP_EINVAL;
+    if (cfg->mode != MCRAT_HIP_MODE_EXACT && (cfg->mode != MCRAT_HIP_MODE_FAST || cfg->cyclosynchrotron_switch)) return MCRAT_HIP_EINVAL;
     int rc = mcrat_hip_pool_create(pool, n_ranks, cfg->slots_per_rank > 0 ? cfg->slots_per_rank : cfg->max_photons);
     if (rc) return rc;
     mcrat_hip_rank_summary *summ = (mcrat_hip_rank_summary *)calloc((size_t)n_ranks, sizeof *summ);
@@ -648,7 +649,9 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 t_now[r] = k->time_now;
                 t_rem[r] = ((F + 1) / cfg->fps) - k->time_now;
             }
-            if (!cfg->cyclosynchrotron_switch) {
+            if (!cfg->cyclosynchrotron_switch && cfg->mode == MCRAT_HIP_MODE_FAST) {
+                if ((rc = mcrat_hip_pool_propagate_frames_fast(pool, open, seeds, t_now, t_rem, cfg->fast_windows, stats))) break;
+            } else if (!cfg->cyclosynchrotron_switch) {
                 if ((rc = mcrat_hip_pool_begin_frames(pool, open, seeds, t_now, t_rem))) break;  /* every list's begin_frame, one launch */
                 mcrat_hip_frame_stats tot;
                 if ((rc = mcrat_hip_run(pool, 0, &tot))) break;                                   /* mcrat.c:761-851 for every list */

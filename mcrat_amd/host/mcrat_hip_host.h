@@ -229,6 +229,10 @@ typedef struct mcrat_host_pool_config {
      * (mcrat_hip_set_hydro_extras) when B_FIELD_CALC needs them.  slots_per_rank must allow for the lists' doublings. */
     int    cyclosynchrotron_switch;
     mcrat_hip_cyclosynch cs;             /* B_FIELD_CALC, EPSILON_B, CYCLOSYNCHROTRON_REBIN_* (the frame numbers are filled per rank) */
+    /* MCRAT_HIP_MODE_EXACT (0): the event-driven loop of mcrat.c:761-851 per rank.  MCRAT_HIP_MODE_FAST: every photon on its own clock
+     * (mcrat_hip_pool_propagate_frames_fast; statistically equivalent, see mcrat_hip.h) -- each rank still with its own per-frame seed and
+     * stream, so its files do not depend on which other ranks the process adopted.  Not with cyclosynchrotron_switch. */
+    int    mode, fast_windows;
     /* out */
     long long hydro_frames_read;         /* get_hydro calls */
     long long launches;                  /* mcrat_hip_run calls */

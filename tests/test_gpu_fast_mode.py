@@ -178,4 +178,22 @@ def test_fast_mode_on_a_rank_pool(hip):
         assert np.allclose(moved[ns == 0], synth.C_LIGHT * rem, rtol=1e-9)
     assert total == st.frame_scatt_cnt
     assert pool.pool_summaries()[3].list_capacity == 0
+    # a list of the pool is a context of its own: same stream, same seed -> the same photons bit for bit, whatever else shares the pool
+    lo, hi = cuts[1]
+    own = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=41)
+    own.set_hydro(frame)
+    own.set_photons({k: (a[lo:hi].copy() if isinstance(a, np.ndarray) else a) for k, a in ph.items()})
+    own.propagate_frame_fast(1.0, rem, 21)
+    a, b = own.get_photons(), views[1].get_photons()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    own.close()
+    # per-list seeds, clocks and counters
+    for v, (lo, hi) in zip(views, cuts):
+        v.set_photons({k: (a[lo:hi].copy() if isinstance(a, np.ndarray) else a) for k, a in ph.items()})
+    per = pool.pool_propagate_frames_fast([1, 0, 1, 0], [5, 6, 7, 8], [0.0, 0.0, 2.0, 0.0], [rem, rem, rem / 2, rem])
+    assert per[0].time_now == rem and per[2].time_now == 2.0 + rem / 2 and per[0].frame_scatt_cnt > per[2].frame_scatt_cnt > 500
+    untouched = views[1].get_photons()
+    assert np.array_equal(untouched["r0"], ph["r0"][cuts[1][0]:cuts[1][1]]) and np.array_equal(untouched["num_scatt"], ph["num_scatt"][cuts[1][0]:cuts[1][1]])
+    assert int((views[2].get_photons()["num_scatt"] - ph["num_scatt"][cuts[2][0]:cuts[2][1]]).sum()) == per[2].frame_scatt_cnt
     pool.close()

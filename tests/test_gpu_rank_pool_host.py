@@ -42,7 +42,12 @@ def _slab_dict(s):
                 r0_domain=tuple(s.r0_domain), r1_domain=tuple(s.r1_domain), r2_domain=tuple(s.r2_domain))
 
 
-def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, oracle, tmp_path):
+@pytest.mark.parametrize("mode", ["exact", "fast"])
+def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, oracle, tmp_path, mode):
+    """mode "fast": mcrat_host_pool_config.mode = MCRAT_HIP_MODE_FAST -- every rank's frame through mcrat_hip_pool_propagate_frames_fast with the
+    rank's own seed and stream; its files are then byte for byte those of a context doing the rank's steps by hand in FAST mode (there is no
+    oracle of the FAST sequence: tests/test_gpu_fast_mode.py holds it against the exact mode in distribution)"""
+    fast = mode == "fast"
     from mcrat_amd.host import binding as B
     host, h5 = B.host(), B.host_h5()
     libc = C.CDLL(None)
@@ -86,6 +91,7 @@ def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, orac
     if h5 is not None:
         cfg.print_photons = C.cast(h5.mcrat_host_print_photon_arrays, C.c_void_p).value
     cfg.comv_switch, cfg.stokes_switch, cfg.save_type = 1, 1, 1
+    cfg.mode, cfg.fast_windows = (hip.MODE_FAST, 4) if fast else (hip.MODE_EXACT, 0)
     assert host.mcrat_host_run_ranks(pool.ctx, ranks, R, C.byref(cfg)) == 0
     for f in logs:
         libc.fclose(f)
@@ -128,11 +134,14 @@ def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, orac
                 seed = B.rank_seed(base_seed, draws)
                 draws += 1
                 rem = (F + 1) / FPS - t
-                t_new, st = e.propagate_frame(t, rem, seed)
-                ref_frame, _ = oracle.hydro_ingest(cfg_o, raw, sl, oracle.outflow(3, lumi=2e53, theta_j=0.1))
-                H = oracle.OracleHydro(dict(ref_frame, **DOM, fps=FPS))
-                ost, otime, _, _ = oracle.photon_loop(cfg_o, P, H, seed=seed, time_now=t, remaining_time=rem, stream=k.rng_stream)
-                assert (st.iterations, st.frame_scatt_cnt) == (ost.iterations, ost.frame_scatt_cnt)
+                if fast:
+                    t_new, st = e.propagate_frame_fast(t, rem, seed, 4)
+                else:
+                    t_new, st = e.propagate_frame(t, rem, seed)
+                    ref_frame, _ = oracle.hydro_ingest(cfg_o, raw, sl, oracle.outflow(3, lumi=2e53, theta_j=0.1))
+                    H = oracle.OracleHydro(dict(ref_frame, **DOM, fps=FPS))
+                    ost, otime, _, _ = oracle.photon_loop(cfg_o, P, H, seed=seed, time_now=t, remaining_time=rem, stream=k.rng_stream)
+                    assert (st.iterations, st.frame_scatt_cnt) == (ost.iterations, ost.frame_scatt_cnt)
                 total_scatt += st.frame_scatt_cnt
                 t = t_new
                 assert host.mcrat_host_save_checkpoint(own.encode(), frame, k.frm2, F, t, e.ctx, None, n, LAST, k.angle_id, k.angle_procs, 0) == 0
@@ -150,7 +159,7 @@ def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, orac
         # ... whose records are the rank's photons after its last frame, within 1e-9 of the oracle's.  (A rank whose last injection frame
         # is the last hydro frame ends with frame == scatt_frame in the closing call, which removes the file instead of keeping it,
         # mcrat_io.c:900-903: its _old is an earlier frame's -- equal to the by-hand one above, not compared with the oracle here.)
-        if k.frm2 != LAST:
+        if k.frm2 != LAST and not fast:
             old = open(d + "mc_chkpt_%d.dat_old" % k.angle_id, "rb").read()
             rec = np.frombuffer(old[4 + 1 + 4 + 4:], dtype=hip.PHOTON_DTYPE)      # the 'i' layout of the last scatter frame (mcrat_io.c:974-998)
             assert old[4:5] == b"i" and len(rec) == len(last_list[0])
