@@ -197,3 +197,49 @@ def test_fast_mode_on_a_rank_pool(hip):
     assert np.array_equal(untouched["r0"], ph["r0"][cuts[1][0]:cuts[1][1]]) and np.array_equal(untouched["num_scatt"], ph["num_scatt"][cuts[1][0]:cuts[1][1]])
     assert int((views[2].get_photons()["num_scatt"] - ph["num_scatt"][cuts[2][0]:cuts[2][1]]).sum()) == per[2].frame_scatt_cnt
     pool.close()
+
+
+def _hot_table():
+    """a smooth stand-in for thermal_hot_x_section.dat on the reference's grid (as tests/test_gpu_parity.py)"""
+    i, j = np.meshgrid(np.arange(221), np.arange(81), indexing="ij")
+    x = -12.0 + i * (18.0 / 220)
+    y = -4.0 + j * (8.0 / 80)
+    return -0.35 * np.log1p(np.exp(2.0 * (x + 0.5))) / np.log(10) - 0.02 * (y + 4.0) * (1 + 0.1 * np.tanh(x))
+
+
+@pytest.mark.parametrize("case", ["table-cfg2", "2.5d-spherical", "3d-spherical", "3d-cartesian"])
+def test_fast_mode_in_the_other_builds_of_the_kernels(hip, case):
+    """the kernels exist per TAU_CALCULATION x DIMENSIONS (kernels*_d*.hip): FAST against EXACT in the TABLE build and in the 2.5-D and 3-D ones"""
+    kw, tab = {}, None
+    if case == "table-cfg2":
+        frame, ph, cfg = synth.config2(n_photons=60_000, nzc=16, stokes=1, lumi=3e52)
+        kw, tab = dict(tau_calculation=hip.TAU_TABLE), _hot_table()
+    elif case == "2.5d-spherical":
+        frame, ph, cfg = synth.config_25d(synth.SPHERICAL, n_photons=40_000, stokes=1, lumi=3e53)
+    elif case == "3d-spherical":
+        frame, ph, cfg = synth.config_3d(synth.SPHERICAL, n_photons=40_000)
+    else:
+        frame, ph, cfg = synth.config_3d_cartesian(n_photons=40_000)
+    rem = 1.0 / frame["fps"]
+    res = {}
+    for mode in ("exact", "fast"):
+        e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=1000 if mode == "exact" else 0, **kw)
+        if tab is not None:
+            e.set_hot_cross_section(tab)
+        e.set_hydro(frame)
+        e.set_photons(ph)
+        if mode == "exact":
+            _, st = e.propagate_frame(0.0, rem, 31)
+        else:
+            _, st = e.propagate_frame_fast(0.0, rem, 32, 16)
+        res[mode] = (st, e.get_photons())
+        e.close()
+    st_e, ex = res["exact"]
+    st_f, fa = res["fast"]
+    assert st_e.frame_scatt_cnt > 2000, st_e.frame_scatt_cnt
+    assert int((fa["num_scatt"] - ph["num_scatt"]).sum()) == st_f.frame_scatt_cnt
+    me, mf = _moments(ph, ex), _moments(ph, fa)
+    for k in ("ns", "loge", "q", "u"):
+        z = (me[k][0] - mf[k][0]) / max(1e-300, np.hypot(me[k][1], mf[k][1]))
+        assert abs(z) < 4.5, (case, k, me[k], mf[k], z)
+    assert st_f.not_found == st_e.not_found == 0 or abs(st_f.not_found - st_e.not_found) <= 0.2 * max(st_e.not_found, 50)
