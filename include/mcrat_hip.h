@@ -543,6 +543,25 @@ int mcrat_hip_step_event(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);
 size_t mcrat_hip_shared_clock_bytes_per_rank(void);
 int mcrat_hip_shared_clock_attach(mcrat_hip_ctx *ctx, int world, int rank, long long slot_base, void *send, void *recv);
 int mcrat_hip_shared_clock_buffers(mcrat_hip_ctx *ctx, void **send, void **recv);
+/* The exchange done by the GPUs themselves (one-shot peer writes and a local wait instead of a collective launched by the host):
+ *   mcrat_hip_shared_clock_attach_device   attach as above with library-owned, fine-grained (peer-coherent) buffers: a receive buffer of
+ *                                          2 x world proposals (the rounds alternate between its halves) and world stamps;
+ *   mcrat_hip_shared_clock_peer_buffers    their addresses and sizes, for the caller to hand to the other ranks (hipIpcGetMemHandle between
+ *                                          processes, the pointers themselves between contexts of one process or with peer access enabled);
+ *   mcrat_hip_shared_clock_set_peers       [world] arrays with every rank's receive buffer and stamps as THIS process addresses them (the own
+ *                                          entries are ignored);
+ *   mcrat_hip_shared_clock_exchange        between propose and resolve: a kernel writes this rank's proposal into every peer's buffer and
+ *                                          stamps it (_push), a second one waits for the stamps of all ranks (_wait; bounded: a peer that
+ *                                          never arrives makes the next poll fail with MCRAT_HIP_EHIP instead of hanging the GPU).
+ * All on the context's stream and without per-round arguments (the round number lives on the device, the wait kernel copies the round's
+ * proposals to the fixed place resolve reads), so propose / exchange / resolve capture into a hipGraph like the collective.  Every rank must run the same
+ * number of rounds (rounds after the frame's end are no-ops but still exchange), as with the all-gather. */
+int mcrat_hip_shared_clock_attach_device(mcrat_hip_ctx *ctx, int world, int rank, long long slot_base);
+int mcrat_hip_shared_clock_peer_buffers(mcrat_hip_ctx *ctx, void **recv, size_t *recv_bytes, void **flags, size_t *flags_bytes);
+int mcrat_hip_shared_clock_set_peers(mcrat_hip_ctx *ctx, void *const *peer_recv, void *const *peer_flags);
+int mcrat_hip_shared_clock_exchange_push(mcrat_hip_ctx *ctx);
+int mcrat_hip_shared_clock_exchange_wait(mcrat_hip_ctx *ctx);
+int mcrat_hip_shared_clock_exchange(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_propose(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_resolve(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_poll(mcrat_hip_ctx *ctx, int *frame_done, mcrat_hip_frame_stats *stats);   /* synchronises the stream */

@@ -110,6 +110,11 @@ struct mcrat_hip_ctx {
     int sc_world = 0, sc_rank = 0;
     ScState *d_sc = nullptr;
     ScProposal *sc_send = nullptr, *sc_recv = nullptr;
+    // device-initiated exchange (mcrat_hip_shared_clock_attach_device): fine-grained receive buffer (2 x world proposals) and stamps
+    bool sc_device = false, sc_peers_set = false;
+    unsigned long long *sc_flags = nullptr;
+    ScProposal *sc_gather = nullptr;   // the round's proposals of all ranks, copied out of the receive buffer's current half: what resolve reads
+    ScPeers sc_peers{};
     bool sc_own_send = false, sc_own_recv = false;
 
     // scratch
@@ -267,6 +272,8 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->d_sc) (void)hipFree(c->d_sc);
     if (c->sc_own_send && c->sc_send) (void)hipFree(c->sc_send);
     if (c->sc_own_recv && c->sc_recv) (void)hipFree(c->sc_recv);
+    if (c->sc_flags) (void)hipFree(c->sc_flags);
+    if (c->sc_gather) (void)hipFree(c->sc_gather);
     if (c->d_rstates) (void)hipFree(c->d_rstates);
     if (c->h_rstates) (void)hipHostFree(c->h_rstates);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -2866,6 +2873,9 @@ extern "C" int mcrat_hip_shared_clock_attach(mcrat_hip_ctx *c, int world, int ra
     if (c->sc_own_send && c->sc_send) { (void)hipFree(c->sc_send); c->sc_send = nullptr; }
     if (c->sc_own_recv && c->sc_recv) { (void)hipFree(c->sc_recv); c->sc_recv = nullptr; }
     c->sc_own_send = c->sc_own_recv = false;
+    if (c->sc_flags) { (void)hipFree(c->sc_flags); c->sc_flags = nullptr; }
+    if (c->sc_gather) { (void)hipFree(c->sc_gather); c->sc_gather = nullptr; }
+    c->sc_device = c->sc_peers_set = false;
     if (send) c->sc_send = (ScProposal *)send;
     else { HIPCHK(c, hipMalloc((void **)&c->sc_send, sizeof(ScProposal))); c->sc_own_send = true; }
     if (recv) c->sc_recv = (ScProposal *)recv;
@@ -2879,6 +2889,75 @@ extern "C" int mcrat_hip_shared_clock_attach(mcrat_hip_ctx *c, int world, int ra
     c->frame_open = false;
     drop_graph(c);
     return MCRAT_HIP_OK;
+}
+
+// the same attachment with the exchange done by the GPUs themselves: no host collective between propose and resolve
+extern "C" int mcrat_hip_shared_clock_attach_device(mcrat_hip_ctx *c, int world, int rank, long long slot_base)
+{
+    int rc = mcrat_hip_shared_clock_attach(c, world, rank, slot_base, nullptr, nullptr);
+    if (rc) return rc;
+    if (c->sc_own_recv && c->sc_recv) (void)hipFree(c->sc_recv);
+    c->sc_recv = nullptr; c->sc_own_recv = false;
+    const size_t recv_bytes = sizeof(ScProposal) * 2 * (size_t)world, flag_bytes = sizeof(unsigned long long) * SC_FLAG_WORDS;
+    HIPCHK(c, hipMalloc((void **)&c->sc_gather, sizeof(ScProposal) * (size_t)world));
+    HIPCHK(c, hipMemset(c->sc_gather, 0, sizeof(ScProposal) * (size_t)world));
+    HIPCHK(c, hipExtMallocWithFlags((void **)&c->sc_recv, recv_bytes, hipDeviceMallocFinegrained));
+    c->sc_own_recv = true;
+    HIPCHK(c, hipExtMallocWithFlags((void **)&c->sc_flags, flag_bytes, hipDeviceMallocFinegrained));
+    HIPCHK(c, hipMemset(c->sc_recv, 0, recv_bytes));
+    HIPCHK(c, hipMemset(c->sc_flags, 0, flag_bytes));
+    HIPCHK(c, hipDeviceSynchronize());
+    c->sc_device = true;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_peer_buffers(mcrat_hip_ctx *c, void **recv, size_t *recv_bytes, void **flags, size_t *flags_bytes)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->sc_device) return MCRAT_HIP_ESTATE;
+    if (recv) *recv = c->sc_recv;
+    if (recv_bytes) *recv_bytes = sizeof(ScProposal) * 2 * (size_t)c->sc_world;
+    if (flags) *flags = c->sc_flags;
+    if (flags_bytes) *flags_bytes = sizeof(unsigned long long) * SC_FLAG_WORDS;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_set_peers(mcrat_hip_ctx *c, void *const *peer_recv, void *const *peer_flags)
+{
+    if (!c || !peer_recv || !peer_flags) return MCRAT_HIP_EINVAL;
+    if (!c->sc_device) return MCRAT_HIP_ESTATE;
+    for (int r = 0; r < c->sc_world; ++r) {
+        void *pr = r == c->sc_rank ? (void *)c->sc_recv : peer_recv[r], *pf = r == c->sc_rank ? (void *)c->sc_flags : peer_flags[r];
+        if (!pr || !pf) return MCRAT_HIP_EINVAL;
+        c->sc_peers.recv[r] = static_cast<ScProposal *>(pr);
+        c->sc_peers.flag[r] = static_cast<unsigned long long *>(pf);
+    }
+    c->sc_peers_set = true;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_exchange_push(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->sc_device || !c->sc_peers_set || !c->frame_open) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, launch_sc_push(c->sc_send, c->sc_peers, c->sc_flags, c->sc_world, c->sc_rank, c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_exchange_wait(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->sc_device || !c->sc_peers_set || !c->frame_open) return MCRAT_HIP_ESTATE;
+    int spins = 4000000;                                             // a few seconds: ranks enter a frame together (a barrier on the host)
+    if (const char *e = getenv("MCRAT_HIP_SC_WAIT_SPINS")) spins = atoi(e) > 0 ? atoi(e) : spins;
+    HIPCHK(c, launch_sc_wait(c->sc_flags, c->sc_recv, c->sc_gather, c->sc_world, spins, c->stream));
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_shared_clock_exchange(mcrat_hip_ctx *c)
+{
+    int rc = mcrat_hip_shared_clock_exchange_push(c);
+    return rc ? rc : mcrat_hip_shared_clock_exchange_wait(c);
 }
 
 extern "C" int mcrat_hip_shared_clock_buffers(mcrat_hip_ctx *c, void **send, void **recv)
@@ -2904,7 +2983,8 @@ extern "C" int mcrat_hip_shared_clock_resolve(mcrat_hip_ctx *c)
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
-    HIPCHK(c, launch_sc_resolve(c->kc, c->ph, c->hy, c->d_state, c->d_sc, c->key, c->sc_recv, c->sc_world, c->stream));
+    const ScProposal *all = c->sc_device ? c->sc_gather : c->sc_recv;                   // device exchange: the wait kernel has copied the round out
+    HIPCHK(c, launch_sc_resolve(c->kc, c->ph, c->hy, c->d_state, c->d_sc, c->key, all, c->sc_world, c->stream));
     return MCRAT_HIP_OK;
 }
 
@@ -2913,7 +2993,10 @@ extern "C" int mcrat_hip_shared_clock_poll(mcrat_hip_ctx *c, int *frame_done, mc
     if (!c) return MCRAT_HIP_EINVAL;
     if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
+    unsigned long long gave_up = 0;
+    if (c->sc_device) HIPCHK(c, hipMemcpyAsync(&gave_up, c->sc_flags + SC_GAVE_UP_WORD, sizeof gave_up, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (gave_up) { c->last_error = "shared clock: a peer's proposal did not arrive (device-initiated exchange gave up waiting)"; return MCRAT_HIP_EHIP; }
     if (frame_done) *frame_done = c->h_state->done == LOOP_DONE;
     fill_stats(c, stats);
     return MCRAT_HIP_OK;

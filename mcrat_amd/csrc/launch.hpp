@@ -32,6 +32,12 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, struct CsFrame *cs, long long max_passes, int block,
                             hipStream_t stream);
+// shared clock with a device-initiated exchange (staging.hip): recv[r] = rank r's receive buffer (2 x world proposals, by round parity),
+// flag[r] = rank r's stamps (SC_MAX_WORLD words, one per sender, + a word counting waits that gave up + the rank's own round number)
+struct ScPeers { ScProposal *recv[SC_MAX_WORLD]; unsigned long long *flag[SC_MAX_WORLD]; };
+constexpr int SC_GAVE_UP_WORD = SC_MAX_WORLD, SC_ROUND_WORD = SC_MAX_WORLD + 1, SC_FLAG_WORDS = SC_MAX_WORLD + 2;
+hipError_t launch_sc_push(const ScProposal *send, const ScPeers &peers, unsigned long long *my_flags, int world, int rank, hipStream_t stream);
+hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins, hipStream_t stream);
 // FAST mode: every photon through the whole frame on its own clock (kernels.hip, fast_frame_kernel); the counters add up over launches
 struct FastCounts { unsigned long long photon_steps, scatterings, kn_rejections, relocated, not_found, unfinished, passes; };
 // desc != nullptr: the photons are the lists of a rank pool (list r in slots [r * stride, r * stride + desc[r].len), stride a multiple of 256);

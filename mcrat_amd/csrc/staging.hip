@@ -373,6 +373,67 @@ hipError_t launch_cs_absorb(const CsParams &p, const PhotonDev &ph, const double
     return hipGetLastError();
 }
 
+// ---- shared clock, device-initiated exchange (one-shot peer writes + a local wait; launch.hpp).  sc_push_kernel copies this GPU's
+// proposal of the round into slot `rank` of every peer's receive buffer (peer pointers: the same process' other contexts, hipIpc mappings of
+// other processes' buffers, or other GPUs' over xGMI; the buffers are fine-grained allocations) and then stamps the round into the peer's
+// flag word for this rank; sc_wait_kernel, lane r, waits until rank r's stamp has reached the round.  Two receive buffers alternate by the
+// round's parity: a rank can push round k + 2 only after its own resolve of round k + 1, which needed every peer's push of round k + 1,
+// which that peer issued after ITS resolve of round k -- so nobody still reads the buffer that is overwritten.  The wait is bounded.
+__global__ __launch_bounds__(256) void sc_push_kernel(const ScProposal *__restrict__ send, ScPeers peers, unsigned long long *my_flags, int world, int rank)
+{
+    constexpr int WORDS = (int)(sizeof(ScProposal) / sizeof(unsigned long long));
+    static_assert(sizeof(ScProposal) % sizeof(unsigned long long) == 0, "proposal copied by 8-byte words");
+    // the round number lives on the device (my_flags[SC_ROUND_WORD], touched by this rank's kernels only, in stream order): the launches
+    // carry no per-round argument and can be replayed from a hipGraph
+    const unsigned long long round = my_flags[SC_ROUND_WORD] + 1ull;
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(send);
+    for (int k = threadIdx.x; k < WORDS * world; k += 256) {
+        const int peer = k / WORDS, w = k - peer * WORDS;
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(peers.recv[peer] + (size_t)(round & 1ull) * (size_t)world + (size_t)rank);
+        __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if ((int)threadIdx.x < world) __hip_atomic_store(peers.flag[threadIdx.x] + rank, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) my_flags[SC_ROUND_WORD] = round;
+}
+
+// waits for the round's stamps of all ranks, then copies the round's half of the receive buffer into `gathered`, which is what
+// sc_resolve_kernel reads (a fixed address: no per-round argument there either)
+__global__ __launch_bounds__(256) void sc_wait_kernel(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins)
+{
+    constexpr int WORDS = (int)(sizeof(ScProposal) / sizeof(unsigned long long));
+    const unsigned long long round = my_flags[SC_ROUND_WORD];
+    const int r = threadIdx.x;
+    if (r < world) {
+        int spins = 0;
+        while (__hip_atomic_load(my_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < round) {
+            if (++spins > max_spins) {                              // a peer that never arrives must not hang the GPU: say so and go on
+                __hip_atomic_fetch_add(my_flags + SC_GAVE_UP_WORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(recv + (size_t)(round & 1ull) * (size_t)world);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(gathered);
+    for (int k = threadIdx.x; k < WORDS * world; k += 256) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_sc_push(const ScProposal *send, const ScPeers &peers, unsigned long long *my_flags, int world, int rank, hipStream_t stream)
+{
+    sc_push_kernel<<<dim3(1), dim3(256), 0, stream>>>(send, peers, my_flags, world, rank);
+    return hipGetLastError();
+}
+
+hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins, hipStream_t stream)
+{
+    sc_wait_kernel<<<dim3(1), dim3(256), 0, stream>>>(my_flags, recv, gathered, world, max_spins);
+    return hipGetLastError();
+}
+
 hipError_t launch_cs_absorb_pool(const CsParams &p, const PhotonDev &pool, int stride, int n_ranks, const RankDesc *desc, const int *open, const double *temp,
                                  const HydroCols &h, CsAbsPartial *per_list, hipStream_t stream)
 {

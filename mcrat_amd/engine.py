@@ -232,6 +232,12 @@ SYMBOLS = {
     "mcrat_hip_frame_statistics": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_shared_clock_bytes_per_rank": (C.c_size_t, []),
     "mcrat_hip_shared_clock_attach": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p]),
+    "mcrat_hip_shared_clock_attach_device": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_longlong]),
+    "mcrat_hip_shared_clock_peer_buffers": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "mcrat_hip_shared_clock_set_peers": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "mcrat_hip_shared_clock_exchange_push": (C.c_int, [_ctx]),
+    "mcrat_hip_shared_clock_exchange_wait": (C.c_int, [_ctx]),
+    "mcrat_hip_shared_clock_exchange": (C.c_int, [_ctx]),
     "mcrat_hip_shared_clock_buffers": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mcrat_hip_shared_clock_propose": (C.c_int, [_ctx]),
     "mcrat_hip_shared_clock_resolve": (C.c_int, [_ctx]),
@@ -691,6 +697,25 @@ class Engine:
         self._check(self.lib.mcrat_hip_shared_clock_attach(self.ctx, int(world), int(rank), int(slot_base),
                                                            C.c_void_p(send_ptr) if send_ptr else None,
                                                            C.c_void_p(recv_ptr) if recv_ptr else None), "shared_clock_attach")
+
+    def shared_clock_attach_device(self, world, rank, slot_base):
+        """device-initiated exchange: library-owned fine-grained buffers -> (recv address, recv bytes, flags address, flags bytes)"""
+        self._check(self.lib.mcrat_hip_shared_clock_attach_device(self.ctx, int(world), int(rank), int(slot_base)), "shared_clock_attach_device")
+        r, f, rb, fb = C.c_void_p(), C.c_void_p(), C.c_size_t(), C.c_size_t()
+        self._check(self.lib.mcrat_hip_shared_clock_peer_buffers(self.ctx, C.byref(r), C.byref(rb), C.byref(f), C.byref(fb)), "shared_clock_peer_buffers")
+        return r.value, rb.value, f.value, fb.value
+
+    def shared_clock_set_peers(self, peer_recv, peer_flags):
+        n = len(peer_recv)
+        a = (C.c_void_p * n)(*[C.c_void_p(x) for x in peer_recv])
+        b = (C.c_void_p * n)(*[C.c_void_p(x) for x in peer_flags])
+        self._check(self.lib.mcrat_hip_shared_clock_set_peers(self.ctx, a, b), "shared_clock_set_peers")
+
+    def shared_clock_exchange_push(self):
+        self._check(self.lib.mcrat_hip_shared_clock_exchange_push(self.ctx), "shared_clock_exchange_push")
+
+    def shared_clock_exchange_wait(self):
+        self._check(self.lib.mcrat_hip_shared_clock_exchange_wait(self.ctx), "shared_clock_exchange_wait")
 
     def shared_clock_propose(self):
         self._check(self.lib.mcrat_hip_shared_clock_propose(self.ctx), "shared_clock_propose")

@@ -69,6 +69,8 @@ def host():
         lib.mcrat_host_shared_clock_frame.restype = C.c_int
         lib.mcrat_host_shared_clock_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
                                                       C.POINTER(C.c_double), C.c_double, C.c_uint64, C.c_int, C.POINTER(engine.FrameStats)]
+        lib.mcrat_host_exchange_device.restype = C.c_int
+        lib.mcrat_host_exchange_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         lib.mcrat_host_run_ranks.restype = C.c_int
         lib.mcrat_host_run_ranks.argtypes = [C.c_void_p, C.POINTER(HostRank), C.c_int, C.POINTER(PoolConfig)]
         _host = lib
@@ -112,6 +114,11 @@ def host_rccl():
         lib.mcrat_host_rccl_comm_single.restype = C.c_int
         lib.mcrat_host_rccl_comm_single.argtypes = [C.POINTER(C.c_void_p)]
         lib.mcrat_host_rccl_comm_destroy.argtypes = [C.c_void_p]
+        lib.mcrat_host_ipc_export.restype = C.c_int
+        lib.mcrat_host_ipc_export.argtypes = [C.c_void_p, C.c_char_p]
+        lib.mcrat_host_ipc_import.restype = C.c_int
+        lib.mcrat_host_ipc_import.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.mcrat_host_ipc_close.argtypes = [C.c_void_p]
         _rccl = lib
     return _rccl
 

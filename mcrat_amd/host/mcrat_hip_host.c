@@ -804,7 +804,7 @@ int mcrat_host_shared_clock_frame(mcrat_hip_ctx *ctx, int world, int rank, long 
     while (!done) {
         for (int k = 0; k < rounds_per_poll; k++) {
             if ((rc = mcrat_hip_shared_clock_propose(ctx)) != 0) return rc;
-            if (world > 1 && (rc = exchange(user, send, recv, nb, stream)) != 0) return rc;
+            if (exchange && (rc = exchange(user, send, recv, nb, stream)) != 0) return rc;   /* (one rank needs none, but may have one: device exchange) */
             if ((rc = mcrat_hip_shared_clock_resolve(ctx)) != 0) return rc;
         }
         if ((rc = mcrat_hip_shared_clock_poll(ctx, &done, &st)) != 0) return rc;      /* identical on every rank: the loops stay in step */
@@ -813,6 +813,12 @@ int mcrat_host_shared_clock_frame(mcrat_hip_ctx *ctx, int world, int rank, long 
     *time_now = st.time_now;
     if (stats) *stats = st;
     return MCRAT_HIP_OK;
+}
+
+int mcrat_host_exchange_device(void *user, const void *send, void *recv, size_t bytes_per_rank, void *stream)
+{
+    (void)send; (void)recv; (void)bytes_per_rank; (void)stream;    /* the context knows its buffers, peers and stream */
+    return mcrat_hip_shared_clock_exchange((mcrat_hip_ctx *)user);
 }
 
 /* ------------------------------------------------------------------ A/B shims (mcrat_hip_host.h) */

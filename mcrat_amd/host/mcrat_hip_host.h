@@ -253,6 +253,14 @@ typedef int (*mcrat_host_allgather_fn)(void *user, const void *send, void *recv,
 int mcrat_host_shared_clock_frame(mcrat_hip_ctx *ctx, int world, int rank, long long slot_base, mcrat_host_allgather_fn exchange, void *user,
                                   void *stream, double *time_now, double remaining_time, uint64_t seed, int rounds_per_poll,
                                   mcrat_hip_frame_stats *stats);
+/* the exchange done by the GPUs themselves (mcrat_hip_shared_clock_attach_device / _set_peers in mcrat_hip.h): pass this as `exchange` with
+ * user = the context; no collective is launched, a kernel writes the proposal into every peer's buffer and a second one waits for theirs */
+int mcrat_host_exchange_device(void *user /* mcrat_hip_ctx * */, const void *send, void *recv, size_t bytes_per_rank, void *stream);
+/* (in libmcrat_hip_host_rccl.so, which links HIP) a device allocation as a 64-byte handle another process can map, for the peer buffers:
+ * hipIpcGetMemHandle / hipIpcOpenMemHandle / hipIpcCloseMemHandle.  0 or MCRAT_HIP_EHIP. */
+int  mcrat_host_ipc_export(void *device_ptr, unsigned char handle[64]);
+int  mcrat_host_ipc_import(const unsigned char handle[64], void **device_ptr);
+void mcrat_host_ipc_close(void *device_ptr);
 /* mcrat_hip_host_rccl.c (libmcrat_hip_host_rccl.so, links librccl): the exchange as ncclAllGather -- `user` points at the caller's
  * ncclComm_t --, and the same frame with its rounds captured in a hipGraph (the forced first round is launched eagerly, then
  * rounds_per_graph rounds of {propose kernels, ncclAllGather, resolve kernel} replay as one graph launch between two polls).

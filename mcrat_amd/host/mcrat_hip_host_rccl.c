@@ -3,6 +3,7 @@
 #define __HIP_PLATFORM_AMD__ 1
 #include "mcrat_hip_host.h"
 
+#include <string.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -33,7 +34,10 @@ int mcrat_host_shared_clock_frame_graph(mcrat_hip_ctx *ctx, int world, int rank,
                                         double *time_now, double remaining_time, uint64_t seed, int rounds_per_graph,
                                         mcrat_hip_frame_stats *stats)
 {
-    if (!ctx || !time_now || !stream_ || world < 1 || (world > 1 && !nccl_comm)) return MCRAT_HIP_EINVAL;
+    /* nccl_comm == NULL with world > 1: the context must be attached with the device-initiated exchange (mcrat_hip_shared_clock_attach_device,
+     * peers set): its two kernels are captured in place of the collective */
+    const int device_exchange = ctx && mcrat_hip_shared_clock_peer_buffers(ctx, NULL, NULL, NULL, NULL) == 0;
+    if (!ctx || !time_now || !stream_ || world < 1 || (world > 1 && !nccl_comm && !device_exchange)) return MCRAT_HIP_EINVAL;
     if (rounds_per_graph < 1) rounds_per_graph = 32;
     hipStream_t stream = (hipStream_t)stream_;
     ncclComm_t comm = (ncclComm_t)nccl_comm;
@@ -49,6 +53,7 @@ int mcrat_host_shared_clock_frame_graph(mcrat_hip_ctx *ctx, int world, int rank,
     do {                                                                                                                            \
         if ((rc = mcrat_hip_shared_clock_propose(ctx)) != 0) break;                                                                 \
         if (comm && ncclAllGather(send, recv, nb, ncclChar, comm, stream) != ncclSuccess) { rc = MCRAT_HIP_EHIP; break; }           \
+        if (!comm && device_exchange && (rc = mcrat_hip_shared_clock_exchange(ctx)) != 0) break;                                    \
         rc = mcrat_hip_shared_clock_resolve(ctx);                                                                                   \
     } while (0)
     ROUND();                                       /* the forced re-location round of the new frame (mcrat.c:756) is not part of the graph */
@@ -74,4 +79,28 @@ int mcrat_host_shared_clock_frame_graph(mcrat_hip_ctx *ctx, int world, int rank,
     if (stats) *stats = st;
     return MCRAT_HIP_OK;
 #undef ROUND
+}
+
+/* ---- hipIpc, for the peer buffers of the device-initiated exchange between processes */
+int mcrat_host_ipc_export(void *device_ptr, unsigned char handle[64])
+{
+    hipIpcMemHandle_t h;
+    if (!device_ptr || !handle || sizeof h != 64) return MCRAT_HIP_EINVAL;
+    if (hipIpcGetMemHandle(&h, device_ptr) != hipSuccess) return MCRAT_HIP_EHIP;
+    memcpy(handle, &h, 64);
+    return MCRAT_HIP_OK;
+}
+
+int mcrat_host_ipc_import(const unsigned char handle[64], void **device_ptr)
+{
+    hipIpcMemHandle_t h;
+    if (!device_ptr || !handle || sizeof h != 64) return MCRAT_HIP_EINVAL;
+    memcpy(&h, handle, 64);
+    if (hipIpcOpenMemHandle(device_ptr, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) return MCRAT_HIP_EHIP;
+    return MCRAT_HIP_OK;
+}
+
+void mcrat_host_ipc_close(void *device_ptr)
+{
+    if (device_ptr) (void)hipIpcCloseMemHandle(device_ptr);
 }

@@ -83,10 +83,14 @@ class LocalGroup:
     """`world` contexts on ONE GPU in ONE process, exchanging by device copies: the whole device side of the
     shared-clock protocol without a process group (tests, and a rehearsal of multi-GPU runs on a one-GPU box)."""
 
-    def __init__(self, dimensions, geometry, stokes, frame, shards, device=0, rng_stream=0):
+    def __init__(self, dimensions, geometry, stokes, frame, shards, device=0, rng_stream=0, device_exchange=False):
         dev = torch.device("cuda", device)
         self.stream = torch.cuda.Stream(device=dev)
         self.members = []
+        self.device_exchange = bool(device_exchange)      # the GPUs exchange by peer writes + a wait kernel (mcrat_hip_shared_clock_exchange)
+        if self.device_exchange:
+            self._init_device_exchange(dimensions, geometry, stokes, frame, shards, device, rng_stream)
+            return
         base = 0
         for r, ph in enumerate(shards):
             eng = Engine(dimensions, geometry, stokes=stokes, device=device, stream=self.stream.cuda_stream, rng_stream=rng_stream)
@@ -99,7 +103,32 @@ class LocalGroup:
             base += eng.n
         self.n_total = base
 
+    def _init_device_exchange(self, dimensions, geometry, stokes, frame, shards, device, rng_stream):
+        class _Member:                                    # what propagate_frame / get_photons use of a SharedClock
+            def __init__(self, engine, world):
+                self.engine, self.world = engine, world
+        base, bufs = 0, []
+        for r, ph in enumerate(shards):
+            eng = Engine(dimensions, geometry, stokes=stokes, device=device, stream=self.stream.cuda_stream, rng_stream=rng_stream)
+            eng.torch_stream = self.stream
+            eng.set_hydro(frame)
+            eng.set_photons(ph)
+            if base % 2:
+                raise ValueError("every shard but the last must hold an even number of slots")
+            bufs.append(eng.shared_clock_attach_device(len(shards), r, base))
+            self.members.append(_Member(eng, len(shards)))
+            base += eng.n
+        for m in self.members:                            # one process: the peers' buffers are addressed as they are
+            m.engine.shared_clock_set_peers([b[0] for b in bufs], [b[2] for b in bufs])
+        self.n_total = base
+
     def exchange(self):
+        if self.device_exchange:                          # every push is queued before any wait: one stream serves all members here
+            for m in self.members:
+                m.engine.shared_clock_exchange_push()
+            for m in self.members:
+                m.engine.shared_clock_exchange_wait()
+            return
         b = self.members[0].bytes
         for dst in self.members:
             if dst.world == 1:

@@ -32,12 +32,15 @@ def test_one_rank_frame_through_the_c_loop_and_through_the_graph(hip):
     rem = 0.004                                                    # a whole (short) frame: a few hundred passes
     e, single, st1 = _gpu_run(hip, frame, ph, cfg, 99, 3.0, rem)
     assert st1.frame_scatt_cnt > 50 and st1.remaining_time == 0.0
-    variants = ["loop"] + (["graph", "graph+rccl"] if rccl is not None else [])
+    variants = ["loop"] + (["graph", "graph+rccl", "graph+device"] if rccl is not None else [])
     for variant in variants:
         stream = torch.cuda.Stream()
         eng = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], stream=stream.cuda_stream)
         eng.set_hydro(frame)
         eng.set_photons(ph)
+        if variant == "graph+device":                             # the device-initiated exchange (with itself: one rank) inside the captured rounds
+            recv, _, flags, _ = eng.shared_clock_attach_device(1, 0, 0)
+            eng.shared_clock_set_peers([recv], [flags])
         t, st = C.c_double(3.0), hip.FrameStats()
         if variant == "loop":
             rc = host.mcrat_host_shared_clock_frame(eng.ctx, 1, 0, 0, None, None, C.c_void_p(stream.cuda_stream), C.byref(t), rem, 99, 16, C.byref(st))

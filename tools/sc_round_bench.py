@@ -13,18 +13,24 @@ n = int(os.environ.get("N", "1000000"))
 frame, ph, cfg = synth.config2(n_photons=n)
 host, rccl = B.host(), B.host_rccl()
 rem = float(os.environ.get("REM", "0.02"))           # a tenth of the frame: ~800 passes of the one list
-for variant in ("c-loop", "c-graph", "c-graph+rccl"):
+for variant in ("c-loop", "c-graph", "c-graph+rccl", "c-loop+device", "c-graph+device"):
     stream = torch.cuda.Stream()
     e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], stream=stream.cuda_stream)
     e.set_hydro(frame)
     e.set_photons(ph)
     t, st = C.c_double(0.0), engine.FrameStats()
     comm = C.c_void_p()
+    if variant.endswith("+device"):                      # device-initiated exchange (one rank: with itself): a push and a wait kernel per round
+        recv, _, flags, _ = e.shared_clock_attach_device(1, 0, 0)
+        e.shared_clock_set_peers([recv], [flags])
     if variant == "c-graph+rccl":
         rccl.mcrat_host_rccl_comm_single(C.byref(comm))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if variant == "c-loop":
+    if variant == "c-loop+device":
+        cb = C.cast(host.mcrat_host_exchange_device, B.ALLGATHER)
+        rc = host.mcrat_host_shared_clock_frame(e.ctx, 1, 0, 0, cb, e.ctx, C.c_void_p(stream.cuda_stream), C.byref(t), rem, 7, 64, C.byref(st))
+    elif variant == "c-loop":
         rc = host.mcrat_host_shared_clock_frame(e.ctx, 1, 0, 0, None, None, C.c_void_p(stream.cuda_stream), C.byref(t), rem, 7, 64, C.byref(st))
     else:
         rc = rccl.mcrat_host_shared_clock_frame_graph(e.ctx, 1, 0, 0, comm, C.c_void_p(stream.cuda_stream), C.byref(t), rem, 7, 64, C.byref(st))
