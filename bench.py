@@ -291,7 +291,8 @@ def cfg5_cpu_baseline(pool, field, R, max_photons, fps, r_inj, th_max, cores):
     H = O.OracleHydro(dict(cols, **dom, fps=fps))
     c = O.make_config(synth.THREE, synth.SPHERICAL, 1)
     ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
-    lists = [pool.pool_rank(r, r).get_photons_aos().astype(O.PHOTON_DTYPE) for r in range(min(cores, R))]
+    n_sample = min(R, 64 * cores)                    # ~10 s of CPU work on the box's cores: whole frames of 64 lists per core
+    lists = [pool.pool_rank(r, r).get_photons_aos().astype(O.PHOTON_DTYPE) for r in range(n_sample)]
     L = O.lib()
 
     def one(r):
@@ -310,19 +311,20 @@ def cfg5_cpu_baseline(pool, field, R, max_photons, fps, r_inj, th_max, cores):
         L.orc_rng_init(C.byref(rng), SEED + r, r)
         st, cnt, t = O.Stats(), O.CSCounts(), C.c_double(1.0 / fps)
         t0 = time.perf_counter()
-        L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), 1.0 / fps, r_inj, 1e50, max_photons, 0.0, th_max, 1, 150,
+        L.orc_scatter_frame_cs(C.byref(c), C.byref(cs), C.byref(l), C.byref(H.c), C.byref(rng), C.byref(t), 1.0 / fps, r_inj, 1e50, max_photons, 0.0, th_max, 1, 0,
                                C.byref(st), C.byref(cnt))
         dt = time.perf_counter() - t0
         L.orc_list_free(C.byref(l))
         return st.frame_scatt_cnt, st.photon_steps, dt
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(len(lists)) as ex:
+    with ThreadPoolExecutor(cores) as ex:
         res = list(ex.map(one, range(len(lists))))
     dt = time.perf_counter() - t0
-    return {"value": sum(x[0] for x in res) / dt, "unit": "scatter-events/s", "cores": len(lists), "kind": "port",
-            "photon_steps_per_s": sum(x[1] for x in res) / dt, "wall_s": dt,
-            "sample": "oracle/ (faithful C restatement of mcrat.c:706-878 with the switch on) on %d host cores at once, one of the device's lists per core on the "
-                      "frame the device holds (%d cells): pool emission, then 150 loop passes each" % (len(lists), int(cols["num_elements"]))}
+    return {"value": sum(x[0] for x in res) / dt, "unit": "scatter-events/s", "cores": min(cores, len(lists)), "kind": "port",
+            "photon_steps_per_s": sum(x[1] for x in res) / dt, "wall_s": dt, "rank_frames": len(lists),
+            "sample": "oracle/ (faithful C restatement of mcrat.c:706-878 with the switch on) on %d host cores at once, one of the device's lists per core at a "
+                      "time, %d lists in all, on the frame the device holds (%d cells): each list's whole scatter frame -- pool emission, the loop with the "
+                      "hook, absorption" % (min(cores, len(lists)), len(lists), int(cols["num_elements"]))}
 
 
 def main():

@@ -81,7 +81,7 @@ if os.path.exists(t) and os.path.getsize(t) > 0:
 b = os.path.join(src, "bench.json")
 if os.path.exists(b) and os.path.getsize(b) > 0:
     shutil.copy(b, os.path.join(dst, "%s_bench.json" % tag))
-for name in ("bench_cfg3", "kt_cfg5", "kt_default"):
+for name in ("bench_cfg3", "bench_cfg5", "kt_cfg5", "kt_default"):
     b = os.path.join(src, name + ".json")
     if os.path.exists(b) and os.path.getsize(b) > 0:
         shutil.copy(b, os.path.join(dst, "%s_%s.json" % (tag, name.replace("kt_cfg5", "bench_cfg5_traced").replace("kt_default", "bench_traced"))))

@@ -23,6 +23,8 @@ done
 echo "== cfg3 at 1e7 photons, no profiler, then its kernel trace"
 python3 bench.py --config cfg3 --steps 5 --warmup 1 > $out/bench_cfg3.json 2> $out/bench_cfg3.err; echo "exit=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg3 -- python3 bench.py --config cfg3 --steps 5 --warmup 1 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_cfg3.json 2> $out/kt_cfg3.err; echo "exit=$?"
+echo "== cfg5 at 1e7 photons, no profiler"
+python3 bench.py --config cfg5 --steps 2 --warmup 1 > $out/bench_cfg5.json 2> $out/bench_cfg5.err; echo "exit=$?"
 echo "== cfg5 at 1e7 photons: kernel trace"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg5 -- python3 bench.py --config cfg5 --steps 2 --warmup 1 --no-cpu-baseline > $out/kt_cfg5.json 2> $out/kt_cfg5.err; echo "exit=$?"
 echo "== kernel trace, producers and consumers around the loop (ingest, injection, output, hot table)"
