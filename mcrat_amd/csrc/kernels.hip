@@ -1288,6 +1288,12 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
     __shared__ int s_q[FAST_BLOCK];
     __shared__ int s_nq;
     __shared__ unsigned long long s_cnt[6];
+#ifdef MCRAT_DIAG
+    __shared__ LoopState s_stamps;                   // scatter_core's shader-clock stamps of the diagnostic build need somewhere to go
+    LoopState *const stamp_state = &s_stamps;
+#else
+    LoopState *const stamp_state = nullptr;          // (never dereferenced: MC_STAMP is empty)
+#endif
     const int tid = threadIdx.x;
     const int i = blockIdx.x * FAST_BLOCK + tid;
     int first = 0, len = ph.n;
@@ -1380,7 +1386,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
             if constexpr (STOKES) { s[0] = ph.s0[k]; s[1] = ph.s1[k]; s[2] = ph.s2[k]; s[3] = ph.s3[k]; }
             const unsigned kf = ph.flags[k];
             double fluid_temp, tau_new;
-            if (scatter_core<DIMS, GEOM, STOKES, false>(hy, (LoopState *)nullptr, key, (unsigned long long)pass, (uint32_t)k + rng_first, kc, r, p, pc, s,
+            if (scatter_core<DIMS, GEOM, STOKES, false>(hy, stamp_state, key, (unsigned long long)pass, (uint32_t)k + rng_first, kc, r, p, pc, s,
                                                         fluid_temp, tau_new)) {
                 commit_scatter<STOKES>(ph, k, p, pc, s, r, tau_new, kf);
                 scatt += 1;
