@@ -343,7 +343,7 @@ int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *c
  *                                weight in its cell (:786-795; photonEmitCyclosynch with inject_single_switch = 1, the list doubling
  *                                when it has no null slot), and every 1000 scatterings the comptonised photons are rebinned once there
  *                                are more than max_photons of them (:797-808).  Needs a context created with
- *                                cyclosynchrotron_switch = 1 (one list per context: no virtual ranks, no shared clock; mcrat_hip_run
+ *                                cyclosynchrotron_switch = 1 (one list per context -- many lists: mcrat_hip_pool_scatter_frames_cyclosynch --, no shared clock; mcrat_hip_run
  *                                and mcrat_hip_propagate_frame refuse such a context).  max_iterations <= 0: until the frame is over. */
 typedef struct mcrat_hip_cyclosynch_counts {
     int    num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph, frame_abs_cnt;   /* the counters of mcrat.c:735-878.  scatt_cyclosynch_num_ph is IN/OUT:
