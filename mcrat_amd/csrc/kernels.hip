@@ -755,6 +755,9 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
     // (-DMCRAT_NO_WAVE_WALK=1 builds the one-lane walk for A/B runs, tools/hot_bench.py.)
     for (int round = 0; round < max_rounds; ++round) {
         if (WAVE_WALK ? tid < 64 : tid == 0) {
+#ifndef MCRAT_NO_WALK_PRIORITY
+            __builtin_amdgcn_s_setprio(3);                 // the walk is its list's critical path: it goes first where its SIMD is shared
+#endif
             int status = EV_NEED_MORE;
             if (n_list == 0) {                             // every slot was tried (or there is none): mclib.c:1128 loop ends
                 w.dt = (round == 0) ? w.dt_max : w.old_scatt_time;
@@ -770,6 +773,9 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
                 rescans += 1;
             }
             sh.status = status;
+#ifndef MCRAT_NO_WALK_PRIORITY
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         __syncthreads();
         if (sh.status != EV_NEED_MORE) break;
