@@ -344,6 +344,7 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=300, help="list-mode passes bracketed by HIP events for the roofline")
     ap.add_argument("--other-mode", type=int, default=1, help="also measure the other run shape briefly")
+    ap.add_argument("--pools", type=int, default=2, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to")
     ap.add_argument("--fast-windows", type=int, default=8, help="FAST mode beside the exact headline: refreshes per frame (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shared-clock-rounds", type=int, default=300,
@@ -415,7 +416,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def make_engine(mode, profile=False, per_sync=None, photons=None, lists=None, stream_base=None):
+    def make_engine(mode, profile=False, per_sync=None, photons=None, lists=None, stream_base=None, stream=stream):
         if mode == "ranks":
             # a rank pool: every list its own length, stream and clock, all lists propagated by one launch (mcrat_hip_pool_*)
             src = ph if photons is None else photons
@@ -447,17 +448,51 @@ def main():
             it += st.iterations
         return ev, ps, it
 
-    def measure_ranks(k_frames, k_warm, with_roofline):
-        e = make_engine("ranks")
-        e.snapshot_photons()
-        run_ranks(e, k_warm, SEED + 1000)
+    def run_pooled(l0, l1, k_frames, k_warm, photons=None, stream_base=None):
+        """the lists [l0, l1) as --pools rank pools on their own HIP streams, a host thread each; k_warm untimed frames, then k_frames frames
+        timed between two barriers -> (events, photon_steps, passes, seconds)"""
+        import threading
+        pools = max(1, min(int(args.pools), l1 - l0))
+        engines, keep = [], []
+        for p in range(pools):
+            lo, hi = l0 + (p * (l1 - l0)) // pools, l0 + ((p + 1) * (l1 - l0)) // pools
+            ts = torch.cuda.Stream()
+            keep.append(ts)
+            engines.append(make_engine("ranks", photons=photons, lists=(lo, hi), stream_base=stream_base, stream=ts.cuda_stream if pools > 1 else stream))
+            engines[-1].snapshot_photons()
+        tot = [None] * pools
+        gate = threading.Barrier(pools + 1)
+
+        def drive(p):
+            torch.cuda.set_device(local_rank)
+            run_ranks(engines[p], k_warm, SEED + 1000)
+            engines[p].synchronize()
+            gate.wait()                       # warm-up done everywhere
+            gate.wait()                       # the clock is running
+            tot[p] = run_ranks(engines[p], k_frames, SEED)
+            engines[p].synchronize()
+        threads = [threading.Thread(target=drive, args=(p,)) for p in range(pools)]
+        for th in threads:
+            th.start()
+        gate.wait()
         sync()
         t0 = time.perf_counter()
-        ev, ps, it = run_ranks(e, k_frames, SEED)
+        gate.wait()
+        for th in threads:
+            th.join()
         sync()
         dt = time.perf_counter() - t0
+        for e in engines:
+            e.close()
+        return sum(x[0] for x in tot), sum(x[1] for x in tot), sum(x[2] for x in tot), dt
+
+    def measure_ranks(k_frames, k_warm, with_roofline):
+        # The adopted ranks never wait for each other (the reference's MPI ranks are asynchronous processes), so they need not share one
+        # launch either: --pools P deals the lists out to P rank pools, each on its own HIP stream and driven by its own host thread
+        # (as P processes sharing the GPU would be).  A step is still one hydro frame for ALL lists; what changes is that a pool whose last
+        # lists are finishing no longer leaves the rest of the device idle -- the other pools' next frames fill it.
+        ev, ps, it, dt = run_pooled(0, n_lists, k_frames, k_warm)
         nr = n_lists
-        e.close()
         roof = None
         if with_roofline:
             # rank_loop_kernel between HIP events (one launch per frame here); algorithmic bytes = 110 B x the
@@ -482,7 +517,9 @@ def main():
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches),
                     "note": "latency-bound persistent kernel (one workgroup walks one list's whole frame; the forced "
-                            "re-location pass of the new frame is inside the launch); the HBM-bound kernel of this path is "
+                            "re-location pass of the new frame is inside the launch), measured on ONE pool holding all lists -- one "
+                            "launch per frame, alone on the device (with --pools > 1 the headline's launches overlap each other, "
+                            "which is the point, and have no duration of their own); the HBM-bound kernel of this path is "
                             "step_kernel, see other_mode.roofline"}
         return dict(events=ev, photon_steps=ps, passes=it, seconds=dt, ranks=nr, roofline=roof)
 
@@ -497,15 +534,7 @@ def main():
         else:
             _, common, _ = synth.config2(n_photons=args.photons, seed=SEED, nzc=args.nzc, stokes=args.stokes)
         lo, hi = sharding.shard_bounds(n_lists, world, rank)
-        e = make_engine("ranks", photons=common, lists=(lo, hi), stream_base=0)
-        e.snapshot_photons()
-        run_ranks(e, k_warm, SEED + 1000)
-        sync()
-        t0 = time.perf_counter()
-        ev, ps, it = run_ranks(e, k_frames, SEED)
-        sync()
-        dt = time.perf_counter() - t0
-        e.close()
+        ev, ps, it, dt = run_pooled(lo, hi, k_frames, k_warm, photons=common, stream_base=0)
         return ev, ps, dt, hi - lo
 
     def measure_list(k_steps, k_warm, prof_steps):
@@ -901,10 +930,14 @@ def main():
 
     if rank == 0:
         if args.mode == "ranks":
-            shape = ("a rank pool of %d adopted ranks with lists of %d-%d photons (independent lists, own clock and RNG stream each: the "
-                     "reference's MPI ranks; one workgroup per list, all lists in one launch); step = one hydro frame (1/fps = %.2f s) for "
-                     "all lists, restarted from the resident snapshot"
-                     % (main_res.get("ranks", 0), int(lens.min()), int(lens.max()), remaining))
+            pools = max(1, min(int(args.pools), n_lists))
+            shape = ("%d adopted ranks with lists of %d-%d photons (independent lists, own clock and RNG stream each: the reference's MPI "
+                     "ranks; one workgroup per list) in %s; step = one hydro frame (1/fps = %.2f s) for all lists, every pool restarted from "
+                     "its resident snapshot"
+                     % (main_res.get("ranks", 0), int(lens.min()), int(lens.max()),
+                        "one rank pool, all lists in one launch" if pools == 1 else
+                        "%d rank pools on %d HIP streams with a host thread each (the ranks are asynchronous in the reference too: a pool whose "
+                        "last lists are finishing no longer leaves the device idle), one launch per pool and frame" % (pools, pools), remaining))
         elif args.mode == "list":
             shape = "one list, one clock; step = one loop pass over all photons"
         else:

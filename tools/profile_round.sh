@@ -9,20 +9,20 @@ rm -rf $out && mkdir -p $out
 echo "== bench, no profiler"
 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "exit=$?"
 echo "== kernel trace of the default bench command"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_default -- python3 bench.py --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_default.json 2> $out/kt_default.err; echo "exit=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_default -- python3 bench.py --pools 1 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_default.json 2> $out/kt_default.err; echo "exit=$?"
 echo "== kernel trace, list mode (eager launches so that every kernel is a trace record)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_list -- python3 bench.py --mode list --steps 500 --warmup 20 --graph 0 --other-mode 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/kt_list.json 2> $out/kt_list.err; echo "exit=$?"
 i=0
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
   echo "== pmc pass $i ($ctrs), ranks mode"
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_ranks/p$i -- python3 bench.py --steps 5 --warmup 1 --other-mode 0 --host-driver 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/pmc_ranks_p$i.json 2> $out/pmc_ranks_p$i.err; echo "exit=$?"
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_ranks/p$i -- python3 bench.py --pools 1 --steps 5 --warmup 1 --other-mode 0 --host-driver 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/pmc_ranks_p$i.json 2> $out/pmc_ranks_p$i.err; echo "exit=$?"
   echo "== pmc pass $i ($ctrs), list mode"
   rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_list/p$i -- python3 bench.py --mode list --steps 100 --warmup 10 --profile-steps 0 --graph 0 --other-mode 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/pmc_list_p$i.json 2> $out/pmc_list_p$i.err; echo "exit=$?"
 done
 echo "== cfg3 at 1e7 photons, no profiler, then its kernel trace"
 python3 bench.py --config cfg3 --steps 5 --warmup 1 > $out/bench_cfg3.json 2> $out/bench_cfg3.err; echo "exit=$?"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg3 -- python3 bench.py --config cfg3 --steps 5 --warmup 1 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_cfg3.json 2> $out/kt_cfg3.err; echo "exit=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_cfg3 -- python3 bench.py --config cfg3 --pools 1 --steps 5 --warmup 1 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_cfg3.json 2> $out/kt_cfg3.err; echo "exit=$?"
 echo "== cfg5 at 1e7 photons, no profiler"
 python3 bench.py --config cfg5 --steps 2 --warmup 1 > $out/bench_cfg5.json 2> $out/bench_cfg5.err; echo "exit=$?"
 echo "== cfg5 at 1e7 photons: kernel trace"
