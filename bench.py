@@ -206,65 +206,101 @@ def bench_cfg5(args):
         return [np.ascontiguousarray(0.2 * b), np.ascontiguousarray(0.1 * b), np.ascontiguousarray(b)]
     R = max(1, int(round(n_target / float(args.rank_photons))))
     max_photons = 2 * args.rank_photons
-    pool = engine.Engine(synth.THREE, synth.SPHERICAL, 1, cyclosynchrotron=1)
-    t0 = time.perf_counter()
-    m_inj, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **dom), jet)
-    pool.pool_create(R, 4 * max_photons)
-    n = 0
-    for r in range(R):
-        k, _ = pool.pool_rank(r, r).inject_photons(r_inj, 1e50, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2, "b", 0.0, th_max, fps, SEED + r)
-        n += k
-    setup_inject = time.perf_counter() - t0
-
-    def stage(F):
-        mm = pool.ph_minmax()
-        lo = min(mm[0], r_inj + synth.C_LIGHT * (F / fps - 0.5 / fps))
-        hi = max(mm[1], r_inj + synth.C_LIGHT * (F / fps + 0.5 / fps))
-        m, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=0, min_r=lo, max_r=hi, min_theta=mm[2], max_theta=mm[3], fps=fps, **dom), jet)
-        pool.set_hydro_extras(None, *field(pool.get_hydro()))
-        return m
-
-    def frame_args(F, t_now, seed0, emit):
-        return [dict(seed=seed0 + r, time_now=t_now, remaining_time=(F + 1) / fps - t_now, r_inj=r_inj, ph_weight_suggest=1e50, theta_min=0.0, theta_max=th_max,
-                     emit_pool=emit, scatt_frame_number=F, inj_frame_number=0) for r in range(R)]
-    stage(0)
-    sts, cnts = pool.pool_scatter_frames_cyclosynch(frame_args(0, 0.0, SEED, 0), max_photons, fps, b_field_calc=2, rebin_ang_phi=45.0)   # the injection frame's own scatter frame: no pool yet
-    m_cells = stage(1)
-    pool.snapshot_photons()
+    n_pools = max(1, min(int(args.pools) if args.pools > 0 else 1, R))
     t1 = 1.0 / fps
 
-    def one(seed0):
-        pool.restore_photons()
-        st, cn = pool.pool_scatter_frames_cyclosynch(frame_args(1, t1, seed0, 1), max_photons, fps, b_field_calc=2, rebin_ang_phi=45.0)
-        slots = sum(int(pool.lib.mcrat_hip_num_photon_slots(pool.pool_rank(r, r).ctx)) for r in range(0, R, max(1, R // 64))) * max(1, R // 64)
-        return (sum(x.frame_scatt_cnt for x in st), sum(x.photon_steps for x in st), sum(x.iterations for x in st), sum(x.num_cyclosynch_ph_emit for x in cn),
-                sum(x.frame_abs_cnt for x in cn), sum(x.rebins for x in cn), slots)
-    for k in range(warmup):
-        one(SEED + 100000 * (k + 1))
+    class Pool:
+        """the adopted ranks [lo, hi) as one rank pool on its own HIP stream: frame ingested, lists injected, the injection frame's own scatter
+        frame done (no pool photons yet), the next frame staged, snapshot taken"""
+
+        def __init__(self, lo, hi):
+            self.lo, self.hi = lo, hi
+            self.ts = torch.cuda.Stream()
+            pool = self.pool = engine.Engine(synth.THREE, synth.SPHERICAL, 1, cyclosynchrotron=1, stream=self.ts.cuda_stream)
+            self.m_inj, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **dom), jet)
+            pool.pool_create(hi - lo, 4 * max_photons)
+            self.n = 0
+            for r in range(lo, hi):
+                k, _ = pool.pool_rank(r - lo, r).inject_photons(r_inj, 1e50, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2, "b", 0.0, th_max, fps, SEED + r)
+                self.n += k
+            self.stage(0)
+            pool.pool_scatter_frames_cyclosynch(self.frame_args(0, 0.0, SEED, 0), max_photons, fps, b_field_calc=2, rebin_ang_phi=45.0)
+            self.m_cells = self.stage(1)
+            pool.snapshot_photons()
+
+        def stage(self, F):
+            pool = self.pool
+            mm = pool.ph_minmax()
+            lo = min(mm[0], r_inj + synth.C_LIGHT * (F / fps - 0.5 / fps))
+            hi = max(mm[1], r_inj + synth.C_LIGHT * (F / fps + 0.5 / fps))
+            m, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=0, min_r=lo, max_r=hi, min_theta=mm[2], max_theta=mm[3], fps=fps, **dom), jet)
+            pool.set_hydro_extras(None, *field(pool.get_hydro()))
+            return m
+
+        def frame_args(self, F, t_now, seed0, emit):
+            return [dict(seed=seed0 + r, time_now=t_now, remaining_time=(F + 1) / fps - t_now, r_inj=r_inj, ph_weight_suggest=1e50, theta_min=0.0, theta_max=th_max,
+                         emit_pool=emit, scatt_frame_number=F, inj_frame_number=0) for r in range(self.lo, self.hi)]
+
+        def one(self, seed0):
+            pool, R_ = self.pool, self.hi - self.lo
+            pool.restore_photons()
+            st, cn = pool.pool_scatter_frames_cyclosynch(self.frame_args(1, t1, seed0, 1), max_photons, fps, b_field_calc=2, rebin_ang_phi=45.0)
+            stride = max(1, R_ // 64)
+            slots = sum(int(pool.lib.mcrat_hip_num_photon_slots(pool.pool_rank(r, self.lo + r).ctx)) for r in range(0, R_, stride)) * stride
+            return (sum(x.frame_scatt_cnt for x in st), sum(x.photon_steps for x in st), sum(x.iterations for x in st), sum(x.num_cyclosynch_ph_emit for x in cn),
+                    sum(x.frame_abs_cnt for x in cn), sum(x.rebins for x in cn), slots)
+    t0 = time.perf_counter()
+    pools = [Pool((p * R) // n_pools, ((p + 1) * R) // n_pools) for p in range(n_pools)]
+    setup_inject = time.perf_counter() - t0
+    n, m_cells = sum(P.n for P in pools), max(P.m_cells for P in pools)
+    pool = pools[0].pool
+    # the pools run their frames side by side, a host thread each (the ranks are asynchronous in the reference too): the twenty-odd launches of
+    # a frame each end with the lists that park last, and another pool's lists fill the device meanwhile
+    import threading
+    gate = threading.Barrier(n_pools + 1)
+    parts = [None] * n_pools
+
+    def drive(p):
+        for k in range(warmup):
+            pools[p].one(SEED + 100000 * (k + 1))
+        pools[p].pool.synchronize()
+        gate.wait()
+        gate.wait()
+        acc = [0] * 7
+        for k in range(steps):
+            acc = [a + b for a, b in zip(acc, pools[p].one(SEED + 7 + 1000 * k))]
+        pools[p].pool.synchronize()
+        parts[p] = acc
+    threads = [threading.Thread(target=drive, args=(p,)) for p in range(n_pools)]
+    for th in threads:
+        th.start()
+    gate.wait()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    tot = [0] * 7
-    for k in range(steps):
-        got = one(SEED + 7 + 1000 * k)
-        tot = [a + b for a, b in zip(tot, got)]
+    gate.wait()
+    for th in threads:
+        th.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tot = [sum(x[j] for x in parts) for j in range(7)]
     achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[1] / dt / 1e9
     cpu = None
     if not args.no_cpu_baseline:
         try:
-            cpu = cfg5_cpu_baseline(pool, field, R, max_photons, fps, r_inj, th_max, host_cores())
+            cpu = cfg5_cpu_baseline(pool, field, pools[0].hi - pools[0].lo, max_photons, fps, r_inj, th_max, host_cores())
         except Exception as ex:
             cpu = {"error": "%s: %s" % (type(ex).__name__, ex)}
-    pool.close()
+    for P in pools:
+        P.pool.close()
     out = {"metric": "photon-scatter-events/sec at 1e7 photons, 3D PLUTO-Chombo MHD jet with cyclo-synchrotron emission/absorption",
            "value": tot[0] / dt, "unit": "scatter-events/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3 / steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "BASELINE.json configs[4] on one GPU: 3-D PLUTO-Chombo AMR frame in spherical coordinates (%d cells read, %d in the photons' "
                                   "slab), B_FIELD_CALC == SIMULATION, cyclo-synchrotron emission and absorption, Compton+KN, Stokes on; %d injected photons "
-                                  "as a rank pool of %d adopted ranks (lists of %d-%d photons that grow with their pool photons); step = one scatter frame "
-                                  "(mcrat.c:706-878: pool emission, loop with replacement of scattered pool photons, rebinning, absorption) for all lists, "
-                                  "from a resident snapshot" % (cells_read, m_cells, n, R, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2),
+                                  "as %d adopted ranks (lists of %d-%d photons that grow with their pool photons) in %d rank pool(s), each on its own HIP stream "
+                                  "with a host thread; step = one scatter frame (mcrat.c:706-878: pool emission, loop with replacement of scattered pool "
+                                  "photons, rebinning, absorption) for all lists, from resident snapshots"
+                                  % (cells_read, m_cells, n, R, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2, n_pools),
                       "mode": "ranks", "photons_per_gpu": n, "cells": int(m_cells), "parallelism": "independent photon shards x1"},
            "photon_steps_per_s": tot[1] / dt, "scatter_events": tot[0], "loop_passes": tot[2],
            "cyclosynchrotron": {"pool_photons_emitted_per_frame": tot[3] / steps, "photons_absorbed_per_frame": tot[4] / steps, "rebinnings_per_frame": tot[5] / steps,
@@ -344,7 +380,8 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=300, help="list-mode passes bracketed by HIP events for the roofline")
     ap.add_argument("--other-mode", type=int, default=1, help="also measure the other run shape briefly")
-    ap.add_argument("--pools", type=int, default=2, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to")
+    ap.add_argument("--pools", type=int, default=0, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to; 0: 2 for "
+                                                        "cfg2 / cfg3 (measured: 0.95 -> 0.70 ms per frame), 1 for cfg5 (measured: 381 ms with one pool, 414 with two)")
     ap.add_argument("--fast-windows", type=int, default=8, help="FAST mode beside the exact headline: refreshes per frame (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shared-clock-rounds", type=int, default=300,
@@ -452,7 +489,7 @@ def main():
         """the lists [l0, l1) as --pools rank pools on their own HIP streams, a host thread each; k_warm untimed frames, then k_frames frames
         timed between two barriers -> (events, photon_steps, passes, seconds)"""
         import threading
-        pools = max(1, min(int(args.pools), l1 - l0))
+        pools = max(1, min(int(args.pools) if args.pools > 0 else 2, l1 - l0))
         engines, keep = [], []
         for p in range(pools):
             lo, hi = l0 + (p * (l1 - l0)) // pools, l0 + ((p + 1) * (l1 - l0)) // pools
@@ -930,7 +967,7 @@ def main():
 
     if rank == 0:
         if args.mode == "ranks":
-            pools = max(1, min(int(args.pools), n_lists))
+            pools = max(1, min(int(args.pools) if args.pools > 0 else 2, n_lists))
             shape = ("%d adopted ranks with lists of %d-%d photons (independent lists, own clock and RNG stream each: the reference's MPI "
                      "ranks; one workgroup per list) in %s; step = one hydro frame (1/fps = %.2f s) for all lists, every pool restarted from "
                      "its resident snapshot"
