@@ -207,3 +207,56 @@ def test_pool_refusals(hip):
     pool.pool_create(3, 1000)                          # re-creating drops the lists
     assert pool.pool_summaries()[0].list_capacity == 0
     pool.close()
+
+
+def test_two_pools_on_two_streams_driven_by_two_host_threads(hip):
+    """the adopted ranks are asynchronous (the reference's MPI ranks are processes): a process may deal them out to several pools, each a context
+    of its own on its own HIP stream with its own host thread (bench.py --pools) -- every list ends up as in one pool"""
+    import threading
+    import torch
+    n, per, R = 12000, 1000, 12
+    frame, ph, cfg = synth.config2(n_photons=n, nzc=8, lumi=3e53)
+    rem = 1.0 / frame["fps"]
+
+    def make(lo, hi, stream=None):
+        p = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], stream=stream)
+        p.set_hydro(frame)
+        p.pool_create(hi - lo, per)
+        for r in range(lo, hi):
+            p.pool_rank(r - lo, 50 + r).set_photons(_cut(ph, r * per, (r + 1) * per, n))
+        p.snapshot_photons()
+        return p
+    one = make(0, R)
+    ref = []
+    for k in range(3):                                                     # three frames from the snapshot, the last one is compared
+        one.restore_photons()
+        one.begin_frame(900 + k, 0.0, rem)
+        tot = one.run(0)
+    ref = [one.pool_rank(r, 50 + r).get_photons() for r in range(R)]
+    assert tot.frame_scatt_cnt > 1000
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    halves = [make(0, 5, streams[0].cuda_stream), make(5, R, streams[1].cuda_stream)]
+    stats, errors = [None, None], []
+
+    def drive(p):
+        try:
+            for k in range(3):
+                halves[p].restore_photons()
+                halves[p].begin_frame(900 + k, 0.0, rem)
+                stats[p] = halves[p].run(0)
+        except Exception as ex:                                            # surfaced below: a thread must not fail silently
+            errors.append(ex)
+    threads = [threading.Thread(target=drive, args=(p,)) for p in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert stats[0].frame_scatt_cnt + stats[1].frame_scatt_cnt == tot.frame_scatt_cnt
+    for p, (lo, hi) in enumerate(((0, 5), (5, R))):
+        for r in range(lo, hi):
+            out = halves[p].pool_rank(r - lo, 50 + r).get_photons()
+            for k in FLOAT_FIELDS + INT_FIELDS:
+                assert np.array_equal(out[k], ref[r][k], equal_nan=True), (r, k)
+    for e in [one] + halves:
+        e.close()
