@@ -31,10 +31,28 @@ def _lists(ph, lens):
     return out
 
 
-@pytest.mark.parametrize("case", ["cfg2-stokes", "cfg3-stokes-long", "cfg1-global"])
+def _hot_table():
+    """a smooth stand-in for thermal_hot_x_section.dat on the reference's grid (as tests/test_gpu_parity.py)"""
+    i, j = np.meshgrid(np.arange(221), np.arange(81), indexing="ij")
+    x = -12.0 + i * (18.0 / 220)
+    y = -4.0 + j * (8.0 / 80)
+    return -0.35 * np.log1p(np.exp(2.0 * (x + 0.5))) / np.log(10) - 0.02 * (y + 4.0) * (1 + 0.1 * np.tanh(x))
+
+
+@pytest.mark.parametrize("case", ["cfg2-stokes", "cfg3-stokes-long", "cfg1-global", "cfg2-table", "2.5d-cylindrical", "3d-spherical", "3d-cartesian"])
 def test_unequal_lists_equal_independent_oracle_runs(hip, oracle, case, monkeypatch):
     lens = [137, 1000, 512, 999, 3, 64, 700, 1024]
-    if case == "cfg2-stokes":
+    kw, okw = {}, {}
+    if case == "cfg2-table":                          # the TAU_CALCULATION == TABLE build of the kernels (kernels_table_d0.hip)
+        frame, ph, cfg = synth.config2(n_photons=sum(lens), nzc=8, stokes=1, lumi=1e54)
+        kw, okw = dict(tau_calculation=hip.TAU_TABLE), dict(hot_table=_hot_table())
+    elif case == "2.5d-cylindrical":                  # kernels_d1.hip
+        frame, ph, cfg = synth.config_25d(synth.CYLINDRICAL, n_photons=sum(lens))
+    elif case == "3d-spherical":                      # kernels_d2.hip
+        frame, ph, cfg = synth.config_3d(synth.SPHERICAL, n_photons=sum(lens))
+    elif case == "3d-cartesian":
+        frame, ph, cfg = synth.config_3d_cartesian(n_photons=sum(lens))
+    elif case == "cfg2-stokes":
         frame, ph, cfg = synth.config2(n_photons=sum(lens), nzc=8, stokes=1, lumi=1e54)
     elif case == "cfg3-stokes-long":
         lens[5] = 1500                                 # one list beyond what is kept in LDS: every list takes the HBM/L2 path
@@ -50,7 +68,9 @@ def test_unequal_lists_equal_independent_oracle_runs(hip, oracle, case, monkeypa
     rem = [0.2 - 0.01 * r for r in range(R)]
     passes = 250
 
-    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], **kw)
+    if "hot_table" in okw:
+        pool.set_hot_cross_section(okw["hot_table"])
     pool.set_hydro(frame)
     pool.pool_create(R, 1600)
     views = []
@@ -64,7 +84,7 @@ def test_unequal_lists_equal_independent_oracle_runs(hip, oracle, case, monkeypa
     tot = pool.run(passes)
 
     H = oracle.OracleHydro(frame)
-    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"], **okw)
     sums = dict(it=0, sc=0)
     for r in range(R):
         if r == 4:
