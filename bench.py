@@ -382,6 +382,7 @@ def main():
     ap.add_argument("--other-mode", type=int, default=1, help="also measure the other run shape briefly")
     ap.add_argument("--pools", type=int, default=0, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to; 0: 2 for "
                                                         "cfg2 / cfg3 (measured: 0.95 -> 0.70 ms per frame), 1 for cfg5 (measured: 381 ms with one pool, 414 with two)")
+    ap.add_argument("--share-hydro", type=int, default=1, help="the pools read one staged copy of the hydro frame (mcrat_hip_share_hydro)")
     ap.add_argument("--fast-windows", type=int, default=8, help="FAST mode beside the exact headline: refreshes per frame (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shared-clock-rounds", type=int, default=300,
@@ -453,7 +454,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def make_engine(mode, profile=False, per_sync=None, photons=None, lists=None, stream_base=None, stream=stream):
+    def make_engine(mode, profile=False, per_sync=None, photons=None, lists=None, stream_base=None, stream=stream, share_from=None):
         if mode == "ranks":
             # a rank pool: every list its own length, stream and clock, all lists propagated by one launch (mcrat_hip_pool_*)
             src = ph if photons is None else photons
@@ -461,7 +462,10 @@ def main():
             sb = first_stream if stream_base is None else stream_base
             e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
                               rng_stream=sb, profile=profile)
-            e.set_hydro(frame)
+            if share_from is not None:
+                e.share_hydro(share_from)        # the pools are in the same hydro frame: one staged copy of it for all of them
+            else:
+                e.set_hydro(frame)
             e.pool_create(max(1, hi - lo), int(lens.max()))
             for r in range(lo, hi):
                 e.pool_rank(r - lo, sb + r).set_photons(sub_photons(src, int(offs[r]), int(offs[r + 1])))
@@ -495,7 +499,8 @@ def main():
             lo, hi = l0 + (p * (l1 - l0)) // pools, l0 + ((p + 1) * (l1 - l0)) // pools
             ts = torch.cuda.Stream()
             keep.append(ts)
-            engines.append(make_engine("ranks", photons=photons, lists=(lo, hi), stream_base=stream_base, stream=ts.cuda_stream if pools > 1 else stream))
+            engines.append(make_engine("ranks", photons=photons, lists=(lo, hi), stream_base=stream_base, stream=ts.cuda_stream if pools > 1 else stream,
+                                       share_from=engines[0] if (engines and args.share_hydro) else None))
             engines[-1].snapshot_photons()
         tot = [None] * pools
         gate = threading.Barrier(pools + 1)
@@ -519,7 +524,7 @@ def main():
             th.join()
         sync()
         dt = time.perf_counter() - t0
-        for e in engines:
+        for e in reversed(engines):           # (the pools that read engines[0]'s frame go first)
             e.close()
         return sum(x[0] for x in tot), sum(x[1] for x in tot), sum(x[2] for x in tot), dt
 

@@ -409,6 +409,13 @@ int mcrat_hip_set_photons_soa(mcrat_hip_ctx *ctx, const mcrat_hip_photon_soa *so
 int mcrat_hip_get_photons_soa(mcrat_hip_ctx *ctx, const mcrat_hip_photon_soa *soa);
 int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *ctx);
 
+/* Several contexts on one GPU that are in the same hydro frame -- rank pools on their own HIP streams with a host thread each (INTEGRATION.md,
+ * "Two pools per GPU") -- need one copy of the staged frame, its per-cell records, its lookup grid and the cross-section table, not one each:
+ * after this call `ctx` reads `owner`'s.  The owner must keep that frame (no re-staging, no mcrat_hip_destroy) while others read it; staging a
+ * frame on `ctx` itself (mcrat_hip_set_hydro, mcrat_hip_ingest_*) or sharing again ends the arrangement.  Same DIMENSIONS / GEOMETRY /
+ * TAU_CALCULATION and device on both. */
+int mcrat_hip_share_hydro(mcrat_hip_ctx *ctx, mcrat_hip_ctx *owner);
+
 /* the loop -------------------------------------------------------------------- */
 /* replaces mcrat.c:754-851 for one hydro frame: sets find_nearest_grid_switch=1,
  * runs until remaining_time is used up, updates *time_now, fills *stats.

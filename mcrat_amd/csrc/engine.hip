@@ -78,6 +78,7 @@ struct mcrat_hip_ctx {
     int find_switch = 1;
     RngKey key{0, 0, 0};
     long long frame_photon_steps = 0;
+    mcrat_hip_ctx *hydro_owner = nullptr;   // mcrat_hip_share_hydro: the staged frame (and cross-section table) are another context's
     void *d_fast = nullptr;           // FAST mode's counters (FastCounts)
     bool pending_applied = false;     // step_locate_sample has applied the pending advance that LoopState still lists
     bool rank_current = false;        // a view whose frame rank_loop_kernel has run: it leaves no pending advance (until the next begin_frame)
@@ -153,6 +154,7 @@ static void drop_graph(mcrat_hip_ctx *c)
 
 static void sync_views(mcrat_hip_ctx *c);
 static int view_refuses(mcrat_hip_ctx *c, const char *what);
+static void release_shared_hydro(mcrat_hip_ctx *c);
 static int ensure_counts(mcrat_hip_ctx *c, size_t n);
 
 extern "C" const char *mcrat_hip_version(void) { return "mcrat_hip 0.1 (gfx950, abi 1)"; }
@@ -251,6 +253,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     c->views.clear();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
+    if (c->hydro_owner) { c->hcol_buf = nullptr; c->d_hot_table = nullptr; c->hydro_owner = nullptr; }     // another context's
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
@@ -536,6 +539,7 @@ extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *t
     for (size_t k = 0; k < count; ++k)
         if (!(thermal_table[k] == thermal_table[k])) { c->last_error = "NaN in the cross-section table"; return MCRAT_HIP_EINVAL; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    release_shared_hydro(c);
     if (c->d_hot_table) { (void)hipFree(c->d_hot_table); c->d_hot_table = nullptr; }
     HIPCHK(c, hipMalloc((void **)&c->d_hot_table, count * sizeof(double)));
     HIPCHK(c, hipMemcpy(c->d_hot_table, thermal_table, count * sizeof(double), hipMemcpyHostToDevice));
@@ -594,6 +598,7 @@ static int view_refuses(mcrat_hip_ctx *c, const char *what)
 // cross-check of the device path (tests/test_gpu_parity.py).
 static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const double *dom0, const double *dom1, const double *dom2)
 {
+    if (c->hydro_owner) { c->last_error = "stage_hydro on a context that reads another one's frame"; return MCRAT_HIP_ESTATE; }   // (ensure_hcol released it)
     const bool three = c->kc.dimensions == DIM_THREE, two = c->kc.dimensions == DIM_TWO;
     const int naxes = three ? 3 : 2;
     const bool host_grid = h != nullptr;
@@ -794,9 +799,59 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
     return MCRAT_HIP_OK;
 }
 
+// a context that reads another one's staged frame (mcrat_hip_share_hydro) holds that context's pointers: forget them before staging its own
+static void release_shared_hydro(mcrat_hip_ctx *c)
+{
+    if (!c->hydro_owner) return;
+    c->hydro_owner = nullptr;
+    c->hy = HydroDev{};
+    c->hcol = HydroCols{};
+    c->hcol_buf = nullptr; c->hcol_M = 0; c->hcol_bytes = 0;
+    c->d_hot_table = nullptr;
+    c->have_hydro = false;
+    sync_views(c);
+}
+
+// Several contexts on one GPU that are in the same hydro frame (rank pools on their own streams, bench.py --pools) need
+// one copy of the frame, its per-cell records and its lookup grid, not one each: `ctx` reads `owner`'s staged frame (and cross-section table)
+// from now on.  The owner must keep that frame (not re-stage, not be destroyed) while others read it; staging a frame on `ctx` itself, or
+// sharing again, ends the arrangement.  Both contexts must be of the same DIMENSIONS / GEOMETRY / TAU_CALCULATION on the same device.
+extern "C" int mcrat_hip_share_hydro(mcrat_hip_ctx *c, mcrat_hip_ctx *owner)
+{
+    if (!c || !owner || c == owner) return MCRAT_HIP_EINVAL;
+    if (c->parent) return view_refuses(c, "share_hydro");
+    if (owner->parent) owner = owner->parent;
+    if (!owner->have_hydro || owner->hydro_owner == c) return MCRAT_HIP_ESTATE;
+    if (owner->hydro_owner) owner = owner->hydro_owner;
+    if (c->kc.dimensions != owner->kc.dimensions || c->kc.geometry != owner->kc.geometry || c->kc.table != owner->kc.table ||
+        c->cfg.device != owner->cfg.device) {
+        c->last_error = "share_hydro: the two contexts differ in DIMENSIONS / GEOMETRY / TAU_CALCULATION or device";
+        return MCRAT_HIP_EINVAL;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(owner->stream));            // the owner's staging kernels have finished
+    release_shared_hydro(c);
+    if (c->hy_buf) { HIPCHK(c, hipFree(c->hy_buf)); c->hy_buf = nullptr; c->hy_bytes = 0; }
+    if (c->grid_buf) { HIPCHK(c, hipFree(c->grid_buf)); c->grid_buf = nullptr; c->grid_bytes = 0; }
+    if (c->hcol_buf) { HIPCHK(c, hipFree(c->hcol_buf)); c->hcol_buf = nullptr; c->hcol_bytes = 0; }
+    if (c->d_hot_table) { HIPCHK(c, hipFree(c->d_hot_table)); c->d_hot_table = nullptr; }
+    c->hy = owner->hy;
+    c->hcol = owner->hcol; c->hcol_buf = owner->hcol_buf; c->hcol_M = owner->hcol_M;
+    c->d_hot_table = owner->d_hot_table; c->hot_n_ph_e = owner->hot_n_ph_e; c->hot_n_t = owner->hot_n_t;
+    for (int k = 0; k < 4; ++k) c->hot_grid[k] = owner->hot_grid[k];
+    apply_hot_table(c);                                        // (the count of lookups outside the table stays this context's own)
+    c->have_hydro = true;
+    c->hydro_owner = owner;
+    c->frame_open = false;
+    drop_graph(c);
+    sync_views(c);
+    return MCRAT_HIP_OK;
+}
+
 // struct hydro_dataframe's columns on the device: 16 arrays of M doubles
 static int ensure_hcol(mcrat_hip_ctx *c, int M)
 {
+    release_shared_hydro(c);
     const size_t stride = align_up(sizeof(double) * (size_t)M, 256), total = 19 * stride;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->hcol_buf && c->hcol_bytes < total) { HIPCHK(c, hipFree(c->hcol_buf)); c->hcol_buf = nullptr; c->hcol_bytes = 0; }

@@ -209,6 +209,7 @@ SYMBOLS = {
     "mcrat_hip_set_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_get_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
+    "mcrat_hip_share_hydro": (C.c_int, [_ctx, _ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
     "mcrat_hip_propagate_frame_mode": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.c_int, C.c_int, C.POINTER(FrameStats)]),
     "mcrat_hip_pool_propagate_frames_fast": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_uint64), _dp, _dp, C.c_int, C.POINTER(FrameStats)]),
@@ -639,6 +640,11 @@ class Engine:
         self._check(self.lib.mcrat_hip_propagate_frame(self.ctx, C.byref(tn), float(remaining_time), int(seed), C.byref(st)),
                     "propagate_frame")
         return tn.value, st
+
+    def share_hydro(self, owner):
+        """read `owner`'s staged frame (one copy for several contexts in the same hydro frame); the owner must keep it while shared"""
+        self._check(self.lib.mcrat_hip_share_hydro(self.ctx, owner.ctx), "share_hydro")
+        self._hydro_owner = owner          # keeps the owner alive as long as this engine
 
     def propagate_frame_fast(self, time_now, remaining_time, seed, windows=0):
         """MCRAT_HIP_MODE_FAST: every photon through the frame on its own clock (statistically, not sequence-, equivalent)"""

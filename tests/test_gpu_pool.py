@@ -256,6 +256,7 @@ def test_two_pools_on_two_streams_driven_by_two_host_threads(hip):
     assert tot.frame_scatt_cnt > 1000
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     halves = [make(0, 5, streams[0].cuda_stream), make(5, R, streams[1].cuda_stream)]
+    halves[1].share_hydro(halves[0])                                       # both pools are in the same hydro frame: one staged copy of it
     stats, errors = [None, None], []
 
     def drive(p):
@@ -278,5 +279,15 @@ def test_two_pools_on_two_streams_driven_by_two_host_threads(hip):
             out = halves[p].pool_rank(r - lo, 50 + r).get_photons()
             for k in FLOAT_FIELDS + INT_FIELDS:
                 assert np.array_equal(out[k], ref[r][k], equal_nan=True), (r, k)
-    for e in [one] + halves:
+    # the borrower stages a frame of its own again: the arrangement ends, results unchanged
+    halves[1].set_hydro(frame)
+    halves[1].restore_photons()
+    halves[1].begin_frame(902, 0.0, rem)
+    again = halves[1].run(0)
+    assert again.frame_scatt_cnt == stats[1].frame_scatt_cnt
+    other = hip.Engine(synth.TWO, synth.SPHERICAL, cfg["stokes"])
+    with pytest.raises(hip.McratHipError, match="GEOMETRY"):
+        other.share_hydro(halves[0])
+    other.close()
+    for e in [one, halves[1], halves[0]]:
         e.close()
