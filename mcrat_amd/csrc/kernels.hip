@@ -924,6 +924,27 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     }
     __syncthreads();
     if (st.done || n <= 0) return;
+    // Cyclo-synchrotron lists double when they run out of null slots (photons.c:112-121), so half of a list can be null slots behind the
+    // last photon.  A null slot takes no part in a pass -- no cell, never the earliest candidate, time_to_scatter = 1e12/c every time
+    // (mclib.c:620,684) -- so the passes of this launch run over the slots up to the last one that is NOT such a settled null slot (a fresh
+    // null slot still has to receive its time_to_scatter once).  Nothing observable changes; a doubled list costs a pass what its photons do.
+    int n_pass = n;
+    if (lay.cs) {
+        int last = -1;
+        for (int il = tid; il < n; il += EVENT_BLOCK) {
+            const int i = base + il;
+            const bool settled_null = gph.type[i] == 'N' && gph.idx[i] == -1 && gph.tts[i] == 1e12 / C_LIGHT;
+            if (!settled_null) last = il;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) last = max(last, __shfl_xor(last, off, 64));
+        if (lane == 0) sh.wi[tid >> 6] = last;
+        __syncthreads();
+#pragma unroll
+        for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) last = max(last, sh.wi[wv]);
+        __syncthreads();
+        n_pass = min(n, max(2, (last + 2) & ~1));            // slots go in pairs (one Philox block per pair)
+    }
 #ifdef MCRAT_DIAG
     long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ticks: load, forced step, step, event, store; [5] passes
     long long dg_t = (long long)__builtin_amdgcn_s_memtime();
@@ -977,7 +998,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         // cells' light-crossing times apart) a thread takes its own slots through the re-location in lockstep (relocate_lockstep)
         // instead of queueing them: no hand-over through LDS, and the chains of its slots overlap.  Where few do (dense frames), the
         // queue keeps the lanes of the slow path dense.  Same arithmetic either way.
-        const bool fused = FUSE && !TABLE_MODE && (force || RANK_FUSE_DEN * prev_rel > n);
+        const bool fused = FUSE && !TABLE_MODE && (force || RANK_FUSE_DEN * prev_rel > n_pass);
         if (tid == 0) { s_qn = 0; s_sln = 0; s_nrel = 0; }
         __syncthreads();
         int n_rel = 0;
@@ -992,8 +1013,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         // ---- phase 1 + phase 2, in chunks of RANK_QCAP slots so that the slow-path queue always holds a chunk's worth
         // (a list of up to 1024 photons is one chunk).  Phase 1: the step of every slot (cf. step_kernel); a thread owns
         // slot pairs so that one Philox block serves two slots, as the draw order prescribes (rng.hpp).
-        for (int c0 = 0; c0 < n; c0 += RANK_QCAP) {
-            const int c1 = min(n, c0 + RANK_QCAP);
+        for (int c0 = 0; c0 < n_pass; c0 += RANK_QCAP) {
+            const int c1 = min(n_pass, c0 + RANK_QCAP);
             if (c0 > 0) {
                 __syncthreads();                             // the previous chunk's queue has been worked off
                 if (tid == 0) s_qn = 0;
@@ -1167,7 +1188,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             }
             if (!force) RANK_TICK(6);
             if constexpr (FUSE) {                            // how many slots changed cell this pass: the next pass's form
-                if (c0 + RANK_QCAP >= n) {
+                if (c0 + RANK_QCAP >= n_pass) {
                     int w = n_rel;
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
@@ -1201,7 +1222,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
         if (force) RANK_TICK(1); else RANK_TICK(2);
         // ---- the event half and the bookkeeping
-        event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n, iter, st.remaining_time, st.last_scattered_index, st.t_est);
+        event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n_pass, iter, st.remaining_time, st.last_scattered_index, st.t_est);
         if (tid == 0) {
             st.force_relocate = 0;
             // cyclo-synchrotron lists: if photonEvent reported a pool photon (it becomes a comptonised one and is replaced, mcrat.c:786-795)
