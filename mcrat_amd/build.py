@@ -15,14 +15,14 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmcrat_hip.so")
 KERNEL_TUS = ["kernels%s_d%d.hip" % (m, d) for m in ("", "_table") for d in (0, 1, 2)]   # kernels.hip per TAU_CALCULATION x DIMENSIONS
 SOURCES = KERNEL_TUS + ["launchers.hip", "grid_build.hip", "staging.hip", "inject.hip", "ingest.hip", "hot_table.hip", "functions.hip", "engine.hip"]
-HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
+HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", "cs_device.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden"]
 OBJDIR = os.path.join(HERE, "_obj")
-_KERNEL_DEPS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"]
+_KERNEL_DEPS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", "cs_device.hpp"]
 DEPS = {"launchers.hip": ["launchers.hip", "device_types.hpp", "launch.hpp"],
         "grid_build.hip": ["grid_build.hip", "device_types.hpp", "launch.hpp"],
         "staging.hip": ["staging.hip", "device_types.hpp", "launch.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")],
-        "inject.hip": ["inject.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"],
+        "inject.hip": ["inject.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", "cs_device.hpp"],
         "ingest.hip": ["ingest.hip", "device_types.hpp", "launch.hpp"],
         "hot_table.hip": ["hot_table.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp"],
         "functions.hip": ["functions.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")],

@@ -58,6 +58,7 @@ struct mcrat_hip_ctx {
     size_t grid_count_cap = 0;
     unsigned long long *d_grid_total = nullptr;
     void *d_cs_hook = nullptr;                 // CsFrame of the cyclo-synchrotron frame driver
+    void *d_cs_args = nullptr;                 // CsHookArgs of the pool's frame driver
     HydroCols hcol{};                  // the frame as struct hydro_dataframe's columns (set_hydro / ingest), kept for get_hydro
     void *hcol_buf = nullptr;
     size_t hcol_bytes = 0;
@@ -267,6 +268,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->grid_count) (void)hipFree(c->grid_count);
     if (c->d_grid_total) (void)hipFree(c->d_grid_total);
     if (c->d_cs_hook) (void)hipFree(c->d_cs_hook);
+    if (c->d_cs_args) (void)hipFree(c->d_cs_args);
     if (c->d_fast) (void)hipFree(c->d_fast);
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
@@ -2253,7 +2255,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
             if (rc) return rc;
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
-        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, nullptr, batch,
+        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, nullptr, nullptr, batch,
                                    c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
         if (c->cfg.profile) {
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -2769,11 +2771,24 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
         c->rank_fuse = false;
         if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) c->rank_block = (atoi(e) == 128) ? 128 : 256;
     }
-    const int pairs_per_sync = 8;
+    // The hook runs inside rank_loop_kernel (its CSH build: cs_hook_body right after the pass, the list goes on in the same launch); with
+    // MCRAT_HIP_CS_HOOK_KERNEL=1 the lists park after such a pass instead and cs_replace_pool_kernel runs it between two launches (the
+    // first form of this driver, kept for the A/B).  Either way a list only stays parked for the host when it has to be rebinned.
+    const bool hook_kernel = getenv("MCRAT_HIP_CS_HOOK_KERNEL") && atoi(getenv("MCRAT_HIP_CS_HOOK_KERNEL")) != 0;
+    if (!c->d_cs_args) HIPCHK(c, hipMalloc(&c->d_cs_args, sizeof(CsHookArgs)));
+    {
+        CsHookArgs ha;
+        ha.p = p; ha.h = c->hcol;
+        HIPCHK(c, hipMemcpyAsync(c->d_cs_args, &ha, sizeof ha, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    const CsHookArgs *d_args = hook_kernel ? nullptr : static_cast<const CsHookArgs *>(c->d_cs_args);
+    const int pairs_per_sync = hook_kernel ? 8 : 2;
     for (;;) {
         for (int k = 0; k < pairs_per_sync; ++k) {
-            HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, 1 << 30, c->d_desc, d_cf, 4096, c->rank_block, c->stream));
-            HIPCHK(c, launch_cs_replace_pool(p, c->hy, c->hcol, c->d_rstates, c->ph, c->rank_stride, R, c->d_desc, d_cf, c->stream));
+            HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, 1 << 30, c->d_desc, d_cf, d_args, 4096, c->rank_block,
+                                       c->stream));
+            if (hook_kernel) HIPCHK(c, launch_cs_replace_pool(p, c->hy, c->hcol, c->d_rstates, c->ph, c->rank_stride, R, c->d_desc, d_cf, c->stream));
         }
         HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(cf.data(), d_cf, sizeof(CsFrame) * (size_t)R, hipMemcpyDeviceToHost, c->stream));

@@ -22,6 +22,7 @@
 #include "launch.hpp"
 #include "physics.hpp"
 #include "rng.hpp"
+#include "cs_device.hpp"
 
 // This file is a template for six translation units (kernels_d{0,1,2}.hip, kernels_table_d{0,1,2}.hip): one per
 // TAU_CALCULATION (DIRECT, optical_depth.c:125-127 / TABLE, :132-149) and DIMENSIONS (TWO, TWO_POINT_FIVE, THREE), each
@@ -871,6 +872,7 @@ struct RankLayout {
     int n_total;
     const RankDesc *desc;
     CsFrame *cs;          // CYCLOSYNCHROTRON_SWITCH on: per list, where a pass the hook of mcrat.c:786-808 must look at parks the list
+    const CsHookArgs *hook;   // ... or, when given (and the kernel built with CSH), what the hook needs to run right there, inside the loop
 };
 
 // Four lists per CU.  Measured by varying the number of lists on a dense jet: a workgroup alone on its CU needs 25 us per
@@ -891,7 +893,7 @@ constexpr int rank_lds_bytes_per_slot(int block) { return block >= 256 ? 7 * (in
 
 // FUSE: the kernel also holds the fused form of a pass (below).  It pays in optically thin frames and costs dense ones code they never
 // run (instruction cache, registers), so it is a build of its own and engine.hip picks per frame, as it picks the workgroup size.
-template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK, bool FUSE>
+template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK, bool FUSE, bool CSH = false>
 __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
@@ -900,7 +902,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's r and -1/tau columns when it fits (lds_slots >= n)
     __shared__ LoopState st;
     __shared__ EventSharedT<RANK_BLOCK> sh;
-    __shared__ int s_qn, s_sln, s_nrel;
+    __shared__ int s_qn, s_sln, s_nrel, s_hook, s_len;
     __shared__ int s_qb[RANK_QCAP];
     // the slow-path queue shares memory with the event walk's sorted list: the queue is empty before the list is written
     static_assert(sizeof(sh.list) >= sizeof(int) * RANK_QCAP, "queue fits into the sorted-list storage");
@@ -929,7 +931,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     // (mclib.c:620,684) -- so the passes of this launch run over the slots up to the last one that is NOT such a settled null slot (a fresh
     // null slot still has to receive its time_to_scatter once).  Nothing observable changes; a doubled list costs a pass what its photons do.
     int n_pass = n;
-    if (lay.cs) {
+    auto settle_pass_limit = [&]() {
         int last = -1;
         for (int il = tid; il < n; il += EVENT_BLOCK) {
             const int i = base + il;
@@ -944,7 +946,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) last = max(last, sh.wi[wv]);
         __syncthreads();
         n_pass = min(n, max(2, (last + 2) & ~1));            // slots go in pairs (one Philox block per pair)
-    }
+    };
+    if (lay.cs) settle_pass_limit();
 #ifdef MCRAT_DIAG
     long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ticks: load, forced step, step, event, store; [5] passes
     long long dg_t = (long long)__builtin_amdgcn_s_memtime();
@@ -987,6 +990,25 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     }
     RANK_TICK(0);
 
+    // the advance the last pass left pending (LoopState::seg), applied to every moving slot but the one the event advanced itself
+    auto apply_pending = [&]() {
+        const int nseg = st.nseg, skip = st.skip_idx;
+        if (nseg > 0) {
+            for (int il = tid; il < n; il += EVENT_BLOCK) {
+                const int i = base + il;
+                const int h = i - ph.hot_bias;
+                if ((ph.flags[i - ph.if_bias] & FLAG_MOVES) && i != skip) {
+                    const double u0 = ph.u0[i - ph.u_bias], u1 = ph.u1[i - ph.u_bias], u2 = ph.u2[i - ph.u_bias];
+                    double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
+                    for (int s = 0; s < nseg; ++s) {
+                        const double t = st.seg[s];
+                        r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
+                    }
+                    ph.r0[h] = r0; ph.r1[h] = r1; ph.r2[h] = r2;
+                }
+            }
+        }
+    };
     int prev_rel = 0;                                        // slots that changed cell in the previous pass
     for (long long pass = 0; pass < max_passes; ++pass) {
         const int nseg = st.nseg;
@@ -1226,20 +1248,45 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if (tid == 0) {
             st.force_relocate = 0;
             // cyclo-synchrotron lists: if photonEvent reported a pool photon (it becomes a comptonised one and is replaced, mcrat.c:786-795)
-            // or the rebinning is to be looked at (every 1000 scatterings, :797), the list leaves the loop here -- its photons made
-            // current below -- for cs_replace_pool_kernel, which lets it go on in the next launch
+            // or the rebinning is to be looked at (every 1000 scatterings, :797), the hook has to look at this pass: right here when the
+            // kernel carries it (CSH), else the list leaves the loop -- its photons made current below -- for cs_replace_pool_kernel,
+            // which lets it go on in the next launch
+            s_hook = 0;
             if (lay.cs && st.photon_event_called) {
                 const int sidx = st.last_scattered_index;
                 const bool pool_photon = sidx >= 0 && gph.type[sidx] == 'p';
                 const bool thousand = (st.frame_scatt_cnt % 1000 == 0) && st.frame_scatt_cnt != 0;
                 if (pool_photon || thousand) {
-                    lay.cs[rank].halt = CS_HALT_HOOK;
-                    lay.cs[rank].saved_done = st.done;
-                    st.done = LOOP_CS_HALT;
+                    if (CSH && lay.hook) {
+                        s_hook = 1;
+                    } else {
+                        lay.cs[rank].halt = CS_HALT_HOOK;
+                        lay.cs[rank].saved_done = st.done;
+                        st.done = LOOP_CS_HALT;
+                    }
                 }
             }
         }
         __syncthreads();
+        if constexpr (CSH) {
+            if (s_hook) {
+                apply_pending();                             // the hook moves the scattered photon and places a new one: positions must be current
+                __syncthreads();
+                if (tid == 0) { st.nseg = 0; st.skip_idx = -1; s_len = n; }
+                __syncthreads();
+                PhotonDev lp = gph;                          // the list as a list of its own, as cs_replace_pool_kernel sees it
+                offset_photons(lp, (size_t)base);
+                lp.n = n;
+                cs_hook_body<RANK_BLOCK>(lay.hook->p, hy, lay.hook->h, rk, &st, lp, &lay.cs[rank], 1, sh.wi, lay.stride, &s_len, idx_shift);
+                __threadfence_block();
+                __syncthreads();
+                if (s_len != n) {                            // the list doubled inside its window (photons.c:112-121)
+                    n = s_len;
+                    if (tid == 0) const_cast<RankDesc *>(lay.desc)[rank].len = n;
+                }
+                settle_pass_limit();                         // (the new photon's slot, fresh null slots)
+            }
+        }
         RANK_TICK(3);
 #ifdef MCRAT_DIAG
         dg[5] += 1;
@@ -1249,22 +1296,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
 
     // leave the photons current: apply the advance still pending (cf. flush_kernel)
     {
-        const int nseg = st.nseg, skip = st.skip_idx;
-        if (nseg > 0) {
-            for (int il = tid; il < n; il += EVENT_BLOCK) {
-                const int i = base + il;
-                const int h = i - ph.hot_bias;
-                if ((ph.flags[i - ph.if_bias] & FLAG_MOVES) && i != skip) {
-                    const double u0 = ph.u0[i - ph.u_bias], u1 = ph.u1[i - ph.u_bias], u2 = ph.u2[i - ph.u_bias];
-                    double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
-                    for (int s = 0; s < nseg; ++s) {
-                        const double t = st.seg[s];
-                        r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
-                    }
-                    ph.r0[h] = r0; ph.r1[h] = r1; ph.r2[h] = r2;
-                }
-            }
-        }
+        apply_pending();
         __syncthreads();
         if constexpr (RESIDENT) {
             for (int il = tid; il < n; il += EVENT_BLOCK) {
@@ -1906,12 +1938,24 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 }
 
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream)
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream)
 {
     const bool fuse = block >= 1000;               // block: 128 or 256 threads per list, + 1000 for the build with the fused pass (256 threads)
     if (fuse) block -= 1000;
-    RankLayout lay = {n_ranks, rank_stride, ph.n, desc, cs};
+    RankLayout lay = {n_ranks, rank_stride, ph.n, desc, cs, hook};
+    if (cs && hook && desc) {                      // cyclo-synchrotron lists with the hook inside the loop: columns in HBM/L2, no fused pass
+        return dispatch(kc, [&](auto D, auto G) {
+            constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
+            if (block == 128) {
+                if (kc.stokes) rank_loop_kernel<DV, GV, true, false, 128, false, true><<<dim3(n_ranks), dim3(128), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+                else rank_loop_kernel<DV, GV, false, false, 128, false, true><<<dim3(n_ranks), dim3(128), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+            } else {
+                if (kc.stokes) rank_loop_kernel<DV, GV, true, false, 256, false, true><<<dim3(n_ranks), dim3(256), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+                else rank_loop_kernel<DV, GV, false, false, 256, false, true><<<dim3(n_ranks), dim3(256), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+            }
+        });
+    }
     // per-pass columns in LDS (32 B per slot with 128 threads, 61 B with 256: rank_loop_kernel) for lists of up to 1024 photons
     int lds_slots = 0;
     if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && longest_list <= 1024) lds_slots = (longest_list + 15) & ~15;

@@ -29,9 +29,11 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 // virtual ranks: every workgroup (of `block` = 128 or 256 threads) runs the whole loop of one independent photon list: the slots
 // [r * rank_stride, ...) -- rank_stride of them, or desc[r].len with the list's own seed and stream (rank pool); longest_list sizes the LDS copy
+// hook: (device memory) what the cyclo-synchrotron hook needs -- then lists with `cs` run it inside the loop instead of parking for
+// cs_replace_pool_kernel after every pass it has to look at
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, struct CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, struct CsFrame *cs, const struct CsHookArgs *hook,
+                            long long max_passes, int block, hipStream_t stream);
 // shared clock with a device-initiated exchange (staging.hip): recv[r] = rank r's receive buffer (2 x world proposals, by round parity),
 // flag[r] = rank r's stamps (SC_MAX_WORLD words, one per sender, + a word counting waits that gave up + the rank's own round number)
 struct ScPeers { ScProposal *recv[SC_MAX_WORLD]; unsigned long long *flag[SC_MAX_WORLD]; };
@@ -187,6 +189,7 @@ struct CsEmitParams {
     double epsilon_b;
     double rmin, rmax, theta_min, theta_max;        // the shell of :1203-1204 and the thread's angle range
 };
+struct CsHookArgs { CsEmitParams p; HydroCols h; };      // (see launch_rank_loop)
 hipError_t launch_cs_emit_count(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, unsigned long long attempt,
                                 RngKey key, unsigned *count, unsigned long long *d_total, unsigned *d_flags, hipStream_t stream);
 hipError_t launch_cs_emit_generate(const CsEmitParams &p, const HydroDev &hy, const HydroCols &h, double ph_weight_adjusted, RngKey key, const int *start,

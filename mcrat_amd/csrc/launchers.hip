@@ -12,8 +12,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -34,8 +34,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -50,8 +50,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -66,8 +66,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -82,8 +82,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -98,8 +98,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream);
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -137,10 +137,10 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
 }
 
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
-                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, long long max_passes, int block,
-                            hipStream_t stream)
+                            int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
+                            int block, hipStream_t stream)
 {
-    MCRAT_ROUTE(launch_rank_loop, kc, ph, hy, states, key, n_ranks, rank_stride, longest_list, desc, cs, max_passes, block, stream);
+    MCRAT_ROUTE(launch_rank_loop, kc, ph, hy, states, key, n_ranks, rank_stride, longest_list, desc, cs, hook, max_passes, block, stream);
 }
 
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
