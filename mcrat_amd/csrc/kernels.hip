@@ -898,6 +898,10 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
     constexpr int EVENT_BLOCK = RANK_BLOCK;                    // (shadows the event kernel's block size inside this kernel)
+#ifndef RANK_NS_SPHERICAL
+#define RANK_NS_SPHERICAL 4
+#endif
+    constexpr int RANK_NS_QUEUE = (GEOM == GEOM_SPHERICAL) ? RANK_NS_SPHERICAL : 4;   // slots a thread takes through phase 1 together (queue form)
     constexpr int RANK_QCAP = 4 * RANK_BLOCK;                  // slots per chunk = capacity of the slow-path queue
     extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's r and -1/tau columns when it fits (lds_slots >= n)
     __shared__ LoopState st;
@@ -1204,9 +1208,9 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             };
             if constexpr (FUSE && !TABLE_MODE) {
                 if (fused) phase1(std::integral_constant<int, 2>{}, std::true_type{});
-                else phase1(std::integral_constant<int, 4>{}, std::false_type{});
+                else phase1(std::integral_constant<int, RANK_NS_QUEUE>{}, std::false_type{});
             } else {
-                phase1(std::integral_constant<int, 4>{}, std::false_type{});
+                phase1(std::integral_constant<int, RANK_NS_QUEUE>{}, std::false_type{});
             }
             if (!force) RANK_TICK(6);
             if constexpr (FUSE) {                            // how many slots changed cell this pass: the next pass's form
