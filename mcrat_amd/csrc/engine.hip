@@ -2715,11 +2715,12 @@ static int pool_emit_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs
 }
 
 // The scatter frame of mcrat.c:706-878 with CYCLOSYNCHROTRON_SWITCH on for the lists of a rank pool: what mcrat_hip_scatter_frame_cyclosynch
-// does for one list, for every open list -- the loop of all of them in the same launches.  rank_loop_kernel runs every list until a pass
-// the hook of :786-808 must look at (photonEvent reported a pool photon; a thousand scatterings are full) and parks it there;
-// cs_replace_pool_kernel, one workgroup per parked list, converts and replaces the pool photon (doubling the list inside its window
-// of the pool when it has no null slot left), evaluates the rebinning trigger and lets the list go on; the two launches alternate,
-// several pairs per read-back.  Only the rebinning itself needs the host (the view's mcrat_hip_rebin_cyclosynch).
+// does for one list, for every open list -- the loop of all of them in the same launches.  rank_loop_kernel (its CSH build) runs every list
+// and, after a pass the hook of :786-808 must look at (photonEvent reported a pool photon; a thousand scatterings are full), the hook itself:
+// it converts and replaces the pool photon (doubling the list inside its window of the pool when it has no null slot left) and evaluates
+// the rebinning trigger; the list goes on in the same launch.  Only the rebinning itself parks a list for the host (the view's
+// mcrat_hip_rebin_cyclosynch).  (First form, MCRAT_HIP_CS_HOOK_KERNEL=1: the list parks after every such pass and cs_replace_pool_kernel,
+// one workgroup per parked list, runs the hook between two launches of the loop.)
 extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, int max_photons, double fps,
                                                         const mcrat_hip_pool_cs_list *lists, mcrat_hip_frame_stats *stats,
                                                         mcrat_hip_cyclosynch_counts *counts)

@@ -201,7 +201,7 @@ hipError_t launch_cs_emit_generate(const CsEmitParams &p, const HydroDev &hy, co
 constexpr int LOOP_CS_HALT = 3;      // LoopState::done value
 constexpr int CS_HALT_GROW = 1;      // nothing was done for this pass: double the list, launch the hook again with resume = 1
 constexpr int CS_HALT_REBIN = 2;     // the pass is complete; rebinCyclosynchCompPhotons is due (mcrat.c:797-808)
-constexpr int CS_HALT_HOOK = 3;      // rank pool: rank_loop_kernel parked the list after a pass the hook has to look at (cs_replace_pool_kernel)
+constexpr int CS_HALT_HOOK = 3;      // rank pool, hook-kernel form: rank_loop_kernel parked the list after a pass the hook has to look at (cs_replace_pool_kernel)
 struct CsFrame {
     int halt;
     int saved_done;                  // LoopState::done as the pass left it
