@@ -2245,7 +2245,9 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
     if (c->is_pool) { int rc = pool_describe(c); if (rc) return rc; }
     const int longest = longest_rank_list(c);
     if (!c->rank_block_fixed) { choose_rank_block(c); c->rank_block_fixed = true; }    // one choice per frame (begin_frame resets)
-    const long long per_launch_cap = 4096;      // bounds one launch to seconds even for the densest lists
+    long long per_launch_cap = 32768;           // bounds one launch to a second or two even for the densest lists (4096: the first 60 frames of
+                                                // tools/lundman_run.py, 9.3e6 scatterings in the first one, 9.3 -> 8.9 s)
+    if (const char *e = getenv("MCRAT_HIP_RANK_LAUNCH_CAP")) per_launch_cap = atoll(e) > 0 ? atoll(e) : per_launch_cap;
     long long it = 0;
     while (max_iterations <= 0 || it < max_iterations) {
         long long batch = per_launch_cap;
