@@ -2223,7 +2223,9 @@ static void choose_rank_block(mcrat_hip_ctx *c)
     c->rank_block = (many && c->rank_passes_per_list >= 48.0) ? 128 : 256;
     // the build with the fused pass (kernels.hip, rank_loop_kernel<.., FUSE>) for frames that looked optically thin last time (or
     // have not been seen yet): there most slots change cell between two events
-    c->rank_fuse = c->rank_block == 256 && c->rank_passes_per_list < 48.0;
+    // (not in spherical geometry: two slots' acos / atan2 side by side cost the fused build 50 B of scratch per lane, and the spherical
+    // benchmark frames run 2 % faster without it -- cfg3 at 1e7 photons 8.62 -> 8.43 ms; the cylindrical Stokes frame 1.07 -> 0.94 ms with it)
+    c->rank_fuse = c->rank_block == 256 && c->rank_passes_per_list < 48.0 && c->kc.geometry != GEOM_SPHERICAL;
     if (const char *e = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = c->rank_block == 256 && atoi(e) != 0;
 }
 
