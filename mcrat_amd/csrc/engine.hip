@@ -2220,13 +2220,17 @@ static void choose_rank_block(mcrat_hip_ctx *c)
     int cus = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const bool many = c->n_ranks > 2 * cus && longest_rank_list(c) <= 1024;
-    c->rank_block = (many && c->rank_passes_per_list >= 48.0) ? 128 : 256;
+    // ... and, whatever the frame looks like, when there are many times more lists than the device holds at once: four lists per CU then
+    // overlap one list's walk with the others' passes all the time (10 246 lists, thin frames: cfg2 5.70 -> 4.96 ms, cfg3 8.44 -> 7.08 ms;
+    // 4098 lists 2.50 -> 2.32 ms; 2049 lists no difference; 1025 lists 0.83 -> 0.85 ms)
+    const bool very_many = c->n_ranks >= 12 * cus && longest_rank_list(c) <= 1024;
+    c->rank_block = ((many && c->rank_passes_per_list >= 48.0) || very_many) ? 128 : 256;
     // the build with the fused pass (kernels.hip, rank_loop_kernel<.., FUSE>) for frames that looked optically thin last time (or
     // have not been seen yet): there most slots change cell between two events
     // (not in spherical geometry: two slots' acos / atan2 side by side cost the fused build 50 B of scratch per lane, and the spherical
     // benchmark frames run 2 % faster without it -- cfg3 at 1e7 photons 8.62 -> 8.43 ms; the cylindrical Stokes frame 1.07 -> 0.94 ms with it)
-    c->rank_fuse = c->rank_block == 256 && c->rank_passes_per_list < 48.0 && c->kc.geometry != GEOM_SPHERICAL;
-    if (const char *e = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = c->rank_block == 256 && atoi(e) != 0;
+    c->rank_fuse = c->rank_passes_per_list < 48.0 && c->kc.geometry != GEOM_SPHERICAL;
+    if (const char *e = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = atoi(e) != 0;
 }
 
 // rank pool: what the kernel needs to know about every list, from its view
