@@ -2777,8 +2777,11 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
         int cus = 256, dev = 0;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         c->rank_block = R > 2 * cus ? 128 : 256;
+        // ... and with eight and more per CU one wavefront per list (eight on a CU): no wave ever waits at a barrier for the one that walks
+        // the event (cfg5: 250 -> 230 ms per frame); only with the hook inside the loop (the hook kernel is written for 128 threads and more)
+        if (R > 8 * cus && !(getenv("MCRAT_HIP_CS_HOOK_KERNEL") && atoi(getenv("MCRAT_HIP_CS_HOOK_KERNEL")) != 0)) c->rank_block = 64;
         c->rank_fuse = false;
-        if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) c->rank_block = (atoi(e) == 128) ? 128 : 256;
+        if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) c->rank_block = (atoi(e) == 64) ? 64 : (atoi(e) == 128) ? 128 : 256;
     }
     // The hook runs inside rank_loop_kernel (its CSH build: cs_hook_body right after the pass, the list goes on in the same launch); with
     // MCRAT_HIP_CS_HOOK_KERNEL=1 the lists park after such a pass instead and cs_replace_pool_kernel runs it between two launches (the

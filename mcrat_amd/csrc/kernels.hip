@@ -1941,6 +1941,9 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
     });
 }
 
+#ifndef RANK_SMALL
+#define RANK_SMALL 128                 // threads of the small workgroup (block == 128 below); -DRANK_SMALL=64 for the A/B of one-wave lists
+#endif
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream)
@@ -1951,9 +1954,12 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
     if (cs && hook && desc) {                      // cyclo-synchrotron lists with the hook inside the loop: columns in HBM/L2, no fused pass
         return dispatch(kc, [&](auto D, auto G) {
             constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
-            if (block == 128) {
-                if (kc.stokes) rank_loop_kernel<DV, GV, true, false, 128, false, true><<<dim3(n_ranks), dim3(128), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
-                else rank_loop_kernel<DV, GV, false, false, 128, false, true><<<dim3(n_ranks), dim3(128), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+            if (block == 64) {                     // one wavefront per list, eight lists per CU: every resident wave is always at work (no barrier waits)
+                if (kc.stokes) rank_loop_kernel<DV, GV, true, false, 64, false, true><<<dim3(n_ranks), dim3(64), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+                else rank_loop_kernel<DV, GV, false, false, 64, false, true><<<dim3(n_ranks), dim3(64), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+            } else if (block == 128) {
+                if (kc.stokes) rank_loop_kernel<DV, GV, true, false, RANK_SMALL, false, true><<<dim3(n_ranks), dim3(RANK_SMALL), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+                else rank_loop_kernel<DV, GV, false, false, RANK_SMALL, false, true><<<dim3(n_ranks), dim3(RANK_SMALL), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
             } else {
                 if (kc.stokes) rank_loop_kernel<DV, GV, true, false, 256, false, true><<<dim3(n_ranks), dim3(256), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
                 else rank_loop_kernel<DV, GV, false, false, 256, false, true><<<dim3(n_ranks), dim3(256), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
@@ -1978,11 +1984,11 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
             }
         };
         if (block == 128 && fuse && !TABLE_MODE) {
-            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 128, true>, rank_loop_kernel<DV, GV, true, false, 128, true>, 128);
-            else launch(rank_loop_kernel<DV, GV, false, true, 128, true>, rank_loop_kernel<DV, GV, false, false, 128, true>, 128);
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, RANK_SMALL, true>, rank_loop_kernel<DV, GV, true, false, RANK_SMALL, true>, RANK_SMALL);
+            else launch(rank_loop_kernel<DV, GV, false, true, RANK_SMALL, true>, rank_loop_kernel<DV, GV, false, false, RANK_SMALL, true>, RANK_SMALL);
         } else if (block == 128) {
-            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 128, false>, rank_loop_kernel<DV, GV, true, false, 128, false>, 128);
-            else launch(rank_loop_kernel<DV, GV, false, true, 128, false>, rank_loop_kernel<DV, GV, false, false, 128, false>, 128);
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, RANK_SMALL, false>, rank_loop_kernel<DV, GV, true, false, RANK_SMALL, false>, RANK_SMALL);
+            else launch(rank_loop_kernel<DV, GV, false, true, RANK_SMALL, false>, rank_loop_kernel<DV, GV, false, false, RANK_SMALL, false>, RANK_SMALL);
         } else if (fuse && !TABLE_MODE) {
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256, true>, rank_loop_kernel<DV, GV, true, false, 256, true>, 256);
             else launch(rank_loop_kernel<DV, GV, false, true, 256, true>, rank_loop_kernel<DV, GV, false, false, 256, true>, 256);

@@ -73,10 +73,10 @@ POOLS = {
 }
 
 
-@pytest.mark.parametrize("threads", ["256", "128"])
+@pytest.mark.parametrize("threads", ["256", "128", "64"])
 @pytest.mark.parametrize("case", sorted(POOLS))
 def test_pool_lists_with_the_switch_on_match_the_oracle_list_by_list(hip, oracle, case, threads, monkeypatch):
-    monkeypatch.setenv("MCRAT_HIP_RANK_BLOCK", threads)           # large pools run 128-thread lists (four per CU): both builds of the kernel
+    monkeypatch.setenv("MCRAT_HIP_RANK_BLOCK", threads)           # large pools run 128-thread lists (four per CU), very large ones 64-thread lists (eight): all builds of the kernel
     mesh, b_field_calc, max_photons, theta_max, ang_phi, lists = POOLS[case]
     if mesh == "2d":
         frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
