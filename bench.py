@@ -380,8 +380,9 @@ def main():
     ap.add_argument("--graph", type=int, default=1)
     ap.add_argument("--profile-steps", type=int, default=300, help="list-mode passes bracketed by HIP events for the roofline")
     ap.add_argument("--other-mode", type=int, default=1, help="also measure the other run shape briefly")
-    ap.add_argument("--pools", type=int, default=0, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to; 0: 2 for "
-                                                        "cfg2 / cfg3 (measured: 0.95 -> 0.70 ms per frame), 1 for cfg5 (measured: 381 ms with one pool, 414 with two)")
+    ap.add_argument("--pools", type=int, default=0, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to; 0: 3 for "
+                                                        "cfg2 / cfg3 (measured on cfg2: 0.95 ms per frame with one, 0.70 with two, 0.65 with three, 1.0 with four: HIP has "
+                                                        "four hardware queues), 1 for cfg5 (measured: slower with two)")
     ap.add_argument("--share-hydro", type=int, default=1, help="the pools read one staged copy of the hydro frame (mcrat_hip_share_hydro)")
     ap.add_argument("--fast-windows", type=int, default=8, help="FAST mode beside the exact headline: refreshes per frame (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -493,7 +494,7 @@ def main():
         """the lists [l0, l1) as --pools rank pools on their own HIP streams, a host thread each; k_warm untimed frames, then k_frames frames
         timed between two barriers -> (events, photon_steps, passes, seconds)"""
         import threading
-        pools = max(1, min(int(args.pools) if args.pools > 0 else 2, l1 - l0))
+        pools = max(1, min(int(args.pools) if args.pools > 0 else 3, l1 - l0))
         engines, keep = [], []
         for p in range(pools):
             lo, hi = l0 + (p * (l1 - l0)) // pools, l0 + ((p + 1) * (l1 - l0)) // pools
@@ -972,7 +973,7 @@ def main():
 
     if rank == 0:
         if args.mode == "ranks":
-            pools = max(1, min(int(args.pools) if args.pools > 0 else 2, n_lists))
+            pools = max(1, min(int(args.pools) if args.pools > 0 else 3, n_lists))
             shape = ("%d adopted ranks with lists of %d-%d photons (independent lists, own clock and RNG stream each: the reference's MPI "
                      "ranks; one workgroup per list) in %s; step = one hydro frame (1/fps = %.2f s) for all lists, every pool restarted from "
                      "its resident snapshot"
