@@ -508,6 +508,7 @@ def main():
 
         def drive(p):
             torch.cuda.set_device(local_rank)
+            engines[p].bind_thread()          # (HIP's current device is per host thread)
             run_ranks(engines[p], k_warm, SEED + 1000)
             engines[p].synchronize()
             gate.wait()                       # warm-up done everywhere

@@ -168,6 +168,10 @@ void mcrat_hip_destroy(mcrat_hip_ctx *ctx);
 const char *mcrat_hip_version(void);
 const char *mcrat_hip_strerror(int code);
 const char *mcrat_hip_last_error(const mcrat_hip_ctx *ctx);   /* text of the last HIP failure */
+/* A context belongs to the device it was created on (mcrat_hip_config.device), and HIP's "current device" is a property of the host thread:
+ * a thread other than the creating one calls this once before it uses the context (two pools per GPU with a host thread each: INTEGRATION.md).
+ * One context, one thread at a time. */
+int mcrat_hip_bind_thread(mcrat_hip_ctx *ctx);
 
 /* staging: once per hydro frame (after getHydroData, mcrat.c:721) ------------- */
 int mcrat_hip_set_hydro(mcrat_hip_ctx *ctx, const mcrat_hip_hydro *hydro);

@@ -289,6 +289,15 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     delete c;
 }
 
+// HIP's current device is a property of the host thread: a thread other than the one that created the context must select the context's
+// device before it calls into the library (allocations made on the way would otherwise land on the thread's default device)
+extern "C" int mcrat_hip_bind_thread(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return MCRAT_HIP_ENODEV;
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_synchronize(mcrat_hip_ctx *c)
 {
     if (!c) return MCRAT_HIP_EINVAL;

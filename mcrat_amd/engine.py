@@ -209,6 +209,7 @@ SYMBOLS = {
     "mcrat_hip_set_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_get_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
+    "mcrat_hip_bind_thread": (C.c_int, [_ctx]),
     "mcrat_hip_share_hydro": (C.c_int, [_ctx, _ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
     "mcrat_hip_propagate_frame_mode": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.c_int, C.c_int, C.POINTER(FrameStats)]),
@@ -640,6 +641,10 @@ class Engine:
         self._check(self.lib.mcrat_hip_propagate_frame(self.ctx, C.byref(tn), float(remaining_time), int(seed), C.byref(st)),
                     "propagate_frame")
         return tn.value, st
+
+    def bind_thread(self):
+        """select this engine's device in the calling host thread (HIP's current device is per thread)"""
+        self._check(self.lib.mcrat_hip_bind_thread(self.ctx), "bind_thread")
 
     def share_hydro(self, owner):
         """read `owner`'s staged frame (one copy for several contexts in the same hydro frame); the owner must keep it while shared"""

@@ -261,6 +261,7 @@ def test_two_pools_on_two_streams_driven_by_two_host_threads(hip):
 
     def drive(p):
         try:
+            halves[p].bind_thread()
             for k in range(3):
                 halves[p].restore_photons()
                 halves[p].begin_frame(900 + k, 0.0, rem)
