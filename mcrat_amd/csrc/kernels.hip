@@ -1348,7 +1348,7 @@ template <int DIMS, int GEOM, bool STOKES>
 __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph, HydroDev hy, RngKey key, double remaining_time, int windows,
                                                                    int max_passes, FastCounts *__restrict__ counts, FastLists lists)
 {
-    __shared__ int s_q[FAST_BLOCK];
+    __shared__ int s_q[2 * FAST_BLOCK];
     __shared__ int s_nq;
     __shared__ unsigned long long s_cnt[6];
 #ifdef MCRAT_DIAG
@@ -1358,13 +1358,13 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
     LoopState *const stamp_state = nullptr;          // (never dereferenced: MC_STAMP is empty)
 #endif
     const int tid = threadIdx.x;
-    const int i = blockIdx.x * FAST_BLOCK + tid;
+    const int i0 = 2 * (blockIdx.x * FAST_BLOCK + tid);               // a lane takes a pair of photons through the frame (their re-locations in lockstep)
     int first = 0, len = ph.n;
     if (lists.desc) {
         // the lists of a rank pool (windows of lists.stride slots, a multiple of 512: a workgroup lies within one list): each list with
         // its own seed, stream and frame time and list-local slot numbers in its keys -- the photons a list ends up with do not depend
         // on which other lists share the pool, as in the exact mode
-        const int r = (blockIdx.x * FAST_BLOCK) / lists.stride;
+        const int r = (2 * blockIdx.x * FAST_BLOCK) / lists.stride;
         const RankDesc d = lists.desc[r];
         first = r * lists.stride;
         len = d.len;
@@ -1374,13 +1374,18 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
         counts += r;
     }
     const uint32_t rng_first = key.slot_base - (uint32_t)first;       // key slot of photon i: i + rng_first
-    const bool have = i - first < len && i < ph.n;
-    const unsigned fl0 = have ? (unsigned)ph.flags[i] : 0u;
-    const bool valid = have && (fl0 & FLAG_VALID);
-    const bool moves = (fl0 & FLAG_MOVES) != 0;
     const double window = remaining_time / (double)windows;
-    double t_left = remaining_time, w_left = window;
-    bool done = !valid || !(remaining_time > 0);
+    double t_left[2], w_left[2];
+    bool done[2], moves[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = i0 + k;
+        const bool have = i - first < len && i < ph.n;
+        const unsigned fl0 = have ? (unsigned)ph.flags[i] : 0u;
+        moves[k] = (fl0 & FLAG_MOVES) != 0;
+        t_left[k] = remaining_time; w_left[k] = window;
+        done[k] = !(have && (fl0 & FLAG_VALID)) || !(remaining_time > 0);
+    }
     int relocated = 0, not_found = 0;
     unsigned steps = 0, scatt = 0, rej = 0;
     if (tid < 6) s_cnt[tid] = 0;
@@ -1388,58 +1393,87 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
     for (; pass < max_passes; ++pass) {
         if (tid == 0) s_nq = 0;
         __syncthreads();
-        if (!done) {
-            // the photon's state lives in the columns between passes (61 B in, 24 B out per pass, like step_kernel): nothing but the
-            // two clocks stays in registers across phase B, whose event code needs them all
-            const unsigned fl = ph.flags[i];
-            int cell = ph.idx[i];
-            double r0 = ph.r0[i], r1 = ph.r1[i], r2 = ph.r2[i];
-            const double ntau = ph.ntau[i];
-            const Philox4 blk = keyed_block(key.seed, (uint64_t)pass, (uint32_t)i + rng_first, RNG_FAST_FREEPATH, key.stream);
-            const uint64_t bits = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
-            int queue, bucket;
-            double a0, a1, a2;
-            double t = fast_one<DIMS, GEOM, false>(ph, hy, i, fl, cell, r0, r1, r2, ntau, bits, queue, bucket, a0, a1, a2);
-            const bool inside = (cell != -1) && phys::in_domain<DIMS>(hy, a0, a1, a2);
-            if (pass == 0 && inside && queue != 1) {                      // find_nearest_grid_switch = 1 on a new frame (mcrat.c:756)
-                queue = 1;
-                bucket = phys::grid_bucket(hy.grid, a0, a1, a2);
+        if (!done[0] || !done[1]) {
+            // the photons' state lives in the columns between passes (61 B in, 24 B out per pass, like step_kernel): nothing but the
+            // clocks stays in registers across phase B, whose event code needs them all
+            const int slot[2] = {i0, i0 + 1};                                  // (both below the columns' padded capacity)
+            unsigned fl[2];
+            int cell[2], queue[2], code[2];
+            double r0[2], r1[2], r2[2], a0[2], a1[2], a2[2], t[2];
+            uint64_t bits[2];
+            bool act[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = slot[k];
+                act[k] = !done[k];
+                if (!act[k]) {                                              // finished (or no photon): its half of the lane idles
+                    fl[k] = 0; cell[k] = -1; queue[k] = 0; code[k] = -1; bits[k] = 0; t[k] = 0;
+                    r0[k] = r1[k] = r2[k] = a0[k] = a1[k] = a2[k] = 0;
+                    continue;
+                }
+                fl[k] = ph.flags[i];
+                cell[k] = ph.idx[i];
+                r0[k] = ph.r0[i]; r1[k] = ph.r1[i]; r2[k] = ph.r2[i];
+                const double ntau = ph.ntau[i];
+                const Philox4 blk = keyed_block(key.seed, (uint64_t)pass, (uint32_t)i + rng_first, RNG_FAST_FREEPATH, key.stream);
+                bits[k] = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
+                t[k] = fast_one<DIMS, GEOM, false>(ph, hy, i, fl[k], cell[k], r0[k], r1[k], r2[k], ntau, bits[k], queue[k], code[k], a0[k], a1[k], a2[k]);
+                const bool inside = (cell[k] != -1) && phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);
+                if (pass == 0 && inside && queue[k] != 1) {                 // find_nearest_grid_switch = 1 on a new frame (mcrat.c:756)
+                    queue[k] = 1;
+                    code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]);
+                }
+                if (!inside) cell[k] = -1;                                  // (fast_one has stored it, mclib.c:592)
             }
-            if (!inside) cell = -1;                                       // (fast_one has stored it, mclib.c:592)
-            if (queue) {
-                t = slow_one<DIMS, GEOM>(ph, hy, i, queue == 1, bucket, true, bits, relocated, not_found);
-                cell = ph.idx[i];
-            }
-            steps += 1;
-            double adv;
-            if (cell == -1) {                                             // outside the frame's cells: streams to the end of the frame
-                adv = t_left;
-                t_left = 0;
-                done = true;
-            } else {
-                const double limit = fmin(t_left, w_left);
-                if (t < limit) {
-                    adv = t;
-                    t_left -= adv; w_left -= adv;
-                    s_q[atomicAdd(&s_nq, 1)] = i;                         // scatters at the end of this flight: phase B
-                } else if (limit == t_left) {
-                    adv = limit;
-                    t_left = 0;
-                    done = true;
-                } else {
-                    adv = limit;
-                    t_left -= adv;
-                    w_left = window;                                      // a window boundary: the next pass re-locates and redraws
+            if constexpr (!TABLE_MODE) {                                    // the pair's re-locations in lockstep; what the hints do not settle goes on below
+                bool todo[2] = {queue[0] == 1, queue[1] == 1};
+                if (todo[0] || todo[1]) {
+                    double tt[2];
+                    relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, true, tt, relocated);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k)
+                        if (queue[k] == 1 && !todo[k]) { t[k] = tt[k]; queue[k] = 0; cell[k] = ph.idx[slot[k]]; }
                 }
             }
-            if (moves) {
-                const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
-                ph.r0[i] = r0 + u0 * adv; ph.r1[i] = r1 + u1 * adv; ph.r2[i] = r2 + u2 * adv;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!act[k]) continue;
+                const int i = slot[k];
+                if (queue[k]) {
+                    t[k] = slow_one<DIMS, GEOM>(ph, hy, i, queue[k] == 1, code[k], true, bits[k], relocated, not_found);
+                    cell[k] = ph.idx[i];
+                }
+                steps += 1;
+                double adv;
+                if (cell[k] == -1) {                                        // outside the frame's cells: streams to the end of the frame
+                    adv = t_left[k];
+                    t_left[k] = 0;
+                    done[k] = true;
+                } else {
+                    const double limit = fmin(t_left[k], w_left[k]);
+                    if (t[k] < limit) {
+                        adv = t[k];
+                        t_left[k] -= adv; w_left[k] -= adv;
+                        s_q[atomicAdd(&s_nq, 1)] = i;                       // scatters at the end of this flight: phase B
+                    } else if (limit == t_left[k]) {
+                        adv = limit;
+                        t_left[k] = 0;
+                        done[k] = true;
+                    } else {
+                        adv = limit;
+                        t_left[k] -= adv;
+                        w_left[k] = window;                                 // a window boundary: the next pass re-locates and redraws
+                    }
+                }
+                if (moves[k]) {
+                    const double u0 = ph.u0[i], u1 = ph.u1[i], u2 = ph.u2[i];
+                    ph.r0[i] = r0[k] + u0 * adv; ph.r1[i] = r1[k] + u1 * adv; ph.r2[i] = r2[k] + u2 * adv;
+                }
             }
         }
         __syncthreads();
         const int nq = s_nq;
-        for (int j = tid; j < nq; j += FAST_BLOCK) {                      // phase B: one queued photon per lane
+        for (int j = tid; j < nq; j += FAST_BLOCK) {                      // phase B: one queued photon per lane (at most two rounds)
             const int k = s_q[j];
             const int kc = ph.idx[k];
             double p[4] = {ph.p0[k], ph.p1[k], ph.p2[k], ph.p3[k]};
@@ -1457,10 +1491,10 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
                 rej += 1;
             }
         }
-        if (!__syncthreads_or(!done)) { pass += 1; break; }
+        if (!__syncthreads_or(!done[0] || !done[1])) { pass += 1; break; }
     }
     // the workgroup's counters
-    unsigned long long v[6] = {(unsigned long long)steps, (unsigned long long)scatt, (unsigned long long)rej, (unsigned long long)relocated, (unsigned long long)not_found, (valid && !done) ? 1ull : 0ull};
+    unsigned long long v[6] = {(unsigned long long)steps, (unsigned long long)scatt, (unsigned long long)rej, (unsigned long long)relocated, (unsigned long long)not_found, (unsigned long long)((done[0] ? 0 : 1) + (done[1] ? 0 : 1))};
     for (int c = 0; c < 6; ++c) {
         unsigned long long x = v[c];
         for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
@@ -2002,8 +2036,8 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream)
 {
-    if (lists.desc && (lists.stride <= 0 || lists.stride % FAST_BLOCK != 0)) return hipErrorInvalidValue;
-    const int blocks = (ph.n + FAST_BLOCK - 1) / FAST_BLOCK;
+    if (lists.desc && (lists.stride <= 0 || lists.stride % (2 * FAST_BLOCK) != 0)) return hipErrorInvalidValue;
+    const int blocks = (ph.n + 2 * FAST_BLOCK - 1) / (2 * FAST_BLOCK);     // a lane takes two photons
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
         if (kc.stokes) fast_frame_kernel<DV, GV, true><<<dim3(blocks), dim3(FAST_BLOCK), 0, stream>>>(ph, hy, key, remaining_time, windows, max_passes, counts, lists);
