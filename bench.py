@@ -219,10 +219,11 @@ def bench_cfg5(args):
             pool = self.pool = engine.Engine(synth.THREE, synth.SPHERICAL, 1, cyclosynchrotron=1, stream=self.ts.cuda_stream)
             self.m_inj, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **dom), jet)
             pool.pool_create(hi - lo, 4 * max_photons)
-            self.n = 0
             for r in range(lo, hi):
-                k, _ = pool.pool_rank(r - lo, r).inject_photons(r_inj, 1e50, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2, "b", 0.0, th_max, fps, SEED + r)
-                self.n += k
+                pool.pool_rank(r - lo, r)
+            got = pool.pool_inject_photons(fps, [dict(r_inj=r_inj, ph_weight=1e50, min_photons=args.rank_photons * 3 // 4, max_photons=args.rank_photons * 3 // 2,
+                                                      spect="b", theta_min=0.0, theta_max=th_max, seed=SEED + r) for r in range(lo, hi)])
+            self.n = sum(g[0] for g in got)
             self.stage(0)
             pool.pool_scatter_frames_cyclosynch(self.frame_args(0, 0.0, SEED, 0), max_photons, fps, b_field_calc=2, rebin_ang_phi=45.0)
             self.m_cells = self.stage(1)

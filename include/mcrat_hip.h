@@ -517,6 +517,19 @@ typedef struct mcrat_hip_pool_cs_list {
 } mcrat_hip_pool_cs_list;
 int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *pool, const mcrat_hip_cyclosynch *cs, int max_photons, double fps,
                                              const mcrat_hip_pool_cs_list *lists, mcrat_hip_frame_stats *stats, mcrat_hip_cyclosynch_counts *counts);
+/* photonInjection (mcrat_hip_inject_photons) for every list of the pool with inject != 0, a handful of launches for all of them: each list gets
+ * exactly the photons mcrat_hip_inject_photons(view, ...) would give it (same keys, same order); num_photons / ph_weight_adjusted are filled.
+ * lists: [n_ranks]; the lists' views must exist (mcrat_hip_pool_rank). */
+typedef struct mcrat_hip_pool_inject_list {
+    int      inject;
+    char     spect;                        /* 'b' or 'w' */
+    int      min_photons, max_photons;
+    double   r_inj, ph_weight, theta_min, theta_max;
+    uint64_t seed;
+    int      num_photons;                  /* out */
+    double   ph_weight_adjusted;           /* out */
+} mcrat_hip_pool_inject_list;
+int mcrat_hip_pool_inject_photons(mcrat_hip_ctx *pool, double fps, mcrat_hip_pool_inject_list *lists);
 int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *pool, const int *open, const uint64_t *seeds, const double *time_now, const double *remaining_time);
 int mcrat_hip_pool_frame_stats(mcrat_hip_ctx *pool, mcrat_hip_frame_stats *out /* [n_ranks] */);
 int mcrat_hip_pool_layout(const mcrat_hip_ctx *pool, int *n_ranks, int *slots_per_rank);

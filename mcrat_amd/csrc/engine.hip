@@ -1453,6 +1453,91 @@ extern "C" int mcrat_hip_inject_photons(mcrat_hip_ctx *c, double r_inj, double p
     return MCRAT_HIP_OK;
 }
 
+// photonInjection (mclib.c:9-300) for the lists of a rank pool that ask for it, a handful of launches for all of them: the injection slab
+// of each group of lists that share one (same radius, angles and spectrum: the ranks of an angle bin) is found once, then one workgroup per
+// list runs the list's weight loop and writes its photons into the list's window (inject.hip).  Every list gets exactly the photons
+// mcrat_hip_inject_photons gives its view (same keys); a list with more photons than the kernel's table holds takes that path.
+extern "C" int mcrat_hip_pool_inject_photons(mcrat_hip_ctx *c, double fps, mcrat_hip_pool_inject_list *lists)
+{
+    if (!c || !lists || !(fps > 0)) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    if (!c->have_hydro) return MCRAT_HIP_ESTATE;
+    const int R = c->n_ranks, M = c->hy.M;
+    struct Slab { double rmin, rmax, tmin, tmax; int wien; };
+    std::vector<Slab> slabs;
+    std::vector<PoolInject> pi((size_t)R);
+    bool any = false;
+    int rc;
+    for (int r = 0; r < R; ++r) {
+        pi[(size_t)r] = PoolInject{};
+        mcrat_hip_pool_inject_list &q = lists[r];
+        if (!q.inject) continue;
+        if (!(q.ph_weight > 0) || q.min_photons < 0 || q.max_photons < q.min_photons || (q.spect != 'b' && q.spect != 'w')) return MCRAT_HIP_EINVAL;
+        mcrat_hip_ctx *v = c->views[r];
+        if (!v) { c->last_error = "pool_inject_photons: a list without a view (mcrat_hip_pool_rank)"; return MCRAT_HIP_ESTATE; }
+        if ((rc = alloc_view_photons(v, 0))) { c->last_error = v->last_error; return rc; }      // the window cleared, the view's columns in place
+        v->have_photons = false;
+        Slab sl{q.r_inj - 0.5 * C_LIGHT / fps, q.r_inj + 0.5 * C_LIGHT / fps, q.theta_min, q.theta_max, q.spect == 'w'};   // mclib.c:34-35
+        int g = -1;
+        for (size_t k = 0; k < slabs.size(); ++k)
+            if (slabs[k].rmin == sl.rmin && slabs[k].rmax == sl.rmax && slabs[k].tmin == sl.tmin && slabs[k].tmax == sl.tmax && slabs[k].wien == sl.wien) { g = (int)k; break; }
+        if (g < 0) { g = (int)slabs.size(); slabs.push_back(sl); }
+        PoolInject &e = pi[(size_t)r];
+        e.inject = 1; e.group = g; e.seed = q.seed; e.stream = v->key.stream; e.weight_in = q.ph_weight; e.min_photons = q.min_photons; e.max_photons = q.max_photons;
+        any = true;
+    }
+    if (!any) return MCRAT_HIP_OK;
+    if ((rc = ensure_counts(c, (size_t)M + 8))) return rc;
+    const size_t scan_ints = (size_t)M + 1 + grid_scan_scratch_ints(M);
+    int *d_start = nullptr;
+    PoolInject *d_pi = nullptr;
+    InjectSlabCell *d_slab = nullptr;
+    size_t slab_cap = 0;
+    auto done = [&](int code) { (void)hipFree(d_start); (void)hipFree(d_pi); (void)hipFree(d_slab); return code; };
+    if (hipMalloc((void **)&d_start, sizeof(int) * scan_ints) != hipSuccess || hipMalloc((void **)&d_pi, sizeof(PoolInject) * (size_t)R) != hipSuccess)
+        return done(MCRAT_HIP_ENOMEM);
+    if (hipMemcpyAsync(d_pi, pi.data(), sizeof(PoolInject) * (size_t)R, hipMemcpyHostToDevice, c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+    for (size_t g = 0; g < slabs.size(); ++g) {
+        InjectParams p;
+        p.dimensions = c->kc.dimensions; p.geometry = c->kc.geometry;
+        p.rmin = slabs[g].rmin; p.rmax = slabs[g].rmax; p.theta_min = slabs[g].tmin; p.theta_max = slabs[g].tmax;
+        p.num_dens_coeff = slabs[g].wien ? (double)8.44f : (double)20.29f;   // a float in the reference, mclib.c:17,23-32
+        p.wien = slabs[g].wien;
+        int n_slab = 0;
+        if (launch_inject_slab_flag(p, c->hy, c->grid_count, c->d_grid_total, &n_slab, c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+        if ((size_t)n_slab > slab_cap) {
+            (void)hipFree(d_slab); d_slab = nullptr;
+            if (hipMalloc((void **)&d_slab, sizeof(InjectSlabCell) * (size_t)n_slab) != hipSuccess) return done(MCRAT_HIP_ENOMEM);
+            slab_cap = (size_t)n_slab;
+        }
+        if (n_slab > 0 && launch_inject_slab_write(p, c->hy, c->grid_count, n_slab, d_start, d_start + M + 1, d_slab, c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+        if (launch_inject_pool(p, c->hy, c->ph, c->rank_stride, R, d_slab, n_slab, d_pi, (int)g, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess) { c->last_error = "photon injection of the pool's lists failed"; return done(MCRAT_HIP_EHIP); }
+    }
+    if (hipMemcpyAsync(pi.data(), d_pi, sizeof(PoolInject) * (size_t)R, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
+    (void)done(0);
+    for (int r = 0; r < R; ++r) {
+        const PoolInject &e = pi[(size_t)r];
+        if (!e.inject) continue;
+        mcrat_hip_ctx *v = c->views[r];
+        mcrat_hip_pool_inject_list &q = lists[r];
+        if (e.error == 3) {                                                 // more photons than the kernel's table: the one-list path (it says what is wrong, if anything)
+            if ((rc = mcrat_hip_inject_photons(v, q.r_inj, q.ph_weight, q.min_photons, q.max_photons, q.spect, q.theta_min, q.theta_max, fps, q.seed,
+                                               &q.num_photons, &q.ph_weight_adjusted))) { c->last_error = v->last_error; return rc; }
+            continue;
+        }
+        if (e.error == 1) { c->last_error = "photon injection: no weight puts the photon count between min_photons and max_photons"; return MCRAT_HIP_EINVAL; }
+        if (e.error == 2) { c->last_error = "photon injection: no photons (no cell of the frame touches the injection slab?)"; return MCRAT_HIP_EINVAL; }
+        v->ph.n = e.n;
+        v->have_photons = true;
+        v->frame_open = false;
+        q.num_photons = e.n;
+        q.ph_weight_adjusted = e.weight_out;
+    }
+    return MCRAT_HIP_OK;
+}
+
 // reallocatePhotonListMemory (photons.c:37-80) on the device: a larger set of columns, the old slots copied, the new ones null
 static int grow_photons(mcrat_hip_ctx *c, int new_n)
 {
@@ -2286,7 +2371,10 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
         HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * c->n_ranks, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all_done = true;
-        for (int r = 0; r < c->n_ranks && all_done; ++r) all_done = c->h_rstates[r].done != 0;
+        for (int r = 0; r < c->n_ranks && all_done; ++r) {
+            if (c->is_pool && c->h_desc[r].len <= 0) continue;     // a window without a list (or without a frame) has nothing to finish
+            all_done = c->h_rstates[r].done != 0;
+        }
         if (all_done) {
             if (c->is_pool)
                 for (mcrat_hip_ctx *v : c->views)

@@ -129,18 +129,24 @@ __global__ __launch_bounds__(256) void inject_count_kernel(InjectParams p, Hydro
     if (threadIdx.x == 0) atomicAdd(total, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
 }
 
-__global__ __launch_bounds__(256) void inject_generate_kernel(InjectParams p, HydroDev hy, double weight, RngKey key, const int *__restrict__ start,
-                                                              PhotonDev ph)
+// exclusive scan of one value per thread over the workgroup (256 threads); returns the thread's offset, *total the sum
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int *s_w, int *total)
 {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= ph.n) return;
-    // the cell of photon k: start[i] <= k < start[i+1]
-    int lo = 0, hi = hy.M;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (start[mid] <= k) lo = mid; else hi = mid;
-    }
-    const int i = lo;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
+    __syncthreads();
+    if (lane == 63) s_w[w] = x;
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < w; ++k) before += s_w[k];
+    *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return before + x - v;
+}
+
+// photon k of an injection, born in cell i (mclib.c:150-296), into slot k of `ph`
+__device__ void inject_one(const InjectParams &p, const HydroDev &hy, double weight, const RngKey &key, int k, int i, const PhotonDev &ph)
+{
     const CellRec c = load_cell(hy, p.dimensions, i);
     const double T = hy.temp[i];
     EventStream rng = keyed_stream(key, 0ull, (uint32_t)k, RNG_INJECT_PHOTON);
@@ -210,6 +216,116 @@ __global__ __launch_bounds__(256) void inject_generate_kernel(InjectParams p, Hy
     if (weight != 0) fl |= FLAG_MOVES;                                       // type 'i' is not a CS-pool photon
     ph.flags[k] = (unsigned char)fl;
     ph.type[k] = 'i';                                                        // INJECTED_PHOTON, mcrat.h
+}
+
+__global__ __launch_bounds__(256) void inject_generate_kernel(InjectParams p, HydroDev hy, double weight, RngKey key, const int *__restrict__ start,
+                                                              PhotonDev ph)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ph.n) return;
+    // the cell of photon k: start[i] <= k < start[i+1]
+    int lo = 0, hi = hy.M;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (start[mid] <= k) lo = mid; else hi = mid;
+    }
+    inject_one(p, hy, weight, key, k, lo, ph);
+}
+
+// ---- photonInjection for many lists of a rank pool at once.  Whether a cell touches the injection slab, its volume and gamma T^3 do not depend
+// on the list: inject_slab_* find the slab's cells once per group of lists with the same slab (an angle bin's ranks), in cell order, with the
+// two factors of mclib.c:110; inject_pool_kernel, one workgroup per list, runs the list's weight loop on its own Poisson streams (the keys of
+// the one-list path: {seed, attempt, cell, INJECT_COUNT}), and writes its photons ({seed, 0, k, INJECT_PHOTON}) into the list's window.
+__global__ __launch_bounds__(256) void inject_slab_flag_kernel(InjectParams p, HydroDev hy, unsigned *__restrict__ flag, unsigned long long *__restrict__ total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned in = 0;
+    if (i < hy.M) {
+        in = in_injection_slab(p, load_cell(hy, p.dimensions, i)) ? 1u : 0u;
+        flag[i] = in;
+    }
+    const unsigned long long m = __ballot(in != 0);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(total, (unsigned long long)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void inject_slab_write_kernel(InjectParams p, HydroDev hy, const unsigned *__restrict__ flag, const int *__restrict__ start,
+                                                                InjectSlabCell *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= hy.M || !flag[i]) return;
+    const CellRec c = load_cell(hy, p.dimensions, i);
+    const double T = hy.temp[i];
+    InjectSlabCell s;
+    s.cell = i; s.pad = 0;
+    s.v43 = (4.0 / 3.0) * element_volume(p.dimensions, p.geometry, c);       // mclib.c:110: (4/3) V * ((gamma a_n T^3) / weight), in that order
+    s.g = hy.gamma[i] * p.num_dens_coeff * T * T * T;
+    out[start[i]] = s;
+}
+
+__global__ __launch_bounds__(256) void inject_pool_kernel(InjectParams p, HydroDev hy, PhotonDev pool, int stride, const InjectSlabCell *__restrict__ slab,
+                                                          int n_slab, PoolInject *lists, int group)
+{
+    __shared__ unsigned long long s_sum[4];
+    __shared__ int s_w[4];
+    __shared__ int s_cell[POOL_INJECT_CAP];
+    __shared__ double s_weight;
+    __shared__ int s_ok, s_attempt;
+    const int r = blockIdx.x, tid = threadIdx.x;
+    PoolInject &L = lists[r];
+    if (!L.inject || L.group != group) return;
+    PhotonDev ph = pool;
+    offset_photons(ph, (size_t)r * (size_t)stride);
+    const RngKey key = {L.seed, L.stream, 0u};
+    if (tid == 0) { s_weight = L.weight_in; s_ok = 0; s_attempt = 0; }
+    __syncthreads();
+    unsigned long long total = 0;
+    for (int attempt = 0; attempt <= 200; ++attempt) {                       // mclib.c:87-136
+        const double weight = s_weight;
+        unsigned long long mine = 0;
+        for (int s = tid; s < n_slab; s += 256) {
+            const double ph_dens_calc = slab[s].v43 * (slab[s].g / weight);
+            EventStream rng = keyed_stream(key, (unsigned long long)attempt, (uint32_t)slab[s].cell, RNG_INJECT_COUNT);
+            const long long k = poisson(rng, ph_dens_calc);
+            mine += (unsigned long long)(k < 0 ? 0 : (k > 0x7fffffffll ? 0x7fffffffll : k));
+        }
+        for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) s_sum[tid >> 6] = mine;
+        __syncthreads();
+        total = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        if (tid == 0) {
+            if (total > (unsigned long long)L.max_photons) s_weight = weight * 10;
+            else if (total < (unsigned long long)L.min_photons) s_weight = weight * 0.5;
+            else { s_ok = 1; s_attempt = attempt; }
+        }
+        __syncthreads();
+        if (s_ok) break;
+    }
+    if (!s_ok) { if (tid == 0) { L.error = 1; L.n = 0; } return; }
+    const double weight = s_weight;
+    const int attempt = s_attempt, n = (int)total;
+    if (tid == 0) { L.n = n; L.weight_out = weight; L.error = n == 0 ? 2 : (n > stride || n > POOL_INJECT_CAP ? 3 : 0); }
+    if (n == 0 || n > stride || n > POOL_INJECT_CAP) return;
+    // photon k -> its cell: the accepted attempt's counts again, in cell order
+    int base = 0;
+    for (int c0 = 0; c0 < n_slab; c0 += 256) {
+        const int s = c0 + tid;
+        int cnt = 0, cell = -1;
+        if (s < n_slab) {
+            const double ph_dens_calc = slab[s].v43 * (slab[s].g / weight);
+            EventStream rng = keyed_stream(key, (unsigned long long)attempt, (uint32_t)slab[s].cell, RNG_INJECT_COUNT);
+            const long long k = poisson(rng, ph_dens_calc);
+            cnt = (int)(k < 0 ? 0 : (k > 0x7fffffffll ? 0x7fffffffll : k));
+            cell = slab[s].cell;
+        }
+        int chunk_total;
+        const int off = block_exclusive_scan_256(cnt, s_w, &chunk_total);
+        for (int j = 0; j < cnt; ++j) s_cell[base + off + j] = cell;
+        base += chunk_total;
+        __syncthreads();
+    }
+    ph.n = n;
+    for (int k = tid; k < n; k += 256) inject_one(p, hy, weight, key, k, s_cell[k], ph);
 }
 
 // ---------------------------------------------------------------------------------------------- cyclo-synchrotron pool emission
@@ -363,21 +479,6 @@ __global__ __launch_bounds__(256) void cs_shell_write_kernel(CsEmitParams p, Hyd
     s.volume = element_volume(p.dimensions, p.geometry, c);
     if (!converged) atomicAdd(not_converged, 1u);
     out[start[i]] = s;
-}
-
-// exclusive scan of one value per thread over the workgroup (256 threads); returns the thread's offset, *total the sum
-__device__ __forceinline__ int block_exclusive_scan_256(int v, int *s_w, int *total)
-{
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int x = v;
-    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off); if (lane >= off) x += y; }
-    __syncthreads();
-    if (lane == 63) s_w[w] = x;
-    __syncthreads();
-    int before = 0;
-    for (int k = 0; k < w; ++k) before += s_w[k];
-    *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    return before + x - v;
 }
 
 constexpr int CS_POOL_EMIT_CAP = 4096;       // pool photons one list may receive in one emission (LDS tables of cells and slots)
@@ -809,6 +910,34 @@ hipError_t launch_cs_replace(const CsEmitParams &p, const HydroDev &hy, const Hy
                              CsFrame *frame, int resume, hipStream_t stream)
 {
     cs_replace_kernel<<<dim3(1), dim3(256), 0, stream>>>(p, hy, h, key, st, ph, frame, resume);
+    return hipGetLastError();
+}
+
+hipError_t launch_inject_slab_flag(const InjectParams &p, const HydroDev &hy, unsigned *flag, unsigned long long *d_total, int *n_slab, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(d_total, 0, sizeof(unsigned long long), stream);
+    if (e != hipSuccess) return e;
+    inject_slab_flag_kernel<<<dim3((hy.M + 255) / 256), dim3(256), 0, stream>>>(p, hy, flag, d_total);
+    unsigned long long total = 0;
+    if ((e = hipMemcpyAsync(&total, d_total, sizeof total, hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+    *n_slab = (int)total;
+    return hipGetLastError();
+}
+
+hipError_t launch_inject_slab_write(const InjectParams &p, const HydroDev &hy, const unsigned *flag, int n_slab, int *start, int *scratch, InjectSlabCell *out,
+                                    hipStream_t stream)
+{
+    hipError_t e = launch_exclusive_scan(flag, hy.M, start, scratch, (long long)n_slab, stream);
+    if (e != hipSuccess) return e;
+    inject_slab_write_kernel<<<dim3((hy.M + 255) / 256), dim3(256), 0, stream>>>(p, hy, flag, start, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_inject_pool(const InjectParams &p, const HydroDev &hy, const PhotonDev &pool, int stride, int n_ranks, const InjectSlabCell *slab, int n_slab,
+                              PoolInject *lists, int group, hipStream_t stream)
+{
+    inject_pool_kernel<<<dim3(n_ranks), dim3(256), 0, stream>>>(p, hy, pool, stride, slab, n_slab, lists, group);
     return hipGetLastError();
 }
 

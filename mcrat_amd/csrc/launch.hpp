@@ -98,6 +98,24 @@ hipError_t launch_inject_count(const InjectParams &p, const HydroDev &hy, double
 // the photons themselves (mclib.c:150-296), ordered by cell then draw, into the SoA columns
 hipError_t launch_inject_generate(const InjectParams &p, const HydroDev &hy, double ph_weight_adjusted, RngKey key, const int *start,
                                   const PhotonDev &ph, hipStream_t stream);
+// photonInjection for the lists of a rank pool (inject.hip): the slab's cells with the two list-independent factors of mclib.c:110, once per group
+// of lists that share the slab, then one workgroup per list
+struct alignas(8) InjectSlabCell { int cell; int pad; double v43, g; };
+constexpr int POOL_INJECT_CAP = 8192;        // photons one list may receive (LDS table of their cells)
+struct alignas(8) PoolInject {
+    int inject, group;               // in: takes part; which slab
+    unsigned long long seed;         // in
+    unsigned stream; int pad;        // in: the list's RNG stream
+    double weight_in;                // in: ph_weight
+    int min_photons, max_photons;    // in
+    double weight_out;               // out
+    int n, error;                    // out: photons; 0 ok, 1 no weight fits, 2 no photons, 3 more than the list's window (or the kernel's table) holds
+};
+hipError_t launch_inject_slab_flag(const InjectParams &p, const HydroDev &hy, unsigned *flag, unsigned long long *d_total, int *n_slab, hipStream_t stream);   // waits
+hipError_t launch_inject_slab_write(const InjectParams &p, const HydroDev &hy, const unsigned *flag, int n_slab, int *start, int *scratch, InjectSlabCell *out,
+                                    hipStream_t stream);
+hipError_t launch_inject_pool(const InjectParams &p, const HydroDev &hy, const PhotonDev &pool, int stride, int n_ranks, const InjectSlabCell *slab, int n_slab,
+                              PoolInject *lists, int group, hipStream_t stream);
 // getHydroData on the device (ingest.hip; mcrat_io.c:1898-1990)
 struct HydroCols {          // struct hydro_dataframe's columns (mcrat.h:194-244), device arrays of M doubles
     double *r0, *r1, *r2, *s0, *s1, *s2;

@@ -154,6 +154,13 @@ class OutputColumns(C.Structure):
     _fields_ = [("count", C.c_int)] + [(f, _dp) for f in OUTPUT_COLUMNS] + [("type", C.c_char_p)]
 
 
+class PoolInjectList(C.Structure):
+    """mcrat_hip_pool_inject_list"""
+    _fields_ = [("inject", C.c_int), ("spect", C.c_char), ("min_photons", C.c_int), ("max_photons", C.c_int),
+                ("r_inj", C.c_double), ("ph_weight", C.c_double), ("theta_min", C.c_double), ("theta_max", C.c_double),
+                ("seed", C.c_uint64), ("num_photons", C.c_int), ("ph_weight_adjusted", C.c_double)]
+
+
 class RankSummary(C.Structure):
     """mcrat_hip_rank_summary: the per-frame reductions and printPhotons' count of one list of a rank pool"""
     _fields_ = [("min_r", C.c_double), ("max_r", C.c_double), ("min_theta", C.c_double), ("max_theta", C.c_double),
@@ -209,6 +216,7 @@ SYMBOLS = {
     "mcrat_hip_set_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_get_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
+    "mcrat_hip_pool_inject_photons": (C.c_int, [_ctx, C.c_double, C.POINTER(PoolInjectList)]),
     "mcrat_hip_bind_thread": (C.c_int, [_ctx]),
     "mcrat_hip_share_hydro": (C.c_int, [_ctx, _ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
@@ -357,6 +365,30 @@ class Engine:
         self._check(self.lib.mcrat_hip_pool_scatter_frames_cyclosynch(self.ctx, C.byref(cs), int(max_photons), float(fps), arr, st, cnt),
                     "pool_scatter_frames_cyclosynch")
         return list(st), list(cnt)
+
+    def pool_inject_photons(self, fps, lists):
+        """lists: one dict per list (None: no injection) with r_inj, ph_weight, min_photons, max_photons, spect, theta_min, theta_max, seed
+        -> [(num_photons, ph_weight_adjusted) or None]"""
+        R = self.n_pool_ranks
+        arr = (PoolInjectList * R)()
+        for r, q in enumerate(lists):
+            if q is None:
+                continue
+            a = arr[r]
+            a.inject, a.spect = 1, q["spect"].encode() if isinstance(q["spect"], str) else q["spect"]
+            a.min_photons, a.max_photons = int(q["min_photons"]), int(q["max_photons"])
+            a.r_inj, a.ph_weight, a.theta_min, a.theta_max, a.seed = float(q["r_inj"]), float(q["ph_weight"]), float(q["theta_min"]), float(q["theta_max"]), int(q["seed"])
+        self._check(self.lib.mcrat_hip_pool_inject_photons(self.ctx, float(fps), arr), "pool_inject_photons")
+        out = []
+        for r, q in enumerate(lists):
+            if q is None:
+                out.append(None)
+                continue
+            v = self.views.get(r) if hasattr(self, "views") else None
+            if v is not None:
+                v.n = int(arr[r].num_photons)
+            out.append((int(arr[r].num_photons), float(arr[r].ph_weight_adjusted)))
+        return out
 
     def pool_summaries(self):
         out = (RankSummary * self.n_pool_ranks)()

@@ -522,6 +522,7 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     mcrat_hip_rank_summary *summ = (mcrat_hip_rank_summary *)calloc((size_t)n_ranks, sizeof *summ);
     mcrat_hip_frame_stats *stats = (mcrat_hip_frame_stats *)calloc((size_t)n_ranks, sizeof *stats);
     int *open = (int *)calloc((size_t)n_ranks, sizeof(int));
+    mcrat_hip_pool_inject_list *inj = (mcrat_hip_pool_inject_list *)calloc((size_t)n_ranks, sizeof *inj);
     uint64_t *seeds = (uint64_t *)calloc((size_t)n_ranks, sizeof(uint64_t));
     double *t_now = (double *)calloc((size_t)n_ranks, sizeof(double)), *t_rem = (double *)calloc((size_t)n_ranks, sizeof(double));
     mcrat_hip_pool_cs_list *cs_lists = (mcrat_hip_pool_cs_list *)calloc((size_t)n_ranks, sizeof *cs_lists);
@@ -531,8 +532,8 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     char *out_type = NULL;
     size_t out_cap = 0;
     int stride = 0;
-    if (!summ || !stats || !open || !seeds || !t_now || !t_rem || !cs_lists || !cs_counts || mcrat_hip_pool_layout(pool, NULL, &stride) != 0) {
-        free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
+    if (!summ || !stats || !open || !inj || !seeds || !t_now || !t_rem || !cs_lists || !cs_counts || mcrat_hip_pool_layout(pool, NULL, &stride) != 0) {
+        free(summ); free(stats); free(open); free(inj); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
         return MCRAT_HIP_ENOMEM;
     }
     cfg->hydro_frames_read = cfg->launches = 0;
@@ -574,32 +575,47 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
             else ranks[r].state = 3;
         if (first == INT_MAX) break;
         for (int F = first; F <= cfg->last_frm && rc == 0 && !stop; F++) {                         /* the hydro frames, read once for all ranks */
-            /* ranks whose injection frame this is (mcrat.c:626-647) */
-            double staged_r_inj = -1;
-            for (int r = 0; r < n_ranks && rc == 0; r++) {
-                mcrat_host_rank *k = &ranks[r];
-                if (k->state != 0 || k->frame != F) continue;
-                k->time_now = F / cfg->fps;                                                       /* :628 */
-                if (k->fPtr) fprintf(k->fPtr, ">> Im Proc: %d with angles %0.1lf - %0.1lf Working on Frame: %d\n", k->angle_id, RANK_DEG(k), F);
-                if (staged_r_inj != k->inj_radius) {                                              /* getHydroData(..., inj_radius, 1, ...), :638 */
-                    slab.r_inj = k->inj_radius; slab.ph_inj_switch = 1;
-                    slab.min_r = slab.max_r = slab.min_theta = slab.max_theta = 0;
+            /* ranks whose injection frame this is (mcrat.c:626-647): the injection frame staged once per injection radius (getHydroData(...,
+             * inj_radius, 1, ...), :638), then photonInjection (:645) for all ranks of that radius at once (mcrat_hip_pool_inject_photons) */
+            for (int r = 0; r < n_ranks; r++) inj[r].inject = 0;
+            for (int r0 = 0; r0 < n_ranks && rc == 0; r0++) {
+                if (ranks[r0].state != 0 || ranks[r0].frame != F) continue;                       /* the first rank still to inject at this frame ... */
+                const double radius = ranks[r0].inj_radius;
+                slab.r_inj = radius; slab.ph_inj_switch = 1;
+                slab.min_r = slab.max_r = slab.min_theta = slab.max_theta = 0;
+                {
                     const double t0 = wall_ms();
                     rc = cfg->get_hydro(cfg->user, pool, F, &slab);
                     cfg->ms_hydro += wall_ms() - t0;
                     cfg->hydro_frames_read += 1;
                     if (rc) break;
-                    staged_r_inj = k->inj_radius;
                 }
-                if (k->fPtr) fprintf(k->fPtr, ">>  Proc: %d with angles %0.1lf-%0.1lf: Injecting photons\n", k->angle_id, RANK_DEG(k));
-                rc = mcrat_hip_inject_photons(k->view, k->inj_radius, k->ph_weight_suggest, cfg->min_photons, cfg->max_photons, cfg->spect,
-                                              k->theta_jmin_thread, k->theta_jmax_thread, cfg->fps, mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++),
-                                              &k->num_photons, &k->ph_weight);                   /* photonInjection, :645 */
-                if (rc) break;
-                k->state = 1;
-                k->scatt_frame = F;                                                               /* scatt_framestart = frame, :660 */
-                k->first_scatt_frame = F;
-                k->scatt_cyclosynch_num_ph = 0;                                                   /* :921 */
+                for (int r = r0; r < n_ranks; r++) {                                              /* ... and everyone else of its radius */
+                    mcrat_host_rank *k = &ranks[r];
+                    inj[r].inject = 0;
+                    if (k->state != 0 || k->frame != F || k->inj_radius != radius) continue;
+                    k->time_now = F / cfg->fps;                                                   /* :628 */
+                    if (k->fPtr) {
+                        fprintf(k->fPtr, ">> Im Proc: %d with angles %0.1lf - %0.1lf Working on Frame: %d\n", k->angle_id, RANK_DEG(k), F);
+                        fprintf(k->fPtr, ">>  Proc: %d with angles %0.1lf-%0.1lf: Injecting photons\n", k->angle_id, RANK_DEG(k));
+                    }
+                    inj[r].inject = 1; inj[r].spect = cfg->spect; inj[r].min_photons = cfg->min_photons; inj[r].max_photons = cfg->max_photons;
+                    inj[r].r_inj = radius; inj[r].ph_weight = k->ph_weight_suggest;
+                    inj[r].theta_min = k->theta_jmin_thread; inj[r].theta_max = k->theta_jmax_thread;
+                    inj[r].seed = mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++);
+                }
+                if ((rc = mcrat_hip_pool_inject_photons(pool, cfg->fps, inj))) break;
+                for (int r = r0; r < n_ranks; r++) {
+                    mcrat_host_rank *k = &ranks[r];
+                    if (!inj[r].inject) continue;
+                    inj[r].inject = 0;
+                    k->num_photons = inj[r].num_photons;
+                    k->ph_weight = inj[r].ph_weight_adjusted;
+                    k->state = 1;
+                    k->scatt_frame = F;                                                           /* scatt_framestart = frame, :660 */
+                    k->first_scatt_frame = F;
+                    k->scatt_cyclosynch_num_ph = 0;                                               /* :921 */
+                }
             }
             if (rc) break;
             int n_active = 0;
@@ -779,7 +795,7 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                                              k->angle_procs, 0);
             if (k->fPtr) { fprintf(k->fPtr, "Process %d has completed the MC calculation.\n", k->angle_id); fflush(k->fPtr); }
         }
-    free(summ); free(stats); free(open); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
+    free(summ); free(stats); free(open); free(inj); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
     free(rec_buf); free(out_buf); free(out_type);
     return rc;
 }

@@ -292,3 +292,52 @@ def test_two_pools_on_two_streams_driven_by_two_host_threads(hip):
     other.close()
     for e in [one, halves[1], halves[0]]:
         e.close()
+
+
+def test_pool_injection_gives_every_list_the_photons_of_its_own_injection(hip):
+    """mcrat_hip_pool_inject_photons (one slab search per group of lists, one workgroup per list) against mcrat_hip_inject_photons on the views"""
+    raw = synth.pluto_raw_grid(synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.6), (384, 96), seed=31, log_axis0=True)
+    jet = hip.Engine.outflow(3, lumi=2e53, theta_j=0.1)
+    dom = dict(r0_domain=(1e11, 4e12), r1_domain=(0.0, 0.6), r2_domain=(0.0, 0.0))
+    fps = 5.0
+    specs = [dict(r_inj=1e12, ph_weight=1e50, min_photons=300, max_photons=900, spect="b", theta_min=0.0, theta_max=0.05, seed=11),
+             dict(r_inj=1e12, ph_weight=1e50, min_photons=300, max_photons=900, spect="b", theta_min=0.0, theta_max=0.05, seed=12),
+             None,
+             dict(r_inj=1e12, ph_weight=3e49, min_photons=200, max_photons=600, spect="b", theta_min=0.05, theta_max=0.1, seed=13),
+             dict(r_inj=1e12, ph_weight=1e50, min_photons=300, max_photons=900, spect="w", theta_min=0.0, theta_max=0.05, seed=14),
+             dict(r_inj=1e12, ph_weight=1e44, min_photons=300, max_photons=900, spect="b", theta_min=0.0, theta_max=0.05, seed=15)]   # the weight loop has to climb
+    R = len(specs)
+    slab = dict(r_inj=1e12, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **dom)
+    pools = []
+    for batched in (True, False):
+        pool = hip.Engine(synth.TWO, synth.SPHERICAL, 1)
+        pool.ingest(raw, slab, jet)
+        pool.pool_create(R, 1024)
+        views = [pool.pool_rank(r, 70 + r) for r in range(R)]
+        if batched:
+            got = pool.pool_inject_photons(fps, specs)
+        else:
+            got = [None if q is None else views[r].inject_photons(q["r_inj"], q["ph_weight"], q["min_photons"], q["max_photons"], q["spect"], q["theta_min"],
+                                                                  q["theta_max"], fps, q["seed"]) for r, q in enumerate(specs)]
+        pools.append((pool, views, got))
+    (pa, va, ga), (pb, vb, gb) = pools
+    assert ga == gb and ga[2] is None and ga[5][1] > 1e44
+    assert len({g[0] for g in ga if g}) > 2                                 # Poisson-sized lists
+    for r, q in enumerate(specs):
+        if q is None:
+            assert pa.pool_summaries()[r].list_capacity == 0
+            continue
+        a, b = va[r].get_photons(), vb[r].get_photons()
+        assert len(a["p0"]) == ga[r][0] and q["min_photons"] <= ga[r][0] <= q["max_photons"]
+        for k in a:
+            assert np.array_equal(a[k], b[k], equal_nan=(np.asarray(a[k]).dtype.kind == "f")), (r, k)
+    # the batched lists run like any others (the window without a list sits the frame out)
+    mm = pa.ph_minmax()
+    pa.ingest(raw, dict(slab, ph_inj_switch=0, min_r=mm[0], max_r=mm[1], min_theta=0.0, max_theta=0.12), jet)
+    pa.begin_frame(5, 1.0, 1.0 / fps)
+    pa.run(0)
+    for r, q in enumerate(specs):
+        if q is not None:
+            assert va[r].frame_statistics().remaining_time == 0.0
+    pa.close()
+    pb.close()
