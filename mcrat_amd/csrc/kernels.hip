@@ -2002,7 +2002,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
     }
     // per-pass columns in LDS (32 B per slot with 128 threads, 61 B with 256: rank_loop_kernel) for lists of up to 1024 photons
     int lds_slots = 0;
-    if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && longest_list <= 1024) lds_slots = (longest_list + 15) & ~15;
+    // (two 256-thread lists per CU: 13 KB of static LDS and 61 B per slot each within 160 KB -> 1088 slots; four 128-thread ones at 32 B: 1024)
+    const int lds_limit = (block == 128) ? 1024 : 1088;
+    if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && longest_list <= lds_limit) lds_slots = (longest_list + 15) & ~15;
     size_t dyn = (size_t)lds_slots * rank_lds_bytes_per_slot(block == 128 ? 128 : 256);
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
