@@ -55,14 +55,9 @@ struct PhotonDev {
     char *type;
     int n;                       // list_capacity
     int n_pad;
-    // The "hot" columns r0-2 and ntau are indexed as col[i - hot_bias].  0 in HBM; in
-    // rank_loop_kernel, when a list's hot columns live in LDS, the list's first slot (so that the LDS copies are
-    // indexed from 0 without ever forming an out-of-bounds pointer).
-    int hot_bias;
-    // the same for the other per-pass columns: rank_loop_kernel keeps r and -1/tau in LDS (hot_bias = the list's first slot)
-    // and leaves idx, flags (if_bias) and u0-2 (u_bias) in HBM/L2, so that four lists fit a CU
-    int if_bias;
-    int u_bias;
+    // the 24 double columns above are ONE allocation, column k (in member order, photon_cols.hpp) at r0 + k * col_stride doubles:
+    // rank_loop_kernel addresses them through the base pointer and this stride instead of 24 pointers
+    unsigned col_stride;
 };
 // the columns from slot `first` on: a list of a rank pool as a list of its own (the biases stay 0)
 #if defined(__HIPCC__)
@@ -82,42 +77,55 @@ struct alignas(32) CellGeom {    // one 32-B sector per in-cell test (geometry.c
 struct alignas(16) CellGeom2 {   // third axis, 3-D only
     double c2, s2;
 };
-// the per-cell operands of calculateOpticalDepth, as optical_depth.c:52,57 computes them (host and device: -ffp-contract=off both)
+// What the loop needs from a cell whenever it re-locates a photon into it or scatters one there, staged ONCE per frame instead of being
+// recomputed per photon (round 3; the values depend on the cell alone):
+//   a, b, c   the fluid velocity with the per-cell part of hydroVectorToCartesian applied (geometry.c:189-253; physics.hpp, beta_from_record)
+//   w         beta_g / |v|,  beta_g = sqrt(1 - 1/gamma^2) from the cell's `gamma` (optical_depth.c:52), |v| from the velocity components
+//             (optical_depth.c:44): calculateOpticalDepth's  beta_g * (v.p) / (|v| |p|)  is then  w * (v.p) / |p|.  A cell at rest gives 0/0 = NaN,
+//             as the reference's cosine does (optical_depth.c:46)
+//   nsig      (dens_lab / M_P) * THOM_X_SECT                                               (optical_depth.c:57,59)
+//   gam, kf   the Lorentz factor of |v| and (gam - 1)/|v|^2 = gam^2/(gam + 1): the two scalars of the boost matrix of lorentzBoost
+//             (mclib.c:318-340), whose |v| does not depend on the photon's azimuth
+struct alignas(32) CellFluid {
+    double a, b, c, w;
+    double nsig, gam, kf, pad;
+};
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline void cell_tau_operands(double gamma_cell, double dens_lab, double &beta_g, double &n_dens)
+inline void cell_staged_operands(double a, double b, double c, double gamma_cell, double dens_lab, CellFluid &f)
 {
-    beta_g = __builtin_sqrt(1.0 - 1.0 / (gamma_cell * gamma_cell));
-    n_dens = dens_lab / M_P;
+    const double beta_g = __builtin_sqrt(1.0 - 1.0 / (gamma_cell * gamma_cell));
+    const double v2 = (a * a + b * b) + c * c;
+    f.a = a; f.b = b; f.c = c;
+    f.w = beta_g / __builtin_sqrt(v2);
+    f.nsig = (dens_lab / M_P) * THOM_X_SECT;
+    f.gam = 1.0 / __builtin_sqrt(1.0 - v2);
+    f.kf = (f.gam * f.gam) / (f.gam + 1.0);
+    f.pad = 0.0;
 }
-
-struct alignas(32) CellFluid {   // gathered when tau or the comoving momentum is recomputed
-    double a, b;                 // velocity with the per-cell part of geometry.c:189-253 applied (physics.hpp, cell_beta)
-    // what calculateOpticalDepth makes of the cell alone (optical_depth.c:52-57), computed once per frame instead of once per
-    // re-location -- the same operations on the same operands, so the same bits:
-    double beta_g;               // sqrt(1.0 - 1.0 / (gamma * gamma))
-    double n_dens;               // dens_lab / M_P
-};
 
 // exact accelerator for findContainingBlock (geometry.c:350-391): uniform buckets (optionally in
 // log of the coordinate) whose member lists are ascending in cell index, so the first hit of the
 // closed-interval test is the lowest-index containing cell, i.e. what the reference's linear scan returns.
 // bucket-list entry: the cell index with copies of everything the slow path needs from that cell, so that a
-// re-location costs two dependent load rounds (list range, then up to four entries) instead of five
+// re-location costs two dependent load rounds (list range, then one entry: exactly one 128-B line) instead of five
+// (alignas(32), not 128: a local copy must not ask for an over-aligned stack slot; the array itself starts on a 256-B boundary)
 struct alignas(32) FatCell {
     double c0, c1, s0, s1;       // CellGeom
-    double a, b, beta_g, n_dens;    // CellFluid
+    double a, b, c, w;           // CellFluid
+    double nsig, gam, kf;
     double c2, s2;               // CellGeom2 (3-D)
-    double fc;                   // HydroDev::fluid_c
     int cell;
     int pad;
+    double pad2[2];
 };
+static_assert(sizeof(FatCell) == 128, "one cache line per bucket-list entry");
 
 // one bucket of the lookup grid: its list, and for each octant (half a bucket per axis; quadrant in 2-D) the one
 // list entry whose cell covers that octant, if exactly one cell reaches into it.  A point well inside an octant
 // and well inside the hinted cell is in no other cell, so a lookup then costs this record and ONE FatCell
-// (112 B) instead of the whole list; every other point takes the exact list walk.
+// (128 B) instead of the whole list; every other point takes the exact list walk.
 constexpr unsigned GRID_NO_HINT = 15u;
 constexpr int GRID_CODE_OCT_SHIFT = 27;      // bucket code = bucket | octant << 27 | (position usable for a hint) << 30
 constexpr int GRID_CODE_HINT_OK = 1 << 30;
@@ -144,8 +152,8 @@ struct HydroDev {
     const CellGeom2 *geom2;
     const CellFluid *fluid;
     const double *temp;
-    const double *fluid_c;       // third velocity component (2.5-D: v2; 3-D: Cartesian z), absent in 2-D
-    const double *gamma;         // the cells' Lorentz factor (photonInjection's count, mclib.c:95; the loop reads CellFluid::beta_g)
+    const double *fluid_c;       // third velocity component (2.5-D: v2; 3-D: Cartesian z), absent in 2-D (= CellFluid::c; injection and emission read it here)
+    const double *gamma;         // the cells' Lorentz factor (photonInjection's count, mclib.c:95; the loop reads CellFluid::w)
     const double *k2e;           // exp(x) K_2(x), x = m_e c^2 / k T, for cells with T >= 1e7 K (else 0)
     int M;
     double dom0[2], dom1[2], dom2[2];

@@ -677,31 +677,33 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
     const int geomv = c->kc.geometry;
     for (int i = 0; host_grid && i < M; ++i) {
         geom[i].c0 = h->r0[i]; geom[i].c1 = h->r1[i]; geom[i].s0 = h->r0_size[i]; geom[i].s1 = h->r1_size[i];
-        cell_tau_operands(h->gamma[i], h->dens_lab[i], fluid[i].beta_g, fluid[i].n_dens);
         const double v0 = h->v0[i], v1 = h->v1[i], v2 = two ? 0.0 : h->v2[i];
+        double fa, fb, fcv = 0.0;
         if (!three) {
             if (geomv == GEOM_SPHERICAL) {
                 const double th = h->r1[i];
-                fluid[i].a = v0 * std::sin(th) + v1 * std::cos(th);
-                fluid[i].b = v0 * std::cos(th) - v1 * std::sin(th);
+                fa = v0 * std::sin(th) + v1 * std::cos(th);
+                fb = v0 * std::cos(th) - v1 * std::sin(th);
             } else {
-                fluid[i].a = v0;
-                fluid[i].b = v1;
+                fa = v0;
+                fb = v1;
             }
-            if (fc) fc[i] = v2;
+            fcv = v2;
         } else if (geomv == GEOM_CARTESIAN) {
-            fluid[i].a = v0; fluid[i].b = v1; fc[i] = v2;
+            fa = v0; fb = v1; fcv = v2;
         } else if (geomv == GEOM_SPHERICAL) {
             const double x1 = h->r1[i], x2 = h->r2[i];
-            fluid[i].a = v0 * std::sin(x1) * std::cos(x2) + v1 * std::cos(x1) * std::cos(x2) - v2 * std::sin(x2);
-            fluid[i].b = v0 * std::sin(x1) * std::sin(x2) + v1 * std::cos(x1) * std::sin(x2) + v2 * std::cos(x2);
-            fc[i] = v0 * std::cos(x1) - v1 * std::sin(x1);
+            fa = v0 * std::sin(x1) * std::cos(x2) + v1 * std::cos(x1) * std::cos(x2) - v2 * std::sin(x2);
+            fb = v0 * std::sin(x1) * std::sin(x2) + v1 * std::cos(x1) * std::sin(x2) + v2 * std::cos(x2);
+            fcv = v0 * std::cos(x1) - v1 * std::sin(x1);
         } else {   // POLAR
             const double x1 = h->r1[i];
-            fluid[i].a = v0 * std::cos(x1) - v1 * std::sin(x1);
-            fluid[i].b = v0 * std::sin(x1) + v1 * std::cos(x1);
-            fc[i] = v2;
+            fa = v0 * std::cos(x1) - v1 * std::sin(x1);
+            fb = v0 * std::sin(x1) + v1 * std::cos(x1);
+            fcv = v2;
         }
+        if (fc) fc[i] = fcv;
+        cell_staged_operands(fa, fb, fcv, h->gamma[i], h->dens_lab[i], fluid[i]);
     }
     if (host_grid) {
         if (three) {
@@ -778,10 +780,10 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
             const int ci = g.cells[e];
             FatCell &f = fat[e];
             f.c0 = geom[ci].c0; f.c1 = geom[ci].c1; f.s0 = geom[ci].s0; f.s1 = geom[ci].s1;
-            f.a = fluid[ci].a; f.b = fluid[ci].b; f.beta_g = fluid[ci].beta_g; f.n_dens = fluid[ci].n_dens;
+            f.a = fluid[ci].a; f.b = fluid[ci].b; f.c = fluid[ci].c; f.w = fluid[ci].w;
+            f.nsig = fluid[ci].nsig; f.gam = fluid[ci].gam; f.kf = fluid[ci].kf;
             f.c2 = three ? h->r2[ci] : 0.0; f.s2 = three ? h->r2_size[ci] : 0.0;
-            f.fc = fc ? fc[ci] : 0.0;
-            f.cell = ci; f.pad = 0;
+            f.cell = ci; f.pad = 0; f.pad2[0] = f.pad2[1] = 0.0;
         }
         HIPCHK(c, hipMemcpy(gbase, gh.data(), o_start, hipMemcpyHostToDevice));
     } else {
@@ -1241,8 +1243,7 @@ static int alloc_view_photons(mcrat_hip_ctx *c, int n)
     for (int k = 0; k < 24; ++k) *cols[k] += o;
     p.idx += o; p.flags += o; p.type += o;
     p.n = n;
-    p.n_pad = P->rank_stride;
-    p.hot_bias = p.if_bias = p.u_bias = 0;
+    p.n_pad = P->rank_stride;                 // (col_stride stays the pool's: the columns of a view are windows into the pool's)
     c->ph = p;
     HIPCHK(c, launch_clear_slots(c->ph, 0, P->rank_stride, c->stream));
     c->step_blocks = step_grid_blocks(p.n_pad);
@@ -1290,7 +1291,10 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     p.type = b + o_type;
     p.n = n;
     p.n_pad = n_pad;
-    p.hot_bias = p.if_bias = p.u_bias = 0;
+    if ((o_d[1] - o_d[0]) / sizeof(double) * 24 > 0xffffffffull) { c->last_error = "photon list: more than 2^32 / 24 slots"; return MCRAT_HIP_EINVAL; }
+    p.col_stride = (unsigned)((o_d[1] - o_d[0]) / sizeof(double));
+    for (int k = 1; k < 24; ++k)
+        if (o_d[k] - o_d[k - 1] != o_d[1] - o_d[0]) { c->last_error = "photon columns are not equally spaced"; return MCRAT_HIP_EHIP; }
     c->step_blocks = step_grid_blocks(n_pad);
     const int need = c->step_blocks;                          // one candidate per workgroup of the step kernel
     if (c->partials_cap < need) {

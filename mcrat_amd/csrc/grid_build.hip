@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void grid_fill_kernel(GridPlan p, const CellGe
 __device__ __forceinline__ double mapped(double x, int logmap) { return logmap ? log(fmax(x, 1e-300)) : x; }
 
 // one thread per list entry: the entry's complete cell record (device_types.hpp, FatCell).  Neighbouring threads write
-// neighbouring 96-B records, so the ~4 M x 96 B of a 10^6-cell frame stream out coalesced (one thread per bucket writing
+// neighbouring 128-B records, so the ~4 M x 128 B of a 10^6-cell frame stream out coalesced (one thread per bucket writing
 // its whole list took 650 us per frame, this 130).
 __global__ __launch_bounds__(256) void grid_records_kernel(int naxes, long long total, const int *__restrict__ entries,
                                                            const CellGeom *__restrict__ geom, const CellGeom2 *__restrict__ geom2,
@@ -182,11 +182,11 @@ __global__ __launch_bounds__(256) void grid_records_kernel(int naxes, long long 
     const CellFluid f = fluid[ci];
     FatCell fc;
     fc.c0 = g.c0; fc.c1 = g.c1; fc.s0 = g.s0; fc.s1 = g.s1;
-    fc.a = f.a; fc.b = f.b; fc.beta_g = f.beta_g; fc.n_dens = f.n_dens;
+    fc.a = f.a; fc.b = f.b; fc.c = f.c; fc.w = f.w;
+    fc.nsig = f.nsig; fc.gam = f.gam; fc.kf = f.kf;
     fc.c2 = 0; fc.s2 = 0;
     if (naxes == 3) { const CellGeom2 g2 = geom2[ci]; fc.c2 = g2.c2; fc.s2 = g2.s2; }
-    fc.fc = fluid_c ? fluid_c[ci] : 0.0;
-    fc.cell = ci; fc.pad = 0;
+    fc.cell = ci; fc.pad = 0; fc.pad2[0] = fc.pad2[1] = 0.0;
     cells[e] = fc;
 }
 

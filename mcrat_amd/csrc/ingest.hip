@@ -383,29 +383,29 @@ __global__ __launch_bounds__(IB) void stage_cells_kernel(int dims, int geom, Hyd
         og[i] = g;
         if (three) { CellGeom2 g2; g2.c2 = c2; g2.s2 = s2; og2[i] = g2; }
         const double v0 = h.v0[i], v1 = h.v1[i], v2 = two ? 0.0 : h.v2[i];
-        CellFluid f;
-        cell_tau_operands(h.gamma[i], h.dens_lab[i], f.beta_g, f.n_dens);
         ogamma[i] = h.gamma[i];
-        double fc = 0;
+        double fa, fb, fc = 0;
         if (!three) {
             if (geom == GEOM_SPHERICAL) {
-                f.a = v0 * sin(c1) + v1 * cos(c1);
-                f.b = v0 * cos(c1) - v1 * sin(c1);
+                fa = v0 * sin(c1) + v1 * cos(c1);
+                fb = v0 * cos(c1) - v1 * sin(c1);
             } else {
-                f.a = v0; f.b = v1;
+                fa = v0; fb = v1;
             }
             fc = v2;
         } else if (geom == GEOM_CARTESIAN) {
-            f.a = v0; f.b = v1; fc = v2;
+            fa = v0; fb = v1; fc = v2;
         } else if (geom == GEOM_SPHERICAL) {
-            f.a = v0 * sin(c1) * cos(c2) + v1 * cos(c1) * cos(c2) - v2 * sin(c2);
-            f.b = v0 * sin(c1) * sin(c2) + v1 * cos(c1) * sin(c2) + v2 * cos(c2);
+            fa = v0 * sin(c1) * cos(c2) + v1 * cos(c1) * cos(c2) - v2 * sin(c2);
+            fb = v0 * sin(c1) * sin(c2) + v1 * cos(c1) * sin(c2) + v2 * cos(c2);
             fc = v0 * cos(c1) - v1 * sin(c1);
         } else {   // POLAR
-            f.a = v0 * cos(c1) - v1 * sin(c1);
-            f.b = v0 * sin(c1) + v1 * cos(c1);
+            fa = v0 * cos(c1) - v1 * sin(c1);
+            fb = v0 * sin(c1) + v1 * cos(c1);
             fc = v2;
         }
+        CellFluid f;
+        cell_staged_operands(fa, fb, fc, h.gamma[i], h.dens_lab[i], f);
         of[i] = f;
         if (ofc) ofc[i] = fc;
         const double t = h.temp[i];

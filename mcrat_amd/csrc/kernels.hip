@@ -21,6 +21,7 @@
 #include "device_types.hpp"
 #include "launch.hpp"
 #include "physics.hpp"
+#include "photon_cols.hpp"
 #include "rng.hpp"
 #include "cs_device.hpp"
 
@@ -221,8 +222,8 @@ constexpr int Q_RECALC_ONLY = (int)0x80000000;   // queue entry flag: the slot i
 
 // streaming half of an iteration for one slot.  Returns the free time, or sets `queue` (0: no, 1: re-locate,
 // 2: recalc tau only) when the slot must go through the slow path; the time returned then is a placeholder.
-template <int DIMS, int GEOM, bool FORCE>
-__device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &hy, int i, unsigned fl, int cell,
+template <int DIMS, int GEOM, bool FORCE, class PH>
+__device__ __forceinline__ double fast_one(const PH &ph, const HydroDev &hy, int i, unsigned fl, int cell,
                                            double r0, double r1, double r2, double ntau, uint64_t bits, int &queue, int &bucket,
                                            double &a0, double &a1, double &a2)
 {
@@ -240,8 +241,8 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
             else if (!phys::check_in_block<DIMS>(hy, cell, a0, a1, a2)) queue = 1;    // mclib.c:507,528
             else if (fl & FLAG_RECALC) {                                         // mclib.c:668
                 if (fl & FLAG_TAU_FRESH) {
-                    ph.flags[i - ph.if_bias] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));
-                    ph.tau[i] = ph.tau_next[i];
+                    ph.flags(i) = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                    ph.tau(i) = ph.tau_next(i);
                 } else {
                     queue = 2;
                 }
@@ -252,7 +253,7 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
         if (MC_DIAG(DIAG_SKIP_SAMPLE)) return 1e-3 + (double)i * 1e-12 + (double)(bits & 1) * 0.0 + ntau * 0.0;
         return sample_free_time(ntau, bits);
     }
-    if (cell != -1) ph.idx[i - ph.if_bias] = -1;                                 // mclib.c:592
+    if (cell != -1) ph.idx(i) = -1;                                              // mclib.c:592
     return 1e12 / C_LIGHT;                                                       // mclib.c:620,684
 }
 
@@ -261,29 +262,27 @@ __device__ __forceinline__ double fast_one(const PhotonDev &ph, const HydroDev &
 // rounds: {photon columns, bucket range} then {bucket entries | the cell's fluid record}.
 // `bits` is the slot's free-path draw of this pass: phase 1 has computed the pair's Philox block anyway (one block serves two
 // slots) and hands the 64 bits over -- for queued slots through the slot's time_to_scatter entry, which this function overwrites.
-template <int DIMS, int GEOM>
-__device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &hy, int i, bool relocate, int bucket, bool count_it,
+template <int DIMS, int GEOM, class PH>
+__device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int i, bool relocate, int bucket, bool count_it,
                                            uint64_t bits, int &relocated, int &not_found)
 {
-    const int h = i - ph.hot_bias;               // index into the hot columns
-    const double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
-    const double p0 = ph.p0[i], p1 = ph.p1[i], p2 = ph.p2[i], p3 = ph.p3[i];
-    const int hf = i - ph.if_bias;               // index into idx and flags
-    const unsigned fl = ph.flags[hf];
+    const double r0 = ph.r0(i), r1 = ph.r1(i), r2 = ph.r2(i);
+    const double p0 = ph.p0(i), p1 = ph.p1(i), p2 = ph.p2(i), p3 = ph.p3(i);
+    const unsigned fl = ph.flags(i);
     int cell;
     bool need_tau = (fl & FLAG_RECALC) != 0;
     bool new_cell = false;
-    double fa = 0, fb = 0, fc = 0, fbeta_g = 0, fdens = 0;
-    if (MC_DIAG(DIAG_SLOW_EMPTY)) { ph.tts[i] = 1e-3 + i * 1e-12; return 1e-3 + i * 1e-12; }
+    double fa = 0, fb = 0, fc = 0, fw = 0, fnsig = 0, fgam = 1, fkf = 0.5;
+    double a0 = 0, a1 = 0, a2 = 0;
+    if (MC_DIAG(DIAG_SLOW_EMPTY)) { ph.tts(i) = 1e-3 + i * 1e-12; return 1e-3 + i * 1e-12; }
     if (MC_DIAG(DIAG_SLOW_NO_SEARCH)) relocate = false;
     if (relocate) {
-        double a0, a1, a2;
         phys::hydro_coords<DIMS, GEOM>(r0, r1, r2, a0, a1, a2);
         FatCell hit;
         cell = phys::find_in_bucket<DIMS>(hy.grid, bucket, a0, a1, a2, hit);     // mclib.c:534
-        ph.idx[hf] = cell;                                                       // mclib.c:536
+        ph.idx(i) = cell;                                                        // mclib.c:536
         if (cell != -1) {
-            fa = hit.a; fb = hit.b; fc = hit.fc; fbeta_g = hit.beta_g; fdens = hit.n_dens;
+            fa = hit.a; fb = hit.b; fc = hit.c; fw = hit.w; fnsig = hit.nsig; fgam = hit.gam; fkf = hit.kf;
             new_cell = true;
             need_tau = true;                                                     // mclib.c:570
             if (count_it) relocated += 1;                                        // mclib.c:579,608-611
@@ -291,11 +290,10 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
             not_found += 1;                                                      // mclib.c:583
         }
     } else {
-        cell = ph.idx[hf];
+        cell = ph.idx(i);
         if (cell != -1) {
             const CellFluid f = hy.fluid[cell];
-            fa = f.a; fb = f.b; fbeta_g = f.beta_g; fdens = f.n_dens;
-            if constexpr (DIMS != DIM_TWO) fc = hy.fluid_c[cell];
+            fa = f.a; fb = f.b; fc = f.c; fw = f.w; fnsig = f.nsig;
         }
     }
     double t;
@@ -304,35 +302,36 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
         double ntau;
         if (need_tau) {
             double cphi, sphi;
-            phys::cos_sin_of_atan2(r1, r0, cphi, sphi);                          // photon azimuth, mclib.c:549-552
+            if (new_cell) phys::relocation_azimuth<DIMS, GEOM>(r0, r1, a0, cphi, sphi);   // photon azimuth, mclib.c:549-552
+            else phys::cos_sin_of_atan2(r1, r0, cphi, sphi);                              // optical_depth.c:30-35
             double beta[3];
             phys::beta_from_record<DIMS>(fa, fb, fc, cphi, sphi, beta);
             double comv0 = 0;
             if (new_cell) {
                 const double lab[4] = {p0, p1, p2, p3};
                 double comv[4];
-                phys::lorentz_boost(beta, lab, comv, true);                      // mclib.c:558
-                ph.c0[i] = comv[0]; ph.c1[i] = comv[1]; ph.c2[i] = comv[2]; ph.c3[i] = comv[3];
+                phys::boost_with<true>(beta, fgam, fkf, lab, comv);              // mclib.c:558
+                ph.c0(i) = comv[0]; ph.c1(i) = comv[1]; ph.c2(i) = comv[2]; ph.c3(i) = comv[3];
                 comv0 = comv[0];
             }
             double norm = 1.0;
             if constexpr (TABLE_MODE) {                                          // TAU_CALCULATION == TABLE, optical_depth.c:58
-                if (!new_cell) comv0 = ph.c0[i];
+                if (!new_cell) comv0 = ph.c0(i);
                 norm = phys::thermal_cross_section(hy, comv0, hy.temp[cell]);
             }
-            const double tau = phys::optical_depth_direct(beta, fbeta_g, fdens, p1, p2, p3, norm);
-            ntau = -1.0 / tau;
-            ph.tau[i] = tau;
-            ph.ntau[h] = ntau;
-            if (fl & FLAG_RECALC) ph.flags[hf] = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));  // mclib.c:571-576,672
+            const double tau = phys::optical_depth_staged(beta, fw, fnsig, p1, p2, p3, norm);
+            ntau = -phys::rcp_nr(tau);
+            ph.tau(i) = tau;
+            ph.ntau(i) = ntau;
+            if (fl & FLAG_RECALC) ph.flags(i) = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));  // mclib.c:571-576,672
         } else {
-            ntau = ph.ntau[h];
+            ntau = ph.ntau(i);
         }
         t = sample_free_time(ntau, bits);
     } else {
         t = 1e12 / C_LIGHT;
     }
-    ph.tts[i] = t;
+    ph.tts(i) = t;
     return t;
 }
 
@@ -345,8 +344,8 @@ __device__ __forceinline__ double slow_one(const PhotonDev &ph, const HydroDev &
 // Takes a slot only when the bucket's hint settles it (one 96-B entry, the cell provably the only one that holds the point:
 // find_in_bucket); todo[k] stays set for the others -- list walks, points outside every cell -- and the caller falls back to slow_one.
 // (DIRECT optical depths only: the TABLE build keeps slow_one.)
-template <int DIMS, int GEOM, int K>
-__device__ __forceinline__ void relocate_lockstep(const PhotonDev &ph, const HydroDev &hy, const int (&slot)[K], bool (&todo)[K],
+template <int DIMS, int GEOM, int K, class PH>
+__device__ __forceinline__ void relocate_lockstep(const PH &ph, const HydroDev &hy, const int (&slot)[K], bool (&todo)[K],
                                                   const double (&r0)[K], const double (&r1)[K], const double (&a0)[K], const double (&a1)[K],
                                                   const double (&a2)[K], const int (&code)[K], const uint64_t (&bits)[K], const unsigned (&fl)[K],
                                                   bool count_it, double (&t)[K], int &relocated)
@@ -361,7 +360,7 @@ __device__ __forceinline__ void relocate_lockstep(const PhotonDev &ph, const Hyd
         take[k] = todo[k] && code[k] >= 0;
         d[k] = g.dir[take[k] ? (code[k] & GRID_CODE_BUCKET_MASK) : 0];
         const int i = slot[k];
-        p0[k] = ph.p0[i]; p1[k] = ph.p1[i]; p2[k] = ph.p2[i]; p3[k] = ph.p3[i];
+        p0[k] = ph.p0(i); p1[k] = ph.p1(i); p2[k] = ph.p2(i); p3[k] = ph.p3(i);
     }
     FatCell f[K];
 #pragma unroll
@@ -375,25 +374,25 @@ __device__ __forceinline__ void relocate_lockstep(const PhotonDev &ph, const Hyd
     for (int k = 0; k < K; ++k) {
         take[k] = take[k] && phys::well_in_fat_cell<DIMS>(f[k], a0[k], a1[k], a2[k]);
         double cphi, sphi;
-        phys::cos_sin_of_atan2(r1[k], r0[k], cphi, sphi);                        // photon azimuth, mclib.c:549-552
+        phys::relocation_azimuth<DIMS, GEOM>(r0[k], r1[k], a0[k], cphi, sphi);  // photon azimuth, mclib.c:549-552
         double beta[3];
-        phys::beta_from_record<DIMS>(f[k].a, f[k].b, f[k].fc, cphi, sphi, beta);
+        phys::beta_from_record<DIMS>(f[k].a, f[k].b, f[k].c, cphi, sphi, beta);
         const double lab[4] = {p0[k], p1[k], p2[k], p3[k]};
-        phys::lorentz_boost(beta, lab, comv[k], true);                           // mclib.c:558
-        tau[k] = phys::optical_depth_direct(beta, f[k].beta_g, f[k].n_dens, p1[k], p2[k], p3[k], 1.0);
-        ntau[k] = -1.0 / tau[k];
+        phys::boost_with<true>(beta, f[k].gam, f[k].kf, lab, comv[k]);           // mclib.c:558
+        tau[k] = phys::optical_depth_staged(beta, f[k].w, f[k].nsig, p1[k], p2[k], p3[k], 1.0);
+        ntau[k] = -phys::rcp_nr(tau[k]);
         t[k] = sample_free_time(ntau[k], bits[k]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!take[k]) continue;
-        const int i = slot[k], h = i - ph.hot_bias, hf = i - ph.if_bias;
-        ph.idx[hf] = f[k].cell;                                                  // mclib.c:536
-        ph.c0[i] = comv[k][0]; ph.c1[i] = comv[k][1]; ph.c2[i] = comv[k][2]; ph.c3[i] = comv[k][3];
-        ph.tau[i] = tau[k];
-        ph.ntau[h] = ntau[k];
-        if (fl[k] & FLAG_RECALC) ph.flags[hf] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));   // mclib.c:571-576
-        ph.tts[i] = t[k];
+        const int i = slot[k];
+        ph.idx(i) = f[k].cell;                                                   // mclib.c:536
+        ph.c0(i) = comv[k][0]; ph.c1(i) = comv[k][1]; ph.c2(i) = comv[k][2]; ph.c3(i) = comv[k][3];
+        ph.tau(i) = tau[k];
+        ph.ntau(i) = ntau[k];
+        if (fl[k] & FLAG_RECALC) ph.flags(i) = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));    // mclib.c:571-576
+        ph.tts(i) = t[k];
         if (count_it) relocated += 1;                                            // mclib.c:579,608-611
         todo[k] = false;
     }
@@ -443,6 +442,7 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
     __shared__ double s_wt[STEP_BLOCK / 64];
     __shared__ int s_wi[STEP_BLOCK / 64];
     if (st->done) return;
+    const PtrCols pc(ph);                        // the accessor the shared device functions take (photon_cols.hpp)
     const int nseg = st->nseg;
     const int skip = st->skip_idx;
     const unsigned long long iter = st->iteration;
@@ -484,8 +484,8 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
         int q0, q1, b0, b1;
         double2 T;
         double A0[2], A1[2], A2[2];
-        T.x = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0, b0, A0[0], A1[0], A2[0]);
-        T.y = fast_one<DIMS, GEOM, FORCE>(ph, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1, b1, A0[1], A1[1], A2[1]);
+        T.x = fast_one<DIMS, GEOM, FORCE>(pc, hy, i0, in.FL.x, in.ID.x, in.R0.x, in.R1.x, in.R2.x, in.NTAU.x, bits0, q0, b0, A0[0], A1[0], A2[0]);
+        T.y = fast_one<DIMS, GEOM, FORCE>(pc, hy, i0 + 1, in.FL.y, in.ID.y, in.R0.y, in.R1.y, in.R2.y, in.NTAU.y, bits1, q1, b1, A0[1], A1[1], A2[1]);
         if constexpr (FORCE) {
             if constexpr (!TABLE_MODE) {             // both slots of the pair in lockstep; what the hints do not settle goes on below
                 const int slot[2] = {i0, i0 + 1}, code[2] = {b0, b1};
@@ -496,13 +496,13 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
                 double tt[2];
                 int dummy = 0;
                 if (todo[0] || todo[1]) {
-                    relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, R0, R1, A0, A1, A2, code, bits, fl, false, tt, dummy);
+                    relocate_lockstep<DIMS, GEOM, 2>(pc, hy, slot, todo, R0, R1, A0, A1, A2, code, bits, fl, false, tt, dummy);
                     if (q0 && !todo[0]) { T.x = tt[0]; q0 = 0; }
                     if (q1 && !todo[1]) { T.y = tt[1]; q1 = 0; }
                 }
             }
-            if (q0) T.x = slow_one<DIMS, GEOM>(ph, hy, i0, true, b0, false, bits0, relocated, not_found);
-            if (q1) T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, true, b1, false, bits1, relocated, not_found);
+            if (q0) T.x = slow_one<DIMS, GEOM>(pc, hy, i0, true, b0, false, bits0, relocated, not_found);
+            if (q1) T.y = slow_one<DIMS, GEOM>(pc, hy, i0 + 1, true, b1, false, bits1, relocated, not_found);
             q0 = q1 = 0;
         } else {
             // ballot-compact the slots that need the slow path into the workgroup's LDS queue (one LDS atomic
@@ -518,8 +518,8 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
                     if (q0) { const int e = base + __popcll(m0 & below); s_q[e] = i0 | (q0 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b0; }
                     if (q1) { const int e = base + c0 + __popcll(m1 & below); s_q[e] = (i0 + 1) | (q1 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b1; }
                 } else {
-                    if (q0) { T.x = slow_one<DIMS, GEOM>(ph, hy, i0, q0 == 1, b0, true, bits0, relocated, not_found); q0 = 0; }
-                    if (q1) { T.y = slow_one<DIMS, GEOM>(ph, hy, i0 + 1, q1 == 1, b1, true, bits1, relocated, not_found); q1 = 0; }
+                    if (q0) { T.x = slow_one<DIMS, GEOM>(pc, hy, i0, q0 == 1, b0, true, bits0, relocated, not_found); q0 = 0; }
+                    if (q1) { T.y = slow_one<DIMS, GEOM>(pc, hy, i0 + 1, q1 == 1, b1, true, bits1, relocated, not_found); q1 = 0; }
                 }
             }
         }
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
             if (entry == -1) continue;
             const int i = entry & ~Q_RECALC_ONLY;
             const uint64_t bits = (uint64_t)__double_as_longlong(ph.tts[i]);
-            const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(entry & Q_RECALC_ONLY), s_qb[e], true, bits, relocated, not_found);
+            const double t = slow_one<DIMS, GEOM>(pc, hy, i, !(entry & Q_RECALC_ONLY), s_qb[e], true, bits, relocated, not_found);
             best.offer(t, i);
             if (t < t_cut) shortlist_push(sl, t, i);
         }
@@ -599,10 +599,11 @@ __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, 
 {
     MC_STAMP(st, 2);
     fluid_temp = hy.temp[cell];                            // mclib.c:1148
+    const CellFluid f = hy.fluid[cell];
     double cphi, sphi;
     phys::cos_sin_of_atan2(r[1], r[0], cphi, sphi);        // ph_phi, mclib.c:1151
     double beta[3];
-    phys::cell_beta<DIMS>(hy, cell, cphi, sphi, beta);     // mclib.c:1167-1174
+    phys::cell_beta<DIMS>(f, cphi, sphi, beta);            // mclib.c:1167-1174
     if constexpr (STOKES) phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
     EventStream rng = event_stream(key.seed, iter, rng_slot, key.stream);
     const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
@@ -612,43 +613,40 @@ __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, 
     MC_STAMP(st, 4);
     if (!phys::single_scatter<STOKES>(el, pc, s, rng)) return false;   // mclib.c:1245
     MC_STAMP(st, 5);
-    const double nb[3] = {-1 * beta[0], -1 * beta[1], -1 * beta[2]};
-    phys::lorentz_boost(nb, pc, p, true);                              // mclib.c:1265
+    const double nb[3] = {-beta[0], -beta[1], -beta[2]};
+    phys::boost_with<true>(nb, f.gam, f.kf, pc, p);                    // mclib.c:1265
     if constexpr (STOKES) phys::stokes_rotation(nb, pc + 1, p + 1, s); // mclib.c:1280
     // recalc_properties = 1 (mclib.c:1322).  The optical depth the next pass would recompute for this slot in its
     // cached cell (calcMeanFreePath, mclib.c:668-673: same position, same cell record, the new momentum) is computed
     // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
-    const CellFluid f = hy.fluid[cell];
     double norm = 1.0;
     if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], fluid_temp, !WAVE || (threadIdx.x & 63) == 0);   // optical_depth.c:58
-    tau_new = phys::optical_depth_direct(beta, f.beta_g, f.n_dens, p[1], p[2], p[3], norm);
+    tau_new = phys::optical_depth_staged(beta, f.w, f.nsig, p[1], p[2], p[3], norm);
     return true;
 }
 
 // stores of a successful scatter, mclib.c:1290-1322
-template <bool STOKES>
-__device__ __forceinline__ void commit_scatter(const PhotonDev &ph, int i, const double p[4], const double pc[4], const double s[4],
+template <bool STOKES, class PH>
+__device__ __forceinline__ void commit_scatter(const PH &ph, int i, const double p[4], const double pc[4], const double s[4],
                                                const double r[3], double tau_new, unsigned cand_flags)
 {
-    const int h = i - ph.hot_bias;
-    if constexpr (STOKES) { ph.s0[i] = s[0]; ph.s1[i] = s[1]; ph.s2[i] = s[2]; ph.s3[i] = s[3]; }
-    ph.p0[i] = p[0]; ph.p1[i] = p[1]; ph.p2[i] = p[2]; ph.p3[i] = p[3];
+    if constexpr (STOKES) { ph.s0(i) = s[0]; ph.s1(i) = s[1]; ph.s2(i) = s[2]; ph.s3(i) = s[3]; }
+    ph.p0(i) = p[0]; ph.p1(i) = p[1]; ph.p2(i) = p[2]; ph.p3(i) = p[3];
     {
-        const double d = 1.0 / p[0];                                   // mclib.c:1074-1080 factors of the new momentum
-        const int hu = i - ph.u_bias;
-        ph.u0[hu] = p[1] * d * C_LIGHT; ph.u1[hu] = p[2] * d * C_LIGHT; ph.u2[hu] = p[3] * d * C_LIGHT;
+        const double d = phys::rcp_nr(p[0]);                           // mclib.c:1074-1080 factors of the new momentum
+        ph.u0(i) = p[1] * d * C_LIGHT; ph.u1(i) = p[2] * d * C_LIGHT; ph.u2(i) = p[3] * d * C_LIGHT;
     }
-    ph.c0[i] = pc[0]; ph.c1[i] = pc[1]; ph.c2[i] = pc[2]; ph.c3[i] = pc[3];
-    ph.r0[h] = r[0]; ph.r1[h] = r[1]; ph.r2[h] = r[2];              // already advanced: the next step kernel skips it
-    ph.num_scatt[i] += 1;                                              // mclib.c:1317
-    ph.tau_next[i] = tau_new;
-    ph.ntau[h] = -1.0 / tau_new;
-    ph.flags[i - ph.if_bias] = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
+    ph.c0(i) = pc[0]; ph.c1(i) = pc[1]; ph.c2(i) = pc[2]; ph.c3(i) = pc[3];
+    ph.r0(i) = r[0]; ph.r1(i) = r[1]; ph.r2(i) = r[2];              // already advanced: the next step kernel skips it
+    ph.num_scatt(i) += 1;                                              // mclib.c:1317
+    ph.tau_next(i) = tau_new;
+    ph.ntau(i) = -phys::rcp_nr(tau_new);
+    ph.flags(i) = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
 }
 
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
-template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
-__device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class PH>
+__device__ __forceinline__ int try_candidate(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
                                              unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base)
 {
     // *scattered_ph_index (mclib.c:1341) is the last candidate photonEvent looked at; main() does not call
@@ -668,16 +666,15 @@ __device__ __forceinline__ int try_candidate(const PhotonDev &ph, const HydroDev
     if (w.nseg < MAX_SEG) w.seg[w.nseg++] = this_seg;
     else w.seg[MAX_SEG - 1] += this_seg;
     w.old_scatt_time = scatt_time;
-    const int h = i - ph.hot_bias;               // index into the hot columns
     // one round of independent loads for everything the candidate needs (this lane's latency is the kernel's)
-    const int cell = ph.idx[i - ph.if_bias];
-    double p[4] = {ph.p0[i], ph.p1[i], ph.p2[i], ph.p3[i]};
-    double r[3] = {ph.r0[h], ph.r1[h], ph.r2[h]};
-    double pc[4] = {ph.c0[i], ph.c1[i], ph.c2[i], ph.c3[i]};
-    const unsigned cand_flags = ph.flags[i - ph.if_bias];
-    const double u0 = ph.u0[i - ph.u_bias], u1 = ph.u1[i - ph.u_bias], u2 = ph.u2[i - ph.u_bias];
+    const int cell = ph.idx(i);
+    double p[4] = {ph.p0(i), ph.p1(i), ph.p2(i), ph.p3(i)};
+    double r[3] = {ph.r0(i), ph.r1(i), ph.r2(i)};
+    double pc[4] = {ph.c0(i), ph.c1(i), ph.c2(i), ph.c3(i)};
+    const unsigned cand_flags = ph.flags(i);
+    const double u0 = ph.u0(i), u1 = ph.u1(i), u2 = ph.u2(i);
     double s[4] = {1, 0, 0, 0};
-    if constexpr (STOKES) { s[0] = ph.s0[i]; s[1] = ph.s1[i]; s[2] = ph.s2[i]; s[3] = ph.s3[i]; }
+    if constexpr (STOKES) { s[0] = ph.s0(i); s[1] = ph.s1(i); s[2] = ph.s2(i); s[3] = ph.s3(i); }
     if (cell == -1) return EV_RUNNING;                     // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
 
     if (cand_flags & FLAG_MOVES) {                         // the candidate's own position after mclib.c:1138
@@ -722,8 +719,8 @@ using EventShared = EventSharedT<EVENT_BLOCK>;
 // (sh.raw[0..n_raw), complete below t_cut unless it overflowed), walk it as photonEvent does, refill from
 // time_to_scatter if it runs out, then the bookkeeping of mcrat.c:782-784 / 837-845 into *st.
 // All BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
-template <int DIMS, int GEOM, bool STOKES, int BLOCK>
-__device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
+template <int DIMS, int GEOM, bool STOKES, int BLOCK, class PH>
+__device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
                                             EventSharedT<BLOCK> &sh, int n_raw, Cand gmin, int base, int n,
                                             unsigned long long iter, double dt_max, int last_idx, double t_est)
 {
@@ -786,7 +783,7 @@ __device__ __forceinline__ void event_block(const PhotonDev &ph, const HydroDev 
             TopK more;
             more.init();
             for (int i = base + tid; i < base + n; i += BLOCK) {
-                double t = ph.tts[i];
+                double t = ph.tts(i);
                 if (t != t) t = INFINITY;
                 if (cand_less(lt, li, t, i)) more.insert(t, i);
             }
@@ -851,7 +848,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
     for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(sh.wt[wv], sh.wi[wv]);
     Cand gmin;
     gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
-    event_block<DIMS, GEOM, STOKES, EVENT_BLOCK>(ph, hy, st, key, sh, n_raw, gmin, 0, ph.n, iter, dt_max, last_idx, t_est);
+    event_block<DIMS, GEOM, STOKES, EVENT_BLOCK>(PtrCols(ph), hy, st, key, sh, n_raw, gmin, 0, ph.n, iter, dt_max, last_idx, t_est);
     if (tid == 0) sl->count = 0;
 }
 
@@ -939,7 +936,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         int last = -1;
         for (int il = tid; il < n; il += EVENT_BLOCK) {
             const int i = base + il;
-            const bool settled_null = gph.type[i] == 'N' && gph.idx[i] == -1 && gph.tts[i] == 1e12 / C_LIGHT;
+            const bool settled_null = gph.type[i] == 'N' && gph.idx[i] == -1 && gph.tts[i] == 1e12 / C_LIGHT;   // (cyclo-synchrotron lists: columns in HBM/L2)
             if (!settled_null) last = il;
         }
 #pragma unroll
@@ -967,28 +964,19 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     // function below works on it unchanged (col[i - bias]).  (RESIDENT is a template parameter so that the pointers provably
     // address LDS and the accesses compile to ds_read / ds_write instead of flat loads.)
     constexpr bool FULL_HOT = RANK_BLOCK >= 256;
-    PhotonDev ph = gph;
+    constexpr unsigned LDS_MASK = RESIDENT ? (FULL_HOT ? LIST_MASK_FULL : LIST_MASK_SMALL) : 0u;
+    using Cols = ListCols<LDS_MASK>;
+    static_assert(Cols::lds_bytes_per_slot == (RESIDENT ? (size_t)rank_lds_bytes_per_slot(RANK_BLOCK) : 0), "launch_rank_loop sizes the dynamic LDS with this");
+    const Cols ph(gph, RESIDENT ? s_dyn : nullptr, lds_slots, base);
     if constexpr (RESIDENT) {
-        double *d = reinterpret_cast<double *>(s_dyn);
-        double *l_r0 = d, *l_r1 = d + lds_slots, *l_r2 = d + 2 * lds_slots, *l_nt = d + 3 * lds_slots;
-        double *l_u0 = d + 4 * lds_slots, *l_u1 = d + 5 * lds_slots, *l_u2 = d + 6 * lds_slots;     // FULL_HOT only
-        int *l_idx = reinterpret_cast<int *>(d + 7 * lds_slots);
-        unsigned char *l_fl = reinterpret_cast<unsigned char *>(l_idx + lds_slots);
         for (int il = tid; il < n; il += EVENT_BLOCK) {
             const int i = base + il;
-            l_r0[il] = gph.r0[i]; l_r1[il] = gph.r1[i]; l_r2[il] = gph.r2[i];
-            l_nt[il] = gph.ntau[i];
+            ph.r0(i) = ph.template gcol<COL_R0>(i); ph.r1(i) = ph.template gcol<COL_R1>(i); ph.r2(i) = ph.template gcol<COL_R2>(i);
+            ph.ntau(i) = ph.template gcol<COL_NTAU>(i);
             if constexpr (FULL_HOT) {
-                l_u0[il] = gph.u0[i]; l_u1[il] = gph.u1[i]; l_u2[il] = gph.u2[i];
-                l_idx[il] = gph.idx[i]; l_fl[il] = gph.flags[i];
+                ph.u0(i) = ph.template gcol<COL_U0>(i); ph.u1(i) = ph.template gcol<COL_U1>(i); ph.u2(i) = ph.template gcol<COL_U2>(i);
+                ph.idx(i) = ph.g_idx_at(i); ph.flags(i) = ph.g_flags_at(i);
             }
-        }
-        ph.r0 = l_r0; ph.r1 = l_r1; ph.r2 = l_r2;
-        ph.ntau = l_nt;
-        ph.hot_bias = base;
-        if constexpr (FULL_HOT) {
-            ph.u0 = l_u0; ph.u1 = l_u1; ph.u2 = l_u2; ph.u_bias = base;
-            ph.idx = l_idx; ph.flags = l_fl; ph.if_bias = base;
         }
         __syncthreads();
     }
@@ -1000,15 +988,14 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if (nseg > 0) {
             for (int il = tid; il < n; il += EVENT_BLOCK) {
                 const int i = base + il;
-                const int h = i - ph.hot_bias;
-                if ((ph.flags[i - ph.if_bias] & FLAG_MOVES) && i != skip) {
-                    const double u0 = ph.u0[i - ph.u_bias], u1 = ph.u1[i - ph.u_bias], u2 = ph.u2[i - ph.u_bias];
-                    double r0 = ph.r0[h], r1 = ph.r1[h], r2 = ph.r2[h];
+                if ((ph.flags(i) & FLAG_MOVES) && i != skip) {
+                    const double u0 = ph.u0(i), u1 = ph.u1(i), u2 = ph.u2(i);
+                    double r0 = ph.r0(i), r1 = ph.r1(i), r2 = ph.r2(i);
                     for (int s = 0; s < nseg; ++s) {
                         const double t = st.seg[s];
                         r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
                     }
-                    ph.r0[h] = r0; ph.r1[h] = r1; ph.r2[h] = r2;
+                    ph.r0(i) = r0; ph.r1(i) = r1; ph.r2(i) = r2;
                 }
             }
         }
@@ -1051,7 +1038,6 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             // Philox -> log) in flight hide part of each other's latency; slots that need the slow path go to the LDS queue.
             // Fused form: one slot pair per trip, its re-locations in lockstep right here (relocate_lockstep); only what the hints
             // do not settle is queued.  Same arithmetic per slot as fast_one / slow_one in both.
-            const int hoff = base - ph.hot_bias;
             auto phase1 = [&](auto ns_c, auto fused_c) {
                 constexpr int NS = decltype(ns_c)::value;
                 constexpr bool FUSED = decltype(fused_c)::value;
@@ -1068,18 +1054,17 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                     unsigned fl[NS];
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        const int h = il[k] + hoff;
-                        r0[k] = ph.r0[h]; r1[k] = ph.r1[h]; r2[k] = ph.r2[h];
-                        const int hf = base + il[k] - ph.if_bias;
-                        ntau[k] = ph.ntau[h]; cell[k] = ph.idx[hf]; fl[k] = ph.flags[hf];
+                        const int i = base + il[k];
+                        r0[k] = ph.r0(i); r1[k] = ph.r1(i); r2[k] = ph.r2(i);
+                        ntau[k] = ph.ntau(i); cell[k] = ph.idx(i); fl[k] = ph.flags(i);
                     }
                     if (nseg > 0) {                                  // pending updatePhotonPosition, mclib.c:1067-1095
                         double u0[NS], u1[NS], u2[NS];
                         bool mv[NS];
 #pragma unroll
                         for (int k = 0; k < NS; ++k) {
-                            const int hu = base + il[k] - ph.u_bias;
-                            u0[k] = ph.u0[hu]; u1[k] = ph.u1[hu]; u2[k] = ph.u2[hu];
+                            const int i = base + il[k];
+                            u0[k] = ph.u0(i); u1[k] = ph.u1(i); u2[k] = ph.u2(i);
                             mv[k] = live[k] && (fl[k] & FLAG_MOVES) && (base + il[k] != skip);
                         }
                         for (int sg = 0; sg < nseg; ++sg) {
@@ -1092,7 +1077,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         }
 #pragma unroll
                         for (int k = 0; k < NS; ++k)
-                            if (mv[k]) { const int h = il[k] + hoff; ph.r0[h] = r0[k]; ph.r1[h] = r1[k]; ph.r2[h] = r2[k]; }
+                            if (mv[k]) { const int i = base + il[k]; ph.r0(i) = r0[k]; ph.r1(i) = r1[k]; ph.r2(i) = r2[k]; }
                     }
                     double a0[NS], a1[NS], a2[NS], tf[NS];
                     bool dom[NS], inb[NS];
@@ -1174,7 +1159,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         if (!live[k]) continue;
                         const int i = base + il[k];
                         double t;
-                        if (!(fl[k] & FLAG_VALID)) { ph.tts[i] = INFINITY; continue; }
+                        if (!(fl[k] & FLAG_VALID)) { ph.tts(i) = INFINITY; continue; }
                         if (settled[k]) {                                             // re-located in lockstep above; everything is stored
                             best.offer(tl[k], i);
                             if (tl[k] < t_cut) shortlist_lds(tl[k], i);
@@ -1183,23 +1168,23 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         if (dom[k] && cell[k] != -1) {
                             const int q = qd[k];
                             if (!q && (fl[k] & FLAG_RECALC)) {                        // mclib.c:668, tau of the new momentum is at hand
-                                ph.flags[i - ph.if_bias] = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
-                                ph.tau[i] = ph.tau_next[i];
+                                ph.flags(i) = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                                ph.tau(i) = ph.tau_next(i);
                             }
                             if (q) {
                                 const int e = atomicAdd(&s_qn, 1);                    // < RANK_QCAP: a chunk has no more slots than that
                                 s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0);
                                 s_qb[e] = code[k];
-                                ph.tts[i] = __longlong_as_double((long long)bits[k]);   // the draw, for phase 2 (which stores the free time)
+                                ph.tts(i) = __longlong_as_double((long long)bits[k]);   // the draw, for phase 2 (which stores the free time)
                                 continue;
                             } else {
                                 t = tf[k];
-                                ph.tts[i] = t;
+                                ph.tts(i) = t;
                             }
                         } else {
-                            if (cell[k] != -1) ph.idx[i - ph.if_bias] = -1;           // mclib.c:592
+                            if (cell[k] != -1) ph.idx(i) = -1;                        // mclib.c:592
                             t = 1e12 / C_LIGHT;                                       // mclib.c:620,684
-                            ph.tts[i] = t;
+                            ph.tts(i) = t;
                         }
                         best.offer(t, i);
                         if (t < t_cut) shortlist_lds(t, i);
@@ -1228,7 +1213,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             for (int e = tid; e < qn; e += EVENT_BLOCK) {
                 const int il = s_q[e] & ~Q_RECALC_ONLY;
                 const int i = base + il;
-                const uint64_t qbits = (uint64_t)__double_as_longlong(ph.tts[i]);
+                const uint64_t qbits = (uint64_t)__double_as_longlong(ph.tts(i));
                 const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, qbits, relocated, not_found);
                 best.offer(t, i);
                 if (t < t_cut) shortlist_lds(t, i);
@@ -1305,11 +1290,11 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if constexpr (RESIDENT) {
             for (int il = tid; il < n; il += EVENT_BLOCK) {
                 const int i = base + il;
-                gph.r0[i] = ph.r0[il]; gph.r1[i] = ph.r1[il]; gph.r2[i] = ph.r2[il];
-                gph.ntau[i] = ph.ntau[il];
+                ph.template gcol<COL_R0>(i) = ph.r0(i); ph.template gcol<COL_R1>(i) = ph.r1(i); ph.template gcol<COL_R2>(i) = ph.r2(i);
+                ph.template gcol<COL_NTAU>(i) = ph.ntau(i);
                 if constexpr (FULL_HOT) {
-                    gph.u0[i] = ph.u0[il]; gph.u1[i] = ph.u1[il]; gph.u2[i] = ph.u2[il];
-                    gph.idx[i] = ph.idx[il]; gph.flags[i] = ph.flags[il];
+                    ph.template gcol<COL_U0>(i) = ph.u0(i); ph.template gcol<COL_U1>(i) = ph.u1(i); ph.template gcol<COL_U2>(i) = ph.u2(i);
+                    ph.g_idx_at(i) = ph.idx(i); ph.g_flags_at(i) = ph.flags(i);
                 }
             }
         }
@@ -1358,6 +1343,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
     LoopState *const stamp_state = nullptr;          // (never dereferenced: MC_STAMP is empty)
 #endif
     const int tid = threadIdx.x;
+    const PtrCols pcols(ph);                                          // the accessor the shared device functions take (photon_cols.hpp)
     const int i0 = 2 * (blockIdx.x * FAST_BLOCK + tid);               // a lane takes a pair of photons through the frame (their re-locations in lockstep)
     int first = 0, len = ph.n;
     if (lists.desc) {
@@ -1417,7 +1403,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
                 const double ntau = ph.ntau[i];
                 const Philox4 blk = keyed_block(key.seed, (uint64_t)pass, (uint32_t)i + rng_first, RNG_FAST_FREEPATH, key.stream);
                 bits[k] = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
-                t[k] = fast_one<DIMS, GEOM, false>(ph, hy, i, fl[k], cell[k], r0[k], r1[k], r2[k], ntau, bits[k], queue[k], code[k], a0[k], a1[k], a2[k]);
+                t[k] = fast_one<DIMS, GEOM, false>(pcols, hy, i, fl[k], cell[k], r0[k], r1[k], r2[k], ntau, bits[k], queue[k], code[k], a0[k], a1[k], a2[k]);
                 const bool inside = (cell[k] != -1) && phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);
                 if (pass == 0 && inside && queue[k] != 1) {                 // find_nearest_grid_switch = 1 on a new frame (mcrat.c:756)
                     queue[k] = 1;
@@ -1429,7 +1415,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
                 bool todo[2] = {queue[0] == 1, queue[1] == 1};
                 if (todo[0] || todo[1]) {
                     double tt[2];
-                    relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, true, tt, relocated);
+                    relocate_lockstep<DIMS, GEOM, 2>(pcols, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, true, tt, relocated);
 #pragma unroll
                     for (int k = 0; k < 2; ++k)
                         if (queue[k] == 1 && !todo[k]) { t[k] = tt[k]; queue[k] = 0; cell[k] = ph.idx[slot[k]]; }
@@ -1440,7 +1426,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
                 if (!act[k]) continue;
                 const int i = slot[k];
                 if (queue[k]) {
-                    t[k] = slow_one<DIMS, GEOM>(ph, hy, i, queue[k] == 1, code[k], true, bits[k], relocated, not_found);
+                    t[k] = slow_one<DIMS, GEOM>(pcols, hy, i, queue[k] == 1, code[k], true, bits[k], relocated, not_found);
                     cell[k] = ph.idx[i];
                 }
                 steps += 1;
@@ -1485,7 +1471,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
             double fluid_temp, tau_new;
             if (scatter_core<DIMS, GEOM, STOKES, false>(hy, stamp_state, key, (unsigned long long)pass, (uint32_t)k + rng_first, kc, r, p, pc, s,
                                                         fluid_temp, tau_new)) {
-                commit_scatter<STOKES>(ph, k, p, pc, s, r, tau_new, kf);
+                commit_scatter<STOKES>(pcols, k, p, pc, s, r, tau_new, kf);
                 scatt += 1;
             } else {
                 rej += 1;
@@ -1744,7 +1730,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void sc_resolve_kernel(PhotonDev ph, H
         }
         if (c.gid >= lo && c.gid < hi) {                            // ours
             skip = (int)(c.gid - lo);
-            commit_scatter<STOKES>(ph, skip, p, pc, s, r, tau_new, c.flags);
+            commit_scatter<STOKES>(PtrCols(ph), skip, p, pc, s, r, tau_new, c.flags);
         }
         st->frame_scatt_cnt += 1;                                   // mclib.c:1318
         st->last_scattered_temp = fluid_temp;
@@ -1934,18 +1920,27 @@ static hipError_t dispatch(const KernelConfig &kc, F &&f)
 {
     const int d = kc.dimensions, g = kc.geometry;
     if (d != MCRAT_TU_DIMS) return hipErrorInvalidValue;          // launchers.hip routes by DIMENSIONS
-#if MCRAT_TU_DIMS == 0
-    if (g == GEOM_CARTESIAN) f(ic<DIM_TWO>{}, ic<GEOM_CARTESIAN>{});
-    else if (g == GEOM_CYLINDRICAL) f(ic<DIM_TWO>{}, ic<GEOM_CYLINDRICAL>{});
-    else if (g == GEOM_SPHERICAL) f(ic<DIM_TWO>{}, ic<GEOM_SPHERICAL>{});
-#elif MCRAT_TU_DIMS == 1
-    if (g == GEOM_CARTESIAN) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CARTESIAN>{});
-    else if (g == GEOM_CYLINDRICAL) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CYLINDRICAL>{});
-    else if (g == GEOM_SPHERICAL) f(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_SPHERICAL>{});
+    // (-DMCRAT_DEV_GEOM=<g>: a development build with the kernels of one GEOMETRY only -- a third of the compile time; every other geometry is refused)
+#ifdef MCRAT_DEV_GEOM
+#define MCRAT_GEOM_BUILT(G) ((G) == MCRAT_DEV_GEOM)
 #else
-    if (g == GEOM_CARTESIAN) f(ic<DIM_THREE>{}, ic<GEOM_CARTESIAN>{});
-    else if (g == GEOM_SPHERICAL) f(ic<DIM_THREE>{}, ic<GEOM_SPHERICAL>{});
-    else if (g == GEOM_POLAR) f(ic<DIM_THREE>{}, ic<GEOM_POLAR>{});
+#define MCRAT_GEOM_BUILT(G) true
+#endif
+    auto run = [&](auto D, auto G) { if constexpr (MCRAT_GEOM_BUILT(decltype(G)::value)) f(D, G); };
+    const bool built = MCRAT_GEOM_BUILT(g);
+    if (!built) return hipErrorInvalidValue;
+#if MCRAT_TU_DIMS == 0
+    if (g == GEOM_CARTESIAN) run(ic<DIM_TWO>{}, ic<GEOM_CARTESIAN>{});
+    else if (g == GEOM_CYLINDRICAL) run(ic<DIM_TWO>{}, ic<GEOM_CYLINDRICAL>{});
+    else if (g == GEOM_SPHERICAL) run(ic<DIM_TWO>{}, ic<GEOM_SPHERICAL>{});
+#elif MCRAT_TU_DIMS == 1
+    if (g == GEOM_CARTESIAN) run(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CARTESIAN>{});
+    else if (g == GEOM_CYLINDRICAL) run(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_CYLINDRICAL>{});
+    else if (g == GEOM_SPHERICAL) run(ic<DIM_TWO_POINT_FIVE>{}, ic<GEOM_SPHERICAL>{});
+#else
+    if (g == GEOM_CARTESIAN) run(ic<DIM_THREE>{}, ic<GEOM_CARTESIAN>{});
+    else if (g == GEOM_SPHERICAL) run(ic<DIM_THREE>{}, ic<GEOM_SPHERICAL>{});
+    else if (g == GEOM_POLAR) run(ic<DIM_THREE>{}, ic<GEOM_POLAR>{});
 #endif
     else return hipErrorInvalidValue;
     return hipGetLastError();

@@ -17,6 +17,41 @@ namespace phys {
 
 constexpr int REJECTION_CAP = 1 << 22;   // every rejection loop is bounded so that a wave always finishes
 
+// ---------------------------------------------------------------- reciprocal and inverse square root
+// The loop's arithmetic is a chain of dependent f64 operations on a wave that has one or two neighbours on its SIMD, so what a
+// re-location or a scattering costs is the LENGTH of that chain.  An IEEE division is v_div_scale + v_rcp + five FMAs + v_div_fmas +
+// v_div_fixup (eleven dependent instructions), a square root fourteen; the hardware's v_rcp_f64 / v_rsq_f64 with two Newton steps
+// give 1/x and 1/sqrt(x) to one or two ulp in five and seven.  Round 3 writes the loop's divisions and roots with these wherever the
+// result only feeds further arithmetic (never where it decides a cell or is compared on a face: hydro_coords keeps the IEEE sqrt),
+// and folds the divisions the reference repeats (p/|p| thrice in zeroNorm, six by beta^2 in lorentzBoost) into one reciprocal.
+// The values are the reference's real numbers rounded differently in the last place or two; the gates are the oracle's
+// (integers exact, doubles 1e-9 over trajectories, tests/).
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r0, 1.0);
+    double r = fma(r0, e, r0);
+    e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    return (fabs(r0) < INFINITY && r0 != 0.0) ? r : r0;     // 1/0, 1/inf, NaN: the hardware's answer (+-inf, +-0, NaN)
+}
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    double e = fma(-(h * y0), y0, 0.5);
+    double y = fma(y0, e, y0);
+    e = fma(-(h * y), y, 0.5);
+    y = fma(y, e, y);
+    return (y0 < INFINITY && y0 > 0.0) ? y : y0;             // x = 0 -> inf, x = inf -> 0, x < 0 or NaN -> NaN
+}
+// sqrt(x) for x >= 0 as x * rsqrt(x) (0 for x == 0; NaN for negative x, like sqrt)
+__device__ __forceinline__ double sqrt_nr(double x)
+{
+    const double y = x * rsqrt_nr(x);
+    return (x == 0.0) ? 0.0 : y;
+}
+
 // ---------------------------------------------------------------- geometry
 // geometry.c:15-64
 template <int DIMS, int GEOM>
@@ -188,11 +223,29 @@ __device__ __forceinline__ void beta_from_record(double a, double b, double c, d
 // photons through these functions in lockstep -- relocate_lockstep, kernels.hip -- gets one straight-line block to interleave)
 __device__ __forceinline__ void cos_sin_of_atan2(double y, double x, double &c, double &s)
 {
-    const double h = sqrt(x * x + y * y);
-    const double ch = x / h, sh = y / h;
+    const double h2 = x * x + y * y;
+    const double ih = rsqrt_nr(h2);
+    const bool pos = h2 > 0;
+    c = pos ? x * ih : ((x < 0 || (x == 0 && signbit(x))) ? -1.0 : 1.0);
+    s = pos ? y * ih : 0.0;
+}
+// the same from a hypotenuse the caller already has (2-D cylindrical / Cartesian: hydro_coords' sqrt(x^2 + y^2) is the photon's azimuth radius)
+__device__ __forceinline__ void cos_sin_with_hypot(double y, double x, double h, double &c, double &s)
+{
+    const double ih = rcp_nr(h);
     const bool pos = h > 0;
-    c = pos ? ch : ((x < 0 || (x == 0 && signbit(x))) ? -1.0 : 1.0);
-    s = pos ? sh : 0.0;
+    c = pos ? x * ih : ((x < 0 || (x == 0 && signbit(x))) ? -1.0 : 1.0);
+    s = pos ? y * ih : 0.0;
+}
+
+// the photon's azimuth at a re-location (mclib.c:549-552), given its hydro coordinates: where the first of them IS the azimuth radius
+// (2-D / 2.5-D cylindrical and Cartesian: geometry.c:21-24) one reciprocal of it serves, else the reciprocal root of x^2 + y^2.
+// (One function for every kernel that re-locates, so that they all produce the same bits.)
+template <int DIMS, int GEOM>
+__device__ __forceinline__ void relocation_azimuth(double x, double y, double a0, double &c, double &s)
+{
+    if constexpr (DIMS != DIM_THREE && GEOM != GEOM_SPHERICAL) cos_sin_with_hypot(y, x, a0, c, s);
+    else cos_sin_of_atan2(y, x, c, s);
 }
 
 // geometry.c:189-253: fluid velocity of a cell (hydro basis) -> Cartesian, for a photon at azimuth
@@ -202,12 +255,9 @@ __device__ __forceinline__ void cos_sin_of_atan2(double y, double x, double &c, 
 // (a = v0, b = v1 in CARTESIAN/CYLINDRICAL; a = v0 sin(th)+v1 cos(th), b = v0 cos(th)-v1 sin(th) in SPHERICAL;
 // c = v2 in 2.5-D, absent in 2-D) and 3-D runs store the Cartesian vector itself.
 template <int DIMS>
-__device__ __forceinline__ void cell_beta(const HydroDev &h, int cell, double cphi, double sphi, double out[3])
+__device__ __forceinline__ void cell_beta(const CellFluid &f, double cphi, double sphi, double out[3])
 {
-    const CellFluid f = h.fluid[cell];
-    double c = 0.0;
-    if constexpr (DIMS != DIM_TWO) c = h.fluid_c[cell];
-    beta_from_record<DIMS>(f.a, f.b, c, cphi, sphi, out);
+    beta_from_record<DIMS>(f.a, f.b, f.c, cphi, sphi, out);
 }
 
 // ---------------------------------------------------------------- boosts
@@ -248,19 +298,40 @@ __device__ __forceinline__ void lorentz_boost(const double b[3], const double p[
     out[0] = r[0]; out[1] = r[1]; out[2] = r[2]; out[3] = r[3];
 }
 
-// ---------------------------------------------------------------- optical depth
-// optical_depth.c:7-59 (TAU_CALCULATION == DIRECT): tau' = n_lab sigma_T (1 - beta cos(angle to the flow)) [1/cm]
-// beta_g = sqrt(1 - 1/gamma^2) (:52) and n_dens = dens_lab / M_P (:57) depend on the cell alone and come staged (CellFluid).
-__device__ __forceinline__ double optical_depth_direct(const double fluid_beta[3], double beta_g, double n_dens,
-                                                       double p1, double p2, double p3, double norm_cross_section = 1.0)
+// lorentzBoost + zeroNorm (mclib.c:302-434) in the form the loop uses.  The boost matrix of mclib.c:318-340 is
+//   L00 = g, L0i = -g b_i, Lij = delta_ij + (g - 1) b_i b_j / b^2,
+// so  p'_0 = g (p_0 - b.p)  and  p'_i = p_i + (kf (b.p) - g p_0) b_i  with kf = (g - 1)/b^2 = g^2/(g + 1): one dot product and four
+// multiply-adds once g and kf are known -- per cell for the fluid frame (CellFluid::gam, ::kf), from the electron's energy for the
+// electron frame -- instead of a square root and eight divisions per call.  b = 0 needs no special case (g = 1, kf = 1/2).
+// zeroNorm rescales the spatial part to the time component with ONE reciprocal root (the reference divides thrice and skips the
+// rescaling when the norm already matches: the same vector to an ulp).
+__device__ __forceinline__ void zero_norm_lean(double p[4])
 {
-    const double fl_v_norm = sqrt(fluid_beta[0] * fluid_beta[0] + fluid_beta[1] * fluid_beta[1] + fluid_beta[2] * fluid_beta[2]);
-    const double ph_v_norm = sqrt(p1 * p1 + p2 * p2 + p3 * p3);
-    const double n_cosangle = ((fluid_beta[0] * p1) + (fluid_beta[1] * p2) + (fluid_beta[2] * p3)) / (fl_v_norm * ph_v_norm);
-    const double fluid_factor = (1.0 - beta_g * n_cosangle);
-    return (n_dens) * (THOM_X_SECT * norm_cross_section) * fluid_factor;
+    const double s = p[0] * rsqrt_nr((p[1] * p[1] + p[2] * p[2]) + p[3] * p[3]);
+    p[1] *= s; p[2] *= s; p[3] *= s;
+}
+template <bool PHOTON>
+__device__ __forceinline__ void boost_with(const double b[3], double g, double kf, const double p[4], double out[4])
+{
+    const double bp = (b[0] * p[1] + b[1] * p[2]) + b[2] * p[3];
+    const double f = kf * bp - g * p[0];
+    out[0] = g * (p[0] - bp);
+    out[1] = p[1] + f * b[0];
+    out[2] = p[2] + f * b[1];
+    out[3] = p[3] + f * b[2];
+    if constexpr (PHOTON) zero_norm_lean(out);
 }
 
+// calculateOpticalDepth, optical_depth.c:7-59, on the staged operands (CellFluid):  tau' = nsig * sigma_hat * (1 - w (v.p)/|p|)  [1/cm]
+__device__ __forceinline__ double optical_depth_staged(const double fluid_beta[3], double w, double nsig, double p1, double p2, double p3,
+                                                       double norm_cross_section = 1.0)
+{
+    const double bp = (fluid_beta[0] * p1 + fluid_beta[1] * p2) + fluid_beta[2] * p3;
+    const double ipn = rsqrt_nr((p1 * p1 + p2 * p2) + p3 * p3);
+    return (nsig * norm_cross_section) * (1.0 - w * (bp * ipn));
+}
+
+// ---------------------------------------------------------------- optical depth (optical_depth_staged above)
 
 // getCrossSection / getThermalCrossSection, optical_depth.c:117-149: 1 in DIRECT; in TABLE
 // 10^interp(log10(h nu'/m_e c^2), log10(kT/m_e c^2)) with GSL's bilinear interp2d scheme on the uniform grid of
@@ -309,12 +380,12 @@ __device__ __forceinline__ void find_xy(const double v[3], const double ref[3], 
     y[0] = (v[1] * ref[2] - v[2] * ref[1]);
     y[1] = -1 * (v[0] * ref[2] - v[2] * ref[0]);
     y[2] = (v[0] * ref[1] - v[1] * ref[0]);
-    double norm = 1.0 / sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    double norm = rsqrt_nr(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
     y[0] *= norm; y[1] *= norm; y[2] *= norm;
     x[0] = y[1] * v[2] - y[2] * v[1];
     x[1] = -1 * (y[0] * v[2] - y[2] * v[0]);
     x[2] = y[0] * v[1] - y[1] * v[0];
-    norm = 1.0 / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    norm = rsqrt_nr(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
     x[0] *= norm; x[1] *= norm; x[2] *= norm;
 }
 
@@ -352,9 +423,11 @@ __device__ __forceinline__ void stokes_rotation(const double v[3], const double 
 // mcrat_scattering.c:597-623
 __device__ __forceinline__ double kn_cross_section(double e)
 {
-    if (e >= 1e-3)
-        return (3. / 4.) * (2. / (e * e) + (1. / (2. * e) - (1. + e) / (e * e * e)) * log(1. + 2. * e)
-                            + (1. + e) / ((1. + 2. * e) * (1. + 2. * e)));
+    if (e >= 1e-3) {
+        // (3/4) (2/e^2 + (1/(2e) - (1+e)/e^3) log(1+2e) + (1+e)/(1+2e)^2): the reference's terms, its five divisions as two reciprocals
+        const double ie = rcp_nr(e), ie2 = ie * ie, i12 = rcp_nr(1. + 2. * e);
+        return (3. / 4.) * (2. * ie2 + (0.5 * ie - (1. + e) * (ie2 * ie)) * log(1. + 2. * e) + (1. + e) * (i12 * i12));
+    }
     return (1. - 2. * e);
 }
 
@@ -363,7 +436,7 @@ template <bool STOKES>
 __device__ __forceinline__ bool kn_scatter(double &cos_theta, double &cos_phi, double &sin_phi, double p0, double q, double u,
                                            EventStream &rng)
 {
-    const double energy_ratio = p0 / (M_EL * C_LIGHT);
+    const double energy_ratio = p0 * (1.0 / (M_EL * C_LIGHT));
     const double kn = kn_cross_section(energy_ratio);
     const double rand_num = rng.uniform();
     if (!(rand_num <= kn)) return false;
@@ -372,8 +445,8 @@ __device__ __forceinline__ bool kn_scatter(double &cos_theta, double &cos_phi, d
     for (int it = 0; it < REJECTION_CAP && (y_cos > f_cos); ++it) {
         y_cos = rng.uniform() * 2;
         cos_theta_dum = rng.uniform() * 2 - 1;
-        const double a = (1 + energy_ratio * (1 - cos_theta_dum));
-        f_cos = (1.0 / (a * a)) * (energy_ratio * (1 - cos_theta_dum) + (1 / a) + cos_theta_dum * cos_theta_dum);
+        const double ia = rcp_nr(1 + energy_ratio * (1 - cos_theta_dum));
+        f_cos = (ia * ia) * (energy_ratio * (1 - cos_theta_dum) + ia + cos_theta_dum * cos_theta_dum);
     }
     cos_theta = cos_theta_dum;
     double phi_dum = 0;
@@ -382,20 +455,20 @@ __device__ __forceinline__ bool kn_scatter(double &cos_theta, double &cos_phi, d
     if (uniform_phi) {
         phi_dum = rng.uniform() * 2 * M_PI;
     } else {
-        const double mu = 1 + energy_ratio * (1 - cos_theta_dum);
+        const double imu = rcp_nr(1 + energy_ratio * (1 - cos_theta_dum));
         const double st = sqrt(1 - cos_theta_dum * cos_theta_dum);
-        const double f_theta = (1.0 / mu + 1.0 / (mu * mu * mu) - (1.0 / (mu * mu)) * st * st) * st;
+        const double f_theta = (imu + imu * imu * imu - (imu * imu) * st * st) * st;
         // phi_max = |atan2(-u, q)| / 2  ->  cos(2 phi_max) = q / h, sin(2 phi_max) = |u| / h
-        const double h = sqrt(q * q + u * u);
-        const double pol = (1.0 / (mu * mu)) * st * st * st;
-        const double norm = (f_theta + pol * (q * (q / h) - u * (fabs(u) / h)));
+        const double ih = rsqrt_nr(q * q + u * u);
+        const double pol = (imu * imu) * st * st * st;
+        const double inorm = rcp_nr(f_theta + pol * (q * (q * ih) - u * (fabs(u) * ih)));
         double y_phi = 1, f_phi = 0;
         for (int it = 0; it < REJECTION_CAP && (y_phi > f_phi); ++it) {
             y_phi = rng.uniform();
             phi_dum = rng.uniform() * 2 * M_PI;
             double s2, c2;
             sincos(2 * phi_dum, &s2, &c2);
-            f_phi = (f_theta + pol * (q * c2 - u * s2)) / norm;
+            f_phi = (f_theta + pol * (q * c2 - u * s2)) * inorm;
         }
     }
     sincos(phi_dum, &sin_phi, &cos_phi);
@@ -495,13 +568,13 @@ __device__ __forceinline__ double sample_thermal_electron(double temp, double k2
                 base += 0x9E3779B97F4A7C15ull * (uint64_t)(2 * used);
             }
             rng.state = base;
-            g1 = v0 / C_LIGHT; g2 = v1 / C_LIGHT; g3 = v2 / C_LIGHT;
+            g1 = v0 * (1.0 / C_LIGHT); g2 = v1 * (1.0 / C_LIGHT); g3 = v2 * (1.0 / C_LIGHT);
         } else {
-            g1 = gaussian(rng, factor) / C_LIGHT;
-            g2 = gaussian(rng, factor) / C_LIGHT;
-            g3 = gaussian(rng, factor) / C_LIGHT;
+            g1 = gaussian(rng, factor) * (1.0 / C_LIGHT);
+            g2 = gaussian(rng, factor) * (1.0 / C_LIGHT);
+            g3 = gaussian(rng, factor) * (1.0 / C_LIGHT);
         }
-        gamma = 1.0 / sqrt(1 - ((g1 * g1 + g2 * g2) + g3 * g3));
+        gamma = rsqrt_nr(1 - ((g1 * g1 + g2 * g2) + g3 * g3));
     }
     return gamma;
 }
@@ -511,11 +584,12 @@ template <bool WAVE = false>
 __device__ __forceinline__ void single_thermal_electron(double el_p[4], double temp, double k2e, const double ph_p[4], EventStream &rng)
 {
     const double gamma = sample_thermal_electron<WAVE>(temp, k2e, rng);
-    const double beta = sqrt(1 - (1 / (gamma * gamma)));
+    const double ig = rcp_nr(gamma);
+    const double beta = sqrt_nr(1 - ig * ig);
     const double phi = rng.uniform() * 2 * M_PI;
     // theta = acos(ct): only cos(theta) = ct and sin(theta) = sqrt(1 - ct^2) are used
-    const double ct_e = (1 - sqrt(1 + beta * beta + 2 * beta - 4 * beta * rng.uniform())) / beta;
-    const double st_e = sqrt(1 - ct_e * ct_e);
+    const double ct_e = (1 - sqrt_nr(1 + beta * beta + 2 * beta - 4 * beta * rng.uniform())) * rcp_nr(beta);
+    const double st_e = sqrt_nr(1 - ct_e * ct_e);
     double sphi, cphi;
     sincos(phi, &sphi, &cphi);
     const double mc = gamma * (M_EL) * (C_LIGHT);
@@ -524,20 +598,24 @@ __device__ __forceinline__ void single_thermal_electron(double el_p[4], double t
     const double e2 = mc * beta * st_e * sphi;
     const double e3 = mc * beta * st_e * cphi;
 
-    // ph_phi = atan2(p2, p3), ph_theta = atan2(sqrt(p2^2 + p3^2), p1)
-    const double rho = sqrt(ph_p[2] * ph_p[2] + ph_p[3] * ph_p[3]);
-    double ct, sth, cp, spp;
-    cos_sin_of_atan2(rho, ph_p[1], ct, sth);
-    cos_sin_of_atan2(ph_p[2], ph_p[3], cp, spp);
+    // ph_phi = atan2(p2, p3), ph_theta = atan2(sqrt(p2^2 + p3^2), p1): with rho^2 = p2^2 + p3^2 and n^2 = rho^2 + p1^2,
+    // cos/sin(ph_theta) = p1/n, rho/n and cos/sin(ph_phi) = p3/rho, p2/rho -- two reciprocal roots for the two angles
+    const double rho2 = ph_p[2] * ph_p[2] + ph_p[3] * ph_p[3];
+    const double irho = rsqrt_nr(rho2), in = rsqrt_nr(rho2 + ph_p[1] * ph_p[1]);
+    const bool off_axis = rho2 > 0;
+    const double ct = off_axis ? ph_p[1] * in : ((ph_p[1] < 0 || (ph_p[1] == 0 && signbit(ph_p[1]))) ? -1.0 : 1.0);
+    const double sth = off_axis ? (rho2 * irho) * in : 0.0;
+    const double cp = off_axis ? ph_p[3] * irho : (signbit(ph_p[3]) ? -1.0 : 1.0);
+    const double spp = off_axis ? ph_p[2] * irho : 0.0;
     const double sp = -spp;                       // sin(-ph_phi); cos(-ph_phi) = cp
     // R_y: rows (ct, 0, -st), (0,1,0), (st, 0, ct)
-    const double w0 = (e1 * ct + e2 * 0.0) + e3 * (-sth);
+    const double w0 = e1 * ct + e3 * (-sth);
     const double w1 = e2;
-    const double w2 = (e1 * sth + e2 * 0.0) + e3 * ct;
+    const double w2 = e1 * sth + e3 * ct;
     // R_x(-phi): rows (1,0,0), (0, cos(-phi), -sin(-phi)), (0, sin(-phi), cos(-phi))
     el_p[1] = w0;
-    el_p[2] = (w0 * 0.0 + w1 * cp) + w2 * (-sp);
-    el_p[3] = (w0 * 0.0 + w1 * sp) + w2 * cp;
+    el_p[2] = w1 * cp + w2 * (-sp);
+    el_p[3] = w1 * sp + w2 * cp;
 }
 
 // ---------------------------------------------------------------- the scattering itself
@@ -546,9 +624,14 @@ template <bool STOKES>
 __device__ __forceinline__ bool single_scatter(const double el_comov[4], double ph_comov[4], double s[4], EventStream &rng)
 {
     const double z_axis[3] = {0, 0, 1};
-    double el_v[3] = {el_comov[1] / el_comov[0], el_comov[2] / el_comov[0], el_comov[3] / el_comov[0]};
+    const double ie0 = rcp_nr(el_comov[0]);
+    const double el_v[3] = {el_comov[1] * ie0, el_comov[2] * ie0, el_comov[3] * ie0};
+    // the electron's Lorentz factor from its energy (el_comov[0] = gamma m_e c, electron.c:86) rather than from 1/sqrt(1 - v^2) of the
+    // quotient above (mclib.c:316): the same number without the cancellation
+    const double g_e = el_comov[0] * (1.0 / (M_EL * C_LIGHT));
+    const double kf_e = (g_e * g_e) * rcp_nr(g_e + 1.0);
     double ph_pr[4];
-    lorentz_boost(el_v, ph_comov, ph_pr, true);                                   // :218
+    boost_with<true>(el_v, g_e, kf_e, ph_comov, ph_pr);                           // :218
     if constexpr (STOKES) stokes_rotation(el_v, ph_comov + 1, ph_pr + 1, s);      // :225
     const double ph_orig[4] = {ph_pr[0], ph_pr[1], ph_pr[2], ph_pr[3]};
 
@@ -557,8 +640,8 @@ __device__ __forceinline__ bool single_scatter(const double el_comov[4], double 
     cos_sin_of_atan2(ph_pr[2], ph_pr[1], c0, sp0);
     const double s0 = -sp0;
     // rot0 rows (c0, -s0, 0), (s0, c0, 0), (0,0,1)
-    const double r00 = (ph_pr[1] * c0 + ph_pr[2] * (-s0)) + ph_pr[3] * 0.0;
-    const double r02 = (ph_pr[1] * 0.0 + ph_pr[2] * 0.0) + ph_pr[3] * 1.0;
+    const double r00 = ph_pr[1] * c0 + ph_pr[2] * (-s0);
+    const double r02 = ph_pr[3];
     // phi1 = atan2(r02, r00) (:269): c1 = cos(-phi1), s1 = sin(-phi1)
     double c1, sp1;
     cos_sin_of_atan2(r02, r00, c1, sp1);
@@ -568,23 +651,23 @@ __device__ __forceinline__ bool single_scatter(const double el_comov[4], double 
     double ct = 0, cphi = 1, sphi = 0;
     const bool occurred = kn_scatter<STOKES>(ct, cphi, sphi, ph_pr[0], s[1], s[2], rng);   // :307
     if (!occurred) return false;
-    const double sth = sqrt(1 - ct * ct);
+    const double sth = sqrt_nr(1 - ct * ct);
 
     double result[4];
-    result[0] = ph_pr[0] / (1 + ((ph_pr[0] * (1 - ct)) / (M_EL * C_LIGHT)));     // :322
+    result[0] = ph_pr[0] * rcp_nr(1 + ((ph_pr[0] * (1 - ct)) * (1.0 / (M_EL * C_LIGHT))));     // :322
     result[1] = result[0] * ct;
     result[2] = result[0] * sth * sphi;
     result[3] = result[0] * sth * cphi;
 
     // undo rot1: rows (c1, 0, s1), (0,1,0), (-s1, 0, c1)                                :360-366
-    const double u0 = (result[1] * c1 + result[2] * 0.0) + result[3] * s1;
-    const double u1 = (result[1] * 0.0 + result[2] * 1.0) + result[3] * 0.0;
-    const double u2 = (result[1] * (-s1) + result[2] * 0.0) + result[3] * c1;
+    const double u0 = result[1] * c1 + result[3] * s1;
+    const double u1 = result[2];
+    const double u2 = result[1] * (-s1) + result[3] * c1;
     // undo rot0: rows (c0, s0, 0), (-s0, c0, 0), (0,0,1)                                :380-386
     double res0[3];
-    res0[0] = (u0 * c0 + u1 * s0) + u2 * 0.0;
-    res0[1] = (u0 * (-s0) + u1 * c0) + u2 * 0.0;
-    res0[2] = (u0 * 0.0 + u1 * 0.0) + u2 * 1.0;
+    res0[0] = u0 * c0 + u1 * s0;
+    res0[1] = u0 * (-s0) + u1 * c0;
+    res0[2] = u2;
 
     if constexpr (STOKES) {
         double xt[3], yt[3], xn[3], yn[3];
@@ -592,28 +675,31 @@ __device__ __forceinline__ bool single_scatter(const double el_comov[4], double 
         find_xy(res0, ph_orig + 1, xn, yn);                                       // :403
         rotate_stokes_between(xt, yt, yn, s);                                     // :404-405
         // theta between incoming and scattered photon (:408): only its cosine and sine are used
-        const double cth = ((ph_orig[1] * res0[0] + ph_orig[2] * res0[1]) + ph_orig[3] * res0[2]) / (ph_orig[0] * result[0]);
+        const double cth = ((ph_orig[1] * res0[0] + ph_orig[2] * res0[1]) + ph_orig[3] * res0[2]) * rcp_nr(ph_orig[0] * result[0]);
         const double sn2 = 1 - cth * cth;                                         // sin^2
         // Fano's matrix :411-416
-        const double t00 = 1.0 + cth * cth + ((1 - cth) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
+        const double de = (ph_orig[0] - result[0]) * (1.0 / (M_EL * C_LIGHT));
+        const double t00 = 1.0 + cth * cth + ((1 - cth) * de);
         const double t01 = sn2;
         const double t11 = 1.0 + cth * cth;
         const double t22 = 2.0 * cth;
-        const double t33 = 2.0 * cth + ((cth) * (1 - cth) * (ph_orig[0] - result[0]) / (M_EL * C_LIGHT));
-        const double o0 = ((s[0] * t00 + s[1] * t01) + s[2] * 0.0) + s[3] * 0.0;
-        const double o1 = ((s[0] * t01 + s[1] * t11) + s[2] * 0.0) + s[3] * 0.0;
-        const double o2 = ((s[0] * 0.0 + s[1] * 0.0) + s[2] * t22) + s[3] * 0.0;
-        const double o3 = ((s[0] * 0.0 + s[1] * 0.0) + s[2] * 0.0) + s[3] * t33;
-        s[0] = o0 / o0; s[1] = o1 / o0; s[2] = o2 / o0; s[3] = o3 / o0;          // :430-433
+        const double t33 = 2.0 * cth + ((cth) * (1 - cth) * de);
+        const double o0 = s[0] * t00 + s[1] * t01;
+        const double o1 = s[0] * t01 + s[1] * t11;
+        const double o2 = s[2] * t22;
+        const double o3 = s[3] * t33;
+        const double io0 = rcp_nr(o0);
+        s[0] = (fabs(io0) < INFINITY && io0 != 0.0) ? 1.0 : __builtin_nan("");   // o0 / o0
+        s[1] = o1 * io0; s[2] = o2 * io0; s[3] = o3 * io0;                        // :430-433
         find_xy(res0, ph_orig + 1, xt, yt);                                       // :438
         find_xy(res0, z_axis, xn, yn);                                            // :441
         rotate_stokes_between(xt, yt, yn, s);                                     // :444-447
     }
 
     double ph_out[4] = {result[0], res0[0], res0[1], res0[2]};                    // :452-454
-    const double neg_el_v[3] = {-1 * el_v[0], -1 * el_v[1], -1 * el_v[2]};
+    const double neg_el_v[3] = {-el_v[0], -el_v[1], -el_v[2]};
     double back[4];
-    lorentz_boost(neg_el_v, ph_out, back, true);                                  // :465
+    boost_with<true>(neg_el_v, g_e, kf_e, ph_out, back);                          // :465
     if constexpr (STOKES) stokes_rotation(neg_el_v, ph_out + 1, back + 1, s);     // :473
     ph_comov[0] = back[0]; ph_comov[1] = back[1]; ph_comov[2] = back[2]; ph_comov[3] = back[3];
     return true;
