@@ -111,14 +111,19 @@ inline void cell_staged_operands(double a, double b, double c, double gamma_cell
 // bucket-list entry: the cell index with copies of everything the slow path needs from that cell, so that a
 // re-location costs two dependent load rounds (list range, then one entry: exactly one 128-B line) instead of five
 // (alignas(32), not 128: a local copy must not ask for an over-aligned stack slot; the array itself starts on a 256-B boundary)
+// Member order: a lane reads its entry in 16-B pieces, and what a re-location costs the CU's vector cache is the NUMBER of pieces (about one
+// lane-piece per clock when every lane is on a line of its own, tools/gather_bench.hip) -- so what a 2-D re-location needs comes first, in
+// five pieces {c0,c1} {s0,s1} {a,b} {w,nsig} {gam,cell}; kf = gam^2/(gam + 1) is recomputed (one reciprocal) instead of read; 2.5-D adds
+// {c,.}, 3-D {c,c2} {s2,.}.
 struct alignas(32) FatCell {
     double c0, c1, s0, s1;       // CellGeom
-    double a, b, c, w;           // CellFluid
-    double nsig, gam, kf;
-    double c2, s2;               // CellGeom2 (3-D)
+    double a, b, w, nsig;        // CellFluid
+    double gam;
     int cell;
     int pad;
-    double pad2[2];
+    double c;                    // CellFluid (2.5-D, 3-D)
+    double c2, s2;               // CellGeom2 (3-D)
+    double pad2[3];
 };
 static_assert(sizeof(FatCell) == 128, "one cache line per bucket-list entry");
 

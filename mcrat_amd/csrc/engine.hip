@@ -88,6 +88,7 @@ struct mcrat_hip_ctx {
     int n_ranks = 0;
     int rank_block = 256;             // threads per list of the next launches (choose_rank_block)
     bool rank_fuse = true;            // ... and whether they use the build with the fused pass
+    bool rank_pipe = false;           // ... or rank_pipe_kernel (the passes pipelined; lists of up to 1024 slots, DIRECT optical depths)
     bool rank_block_fixed = false;
     double rank_passes_per_list = 0;  // of the last completed frame
     LoopState *d_rstates = nullptr;
@@ -781,9 +782,9 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
             FatCell &f = fat[e];
             f.c0 = geom[ci].c0; f.c1 = geom[ci].c1; f.s0 = geom[ci].s0; f.s1 = geom[ci].s1;
             f.a = fluid[ci].a; f.b = fluid[ci].b; f.c = fluid[ci].c; f.w = fluid[ci].w;
-            f.nsig = fluid[ci].nsig; f.gam = fluid[ci].gam; f.kf = fluid[ci].kf;
+            f.nsig = fluid[ci].nsig; f.gam = fluid[ci].gam;
             f.c2 = three ? h->r2[ci] : 0.0; f.s2 = three ? h->r2_size[ci] : 0.0;
-            f.cell = ci; f.pad = 0; f.pad2[0] = f.pad2[1] = 0.0;
+            f.cell = ci; f.pad = 0; f.pad2[0] = f.pad2[1] = f.pad2[2] = 0.0;
         }
         HIPCHK(c, hipMemcpy(gbase, gh.data(), o_start, hipMemcpyHostToDevice));
     } else {
@@ -2307,12 +2308,22 @@ static int ensure_events(mcrat_hip_ctx *c, size_t n);
 // are too long to keep in LDS, or the frames are optically thin: a thin frame is a dozen passes in which half the photons
 // change cell, i.e. slow-path throughput per list, and there 256 threads per list do better.  The engine cannot know the
 // optical depth before it has run a frame; it looks at the previous one (passes per list).
+// rank_pipe_kernel (kernels.hip; builds with -DMCRAT_RANK_PIPE=1 only -- it measured slower): the event's completion and the next pass
+// overlap.  256-thread lists only; launch_rank_loop falls back to rank_loop_kernel for lists it cannot hold (longer than 1024 slots,
+// TAU_CALCULATION == TABLE) and in builds without it.  MCRAT_HIP_RANK_PIPE=1 asks for it.
+static void choose_rank_pipe(mcrat_hip_ctx *c)
+{
+    c->rank_pipe = false;
+    if (const char *e = getenv("MCRAT_HIP_RANK_PIPE")) c->rank_pipe = atoi(e) != 0 && c->rank_block == 256;
+}
+
 static void choose_rank_block(mcrat_hip_ctx *c)
 {
     if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) {
         c->rank_block = (atoi(e) == 128) ? 128 : 256;
         c->rank_fuse = c->rank_passes_per_list < 48.0;
         if (const char *f = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = atoi(f) != 0;
+        choose_rank_pipe(c);
         return;
     }
     int cus = 256, dev = 0;
@@ -2329,6 +2340,7 @@ static void choose_rank_block(mcrat_hip_ctx *c)
     // benchmark frames run 2 % faster without it -- cfg3 at 1e7 photons 8.62 -> 8.43 ms; the cylindrical Stokes frame 1.07 -> 0.94 ms with it)
     c->rank_fuse = c->rank_passes_per_list < 48.0 && c->kc.geometry != GEOM_SPHERICAL;
     if (const char *e = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = atoi(e) != 0;
+    choose_rank_pipe(c);
 }
 
 // rank pool: what the kernel needs to know about every list, from its view
@@ -2362,7 +2374,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
         HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, nullptr, nullptr, batch,
-                                   c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
+                                   c->rank_block + (c->rank_fuse ? 1000 : 0) + (c->rank_pipe ? 2000 : 0), c->stream));
         if (c->cfg.profile) {
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
             HIPCHK(c, hipEventSynchronize(c->ev[1]));

@@ -183,10 +183,10 @@ __global__ __launch_bounds__(256) void grid_records_kernel(int naxes, long long 
     FatCell fc;
     fc.c0 = g.c0; fc.c1 = g.c1; fc.s0 = g.s0; fc.s1 = g.s1;
     fc.a = f.a; fc.b = f.b; fc.c = f.c; fc.w = f.w;
-    fc.nsig = f.nsig; fc.gam = f.gam; fc.kf = f.kf;
+    fc.nsig = f.nsig; fc.gam = f.gam;
     fc.c2 = 0; fc.s2 = 0;
     if (naxes == 3) { const CellGeom2 g2 = geom2[ci]; fc.c2 = g2.c2; fc.s2 = g2.s2; }
-    fc.cell = ci; fc.pad = 0; fc.pad2[0] = fc.pad2[1] = 0.0;
+    fc.cell = ci; fc.pad = 0; fc.pad2[0] = fc.pad2[1] = fc.pad2[2] = 0.0;
     cells[e] = fc;
 }
 

@@ -262,7 +262,10 @@ __device__ __forceinline__ double fast_one(const PH &ph, const HydroDev &hy, int
 // rounds: {photon columns, bucket range} then {bucket entries | the cell's fluid record}.
 // `bits` is the slot's free-path draw of this pass: phase 1 has computed the pair's Philox block anyway (one block serves two
 // slots) and hands the 64 bits over -- for queued slots through the slot's time_to_scatter entry, which this function overwrites.
-template <int DIMS, int GEOM, class PH>
+// (LOGS: `bits` is not the draw but the bit pattern of log(u) of the draw -- rank_pipe_kernel computes the logarithms of a pass ahead of time)
+__device__ __forceinline__ double free_time_from_log(double ntau, double log_u) { return div_by_c(ntau * log_u); }   // = sample_free_time, its log at hand
+
+template <int DIMS, int GEOM, bool LOGS = false, class PH>
 __device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int i, bool relocate, int bucket, bool count_it,
                                            uint64_t bits, int &relocated, int &not_found)
 {
@@ -282,7 +285,7 @@ __device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int
         cell = phys::find_in_bucket<DIMS>(hy.grid, bucket, a0, a1, a2, hit);     // mclib.c:534
         ph.idx(i) = cell;                                                        // mclib.c:536
         if (cell != -1) {
-            fa = hit.a; fb = hit.b; fc = hit.c; fw = hit.w; fnsig = hit.nsig; fgam = hit.gam; fkf = hit.kf;
+            fa = hit.a; fb = hit.b; fc = hit.c; fw = hit.w; fnsig = hit.nsig; fgam = hit.gam; fkf = phys::kf_of_gamma(hit.gam);
             new_cell = true;
             need_tau = true;                                                     // mclib.c:570
             if (count_it) relocated += 1;                                        // mclib.c:579,608-611
@@ -327,7 +330,7 @@ __device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int
         } else {
             ntau = ph.ntau(i);
         }
-        t = sample_free_time(ntau, bits);
+        t = LOGS ? free_time_from_log(ntau, __longlong_as_double((long long)bits)) : sample_free_time(ntau, bits);
     } else {
         t = 1e12 / C_LIGHT;
     }
@@ -344,11 +347,21 @@ __device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int
 // Takes a slot only when the bucket's hint settles it (one 96-B entry, the cell provably the only one that holds the point:
 // find_in_bucket); todo[k] stays set for the others -- list walks, points outside every cell -- and the caller falls back to slow_one.
 // (DIRECT optical depths only: the TABLE build keeps slow_one.)
-template <int DIMS, int GEOM, int K, class PH>
+// `probe` (rank_pipe_kernel's optically thin passes): the caller has NOT tested the slots against their cached cells -- the entry the hint
+// names settles that too.  A point well inside the hinted cell is in no other cell (device_types.hpp, BucketDir), so if that cell is the
+// cached one the slot has stayed (checkInBlock, geometry.c:394, would have said so) and nothing is stored for it (probe->same[k] set), and
+// if it is another one the slot has left its cell (mclib.c:507,528).  This saves every slot the 32-B gather of its cached cell's geometry.
+struct LockstepProbe {
+    const int *cached;           // [K] the slots' cached cells
+    bool force;                  // forced pass (mcrat.c:756): a slot is re-located even into the cell it is in
+    bool *same;                  // [K] out: settled, and still in its cached cell
+};
+
+template <int DIMS, int GEOM, int K, bool LOGS = false, class PH>
 __device__ __forceinline__ void relocate_lockstep(const PH &ph, const HydroDev &hy, const int (&slot)[K], bool (&todo)[K],
                                                   const double (&r0)[K], const double (&r1)[K], const double (&a0)[K], const double (&a1)[K],
                                                   const double (&a2)[K], const int (&code)[K], const uint64_t (&bits)[K], const unsigned (&fl)[K],
-                                                  bool count_it, double (&t)[K], int &relocated)
+                                                  bool count_it, double (&t)[K], int &relocated, const LockstepProbe *probe = nullptr)
 {
     static_assert(!TABLE_MODE, "DIRECT optical depths");
     const GridDev &g = hy.grid;
@@ -378,14 +391,18 @@ __device__ __forceinline__ void relocate_lockstep(const PH &ph, const HydroDev &
         double beta[3];
         phys::beta_from_record<DIMS>(f[k].a, f[k].b, f[k].c, cphi, sphi, beta);
         const double lab[4] = {p0[k], p1[k], p2[k], p3[k]};
-        phys::boost_with<true>(beta, f[k].gam, f[k].kf, lab, comv[k]);           // mclib.c:558
+        phys::boost_with<true>(beta, f[k].gam, phys::kf_of_gamma(f[k].gam), lab, comv[k]);   // mclib.c:558
         tau[k] = phys::optical_depth_staged(beta, f[k].w, f[k].nsig, p1[k], p2[k], p3[k], 1.0);
         ntau[k] = -phys::rcp_nr(tau[k]);
-        t[k] = sample_free_time(ntau[k], bits[k]);
+        t[k] = LOGS ? free_time_from_log(ntau[k], __longlong_as_double((long long)bits[k])) : sample_free_time(ntau[k], bits[k]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!take[k]) continue;
+        if (probe) {
+            probe->same[k] = !probe->force && f[k].cell == probe->cached[k];
+            if (probe->same[k]) { todo[k] = false; continue; }
+        }
         const int i = slot[k];
         ph.idx(i) = f[k].cell;                                                   // mclib.c:536
         ph.c0(i) = comv[k][0]; ph.c1(i) = comv[k][1]; ph.c2(i) = comv[k][2]; ph.c3(i) = comv[k][3];
@@ -589,39 +606,66 @@ struct EventWalk {
 
 // the physics of one candidate between mclib.c:1144 and :1322: fluid frame at the photon's azimuth, Stokes rotation
 // into the comoving frame, electron draw, singleScatter, boost back.  r is the candidate's position at the event.
-// Returns false on a Klein-Nishina rejection (p, pc, s are then unspecified, nothing was stored).  tau_new is the
-// optical depth of the new momentum in the cached cell (see commit_scatter).
+// In two halves (cf. physics.hpp, single_scatter_begin / _finish): scatter_decide goes as far as the Klein-Nishina acceptance test and
+// returns false on a rejection (nothing was stored; s is then unspecified); scatter_finish completes an accepted scattering -- it cannot
+// fail -- and returns tau_new, the optical depth of the new momentum in the cached cell (see commit_scatter).
 // WAVE: called by all 64 lanes of a wavefront with the same arguments (event_block's walk); see phys::sample_thermal_electron.
+struct EventMid {
+    phys::ScatterMid sm;
+    double beta[3];
+    double w, nsig, gam, kf;
+    double fluid_temp;
+    EventStream rng;
+};
+
 template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
-__device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter,
-                                             uint32_t rng_slot, int cell, const double r[3], double p[4], double pc[4], double s[4],
-                                             double &fluid_temp, double &tau_new)
+__device__ __forceinline__ bool scatter_decide(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter,
+                                               uint32_t rng_slot, int cell, const double r[3], const double p[4], const double pc[4], double s[4],
+                                               EventMid &m)
 {
     MC_STAMP(st, 2);
-    fluid_temp = hy.temp[cell];                            // mclib.c:1148
+    m.fluid_temp = hy.temp[cell];                          // mclib.c:1148
     const CellFluid f = hy.fluid[cell];
+    m.w = f.w; m.nsig = f.nsig; m.gam = f.gam; m.kf = f.kf;
     double cphi, sphi;
     phys::cos_sin_of_atan2(r[1], r[0], cphi, sphi);        // ph_phi, mclib.c:1151
-    double beta[3];
-    phys::cell_beta<DIMS>(f, cphi, sphi, beta);            // mclib.c:1167-1174
-    if constexpr (STOKES) phys::stokes_rotation(beta, p + 1, pc + 1, s);     // mclib.c:1227
-    EventStream rng = event_stream(key.seed, iter, rng_slot, key.stream);
+    phys::cell_beta<DIMS>(f, cphi, sphi, m.beta);          // mclib.c:1167-1174
+    if constexpr (STOKES) phys::stokes_rotation(m.beta, p + 1, pc + 1, s);   // mclib.c:1227
+    m.rng = event_stream(key.seed, iter, rng_slot, key.stream);
     const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
     double el[4];
     MC_STAMP(st, 3);
-    phys::single_thermal_electron<WAVE>(el, fluid_temp, k2e, pc, rng); // mclib.c:1234
+    phys::single_thermal_electron<WAVE>(el, m.fluid_temp, k2e, pc, m.rng);   // mclib.c:1234
     MC_STAMP(st, 4);
-    if (!phys::single_scatter<STOKES>(el, pc, s, rng)) return false;   // mclib.c:1245
+    return phys::single_scatter_begin<STOKES>(el, pc, s, m.sm, m.rng);       // mclib.c:1245 as far as kleinNishinaScatter's test
+}
+
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
+__device__ __forceinline__ void scatter_finish(const HydroDev &hy, LoopState *st, EventMid &m, double p[4], double pc[4], double s[4], double &tau_new)
+{
+    phys::single_scatter_finish<STOKES>(m.sm, pc, s, m.rng);           // the rest of mclib.c:1245
     MC_STAMP(st, 5);
-    const double nb[3] = {-beta[0], -beta[1], -beta[2]};
-    phys::boost_with<true>(nb, f.gam, f.kf, pc, p);                    // mclib.c:1265
+    const double nb[3] = {-m.beta[0], -m.beta[1], -m.beta[2]};
+    phys::boost_with<true>(nb, m.gam, m.kf, pc, p);                    // mclib.c:1265
     if constexpr (STOKES) phys::stokes_rotation(nb, pc + 1, p + 1, s); // mclib.c:1280
     // recalc_properties = 1 (mclib.c:1322).  The optical depth the next pass would recompute for this slot in its
     // cached cell (calcMeanFreePath, mclib.c:668-673: same position, same cell record, the new momentum) is computed
     // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
     double norm = 1.0;
-    if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], fluid_temp, !WAVE || (threadIdx.x & 63) == 0);   // optical_depth.c:58
-    tau_new = phys::optical_depth_staged(beta, f.w, f.nsig, p[1], p[2], p[3], norm);
+    if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], m.fluid_temp, !WAVE || (threadIdx.x & 63) == 0);   // optical_depth.c:58
+    tau_new = phys::optical_depth_staged(m.beta, m.w, m.nsig, p[1], p[2], p[3], norm);
+}
+
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
+__device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter,
+                                             uint32_t rng_slot, int cell, const double r[3], double p[4], double pc[4], double s[4],
+                                             double &fluid_temp, double &tau_new)
+{
+    EventMid m;
+    const bool ok = scatter_decide<DIMS, GEOM, STOKES, WAVE>(hy, st, key, iter, rng_slot, cell, r, p, pc, s, m);
+    fluid_temp = m.fluid_temp;
+    if (!ok) return false;
+    scatter_finish<DIMS, GEOM, STOKES, WAVE>(hy, st, m, p, pc, s, tau_new);
     return true;
 }
 
@@ -952,7 +996,9 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
 #ifdef MCRAT_DIAG
     long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // ticks: load, forced step, step, event, store; [5] passes
     long long dg_t = (long long)__builtin_amdgcn_s_memtime();
-#define RANK_TICK(k) do { __builtin_amdgcn_sched_barrier(0); const long long n_ = (long long)__builtin_amdgcn_s_memtime(); dg[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+    const bool dg_clock = (g_diag & 1024) != 0;      // only the list's start and end on the 100 MHz clock (and its length in shader-clock ticks)
+    const long long dg_real0 = (long long)__builtin_amdgcn_s_memrealtime(), dg_tick0 = dg_t;
+#define RANK_TICK(k) do { if (!dg_clock) { __builtin_amdgcn_sched_barrier(0); const long long n_ = (long long)__builtin_amdgcn_s_memtime(); dg[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define RANK_TICK(k) do { } while (0)
 #endif
@@ -1083,11 +1129,15 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                     bool dom[NS], inb[NS];
                     CellGeom cg[NS];
                     CellGeom2 cg2[NS];
+                    // (the fused form looks every slot up in the grid first and learns from the entry whether it has left its cached cell --
+                    // LockstepProbe -- so it does not gather the cached cell's geometry here)
+                    if constexpr (!(FUSED && !TABLE_MODE)) {
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) {
-                        const int cc = (cell[k] < 0 || MC_DIAG(DIAG_SKIP_INCELL)) ? 0 : cell[k];
-                        cg[k] = hy.geom[cc];                                         // geometry.c:394-417 operands
-                        if constexpr (DIMS == DIM_THREE) cg2[k] = hy.geom2[cc];
+                        for (int k = 0; k < NS; ++k) {
+                            const int cc = (cell[k] < 0 || MC_DIAG(DIAG_SKIP_INCELL)) ? 0 : cell[k];
+                            cg[k] = hy.geom[cc];                                     // geometry.c:394-417 operands
+                            if constexpr (DIMS == DIM_THREE) cg2[k] = hy.geom2[cc];
+                        }
                     }
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
@@ -1107,6 +1157,45 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                     }
                     // decisions, slot by slot
                     int qd[NS], code[NS];
+                    bool settled[NS];
+                    double tl[NS];
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) { settled[k] = false; tl[k] = 0; qd[k] = 0; code[k] = -1; }
+                    if constexpr (FUSED && !TABLE_MODE) {
+                        static_assert(NS == 2, "the fused form takes one slot pair per trip");
+                        bool cand[2], same[2] = {false, false};
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            cand[k] = live[k] && (fl[k] & FLAG_VALID) && dom[k] && cell[k] != -1;
+                            if (cand[k]) code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]);
+                        }
+                        bool todo[2] = {cand[0], cand[1]};
+                        if (todo[0] || todo[1]) {
+                            const int slot[2] = {base + il[0], base + il[1]};
+                            const LockstepProbe probe = {cell, force, same};
+                            double tt[2];
+                            relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, !force, tt, relocated, &probe);
+#pragma unroll
+                            for (int k = 0; k < 2; ++k)
+                                if (cand[k] && !todo[k] && !same[k]) { settled[k] = true; tl[k] = tt[k]; n_rel += 1; }
+                        }
+                        bool any = false;
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            if (!cand[k]) continue;
+                            bool stays = same[k];
+                            if (todo[k]) {                                            // no hint settles this slot: the test on its cached cell
+                                stays = !force && phys::check_in_block<DIMS>(hy, cell[k], a0[k], a1[k], a2[k]);   // mclib.c:507,528
+                                if (!stays) { qd[k] = 1; n_rel += 1; }
+                            }
+                            if (stays && (fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;          // mclib.c:668
+                            any = any || (stays && qd[k] == 0);
+                        }
+                        if (any) {                                                    // the draws of the slots that stay in their cells
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) tf[k] = sample_free_time(ntau[k], bits[k]);
+                        }
+                    } else {
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
                         inb[k] = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) && (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
@@ -1118,41 +1207,11 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         else if ((fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;   // mclib.c:668
                         if (qd[k] == 1) { code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]); n_rel += 1; }
                     }
-                    if constexpr (FUSED) {                           // the draws of the slots that stay in their cells, if there are any
-                        bool any = false;
 #pragma unroll
-                        for (int k = 0; k < NS; ++k) any = any || (live[k] && (fl[k] & FLAG_VALID) && dom[k] && cell[k] != -1 && qd[k] == 0);
-                        if (any) {
-#pragma unroll
-                            for (int k = 0; k < NS; ++k) tf[k] = sample_free_time(ntau[k], bits[k]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) {
-                            tf[k] = sample_free_time(ntau[k], bits[k]);               // mclib.c:675-687
-                            if (MC_DIAG(DIAG_SKIP_SAMPLE)) tf[k] = 1e-7 * (1.0 + (double)(bits[k] >> 40) * 1e-3) + ntau[k] * 0.0;
-                        }
+                    for (int k = 0; k < NS; ++k) {
+                        tf[k] = sample_free_time(ntau[k], bits[k]);                   // mclib.c:675-687
+                        if (MC_DIAG(DIAG_SKIP_SAMPLE)) tf[k] = 1e-7 * (1.0 + (double)(bits[k] >> 40) * 1e-3) + ntau[k] * 0.0;
                     }
-                    bool settled[NS];
-                    double tl[NS];
-#pragma unroll
-                    for (int k = 0; k < NS; ++k) { settled[k] = false; tl[k] = 0; }
-                    if constexpr (FUSED && !TABLE_MODE) {
-#pragma unroll
-                        for (int k0 = 0; k0 < NS; k0 += 2) {
-                            bool todo[2] = {qd[k0] == 1, qd[k0 + 1] == 1};
-                            if (!(todo[0] || todo[1])) continue;
-                            const int slot[2] = {base + il[k0], base + il[k0 + 1]}, cd[2] = {code[k0], code[k0 + 1]};
-                            const double R0[2] = {r0[k0], r0[k0 + 1]}, R1[2] = {r1[k0], r1[k0 + 1]};
-                            const double A0[2] = {a0[k0], a0[k0 + 1]}, A1[2] = {a1[k0], a1[k0 + 1]}, A2[2] = {a2[k0], a2[k0 + 1]};
-                            const uint64_t bt[2] = {bits[k0], bits[k0 + 1]};
-                            const unsigned fk[2] = {fl[k0], fl[k0 + 1]};
-                            double tt[2];
-                            relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, R0, R1, A0, A1, A2, cd, bt, fk, !force, tt, relocated);
-#pragma unroll
-                            for (int j = 0; j < 2; ++j)
-                                if (qd[k0 + j] == 1 && !todo[j]) { settled[k0 + j] = true; tl[k0 + j] = tt[j]; }
-                        }
                     }
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
@@ -1302,6 +1361,10 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         __syncthreads();
         RANK_TICK(4);
         if (tid == 0) for (int k = 0; k < 8; ++k) st.stamps[k] = dg[k];
+        if (tid == 0 && dg_clock) {
+            st.stamps[0] = dg_real0; st.stamps[1] = (long long)__builtin_amdgcn_s_memrealtime();
+            st.stamps[2] = (long long)__builtin_amdgcn_s_memtime() - dg_tick0;
+        }
 #endif
         if (tid == 0) {
             st.nseg = 0; st.skip_idx = -1;
@@ -1310,6 +1373,579 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         }
     }
 }
+
+// ------------------------------------------------------------------ virtual ranks, the passes pipelined (round 3; -DMCRAT_RANK_PIPE=1 only)
+// MEASURED SLOWER than rank_loop_kernel and therefore not part of the product build ("the passes pipelined"): a list's
+// pass took 29.5 us against 26.0 us (1025 lists of 976 photons, cfg2, lives of the lists on the 100 MHz clock, tools/diag_pipe.py).  What the
+// walk's completion hides is less than what phase 1 loses by running on three wavefronts in three rounds of 64 slot pairs instead of on four
+// in two, and u0-2 coming from L2 instead of LDS puts one more memory latency into every round.  Kept for the next attempt (it is parity-green
+// against the oracle, tests/test_gpu_pool.py with MCRAT_HIP_RANK_PIPE=1 on such a build); the rest of this comment is the design.
+#if defined(MCRAT_RANK_PIPE) && MCRAT_RANK_PIPE
+// rank_loop_kernel runs a list's passes strictly one after the other: phase 1 (every slot: pending advance, in-cell test, re-location, free
+// path), the leftovers, the minimum, the sort -- then ONE wavefront walks the event (photonEvent, mclib.c:1107-1356) while the other three
+// wait at a barrier: a quarter of a list's frame.  Nothing in the next pass depends on what the scattered photon looks like afterwards: the
+// other slots need the pass's time segments (mclib.c:1138,1332) and which slot to leave alone, and both are known the moment the
+// Klein-Nishina test accepts a candidate (kleinNishinaScatter, mcrat_scattering.c:509-523) -- the sampling of the angles, the Compton shift,
+// Fano's matrix and the boosts back cannot fail.  So the walk is cut there (scatter_decide / scatter_finish):
+//   wavefront 0           walks the sorted candidates as far as an accepted test, publishes {segments, scattered slot, pass number, shortlist
+//                         threshold} (PipeNext) and meets the others at barrier A; then completes the scattering, stores it, takes the
+//                         scattered slot through ITS phase 1 of the next pass, and joins the others
+//   wavefronts 1-3        meanwhile compute the next pass's Philox blocks and log(u) for every slot (the key {pass + 1, slot} does not depend
+//                         on the event) into LDS; after barrier A they run phase 1 of the next pass for every other slot, 64 slot pairs at a
+//                         time from a shared counter
+// so a pass costs {decision half of the walk} + {phase 1 without its draws, on three to four wavefronts} + {minimum, sort}, instead of the
+// sum of everything.  The arithmetic of every slot and of the event is that of rank_loop_kernel / step_kernel + event_kernel -- the same
+// device functions in the same order -- so a list's photons are bit for bit what those kernels give (tests/test_gpu_parity.py,
+// tests/test_gpu_pool.py run both).
+// LDS per list: r, -1/tau, cell, flags (37 B per slot) and the logarithms (8 B); u0-2 are read from L2 once per pass (no dependent
+// chain hangs on them).  Lists of up to 1024 slots, two per CU.  Not for cyclo-synchrotron lists (their hook needs the pass complete) or
+// TAU_CALCULATION == TABLE (rank_loop_kernel keeps those).
+constexpr unsigned LIST_MASK_PIPE = colbit(COL_R0) | colbit(COL_R1) | colbit(COL_R2) | colbit(COL_NTAU) | COLBIT_IDX | COLBIT_FLAGS;
+constexpr int PIPE_BLOCK = 256;
+constexpr int PIPE_QCAP = 512;           // leftovers of a pass: slots the bucket hints do not settle, slots whose tau alone is stale, and in
+                                         // passes in which few slots change cell (dense frames) those that do
+constexpr int rank_pipe_lds_bytes_per_slot() { return (int)ListCols<LIST_MASK_PIPE>::lds_bytes_per_slot + (int)sizeof(double); }
+
+struct alignas(16) PipeNext {            // what the walk of pass k tells phase 1 of pass k + 1
+    double seg[MAX_SEG];                 // the pass's advance segments (mclib.c:1138,1332), applied to every moving slot but `skip`
+    double t_cut;                        // shortlist threshold of pass k + 1
+    unsigned long long iter;             // its number (the RNG counter)
+    int nseg, skip;                      // skip: the scattered slot, advanced by the event itself (-1: none)
+    int go;                              // 0: the frame (or this launch's share of passes) is over
+    int force;                           // pass k + 1 is the forced re-location pass of a new frame (mcrat.c:756)
+    int thin;                            // most slots changed cell in the last pass: pass k + 1 looks every slot up in the grid first (LockstepProbe)
+    int pad;
+};
+
+// the K smallest (t, i) of a wavefront's lanes -> out[0..TOPK) (ascending); every lane returns with the same out
+__device__ __forceinline__ void wave_topk(TopK &mine, Cand (&out)[TOPK])
+{
+#pragma unroll
+    for (int r = 0; r < TOPK; ++r) {
+        double ht = mine.t[0];
+        int hi = mine.i[0];
+        wave_min_pair(ht, hi);
+        if (mine.i[0] == hi && mine.t[0] == ht) mine.pop();
+        out[r].t = ht; out[r].idx = hi; out[r].pad = 0;
+    }
+}
+
+template <int DIMS, int GEOM, bool STOKES>
+__global__ __launch_bounds__(PIPE_BLOCK, RANK_WAVES_PER_SIMD) void rank_pipe_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
+                                                                                RankLayout lay, long long max_passes, int lds_slots)
+{
+    static_assert(!TABLE_MODE, "DIRECT optical depths (relocate_lockstep)");
+    constexpr int BLOCK = PIPE_BLOCK;
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    __shared__ LoopState st;
+    __shared__ PipeNext nx;
+    __shared__ Cand s_raw[BLOCK], s_list[BLOCK];           // shortlist of the pass being built / sorted shortlist of the pass being walked
+    __shared__ double s_wt[BLOCK / 64];
+    __shared__ int s_wi[BLOCK / 64];
+    __shared__ int s_q[PIPE_QCAP], s_qb[PIPE_QCAP];
+    __shared__ int s_qn, s_sln, s_chunk, s_nrel;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rank = blockIdx.x;
+    const int base = rank * lay.stride;
+    int n = min(lay.stride, lay.n_total - base);
+    RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
+    if (lay.desc) {
+        const RankDesc d = lay.desc[rank];
+        n = min(n, d.len);
+        rk.seed = d.seed;
+        rk.stream = d.stream;
+    }
+    const int idx_shift = lay.desc ? base : 0;             // a pool list's *scattered_ph_index is list-local between launches
+    if (tid == 0) {
+        st = states[rank];
+        if (st.last_scattered_index >= 0) st.last_scattered_index += idx_shift;
+    }
+    __syncthreads();
+    if (st.done || n <= 0) return;
+
+    using Cols = ListCols<LIST_MASK_PIPE>;
+    const Cols ph(gph, s_dyn, lds_slots, base);
+    double *const s_lg = reinterpret_cast<double *>(s_dyn + (size_t)lds_slots * Cols::lds_bytes_per_slot);   // log(u) of the pass's draws, per slot
+    for (int il = tid; il < n; il += BLOCK) {
+        const int i = base + il;
+        ph.r0(i) = ph.template gcol<COL_R0>(i); ph.r1(i) = ph.template gcol<COL_R1>(i); ph.r2(i) = ph.template gcol<COL_R2>(i);
+        ph.ntau(i) = ph.template gcol<COL_NTAU>(i);
+        ph.idx(i) = ph.g_idx_at(i); ph.flags(i) = ph.g_flags_at(i);
+    }
+    if (tid == 0) {
+        nx.nseg = st.nseg; nx.skip = st.skip_idx; nx.iter = st.iteration; nx.t_cut = st.t_cut; nx.go = 1; nx.force = st.force_relocate;
+        nx.thin = 1; nx.pad = 0;                             // (the first pass of a launch: a new frame's forced pass, or unknown)
+        for (int k = 0; k < MAX_SEG; ++k) nx.seg[k] = st.seg[k];
+        s_qn = 0; s_sln = 0; s_chunk = 0; s_nrel = 0;
+    }
+    __syncthreads();
+
+#ifdef MCRAT_DIAG
+    // shader-clock sums per list (diagnostic build): set A (g_diag bit 512 clear), by the walker's lane 0: [0] leftovers + minimum + sort, [1] decision half
+    // of the walk, [2] its wait at barrier A, [3] completion + the scattered slot, [4] its share of phase 1, [5] its wait at barrier B; by lane 0 of
+    // wavefront 1: [6] the draws, [7] its phase 1.  Set B (bit 512 set), lane 0 of wavefront 1 inside phase1_pair: [0] loads + advance, [1] cell record +
+    // coordinates + decisions, [2] re-location, [3] stores + shortlist, [4] pairs taken
+    __shared__ long long s_dg[8];
+    if (tid < 8) s_dg[tid] = 0;
+    long long dg_t = 0;
+    const bool dg_inner = (g_diag & 512) != 0;
+    const bool dg_clock = (g_diag & 1024) != 0;          // set C: [0] start and [1] end of the list on the 100 MHz clock, [2] its length in shader-clock ticks
+    const long long dg_real0 = (long long)__builtin_amdgcn_s_memrealtime(), dg_tick0 = (long long)__builtin_amdgcn_s_memtime();
+#define PIPE_T0() do { if (!dg_clock) { __builtin_amdgcn_sched_barrier(0); dg_t = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PIPE_TICK(cond, k) do { if (!dg_clock) { __builtin_amdgcn_sched_barrier(0); const long long n_ = (long long)__builtin_amdgcn_s_memtime(); if (cond) s_dg[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PIPE_TICK_W(cond, k) do { __builtin_amdgcn_s_waitcnt(0); PIPE_TICK(cond, k); } while (0)
+#else
+#define PIPE_T0() do { } while (0)
+#define PIPE_TICK(cond, k) do { } while (0)
+#define PIPE_TICK_W(cond, k) do { } while (0)
+#endif
+    const int npairs = (n + 1) >> 1;
+    // log(u) of every slot's draw of pass `iter` (mclib.c:675): one Philox block per slot pair, as the draw order prescribes (rng.hpp)
+    auto precompute = [&](unsigned long long iter, int first, int step) {
+        for (int pair = first; pair < npairs; pair += step) {
+            const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
+            const uint64_t b0 = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32), b1 = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
+            s_lg[2 * pair] = log(bits_to_uniform_pos(b0));
+            if (2 * pair + 1 < n) s_lg[2 * pair + 1] = log(bits_to_uniform_pos(b1));
+        }
+    };
+    MinCand best;
+    int relocated = 0, not_found = 0, n_rel = 0;
+    auto shortlist_lds = [&](double t, int i) {
+        const int pos = atomicAdd(&s_sln, 1);
+        if (pos < BLOCK) { s_raw[pos].t = t; s_raw[pos].idx = i; s_raw[pos].pad = 0; }
+    };
+    // phase 1 of the pass nx describes, for the slot pair `pair` of this lane: the arithmetic of rank_loop_kernel's fused form (fast_one /
+    // relocate_lockstep per slot), the draw's logarithm from LDS; the scattered slot of the previous pass (nx.skip) is left to the walker
+    auto phase1_pair = [&](int pair) {
+        const int nseg = nx.nseg, skip = nx.skip;
+        const bool force = nx.force != 0;
+        const double t_cut = nx.t_cut;
+#ifdef MCRAT_DIAG
+        const bool dgi = dg_inner && tid == 64;
+        if (dgi) { PIPE_T0(); s_dg[4] += 1; }
+#endif
+        int il[2] = {2 * pair, 2 * pair + 1};
+        bool live[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) { live[k] = il[k] < n && base + il[k] != skip; if (il[k] >= n) il[k] = 0; }
+        double r0[2], r1[2], r2[2], ntau[2], lg[2];
+        int cell[2];
+        unsigned fl[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = base + il[k];
+            r0[k] = ph.r0(i); r1[k] = ph.r1(i); r2[k] = ph.r2(i);
+            ntau[k] = ph.ntau(i); cell[k] = ph.idx(i); fl[k] = ph.flags(i);
+            lg[k] = s_lg[il[k]];
+        }
+        if (nseg > 0) {                                      // pending updatePhotonPosition, mclib.c:1067-1095
+            double u0[2], u1[2], u2[2];
+            bool mv[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = base + il[k];
+                u0[k] = ph.u0(i); u1[k] = ph.u1(i); u2[k] = ph.u2(i);
+                mv[k] = live[k] && (fl[k] & FLAG_MOVES);
+            }
+            for (int sg = 0; sg < nseg; ++sg) {
+                const double t = nx.seg[sg];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double n0 = r0[k] + u0[k] * t, n1 = r1[k] + u1[k] * t, n2 = r2[k] + u2[k] * t;
+                    r0[k] = mv[k] ? n0 : r0[k]; r1[k] = mv[k] ? n1 : r1[k]; r2[k] = mv[k] ? n2 : r2[k];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (mv[k]) { const int i = base + il[k]; ph.r0(i) = r0[k]; ph.r1(i) = r1[k]; ph.r2(i) = r2[k]; }
+        }
+#ifdef MCRAT_DIAG
+        if (dg_inner) PIPE_TICK_W(dgi, 0);
+#endif
+        double a0[2], a1[2], a2[2];
+        bool dom[2], cand[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            phys::hydro_coords<DIMS, GEOM>(r0[k], r1[k], r2[k], a0[k], a1[k], a2[k]);
+            dom[k] = phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);           // mclib.c:492-505
+            cand[k] = live[k] && (fl[k] & FLAG_VALID) && dom[k] && cell[k] != -1;
+        }
+        int qd[2] = {0, 0}, code[2] = {-1, -1};
+        bool settled[2] = {false, false};
+        double tl[2] = {0, 0};
+        const uint64_t lb[2] = {(uint64_t)__double_as_longlong(lg[0]), (uint64_t)__double_as_longlong(lg[1])};
+        const int slot[2] = {base + il[0], base + il[1]};
+        if (nx.thin) {
+            // most slots change cell between two events here (or this is a frame's forced pass): every slot is looked up in the grid first, and
+            // the entry its bucket's hint names says both whether it has left its cached cell and where it is (LockstepProbe) -- the gather of
+            // the cached cell's geometry is spent only on the few slots no hint settles
+            bool todo[2] = {cand[0], cand[1]}, same[2] = {false, false};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) if (cand[k]) code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]);
+#ifdef MCRAT_DIAG
+            if (dg_inner) PIPE_TICK_W(dgi, 1);
+#endif
+            if (todo[0] || todo[1]) {
+                const LockstepProbe probe = {cell, force, same};
+                double tt[2];
+                relocate_lockstep<DIMS, GEOM, 2, true>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, lb, fl, !force, tt, relocated, &probe);
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (cand[k] && !todo[k] && !same[k]) { settled[k] = true; tl[k] = tt[k]; n_rel += 1; }
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (!cand[k]) continue;
+                bool stays = same[k];
+                if (todo[k]) {                                                     // no hint settles this slot: the test on its cached cell
+                    stays = !force && phys::check_in_block<DIMS>(hy, cell[k], a0[k], a1[k], a2[k]);   // mclib.c:507,528
+                    if (!stays) { qd[k] = 1; n_rel += 1; }
+                }
+                if (stays && (fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;          // mclib.c:668
+            }
+        } else {
+            CellGeom cg[2];
+            CellGeom2 cg2[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int cc = cell[k] < 0 ? 0 : cell[k];
+                cg[k] = hy.geom[cc];                                              // geometry.c:394-417 operands
+                if constexpr (DIMS == DIM_THREE) cg2[k] = hy.geom2[cc];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                bool inb = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) && (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
+                if constexpr (DIMS == DIM_THREE) inb = inb && (2 * fabs(a2[k] - cg2[k].c2) - cg2[k].s2 <= 0);
+                if (!cand[k]) continue;
+                if (force || !inb) qd[k] = 1;                                      // mclib.c:507,528
+                else if ((fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;   // mclib.c:668
+                if (qd[k] == 1) { code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]); n_rel += 1; }
+            }
+#ifdef MCRAT_DIAG
+            if (dg_inner) PIPE_TICK_W(dgi, 1);
+#endif
+            // (the few slots that changed cell go to the leftover queue: after the pass's barrier they are re-located with dense lanes)
+        }
+#ifdef MCRAT_DIAG
+        if (dg_inner) PIPE_TICK_W(dgi, 2);
+#endif
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!live[k]) continue;
+            const int i = base + il[k];
+            double t;
+            if (!(fl[k] & FLAG_VALID)) { ph.tts(i) = INFINITY; continue; }
+            if (settled[k]) {                                                  // re-located in lockstep above; everything is stored
+                best.offer(tl[k], i);
+                if (tl[k] < t_cut) shortlist_lds(tl[k], i);
+                continue;
+            }
+            if (dom[k] && cell[k] != -1) {
+                const int q = qd[k];
+                if (!q && (fl[k] & FLAG_RECALC)) {                             // mclib.c:668, tau of the new momentum is at hand
+                    ph.flags(i) = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
+                    ph.tau(i) = ph.tau_next(i);
+                }
+                if (q) {
+                    const int e = atomicAdd(&s_qn, 1);
+                    if (e < PIPE_QCAP) {
+                        s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0);
+                        s_qb[e] = code[k];
+                        continue;
+                    }
+                    t = slow_one<DIMS, GEOM, true>(ph, hy, i, q == 1, code[k], !force, (uint64_t)__double_as_longlong(lg[k]), relocated, not_found);   // queue full: in line
+                } else {
+                    t = free_time_from_log(ntau[k], lg[k]);                    // mclib.c:675-687
+                    ph.tts(i) = t;
+                }
+            } else {
+                if (cell[k] != -1) ph.idx(i) = -1;                             // mclib.c:592
+                t = 1e12 / C_LIGHT;                                            // mclib.c:620,684
+                ph.tts(i) = t;
+            }
+            best.offer(t, i);
+            if (t < t_cut) shortlist_lds(t, i);
+        }
+#ifdef MCRAT_DIAG
+        if (dg_inner) PIPE_TICK_W(dgi, 3);
+#endif
+    };
+    // 64 slot pairs at a time from a counter the wavefronts share (the walker joins when it has finished its scattering)
+    auto phase1_work = [&]() {
+        for (;;) {
+            int c = 0;
+            if (lane == 0) c = atomicAdd(&s_chunk, 1);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c * 64 >= npairs) break;
+            const int pair = c * 64 + lane;
+            if (pair < npairs) phase1_pair(pair);
+        }
+        // how many slots changed cell: the next pass's form (PipeNext::thin)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) n_rel += __shfl_xor(n_rel, off, 64);
+        if (lane == 0 && n_rel) atomicAdd(&s_nrel, n_rel);
+        n_rel = 0;
+    };
+
+    // ---- the first pass of this launch: nothing to overlap it with
+    precompute(nx.iter, tid, BLOCK);
+    best.init();
+    __syncthreads();
+    phase1_work();
+
+    PIPE_T0();
+    for (long long pass = 0;; ++pass) {
+        PIPE_TICK(!dg_inner && tid == 64, 7);
+        PIPE_TICK(!dg_inner && tid == 0, 4);
+        __syncthreads();                                     // barrier B: phase 1 of the pass is done (and the scattering of the one before stored)
+        PIPE_TICK(!dg_inner && tid == 0, 5);
+        // ---- what is left of the pass: counters, the slots the hints did not settle, the minimum, the sorted shortlist
+        if (relocated) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.n_relocated), (unsigned long long)relocated); relocated = 0; }
+        if (not_found) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.not_found), (unsigned long long)not_found); not_found = 0; }
+        const int nrel_prev = s_nrel;                        // slots that changed cell in the pass just done
+        const int qn = min(s_qn, PIPE_QCAP);
+        if (qn > 0) {
+            const bool force = nx.force != 0;
+            const double t_cut = nx.t_cut;
+            for (int e = tid; e < qn; e += BLOCK) {
+                const int il = s_q[e] & ~Q_RECALC_ONLY;
+                const int i = base + il;
+                const double t = slow_one<DIMS, GEOM, true>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, (uint64_t)__double_as_longlong(s_lg[il]), relocated, not_found);
+                best.offer(t, i);
+                if (t < t_cut) shortlist_lds(t, i);
+            }
+            if (relocated) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.n_relocated), (unsigned long long)relocated); relocated = 0; }
+            if (not_found) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.not_found), (unsigned long long)not_found); not_found = 0; }
+        }
+        wave_min_pair_dpp(best.t, best.i);
+        if (lane == 0) { s_wt[wave] = best.t; s_wi[wave] = best.i; }
+        __syncthreads();
+        const int n_raw = s_sln;
+        int n_list = (n_raw > BLOCK) ? 0 : n_raw;            // overflowed: incomplete, ignore it
+        if (tid < n_list) {                                  // rank sort (equal (t, idx) pairs cannot occur)
+            const Cand me = s_raw[tid];
+            int rk_ = 0;
+            for (int j = 0; j < n_list; ++j) rk_ += cand_less(s_raw[j].t, s_raw[j].idx, me.t, me.idx) ? 1 : 0;
+            s_list[rk_] = me;
+        }
+        MinCand g;
+        g.init();
+#pragma unroll
+        for (int wv = 0; wv < BLOCK / 64; ++wv) g.offer(s_wt[wv], s_wi[wv]);
+        if (n_list == 0 && tid == 0) { s_list[0].t = g.t; s_list[0].idx = g.i; s_list[0].pad = 0; }
+        if (n_list == 0 && g.i != INT_MAX) n_list = 1;
+        const unsigned long long iter = nx.iter;             // the pass whose event is walked now
+        __syncthreads();
+        PIPE_TICK(!dg_inner && tid == 0, 0);
+        if (tid == 64) PIPE_T0();
+
+        if (wave == 0) {
+            // ---- the walk of photonEvent (mclib.c:1128-1339; cf. event_block / try_candidate) as far as a decision
+            __builtin_amdgcn_s_setprio(3);
+            const double dt_max = st.remaining_time, t_est = st.t_est;
+            const double t_first = (n_list > 0) ? s_list[0].t : INFINITY;
+            double old_scatt_time = 0, dt = 0;
+            int w_nseg = 0, skip = -1, last_idx = st.last_scattered_index;
+            long long rej = 0, rescans = 0;
+            bool first = true, called = false, decided = false, scattered = false;
+            // the scattering in flight between barrier A and its completion
+            EventMid mid;
+            double p[4], pc[4], sv[4] = {1, 0, 0, 0}, r[3];
+            unsigned cand_flags = 0;
+            double scatt_time_acc = 0;
+            Cand cur[TOPK];
+            const Cand *list = s_list;
+            int nl = n_list;
+            const int max_rounds = n / TOPK + 3;
+            for (int round = 0; round < max_rounds && !decided; ++round) {
+                if (nl == 0) {                               // every slot was tried (or there is none): mclib.c:1128 loop ends
+                    dt = (round == 0) ? dt_max : old_scatt_time;
+                    decided = true;
+                    break;
+                }
+                for (int c = 0; c < nl && !decided; ++c) {
+                    const double scatt_time = list[c].t;
+                    const int i = list[c].idx;
+                    const bool in_frame = scatt_time < dt_max;
+                    if (!(first && !in_frame)) last_idx = i;
+                    if (first) called = in_frame;
+                    first = false;
+                    if (!in_frame) {                         // mclib.c:1327-1335
+                        const double this_seg = dt_max - old_scatt_time;
+                        if (w_nseg < MAX_SEG) nx.seg[w_nseg++] = this_seg;
+                        else nx.seg[MAX_SEG - 1] += this_seg;
+                        dt = dt_max;
+                        decided = true;
+                        break;
+                    }
+                    const double this_seg = scatt_time - old_scatt_time;   // mclib.c:1138
+                    if (w_nseg < MAX_SEG) nx.seg[w_nseg++] = this_seg;
+                    else nx.seg[MAX_SEG - 1] += this_seg;
+                    old_scatt_time = scatt_time;
+                    const int cell = ph.idx(i);
+                    p[0] = ph.p0(i); p[1] = ph.p1(i); p[2] = ph.p2(i); p[3] = ph.p3(i);
+                    r[0] = ph.r0(i); r[1] = ph.r1(i); r[2] = ph.r2(i);
+                    pc[0] = ph.c0(i); pc[1] = ph.c1(i); pc[2] = ph.c2(i); pc[3] = ph.c3(i);
+                    cand_flags = ph.flags(i);
+                    const double u0 = ph.u0(i), u1 = ph.u1(i), u2 = ph.u2(i);
+                    sv[0] = 1; sv[1] = 0; sv[2] = 0; sv[3] = 0;
+                    if constexpr (STOKES) { sv[0] = ph.s0(i); sv[1] = ph.s1(i); sv[2] = ph.s2(i); sv[3] = ph.s3(i); }
+                    if (cell == -1) continue;                // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
+                    if (cand_flags & FLAG_MOVES) {           // the candidate's own position after mclib.c:1138
+                        for (int k = 0; k < w_nseg; ++k) {
+                            r[0] += u0 * nx.seg[k];
+                            r[1] += u1 * nx.seg[k];
+                            r[2] += u2 * nx.seg[k];
+                        }
+                    }
+                    if (!scatter_decide<DIMS, GEOM, STOKES, WAVE_WALK>(hy, &st, rk, iter, (uint32_t)(i - base), cell, r, p, pc, sv, mid)) {
+                        rej += 1;
+                        continue;
+                    }
+                    skip = i;
+                    dt = scatt_time;
+                    scatt_time_acc = scatt_time;
+                    scattered = true;
+                    decided = true;
+                }
+                if (!decided) {                              // the list is used up: the next TOPK candidates from time_to_scatter
+                    const double lt = list[nl - 1].t;
+                    const int li = list[nl - 1].idx;
+                    rescans += 1;
+                    TopK more;
+                    more.init();
+                    for (int i = base + lane; i < base + n; i += 64) {
+                        double t = ph.tts(i);
+                        if (t != t) t = INFINITY;
+                        if (cand_less(lt, li, t, i)) more.insert(t, i);
+                    }
+                    wave_topk(more, cur);
+                    list = cur;
+                    nl = 0;
+                    for (int c = 0; c < TOPK; ++c) nl += (cur[c].idx != INT_MAX) ? 1 : 0;
+                }
+            }
+            (void)scatt_time_acc;
+            // ---- the pass is decided: tell the others, then complete it
+            const double rem = dt_max - dt;
+            const bool frame_done = !(rem > 0);
+            const bool go = !frame_done && (pass + 1 < max_passes);
+            double est = t_est;
+            if (t_first < INFINITY) est = (t_est > 0) ? 0.875 * t_est + 0.125 * t_first : t_first;   // shortlist threshold: ~8 expected entries (speed only)
+            if (lane == 0) {
+                nx.nseg = w_nseg; nx.skip = skip; nx.iter = iter + 1; nx.go = go ? 1 : 0; nx.force = 0;
+                nx.thin = (3 * nrel_prev > n) ? 1 : 0;
+                if (t_first < INFINITY) nx.t_cut = 8.0 * est;
+                s_qn = 0; s_sln = 0; s_chunk = 0; s_nrel = 0;
+            }
+            PIPE_TICK(!dg_inner && tid == 0, 1);
+            __syncthreads();                                 // barrier A
+            PIPE_TICK(!dg_inner && tid == 0, 2);
+            if (scattered) {
+                double tau_new;
+                scatter_finish<DIMS, GEOM, STOKES, WAVE_WALK>(hy, &st, mid, p, pc, sv, tau_new);
+                commit_scatter<STOKES>(ph, skip, p, pc, sv, r, tau_new, cand_flags);
+            }
+            if (lane == 0) {                                 // mcrat.c:782-784 / 837-845
+                if (scattered) { st.frame_scatt_cnt += 1; st.last_scattered_temp = mid.fluid_temp; }   // mclib.c:1318
+                st.time_now += dt;
+                st.remaining_time = rem;
+                st.last_time_step = dt;
+                st.iteration = iter + 1;
+                st.iterations += 1;
+                st.done = frame_done;
+                st.nseg = go ? 0 : w_nseg;                   // (go: phase 1 of the next pass, already under way, applies them)
+                for (int k = 0; k < MAX_SEG; ++k) st.seg[k] = (!go && k < w_nseg) ? nx.seg[k] : 0.0;
+                st.skip_idx = go ? -1 : skip;
+                st.last_scattered_index = last_idx;
+                st.kn_rejections += rej;
+                st.photon_event_called = called ? 1 : 0;
+                st.rescans += rescans;
+                st.force_relocate = 0;
+                if (t_first < INFINITY) { st.t_est = est; st.t_cut = 8.0 * est; }
+            }
+            __builtin_amdgcn_s_setprio(0);
+            best.init();
+            if (go && scattered) {
+                // the scattered slot's own phase 1 of the next pass: it has not moved since the event (mclib.c:1332 skips nothing, the event
+                // advanced it), its tau is fresh if it is still in its cell.  Every lane of the wavefront the same values; lane 0 counts.
+                const int i = skip;
+                const unsigned fl = ph.flags(i);
+                const int cell = ph.idx(i);
+                const double lgi = s_lg[i - base];
+                double a0, a1, a2, t;
+                phys::hydro_coords<DIMS, GEOM>(r[0], r[1], r[2], a0, a1, a2);
+                int rel1 = 0, nf1 = 0;
+                if (phys::in_domain<DIMS>(hy, a0, a1, a2) && cell != -1) {
+                    if (!phys::check_in_block<DIMS>(hy, cell, a0, a1, a2)) {
+                        const int code = phys::grid_bucket(hy.grid, a0, a1, a2);
+                        t = slow_one<DIMS, GEOM, true>(ph, hy, i, true, code, true, (uint64_t)__double_as_longlong(lgi), rel1, nf1);
+                    } else {
+                        ph.flags(i) = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));   // mclib.c:668: tau of the new momentum is at hand
+                        ph.tau(i) = ph.tau_next(i);
+                        t = free_time_from_log(ph.ntau(i), lgi);
+                        ph.tts(i) = t;
+                    }
+                } else {
+                    if (cell != -1) ph.idx(i) = -1;                                 // mclib.c:592
+                    t = 1e12 / C_LIGHT;
+                    ph.tts(i) = t;
+                }
+                if (lane == 0) {
+                    relocated += rel1; not_found += nf1;
+                    best.offer(t, i);
+                    if (t < nx.t_cut) shortlist_lds(t, i);
+                }
+            }
+            PIPE_TICK(!dg_inner && tid == 0, 3);
+        } else {
+            precompute(iter + 1, tid - 64, BLOCK - 64);      // the next pass's draws, while the walk decides
+            PIPE_TICK(!dg_inner && tid == 64, 6);
+            __syncthreads();                                 // barrier A
+            if (tid == 64) PIPE_T0();
+            best.init();
+        }
+        if (!nx.go) break;
+        phase1_work();
+    }
+    __syncthreads();
+
+    // leave the photons current: apply the advance still pending (cf. flush_kernel), write the LDS columns back
+    {
+        const int nseg = st.nseg, skip = st.skip_idx;
+        for (int il = tid; il < n; il += BLOCK) {
+            const int i = base + il;
+            double r0 = ph.r0(i), r1 = ph.r1(i), r2 = ph.r2(i);
+            const unsigned fl = ph.flags(i);
+            if (nseg > 0 && (fl & FLAG_MOVES) && i != skip) {
+                const double u0 = ph.u0(i), u1 = ph.u1(i), u2 = ph.u2(i);
+                for (int sg = 0; sg < nseg; ++sg) {
+                    const double t = st.seg[sg];
+                    r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
+                }
+            }
+            ph.template gcol<COL_R0>(i) = r0; ph.template gcol<COL_R1>(i) = r1; ph.template gcol<COL_R2>(i) = r2;
+            ph.template gcol<COL_NTAU>(i) = ph.ntau(i);
+            ph.g_idx_at(i) = ph.idx(i); ph.g_flags_at(i) = (unsigned char)fl;
+        }
+#ifdef MCRAT_DIAG
+        __syncthreads();
+        if (tid == 0) for (int k = 0; k < 8; ++k) st.stamps[k] = s_dg[k];
+        if (tid == 0 && dg_clock) {
+            st.stamps[0] = dg_real0; st.stamps[1] = (long long)__builtin_amdgcn_s_memrealtime();
+            st.stamps[2] = (long long)__builtin_amdgcn_s_memtime() - dg_tick0;
+        }
+#endif
+        if (tid == 0) {
+            st.nseg = 0; st.skip_idx = -1;
+            if (st.last_scattered_index >= 0) st.last_scattered_index -= idx_shift;
+            states[rank] = st;
+        }
+    }
+}
+
+#endif   // MCRAT_RANK_PIPE
 
 // ------------------------------------------------------------------ FAST mode (SURVEY.md section 7, 8b `mode`)
 // Within a frozen hydro frame the photons are mutually independent and exponential free paths are memoryless, so the frame can be run
@@ -1977,9 +2613,29 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream)
 {
-    const bool fuse = block >= 1000;               // block: 128 or 256 threads per list, + 1000 for the build with the fused pass (256 threads)
+    const bool pipe = block >= 2000;               // block: 128 or 256 threads per list, + 1000 for the build with the fused pass, + 2000 for rank_pipe_kernel
+    if (pipe) block -= 2000;
+    const bool fuse = block >= 1000;
     if (fuse) block -= 1000;
     RankLayout lay = {n_ranks, rank_stride, ph.n, desc, cs, hook};
+    (void)pipe;
+#if defined(MCRAT_RANK_PIPE) && MCRAT_RANK_PIPE
+    if constexpr (!TABLE_MODE) {
+        if (pipe && !cs && longest_list <= 1024 && !getenv("MCRAT_HIP_NO_LDS_LISTS")) {      // the pipelined passes: lists that fit its LDS form
+            const int lds_slots = (longest_list + 15) & ~15;
+            const size_t dyn = (size_t)lds_slots * rank_pipe_lds_bytes_per_slot();
+            return dispatch(kc, [&](auto D, auto G) {
+                constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
+                auto go = [&](auto kernel) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+                    kernel<<<dim3(n_ranks), dim3(PIPE_BLOCK), dyn, stream>>>(ph, hy, states, key, lay, max_passes, lds_slots);
+                };
+                if (kc.stokes) go(rank_pipe_kernel<DV, GV, true>);
+                else go(rank_pipe_kernel<DV, GV, false>);
+            });
+        }
+    }
+#endif
     if (cs && hook && desc) {                      // cyclo-synchrotron lists with the hook inside the loop: columns in HBM/L2, no fused pass
         return dispatch(kc, [&](auto D, auto G) {
             constexpr int DV = decltype(D)::value, GV = decltype(G)::value;

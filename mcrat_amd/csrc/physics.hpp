@@ -322,6 +322,9 @@ __device__ __forceinline__ void boost_with(const double b[3], double g, double k
     if constexpr (PHOTON) zero_norm_lean(out);
 }
 
+// (gam - 1)/v^2 = gam^2/(gam + 1) of a bucket-list entry, which carries gam alone (device_types.hpp, FatCell)
+__device__ __forceinline__ double kf_of_gamma(double gam) { return (gam * gam) * rcp_nr(gam + 1.0); }
+
 // calculateOpticalDepth, optical_depth.c:7-59, on the staged operands (CellFluid):  tau' = nsig * sigma_hat * (1 - w (v.p)/|p|)  [1/cm]
 __device__ __forceinline__ double optical_depth_staged(const double fluid_beta[3], double w, double nsig, double p1, double p2, double p3,
                                                        double norm_cross_section = 1.0)
@@ -431,16 +434,22 @@ __device__ __forceinline__ double kn_cross_section(double e)
     return (1. - 2. * e);
 }
 
-// mcrat_scattering.c:509-595.  Returns cos(theta) and (cos phi, sin phi) of the scattered direction.
-template <bool STOKES>
-__device__ __forceinline__ bool kn_scatter(double &cos_theta, double &cos_phi, double &sin_phi, double p0, double q, double u,
-                                           EventStream &rng)
+// mcrat_scattering.c:509-595 in its two halves: the acceptance test against the Klein-Nishina cross section (:509-523), and -- only for an
+// accepted scattering -- the sampling of the polar and azimuthal angles (:525-595; returns cos(theta) and (cos phi, sin phi) of the scattered
+// direction).  Nothing after the test can fail, which is what lets rank_pipe_kernel (kernels.hip) start the next pass while the scattering
+// is being completed.
+__device__ __forceinline__ bool kn_accept(double p0, double &energy_ratio, EventStream &rng)
 {
-    const double energy_ratio = p0 * (1.0 / (M_EL * C_LIGHT));
+    energy_ratio = p0 * (1.0 / (M_EL * C_LIGHT));
     const double kn = kn_cross_section(energy_ratio);
     const double rand_num = rng.uniform();
-    if (!(rand_num <= kn)) return false;
+    return rand_num <= kn;
+}
 
+template <bool STOKES>
+__device__ __forceinline__ void kn_angles(double &cos_theta, double &cos_phi, double &sin_phi, double energy_ratio, double q, double u,
+                                          EventStream &rng)
+{
     double cos_theta_dum = 0, f_cos = 0, y_cos = 1;
     for (int it = 0; it < REJECTION_CAP && (y_cos > f_cos); ++it) {
         y_cos = rng.uniform() * 2;
@@ -472,7 +481,6 @@ __device__ __forceinline__ bool kn_scatter(double &cos_theta, double &cos_phi, d
         }
     }
     sincos(phi_dum, &sin_phi, &cos_phi);
-    return true;
 }
 
 // ---------------------------------------------------------------- electron
@@ -619,42 +627,60 @@ __device__ __forceinline__ void single_thermal_electron(double el_p[4], double t
 }
 
 // ---------------------------------------------------------------- the scattering itself
-// mcrat_scattering.c:151-485.  ph_comov and s are updated only when the scattering happens.
+// mcrat_scattering.c:151-485 in two halves.  single_scatter_begin: into the electron's rest frame (:218-225), the two rotations that
+// put the photon on the x axis (:244-296), the Klein-Nishina acceptance test (:307, kleinNishinaScatter :509-523); it returns false on a
+// rejection (ph_comov and s untouched: s is rotated on a copy).  single_scatter_finish: angles, Compton shift, the rotations undone, Fano's
+// matrix, back to the fluid frame (:307-481); it cannot fail.  ScatterMid is what the first half hands to the second.
+struct ScatterMid {
+    double el_v[3], g_e, kf_e;       // the electron's velocity, its Lorentz factor and (g - 1)/v^2
+    double ph_pr[4];                 // the photon in the electron's rest frame (:218), before the scattering
+    double c0, s0, c1, s1;           // cos / sin of the two alignment rotations (:244, :269)
+    double energy_ratio;             // ph_pr[0] / (m_e c)
+    double s[4];                     // Stokes parameters rotated into the electron frame's basis (:225)
+};
+
 template <bool STOKES>
-__device__ __forceinline__ bool single_scatter(const double el_comov[4], double ph_comov[4], double s[4], EventStream &rng)
+__device__ __forceinline__ bool single_scatter_begin(const double el_comov[4], const double ph_comov[4], const double s_in[4], ScatterMid &m,
+                                                     EventStream &rng)
 {
-    const double z_axis[3] = {0, 0, 1};
     const double ie0 = rcp_nr(el_comov[0]);
-    const double el_v[3] = {el_comov[1] * ie0, el_comov[2] * ie0, el_comov[3] * ie0};
+    m.el_v[0] = el_comov[1] * ie0; m.el_v[1] = el_comov[2] * ie0; m.el_v[2] = el_comov[3] * ie0;
     // the electron's Lorentz factor from its energy (el_comov[0] = gamma m_e c, electron.c:86) rather than from 1/sqrt(1 - v^2) of the
     // quotient above (mclib.c:316): the same number without the cancellation
-    const double g_e = el_comov[0] * (1.0 / (M_EL * C_LIGHT));
-    const double kf_e = (g_e * g_e) * rcp_nr(g_e + 1.0);
-    double ph_pr[4];
-    boost_with<true>(el_v, g_e, kf_e, ph_comov, ph_pr);                           // :218
-    if constexpr (STOKES) stokes_rotation(el_v, ph_comov + 1, ph_pr + 1, s);      // :225
-    const double ph_orig[4] = {ph_pr[0], ph_pr[1], ph_pr[2], ph_pr[3]};
+    m.g_e = el_comov[0] * (1.0 / (M_EL * C_LIGHT));
+    m.kf_e = (m.g_e * m.g_e) * rcp_nr(m.g_e + 1.0);
+    boost_with<true>(m.el_v, m.g_e, m.kf_e, ph_comov, m.ph_pr);                   // :218
+    m.s[0] = s_in[0]; m.s[1] = s_in[1]; m.s[2] = s_in[2]; m.s[3] = s_in[3];
+    if constexpr (STOKES) stokes_rotation(m.el_v, ph_comov + 1, m.ph_pr + 1, m.s);   // :225
 
     // phi0 = atan2(py, px) (:244): c0 = cos(-phi0), s0 = sin(-phi0)
-    double c0, sp0;
-    cos_sin_of_atan2(ph_pr[2], ph_pr[1], c0, sp0);
-    const double s0 = -sp0;
+    double sp0;
+    cos_sin_of_atan2(m.ph_pr[2], m.ph_pr[1], m.c0, sp0);
+    m.s0 = -sp0;
     // rot0 rows (c0, -s0, 0), (s0, c0, 0), (0,0,1)
-    const double r00 = ph_pr[1] * c0 + ph_pr[2] * (-s0);
-    const double r02 = ph_pr[3];
+    const double r00 = m.ph_pr[1] * m.c0 + m.ph_pr[2] * (-m.s0);
+    const double r02 = m.ph_pr[3];
     // phi1 = atan2(r02, r00) (:269): c1 = cos(-phi1), s1 = sin(-phi1)
-    double c1, sp1;
-    cos_sin_of_atan2(r02, r00, c1, sp1);
-    const double s1 = -sp1;
+    double sp1;
+    cos_sin_of_atan2(r02, r00, m.c1, sp1);
+    m.s1 = -sp1;
     // after the two alignment rotations the photon is (p0, p0, 0, 0) by construction (:294-296)
+    return kn_accept(m.ph_pr[0], m.energy_ratio, rng);                            // :307 -> :509-523
+}
 
+template <bool STOKES>
+__device__ __forceinline__ void single_scatter_finish(const ScatterMid &m, double ph_comov[4], double s[4], EventStream &rng)
+{
+    const double z_axis[3] = {0, 0, 1};
+    const double *ph_orig = m.ph_pr;
+    const double c0 = m.c0, s0 = m.s0, c1 = m.c1, s1 = m.s1;
+    s[0] = m.s[0]; s[1] = m.s[1]; s[2] = m.s[2]; s[3] = m.s[3];
     double ct = 0, cphi = 1, sphi = 0;
-    const bool occurred = kn_scatter<STOKES>(ct, cphi, sphi, ph_pr[0], s[1], s[2], rng);   // :307
-    if (!occurred) return false;
+    kn_angles<STOKES>(ct, cphi, sphi, m.energy_ratio, s[1], s[2], rng);           // :525-595
     const double sth = sqrt_nr(1 - ct * ct);
 
     double result[4];
-    result[0] = ph_pr[0] * rcp_nr(1 + ((ph_pr[0] * (1 - ct)) * (1.0 / (M_EL * C_LIGHT))));     // :322
+    result[0] = ph_orig[0] * rcp_nr(1 + ((ph_orig[0] * (1 - ct)) * (1.0 / (M_EL * C_LIGHT))));     // :322
     result[1] = result[0] * ct;
     result[2] = result[0] * sth * sphi;
     result[3] = result[0] * sth * cphi;
@@ -697,11 +723,20 @@ __device__ __forceinline__ bool single_scatter(const double el_comov[4], double 
     }
 
     double ph_out[4] = {result[0], res0[0], res0[1], res0[2]};                    // :452-454
-    const double neg_el_v[3] = {-el_v[0], -el_v[1], -el_v[2]};
+    const double neg_el_v[3] = {-m.el_v[0], -m.el_v[1], -m.el_v[2]};
     double back[4];
-    boost_with<true>(neg_el_v, g_e, kf_e, ph_out, back);                          // :465
+    boost_with<true>(neg_el_v, m.g_e, m.kf_e, ph_out, back);                      // :465
     if constexpr (STOKES) stokes_rotation(neg_el_v, ph_out + 1, back + 1, s);     // :473
     ph_comov[0] = back[0]; ph_comov[1] = back[1]; ph_comov[2] = back[2]; ph_comov[3] = back[3];
+}
+
+// the two halves in one call.  ph_comov and s are updated only when the scattering happens.
+template <bool STOKES>
+__device__ __forceinline__ bool single_scatter(const double el_comov[4], double ph_comov[4], double s[4], EventStream &rng)
+{
+    ScatterMid m;
+    if (!single_scatter_begin<STOKES>(el_comov, ph_comov, s, m, rng)) return false;
+    single_scatter_finish<STOKES>(m, ph_comov, s, rng);
     return true;
 }
 

@@ -64,8 +64,8 @@ int main()
 {
     int cus = 256;
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
-    for (size_t mb : {32, 512}) {
-        const size_t nrec = mb * 1024 * 1024 / sizeof(Rec);
+    for (size_t kb : {16, 2048, 32768}) {      // L1-resident, L2-resident, Infinity-Cache-resident
+        const size_t mb = kb, nrec = kb * 1024 / sizeof(Rec);
         Rec *table; double *out;
         CK(hipMalloc(&table, nrec * sizeof(Rec)));
         CK(hipMemset(table, 0, nrec * sizeof(Rec)));
@@ -86,7 +86,7 @@ int main()
             const double r5 = time([&] { own_kernel<5><<<blocks, 256>>>(table, mask, iters, out); });
             const double r2 = time([&] { own_kernel<2><<<blocks, 256>>>(table, mask, iters, out); });
             const double rc = time([&] { coop_kernel<<<blocks, 256>>>(table, mask, iters, out); });
-            printf("table %4zu MB, %d workgroups of 256 per CU: records/us/CU  own 8 pieces %.1f | 6 pieces %.1f | 5 pieces %.1f | 2 pieces %.1f | cooperative (8 lanes per record, through LDS) %.1f\n",
+            printf("table %6zu KB, %d workgroups of 256 per CU: records/us/CU  own 8 pieces %.1f | 6 pieces %.1f | 5 pieces %.1f | 2 pieces %.1f | cooperative (8 lanes per record, through LDS) %.1f\n",
                    mb, per_cu, r8, r6, r5, r2, rc);
         }
         CK(hipFree(table)); CK(hipFree(out));
