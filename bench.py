@@ -437,15 +437,18 @@ def main():
     n = int(ph["p0"].size)
     # the adopted ranks' lists (mcrat_hip_pool_*): the reference's ranks hold Poisson-sized lists (mclib.c:87-136), so the lengths
     # differ -- here by up to +-40 around the mean, adding up to n exactly
-    n_lists = max(1, int(round(n / float(args.rank_photons))))
-    lens = np.full(n_lists, n // n_lists, dtype=np.int64)
-    lens[: n - int(lens.sum())] += 1
-    if n_lists > 1 and lens.min() > 80:
-        d = np.random.default_rng(SEED).integers(-40, 41, n_lists // 2)
-        lens[: 2 * (n_lists // 2) : 2] += d
-        lens[1 : 2 * (n_lists // 2) : 2] -= d
-    assert int(lens.sum()) == n and lens.min() > 0
-    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    def list_layout(rank_photons):
+        k = max(1, int(round(n / float(rank_photons))))
+        ln = np.full(k, n // k, dtype=np.int64)
+        ln[: n - int(ln.sum())] += 1
+        if k > 1 and ln.min() > 80:
+            d = np.random.default_rng(SEED).integers(-40, 41, k // 2)
+            ln[: 2 * (k // 2) : 2] += d
+            ln[1 : 2 * (k // 2) : 2] -= d
+        assert int(ln.sum()) == n and ln.min() > 0
+        return k, ln, np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+    n_lists, lens, offs = list_layout(args.rank_photons)
+    n_lists0, lens0, offs0 = n_lists, lens, offs
     remaining = 1.0 / frame["fps"]
     stream = torch.cuda.current_stream().cuda_stream
     first_stream = rank * 100000           # RNG streams of this GPU's virtual ranks
@@ -456,10 +459,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def make_engine(mode, profile=False, per_sync=None, photons=None, lists=None, stream_base=None, stream=stream, share_from=None):
+    def make_engine(mode, profile=False, per_sync=None, photons=None, lists=None, stream_base=None, stream=stream, share_from=None, layout=None):
         if mode == "ranks":
             # a rank pool: every list its own length, stream and clock, all lists propagated by one launch (mcrat_hip_pool_*)
             src = ph if photons is None else photons
+            n_lists, lens, offs = layout if layout is not None else (n_lists0, lens0, offs0)
             lo, hi = (0, n_lists) if lists is None else lists
             sb = first_stream if stream_base is None else stream_base
             e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
@@ -491,18 +495,18 @@ def main():
             it += st.iterations
         return ev, ps, it
 
-    def run_pooled(l0, l1, k_frames, k_warm, photons=None, stream_base=None):
+    def run_pooled(l0, l1, k_frames, k_warm, photons=None, stream_base=None, layout=None, n_pools=None):
         """the lists [l0, l1) as --pools rank pools on their own HIP streams, a host thread each; k_warm untimed frames, then k_frames frames
         timed between two barriers -> (events, photon_steps, passes, seconds)"""
         import threading
-        pools = max(1, min(int(args.pools) if args.pools > 0 else 3, l1 - l0))
+        pools = max(1, min(n_pools if n_pools else (int(args.pools) if args.pools > 0 else 3), l1 - l0))
         engines, keep = [], []
         for p in range(pools):
             lo, hi = l0 + (p * (l1 - l0)) // pools, l0 + ((p + 1) * (l1 - l0)) // pools
             ts = torch.cuda.Stream()
             keep.append(ts)
             engines.append(make_engine("ranks", photons=photons, lists=(lo, hi), stream_base=stream_base, stream=ts.cuda_stream if pools > 1 else stream,
-                                       share_from=engines[0] if (engines and args.share_hydro) else None))
+                                       share_from=engines[0] if (engines and args.share_hydro) else None, layout=layout))
             engines[-1].snapshot_photons()
         tot = [None] * pools
         gate = threading.Barrier(pools + 1)
@@ -558,8 +562,12 @@ def main():
             achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
             full = (n == 1_000_000 and args.nzc == 64 and args.config == "cfg2")
             traffic, src = committed_traffic("*_rank_loop_kernel_pmc.json") if full else (None, None)
+            # ... and the same bytes over the WALL time of the timed region (the headline's launch shape: the pools' launches overlap)
+            headline_gbs = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps / dt / 1e9
             roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
+                    "frac": achieved / HBM_PEAK_GBS, "frac_kernel_alone": achieved / HBM_PEAK_GBS,
+                    "frac_headline": headline_gbs / HBM_PEAK_GBS, "achieved_headline": headline_gbs,
+                    "traffic": traffic, "traffic_source": src,
                     "bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches),
                     "note": "latency-bound persistent kernel (one workgroup walks one list's whole frame; the forced "
                             "re-location pass of the new frame is inside the launch), measured on ONE pool holding all lists -- one "
@@ -611,10 +619,15 @@ def main():
             ev_ms = (ps.event_kernel_ms - p0.event_kernel_ms) / max(1, launches)
             achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * n / (avg_ms * 1e-3) / 1e9
             traffic, src = committed_traffic("*_step_kernel_pmc.json") if (n == 1_000_000 and args.nzc == 64) else (None, None)
+            pass_gbs = ALGORITHMIC_BYTES_PER_PHOTON_STEP * n / (dt / k_steps) / 1e9      # the whole pass (step + event + launch gaps), wall time of the timed passes
             roof = {"kernel": "step_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src,
                     "bytes_per_launch": ALGORITHMIC_BYTES_PER_PHOTON_STEP * n, "avg_launch_ms": avg_ms,
-                    "launches": int(launches), "event_kernel_avg_ms": ev_ms}
+                    "launches": int(launches), "event_kernel_avg_ms": ev_ms,
+                    "whole_pass": {"note": "the same 110 B x N over a whole loop pass -- step_kernel, then event_kernel on one workgroup, which the next "
+                                           "step waits for: what a single list of N photons (and a shared-clock shard) actually gets",
+                                   "ms_per_pass": dt * 1e3 / k_steps, "kernels_ms_per_pass": avg_ms + ev_ms,
+                                   "achieved": pass_gbs, "frac": pass_gbs / HBM_PEAK_GBS}}
             p.close()
         e.close()
         return dict(events=st.frame_scatt_cnt - sc0, photon_steps=n * k_steps, passes=k_steps, seconds=dt, roofline=roof,
@@ -746,6 +759,25 @@ def main():
                                        "exact": res["exact"], "fast": res["fast"]}
         except Exception as ex:
             fast = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
+    # lists of the reference's whole range of photons per rank (sample_mc.par:21-22: 1000 - 5000): the same n photons cut into lists of
+    # about 1000, 2000 and 5000 -- the loop's work per event grows with the list (every event re-locates the whole list), so the
+    # comparable figure is photon-steps per second
+    sweep = None
+    if rank == 0 and world == 1 and args.mode == "ranks" and args.other_mode and args.config != "cfg5":
+        try:
+            sweep = {"note": "the same %d photons as lists of about 1000 / 2000 / 5000 photons (the reference's range of photons per rank); one hydro "
+                             "frame per step, 5 timed frames after 1; photon-steps/s is the comparable figure -- an event re-locates its whole list, "
+                             "so events/s falls as the lists grow" % n, "runs": []}
+            for per in (1000, 2000, 5000):
+                lay = list_layout(per)
+                ev_w, ps_w, it_w, dt_w = run_pooled(0, lay[0], 5, 1, layout=lay)
+                sweep["runs"].append({"rank_photons": per, "lists": int(lay[0]), "ms_per_step": dt_w * 1e3 / 5, "photon_steps_per_s": ps_w / dt_w,
+                                      "scatter_events_per_s": ev_w / dt_w, "passes_per_list": it_w / 5.0 / lay[0]})
+            r_ = [x["photon_steps_per_s"] for x in sweep["runs"]]
+            sweep["max_over_min"] = max(r_) / min(r_)
+        except Exception as ex:
+            sweep = {"error": "%s: %s" % (type(ex).__name__, ex)}
 
     other = None
     if rank == 0 and world == 1 and args.other_mode:
@@ -1016,6 +1048,7 @@ def main():
             "loop_passes": main_res["passes"],
             "roofline": main_res["roofline"],
             "strong": strong,
+            "rank_photons_sweep": sweep,
             "fast_mode": fast,
             "other_mode": other,
             "pcie_inclusive": pcie,

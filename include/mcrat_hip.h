@@ -576,7 +576,12 @@ int mcrat_hip_shared_clock_buffers(mcrat_hip_ctx *ctx, void **send, void **recv)
  *                                          entries are ignored);
  *   mcrat_hip_shared_clock_exchange        between propose and resolve: a kernel writes this rank's proposal into every peer's buffer and
  *                                          stamps it (_push), a second one waits for the stamps of all ranks (_wait; bounded: a peer that
- *                                          never arrives makes the next poll fail with MCRAT_HIP_EHIP instead of hanging the GPU).
+ *                                          never arrives makes the next poll fail with MCRAT_HIP_EHIP instead of hanging the GPU).  A wait
+ *                                          that gives up copies nothing and parks the loop: the photons stay at the last pass every rank
+ *                                          completed, and the rounds still queued (a captured batch) return at once instead of each
+ *                                          spinning its own budget;
+ *   mcrat_hip_shared_clock_reset_exchange  after such a failure: clears this rank's give-up word, round number and stamps.  Every rank calls
+ *                                          it, then the ranks synchronise (any barrier), then begin_frame as usual.
  * All on the context's stream and without per-round arguments (the round number lives on the device, the wait kernel copies the round's
  * proposals to the fixed place resolve reads), so propose / exchange / resolve capture into a hipGraph like the collective.  Every rank must run the same
  * number of rounds (rounds after the frame's end are no-ops but still exchange), as with the all-gather. */
@@ -586,10 +591,26 @@ int mcrat_hip_shared_clock_set_peers(mcrat_hip_ctx *ctx, void *const *peer_recv,
 int mcrat_hip_shared_clock_exchange_push(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_exchange_wait(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_exchange(mcrat_hip_ctx *ctx);
+int mcrat_hip_shared_clock_reset_exchange(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_propose(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_resolve(mcrat_hip_ctx *ctx);
 int mcrat_hip_shared_clock_poll(mcrat_hip_ctx *ctx, int *frame_done, mcrat_hip_frame_stats *stats);   /* synchronises the stream */
 int mcrat_hip_shared_clock_finish(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *stats);   /* apply the pending advance, final stats */
+
+/* The random stream as an INPUT ("tape").  MCRaT draws everything from one sequential gsl_rng_ranlxs0 stream
+ * (Src/mcrat.c:99-103, reseeded per frame :701).  The engine's default source is its own keyed generator (every comparison in tests/ uses it on both
+ * sides); with a tape the caller supplies the stream instead -- the doubles MCRaT's generator returned (gsl_rng_type::get_double, in [0,1)), recorded
+ * in call order by tools/ref_harness from the UNMODIFIED reference -- and the loop consumes it exactly as MCRaT does:
+ *   per pass, one gsl_rng_uniform_pos for every slot with a cell (nearest_block_index != -1), in ascending slot order   (Src/mclib.c:646-675)
+ *   then photonEvent's draws for each candidate it tries, in its call order                       (Src/electron.c:81,196,217-233; Src/mcrat_scattering.c:519-574)
+ * gsl_rng_uniform_pos skips zeros, gsl_ran_gaussian (polar method) takes as many pairs as it needs: as GSL publishes them.  The photons after a frame
+ * can then be held against MCRaT's own, photon for photon ("Pinning parity with your GSL").  A validation mode: one list per context
+ * (refused on rank pools, virtual ranks, the shared clock and with the cyclo-synchrotron switch), the free-path draws of a pass taken by one
+ * workgroup.  uniforms == NULL or n == 0 returns to the keyed source.  While a tape is set the seed of begin_frame / propagate_frame is ignored and
+ * the tape is read on across frames (MCRaT's reseeding is part of the recorded stream).
+ *   mcrat_hip_rng_tape_position   entries read so far; *ran_out != 0 if the loop needed more than the tape holds (results then meaningless). */
+int mcrat_hip_set_rng_tape(mcrat_hip_ctx *ctx, const double *uniforms, long long n);
+int mcrat_hip_rng_tape_position(mcrat_hip_ctx *ctx, long long *position, int *ran_out);
 
 /* The device functions of the path, one at a time, on arrays -- for function-level parity tests against the reference functions
  * (tests/test_gpu_functions.py; the loop does not use this entry).  in / out: n rows of doubles, row layouts:

@@ -236,6 +236,8 @@ constexpr int SC_K = 4;              // candidates one GPU proposes per round
 constexpr int SC_MAX_WORLD = 16;
 constexpr int LOOP_DONE = 1;         // LoopState::done values
 constexpr int LOOP_MIDPASS = 2;      // shared clock only: the iteration is not decided yet, the step kernel must not redraw
+constexpr int LOOP_SC_GAVE_UP = 4;   // shared clock, device-initiated exchange: a peer's proposal never arrived; the list stays at its last complete pass
+                                     // (3 is LOOP_CS_HALT, launch.hpp)
 
 struct alignas(16) ScRecord {        // one candidate: 176 B
     double t;                        // time_to_scatter

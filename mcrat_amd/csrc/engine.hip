@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -16,6 +17,7 @@
 #include "../../include/mcrat_hip.h"
 #include "device_types.hpp"
 #include "launch.hpp"
+#include "rng.hpp"
 
 using namespace mcrat;
 
@@ -80,6 +82,7 @@ struct mcrat_hip_ctx {
     RngKey key{0, 0, 0};
     long long frame_photon_steps = 0;
     mcrat_hip_ctx *hydro_owner = nullptr;   // mcrat_hip_share_hydro: the staged frame (and cross-section table) are another context's
+    std::vector<mcrat_hip_ctx *> hydro_sharers;   // ... and, on that context, who reads its frame: they are cut loose before it changes or goes
     void *d_fast = nullptr;           // FAST mode's counters (FastCounts)
     bool pending_applied = false;     // step_locate_sample has applied the pending advance that LoopState still lists
     bool rank_current = false;        // a view whose frame rank_loop_kernel has run: it leaves no pending advance (until the next begin_frame)
@@ -88,6 +91,10 @@ struct mcrat_hip_ctx {
     int n_ranks = 0;
     int rank_block = 256;             // threads per list of the next launches (choose_rank_block)
     bool rank_fuse = true;            // ... and whether they use the build with the fused pass
+    // the random stream as an input (mcrat_hip_set_rng_tape): device copy of the caller's uniforms, the position reached, an error word
+    double *d_tape = nullptr;
+    long long tape_n = 0;
+    long long *d_tape_cursor = nullptr;   // {cursor, error word} in one 16-byte block
     bool rank_pipe = false;           // ... or rank_pipe_kernel (the passes pipelined; lists of up to 1024 slots, DIRECT optical depths)
     bool rank_block_fixed = false;
     double rank_passes_per_list = 0;  // of the last completed frame
@@ -246,16 +253,55 @@ static void destroy_view(mcrat_hip_ctx *v)
     delete v;
 }
 
+// Contexts that read another one's staged frame (mcrat_hip_share_hydro) hold raw device pointers into its buffers.  Before the owner
+// re-stages (the buffers are rewritten in place, or freed when the new frame is larger), replaces its cross-section table or is destroyed,
+// every sharer is cut loose: its stream is drained -- a launch of its own may still be reading the frame -- and it is left WITHOUT a frame
+// (have_hydro = false: begin_frame / run / share answer MCRAT_HIP_ESTATE until it shares or stages again).  One mutex guards the
+// bookkeeping, so that pools driven by their own host threads may share and re-stage; a sharer must not be inside a call of its own
+// while its owner re-stages (stage once per hydro frame behind a barrier and share again after it: INTEGRATION.md).
+static std::mutex g_share_mutex;
+static void sync_views(mcrat_hip_ctx *c);
+
+static void forget_shared_frame(mcrat_hip_ctx *s)          // (g_share_mutex held)
+{
+    s->hydro_owner = nullptr;
+    s->hy = HydroDev{};
+    s->hcol = HydroCols{};
+    s->hcol_buf = nullptr; s->hcol_M = 0; s->hcol_bytes = 0;
+    s->d_hot_table = nullptr;
+    s->have_hydro = false;
+    s->frame_open = false;
+    sync_views(s);
+}
+
+static void detach_sharers(mcrat_hip_ctx *owner, const char *why)
+{
+    std::lock_guard<std::mutex> lock(g_share_mutex);
+    for (mcrat_hip_ctx *s : owner->hydro_sharers) {
+        if (!s || s->hydro_owner != owner) continue;
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        forget_shared_frame(s);
+        s->last_error = std::string("the hydro frame this context shared is gone (its owner ") + why + "): share or stage a frame again";
+    }
+    owner->hydro_sharers.clear();
+}
+
 extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
 {
     if (!c) return;
     if (c->parent) { destroy_view(c); return; }
+    detach_sharers(c, "was destroyed");
     for (mcrat_hip_ctx *v : c->views)
         if (v) { v->parent = nullptr; destroy_view(v); }
     c->views.clear();
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     drop_graph(c);
-    if (c->hydro_owner) { c->hcol_buf = nullptr; c->d_hot_table = nullptr; c->hydro_owner = nullptr; }     // another context's
+    if (c->hydro_owner) {                                    // another context's frame: nothing of it is ours to free
+        std::lock_guard<std::mutex> lock(g_share_mutex);
+        auto &v = c->hydro_owner->hydro_sharers;
+        v.erase(std::remove(v.begin(), v.end(), c), v.end());
+        c->hcol_buf = nullptr; c->d_hot_table = nullptr; c->hydro_owner = nullptr;
+    }
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
@@ -274,6 +320,8 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->partials) (void)hipFree(c->partials);
     if (c->shortlist) (void)hipFree(c->shortlist);
     if (c->d_hot_table) (void)hipFree(c->d_hot_table);
+    if (c->d_tape) (void)hipFree(c->d_tape);
+    if (c->d_tape_cursor) (void)hipFree(c->d_tape_cursor);
     if (c->d_table_misses) (void)hipFree(c->d_table_misses);
     if (c->d_sc) (void)hipFree(c->d_sc);
     if (c->sc_own_send && c->sc_send) (void)hipFree(c->sc_send);
@@ -552,6 +600,7 @@ extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *t
         if (!(thermal_table[k] == thermal_table[k])) { c->last_error = "NaN in the cross-section table"; return MCRAT_HIP_EINVAL; }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     release_shared_hydro(c);
+    detach_sharers(c, "replaced its cross-section table");   // they read this table too
     if (c->d_hot_table) { (void)hipFree(c->d_hot_table); c->d_hot_table = nullptr; }
     HIPCHK(c, hipMalloc((void **)&c->d_hot_table, count * sizeof(double)));
     HIPCHK(c, hipMemcpy(c->d_hot_table, thermal_table, count * sizeof(double), hipMemcpyHostToDevice));
@@ -816,14 +865,11 @@ static int stage_hydro(mcrat_hip_ctx *c, const mcrat_hip_hydro *h, int M, const 
 // a context that reads another one's staged frame (mcrat_hip_share_hydro) holds that context's pointers: forget them before staging its own
 static void release_shared_hydro(mcrat_hip_ctx *c)
 {
+    std::lock_guard<std::mutex> lock(g_share_mutex);
     if (!c->hydro_owner) return;
-    c->hydro_owner = nullptr;
-    c->hy = HydroDev{};
-    c->hcol = HydroCols{};
-    c->hcol_buf = nullptr; c->hcol_M = 0; c->hcol_bytes = 0;
-    c->d_hot_table = nullptr;
-    c->have_hydro = false;
-    sync_views(c);
+    auto &v = c->hydro_owner->hydro_sharers;
+    v.erase(std::remove(v.begin(), v.end(), c), v.end());
+    forget_shared_frame(c);
 }
 
 // Several contexts on one GPU that are in the same hydro frame (rank pools on their own streams, bench.py --pools) need
@@ -845,6 +891,7 @@ extern "C" int mcrat_hip_share_hydro(mcrat_hip_ctx *c, mcrat_hip_ctx *owner)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(owner->stream));            // the owner's staging kernels have finished
     release_shared_hydro(c);
+    detach_sharers(c, "shares another context's frame now");   // its own buffers go
     if (c->hy_buf) { HIPCHK(c, hipFree(c->hy_buf)); c->hy_buf = nullptr; c->hy_bytes = 0; }
     if (c->grid_buf) { HIPCHK(c, hipFree(c->grid_buf)); c->grid_buf = nullptr; c->grid_bytes = 0; }
     if (c->hcol_buf) { HIPCHK(c, hipFree(c->hcol_buf)); c->hcol_buf = nullptr; c->hcol_bytes = 0; }
@@ -855,7 +902,11 @@ extern "C" int mcrat_hip_share_hydro(mcrat_hip_ctx *c, mcrat_hip_ctx *owner)
     for (int k = 0; k < 4; ++k) c->hot_grid[k] = owner->hot_grid[k];
     apply_hot_table(c);                                        // (the count of lookups outside the table stays this context's own)
     c->have_hydro = true;
-    c->hydro_owner = owner;
+    {
+        std::lock_guard<std::mutex> lock(g_share_mutex);
+        c->hydro_owner = owner;
+        owner->hydro_sharers.push_back(c);
+    }
     c->frame_open = false;
     drop_graph(c);
     sync_views(c);
@@ -866,6 +917,7 @@ extern "C" int mcrat_hip_share_hydro(mcrat_hip_ctx *c, mcrat_hip_ctx *owner)
 static int ensure_hcol(mcrat_hip_ctx *c, int M)
 {
     release_shared_hydro(c);
+    detach_sharers(c, "staged another frame");              // the buffers they point into are about to be rewritten or freed
     const size_t stride = align_up(sizeof(double) * (size_t)M, 256), total = 19 * stride;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->hcol_buf && c->hcol_bytes < total) { HIPCHK(c, hipFree(c->hcol_buf)); c->hcol_buf = nullptr; c->hcol_bytes = 0; }
@@ -2063,6 +2115,7 @@ extern "C" int mcrat_hip_pool_create(mcrat_hip_ctx *c, int n_ranks, int slots_pe
     if (!c || n_ranks <= 0 || slots_per_rank <= 0) return MCRAT_HIP_EINVAL;
     if (c->parent) { c->last_error = "a rank view cannot hold a pool"; return MCRAT_HIP_ESTATE; }
     if (c->sc_world > 0) { c->last_error = "shared clock and rank pool exclude each other"; return MCRAT_HIP_ESTATE; }
+    if (c->d_tape) { c->last_error = "a context with a tape of uniforms holds one list (mcrat_hip_set_rng_tape)"; return MCRAT_HIP_ESTATE; }
     const size_t stride = align_up((size_t)slots_per_rank, 2 * STEP_BLOCK);
     if (stride * (size_t)n_ranks > 0x7fffffffull - 2 * STEP_BLOCK) { c->last_error = "rank pool: more than 2^31 slots"; return MCRAT_HIP_EINVAL; }
     for (mcrat_hip_ctx *v : c->views)
@@ -2268,10 +2321,64 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
     return MCRAT_HIP_OK;
 }
 
+// the event half of a pass from the context's random source: the keyed streams, or the caller's tape (then preceded by the pass's free-path
+// draws in slot order, kernels.hip tape_draw_kernel)
+static hipError_t launch_event_of(mcrat_hip_ctx *c)
+{
+    if (c->d_tape) {
+        TapeDev t;
+        t.u = c->d_tape; t.n = c->tape_n; t.cursor = c->d_tape_cursor; t.error = reinterpret_cast<int *>(c->d_tape_cursor + 1);
+        return launch_tape_pass(c->kc, c->ph, c->hy, c->d_state, c->key, t, c->partials, c->step_blocks, c->shortlist, c->stream);
+    }
+    return launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream);
+}
+
 static int launch_iteration(mcrat_hip_ctx *c, bool force)
 {
     HIPCHK(c, launch_step(c->kc, force, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
-    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+    HIPCHK(c, launch_event_of(c));
+    return MCRAT_HIP_OK;
+}
+
+// The random stream as an INPUT (SURVEY.md section 8c "tape").  MCRaT draws everything from one sequential ranlxs0 stream
+// (mcrat.c:99-103,701); a maintainer who records that stream (tools/ref_harness: the doubles the generator returned, in call order) hands it
+// over here and the loop consumes it exactly as MCRaT does -- one gsl_rng_uniform_pos per located slot in ascending slot order
+// (mclib.c:646-675), then photonEvent's draws (electron.c:81,196,217-233; mcrat_scattering.c:519-574), gsl_rng_uniform_pos skipping zeros and the
+// polar Gaussian taking as many pairs as it needs -- so that photons can be compared with MCRaT's own, photon for photon.  A validation mode: one
+// list per context (no rank pool, no shared clock, no cyclo-synchrotron hook), the free-path draws of a pass walked by one workgroup.
+// n == 0 (or uniforms == NULL) returns the context to its keyed streams.  The seed of begin_frame is ignored while a tape is set.
+extern "C" int mcrat_hip_set_rng_tape(mcrat_hip_ctx *c, const double *uniforms, long long n)
+{
+    if (!c || n < 0) return MCRAT_HIP_EINVAL;
+    if (c->parent || c->is_pool || c->n_ranks > 0 || c->cfg.virtual_rank_photons > 0 || c->sc_world > 0 || c->cfg.cyclosynchrotron_switch) {
+        c->last_error = "the tape of uniforms is for one list with one clock (no rank pool, virtual ranks, shared clock or cyclo-synchrotron hook)";
+        return MCRAT_HIP_ESTATE;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drop_graph(c);
+    if (c->d_tape) { (void)hipFree(c->d_tape); c->d_tape = nullptr; c->tape_n = 0; }
+    if (!uniforms || n == 0) return MCRAT_HIP_OK;
+    for (long long k = 0; k < n; ++k)
+        if (!(uniforms[k] >= 0.0 && uniforms[k] < 1.0)) { c->last_error = "the tape holds a value outside [0, 1)"; return MCRAT_HIP_EINVAL; }
+    if (!c->d_tape_cursor) HIPCHK(c, hipMalloc((void **)&c->d_tape_cursor, 2 * sizeof(long long)));
+    HIPCHK(c, hipMemset(c->d_tape_cursor, 0, 2 * sizeof(long long)));
+    HIPCHK(c, hipMalloc((void **)&c->d_tape, sizeof(double) * (size_t)n));
+    HIPCHK(c, hipMemcpy(c->d_tape, uniforms, sizeof(double) * (size_t)n, hipMemcpyHostToDevice));
+    c->tape_n = n;
+    return MCRAT_HIP_OK;
+}
+
+// how far the tape has been read (entries consumed so far, zeros skipped by uniform_pos included); *ran_out != 0: the loop needed more entries
+// than the tape holds (its results are then meaningless).  Synchronises the stream.
+extern "C" int mcrat_hip_rng_tape_position(mcrat_hip_ctx *c, long long *position, int *ran_out)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->d_tape) return MCRAT_HIP_ESTATE;
+    long long h[2] = {0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, c->d_tape_cursor, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (position) *position = h[0];
+    if (ran_out) *ran_out = (int)(h[1] & 0xffffffffll) != 0;
     return MCRAT_HIP_OK;
 }
 
@@ -2320,7 +2427,7 @@ static void choose_rank_pipe(mcrat_hip_ctx *c)
 static void choose_rank_block(mcrat_hip_ctx *c)
 {
     if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) {
-        c->rank_block = (atoi(e) == 128) ? 128 : 256;
+        c->rank_block = (atoi(e) == 128) ? 128 : (atoi(e) == 512 ? 512 : 256);
         c->rank_fuse = c->rank_passes_per_list < 48.0;
         if (const char *f = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = atoi(f) != 0;
         choose_rank_pipe(c);
@@ -2334,6 +2441,9 @@ static void choose_rank_block(mcrat_hip_ctx *c)
     // 4098 lists 2.50 -> 2.32 ms; 2049 lists no difference; 1025 lists 0.83 -> 0.85 ms)
     const bool very_many = c->n_ranks >= 12 * cus && longest_rank_list(c) <= 1024;
     c->rank_block = ((many && c->rank_passes_per_list >= 48.0) || very_many) ? 128 : 256;
+    // lists of thousands of photons (sample_mc.par:21-22 allows 5000 per rank) of which there are about as many as CUs, or fewer: a list has its
+    // CU to itself whatever the workgroup size, so it gets 512 threads -- a pass takes half the trips (200 lists of 5000 photons, cfg2: 5.2 -> ms)
+    if (longest_rank_list(c) > 1088 && c->n_ranks <= cus + cus / 4) c->rank_block = 512;
     // the build with the fused pass (kernels.hip, rank_loop_kernel<.., FUSE>) for frames that looked optically thin last time (or
     // have not been seen yet): there most slots change cell between two events
     // (not in spherical geometry: two slots' acos / atan2 side by side cost the fused build 50 B of scratch per lane, and the spherical
@@ -2438,7 +2548,7 @@ extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_h
                 HIPCHK(c, launch_step(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
                 c->find_switch = 0;
                 HIPCHK(c, hipEventRecord(c->ev[3 * b + 1], c->stream));
-                HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+                HIPCHK(c, launch_event_of(c));
                 HIPCHK(c, hipEventRecord(c->ev[3 * b + 2], c->stream));
             }
         } else {
@@ -3042,7 +3152,7 @@ extern "C" int mcrat_hip_step_event(mcrat_hip_ctx *c, mcrat_hip_frame_stats *sta
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->frame_open || c->n_ranks > 0) return MCRAT_HIP_ESTATE;
-    HIPCHK(c, launch_event(c->kc, c->ph, c->hy, c->d_state, c->key, c->partials, c->step_blocks, c->shortlist, c->stream));
+    HIPCHK(c, launch_event_of(c));
     c->pending_applied = false;
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(LoopState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3145,7 +3255,20 @@ extern "C" int mcrat_hip_shared_clock_exchange_wait(mcrat_hip_ctx *c)
     if (!c->sc_device || !c->sc_peers_set || !c->frame_open) return MCRAT_HIP_ESTATE;
     int spins = 4000000;                                             // a few seconds: ranks enter a frame together (a barrier on the host)
     if (const char *e = getenv("MCRAT_HIP_SC_WAIT_SPINS")) spins = atoi(e) > 0 ? atoi(e) : spins;
-    HIPCHK(c, launch_sc_wait(c->sc_flags, c->sc_recv, c->sc_gather, c->sc_world, spins, c->stream));
+    HIPCHK(c, launch_sc_wait(c->sc_flags, c->sc_recv, c->sc_gather, c->sc_world, spins, c->d_state, c->stream));
+    return MCRAT_HIP_OK;
+}
+
+// After a wait has given up (mcrat_hip_shared_clock_poll answers MCRAT_HIP_EHIP) the ranks' round numbers may be out of step.  Every rank calls this --
+// its give-up word, its round number and the stamps its peers left are cleared --, then the ranks synchronise (any barrier: a peer must not push
+// its first new round before this rank has cleared its stamps), then begin_frame as usual.
+extern "C" int mcrat_hip_shared_clock_reset_exchange(mcrat_hip_ctx *c)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->sc_device) return MCRAT_HIP_ESTATE;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemset(c->sc_flags, 0, sizeof(unsigned long long) * (size_t)SC_FLAG_WORDS));
+    c->frame_open = false;
     return MCRAT_HIP_OK;
 }
 

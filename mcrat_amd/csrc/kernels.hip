@@ -610,18 +610,37 @@ struct EventWalk {
 // returns false on a rejection (nothing was stored; s is then unspecified); scatter_finish completes an accepted scattering -- it cannot
 // fail -- and returns tau_new, the optical depth of the new momentum in the cached cell (see commit_scatter).
 // WAVE: called by all 64 lanes of a wavefront with the same arguments (event_block's walk); see phys::sample_thermal_electron.
-struct EventMid {
+// Where an event's random numbers come from (rng.hpp): the engine's keyed streams -- one per (pass, candidate), any position one addition
+// away, which is what the wave-parallel samplers use -- or the caller's tape (mcrat_hip_set_rng_tape), one sequential stream whose position
+// is a device word: a candidate's draws start where the pass's free-path draws (tape_draw_kernel) or the previous candidate stopped.
+struct KeyedSource {
+    using Stream = EventStream;
+    static constexpr bool wave_parallel = true;
+    __device__ __forceinline__ Stream open(const RngKey &key, unsigned long long iter, uint32_t slot) const { return event_stream(key.seed, iter, slot, key.stream); }
+    __device__ __forceinline__ void close(const Stream &) const {}
+};
+struct TapeSource {
+    using Stream = TapeStream;
+    static constexpr bool wave_parallel = false;     // (uniform_pos and the polar method consume as many entries as they need: no skipping ahead)
+    TapeDev t;
+    __device__ __forceinline__ Stream open(const RngKey &, unsigned long long, uint32_t) const { Stream s = {t.u, t.n, *t.cursor, t.error}; return s; }
+    __device__ __forceinline__ void close(const Stream &s) const { *t.cursor = s.pos; }
+};
+
+template <class STREAM>
+struct EventMidT {
     phys::ScatterMid sm;
     double beta[3];
     double w, nsig, gam, kf;
     double fluid_temp;
-    EventStream rng;
+    STREAM rng;
 };
+using EventMid = EventMidT<EventStream>;
 
-template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class SRC = KeyedSource>
 __device__ __forceinline__ bool scatter_decide(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter,
                                                uint32_t rng_slot, int cell, const double r[3], const double p[4], const double pc[4], double s[4],
-                                               EventMid &m)
+                                               EventMidT<typename SRC::Stream> &m, const SRC &src = SRC())
 {
     MC_STAMP(st, 2);
     m.fluid_temp = hy.temp[cell];                          // mclib.c:1148
@@ -631,19 +650,23 @@ __device__ __forceinline__ bool scatter_decide(const HydroDev &hy, LoopState *st
     phys::cos_sin_of_atan2(r[1], r[0], cphi, sphi);        // ph_phi, mclib.c:1151
     phys::cell_beta<DIMS>(f, cphi, sphi, m.beta);          // mclib.c:1167-1174
     if constexpr (STOKES) phys::stokes_rotation(m.beta, p + 1, pc + 1, s);   // mclib.c:1227
-    m.rng = event_stream(key.seed, iter, rng_slot, key.stream);
+    m.rng = src.open(key, iter, rng_slot);
     const double k2e = hy.k2e ? hy.k2e[cell] : 0.0;
     double el[4];
     MC_STAMP(st, 3);
-    phys::single_thermal_electron<WAVE>(el, m.fluid_temp, k2e, pc, m.rng);   // mclib.c:1234
+    phys::single_thermal_electron<WAVE && SRC::wave_parallel>(el, m.fluid_temp, k2e, pc, m.rng);   // mclib.c:1234
     MC_STAMP(st, 4);
-    return phys::single_scatter_begin<STOKES>(el, pc, s, m.sm, m.rng);       // mclib.c:1245 as far as kleinNishinaScatter's test
+    const bool ok = phys::single_scatter_begin<STOKES>(el, pc, s, m.sm, m.rng);   // mclib.c:1245 as far as kleinNishinaScatter's test
+    if (!ok) src.close(m.rng);
+    return ok;
 }
 
-template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
-__device__ __forceinline__ void scatter_finish(const HydroDev &hy, LoopState *st, EventMid &m, double p[4], double pc[4], double s[4], double &tau_new)
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class SRC = KeyedSource>
+__device__ __forceinline__ void scatter_finish(const HydroDev &hy, LoopState *st, EventMidT<typename SRC::Stream> &m, double p[4], double pc[4], double s[4],
+                                               double &tau_new, const SRC &src = SRC())
 {
     phys::single_scatter_finish<STOKES>(m.sm, pc, s, m.rng);           // the rest of mclib.c:1245
+    src.close(m.rng);
     MC_STAMP(st, 5);
     const double nb[3] = {-m.beta[0], -m.beta[1], -m.beta[2]};
     phys::boost_with<true>(nb, m.gam, m.kf, pc, p);                    // mclib.c:1265
@@ -656,16 +679,16 @@ __device__ __forceinline__ void scatter_finish(const HydroDev &hy, LoopState *st
     tau_new = phys::optical_depth_staged(m.beta, m.w, m.nsig, p[1], p[2], p[3], norm);
 }
 
-template <int DIMS, int GEOM, bool STOKES, bool WAVE = false>
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class SRC = KeyedSource>
 __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter,
                                              uint32_t rng_slot, int cell, const double r[3], double p[4], double pc[4], double s[4],
-                                             double &fluid_temp, double &tau_new)
+                                             double &fluid_temp, double &tau_new, const SRC &src = SRC())
 {
-    EventMid m;
-    const bool ok = scatter_decide<DIMS, GEOM, STOKES, WAVE>(hy, st, key, iter, rng_slot, cell, r, p, pc, s, m);
+    EventMidT<typename SRC::Stream> m;
+    const bool ok = scatter_decide<DIMS, GEOM, STOKES, WAVE, SRC>(hy, st, key, iter, rng_slot, cell, r, p, pc, s, m, src);
     fluid_temp = m.fluid_temp;
     if (!ok) return false;
-    scatter_finish<DIMS, GEOM, STOKES, WAVE>(hy, st, m, p, pc, s, tau_new);
+    scatter_finish<DIMS, GEOM, STOKES, WAVE, SRC>(hy, st, m, p, pc, s, tau_new, src);
     return true;
 }
 
@@ -689,9 +712,9 @@ __device__ __forceinline__ void commit_scatter(const PH &ph, int i, const double
 }
 
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
-template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class PH>
+template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class PH, class SRC = KeyedSource>
 __device__ __forceinline__ int try_candidate(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
-                                             unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base)
+                                             unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base, const SRC &src = SRC())
 {
     // *scattered_ph_index (mclib.c:1341) is the last candidate photonEvent looked at; main() does not call
     // photonEvent at all when even the first free time exceeds the frame (mcrat.c:777,834)
@@ -729,7 +752,7 @@ __device__ __forceinline__ int try_candidate(const PH &ph, const HydroDev &hy, L
         }
     }
     double fluid_temp, tau_new;
-    if (!scatter_core<DIMS, GEOM, STOKES, WAVE>(hy, st, key, iter, (uint32_t)(i - slot_base) + key.slot_base, cell, r, p, pc, s, fluid_temp, tau_new)) {
+    if (!scatter_core<DIMS, GEOM, STOKES, WAVE, SRC>(hy, st, key, iter, (uint32_t)(i - slot_base) + key.slot_base, cell, r, p, pc, s, fluid_temp, tau_new, src)) {
         w.rej += 1;
         return EV_RUNNING;
     }
@@ -763,10 +786,10 @@ using EventShared = EventSharedT<EVENT_BLOCK>;
 // (sh.raw[0..n_raw), complete below t_cut unless it overflowed), walk it as photonEvent does, refill from
 // time_to_scatter if it runs out, then the bookkeeping of mcrat.c:782-784 / 837-845 into *st.
 // All BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
-template <int DIMS, int GEOM, bool STOKES, int BLOCK, class PH>
+template <int DIMS, int GEOM, bool STOKES, int BLOCK, class PH, class SRC = KeyedSource>
 __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
                                             EventSharedT<BLOCK> &sh, int n_raw, Cand gmin, int base, int n,
-                                            unsigned long long iter, double dt_max, int last_idx, double t_est)
+                                            unsigned long long iter, double dt_max, int last_idx, double t_est, const SRC &src = SRC())
 {
     const int tid = threadIdx.x;
     int n_list = (n_raw > BLOCK) ? 0 : n_raw;              // overflowed: incomplete, ignore it
@@ -806,7 +829,7 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
                 status = EV_DONE;
             }
             for (int c = 0; c < n_list && status == EV_NEED_MORE; ++c) {
-                if (try_candidate<DIMS, GEOM, STOKES, WAVE_WALK>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base) == EV_DONE)
+                if (try_candidate<DIMS, GEOM, STOKES, WAVE_WALK>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base, src) == EV_DONE)
                     status = EV_DONE;
             }
             if (status == EV_NEED_MORE) {
@@ -863,9 +886,9 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
     }
 }
 
-template <int DIMS, int GEOM, bool STOKES>
+template <int DIMS, int GEOM, bool STOKES, class SRC = KeyedSource>
 __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroDev hy, LoopState *st, RngKey key,
-                                                            const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl)
+                                                            const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl, SRC src)
 {
     static_assert(EVENT_BLOCK == SHORTLIST_CAP, "one thread per shortlist entry");
     __shared__ EventShared sh;
@@ -892,8 +915,103 @@ __global__ __launch_bounds__(EVENT_BLOCK) void event_kernel(PhotonDev ph, HydroD
     for (int wv = 0; wv < EVENT_BLOCK / 64; ++wv) g.offer(sh.wt[wv], sh.wi[wv]);
     Cand gmin;
     gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
-    event_block<DIMS, GEOM, STOKES, EVENT_BLOCK>(PtrCols(ph), hy, st, key, sh, n_raw, gmin, 0, ph.n, iter, dt_max, last_idx, t_est);
+    event_block<DIMS, GEOM, STOKES, EVENT_BLOCK>(PtrCols(ph), hy, st, key, sh, n_raw, gmin, 0, ph.n, iter, dt_max, last_idx, t_est, src);
     if (tid == 0) sl->count = 0;
+}
+
+// ------------------------------------------------------------------ the random stream as an input (mcrat_hip_set_rng_tape)
+// calcMeanFreePath with the caller's tape (mclib.c:646-675): the slots are taken in ascending order, every slot with a cell (idx != -1) consumes
+// one gsl_rng_uniform_pos -- the next entry of the tape that is not 0 -- and its free time is -ln(u) / (tau' c).  Runs after step_kernel, which has
+// re-located the slots and refreshed their optical depths exactly as in the keyed mode (its own keyed draws are overwritten here, with its
+// minimum and shortlist): ONE workgroup walks the list in chunks of TAPE_BLOCK slots -- a chunk's located slots are ranked by a block scan, the
+// tape window behind the cursor is compacted to its non-zero entries by another, slot k of the chunk takes entry k.  A validation mode (this is a
+// serial dependency through the whole list by construction), not a fast one.
+constexpr int TAPE_BLOCK = 1024;
+
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *s_w, int &total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+    if (lane == 63) s_w[w] = x;
+    __syncthreads();
+    if (w == 0) {
+        int t = lane < TAPE_BLOCK / 64 ? s_w[lane] : 0;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) { const int y = __shfl_up(t, off, 64); if (lane >= off) t += y; }
+        if (lane < TAPE_BLOCK / 64) s_w[lane] = t;
+    }
+    __syncthreads();
+    total = s_w[TAPE_BLOCK / 64 - 1];
+    const int before = (w > 0 ? s_w[w - 1] : 0) + x - v;
+    __syncthreads();
+    return before;
+}
+
+__global__ __launch_bounds__(TAPE_BLOCK) void tape_draw_kernel(PhotonDev ph, const LoopState *__restrict__ st, TapeDev tape, Cand *__restrict__ block_min,
+                                                                int n_blocks, Shortlist *sl)
+{
+    __shared__ double s_u[TAPE_BLOCK];            // the chunk's uniforms: the tape's next non-zero entries
+    __shared__ int s_w[TAPE_BLOCK / 64];
+    __shared__ long long s_pos;
+    __shared__ double s_wt[TAPE_BLOCK / 64];
+    __shared__ int s_wi[TAPE_BLOCK / 64];
+    if (st->done) return;
+    const int tid = threadIdx.x;
+    const double t_cut = st->t_cut;
+    long long pos = *tape.cursor;
+    if (tid == 0) sl->count = 0;
+    __syncthreads();
+    MinCand best;
+    best.init();
+    for (int c0 = 0; c0 < ph.n; c0 += TAPE_BLOCK) {
+        const int i = c0 + tid;
+        const bool valid = i < ph.n && (ph.flags[i] & FLAG_VALID);
+        const bool located = valid && ph.idx[i] != -1;
+        int need = 0;
+        const int rank = block_exclusive_scan_1024(located ? 1 : 0, s_w, need);
+        // the next `need` non-zero entries of the tape, window by window
+        int have = 0;
+        while (have < need) {
+            const long long q = pos + tid;
+            const double v = q < tape.n ? tape.u[q] : 0.5;
+            const bool nz = v != 0.0;
+            int found = 0;
+            const int k = block_exclusive_scan_1024(nz ? 1 : 0, s_w, found);
+            if (nz && have + k < need) s_u[have + k] = v;
+            if (nz && have + k == need - 1) s_pos = q + 1;                 // the entry that completes the chunk: the cursor stops behind it
+            if (q >= tape.n && have + k < need) *tape.error = 1;             // an entry beyond the tape's end was needed
+            __syncthreads();
+            if (have + found >= need) { pos = s_pos; have = need; }
+            else { have += found; pos += TAPE_BLOCK; }
+            __syncthreads();
+        }
+        if (pos > tape.n) { if (tid == 0) *tape.error = 1; pos = tape.n; }
+        if (valid) {
+            double t = ph.tts[i];                                          // slots without a cell: 1e12 / c, stored by step_kernel (mclib.c:620,684)
+            if (located) {
+                t = div_by_c(ph.ntau[i] * log(s_u[rank]));                 // mclib.c:675-687
+                ph.tts[i] = t;
+            }
+            best.offer(t, i);
+            if (t < t_cut) shortlist_push(sl, t, i);
+        }
+        __syncthreads();
+    }
+    wave_min_pair_dpp(best.t, best.i);
+    if ((tid & 63) == 0) { s_wt[tid >> 6] = best.t; s_wi[tid >> 6] = best.i; }
+    __syncthreads();
+    if (tid == 0) {
+        MinCand m;
+        m.init();
+        for (int w = 0; w < TAPE_BLOCK / 64; ++w) m.offer(s_wt[w], s_wi[w]);
+        Cand c;
+        c.t = m.t; c.idx = m.i; c.pad = 0;
+        block_min[0] = c;
+        *tape.cursor = pos;
+    }
+    for (int b = 1 + tid; b < n_blocks; b += TAPE_BLOCK) { Cand c; c.t = INFINITY; c.idx = INT_MAX; c.pad = 0; block_min[b] = c; }
 }
 
 // ------------------------------------------------------------------ virtual ranks
@@ -924,7 +1042,7 @@ struct RankLayout {
 // 40 KB per list.  1000 lists of 1000 photons are then resident all at once.
 // The workgroup size is a template parameter: 256 threads per list when there are few lists (each list then gets the CU
 // it sits on) or the frame is optically thin (its cost is slow-path throughput per list), 128 otherwise; engine.hip picks.
-constexpr int rank_lds_bytes_per_slot(int block) { return block >= 256 ? 7 * (int)sizeof(double) + (int)sizeof(int) + 1 : 4 * (int)sizeof(double); }
+constexpr int rank_lds_bytes_per_slot(int block) { return block == 256 ? 7 * (int)sizeof(double) + (int)sizeof(int) + 1 : 4 * (int)sizeof(double); }
 #ifndef RANK_WAVES_PER_SIMD
 #define RANK_WAVES_PER_SIMD 2
 #endif
@@ -1009,7 +1127,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     // at the end; `ph` is the same PhotonDev with those column pointers aimed at LDS and the biases set, so every device
     // function below works on it unchanged (col[i - bias]).  (RESIDENT is a template parameter so that the pointers provably
     // address LDS and the accesses compile to ds_read / ds_write instead of flat loads.)
-    constexpr bool FULL_HOT = RANK_BLOCK >= 256;
+    constexpr bool FULL_HOT = RANK_BLOCK == 256;            // (512 threads: long lists, one per CU -- r and -1/tau at 32 B per slot reach 4096 slots)
     constexpr unsigned LDS_MASK = RESIDENT ? (FULL_HOT ? LIST_MASK_FULL : LIST_MASK_SMALL) : 0u;
     using Cols = ListCols<LDS_MASK>;
     static_assert(Cols::lds_bytes_per_slot == (RESIDENT ? (size_t)rank_lds_bytes_per_slot(RANK_BLOCK) : 0), "launch_rank_loop sizes the dynamic LDS with this");
@@ -2213,7 +2331,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void sc_propose_kernel(PhotonDev ph, L
     __shared__ int s_wi[EVENT_BLOCK / 64];
     const int tid = threadIdx.x;
     const int done = st->done;
-    if (done == LOOP_DONE) return;
+    if (done == LOOP_DONE || done == LOOP_SC_GAVE_UP) return;
     const bool midpass = done == LOOP_MIDPASS;
     const double cut = midpass ? sc->cut_mid : st->t_cut;          // the threshold the shortlist was filled with
     const int n_raw = sl->count;
@@ -2289,7 +2407,7 @@ __global__ __launch_bounds__(EVENT_BLOCK) void sc_resolve_kernel(PhotonDev ph, H
     __shared__ double s_seg[MAX_SEG];
     const int tid = threadIdx.x;
     const int done = st->done;
-    if (done == LOOP_DONE) return;
+    if (done == LOOP_DONE || done == LOOP_SC_GAVE_UP) return;
     if (tid == 0) {
         int o = 0;
         for (int g = 0; g < world; ++g) { s_off[g] = o; int n = all[g].n; n = n < 0 ? 0 : (n > SC_K ? SC_K : n); o += n; }
@@ -2600,9 +2718,25 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
         if (kc.stokes)
-            event_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl);
+            event_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl, KeyedSource());
         else
-            event_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl);
+            event_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl, KeyedSource());
+    });
+}
+
+// the second half of a pass with the caller's tape: the free-path draws in slot order, then the event reading on from where they stopped
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream)
+{
+    tape_draw_kernel<<<dim3(1), dim3(TAPE_BLOCK), 0, stream>>>(ph, st, tape, block_min, n_blocks, sl);
+    TapeSource src;
+    src.t = tape;
+    return dispatch(kc, [&](auto D, auto G) {
+        constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
+        if (kc.stokes)
+            event_kernel<DV, GV, true, TapeSource><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl, src);
+        else
+            event_kernel<DV, GV, false, TapeSource><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, key, block_min, n_blocks, sl, src);
     });
 }
 
@@ -2654,9 +2788,10 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
     // per-pass columns in LDS (32 B per slot with 128 threads, 61 B with 256: rank_loop_kernel) for lists of up to 1024 photons
     int lds_slots = 0;
     // (two 256-thread lists per CU: 13 KB of static LDS and 61 B per slot each within 160 KB -> 1088 slots; four 128-thread ones at 32 B: 1024)
-    const int lds_limit = (block == 128) ? 1024 : 1088;
+    // (512 threads -- lists of thousands of photons, one list per CU: 27 KB of static LDS and 32 B per slot within 160 KB -> 4096 slots)
+    const int lds_limit = (block == 128) ? 1024 : (block == 512 ? 4096 : 1088);
     if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && longest_list <= lds_limit) lds_slots = (longest_list + 15) & ~15;
-    size_t dyn = (size_t)lds_slots * rank_lds_bytes_per_slot(block == 128 ? 128 : 256);
+    size_t dyn = (size_t)lds_slots * rank_lds_bytes_per_slot(block == 128 ? 128 : (block == 512 ? 512 : 256));
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
         // static + dynamic LDS may exceed the 64 KiB default: the kernel must be told, and if the runtime refuses
@@ -2670,7 +2805,15 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                 kernel_global<<<dim3(n_ranks), dim3(threads), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
             }
         };
-        if (block == 128 && fuse && !TABLE_MODE) {
+        if (block == 512 && fuse && !TABLE_MODE && kc.geometry != GEOM_SPHERICAL) {
+            if constexpr (GV != GEOM_SPHERICAL) {
+                if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 512, true>, rank_loop_kernel<DV, GV, true, false, 512, true>, 512);
+                else launch(rank_loop_kernel<DV, GV, false, true, 512, true>, rank_loop_kernel<DV, GV, false, false, 512, true>, 512);
+            }
+        } else if (block == 512) {
+            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 512, false>, rank_loop_kernel<DV, GV, true, false, 512, false>, 512);
+            else launch(rank_loop_kernel<DV, GV, false, true, 512, false>, rank_loop_kernel<DV, GV, false, false, 512, false>, 512);
+        } else if (block == 128 && fuse && !TABLE_MODE) {
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, RANK_SMALL, true>, rank_loop_kernel<DV, GV, true, false, RANK_SMALL, true>, RANK_SMALL);
             else launch(rank_loop_kernel<DV, GV, false, true, RANK_SMALL, true>, rank_loop_kernel<DV, GV, false, false, RANK_SMALL, true>, RANK_SMALL);
         } else if (block == 128) {

@@ -27,6 +27,11 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
 // candidate selection + photonEvent + loop bookkeeping
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+// ... with the caller's tape of uniforms as the random source (mcrat_hip_set_rng_tape): the pass's free-path draws in slot order
+// (tape_draw_kernel, after launch_step), then the event reading on from where they stopped
+struct TapeDev;
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 // virtual ranks: every workgroup (of `block` = 128 or 256 threads) runs the whole loop of one independent photon list: the slots
 // [r * rank_stride, ...) -- rank_stride of them, or desc[r].len with the list's own seed and stream (rank pool); longest_list sizes the LDS copy
 // hook: (device memory) what the cyclo-synchrotron hook needs -- then lists with `cs` run it inside the loop instead of parking for
@@ -39,7 +44,7 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
 struct ScPeers { ScProposal *recv[SC_MAX_WORLD]; unsigned long long *flag[SC_MAX_WORLD]; };
 constexpr int SC_GAVE_UP_WORD = SC_MAX_WORLD, SC_ROUND_WORD = SC_MAX_WORLD + 1, SC_FLAG_WORDS = SC_MAX_WORLD + 2;
 hipError_t launch_sc_push(const ScProposal *send, const ScPeers &peers, unsigned long long *my_flags, int world, int rank, hipStream_t stream);
-hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins, hipStream_t stream);
+hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins, LoopState *st, hipStream_t stream);
 // FAST mode: every photon through the whole frame on its own clock (kernels.hip, fast_frame_kernel); the counters add up over launches
 struct FastCounts { unsigned long long photon_steps, scatterings, kn_rejections, relocated, not_found, unfinished, passes; };
 // desc != nullptr: the photons are the lists of a rank pool (list r in slots [r * stride, r * stride + desc[r].len), stride a multiple of 256);

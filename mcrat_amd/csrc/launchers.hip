@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "device_types.hpp"
 #include "launch.hpp"
+#include "rng.hpp"
 
 namespace mcrat {
 
@@ -11,6 +12,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
                        LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
@@ -33,6 +36,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
                        LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
@@ -49,6 +54,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
                        LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
@@ -65,6 +72,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
                        LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
@@ -81,6 +90,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
                        LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
@@ -97,6 +108,8 @@ hipError_t launch_step(const KernelConfig &kc, bool force_relocate, const Photon
                        LoopState *st, RngKey key, Cand *block_min, int blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key,
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
@@ -134,6 +147,12 @@ hipError_t launch_event(const KernelConfig &kc, const PhotonDev &ph, const Hydro
                         const Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream)
 {
     MCRAT_ROUTE(launch_event, kc, ph, hy, st, key, block_min, n_blocks, sl, stream);
+}
+
+hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, RngKey key, const TapeDev &tape,
+                            Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream)
+{
+    MCRAT_ROUTE(launch_tape_pass, kc, ph, hy, st, key, tape, block_min, n_blocks, sl, stream);
 }
 
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,

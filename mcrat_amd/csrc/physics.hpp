@@ -438,7 +438,8 @@ __device__ __forceinline__ double kn_cross_section(double e)
 // accepted scattering -- the sampling of the polar and azimuthal angles (:525-595; returns cos(theta) and (cos phi, sin phi) of the scattered
 // direction).  Nothing after the test can fail, which is what lets rank_pipe_kernel (kernels.hip) start the next pass while the scattering
 // is being completed.
-__device__ __forceinline__ bool kn_accept(double p0, double &energy_ratio, EventStream &rng)
+template <class RNG>
+__device__ __forceinline__ bool kn_accept(double p0, double &energy_ratio, RNG &rng)
 {
     energy_ratio = p0 * (1.0 / (M_EL * C_LIGHT));
     const double kn = kn_cross_section(energy_ratio);
@@ -446,9 +447,9 @@ __device__ __forceinline__ bool kn_accept(double p0, double &energy_ratio, Event
     return rand_num <= kn;
 }
 
-template <bool STOKES>
+template <bool STOKES, class RNG>
 __device__ __forceinline__ void kn_angles(double &cos_theta, double &cos_phi, double &sin_phi, double energy_ratio, double q, double u,
-                                          EventStream &rng)
+                                          RNG &rng)
 {
     double cos_theta_dum = 0, f_cos = 0, y_cos = 1;
     for (int it = 0; it < REJECTION_CAP && (y_cos > f_cos); ++it) {
@@ -485,7 +486,8 @@ __device__ __forceinline__ void kn_angles(double &cos_theta, double &cos_phi, do
 
 // ---------------------------------------------------------------- electron
 // Marsaglia polar method, one value per call (the published algorithm of gsl_ran_gaussian)
-__device__ __forceinline__ double gaussian(EventStream &rng, double sigma)
+template <class RNG>
+__device__ __forceinline__ double gaussian(RNG &rng, double sigma)
 {
     double x = 0, y = 0, r2 = 2;
     for (int it = 0; it < REJECTION_CAP && (r2 > 1.0 || r2 == 0.0); ++it) {
@@ -504,8 +506,8 @@ __device__ __forceinline__ double gaussian(EventStream &rng, double sigma)
 // y uniform up to 1/2), and every attempt takes exactly two numbers of the stream, so lane k tries attempt 64 j + k of round j --
 // the stream is a counter, any position is one addition away -- and the first accepted attempt in attempt order wins: the same
 // gamma and the same stream position as the one-lane loop, in a sixty-fourth of its trips.
-template <bool WAVE = false>
-__device__ __forceinline__ double sample_thermal_electron(double temp, double k2e, EventStream &rng)
+template <bool WAVE = false, class RNG>
+__device__ __forceinline__ double sample_thermal_electron(double temp, double k2e, RNG &rng)
 {
     double gamma = 1;
     if (temp >= 1e7) {
@@ -588,8 +590,8 @@ __device__ __forceinline__ double sample_thermal_electron(double temp, double k2
 }
 
 // electron.c:70-94 with sampleElectronTheta (:177-200) and rotateElectron (:126-175) in line
-template <bool WAVE = false>
-__device__ __forceinline__ void single_thermal_electron(double el_p[4], double temp, double k2e, const double ph_p[4], EventStream &rng)
+template <bool WAVE = false, class RNG>
+__device__ __forceinline__ void single_thermal_electron(double el_p[4], double temp, double k2e, const double ph_p[4], RNG &rng)
 {
     const double gamma = sample_thermal_electron<WAVE>(temp, k2e, rng);
     const double ig = rcp_nr(gamma);
@@ -639,9 +641,9 @@ struct ScatterMid {
     double s[4];                     // Stokes parameters rotated into the electron frame's basis (:225)
 };
 
-template <bool STOKES>
+template <bool STOKES, class RNG>
 __device__ __forceinline__ bool single_scatter_begin(const double el_comov[4], const double ph_comov[4], const double s_in[4], ScatterMid &m,
-                                                     EventStream &rng)
+                                                     RNG &rng)
 {
     const double ie0 = rcp_nr(el_comov[0]);
     m.el_v[0] = el_comov[1] * ie0; m.el_v[1] = el_comov[2] * ie0; m.el_v[2] = el_comov[3] * ie0;
@@ -668,8 +670,8 @@ __device__ __forceinline__ bool single_scatter_begin(const double el_comov[4], c
     return kn_accept(m.ph_pr[0], m.energy_ratio, rng);                            // :307 -> :509-523
 }
 
-template <bool STOKES>
-__device__ __forceinline__ void single_scatter_finish(const ScatterMid &m, double ph_comov[4], double s[4], EventStream &rng)
+template <bool STOKES, class RNG>
+__device__ __forceinline__ void single_scatter_finish(const ScatterMid &m, double ph_comov[4], double s[4], RNG &rng)
 {
     const double z_axis[3] = {0, 0, 1};
     const double *ph_orig = m.ph_pr;
@@ -731,8 +733,8 @@ __device__ __forceinline__ void single_scatter_finish(const ScatterMid &m, doubl
 }
 
 // the two halves in one call.  ph_comov and s are updated only when the scattering happens.
-template <bool STOKES>
-__device__ __forceinline__ bool single_scatter(const double el_comov[4], double ph_comov[4], double s[4], EventStream &rng)
+template <bool STOKES, class RNG>
+__device__ __forceinline__ bool single_scatter(const double el_comov[4], double ph_comov[4], double s[4], RNG &rng)
 {
     ScatterMid m;
     if (!single_scatter_begin<STOKES>(el_comov, ph_comov, s, m, rng)) return false;

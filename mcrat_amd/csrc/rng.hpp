@@ -75,6 +75,36 @@ struct EventStream {
     MC_HD double uniform_pos() { return bits_to_uniform_pos(next()); }
 };
 
+// The random stream as an INPUT (mcrat_hip_set_rng_tape; SURVEY.md section 8c, "tape"): a recorded sequence of the doubles MCRaT's generator
+// returned (gsl_rng_type::get_double of ranlxs0, in [0,1)), consumed strictly in the reference's call order -- one gsl_rng_uniform_pos per located
+// slot in ascending slot order (mclib.c:646-675; kernels.hip, tape_draw_kernel), then photonEvent's draws one after the other (electron.c:81,196,
+// 217-233; mcrat_scattering.c:519-574) from the position the pass has reached.  gsl_rng_uniform_pos redraws while it gets 0 and gsl_ran_gaussian's
+// polar method takes as many pairs as it needs: both fall out of reading the tape sequentially.  A tape that runs out raises *error and yields 0.5.
+struct TapeDev {
+    const double *u;
+    long long n;
+    long long *cursor;           // the next unread entry (device word: the loop's kernels advance it in stream order)
+    int *error;
+};
+
+struct TapeStream {
+    const double *u;
+    long long n, pos;
+    int *error;
+    MC_HD double next()
+    {
+        if (pos >= n) { *error = 1; return 0.5; }
+        return u[pos++];
+    }
+    MC_HD double uniform() { return next(); }                                  // gsl_rng_uniform: [0,1)
+    MC_HD double uniform_pos()                                                 // gsl_rng_uniform_pos: redraw while 0
+    {
+        double x = next();
+        while (x == 0.0 && pos < n) x = next();
+        return x;
+    }
+};
+
 MC_HD EventStream event_stream(uint64_t seed, uint64_t iteration, uint32_t slot, uint32_t stream)
 {
     const Philox4 b = keyed_block(seed, iteration, slot, RNG_EVENT, stream);

@@ -379,10 +379,14 @@ hipError_t launch_cs_absorb(const CsParams &p, const PhotonDev &ph, const double
 // flag word for this rank; sc_wait_kernel, lane r, waits until rank r's stamp has reached the round.  Two receive buffers alternate by the
 // round's parity: a rank can push round k + 2 only after its own resolve of round k + 1, which needed every peer's push of round k + 1,
 // which that peer issued after ITS resolve of round k -- so nobody still reads the buffer that is overwritten.  The wait is bounded.
+// Once a wait has given up (my_flags[SC_GAVE_UP_WORD] != 0) the exchange is dead for this frame: push and wait return at once -- no further round
+// stamps go out, no later wait spins its budget again -- and the loop state is parked (LoopState::done = LOOP_SC_GAVE_UP: step, propose and resolve
+// are no-ops), so the photons stay at the last pass every rank completed.  mcrat_hip_shared_clock_reset_exchange clears the state.
 __global__ __launch_bounds__(256) void sc_push_kernel(const ScProposal *__restrict__ send, ScPeers peers, unsigned long long *my_flags, int world, int rank)
 {
     constexpr int WORDS = (int)(sizeof(ScProposal) / sizeof(unsigned long long));
     static_assert(sizeof(ScProposal) % sizeof(unsigned long long) == 0, "proposal copied by 8-byte words");
+    if (my_flags[SC_GAVE_UP_WORD] != 0ull) return;
     // the round number lives on the device (my_flags[SC_ROUND_WORD], touched by this rank's kernels only, in stream order): the launches
     // carry no per-round argument and can be replayed from a hipGraph
     const unsigned long long round = my_flags[SC_ROUND_WORD] + 1ull;
@@ -399,17 +403,23 @@ __global__ __launch_bounds__(256) void sc_push_kernel(const ScProposal *__restri
 }
 
 // waits for the round's stamps of all ranks, then copies the round's half of the receive buffer into `gathered`, which is what
-// sc_resolve_kernel reads (a fixed address: no per-round argument there either)
-__global__ __launch_bounds__(256) void sc_wait_kernel(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins)
+// sc_resolve_kernel reads (a fixed address: no per-round argument there either).  If a stamp does not come within max_spins the wait gives up:
+// nothing is copied (a stale half of the buffer must never be resolved) and the loop is parked.
+__global__ __launch_bounds__(256) void sc_wait_kernel(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins,
+                                                      LoopState *st)
 {
     constexpr int WORDS = (int)(sizeof(ScProposal) / sizeof(unsigned long long));
+    __shared__ int s_failed;
+    if (my_flags[SC_GAVE_UP_WORD] != 0ull) return;                  // dead since an earlier round: not another budget of spins
+    if (threadIdx.x == 0) s_failed = 0;
+    __syncthreads();
     const unsigned long long round = my_flags[SC_ROUND_WORD];
     const int r = threadIdx.x;
     if (r < world) {
         int spins = 0;
         while (__hip_atomic_load(my_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < round) {
-            if (++spins > max_spins) {                              // a peer that never arrives must not hang the GPU: say so and go on
-                __hip_atomic_fetch_add(my_flags + SC_GAVE_UP_WORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (++spins > max_spins) {                              // a peer that never arrives must not hang the GPU: say so and stop
+                s_failed = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
@@ -417,6 +427,13 @@ __global__ __launch_bounds__(256) void sc_wait_kernel(unsigned long long *my_fla
     }
     __threadfence_system();
     __syncthreads();
+    if (s_failed) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(my_flags + SC_GAVE_UP_WORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (st->done != LOOP_DONE) st->done = LOOP_SC_GAVE_UP;
+        }
+        return;
+    }
     const unsigned long long *src = reinterpret_cast<const unsigned long long *>(recv + (size_t)(round & 1ull) * (size_t)world);
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(gathered);
     for (int k = threadIdx.x; k < WORDS * world; k += 256) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -428,9 +445,9 @@ hipError_t launch_sc_push(const ScProposal *send, const ScPeers &peers, unsigned
     return hipGetLastError();
 }
 
-hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins, hipStream_t stream)
+hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins, LoopState *st, hipStream_t stream)
 {
-    sc_wait_kernel<<<dim3(1), dim3(256), 0, stream>>>(my_flags, recv, gathered, world, max_spins);
+    sc_wait_kernel<<<dim3(1), dim3(256), 0, stream>>>(my_flags, recv, gathered, world, max_spins, st);
     return hipGetLastError();
 }
 

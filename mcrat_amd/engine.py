@@ -247,7 +247,10 @@ SYMBOLS = {
     "mcrat_hip_shared_clock_set_peers": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mcrat_hip_shared_clock_exchange_push": (C.c_int, [_ctx]),
     "mcrat_hip_shared_clock_exchange_wait": (C.c_int, [_ctx]),
+    "mcrat_hip_set_rng_tape": (C.c_int, [_ctx, _dp, C.c_longlong]),
+    "mcrat_hip_rng_tape_position": (C.c_int, [_ctx, C.POINTER(C.c_longlong), _ip]),
     "mcrat_hip_shared_clock_exchange": (C.c_int, [_ctx]),
+    "mcrat_hip_shared_clock_reset_exchange": (C.c_int, [_ctx]),
     "mcrat_hip_shared_clock_buffers": (C.c_int, [_ctx, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "mcrat_hip_shared_clock_propose": (C.c_int, [_ctx]),
     "mcrat_hip_shared_clock_resolve": (C.c_int, [_ctx]),
@@ -659,6 +662,19 @@ class Engine:
         self._check(self.lib.mcrat_hip_unregister_host(self.ctx, array.ctypes.data), "unregister_host")
 
     # ---- the loop
+    def set_rng_tape(self, uniforms):
+        """the random stream as an input: a float64 array of uniforms in [0,1) consumed in the reference's call order (None: the keyed source)"""
+        if uniforms is None:
+            self._check(self.lib.mcrat_hip_set_rng_tape(self.ctx, None, 0), "set_rng_tape")
+            return
+        u = _f8(uniforms)
+        self._check(self.lib.mcrat_hip_set_rng_tape(self.ctx, u.ctypes.data_as(_dp), int(u.size)), "set_rng_tape")
+
+    def rng_tape_position(self):
+        pos, out = C.c_longlong(0), C.c_int(0)
+        self._check(self.lib.mcrat_hip_rng_tape_position(self.ctx, C.byref(pos), C.byref(out)), "rng_tape_position")
+        return pos.value, bool(out.value)
+
     def begin_frame(self, seed, time_now, remaining_time):
         self._check(self.lib.mcrat_hip_begin_frame(self.ctx, int(seed), float(time_now), float(remaining_time)), "begin_frame")
 
@@ -759,6 +775,9 @@ class Engine:
 
     def shared_clock_exchange_wait(self):
         self._check(self.lib.mcrat_hip_shared_clock_exchange_wait(self.ctx), "shared_clock_exchange_wait")
+
+    def shared_clock_reset_exchange(self):
+        self._check(self.lib.mcrat_hip_shared_clock_reset_exchange(self.ctx), "shared_clock_reset_exchange")
 
     def shared_clock_propose(self):
         self._check(self.lib.mcrat_hip_shared_clock_propose(self.ctx), "shared_clock_propose")

@@ -845,7 +845,7 @@ void orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hyd
                 orc_calculateOpticalDepth(c, ph, h);
                 ph->recalc_properties = 0;
             }
-            double rnd = orc_rng_freepath_upos(rng, (uint32_t)i);
+            double rnd = orc_rng_freepath_draw(rng, (uint32_t)i);
             mfp = (-1.0 / ph->total_optical_depth) * log(rnd);
         } else {
             mfp = default_mfp;

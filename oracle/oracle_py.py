@@ -37,7 +37,8 @@ _dp = C.POINTER(C.c_double)
 
 class Rng(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("iteration", C.c_uint64), ("stream", C.c_uint32),
-                ("ev_state", C.c_uint64), ("n_draws", C.c_uint64)]
+                ("ev_state", C.c_uint64), ("n_draws", C.c_uint64),
+                ("tape", C.POINTER(C.c_double)), ("tape_n", C.c_int64), ("tape_pos", C.c_int64), ("tape_error", C.c_int)]
 
 
 class PhotonList(C.Structure):
@@ -334,15 +335,28 @@ def photon_injection(cfg, hydro, r_inj, ph_weight, min_photons, max_photons, spe
 
 
 def photon_loop(cfg, photons, hydro, seed, time_now, remaining_time, max_iterations=0,
-                iteration_base=0, find_switch=1, stream=0):
-    """Run orc_photon_loop; returns (stats, time_now, remaining, find_switch)."""
+                iteration_base=0, find_switch=1, stream=0, tape=None, tape_pos=0):
+    """Run orc_photon_loop; returns (stats, time_now, remaining, find_switch).
+    tape: a float64 array of recorded uniforms in [0,1) -- the random stream as an INPUT (oracle_rng.h, TAPE source), consumed from tape_pos on
+    in the reference's call order; the position reached is left in photon_loop.tape_pos, a tape that ran out raises."""
     L = lib()
     rng = Rng()
-    L.orc_rng_init(C.byref(rng), int(seed), int(stream))
+    if tape is not None:
+        import numpy as np
+        t = np.ascontiguousarray(tape, dtype=np.float64)
+        L.orc_rng_init_tape.argtypes = [C.POINTER(Rng), C.POINTER(C.c_double), C.c_int64]
+        L.orc_rng_init_tape(C.byref(rng), t.ctypes.data_as(C.POINTER(C.c_double)), int(t.size))
+        rng.tape_pos = int(tape_pos)
+    else:
+        L.orc_rng_init(C.byref(rng), int(seed), int(stream))
     st = Stats()
     tn, rem, sw = C.c_double(time_now), C.c_double(remaining_time), C.c_int(find_switch)
     L.orc_photon_loop(C.byref(cfg), C.byref(photons.c), C.byref(hydro.c), C.byref(rng),
                       C.byref(tn), C.byref(rem), C.byref(sw), int(max_iterations), int(iteration_base), C.byref(st))
+    if tape is not None:
+        if rng.tape_error:
+            raise RuntimeError("the tape ran out after %d uniforms" % rng.tape_pos)
+        photon_loop.tape_pos = int(rng.tape_pos)
     return st, tn.value, rem.value, sw.value
 
 

@@ -45,6 +45,29 @@ void orc_rng_init(orc_rng *r, uint64_t seed, uint32_t stream)
     r->stream = stream;
     r->ev_state = 0;
     r->n_draws = 0;
+    r->tape = 0;
+    r->tape_n = r->tape_pos = 0;
+    r->tape_error = 0;
+}
+
+void orc_rng_init_tape(orc_rng *r, const double *tape, int64_t n)
+{
+    orc_rng_init(r, 0, 0);
+    r->tape = tape;
+    r->tape_n = n;
+}
+
+static double tape_next(orc_rng *r)
+{
+    r->n_draws++;
+    if (r->tape_pos >= r->tape_n) { r->tape_error = 1; return 0.5; }
+    return r->tape[r->tape_pos++];
+}
+
+double orc_rng_freepath_draw(orc_rng *r, uint32_t slot)
+{
+    if (r->tape) return orc_rng_uniform_pos(r);
+    return orc_rng_freepath_upos(r, slot);
 }
 
 void orc_rng_set_iteration(orc_rng *r, uint64_t k)
@@ -80,6 +103,7 @@ double orc_rng_freepath_upos(const orc_rng *r, uint32_t slot)
 void orc_rng_event_begin(orc_rng *r, uint32_t slot)
 {
     uint32_t w[4];
+    if (r->tape) return;                     /* one sequential stream: nothing to open */
     keyed_block(r, slot, ORC_PURPOSE_EVENT, w);
     r->ev_state = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
     r->n_draws = 0;
@@ -88,6 +112,7 @@ void orc_rng_event_begin(orc_rng *r, uint32_t slot)
 void orc_rng_stream_begin(orc_rng *r, uint32_t word2, uint32_t purpose)
 {
     uint32_t w[4];
+    if (r->tape) return;
     keyed_block(r, word2, purpose, w);
     r->ev_state = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
     r->n_draws = 0;
@@ -95,12 +120,18 @@ void orc_rng_stream_begin(orc_rng *r, uint32_t word2, uint32_t purpose)
 
 double orc_rng_uniform(orc_rng *r)
 {
+    if (r->tape) return tape_next(r);                       /* gsl_rng_uniform: [0,1) */
     r->n_draws++;
     return orc_bits_to_uniform(orc_splitmix64_next(&r->ev_state));
 }
 
 double orc_rng_uniform_pos(orc_rng *r)
 {
+    if (r->tape) {                                          /* gsl_rng_uniform_pos: redraw while 0 */
+        double x;
+        do { x = tape_next(r); } while (x == 0.0 && !r->tape_error);
+        return x;
+    }
     r->n_draws++;
     return orc_bits_to_uniform_pos(orc_splitmix64_next(&r->ev_state));
 }

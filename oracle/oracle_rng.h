@@ -51,12 +51,24 @@ typedef struct orc_rng {
     uint32_t stream;     /* virtual-rank id (0 for a single photon list)          */
     uint64_t ev_state;   /* SplitMix64 state of the current event stream          */
     uint64_t n_draws;    /* draws consumed from the current event stream (stats)  */
+    /* TAPE source (orc_rng_init_tape): the stream is an input -- a recorded sequence of the doubles MCRaT's generator returned
+     * (gsl_rng_type::get_double of ranlxs0, in [0,1)), consumed strictly in the reference's call order: one gsl_rng_uniform_pos per
+     * located slot in ascending slot order (mclib.c:646-675), then photonEvent's draws (electron.c:81,196,217-233;
+     * mcrat_scattering.c:519-574).  gsl_rng_uniform_pos redraws while it gets 0 (GSL rng/gsl_rng.h) and gsl_ran_gaussian's polar method
+     * takes as many pairs as it needs (GSL randist/gauss.c): both fall out of reading the tape sequentially.  A tape that runs out sets
+     * tape_error and yields 0.5.  tools/ref_harness records such tapes from the unmodified reference. */
+    const double *tape;  /* NULL: the keyed source above */
+    int64_t tape_n, tape_pos;
+    int tape_error;
 } orc_rng;
 
 void     orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 uint64_t orc_splitmix64_next(uint64_t *state);
 
 void   orc_rng_init(orc_rng *r, uint64_t seed, uint32_t stream);
+void   orc_rng_init_tape(orc_rng *r, const double *tape, int64_t n);
+/* the free-path draw of slot i in the loop's ascending pass over the slots: keyed by (iteration, slot), or the next of the tape */
+double orc_rng_freepath_draw(orc_rng *r, uint32_t slot);
 void   orc_rng_set_iteration(orc_rng *r, uint64_t k);
 
 /* free-path uniform_pos of photon slot i in the current iteration */

@@ -290,7 +290,27 @@ def test_two_pools_on_two_streams_driven_by_two_host_threads(hip):
     with pytest.raises(hip.McratHipError, match="GEOMETRY"):
         other.share_hydro(halves[0])
     other.close()
-    for e in [one, halves[1], halves[0]]:
+    # The owner stages its next frame while a pool still reads the old one: the reader is cut loose first (its stream drained, no dangling
+    # pointers into buffers that are rewritten or freed) and says so until it shares or stages again; then it runs as before.
+    halves[1].share_hydro(halves[0])
+    halves[0].set_hydro(frame)                                             # (the same cells: the results below must not change)
+    halves[1].restore_photons()
+    with pytest.raises(hip.McratHipError, match="shared is gone"):
+        halves[1].begin_frame(902, 0.0, rem)
+    halves[1].share_hydro(halves[0])
+    halves[1].restore_photons()
+    halves[1].begin_frame(902, 0.0, rem)
+    assert halves[1].run(0).frame_scatt_cnt == stats[1].frame_scatt_cnt
+    # ... and an owner that is destroyed takes no reader's frame with it silently
+    halves[0].close()
+    halves[1].restore_photons()
+    with pytest.raises(hip.McratHipError):
+        halves[1].begin_frame(902, 0.0, rem)
+    halves[1].set_hydro(frame)
+    halves[1].restore_photons()
+    halves[1].begin_frame(902, 0.0, rem)
+    assert halves[1].run(0).frame_scatt_cnt == stats[1].frame_scatt_cnt
+    for e in [one, halves[1]]:
         e.close()
 
 
@@ -341,3 +361,45 @@ def test_pool_injection_gives_every_list_the_photons_of_its_own_injection(hip):
             assert va[r].frame_statistics().remaining_time == 0.0
     pa.close()
     pb.close()
+
+
+@pytest.mark.parametrize("case", ["2000+5000-cylindrical", "2000+4000-cylindrical-stokes", "3000-spherical-stokes"])
+@pytest.mark.parametrize("threads", ["auto", "256"])
+def test_lists_of_thousands_of_photons_equal_the_oracle(hip, oracle, case, threads, monkeypatch):
+    """the reference's ranks hold 1000 - 5000 photons (sample_mc.par:21-22, Doc/mcrat_doc.tex:165-166): lists of 2000 - 5000 photons, list by
+    list against the oracle -- with 512 threads per list (what the engine picks when there are no more such lists than CUs: the columns in
+    LDS up to 4096 slots, in HBM/L2 beyond) and with 256"""
+    if threads != "auto":
+        monkeypatch.setenv("MCRAT_HIP_RANK_BLOCK", threads)
+    if case == "2000+5000-cylindrical":
+        lens, (frame, ph, cfg) = [2000, 5000], synth.config2(n_photons=7000, nzc=8, stokes=0, lumi=3e52)
+    elif case == "2000+4000-cylindrical-stokes":
+        lens, (frame, ph, cfg) = [2000, 4000], synth.config2(n_photons=6000, nzc=8, stokes=1, lumi=1e54)
+    else:
+        lens, (frame, ph, cfg) = [3000, 1100], synth.config3(n_photons=4100, nr=256, nth=128, lumi=1e54)
+    subs = _lists(ph, lens)
+    R = len(lens)
+    seeds, streams = [501 + 13 * r for r in range(R)], [5, 77][:R]
+    t0, rem, passes = 1.5, 0.2, 60
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(R, max(lens))
+    for r in range(R):
+        v = pool.pool_rank(r, streams[r])
+        v.set_photons(subs[r])
+        v.begin_frame(seeds[r], t0, rem)
+    pool.run(passes)
+    H = oracle.OracleHydro(frame)
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"], optimised=True)   # (bit-identical to the faithful port, tests/test_oracle_kat.py)
+    for r in range(R):
+        P = oracle.OraclePhotons(synth.photons_to_aos(subs[r], oracle.PHOTON_DTYPE))
+        rst, rtn, rrem, _ = oracle.photon_loop(c, P, H, seed=seeds[r], time_now=t0, remaining_time=rem, max_iterations=passes, stream=streams[r])
+        v = pool.pool_rank(r, streams[r])
+        st = v.frame_statistics()
+        assert (st.iterations, st.frame_scatt_cnt, st.kn_rejections, st.num_photons_find_new_element) == \
+               (rst.iterations, rst.frame_scatt_cnt, rst.kn_rejections, rst.num_photons_find_new_element)
+        assert st.last_scattered_index == rst.last_scattered_index
+        assert st.time_now == pytest.approx(rtn, rel=1e-12)
+        _compare(v.get_photons(), P.aos)
+        assert rst.frame_scatt_cnt > 0
+    pool.close()

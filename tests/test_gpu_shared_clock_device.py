@@ -68,13 +68,36 @@ def test_a_peer_that_never_arrives_is_an_error_not_a_hang(hip, monkeypatch):
     other_recv = torch.zeros(rb, dtype=torch.uint8, device="cuda")
     other_flags = torch.zeros(fb, dtype=torch.uint8, device="cuda")
     e.shared_clock_set_peers([recv, other_recv.data_ptr()], [flags, other_flags.data_ptr()])
+    before = e.get_photons()
     e.begin_frame(1, 0.0, 0.1)
+    import time
+    t0 = time.perf_counter()
     e.shared_clock_propose()
     e.shared_clock_exchange_push()
     e.shared_clock_exchange_wait()
     e.shared_clock_resolve()
+    e.synchronize()
+    one_wait = time.perf_counter() - t0
+    # the rounds already queued behind the failure (a captured batch would hold 16-32 of them) return at once: together they take no longer
+    # than the one wait that gave up, not a budget of spins each
+    t0 = time.perf_counter()
+    for _ in range(8):
+        e.shared_clock_propose()
+        e.shared_clock_exchange_push()
+        e.shared_clock_exchange_wait()
+        e.shared_clock_resolve()
+    e.synchronize()
+    assert time.perf_counter() - t0 < max(0.5 * one_wait, 0.05), (one_wait, time.perf_counter() - t0)
     with pytest.raises(hip.McratHipError, match="did not arrive"):
         e.shared_clock_poll()
+    # nothing was resolved from a stale buffer: the photons are where the frame found them
+    after = e.get_photons()
+    for k in ("r0", "r1", "r2", "p0", "p1", "p2", "p3", "num_scatt"):       # (the first round's forced re-location pass has run: cells and comoving momenta are its)
+        assert np.array_equal(np.asarray(after[k]), np.asarray(before[k]), equal_nan=True), k
+    # reset (every rank, then a barrier between the ranks) and the exchange works again: a one-rank world needs nobody else
+    e.shared_clock_reset_exchange()
+    with pytest.raises(hip.McratHipError):
+        e.shared_clock_propose()                             # the frame was closed by the reset
     e.close()
 
 
