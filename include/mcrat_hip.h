@@ -432,9 +432,11 @@ int mcrat_hip_propagate_frame(mcrat_hip_ctx *ctx, double *time_now, double remai
  * one scattering per pass per list, comparable pass by pass with the reference.  MCRAT_HIP_MODE_FAST runs every photon through the
  * frame on its own clock with per-photon keyed random numbers (photons are independent within a frozen frame and exponential free
  * paths are memoryless): statistically equivalent, NOT sequence-equivalent -- spectra, scattering counts and polarisation agree with
- * the exact mode within Monte-Carlo error (tests/test_gpu_fast_mode.py), single photons do not.  fast_windows (<= 0: 8) is how often
+ * the exact mode within Monte-Carlo error (tests/test_gpu_fast_mode.py), single photons do not.  fast_windows is how often
  * per frame a photon's cell and optical depth are refreshed besides after its own scatterings; the reference refreshes them whenever
- * any photon of the rank scatters.  Works on a single list, virtual ranks or a rank pool alike (the lists do not matter to it);
+ * any photon of the rank scatters, i.e. -- for its ranks of about 1000 photons -- as often as the frame has scatterings per 1000 photons.
+ * fast_windows <= 0 follows that: the scatterings per 1000 photons of the context's previous FAST frame, between 8 and 128 (32 for the
+ * first frame); a fixed 8 is biased by about a per cent in frames with tens of scatterings per photon.  Works on a single list, virtual ranks or a rank pool alike (the lists do not matter to it);
  * refuses cyclo-synchrotron contexts and an attached shared clock.  stats: iterations = passes of the longest-running workgroup,
  * photon_steps = free-path draws, frame_scatt_cnt, kn_rejections, num_photons_find_new_element, not_found. */
 #define MCRAT_HIP_MODE_EXACT 0
@@ -528,8 +530,14 @@ typedef struct mcrat_hip_pool_inject_list {
     uint64_t seed;
     int      num_photons;                  /* out */
     double   ph_weight_adjusted;           /* out */
+    int      status;                       /* out: MCRAT_HIP_OK, or why THIS list was not injected (the other lists are; the call returns the first
+                                            *      such code).  Arguments are validated for all lists before any window is touched. */
 } mcrat_hip_pool_inject_list;
 int mcrat_hip_pool_inject_photons(mcrat_hip_ctx *pool, double fps, mcrat_hip_pool_inject_list *lists);
+/* mcrat_hip_set_photons for `count` lists of the pool at once -- a CONTINUE run's restart, every adopted rank's checkpointed list (readCheckpoint,
+ * Src/mcrat_io.c:1011): the records cross PCIe in one copy and reach their windows in one launch.  rank_of[j]: the pool rank of lists[j] (its view
+ * exists, no rank twice).  Each list ends up exactly as mcrat_hip_set_photons(view, &lists[j]) leaves it; everything is validated first. */
+int mcrat_hip_pool_set_photons(mcrat_hip_ctx *pool, int count, const int *rank_of, const mcrat_hip_photon_list *lists);
 int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *pool, const int *open, const uint64_t *seeds, const double *time_now, const double *remaining_time);
 int mcrat_hip_pool_frame_stats(mcrat_hip_ctx *pool, mcrat_hip_frame_stats *out /* [n_ranks] */);
 int mcrat_hip_pool_layout(const mcrat_hip_ctx *pool, int *n_ranks, int *slots_per_rank);

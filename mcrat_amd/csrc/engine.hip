@@ -95,6 +95,7 @@ struct mcrat_hip_ctx {
     double *d_tape = nullptr;
     long long tape_n = 0;
     long long *d_tape_cursor = nullptr;   // {cursor, error word} in one 16-byte block
+    int fast_auto_windows = 32;       // FAST mode with fast_windows <= 0: the refresh cadence, from what the last FAST frame looked like (fast_cadence)
     bool rank_pipe = false;           // ... or rank_pipe_kernel (the passes pipelined; lists of up to 1024 slots, DIRECT optical depths)
     bool rank_block_fixed = false;
     double rank_passes_per_list = 0;  // of the last completed frame
@@ -1282,7 +1283,7 @@ extern "C" int mcrat_hip_get_hydro(mcrat_hip_ctx *c, mcrat_hip_hydro_columns *ou
 
 // ---------------------------------------------------------------------------------------------- photons
 // a view's list: a window of `n` slots into the pool's columns (the window spans the pool's slots per rank; slots beyond n stay invalid)
-static int alloc_view_photons(mcrat_hip_ctx *c, int n)
+static int alloc_view_photons(mcrat_hip_ctx *c, int n, bool clear_window = true)
 {
     mcrat_hip_ctx *P = c->parent;
     if (n > P->rank_stride) {
@@ -1298,12 +1299,12 @@ static int alloc_view_photons(mcrat_hip_ctx *c, int n)
     p.n = n;
     p.n_pad = P->rank_stride;                 // (col_stride stays the pool's: the columns of a view are windows into the pool's)
     c->ph = p;
-    HIPCHK(c, launch_clear_slots(c->ph, 0, P->rank_stride, c->stream));
+    if (clear_window) HIPCHK(c, launch_clear_slots(c->ph, 0, P->rank_stride, c->stream));
     c->step_blocks = step_grid_blocks(p.n_pad);
     c->partials = P->partials;                // list-mode scratch is the pool's: one stream, one list at a time
     c->partials_cap = P->partials_cap;
     c->shortlist = P->shortlist;
-    HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
+    if (clear_window) HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
     c->n_ranks = 0;
     drop_graph(c);
     return MCRAT_HIP_OK;
@@ -1462,6 +1463,50 @@ extern "C" int mcrat_hip_set_photons(mcrat_hip_ctx *c, const mcrat_hip_photon_li
     return MCRAT_HIP_OK;
 }
 
+// mcrat_hip_set_photons for many lists of a rank pool at once (a CONTINUE run's restart: every adopted rank's checkpoint, mcrat.c:235-330 /
+// readCheckpoint): the lists' records are gathered into one staging buffer, cross PCIe in ONE copy and are transposed into their windows by ONE
+// launch, instead of a copy, two launches and a wait per list.  rank_of[j] is the pool rank list j goes to (its view must exist:
+// mcrat_hip_pool_rank); every list exactly as mcrat_hip_set_photons(view, list) would leave it.
+extern "C" int mcrat_hip_pool_set_photons(mcrat_hip_ctx *c, int count, const int *rank_of, const mcrat_hip_photon_list *lists)
+{
+    if (!c || count < 0 || (count > 0 && (!rank_of || !lists))) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    if (count == 0) return MCRAT_HIP_OK;
+    struct Desc { int rank, n; long long first; };
+    static_assert(sizeof(Desc) == 16, "PoolSetDesc of staging.hip");
+    std::vector<Desc> desc((size_t)count);
+    std::vector<char> seen((size_t)c->n_ranks, 0);
+    size_t total = 0;
+    for (int j = 0; j < count; ++j) {                                       // everything is checked before any window is touched
+        const int r = rank_of[j];
+        if (r < 0 || r >= c->n_ranks || !lists[j].photons || lists[j].list_capacity <= 0 || seen[(size_t)r]) return MCRAT_HIP_EINVAL;
+        seen[(size_t)r] = 1;
+        if (!c->views[r]) { c->last_error = "pool_set_photons: a list without a view (mcrat_hip_pool_rank)"; return MCRAT_HIP_ESTATE; }
+        if (lists[j].list_capacity > c->rank_stride) { c->last_error = "a list is longer than the pool's slots per rank (mcrat_hip_pool_create)"; return MCRAT_HIP_ENOMEM; }
+        desc[(size_t)j] = Desc{r, lists[j].list_capacity, (long long)total};
+        total += (size_t)lists[j].list_capacity;
+    }
+    const size_t rec_bytes = sizeof(mcrat_hip_photon) * total, desc_bytes = sizeof(Desc) * (size_t)count;
+    int rc = ensure_aos(c, align_up(rec_bytes, 256) + desc_bytes);
+    if (rc) return rc;
+    std::vector<mcrat_hip_photon> host(total);
+    for (int j = 0; j < count; ++j)
+        memcpy(host.data() + desc[(size_t)j].first, lists[j].photons, sizeof(mcrat_hip_photon) * (size_t)lists[j].list_capacity);
+    char *dev = static_cast<char *>(c->aos_buf);
+    HIPCHK(c, hipMemcpyAsync(dev, host.data(), rec_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dev + align_up(rec_bytes, 256), desc.data(), desc_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_pool_aos_to_soa(dev, c->ph, c->rank_stride, dev + align_up(rec_bytes, 256), count, c->stream));
+    for (int j = 0; j < count; ++j) {
+        mcrat_hip_ctx *v = c->views[desc[(size_t)j].rank];
+        if ((rc = alloc_view_photons(v, desc[(size_t)j].n, false))) { c->last_error = v->last_error; return rc; }    // the view's columns in place; the launch above filled and cleared the window
+        v->have_photons = true;
+        v->frame_open = false;
+    }
+    HIPCHK(c, hipMemsetAsync(c->shortlist, 0, sizeof(Shortlist), c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_inject_photons(mcrat_hip_ctx *c, double r_inj, double ph_weight, int min_photons, int max_photons, char spect,
                                         double theta_min, double theta_max, double fps, uint64_t seed, int *num_photons,
                                         double *ph_weight_adjusted)
@@ -1525,13 +1570,23 @@ extern "C" int mcrat_hip_pool_inject_photons(mcrat_hip_ctx *c, double fps, mcrat
     std::vector<PoolInject> pi((size_t)R);
     bool any = false;
     int rc;
+    // every list's arguments are looked at before any window is touched: a bad request for list 7 must not leave lists 0-6 emptied
+    for (int r = 0; r < R; ++r) {
+        mcrat_hip_pool_inject_list &q = lists[r];
+        q.status = MCRAT_HIP_OK;
+        if (!q.inject) continue;
+        if (!(q.ph_weight > 0) || q.min_photons < 0 || q.max_photons < q.min_photons || (q.spect != 'b' && q.spect != 'w')) {
+            q.status = MCRAT_HIP_EINVAL;
+            c->last_error = "pool_inject_photons: a list's weight, photon-count range or spectrum is not valid";
+            return MCRAT_HIP_EINVAL;
+        }
+        if (!c->views[r]) { q.status = MCRAT_HIP_ESTATE; c->last_error = "pool_inject_photons: a list without a view (mcrat_hip_pool_rank)"; return MCRAT_HIP_ESTATE; }
+    }
     for (int r = 0; r < R; ++r) {
         pi[(size_t)r] = PoolInject{};
         mcrat_hip_pool_inject_list &q = lists[r];
         if (!q.inject) continue;
-        if (!(q.ph_weight > 0) || q.min_photons < 0 || q.max_photons < q.min_photons || (q.spect != 'b' && q.spect != 'w')) return MCRAT_HIP_EINVAL;
         mcrat_hip_ctx *v = c->views[r];
-        if (!v) { c->last_error = "pool_inject_photons: a list without a view (mcrat_hip_pool_rank)"; return MCRAT_HIP_ESTATE; }
         if ((rc = alloc_view_photons(v, 0))) { c->last_error = v->last_error; return rc; }      // the window cleared, the view's columns in place
         v->have_photons = false;
         Slab sl{q.r_inj - 0.5 * C_LIGHT / fps, q.r_inj + 0.5 * C_LIGHT / fps, q.theta_min, q.theta_max, q.spect == 'w'};   // mclib.c:34-35
@@ -1574,6 +1629,9 @@ extern "C" int mcrat_hip_pool_inject_photons(mcrat_hip_ctx *c, double fps, mcrat
     if (hipMemcpyAsync(pi.data(), d_pi, sizeof(PoolInject) * (size_t)R, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) return done(MCRAT_HIP_EHIP);
     (void)done(0);
+    // every list that was injected is committed; a list that failed says so in its own status (its window stays empty) and the call returns
+    // the first such code after all lists have been looked at
+    int first_error = MCRAT_HIP_OK;
     for (int r = 0; r < R; ++r) {
         const PoolInject &e = pi[(size_t)r];
         if (!e.inject) continue;
@@ -1581,18 +1639,28 @@ extern "C" int mcrat_hip_pool_inject_photons(mcrat_hip_ctx *c, double fps, mcrat
         mcrat_hip_pool_inject_list &q = lists[r];
         if (e.error == 3) {                                                 // more photons than the kernel's table: the one-list path (it says what is wrong, if anything)
             if ((rc = mcrat_hip_inject_photons(v, q.r_inj, q.ph_weight, q.min_photons, q.max_photons, q.spect, q.theta_min, q.theta_max, fps, q.seed,
-                                               &q.num_photons, &q.ph_weight_adjusted))) { c->last_error = v->last_error; return rc; }
+                                               &q.num_photons, &q.ph_weight_adjusted))) {
+                q.status = rc;
+                if (!first_error) { first_error = rc; c->last_error = v->last_error; }
+            }
             continue;
         }
-        if (e.error == 1) { c->last_error = "photon injection: no weight puts the photon count between min_photons and max_photons"; return MCRAT_HIP_EINVAL; }
-        if (e.error == 2) { c->last_error = "photon injection: no photons (no cell of the frame touches the injection slab?)"; return MCRAT_HIP_EINVAL; }
+        if (e.error == 1 || e.error == 2) {
+            q.status = MCRAT_HIP_EINVAL; q.num_photons = 0;
+            if (!first_error) {
+                first_error = MCRAT_HIP_EINVAL;
+                c->last_error = e.error == 1 ? "photon injection: no weight puts the photon count between min_photons and max_photons"
+                                             : "photon injection: no photons (no cell of the frame touches the injection slab?)";
+            }
+            continue;
+        }
         v->ph.n = e.n;
         v->have_photons = true;
         v->frame_open = false;
         q.num_photons = e.n;
         q.ph_weight_adjusted = e.weight_out;
     }
-    return MCRAT_HIP_OK;
+    return first_error;
 }
 
 // reallocatePhotonListMemory (photons.c:37-80) on the device: a larger set of columns, the old slots copied, the new ones null
@@ -2630,6 +2698,22 @@ static void fast_stats(const FastCounts &fc, double time_now, mcrat_hip_frame_st
     stats->time_now = time_now;
 }
 
+// FAST mode's refresh cadence when the caller does not name one (fast_windows <= 0).  The exact loop re-locates a photon and redraws its free
+// path whenever ANY photon of its rank scatters -- N_events(rank, frame) times per frame, for the reference's ranks of about 1000 photons that
+// is the frame's scatterings per 1000 photons.  A fixed 8 is right for thin frames and biased by a per cent in dense ones (the Lundman run's first
+// frames: 68.0 scatterings per photon against the exact mode's 67.3; 128 windows give 67.3).  So the cadence follows the frame: the scatterings per
+// 1000 photons the context's LAST fast frame counted, between 8 and 128 (beyond which the run above no longer changes), 32 before any frame has run.
+static int fast_cadence(const mcrat_hip_ctx *c, int fast_windows)
+{
+    return fast_windows > 0 ? fast_windows : c->fast_auto_windows;
+}
+static void fast_cadence_learn(mcrat_hip_ctx *c, unsigned long long scatterings, long long photons)
+{
+    if (photons <= 0) return;
+    const double per_thousand = 1000.0 * (double)scatterings / (double)photons;
+    c->fast_auto_windows = per_thousand < 8.0 ? 8 : (per_thousand > 128.0 ? 128 : (int)(per_thousand + 0.5));
+}
+
 // MCRAT_HIP_MODE_FAST for the lists of a rank pool, one launch: list r (open[r] != 0) runs its frame of remaining_time[r] with its own seed
 // and stream and list-local slot numbers in its keys -- bit for bit what mcrat_hip_propagate_frame_mode(view r, ..., seeds[r], FAST, ...) gives
 extern "C" int mcrat_hip_pool_propagate_frames_fast(mcrat_hip_ctx *c, const int *open, const uint64_t *seeds, const double *time_now,
@@ -2658,19 +2742,22 @@ extern "C" int mcrat_hip_pool_propagate_frames_fast(mcrat_hip_ctx *c, const int 
     HIPCHK(c, hipMemcpyAsync(d_rem, rem.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
     const FastLists lists{c->rank_stride, c->d_desc, d_rem};
-    HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, c->key, 0.0, fast_windows > 0 ? fast_windows : 8, 1 << 22, d_cnt, lists, c->stream));
+    HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, c->key, 0.0, fast_cadence(c, fast_windows), 1 << 22, d_cnt, lists, c->stream));
     std::vector<FastCounts> cnt((size_t)R);
     HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(FastCounts) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->frame_open = false;
-    unsigned long long unfinished = 0;
+    unsigned long long unfinished = 0, scatterings = 0;
+    long long photons = 0;
     for (int r = 0; r < R; ++r) {
         if (!open[r]) continue;
         mcrat_hip_ctx *v = c->views[r];
         v->frame_open = false; v->pending_applied = false; v->rank_current = true;
         unfinished += cnt[(size_t)r].unfinished;
+        scatterings += cnt[(size_t)r].scatterings; photons += v->ph.n;
         if (stats) fast_stats(cnt[(size_t)r], time_now[r] + rem[(size_t)r], &stats[r]);
     }
+    fast_cadence_learn(c, scatterings, photons);
     if (unfinished) { c->last_error = "FAST mode: photons left with frame time after 2^22 passes (an optical depth of infinity?)"; return MCRAT_HIP_ESTATE; }
     return MCRAT_HIP_OK;
 }
@@ -2716,11 +2803,12 @@ extern "C" int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *c, double *time_now
     key.seed = seed;
     FastCounts fc{};
     if (remaining_time > 0) {
-        HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, key, remaining_time, fast_windows > 0 ? fast_windows : 8, 1 << 22,
+        HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, key, remaining_time, fast_cadence(c, fast_windows), 1 << 22,
                                     static_cast<FastCounts *>(c->d_fast), FastLists{0, nullptr, nullptr}, c->stream));
         HIPCHK(c, hipMemcpyAsync(&fc, c->d_fast, sizeof fc, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (remaining_time > 0) fast_cadence_learn(c, fc.scatterings, c->ph.n);
     c->frame_open = false;
     c->pending_applied = false;
     if (c->parent) c->rank_current = true;

@@ -975,7 +975,7 @@ __global__ __launch_bounds__(TAPE_BLOCK) void tape_draw_kernel(PhotonDev ph, con
         int have = 0;
         while (have < need) {
             const long long q = pos + tid;
-            const double v = q < tape.n ? tape.u[q] : 0.5;
+            const double v = q < tape.n ? tape.u[q] : 0.25 + 0.5 * (double)(tid & 1);      // (beyond the tape: flagged below)
             const bool nz = v != 0.0;
             int found = 0;
             const int k = block_exclusive_scan_1024(nz ? 1 : 0, s_w, found);
@@ -2813,10 +2813,7 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
         } else if (block == 512) {
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 512, false>, rank_loop_kernel<DV, GV, true, false, 512, false>, 512);
             else launch(rank_loop_kernel<DV, GV, false, true, 512, false>, rank_loop_kernel<DV, GV, false, false, 512, false>, 512);
-        } else if (block == 128 && fuse && !TABLE_MODE) {
-            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, RANK_SMALL, true>, rank_loop_kernel<DV, GV, true, false, RANK_SMALL, true>, RANK_SMALL);
-            else launch(rank_loop_kernel<DV, GV, false, true, RANK_SMALL, true>, rank_loop_kernel<DV, GV, false, false, RANK_SMALL, true>, RANK_SMALL);
-        } else if (block == 128) {
+        } else if (block == 128) {                 // (no fused build at 128 threads: it measured no gain on thin frames, round 2, and was 36 instantiations)
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, RANK_SMALL, false>, rank_loop_kernel<DV, GV, true, false, RANK_SMALL, false>, RANK_SMALL);
             else launch(rank_loop_kernel<DV, GV, false, true, RANK_SMALL, false>, rank_loop_kernel<DV, GV, false, false, RANK_SMALL, false>, RANK_SMALL);
         } else if (fuse && !TABLE_MODE) {

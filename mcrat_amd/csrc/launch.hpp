@@ -70,6 +70,8 @@ hipError_t launch_clear_slots(const PhotonDev &ph, int first, int count, hipStre
 hipError_t launch_rank_reduce(const PhotonDev &ph, int stride, int n_ranks, const RankDesc *desc, ReducePartial *out, int *n_out, hipStream_t stream);
 hipError_t launch_init_states_multi(LoopState *ranks, int n_ranks, const int *open, const double *time_now, const double *remaining, hipStream_t stream);
 hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream);
+// many lists of a rank pool at once: desc = `count` device records {int rank, int n, long long first record in aos}; the rest of each window is cleared
+hipError_t launch_pool_aos_to_soa(const void *aos, const PhotonDev &pool, int stride, const void *desc, int count, hipStream_t stream);
 hipError_t launch_soa_to_aos(const PhotonDev &ph, void *aos, int first, int n, hipStream_t stream);   // record k = slot first + k
 // printPhotons' arrays (mcrat_io.c:137-181): photons with weight != 0, slot order; col: p0-3, comv_p0-3, r0-2, s0-3, num_scatt, weight
 struct OutputCols {

@@ -598,7 +598,8 @@ __device__ __forceinline__ void single_thermal_electron(double el_p[4], double t
     const double beta = sqrt_nr(1 - ig * ig);
     const double phi = rng.uniform() * 2 * M_PI;
     // theta = acos(ct): only cos(theta) = ct and sin(theta) = sqrt(1 - ct^2) are used
-    const double ct_e = (1 - sqrt_nr(1 + beta * beta + 2 * beta - 4 * beta * rng.uniform())) * rcp_nr(beta);
+    // (clamped: for a uniform of exactly 0 -- or towards 1 -- rounding can leave the cosine an ulp outside [-1, 1], where the reference's acos is NaN)
+    const double ct_e = fmin(1.0, fmax(-1.0, (1 - sqrt_nr(1 + beta * beta + 2 * beta - 4 * beta * rng.uniform())) * rcp_nr(beta)));
     const double st_e = sqrt_nr(1 - ct_e * ct_e);
     double sphi, cphi;
     sincos(phi, &sphi, &cphi);

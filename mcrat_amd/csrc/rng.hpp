@@ -79,7 +79,7 @@ struct EventStream {
 // returned (gsl_rng_type::get_double of ranlxs0, in [0,1)), consumed strictly in the reference's call order -- one gsl_rng_uniform_pos per located
 // slot in ascending slot order (mclib.c:646-675; kernels.hip, tape_draw_kernel), then photonEvent's draws one after the other (electron.c:81,196,
 // 217-233; mcrat_scattering.c:519-574) from the position the pass has reached.  gsl_rng_uniform_pos redraws while it gets 0 and gsl_ran_gaussian's
-// polar method takes as many pairs as it needs: both fall out of reading the tape sequentially.  A tape that runs out raises *error and yields 0.5.
+// polar method takes as many pairs as it needs: both fall out of reading the tape sequentially.  A tape that runs out raises *error.
 struct TapeDev {
     const double *u;
     long long n;
@@ -93,7 +93,11 @@ struct TapeStream {
     int *error;
     MC_HD double next()
     {
-        if (pos >= n) { *error = 1; return 0.5; }
+        if (pos >= n) {                                // the tape has run out: say so, and go on with a low-discrepancy filler so that every
+            *error = 1;                                // rejection loop still ends (the results are meaningless from here on)
+            const double g = 0.6180339887498949 * (double)(++pos - n);
+            return g - (double)(long long)g;
+        }
         return u[pos++];
     }
     MC_HD double uniform() { return next(); }                                  // gsl_rng_uniform: [0,1)

@@ -40,6 +40,54 @@ __global__ __launch_bounds__(256) void aos_to_soa_kernel(const mcrat_hip_photon 
     ph.type[i] = q.type;
 }
 
+// the same for many lists of a rank pool in ONE launch (mcrat_hip_pool_set_photons): list j's records aos[d.aos_first ..) go to the window of rank
+// d.rank, the rest of the window is cleared (no list: flag byte 0).  grid = (windows' 256-slot chunks, lists)
+struct alignas(16) PoolSetDesc { int rank, n; long long aos_first; };
+
+__device__ __forceinline__ void store_record(const PhotonDev &ph, int i, const mcrat_hip_photon &q)
+{
+    ph.r0[i] = q.r0; ph.r1[i] = q.r1; ph.r2[i] = q.r2;
+    ph.p0[i] = q.p0; ph.p1[i] = q.p1; ph.p2[i] = q.p2; ph.p3[i] = q.p3;
+    ph.c0[i] = q.comv_p0; ph.c1[i] = q.comv_p1; ph.c2[i] = q.comv_p2; ph.c3[i] = q.comv_p3;
+    ph.s0[i] = q.s0; ph.s1[i] = q.s1; ph.s2[i] = q.s2; ph.s3[i] = q.s3;
+    ph.num_scatt[i] = q.num_scatt;
+    ph.weight[i] = q.weight;
+    ph.tau[i] = q.total_optical_depth;
+    ph.tts[i] = q.time_to_scatter;
+    double u0 = 0, u1 = 0, u2 = 0;
+    if (q.p0 != 0) {
+        const double d = 1.0 / q.p0;
+        u0 = q.p1 * d * C_LIGHT; u1 = q.p2 * d * C_LIGHT; u2 = q.p3 * d * C_LIGHT;
+    }
+    ph.u0[i] = u0; ph.u1[i] = u1; ph.u2[i] = u2;
+    ph.ntau[i] = -1.0 / q.total_optical_depth;
+    ph.tau_next[i] = 0.0;
+    ph.idx[i] = q.nearest_block_index;
+    unsigned f = FLAG_VALID;
+    if (q.type != 'p' && q.weight != 0) f |= FLAG_MOVES;      // mclib.c:1070
+    if (q.recalc_properties == 1) f |= FLAG_RECALC;
+    ph.flags[i] = (unsigned char)f;
+    ph.type[i] = q.type;
+}
+
+__global__ __launch_bounds__(256) void pool_aos_to_soa_kernel(const mcrat_hip_photon *__restrict__ aos, PhotonDev ph, int stride,
+                                                              const PoolSetDesc *__restrict__ desc)
+{
+    const PoolSetDesc d = desc[blockIdx.y];
+    const int il = blockIdx.x * 256 + threadIdx.x;
+    if (il >= stride) return;
+    const int i = d.rank * stride + il;
+    if (il < d.n) {
+        store_record(ph, i, aos[d.aos_first + il]);
+    } else {
+        double *cols[24] = {ph.r0, ph.r1, ph.r2, ph.p0, ph.p1, ph.p2, ph.p3, ph.c0, ph.c1, ph.c2, ph.c3, ph.s0, ph.s1, ph.s2, ph.s3,
+                            ph.num_scatt, ph.weight, ph.tau, ph.tts, ph.u0, ph.u1, ph.u2, ph.ntau, ph.tau_next};
+#pragma unroll
+        for (int c = 0; c < 24; ++c) cols[c][i] = 0.0;
+        ph.idx[i] = 0; ph.flags[i] = 0; ph.type[i] = 0;
+    }
+}
+
 // record k of `aos` is photon slot first + k
 __global__ __launch_bounds__(256) void soa_to_aos_kernel(PhotonDev ph, mcrat_hip_photon *__restrict__ aos, int first, int n)
 {
@@ -356,6 +404,15 @@ hipError_t launch_init_states(LoopState *single, LoopState *ranks, int n_ranks, 
 hipError_t launch_aos_to_soa(const void *aos, const PhotonDev &ph, int n, hipStream_t stream)
 {
     aos_to_soa_kernel<<<dim3((n + 255) / 256), dim3(256), 0, stream>>>(static_cast<const mcrat_hip_photon *>(aos), ph, n);
+    return hipGetLastError();
+}
+
+// desc: `count` device records {rank, n, first record} (three 64-bit-aligned fields, see PoolSetDesc); aos: all lists' records, concatenated
+hipError_t launch_pool_aos_to_soa(const void *aos, const PhotonDev &pool, int stride, const void *desc, int count, hipStream_t stream)
+{
+    if (count <= 0) return hipSuccess;
+    pool_aos_to_soa_kernel<<<dim3((stride + 255) / 256, count), dim3(256), 0, stream>>>(static_cast<const mcrat_hip_photon *>(aos), pool, stride,
+                                                                                         static_cast<const PoolSetDesc *>(desc));
     return hipGetLastError();
 }
 

@@ -158,7 +158,7 @@ class PoolInjectList(C.Structure):
     """mcrat_hip_pool_inject_list"""
     _fields_ = [("inject", C.c_int), ("spect", C.c_char), ("min_photons", C.c_int), ("max_photons", C.c_int),
                 ("r_inj", C.c_double), ("ph_weight", C.c_double), ("theta_min", C.c_double), ("theta_max", C.c_double),
-                ("seed", C.c_uint64), ("num_photons", C.c_int), ("ph_weight_adjusted", C.c_double)]
+                ("seed", C.c_uint64), ("num_photons", C.c_int), ("ph_weight_adjusted", C.c_double), ("status", C.c_int)]
 
 
 class RankSummary(C.Structure):
@@ -217,6 +217,7 @@ SYMBOLS = {
     "mcrat_hip_get_photons_soa": (C.c_int, [_ctx, C.POINTER(PhotonSoA)]),
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_pool_inject_photons": (C.c_int, [_ctx, C.c_double, C.POINTER(PoolInjectList)]),
+    "mcrat_hip_pool_set_photons": (C.c_int, [_ctx, C.c_int, _ip, C.c_void_p]),
     "mcrat_hip_bind_thread": (C.c_int, [_ctx]),
     "mcrat_hip_share_hydro": (C.c_int, [_ctx, _ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
@@ -348,6 +349,21 @@ class Engine:
         if getattr(self, "num_elements", None) is not None:
             v.num_elements = self.num_elements
         return v
+
+    def pool_set_photons(self, ranks, records):
+        """mcrat_hip_pool_set_photons: records[j] (numpy arrays of PHOTON_DTYPE, the reference's struct photon) becomes the list of pool rank
+        ranks[j] -- one copy over PCIe and one launch for all of them (the views must exist: pool_rank)"""
+        n = len(ranks)
+        arrs = [np.ascontiguousarray(a, dtype=PHOTON_DTYPE) for a in records]
+        lists = (PhotonList * n)()
+        for j, a in enumerate(arrs):
+            nulls = int(np.count_nonzero(a["type"] == b"N"))
+            lists[j] = PhotonList(a.ctypes.data, None, len(a) - nulls, nulls, len(a))
+        rk = np.ascontiguousarray(ranks, dtype=np.int32)
+        self._check(self.lib.mcrat_hip_pool_set_photons(self.ctx, n, rk.ctypes.data_as(_ip), C.cast(lists, C.c_void_p)), "pool_set_photons")
+        for r in ranks:
+            if hasattr(self, "views") and r in self.views:
+                self.views[r].n = int(self.lib.mcrat_hip_num_photon_slots(self.views[r].ctx))
 
     def pool_scatter_frames_cyclosynch(self, lists, max_photons, fps, b_field_calc=1, epsilon_b=0.5, rebin_e_perc=0.1, rebin_ang=0.5, rebin_ang_phi=10.0):
         """lists: one dict per list (None: the list sits the frame out) with seed, time_now, remaining_time, r_inj, ph_weight_suggest, theta_min,

@@ -545,9 +545,8 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
         k->state = 0;
         k->seeds_drawn = 0;
         k->frame_scatt_cnt_total = 0;
-        if (rc == 0 && k->restrt == 'c') {                                                        /* readCheckpoint's photons, mcrat.c:487 */
+        if (rc == 0 && k->restrt == 'c') {                                                        /* readCheckpoint's photons, mcrat.c:487 (set below, all at once) */
             if (!k->restart_list) { rc = MCRAT_HIP_EINVAL; break; }
-            rc = mcrat_hip_set_photons(k->view, k->restart_list);
             k->state = 4;
             k->scatt_frame = k->scatt_framestart;
             k->time_now = k->time_now_start;
@@ -557,6 +556,19 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
             fprintf(k->fPtr, "Im Proc %d with angles %0.1lf-%0.1lf  Starting on Frame: %d scatt_framestart: %d\n", k->angle_id, RANK_DEG(k),
                     k->framestart, k->framestart);
             fflush(k->fPtr);
+        }
+    }
+    if (rc == 0) {                        /* the restarted ranks' lists: one copy over PCIe and one launch for all of them (mcrat_hip_pool_set_photons) */
+        int n_restart = 0;
+        for (int r = 0; r < n_ranks; r++) n_restart += ranks[r].state == 4;
+        if (n_restart > 0) {
+            int *which = (int *)malloc(sizeof(int) * (size_t)n_restart);
+            mcrat_hip_photon_list *lists = (mcrat_hip_photon_list *)malloc(sizeof *lists * (size_t)n_restart);
+            if (!which || !lists) rc = MCRAT_HIP_ENOMEM;
+            for (int r = 0, j = 0; r < n_ranks && rc == 0; r++)
+                if (ranks[r].state == 4) { which[j] = r; lists[j] = *ranks[r].restart_list; j++; }
+            if (rc == 0) rc = mcrat_hip_pool_set_photons(pool, n_restart, which, lists);
+            free(which); free(lists);
         }
     }
     mcrat_hip_slab slab;
@@ -708,8 +720,11 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 log_frame(k->fPtr, &stats[r], k->time_now, summ[r].max_scatt, summ[r].min_scatt, summ[r].avg_scatt, summ[r].avg_r);
             }
             /* saveCheckpoint (:902-915): the records of all lists come over in pieces of whole lists, one transfer per piece */
-            if (cfg->cyclosynchrotron_switch && (rc = mcrat_hip_convert_comptonized(pool, NULL))) break;   /* its 'k' -> 'c', on every list at once
-                                                                                                     (the reference converts whether or not the file opens) */
+            /* saveCheckpoint's 'k' -> 'c' (mcrat_io.c:896-900), on every list at once.  In the reference the conversion sits inside saveCheckpoint's
+             * successful-fopen branch, and a run cannot go on without its checkpoint (it exits) -- so every frame of a reference run ends with it.
+             * Here it is therefore part of the FRAME, whatever write_checkpoints says: the next frame's phAbsCyclosynch and the PT column of
+             * mc_proc see the converted types also in runs that skip the checkpoint files (benchmarks). */
+            if (cfg->cyclosynchrotron_switch && (rc = mcrat_hip_convert_comptonized(pool, NULL))) break;
             if (cfg->write_checkpoints) {
                 const int per_piece = (1 << 20) / stride > 0 ? (1 << 20) / stride : 1;
                 if (!rec_buf) rec_buf = (mcrat_hip_photon *)malloc(sizeof(mcrat_hip_photon) * (size_t)per_piece * (size_t)stride);

@@ -218,10 +218,15 @@ typedef struct mcrat_host_pool_config {
     int    slots_per_rank;               /* 0: max_photons */
     mcrat_host_get_hydro_fn get_hydro;   /* the reader: stages hydro frame `scatt_frame` for `slab` on the POOL context (getHydroData) */
     void  *user;
-    int    write_checkpoints;            /* saveCheckpoint per rank and frame, mcrat.c:902 (0: skip -- benchmarks) */
+    int    write_checkpoints;            /* saveCheckpoint per rank and frame, mcrat.c:902 (0: skip -- benchmarks).  With cyclosynchrotron_switch the
+                                          * conversion saveCheckpoint performs on the list ('k' -> 'c', mcrat_io.c:896-900) happens every frame either way:
+                                          * it is what the next frame's absorption and the PT column expect */
     mcrat_host_print_arrays_fn print_photons;    /* mcrat_host_print_photon_arrays (the HDF5 build), or NULL to skip printPhotons */
     int    comv_switch, stokes_switch, save_type;
     int    max_frames;                   /* > 0: stop after this many hydro frames in total (tests, benchmarks) */
+    /* Hydro frames are stepped by ONE at the constant `fps` (time_now = frame / fps).  The legacy RIKEN schedule of mcrat.c:551-556,609-621 --
+     * increment 10 and fps 1 from frame 3000 on -- is not implemented here (the RIKEN reader is out of scope): such data go
+     * through the single-context shims, which take increment_scatt_frame as an argument. */
     /* CYCLOSYNCHROTRON_SWITCH ON (the pool context created with cyclosynchrotron_switch = 1): the frame is mcrat.c:706-878 per rank --
      * pool emission from a rank's second scatter frame on (:707), the hook inside the loop, rebinning, absorption -- through
      * mcrat_hip_pool_scatter_frames_cyclosynch; the slab read for a frame also covers the emission shell (calcCyclosynchRLimits,

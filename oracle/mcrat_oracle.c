@@ -466,7 +466,12 @@ double orc_sampleThermalElectron(double temp, orc_rng *rng)
 /* electron.c:177-200 (eq. 56 of the RAIKOU paper) */
 double orc_sampleElectronTheta(double beta, orc_rng *rng)
 {
-    return acos((1 - sqrt(1 + beta * beta + 2 * beta - 4 * beta * orc_rng_uniform(rng))) / beta);
+    /* the argument is -1 for a uniform of exactly 0 and +1 towards 1, and rounding can leave it an ulp outside [-1,1] there (acos -> NaN in the
+     * reference; a 24-bit ranlxs0 returns exactly 0 once in 1.7e7 draws): clamped, as in the engine (documented deviation, mcrat_oracle.h) */
+    double c = (1 - sqrt(1 + beta * beta + 2 * beta - 4 * beta * orc_rng_uniform(rng))) / beta;
+    if (c < -1.0) c = -1.0;
+    if (c > 1.0) c = 1.0;
+    return acos(c);
 }
 
 /* electron.c:126-175 */

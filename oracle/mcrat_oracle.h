@@ -24,6 +24,8 @@
  *   - a photon whose free time is the 1e12/c "never scatters" default is not
  *     offered to the scattering routine even if dt_max were larger (the
  *     reference would index hydro arrays with -1 there, mclib.c:1146-1148);
+ *   - sampleElectronTheta's cosine (electron.c:177-200) is clamped to [-1, 1]: for a uniform of exactly 0 rounding can leave it an ulp
+ *     outside, where the reference's acos gives NaN;
  *   - fprintf logging is replaced by counters in orc_stats.
  */
 #ifndef MCRAT_ORACLE_H

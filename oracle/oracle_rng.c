@@ -60,7 +60,11 @@ void orc_rng_init_tape(orc_rng *r, const double *tape, int64_t n)
 static double tape_next(orc_rng *r)
 {
     r->n_draws++;
-    if (r->tape_pos >= r->tape_n) { r->tape_error = 1; return 0.5; }
+    if (r->tape_pos >= r->tape_n) {          /* run out: flag it, go on with a filler that lets every rejection loop end */
+        r->tape_error = 1;
+        const double g = 0.6180339887498949 * (double)(++r->tape_pos - r->tape_n);
+        return g - (double)(long long)g;
+    }
     return r->tape[r->tape_pos++];
 }
 

@@ -56,7 +56,7 @@ typedef struct orc_rng {
      * located slot in ascending slot order (mclib.c:646-675), then photonEvent's draws (electron.c:81,196,217-233;
      * mcrat_scattering.c:519-574).  gsl_rng_uniform_pos redraws while it gets 0 (GSL rng/gsl_rng.h) and gsl_ran_gaussian's polar method
      * takes as many pairs as it needs (GSL randist/gauss.c): both fall out of reading the tape sequentially.  A tape that runs out sets
-     * tape_error and yields 0.5.  tools/ref_harness records such tapes from the unmodified reference. */
+     * tape_error (and a filler sequence lets the loops end).  tools/ref_harness records such tapes from the unmodified reference. */
     const double *tape;  /* NULL: the keyed source above */
     int64_t tape_n, tape_pos;
     int tape_error;

@@ -403,3 +403,48 @@ def test_lists_of_thousands_of_photons_equal_the_oracle(hip, oracle, case, threa
         _compare(v.get_photons(), P.aos)
         assert rst.frame_scatt_cnt > 0
     pool.close()
+
+
+def test_pool_set_photons_equals_set_photons_list_by_list(hip):
+    """mcrat_hip_pool_set_photons (a CONTINUE run's restart: all adopted ranks' checkpointed lists in one copy and one launch) leaves every list
+    exactly as mcrat_hip_set_photons on its view does -- columns, derived columns and flags (a frame run afterwards is bit-identical), the rest of
+    the window cleared, lists that were not named untouched; bad requests are refused before anything is touched"""
+    frame, ph, cfg = synth.config2(n_photons=4000, nzc=8, stokes=1, lumi=1e54)
+    lens = [700, 1000, 3, 1024, 512]
+    subs = _lists(ph, lens)
+    recs = [synth.photons_to_aos(sp, hip.PHOTON_DTYPE) for sp in subs]
+    rem = 1.0 / frame["fps"]
+
+    def pool():
+        p = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+        p.set_hydro(frame)
+        p.pool_create(len(lens) + 1, 1100)
+        return p
+    one = pool()
+    for r in range(len(lens)):
+        one.pool_rank(r, 20 + r).set_photons_aos(recs[r])
+    one.begin_frame(4, 0.0, rem)
+    want_stats = one.run(80)
+    want = [one.pool_rank(r, 20 + r).get_photons() for r in range(len(lens))]
+    many = pool()
+    for r in range(len(lens) + 1):
+        many.pool_rank(r, 20 + r)
+    many.pool_rank(5, 25).set_photons_aos(recs[2])                      # a list that is not named below keeps its photons
+    many.pool_rank(1, 21).set_photons_aos(recs[3])                      # a longer list was here before: its tail must be cleared
+    with pytest.raises(hip.McratHipError):
+        many.pool_set_photons([0, 0], [recs[0], recs[1]])               # a rank twice
+    with pytest.raises(hip.McratHipError):
+        many.pool_set_photons([0, 9], [recs[0], recs[1]])               # no such rank
+    many.pool_set_photons([3, 0, 1, 2, 4], [recs[3], recs[0], recs[1], recs[2], recs[4]])
+    assert [many.pool_rank(r, 20 + r).n for r in range(6)] == lens + [lens[2]]
+    kept = many.pool_rank(5, 25).get_photons()
+    assert np.array_equal(kept["p0"], subs[2]["p0"])
+    many.begin_frame(4, 0.0, rem)
+    got_stats = many.run(80)
+    for r in range(len(lens)):
+        out = many.pool_rank(r, 20 + r).get_photons()
+        for k in FLOAT_FIELDS + INT_FIELDS:
+            assert np.array_equal(out[k], want[r][k], equal_nan=True), (r, k)
+    assert got_stats.frame_scatt_cnt >= want_stats.frame_scatt_cnt      # (the extra list scatters too)
+    one.close()
+    many.close()

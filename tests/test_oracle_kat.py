@@ -840,3 +840,28 @@ def test_optimised_cpu_mode_is_bit_identical_to_the_faithful_one(oracle, case):
         assert np.array_equal(a, b, equal_nan=a.dtype.kind == "f"), k
     if case == "cfg1-hot-kn-chains":
         assert out[0][1][3] > 50                                    # the rejection chains really happened
+
+
+def test_oracle_tape_source_is_consumed_in_the_reference_call_order():
+    """oracle_rng.h TAPE source: calcMeanFreePath takes one gsl_rng_uniform_pos per located slot in ascending slot order (mclib.c:646-675) --
+    zeros skipped -- and photonEvent's draws follow (the same tape position as the engine's, tests/test_gpu_tape.py)"""
+    import ctypes as C
+    from mcrat_amd import synth
+    from oracle import oracle_py as O
+    frame, ph, cfg = synth.config2(n_photons=40, nzc=8, stokes=0, lumi=1e54)
+    H = O.OracleHydro(frame)
+    c = O.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    tape = np.random.default_rng(3).random(4000)
+    tape[[2, 3, 17]] = 0.0
+    P = O.OraclePhotons(synth.photons_to_aos(ph, O.PHOTON_DTYPE))
+    st, tn, rem, _ = O.photon_loop(c, P, H, seed=0, time_now=0.0, remaining_time=0.2, max_iterations=1, tape=tape)
+    a = P.aos
+    located = np.nonzero(a["nearest_block_index"] != -1)[0]
+    assert located.size >= 30
+    # after one pass every photon has been advanced by the pass's time step; time_to_scatter still holds the pass's draws
+    nz = tape[tape != 0.0]
+    want = (-1.0 / a["total_optical_depth"][located]) * np.log(nz[: located.size]) / 2.99792458e10
+    scattered = st.last_scattered_index
+    keep = located != scattered                       # (the scattered photon's optical depth is recomputed for its new momentum at the next pass)
+    assert np.allclose(a["time_to_scatter"][located][keep], want[keep], rtol=1e-14)
+    assert O.photon_loop.tape_pos > located.size + 3  # the free-path draws (three zeros skipped among them), then the event's

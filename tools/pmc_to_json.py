@@ -70,7 +70,7 @@ for sub, want, bytes_note in (("pmc_ranks", "rank_loop_kernel", "ranks"), ("pmc_
 open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
 for sub, name in (("kt_default", "%s_kernel_stats.csv" % tag), ("kt_list", "%s_list_kernel_stats.csv" % tag),
                   ("kt_ingest", "%s_ingest_kernel_stats.csv" % tag), ("kt_cfg3", "%s_cfg3_kernel_stats.csv" % tag),
-                  ("kt_cfg5", "%s_cfg5_kernel_stats.csv" % tag)):
+                  ("kt_cfg5", "%s_cfg5_kernel_stats.csv" % tag), ("kt_pools3", "%s_kernel_stats_pools3.csv" % tag)):
     f = stats_file(sub)
     if f:
         shutil.copy(f, os.path.join(dst, name))
@@ -81,8 +81,11 @@ if os.path.exists(t) and os.path.getsize(t) > 0:
 b = os.path.join(src, "bench.json")
 if os.path.exists(b) and os.path.getsize(b) > 0:
     shutil.copy(b, os.path.join(dst, "%s_bench.json" % tag))
-for name in ("bench_cfg3", "bench_cfg5", "kt_cfg5", "kt_default"):
+u = os.path.join(src, "pools3_union.json")
+if os.path.exists(u):
+    shutil.copy(u, os.path.join(dst, "%s_pools3_union.json" % tag))
+for name in ("bench_cfg3", "bench_cfg5", "kt_cfg5", "kt_default", "kt_pools3"):
     b = os.path.join(src, name + ".json")
     if os.path.exists(b) and os.path.getsize(b) > 0:
-        shutil.copy(b, os.path.join(dst, "%s_%s.json" % (tag, name.replace("kt_cfg5", "bench_cfg5_traced").replace("kt_default", "bench_traced"))))
+        shutil.copy(b, os.path.join(dst, "%s_%s.json" % (tag, name.replace("kt_cfg5", "bench_cfg5_traced").replace("kt_default", "bench_traced").replace("kt_pools3", "bench_traced_pools3"))))
 print(json.dumps({k: v["traffic_bytes_per_launch"] for k, v in out.items()}))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in one GPU call:  tools/profile_round.sh  (run through gpurun), then
-# `python tools/pmc_to_json.py gpurun_out/round profiles r02` here to turn the merged output into the committed files.
+# `python tools/pmc_to_json.py gpurun_out/round profiles r03` here to turn the merged output into the committed files.
 # PMC passes are separate runs with --kernel-trace only (never with --sys-trace & co); the program follows `--` directly.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -10,6 +10,9 @@ echo "== bench, no profiler"
 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "exit=$?"
 echo "== kernel trace of the default bench command"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_default -- python3 bench.py --pools 1 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_default.json 2> $out/kt_default.err; echo "exit=$?"
+echo "== kernel trace of the HEADLINE's launch shape: three pools on three streams (the per-dispatch trace is kept until the union of the overlapping launches is taken)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_pools3 -- python3 bench.py --pools 3 --steps 20 --warmup 5 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_pools3.json 2> $out/kt_pools3.err; echo "exit=$?"
+python3 tools/union_busy.py $out/kt_pools3 rank_loop_kernel 20 5 3 $out/pools3_union.json
 echo "== kernel trace, list mode (eager launches so that every kernel is a trace record)"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_list -- python3 bench.py --mode list --steps 500 --warmup 20 --graph 0 --other-mode 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/kt_list.json 2> $out/kt_list.err; echo "exit=$?"
 i=0
