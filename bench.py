@@ -904,9 +904,44 @@ def main():
                               "ms_per_frame": {"propagate_and_statistics": pc.ms_propagate / frames, "output": pc.ms_output / frames,
                                                "hydro_reader_and_ingest": pc.ms_hydro / pc.hydro_frames_read},
                               "scatter_events_per_s_inclusive": events / ((pc.ms_propagate + pc.ms_output + pc.ms_hydro) * 1e-3)}
+                if chk or hdf:
+                    # the writer thread (mcrat_hip_outbox_*): what it spent on the frames' files, how much of that the loop waited for, the rest
+                    # was hidden behind the loop; and what the file system alone takes for as many files of the same size (same C, same box)
+                    res[label]["ms_per_frame"]["writer_thread"] = pc.ms_output_writer / frames
+                    res[label]["ms_per_frame"]["loop_blocked_on_writer"] = pc.ms_output_blocked / frames
+                    res[label]["ms_per_frame"]["writer_hidden_behind_loop"] = max(pc.ms_output_writer - pc.ms_output_blocked, 0.0) / frames
+                    ms_floor = C.c_double(0)
+                    per_rank = 29 + 176 * int(pc.slots_per_rank or pc.max_photons)
+                    if host.mcrat_host_output_floor((tmp + "/").encode(), R, per_rank, frames, 4, C.byref(ms_floor)) == 0:
+                        res[label]["ms_per_frame"]["file_system_floor_checkpoints"] = ms_floor.value
                 pool.close()
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
+        # a CONTINUE run's start (readCheckpoint's lists handed to the pool, mcrat.c:487): R lists of 1000 records from host memory, all at once
+        # (mcrat_hip_pool_set_photons: one copy over PCIe, one launch) and list by list through the views (round 2's path)
+        try:
+            fr2, ph2, _ = synth.config2(n_photons=1000 * 64, nzc=args.nzc)
+            recs = synth.photons_to_aos(ph2, engine.PHOTON_DTYPE)
+            lists = [recs[(r % 64) * 1000:(r % 64 + 1) * 1000] for r in range(R)]
+            pool = engine.Engine(synth.TWO, synth.CYLINDRICAL, 0, device=local_rank, stream=stream)
+            pool.pool_create(R, 1000)
+            views = [pool.pool_rank(r, 7000 + r) for r in range(R)]
+            pool.pool_set_photons(list(range(R)), lists)             # (allocations)
+            pool.synchronize()
+            t0 = time.perf_counter()
+            pool.pool_set_photons(list(range(R)), lists)
+            pool.synchronize()
+            t_all = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for r in range(64):
+                views[r].set_photons_aos(lists[r])
+            pool.synchronize()
+            t_each = (time.perf_counter() - t0) * R / 64
+            res["restart_set_photons"] = {"ranks": R, "photons_per_rank": 1000, "ms_all_at_once": t_all * 1e3,
+                                          "ms_list_by_list": t_each * 1e3, "note": "list by list: 64 lists timed, scaled to %d" % R}
+            pool.close()
+        except Exception as ex:
+            res["restart_set_photons"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
         return res
 
     pcie = None

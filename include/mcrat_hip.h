@@ -302,6 +302,22 @@ int mcrat_hip_get_output(mcrat_hip_ctx *ctx, mcrat_hip_output_columns *out);
 int mcrat_hip_convert_comptonized(mcrat_hip_ctx *ctx, int *num_converted);
 int mcrat_hip_get_photons_range(mcrat_hip_ctx *ctx, int first, int count, mcrat_hip_photon *records);
 
+/* The same two consumers WHILE THE NEXT FRAME RUNS.  The reference calls saveCheckpoint (mcrat.c:902; mcrat_io.c:838-1009) and printPhotons
+ * (mcrat.c:907; mcrat_io.c:114-836) at the end of every frame with the rank idle; an outbox takes what they read off the device without
+ * holding the loop up:
+ *   mcrat_hip_outbox_post   stages the records of ALL slots (want_records) and/or the compacted output columns (want_output; what
+ *                           mcrat_hip_get_output returns) in device memory of the outbox, in the context's stream order, and starts their copy
+ *                           into pinned host memory on a stream of the outbox's own.  When it returns the photons may change: begin the next
+ *                           frame.  Posting again waits for the previous post's copy.
+ *   mcrat_hip_outbox_wait   blocks until the copy has landed; may be called from another thread (a writer).  The pointers address the outbox's
+ *                           pinned memory and stay valid until the next post on the same outbox (columns: all 17 + type; count photons).
+ * Two outboxes give a double buffer: frame f written from one while frame f+1 is posted into the other (mcrat_host_run_ranks does this). */
+typedef struct mcrat_hip_outbox mcrat_hip_outbox;
+int  mcrat_hip_outbox_create(mcrat_hip_ctx *ctx, mcrat_hip_outbox **box);
+void mcrat_hip_outbox_destroy(mcrat_hip_outbox *box);
+int  mcrat_hip_outbox_post(mcrat_hip_ctx *ctx, mcrat_hip_outbox *box, int want_records, int want_output);
+int  mcrat_hip_outbox_wait(mcrat_hip_outbox *box, const mcrat_hip_photon **records, int *n_records, mcrat_hip_output_columns *cols);
+
 /* Cyclo-synchrotron: the stages of a scatter frame with CYCLOSYNCHROTRON_SWITCH on.  They work on whatever photon
  * types the list holds; mcrat_hip_scatter_frame_cyclosynch (below) chains them as mcrat.c:706-878 does and needs a context created
  * with cyclosynchrotron_switch = 1.

@@ -2063,6 +2063,131 @@ extern "C" int mcrat_hip_get_output(mcrat_hip_ctx *c, mcrat_hip_output_columns *
     return MCRAT_HIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- asynchronous output
+// What saveCheckpoint (mcrat_io.c:838-1009) and printPhotons (mcrat_io.c:114-836) read, taken off the device WHILE THE NEXT FRAME RUNS: post()
+// stages the records and the compacted output columns in device buffers of the outbox by kernels in the context's stream order -- the photons
+// may change as soon as post() has returned -- and a copy stream of the outbox's own brings them into pinned host memory; wait() (any thread)
+// blocks until they have landed.  (The reference writes both files at the end of every frame with its rank idle, mcrat.c:902,907.)
+struct mcrat_hip_outbox {
+    int device = 0;
+    hipStream_t copy = nullptr;
+    hipEvent_t staged = nullptr, landed = nullptr;
+    void *d_buf = nullptr, *h_buf = nullptr;
+    size_t cap = 0;
+    size_t o_rec = 0, o_cols = 0, col_stride = 0;
+    int n_records = 0, n_output = 0;
+    bool posted = false, have_records = false, have_output = false;
+};
+
+extern "C" int mcrat_hip_outbox_create(mcrat_hip_ctx *c, mcrat_hip_outbox **out)
+{
+    if (!c || !out) return MCRAT_HIP_EINVAL;
+    mcrat_hip_outbox *b = new (std::nothrow) mcrat_hip_outbox();
+    if (!b) return MCRAT_HIP_ENOMEM;
+    b->device = c->cfg.device;
+    if (hipStreamCreateWithFlags(&b->copy, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&b->staged, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->landed, hipEventDisableTiming) != hipSuccess) {
+        mcrat_hip_outbox_destroy(b);
+        return MCRAT_HIP_EHIP;
+    }
+    *out = b;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" void mcrat_hip_outbox_destroy(mcrat_hip_outbox *b)
+{
+    if (!b) return;
+    if (b->copy) { (void)hipStreamSynchronize(b->copy); (void)hipStreamDestroy(b->copy); }
+    if (b->staged) (void)hipEventDestroy(b->staged);
+    if (b->landed) (void)hipEventDestroy(b->landed);
+    if (b->d_buf) (void)hipFree(b->d_buf);
+    if (b->h_buf) (void)hipHostFree(b->h_buf);
+    delete b;
+}
+
+extern "C" int mcrat_hip_outbox_post(mcrat_hip_ctx *c, mcrat_hip_outbox *b, int want_records, int want_output)
+{
+    if (!c || !b || (!want_records && !want_output)) return MCRAT_HIP_EINVAL;
+    if (!c->have_photons) return MCRAT_HIP_ESTATE;
+    const int n = c->ph.n;
+    int rc = flush_pending(c);
+    if (rc) return rc;
+    if (b->posted) HIPCHK(c, hipEventSynchronize(b->landed));          // (a post over one nobody waited for)
+    b->posted = false;
+    const long long nblk = (n + 255) / 256;
+    unsigned long long total = 0;
+    if (want_output) {
+        int rc_ = ensure_counts(c, (size_t)nblk);
+        if (rc_) return rc_;
+        HIPCHK(c, launch_output_count(c->ph, n, c->grid_count, c->d_grid_total, c->stream));
+        HIPCHK(c, hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    const size_t m = (size_t)total;
+    const size_t rec_bytes = want_records ? align_up(sizeof(mcrat_hip_photon) * (size_t)n, 256) : 0;
+    const size_t stride = align_up(sizeof(double) * (m ? m : 1), 256);
+    const size_t cols_bytes = want_output ? 17 * stride + align_up(m ? m : 1, 256) : 0;
+    const size_t scan_bytes = want_output ? align_up(sizeof(int) * ((size_t)nblk + 1 + grid_scan_scratch_ints(nblk)), 256) : 0;
+    const size_t need = rec_bytes + cols_bytes + scan_bytes;
+    if (need > b->cap) {
+        const size_t cap = need + need / 4;
+        if (b->d_buf) (void)hipFree(b->d_buf);
+        if (b->h_buf) (void)hipHostFree(b->h_buf);
+        b->d_buf = b->h_buf = nullptr;
+        b->cap = 0;
+        HIPCHK(c, hipMalloc(&b->d_buf, cap));
+        HIPCHK(c, hipHostMalloc(&b->h_buf, cap, hipHostMallocDefault));
+        b->cap = cap;
+    }
+    char *d = static_cast<char *>(b->d_buf), *h = static_cast<char *>(b->h_buf);
+    b->o_rec = 0; b->o_cols = rec_bytes; b->col_stride = stride;
+    b->n_records = want_records ? n : 0;
+    b->n_output = (int)m;
+    b->have_records = want_records != 0;
+    b->have_output = want_output != 0;
+    if (want_records) {
+        HIPCHK(c, hipMemsetAsync(d, 0, rec_bytes, c->stream));            // the bytes between the members: zero
+        HIPCHK(c, launch_soa_to_aos(c->ph, d, 0, n, c->stream));
+    }
+    if (want_output && m > 0) {
+        OutputCols oc;
+        for (int k = 0; k < 17; ++k) oc.col[k] = reinterpret_cast<double *>(d + b->o_cols + k * stride);
+        oc.type = d + b->o_cols + 17 * stride;
+        int *start = reinterpret_cast<int *>(d + rec_bytes + cols_bytes), *scratch = start + nblk + 1;
+        HIPCHK(c, launch_exclusive_scan(c->grid_count, nblk, start, scratch, (long long)total, c->stream));
+        HIPCHK(c, launch_output_write(c->ph, n, start, oc, c->stream));
+    }
+    HIPCHK(c, hipEventRecord(b->staged, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(b->copy, b->staged, 0));
+    const size_t bytes = rec_bytes + (want_output && m > 0 ? cols_bytes : 0);
+    if (bytes) HIPCHK(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, b->copy));
+    HIPCHK(c, hipEventRecord(b->landed, b->copy));
+    b->posted = true;
+    return MCRAT_HIP_OK;
+}
+
+extern "C" int mcrat_hip_outbox_wait(mcrat_hip_outbox *b, const mcrat_hip_photon **records, int *n_records, mcrat_hip_output_columns *cols)
+{
+    if (!b) return MCRAT_HIP_EINVAL;
+    if (!b->posted) return MCRAT_HIP_ESTATE;
+    if (hipSetDevice(b->device) != hipSuccess) return MCRAT_HIP_ENODEV;       // (the caller may be a thread of its own)
+    if (hipEventSynchronize(b->landed) != hipSuccess) return MCRAT_HIP_EHIP;
+    char *h = static_cast<char *>(b->h_buf);
+    if (records) *records = b->have_records ? reinterpret_cast<const mcrat_hip_photon *>(h + b->o_rec) : nullptr;
+    if (n_records) *n_records = b->n_records;
+    if (cols) {
+        memset(cols, 0, sizeof *cols);
+        cols->count = b->have_output ? b->n_output : 0;
+        if (b->have_output && b->n_output > 0) {
+            double **dst[17] = {&cols->p0, &cols->p1, &cols->p2, &cols->p3, &cols->comv_p0, &cols->comv_p1, &cols->comv_p2, &cols->comv_p3, &cols->r0, &cols->r1,
+                                &cols->r2, &cols->s0, &cols->s1, &cols->s2, &cols->s3, &cols->num_scatt, &cols->weight};
+            for (int k = 0; k < 17; ++k) *dst[k] = reinterpret_cast<double *>(h + b->o_cols + k * b->col_stride);
+            cols->type = h + b->o_cols + 17 * b->col_stride;
+        }
+    }
+    return MCRAT_HIP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- the loop
 static long long read_table_misses(mcrat_hip_ctx *c)
 {

@@ -38,8 +38,10 @@ class PoolConfig(C.Structure):
                 ("get_hydro", GET_HYDRO), ("user", C.c_void_p), ("write_checkpoints", C.c_int),
                 ("print_photons", C.c_void_p), ("comv_switch", C.c_int), ("stokes_switch", C.c_int), ("save_type", C.c_int),
                 ("max_frames", C.c_int), ("cyclosynchrotron_switch", C.c_int), ("cs", engine.Cyclosynch), ("mode", C.c_int), ("fast_windows", C.c_int),
+                ("sync_output", C.c_int), ("output_threads", C.c_int),
                 ("hydro_frames_read", C.c_longlong), ("launches", C.c_longlong),
-                ("ms_propagate", C.c_double), ("ms_hydro", C.c_double), ("ms_output", C.c_double)]
+                ("ms_propagate", C.c_double), ("ms_hydro", C.c_double), ("ms_output", C.c_double),
+                ("ms_output_writer", C.c_double), ("ms_output_blocked", C.c_double)]
 
 
 _host = None
@@ -71,6 +73,8 @@ def host():
                                                       C.POINTER(C.c_double), C.c_double, C.c_uint64, C.c_int, C.POINTER(engine.FrameStats)]
         lib.mcrat_host_exchange_device.restype = C.c_int
         lib.mcrat_host_exchange_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.mcrat_host_output_floor.restype = C.c_int
+        lib.mcrat_host_output_floor.argtypes = [C.c_char_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
         lib.mcrat_host_run_ranks.restype = C.c_int
         lib.mcrat_host_run_ranks.argtypes = [C.c_void_p, C.POINTER(HostRank), C.c_int, C.POINTER(PoolConfig)]
         _host = lib

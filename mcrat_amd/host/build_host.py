@@ -13,7 +13,7 @@ def build(force=False):
     deps = [SRC, os.path.join(HERE, "mcrat_hip_host.h"), os.path.join(ROOT, "include", "mcrat_hip.h")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(d) <= os.path.getmtime(LIB) for d in deps):
         return LIB
-    cmd = ["gcc", "-std=gnu99", "-O2", "-Wall", "-Wextra", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), SRC,
+    cmd = ["gcc", "-std=gnu99", "-O2", "-Wall", "-Wextra", "-pthread", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), SRC,
            "-o", LIB, "-L", hip_lib_dir, "-lmcrat_hip", "-Wl,-rpath,$ORIGIN/.."]
     subprocess.run(cmd, check=True)
     return LIB

@@ -4,6 +4,7 @@
 #include <ctype.h>
 #include <limits.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -513,6 +514,182 @@ static double wall_ms(void)
 
 #define RANK_DEG(r) (r)->theta_jmin_thread * 180 / M_PI, (r)->theta_jmax_thread * 180 / M_PI
 
+/* ------------------------------------------------------------------ asynchronous output (mcrat_hip_outbox_*, include/mcrat_hip.h)
+ * Frame f's checkpoint and mc_proc files are written by a writer thread from pinned memory while frame f+1 propagates.  The reference writes
+ * them at the end of the frame with the rank idle (mcrat.c:902,907); the bytes are the same, only who waits for the file system differs.
+ * Checkpoints are independent stdio files: `helpers` threads share the ranks.  printPhotons is the caller's callback (HDF5, whose library is
+ * not thread-safe in its default build): the writer thread alone calls it, for one rank after the other, beside the helpers. */
+typedef struct out_rank_meta {
+    int active, frame, frm2, list_capacity, num_output, angle_id, angle_procs;
+    double time_now, deg_lo, deg_hi;
+    const char *mc_dir;
+    FILE *fPtr;
+} out_rank_meta;
+
+typedef struct out_job {
+    int F, n_ranks, stride, last_frm, write_checkpoints, helpers;
+    out_rank_meta *meta;
+    const mcrat_hip_photon *records;
+    mcrat_hip_output_columns cols;
+    mcrat_host_print_arrays_fn print_photons;
+    int comv_switch, stokes_switch, save_type;
+    volatile int rc;
+} out_job;
+
+typedef struct out_slice { out_job *job; int first, step; pthread_t thread; int started; } out_slice;
+
+static void *checkpoint_slice(void *p)
+{
+    out_slice *sl = (out_slice *)p;
+    out_job *j = sl->job;
+    for (int r = sl->first; r < j->n_ranks && j->rc == 0; r += sl->step) {
+        const out_rank_meta *k = &j->meta[r];
+        if (!k->active) continue;
+        mcrat_hip_photon_list l;
+        memset(&l, 0, sizeof l);
+        l.photons = (mcrat_hip_photon *)(j->records + (size_t)r * (size_t)j->stride);     /* (written from, never to) */
+        l.list_capacity = k->list_capacity;
+        if (k->fPtr) fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: Making checkpoint file\n", k->angle_id, k->deg_lo, k->deg_hi);
+        if (mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, j->F, k->time_now, NULL, &l, l.list_capacity, j->last_frm, k->angle_id, k->angle_procs, 0) != 0) {
+            if (k->fPtr) fprintf(k->fPtr, "There is an issue with opening and saving the chkpt file therefore MCRaT is not saving data to the checkpoint or mc_proc files to prevent corruption of those data.\n");
+            j->rc = 1;
+        }
+    }
+    return NULL;
+}
+
+/* saveCheckpoint (mcrat.c:902-915) and printPhotons (:907) of every active rank from the host copies the job points at */
+static int write_frame_files(out_job *j)
+{
+    out_slice sl[64];
+    int T = 0;
+    if (j->write_checkpoints && j->records) {
+        T = j->helpers < 1 ? 1 : (j->helpers > 64 ? 64 : j->helpers);
+        for (int t = 0; t < T; t++) {
+            sl[t].job = j; sl[t].first = t; sl[t].step = T;
+            sl[t].started = (t + 1 < T || j->print_photons) ? pthread_create(&sl[t].thread, NULL, checkpoint_slice, &sl[t]) == 0 : 0;
+            if (!sl[t].started && (t + 1 < T || j->print_photons)) checkpoint_slice(&sl[t]);     /* no thread to be had: here */
+        }
+        if (!j->print_photons) checkpoint_slice(&sl[T - 1]);                                   /* (the last slice on this thread when it has nothing else to do) */
+    }
+    if (j->print_photons) {
+        size_t first = 0;
+        for (int r = 0; r < j->n_ranks && j->rc == 0; r++) {
+            const out_rank_meta *k = &j->meta[r];
+            const size_t m = (size_t)k->num_output;
+            if (k->active && m > 0) {
+                mcrat_hip_output_columns one = j->cols;
+                double **os[17] = {&one.p0, &one.p1, &one.p2, &one.p3, &one.comv_p0, &one.comv_p1, &one.comv_p2, &one.comv_p3, &one.r0, &one.r1, &one.r2,
+                                   &one.s0, &one.s1, &one.s2, &one.s3, &one.num_scatt, &one.weight};
+                for (int c = 0; c < 17; c++) {
+                    const int is_comv = c >= 4 && c < 8, is_stokes = c >= 11 && c < 15;
+                    if ((is_comv && !j->comv_switch) || (is_stokes && !j->stokes_switch)) *os[c] = NULL;
+                    else if (*os[c]) *os[c] += first;
+                }
+                one.type = (j->save_type && one.type) ? one.type + first : NULL;
+                one.count = (int)m;
+                const int prc = j->print_photons(&one, j->F, k->mc_dir, k->angle_id, k->fPtr);
+                if (prc) j->rc = prc;
+            }
+            first += m;
+        }
+    }
+    for (int t = 0; t < T; t++)
+        if (sl[t].started) pthread_join(sl[t].thread, NULL);
+    return j->rc;
+}
+
+typedef struct out_writer {
+    pthread_t thread;
+    int started;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    out_job job[2];
+    mcrat_hip_outbox *box[2];
+    long long submitted, done;
+    int quit, rc;
+    double ms_busy;
+} out_writer;
+
+static void *writer_main(void *p)
+{
+    out_writer *w = (out_writer *)p;
+    for (;;) {
+        pthread_mutex_lock(&w->mu);
+        while (w->done == w->submitted && !w->quit) pthread_cond_wait(&w->cv, &w->mu);
+        if (w->done == w->submitted) { pthread_mutex_unlock(&w->mu); return NULL; }
+        const int slot = (int)(w->done & 1);
+        pthread_mutex_unlock(&w->mu);
+        out_job *j = &w->job[slot];
+        const double t0 = wall_ms();
+        int n_rec = 0;
+        int rc = mcrat_hip_outbox_wait(w->box[slot], &j->records, &n_rec, &j->cols);
+        if (rc == 0) rc = write_frame_files(j);
+        const double dt = wall_ms() - t0;
+        pthread_mutex_lock(&w->mu);
+        if (rc && !w->rc) w->rc = rc;
+        w->ms_busy += dt;
+        w->done += 1;
+        pthread_cond_broadcast(&w->cv);
+        pthread_mutex_unlock(&w->mu);
+    }
+}
+
+/* blocks until fewer than `keep` jobs are in flight; returns the writer's first error */
+static int writer_drain(out_writer *w, long long keep)
+{
+    pthread_mutex_lock(&w->mu);
+    while (w->submitted - w->done >= keep + 1) pthread_cond_wait(&w->cv, &w->mu);
+    const int rc = w->rc;
+    pthread_mutex_unlock(&w->mu);
+    return rc;
+}
+
+static void *floor_slice(void *p)
+{
+    out_slice *sl = (out_slice *)p;
+    out_job *j = sl->job;                       /* (n_ranks files of `stride` bytes each in meta[0].mc_dir, from `records`) */
+    char file[2000], old[2100];
+    for (int r = sl->first; r < j->n_ranks; r += sl->step) {
+        snprintf(file, sizeof file, "%sfloor_%d.dat", j->meta[0].mc_dir, r);
+        snprintf(old, sizeof old, "%s_old", file);
+        (void)rename(file, old);
+        FILE *f = fopen(file, "wb");
+        if (!f) { j->rc = 1; continue; }
+        if (fwrite(j->records, 1, (size_t)j->stride, f) != (size_t)j->stride) j->rc = 1;
+        if (fclose(f) != 0) j->rc = 1;
+    }
+    return NULL;
+}
+
+int mcrat_host_output_floor(const char *dir, int n_files, size_t bytes_each, int frames, int threads, double *ms_per_frame)
+{
+    if (!dir || n_files <= 0 || bytes_each == 0 || bytes_each > (size_t)INT_MAX || frames <= 0 || !ms_per_frame) return MCRAT_HIP_EINVAL;
+    char *payload = (char *)calloc(1, bytes_each);
+    if (!payload) return MCRAT_HIP_ENOMEM;
+    out_rank_meta meta;
+    memset(&meta, 0, sizeof meta);
+    meta.mc_dir = dir;
+    out_job j;
+    memset(&j, 0, sizeof j);
+    j.n_ranks = n_files; j.stride = (int)bytes_each; j.meta = &meta; j.records = (const mcrat_hip_photon *)payload;
+    const int T = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    out_slice sl[64];
+    const double t0 = wall_ms();
+    for (int f = 0; f < frames; f++) {
+        for (int t = 0; t < T; t++) {
+            sl[t].job = &j; sl[t].first = t; sl[t].step = T;
+            sl[t].started = t + 1 < T ? pthread_create(&sl[t].thread, NULL, floor_slice, &sl[t]) == 0 : 0;
+            if (!sl[t].started) floor_slice(&sl[t]);
+        }
+        for (int t = 0; t < T; t++)
+            if (sl[t].started) pthread_join(sl[t].thread, NULL);
+    }
+    *ms_per_frame = (wall_ms() - t0) / frames;
+    free(payload);
+    return j.rc;
+}
+
 int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_ranks, mcrat_host_pool_config *cfg)
 {
     if (!pool || !ranks || n_ranks <= 0 || !cfg || !cfg->get_hydro || !(cfg->fps > 0) || cfg->max_photons <= 0) return MCRAT_HIP_EINVAL;
@@ -538,6 +715,27 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     }
     cfg->hydro_frames_read = cfg->launches = 0;
     cfg->ms_propagate = cfg->ms_hydro = cfg->ms_output = 0;
+    cfg->ms_output_writer = cfg->ms_output_blocked = 0;
+    /* the writer of the frames' files (asynchronous output): two outboxes, two jobs */
+    const int async_out = !cfg->sync_output && (cfg->write_checkpoints || cfg->print_photons);
+    out_writer *wr = NULL;
+    if (async_out) {
+        wr = (out_writer *)calloc(1, sizeof *wr);
+        if (!wr) rc = MCRAT_HIP_ENOMEM;
+        if (rc == 0) {
+            pthread_mutex_init(&wr->mu, NULL);
+            pthread_cond_init(&wr->cv, NULL);
+            for (int b = 0; b < 2 && rc == 0; b++) {
+                wr->job[b].meta = (out_rank_meta *)calloc((size_t)n_ranks, sizeof(out_rank_meta));
+                if (!wr->job[b].meta) rc = MCRAT_HIP_ENOMEM;
+                else rc = mcrat_hip_outbox_create(pool, &wr->box[b]);
+            }
+            if (rc == 0) {
+                wr->started = pthread_create(&wr->thread, NULL, writer_main, wr) == 0;
+                if (!wr->started) rc = MCRAT_HIP_ENOMEM;
+            }
+        }
+    }
     for (int r = 0; r < n_ranks && rc == 0; r++) {
         mcrat_host_rank *k = &ranks[r];
         rc = mcrat_hip_pool_rank(pool, r, k->rng_stream, &k->view);
@@ -725,72 +923,103 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
              * Here it is therefore part of the FRAME, whatever write_checkpoints says: the next frame's phAbsCyclosynch and the PT column of
              * mc_proc see the converted types also in runs that skip the checkpoint files (benchmarks). */
             if (cfg->cyclosynchrotron_switch && (rc = mcrat_hip_convert_comptonized(pool, NULL))) break;
-            if (cfg->write_checkpoints) {
-                const int per_piece = (1 << 20) / stride > 0 ? (1 << 20) / stride : 1;
-                if (!rec_buf) rec_buf = (mcrat_hip_photon *)malloc(sizeof(mcrat_hip_photon) * (size_t)per_piece * (size_t)stride);
-                if (!rec_buf) { rc = MCRAT_HIP_ENOMEM; break; }
-                for (int r0 = 0; r0 < n_ranks && rc == 0; r0 += per_piece) {
-                    const int r1 = r0 + per_piece < n_ranks ? r0 + per_piece : n_ranks;
-                    int any = 0;
-                    for (int r = r0; r < r1; r++) any |= ranks[r].state == 1;
-                    if (!any) continue;
-                    if ((rc = mcrat_hip_get_photons_range(pool, r0 * stride, (r1 - r0) * stride, rec_buf))) break;
-                    for (int r = r0; r < r1; r++) {
-                        mcrat_host_rank *k = &ranks[r];
-                        if (k->state != 1) continue;
-                        mcrat_hip_photon_list l;
-                        memset(&l, 0, sizeof l);
-                        l.photons = rec_buf + (size_t)(r - r0) * (size_t)stride;
-                        l.list_capacity = summ[r].list_capacity;
-                        if (k->fPtr) fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: Making checkpoint file\n", k->angle_id, RANK_DEG(k));
-                        if (mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, F, k->time_now, NULL, &l, l.list_capacity, cfg->last_frm, k->angle_id,
-                                                       k->angle_procs, 0) != 0) {
-                            if (k->fPtr) fprintf(k->fPtr, "There is an issue with opening and saving the chkpt file therefore MCRaT is not saving data to the checkpoint or mc_proc files to prevent corruption of those data.\n");
-                            rc = 1;
-                            break;
+            if (async_out) {
+                /* the files of frame F: records and columns staged on the device in stream order and on their way into pinned memory when post()
+                 * returns; the writer thread takes it from there while the loop goes on with frame F + 1 */
+                const double tb = wall_ms();
+                rc = writer_drain(wr, 1);                                                         /* a free outbox (the one of frame F - 2) */
+                cfg->ms_output_blocked += wall_ms() - tb;
+                if (rc) break;
+                const int slot = (int)(wr->submitted & 1);
+                if ((rc = mcrat_hip_outbox_post(pool, wr->box[slot], cfg->write_checkpoints, cfg->print_photons != NULL))) break;
+                out_job *j = &wr->job[slot];
+                j->F = F; j->n_ranks = n_ranks; j->stride = stride; j->last_frm = cfg->last_frm; j->write_checkpoints = cfg->write_checkpoints;
+                j->helpers = cfg->output_threads > 0 ? cfg->output_threads : 4;
+                j->print_photons = cfg->print_photons;
+                j->comv_switch = cfg->comv_switch; j->stokes_switch = cfg->stokes_switch; j->save_type = cfg->save_type;
+                j->rc = 0;
+                for (int r = 0; r < n_ranks; r++) {
+                    const mcrat_host_rank *k = &ranks[r];
+                    out_rank_meta *m = &j->meta[r];
+                    m->active = k->state == 1;
+                    m->frame = k->frame; m->frm2 = k->frm2; m->time_now = k->time_now;
+                    m->list_capacity = summ[r].list_capacity; m->num_output = summ[r].num_output;
+                    m->angle_id = k->angle_id; m->angle_procs = k->angle_procs;
+                    m->deg_lo = k->theta_jmin_thread * 180 / M_PI; m->deg_hi = k->theta_jmax_thread * 180 / M_PI;
+                    m->mc_dir = k->mc_dir; m->fPtr = k->fPtr;
+                }
+                pthread_mutex_lock(&wr->mu);
+                wr->submitted += 1;
+                pthread_cond_broadcast(&wr->cv);
+                pthread_mutex_unlock(&wr->mu);
+            } else {
+                if (cfg->write_checkpoints) {
+                    const int per_piece = (1 << 20) / stride > 0 ? (1 << 20) / stride : 1;
+                    if (!rec_buf) rec_buf = (mcrat_hip_photon *)malloc(sizeof(mcrat_hip_photon) * (size_t)per_piece * (size_t)stride);
+                    if (!rec_buf) { rc = MCRAT_HIP_ENOMEM; break; }
+                    for (int r0 = 0; r0 < n_ranks && rc == 0; r0 += per_piece) {
+                        const int r1 = r0 + per_piece < n_ranks ? r0 + per_piece : n_ranks;
+                        int any = 0;
+                        for (int r = r0; r < r1; r++) any |= ranks[r].state == 1;
+                        if (!any) continue;
+                        if ((rc = mcrat_hip_get_photons_range(pool, r0 * stride, (r1 - r0) * stride, rec_buf))) break;
+                        for (int r = r0; r < r1; r++) {
+                            mcrat_host_rank *k = &ranks[r];
+                            if (k->state != 1) continue;
+                            mcrat_hip_photon_list l;
+                            memset(&l, 0, sizeof l);
+                            l.photons = rec_buf + (size_t)(r - r0) * (size_t)stride;
+                            l.list_capacity = summ[r].list_capacity;
+                            if (k->fPtr) fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: Making checkpoint file\n", k->angle_id, RANK_DEG(k));
+                            if (mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, F, k->time_now, NULL, &l, l.list_capacity, cfg->last_frm, k->angle_id,
+                                                           k->angle_procs, 0) != 0) {
+                                if (k->fPtr) fprintf(k->fPtr, "There is an issue with opening and saving the chkpt file therefore MCRaT is not saving data to the checkpoint or mc_proc files to prevent corruption of those data.\n");
+                                rc = 1;
+                                break;
+                            }
                         }
                     }
+                    if (rc) break;
                 }
-                if (rc) break;
-            }
-            /* printPhotons (:907): the pool's compacted columns in one transfer (photons with weight != 0 in slot order, i.e. list after list) */
-            if (cfg->print_photons) {
-                mcrat_hip_output_columns all;
-                memset(&all, 0, sizeof all);
-                if ((rc = mcrat_hip_get_output(pool, &all))) break;                               /* the count */
-                const size_t cnt = (size_t)all.count;
-                if (cnt > out_cap) {
-                    free(out_buf); free(out_type);
-                    out_buf = (double *)malloc(sizeof(double) * 17 * (cnt ? cnt : 1));
-                    out_type = (char *)malloc(cnt ? cnt : 1);
-                    out_cap = cnt;
-                    if (!out_buf || !out_type) { rc = MCRAT_HIP_ENOMEM; break; }
-                }
-                double **slot[17] = {&all.p0, &all.p1, &all.p2, &all.p3, &all.comv_p0, &all.comv_p1, &all.comv_p2, &all.comv_p3, &all.r0, &all.r1, &all.r2,
-                                     &all.s0, &all.s1, &all.s2, &all.s3, &all.num_scatt, &all.weight};
-                for (int c = 0; c < 17; c++) {
-                    const int is_comv = c >= 4 && c < 8, is_stokes = c >= 11 && c < 15;
-                    *slot[c] = ((is_comv && !cfg->comv_switch) || (is_stokes && !cfg->stokes_switch)) ? NULL : out_buf + (size_t)c * cnt;
-                }
-                all.type = cfg->save_type ? out_type : NULL;
-                if (cnt && (rc = mcrat_hip_get_output(pool, &all))) break;
-                size_t first = 0;
-                for (int r = 0; r < n_ranks && rc == 0; r++) {
-                    mcrat_host_rank *k = &ranks[r];
-                    const size_t m = (size_t)summ[r].num_output;
-                    if (k->state == 1 && m > 0) {
-                        mcrat_hip_output_columns one = all;
-                        double **os[17] = {&one.p0, &one.p1, &one.p2, &one.p3, &one.comv_p0, &one.comv_p1, &one.comv_p2, &one.comv_p3, &one.r0, &one.r1, &one.r2,
-                                           &one.s0, &one.s1, &one.s2, &one.s3, &one.num_scatt, &one.weight};
-                        for (int c = 0; c < 17; c++)
-                            if (*os[c]) *os[c] += first;
-                        if (one.type) one.type += first;
-                        one.count = (int)m;
-                        rc = cfg->print_photons(&one, F, k->mc_dir, k->angle_id, k->fPtr);
+                /* printPhotons (:907): the pool's compacted columns in one transfer (photons with weight != 0 in slot order, i.e. list after list) */
+                if (cfg->print_photons) {
+                    mcrat_hip_output_columns all;
+                    memset(&all, 0, sizeof all);
+                    if ((rc = mcrat_hip_get_output(pool, &all))) break;                               /* the count */
+                    const size_t cnt = (size_t)all.count;
+                    if (cnt > out_cap) {
+                        free(out_buf); free(out_type);
+                        out_buf = (double *)malloc(sizeof(double) * 17 * (cnt ? cnt : 1));
+                        out_type = (char *)malloc(cnt ? cnt : 1);
+                        out_cap = cnt;
+                        if (!out_buf || !out_type) { rc = MCRAT_HIP_ENOMEM; break; }
                     }
-                    first += m;
+                    double **slot[17] = {&all.p0, &all.p1, &all.p2, &all.p3, &all.comv_p0, &all.comv_p1, &all.comv_p2, &all.comv_p3, &all.r0, &all.r1, &all.r2,
+                                         &all.s0, &all.s1, &all.s2, &all.s3, &all.num_scatt, &all.weight};
+                    for (int c = 0; c < 17; c++) {
+                        const int is_comv = c >= 4 && c < 8, is_stokes = c >= 11 && c < 15;
+                        *slot[c] = ((is_comv && !cfg->comv_switch) || (is_stokes && !cfg->stokes_switch)) ? NULL : out_buf + (size_t)c * cnt;
+                    }
+                    all.type = cfg->save_type ? out_type : NULL;
+                    if (cnt && (rc = mcrat_hip_get_output(pool, &all))) break;
+                    size_t first = 0;
+                    for (int r = 0; r < n_ranks && rc == 0; r++) {
+                        mcrat_host_rank *k = &ranks[r];
+                        const size_t m = (size_t)summ[r].num_output;
+                        if (k->state == 1 && m > 0) {
+                            mcrat_hip_output_columns one = all;
+                            double **os[17] = {&one.p0, &one.p1, &one.p2, &one.p3, &one.comv_p0, &one.comv_p1, &one.comv_p2, &one.comv_p3, &one.r0, &one.r1, &one.r2,
+                                               &one.s0, &one.s1, &one.s2, &one.s3, &one.num_scatt, &one.weight};
+                            for (int c = 0; c < 17; c++)
+                                if (*os[c]) *os[c] += first;
+                            if (one.type) one.type += first;
+                            one.count = (int)m;
+                            rc = cfg->print_photons(&one, F, k->mc_dir, k->angle_id, k->fPtr);
+                        }
+                        first += m;
+                    }
+                    if (rc) break;
                 }
-                if (rc) break;
             }
             for (int r = 0; r < n_ranks; r++)
                 if (ranks[r].state == 1) ranks[r].scatt_frame = F + 1;
@@ -802,6 +1031,25 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
         for (int r = 0; r < n_ranks && !stop; r++)
             if (ranks[r].state == 1) { ranks[r].state = 2; ranks[r].frame += 1; }
             else if (ranks[r].state == 0 || ranks[r].state == 4) { ranks[r].state = 2; ranks[r].frame += 1; }      /* its injection frame lies beyond last_frm: nothing to scatter in */
+    }
+    if (wr) {                                              /* the last frames' files, then the writer goes */
+        if (wr->started) {
+            const double tb = wall_ms();
+            const int wrc = writer_drain(wr, 0);
+            cfg->ms_output_blocked += wall_ms() - tb;
+            cfg->ms_output += wall_ms() - tb;
+            if (rc == 0) rc = wrc;
+            pthread_mutex_lock(&wr->mu);
+            wr->quit = 1;
+            pthread_cond_broadcast(&wr->cv);
+            pthread_mutex_unlock(&wr->mu);
+            pthread_join(wr->thread, NULL);
+            cfg->ms_output_writer = wr->ms_busy;
+        }
+        for (int b = 0; b < 2; b++) { mcrat_hip_outbox_destroy(wr->box[b]); free(wr->job[b].meta); }
+        pthread_mutex_destroy(&wr->mu);
+        pthread_cond_destroy(&wr->cv);
+        free(wr);
     }
     if (rc == 0 && !stop && cfg->write_checkpoints)
         for (int r = 0; r < n_ranks; r++) {                                                       /* the closing saveCheckpoint of :924, list freed */

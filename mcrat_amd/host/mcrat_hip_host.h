@@ -238,14 +238,29 @@ typedef struct mcrat_host_pool_config {
      * (mcrat_hip_pool_propagate_frames_fast; statistically equivalent, see mcrat_hip.h) -- each rank still with its own per-frame seed and
      * stream, so its files do not depend on which other ranks the process adopted.  Not with cyclosynchrotron_switch. */
     int    mode, fast_windows;
+    /* saveCheckpoint (mcrat.c:902) and printPhotons (:907) of frame f are written by a writer thread from pinned host memory while frame f+1
+     * propagates (mcrat_hip_outbox_*): two outboxes of the pool's records + output columns each (176 B + 137 B per slot, device and pinned host).
+     * The files and their bytes are those of the synchronous path; a rank's log file gets the writer's lines ("Making checkpoint file", printPhotons'
+     * own) when they are written, i.e. possibly after the next frame's first lines.  An error of the writer ends the run at the next frame.
+     * sync_output = 1: the reference's order -- the loop waits for the files (records staged in pieces of 2^20 slots: the choice for pools whose
+     * records do not fit pinned memory twice).  output_threads: threads that share the ranks' checkpoint files (0: 4); printPhotons is always
+     * called from one thread, one rank after the other. */
+    int    sync_output, output_threads;
     /* out */
     long long hydro_frames_read;         /* get_hydro calls */
     long long launches;                  /* mcrat_hip_run calls */
-    double ms_propagate, ms_hydro, ms_output;   /* wall time spent in the loop, in the reader callback, in checkpoint + printPhotons */
+    double ms_propagate, ms_hydro, ms_output;   /* wall time of the calling thread in the loop, in the reader callback, in checkpoint + printPhotons
+                                                 * (asynchronous output: posting the outbox, waiting for a free one, the final drain) */
+    double ms_output_writer;                    /* asynchronous output: what the writer thread spent on the frames' files (copy wait + writing) ... */
+    double ms_output_blocked;                   /* ... and how much of that the calling thread had to wait for: the rest was hidden behind the loop */
 } mcrat_host_pool_config;
 /* pool: a context of the run's DIMENSIONS / GEOMETRY / STOKES_SWITCH; the driver creates the pool layout and the views.
  * Returns 0 or the first negative MCRAT_HIP_E* code (1: a checkpoint could not be written, as saveCheckpoint). */
 int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_ranks, mcrat_host_pool_config *cfg);
+/* What the file system alone asks for a frame's checkpoints, measured by the same C: per frame, n_files files of bytes_each bytes in `dir`, each
+ * renamed to <name>_old, opened "wb", written and closed (saveCheckpoint's sequence, mcrat_io.c:846-900, without a byte of photon data moving),
+ * shared by `threads` threads.  *ms_per_frame: wall time per frame.  0, or 1 when a file could not be written. */
+int mcrat_host_output_floor(const char *dir, int n_files, size_t bytes_each, int frames, int threads, double *ms_per_frame);
 
 /* ---- one list over several GPUs, one clock (mcrat_hip_shared_clock_*, include/mcrat_hip.h): the host loop in C ----------------
  * One process per GPU; every process calls this with the same seed, time_now and remaining_time and its own rank / slot_base

@@ -42,12 +42,14 @@ def _slab_dict(s):
                 r0_domain=tuple(s.r0_domain), r1_domain=tuple(s.r1_domain), r2_domain=tuple(s.r2_domain))
 
 
-@pytest.mark.parametrize("mode", ["exact", "fast"])
+@pytest.mark.parametrize("mode", ["exact", "fast", "exact-sync"])
 def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, oracle, tmp_path, mode):
-    """mode "fast": mcrat_host_pool_config.mode = MCRAT_HIP_MODE_FAST -- every rank's frame through mcrat_hip_pool_propagate_frames_fast with the
+    """The files are written by the writer thread while the next frame propagates (mcrat_hip_outbox_*, the default); "exact-sync": sync_output = 1,
+    the reference's order -- the same bytes either way.  mode "fast": mcrat_host_pool_config.mode = MCRAT_HIP_MODE_FAST -- every rank's frame through mcrat_hip_pool_propagate_frames_fast with the
     rank's own seed and stream; its files are then byte for byte those of a context doing the rank's steps by hand in FAST mode (there is no
     oracle of the FAST sequence: tests/test_gpu_fast_mode.py holds it against the exact mode in distribution)"""
     fast = mode == "fast"
+    sync_output = mode.endswith("-sync")
     from mcrat_amd.host import binding as B
     host, h5 = B.host(), B.host_h5()
     libc = C.CDLL(None)
@@ -92,7 +94,9 @@ def test_eight_ranks_through_the_host_c_equal_eight_ranks_on_their_own(hip, orac
         cfg.print_photons = C.cast(h5.mcrat_host_print_photon_arrays, C.c_void_p).value
     cfg.comv_switch, cfg.stokes_switch, cfg.save_type = 1, 1, 1
     cfg.mode, cfg.fast_windows = (hip.MODE_FAST, 4) if fast else (hip.MODE_EXACT, 0)
+    cfg.sync_output, cfg.output_threads = int(sync_output), 3
     assert host.mcrat_host_run_ranks(pool.ctx, ranks, R, C.byref(cfg)) == 0
+    assert (cfg.ms_output_writer > 0) == (not sync_output) and cfg.ms_output_blocked <= cfg.ms_output + 1e-9
     for f in logs:
         libc.fclose(f)
     # every hydro frame was read once per pass over the frames for all ranks in it (+ the injection reads): not once per rank

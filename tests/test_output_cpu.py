@@ -106,3 +106,19 @@ def test_checkpoint_round_trip_with_the_references_restart_conventions(host, tmp
     (tmp_path / "mc_chkpt_3.dat").write_bytes(full[:-100])
     assert host.mcrat_host_read_checkpoint((str(tmp_path) + "/").encode(), C.byref(l), C.byref(frame2), C.byref(framestart), C.byref(scatt),
                                            restart, C.byref(t), 3, C.byref(size)) == -2
+
+
+def test_output_floor_writes_renames_and_times(host, tmp_path):
+    """mcrat_host_output_floor: saveCheckpoint's file sequence (rename to _old, fopen "wb", fwrite, fclose; mcrat_io.c:846-900) on payloads of
+    zeros, shared by threads -- what bench.py holds the asynchronous writer of mcrat_host_run_ranks against"""
+    host.mcrat_host_output_floor.restype = C.c_int
+    host.mcrat_host_output_floor.argtypes = [C.c_char_p, C.c_int, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    ms = C.c_double(-1)
+    d = (str(tmp_path) + "/").encode()
+    assert host.mcrat_host_output_floor(d, 7, 1000, 3, 3, C.byref(ms)) == 0
+    assert ms.value > 0
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(["floor_%d.dat" % r for r in range(7)] + ["floor_%d.dat_old" % r for r in range(7)])
+    assert all(os.path.getsize(tmp_path / n) == 1000 for n in names)
+    assert host.mcrat_host_output_floor(d, 0, 1000, 3, 3, C.byref(ms)) != 0
+    assert host.mcrat_host_output_floor((str(tmp_path) + "/missing/").encode(), 2, 10, 1, 1, C.byref(ms)) == 1
