@@ -1320,8 +1320,8 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     const int n_pad = (int)align_up((size_t)std::max(n, 1), 2 * STEP_BLOCK);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    size_t o_d[24];
-    for (int k = 0; k < 24; ++k) o_d[k] = take(sizeof(double) * n_pad);
+    size_t o_d[25];                                                           // the 24 columns of PhotonDev + rank_loop_kernel's scratch column
+    for (int k = 0; k < 25; ++k) o_d[k] = take(sizeof(double) * n_pad);     // (photon_cols.hpp, ListCols::draw_log)
     const size_t o_idx = take(sizeof(int) * n_pad);
     const size_t o_flags = take(n_pad);
     const size_t o_type = take(n_pad);
@@ -1345,9 +1345,9 @@ static int alloc_photons(mcrat_hip_ctx *c, int n)
     p.type = b + o_type;
     p.n = n;
     p.n_pad = n_pad;
-    if ((o_d[1] - o_d[0]) / sizeof(double) * 24 > 0xffffffffull) { c->last_error = "photon list: more than 2^32 / 24 slots"; return MCRAT_HIP_EINVAL; }
+    if ((o_d[1] - o_d[0]) / sizeof(double) * 25 > 0xffffffffull) { c->last_error = "photon list: more than 2^32 / 25 slots"; return MCRAT_HIP_EINVAL; }
     p.col_stride = (unsigned)((o_d[1] - o_d[0]) / sizeof(double));
-    for (int k = 1; k < 24; ++k)
+    for (int k = 1; k < 25; ++k)
         if (o_d[k] - o_d[k - 1] != o_d[1] - o_d[0]) { c->last_error = "photon columns are not equally spaced"; return MCRAT_HIP_EHIP; }
     c->step_blocks = step_grid_blocks(n_pad);
     const int need = c->step_blocks;                          // one candidate per workgroup of the step kernel

@@ -786,10 +786,15 @@ using EventShared = EventSharedT<EVENT_BLOCK>;
 // (sh.raw[0..n_raw), complete below t_cut unless it overflowed), walk it as photonEvent does, refill from
 // time_to_scatter if it runs out, then the bookkeeping of mcrat.c:782-784 / 837-845 into *st.
 // All BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
-template <int DIMS, int GEOM, bool STOKES, int BLOCK, class PH, class SRC = KeyedSource>
+struct NoIdleWork { __device__ __forceinline__ void operator()() const {} };
+
+// IDLE: what the threads that take no part in the walk do while it runs (called once, by every thread outside the walking wavefront, before the
+// barrier at which they would otherwise wait for the walk's end): rank_loop_kernel draws the next pass's free-path random numbers there.
+template <int DIMS, int GEOM, bool STOKES, int BLOCK, class PH, class SRC = KeyedSource, class IDLE = NoIdleWork>
 __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
                                             EventSharedT<BLOCK> &sh, int n_raw, Cand gmin, int base, int n,
-                                            unsigned long long iter, double dt_max, int last_idx, double t_est, const SRC &src = SRC())
+                                            unsigned long long iter, double dt_max, int last_idx, double t_est, const SRC &src = SRC(),
+                                            const IDLE &idle = IDLE())
 {
     const int tid = threadIdx.x;
     int n_list = (n_raw > BLOCK) ? 0 : n_raw;              // overflowed: incomplete, ignore it
@@ -841,6 +846,8 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
 #ifndef MCRAT_NO_WALK_PRIORITY
             __builtin_amdgcn_s_setprio(0);
 #endif
+        } else if (round == 0 && tid >= 64) {
+            idle();
         }
         __syncthreads();
         if (sh.status != EV_NEED_MORE) break;
@@ -1144,6 +1151,20 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         }
         __syncthreads();
     }
+    // The free-path draws of a pass -- one Philox block per slot pair, log(u+) per slot (mclib.c:675-680; rng.hpp) -- depend on the pass number
+    // and the slot alone, not on what the event before it does: the wavefronts that sit out the event walk (three of four; the walk is one
+    // wavefront's, event_block) compute the NEXT pass's while they would otherwise wait at the barrier, into a scratch column (ListCols::draw_log).
+    // Phase 1 then reads 8 B per slot instead of running ten Philox rounds per pair and a logarithm per slot: the same bits, a shorter pass.
+    auto draw_logs = [&](unsigned long long it, int first_thread, int n_threads) {
+        for (int pair = tid - first_thread; 2 * pair < n_pass; pair += n_threads) {
+            const Philox4 blk = keyed_block(rk.seed, it, (uint32_t)pair, RNG_FREEPATH, rk.stream);
+            const int i = base + 2 * pair;
+            ph.draw_log(i) = log(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32)));
+            if (2 * pair + 1 < n) ph.draw_log(i + 1) = log(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32)));
+        }
+    };
+    draw_logs(st.iteration, 0, EVENT_BLOCK);                 // the first pass of this launch: nobody has drawn for it
+    __syncthreads();
     RANK_TICK(0);
 
     // the advance the last pass left pending (LoopState::seg), applied to every moving slot but the one the event advanced itself
@@ -1263,16 +1284,9 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         else phys::hydro_coords<DIMS, GEOM>(r0[k], r1[k], r2[k], a0[k], a1[k], a2[k]);
                         dom[k] = phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);      // mclib.c:492-505
                     }
-                    uint64_t bits[NS];
+                    uint64_t bits[NS];                                                // the bit pattern of log(u+) of the slot's draw (draw_logs)
 #pragma unroll
-                    for (int j = 0; j < PAIRS; ++j) {
-                        Philox4 blk;
-                        const uint32_t pj = (uint32_t)(pair + j * EVENT_BLOCK);
-                        if (MC_DIAG(DIAG_SKIP_PHILOX)) { blk.w[0] = pj * 2654435761u + (uint32_t)iter; blk.w[1] = pj ^ 0x9e3779b9u; blk.w[2] = ~blk.w[0]; blk.w[3] = blk.w[1] + 7u; }
-                        else blk = keyed_block(rk.seed, iter, pj, RNG_FREEPATH, rk.stream);
-                        bits[2 * j] = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32);
-                        bits[2 * j + 1] = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
-                    }
+                    for (int k = 0; k < NS; ++k) bits[k] = (uint64_t)__double_as_longlong(ph.draw_log(base + il[k]));
                     // decisions, slot by slot
                     int qd[NS], code[NS];
                     bool settled[NS];
@@ -1292,7 +1306,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                             const int slot[2] = {base + il[0], base + il[1]};
                             const LockstepProbe probe = {cell, force, same};
                             double tt[2];
-                            relocate_lockstep<DIMS, GEOM, 2>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, !force, tt, relocated, &probe);
+                            relocate_lockstep<DIMS, GEOM, 2, true>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, !force, tt, relocated, &probe);
 #pragma unroll
                             for (int k = 0; k < 2; ++k)
                                 if (cand[k] && !todo[k] && !same[k]) { settled[k] = true; tl[k] = tt[k]; n_rel += 1; }
@@ -1311,7 +1325,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         }
                         if (any) {                                                    // the draws of the slots that stay in their cells
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) tf[k] = sample_free_time(ntau[k], bits[k]);
+                            for (int k = 0; k < 2; ++k) tf[k] = free_time_from_log(ntau[k], __longlong_as_double((long long)bits[k]));
                         }
                     } else {
 #pragma unroll
@@ -1327,8 +1341,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                     }
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        tf[k] = sample_free_time(ntau[k], bits[k]);                   // mclib.c:675-687
-                        if (MC_DIAG(DIAG_SKIP_SAMPLE)) tf[k] = 1e-7 * (1.0 + (double)(bits[k] >> 40) * 1e-3) + ntau[k] * 0.0;
+                        tf[k] = free_time_from_log(ntau[k], __longlong_as_double((long long)bits[k]));   // mclib.c:675-687
                     }
                     }
 #pragma unroll
@@ -1391,7 +1404,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                 const int il = s_q[e] & ~Q_RECALC_ONLY;
                 const int i = base + il;
                 const uint64_t qbits = (uint64_t)__double_as_longlong(ph.tts(i));
-                const double t = slow_one<DIMS, GEOM>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, qbits, relocated, not_found);
+                const double t = slow_one<DIMS, GEOM, true>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, qbits, relocated, not_found);
                 best.offer(t, i);
                 if (t < t_cut) shortlist_lds(t, i);
             }
@@ -1410,7 +1423,14 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         gmin.t = g.t; gmin.idx = g.i; gmin.pad = 0;
         if (force) RANK_TICK(1); else RANK_TICK(2);
         // ---- the event half and the bookkeeping
-        event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n_pass, iter, st.remaining_time, st.last_scattered_index, st.t_est);
+        const bool frame_goes_on = gmin.t < st.remaining_time;          // (else this pass ends the frame, mcrat.c:834: nobody needs further draws)
+        auto idle_work = [&]() { if constexpr (RANK_BLOCK > 64) { if (frame_goes_on) draw_logs(iter + 1, 64, RANK_BLOCK - 64); } };
+        event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n_pass, iter, st.remaining_time, st.last_scattered_index, st.t_est,
+                                                    KeyedSource(), idle_work);
+        if constexpr (RANK_BLOCK == 64) {                        // one wavefront per list: it draws after its walk
+            if (frame_goes_on) draw_logs(iter + 1, 0, 64);
+            __syncthreads();
+        }
         if (tid == 0) {
             st.force_relocate = 0;
             // cyclo-synchrotron lists: if photonEvent reported a pool photon (it becomes a comptonised one and is replaced, mcrat.c:786-795)
@@ -1451,6 +1471,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                     if (tid == 0) const_cast<RankDesc *>(lay.desc)[rank].len = n;
                 }
                 settle_pass_limit();                         // (the new photon's slot, fresh null slots)
+                draw_logs(st.iteration, 0, EVENT_BLOCK);     // (the pass limit may have grown: the next pass's draws for every pair)
+                __syncthreads();
             }
         }
         RANK_TICK(3);

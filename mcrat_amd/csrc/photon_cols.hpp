@@ -95,6 +95,9 @@ struct ListCols {
     __device__ __forceinline__ int &g_idx_at(int i) const { return g_idx[i]; }
     __device__ __forceinline__ unsigned char &g_flags_at(int i) const { return g_flags[i]; }
     __device__ __forceinline__ char &type(int i) const { return g_type[i]; }
+    // scratch column behind the 24 (engine.hip, alloc_photons): log(u+) of the slot's free-path draw of the NEXT pass, written by the
+    // wavefronts that sit out the event walk (rank_loop_kernel)
+    __device__ __forceinline__ double &draw_log(int i) const { return base[(unsigned)N_DOUBLE_COLS * stride + (unsigned)i]; }
 };
 
 // the per-pass columns a list keeps in LDS: 256-thread lists all of them (61 B per slot), 128- and 64-thread lists r and -1/tau (32 B)

@@ -218,6 +218,10 @@ SYMBOLS = {
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_pool_inject_photons": (C.c_int, [_ctx, C.c_double, C.POINTER(PoolInjectList)]),
     "mcrat_hip_pool_set_photons": (C.c_int, [_ctx, C.c_int, _ip, C.c_void_p]),
+    "mcrat_hip_outbox_create": (C.c_int, [_ctx, C.POINTER(C.c_void_p)]),
+    "mcrat_hip_outbox_destroy": (None, [C.c_void_p]),
+    "mcrat_hip_outbox_post": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "mcrat_hip_outbox_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p]),
     "mcrat_hip_bind_thread": (C.c_int, [_ctx]),
     "mcrat_hip_share_hydro": (C.c_int, [_ctx, _ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
@@ -644,6 +648,32 @@ class Engine:
         self._check(self.lib.mcrat_hip_get_output(self.ctx, C.byref(o)), "get_output")
         assert o.count == m
         return out
+
+    def outbox_create(self):
+        """mcrat_hip_outbox_create: a staging area (device + pinned host) for the frame's records and output columns"""
+        b = C.c_void_p()
+        self._check(self.lib.mcrat_hip_outbox_create(self.ctx, C.byref(b)), "outbox_create")
+        return b
+
+    def outbox_post(self, box, records=True, output=True):
+        """stage what saveCheckpoint / printPhotons read and start its copy to the host; the photons may change when this returns"""
+        self._check(self.lib.mcrat_hip_outbox_post(self.ctx, box, int(records), int(output)), "outbox_post")
+
+    def outbox_wait(self, box):
+        """-> (records or None, output columns dict or None): copies of what has landed in the outbox's pinned memory"""
+        rec, n, o = C.c_void_p(), C.c_int(), OutputColumns()
+        self._check(self.lib.mcrat_hip_outbox_wait(box, C.byref(rec), C.byref(n), C.byref(o)), "outbox_wait")
+        records = None
+        if rec.value:
+            # (the raw bytes first: numpy copies a structured array member by member and leaves the bytes between the members undefined)
+            records = np.frombuffer(C.string_at(rec, PHOTON_DTYPE.itemsize * n.value), dtype=PHOTON_DTYPE) if n.value else np.zeros(0, dtype=PHOTON_DTYPE)
+        m = o.count
+        cols = {f: np.ctypeslib.as_array(getattr(o, f), shape=(m,)).copy() if m else np.empty(0) for f in OUTPUT_COLUMNS}
+        cols["type"] = np.frombuffer(C.string_at(C.cast(o.type, C.c_void_p), m), dtype="S1").copy() if m else np.empty(0, dtype="S1")
+        return records, cols
+
+    def outbox_destroy(self, box):
+        self.lib.mcrat_hip_outbox_destroy(box)
 
     def convert_comptonized(self):
         """saveCheckpoint's 'k' -> 'c' conversion (mcrat_io.c:896-900) on the resident list; returns the number converted"""

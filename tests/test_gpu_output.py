@@ -168,3 +168,31 @@ def test_device_streamed_checkpoint_headers_in_the_three_cases_of_saveCheckpoint
     assert old.read_bytes() == before
     assert path.read_bytes() == struct.pack("=i", 16) + b"i" + struct.pack("=ii", 300, 303) + body
     e.close()
+
+
+def test_outbox_holds_the_frame_while_the_photons_move_on(hip):
+    """mcrat_hip_outbox_post / _wait: the records and output columns of the moment of the post, although the loop has gone on in between
+    (what mcrat_host_run_ranks' writer thread reads while the next frame propagates); posting twice reuses the buffers"""
+    e, dead = _engine_after_a_frame(hip, n=7000)
+    want_rec, want_out = e.get_photons_range(0, 7000), e.get_output()
+    box = e.outbox_create()
+    e.outbox_post(box, True, True)
+    st = e.run(200)                                              # the photons change
+    assert st.iterations > 0 and not np.array_equal(e.get_photons_range(0, 7000)["r0"], want_rec["r0"])
+    rec, out = e.outbox_wait(box)
+    assert rec.tobytes() == want_rec.tobytes()
+    for k in hip.OUTPUT_COLUMNS:
+        assert np.array_equal(out[k], want_out[k], equal_nan=True), k
+    assert np.array_equal(out["type"], want_out["type"])
+    # records only, then columns only
+    now_rec, now_out = e.get_photons_range(0, 7000), e.get_output()
+    e.outbox_post(box, True, False)
+    rec, out = e.outbox_wait(box)
+    assert rec.tobytes() == now_rec.tobytes() and len(out["p0"]) == 0
+    e.outbox_post(box, False, True)
+    rec, out = e.outbox_wait(box)
+    assert rec is None and np.array_equal(out["weight"], now_out["weight"])
+    with pytest.raises(Exception):
+        e.outbox_post(box, False, False)
+    e.outbox_destroy(box)
+    e.close()
