@@ -342,8 +342,12 @@ int mcrat_hip_set_hydro_extras(mcrat_hip_ctx *ctx, const double *dens, const dou
  *                                the list's null slots in slot order, the list doubling first when it has none (addToPhotonList,
  *                                photons.c:108-208; MCRAT_HIP_EINVAL where the reference exits with "Adding to the photon list has
  *                                failed").  The Poisson mean is gsl_integration_qags of the Planck photon density from 10 Hz to the
- *                                cyclotron frequency: QUADPACK's first 21-point rule, which is where QAGS stops for this integrand;
- *                                *integrals_not_converged counts cells where it would not have (weak field in a very hot cell). */
+ *                                cyclotron frequency (:1276): QUADPACK's first 21-point rule, which is where QAGS stops while the
+ *                                cyclotron frequency lies in the Rayleigh-Jeans tail (every cell of a GRB jet); a cell whose rule
+ *                                does not meet QAGS' first-step test is integrated by bisection of the interval with the largest
+ *                                error estimate, as the oracle does (oracle_cyclosynch.c, orc_qags: no epsilon extrapolation), with at
+ *                                most 64 intervals.  *integrals_not_converged counts the cells that ran out of intervals; if there are
+ *                                any the call returns MCRAT_HIP_EREFUSED and emits nothing. */
 int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *ctx, const mcrat_hip_cyclosynch *cs, double r_inj, double ph_weight, int maximum_photons,
                                    double theta_min, double theta_max, double fps, uint64_t seed, int *num_emitted, double *ph_weight_adjusted,
                                    int *integrals_not_converged);

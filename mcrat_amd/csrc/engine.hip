@@ -1717,21 +1717,26 @@ extern "C" int mcrat_hip_emit_cyclosynch_pool(mcrat_hip_ctx *c, const mcrat_hip_
     const size_t need_counts = (size_t)std::max(M, (c->ph.n + 255) / 256 + 8);
     { int rc_ = ensure_counts(c, need_counts); if (rc_) return rc_; }
     unsigned *d_flags = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_flags, 2 * sizeof(unsigned)));
+    HIPCHK(c, hipMalloc((void **)&d_flags, 4 * sizeof(unsigned)));
     auto fail = [&](int code) { (void)hipFree(d_flags); return code; };
     // :1244-1296: the weight loop on the device's totals
     const double max_photons = cs->rebin_e_perc * maximum_photons;
     double weight = ph_weight;
     unsigned long long total = 0;
-    unsigned flags[2] = {0, 0}, cells_in_shell = 0;
+    unsigned flags[4] = {0, 0, 0, 0}, cells_in_shell = 0;
     bool ok = false;
     for (unsigned long long attempt = 0; attempt <= 400 && !ok; ++attempt) {
-        if (hipMemsetAsync(d_flags, 0, 2 * sizeof(unsigned), c->stream) != hipSuccess) return fail(MCRAT_HIP_EHIP);
+        if (hipMemsetAsync(d_flags, 0, 4 * sizeof(unsigned), c->stream) != hipSuccess) return fail(MCRAT_HIP_EHIP);
         if (launch_cs_emit_count(p, c->hy, c->hcol, weight, attempt, key, c->grid_count, c->d_grid_total, d_flags, c->stream) != hipSuccess ||
             hipMemcpyAsync(&total, c->d_grid_total, sizeof total, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipMemcpyAsync(flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
             hipStreamSynchronize(c->stream) != hipSuccess) { c->last_error = "cyclo-synchrotron emission: count pass failed"; return fail(MCRAT_HIP_EHIP); }
         if (attempt == 0) cells_in_shell = flags[1];                                // (the kernel counts them on its first pass only)
+        if (flags[0] != 0) {  // gsl_integration_qags (:1276) past its first rule AND past the device's bisection (inject.hip, qags_planck): not a result to go on with
+            if (integrals_not_converged) *integrals_not_converged = (int)flags[0];
+            c->last_error = "cyclo-synchrotron emission: the photon-density integral of " + std::to_string(flags[0]) + " cell(s) did not converge within the device's interval limit";
+            return fail(MCRAT_HIP_EREFUSED);
+        }
         const int min_photons = cells_in_shell ? 1 : 0;                             // no cell in the shell: nothing to emit (:1236-1239)
         if ((double)total > max_photons) weight *= 10;
         else if ((long long)total < min_photons) weight *= 0.5;
@@ -1926,6 +1931,102 @@ extern "C" int mcrat_hip_rebin_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cycl
     if (scatt_cyclosynch_num_ph) *scatt_cyclosynch_num_ph = B - null_count;                       // :689-690
     if (num_cyclosynch_ph_emit) *num_cyclosynch_ph_emit = B + q.synch - null_count;
     drop_graph(c);
+    return MCRAT_HIP_OK;
+}
+
+// rebinCyclosynchCompPhotons (mc_cyclosynch.c:610-710) for the lists `ids` of a rank pool at once: two launches (one workgroup per list) and two
+// host round trips for all of them, against a dozen launches and four round trips per list through mcrat_hip_rebin_cyclosynch on the views.
+// The host's part in between -- the histograms' axes from the ranges (:324-391) -- is the same code, so a list comes out bit for bit the same.
+// rc[j]: MCRAT_HIP_OK, or MCRAT_HIP_EREFUSED where the reference would refuse or exit (the view's last_error says why); empty / emit / scatt as
+// mcrat_hip_rebin_cyclosynch returns them.  Returns the first hard error.
+struct PoolRebinResult { int rc, empty_bins, num_cyclosynch_ph_emit, scatt_cyclosynch_num_ph; };
+static int pool_rebin_lists(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, int max_photons, const std::vector<int> &ids, std::vector<PoolRebinResult> &res)
+{
+    const int L = (int)ids.size();
+    res.assign((size_t)L, PoolRebinResult{MCRAT_HIP_OK, 0, 0, 0});
+    if (L == 0) return MCRAT_HIP_OK;
+    const int three = c->kc.dimensions == DIM_THREE;
+    std::vector<RebinPoolList> h((size_t)L);
+    for (int j = 0; j < L; ++j) {
+        mcrat_hip_ctx *v = c->views[ids[(size_t)j]];
+        int rc = flush_pending(v);
+        if (rc) return rc;
+        memset(&h[(size_t)j], 0, sizeof(RebinPoolList));
+        h[(size_t)j].first = ids[(size_t)j] * c->rank_stride;
+        h[(size_t)j].n = v->ph.n;
+    }
+    // launch 1: collect_photon_statistics :273-322 of every list
+    const size_t o_lists = 0, o_range = align_up(sizeof(RebinPoolList) * (size_t)L, 256);
+    int rc = ensure_aos(c, o_range + sizeof(RebinRange) * (size_t)L);
+    if (rc) return rc;
+    char *b = static_cast<char *>(c->aos_buf);
+    HIPCHK(c, hipMemcpyAsync(b + o_lists, h.data(), sizeof(RebinPoolList) * (size_t)L, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rebin_pool_range(c->ph, three, reinterpret_cast<const RebinPoolList *>(b + o_lists), L, reinterpret_cast<RebinRange *>(b + o_range), c->stream));
+    std::vector<RebinRange> range((size_t)L);
+    HIPCHK(c, hipMemcpyAsync(range.data(), b + o_range, sizeof(RebinRange) * (size_t)L, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the host's part, list by list: calculate_binning_params :324-347, allocate_histograms :351-391
+    std::vector<RebinPoolList> go;
+    std::vector<int> go_j;
+    size_t scratch = 0;
+    for (int j = 0; j < L; ++j) {
+        mcrat_hip_ctx *v = c->views[ids[(size_t)j]];
+        const RebinRange &q = range[(size_t)j];
+        auto refuse = [&](const char *why) { v->last_error = why; res[(size_t)j].rc = MCRAT_HIP_EREFUSED; };
+        if (q.valid == 0) { refuse("rebinning: no valid photons found for rebinning"); continue; }
+        const double log_p0_min = (q.p0_min > 0 && q.p0_max > 0) ? std::log10(q.p0_min) : 0.0, log_p0_max = (q.p0_min > 0 && q.p0_max > 0) ? std::log10(q.p0_max) : 1.0;
+        RebinAxes ax{};
+        ax.three = three;
+        ax.num_bins = (int)(cs->rebin_e_perc * max_photons);
+        ax.num_bins_theta = (int)std::ceil((q.theta_max - q.theta_min) / (cs->rebin_ang * (M_PI / 180.0)));
+        ax.num_bins_phi = three ? (int)std::ceil((q.phi_max - q.phi_min) / cs->rebin_ang_phi) : 1;
+        const long long total_ll = (long long)ax.num_bins_theta * ax.num_bins * (three ? ax.num_bins_phi : 1);
+        if (total_ll > max_photons) { refuse("rebinning would create more photons than max_photons"); continue; }
+        if (ax.num_bins <= 0 || ax.num_bins_theta <= 0 || ax.num_bins_phi <= 0) { refuse("rebinning: invalid histogram dimensions"); continue; }
+        ax.total_bins = (int)total_ll;
+        ax.e_lo = log_p0_min; ax.e_hi = log_p0_max + (log_p0_max - log_p0_min) * 1e-6;
+        ax.t_lo = q.theta_min; ax.t_hi = q.theta_max + (q.theta_max - q.theta_min) * 1e-6;
+        ax.p_lo = q.phi_min; ax.p_hi = q.phi_max + (q.phi_max - q.phi_min) * 1e-6;
+        RebinPoolList l = h[(size_t)j];
+        l.ax = ax;
+        l.scratch = scratch;
+        l.status = -1;
+        scratch += rebin_pool_scratch_bytes(l.n, ax.total_bins);
+        go.push_back(l);
+        go_j.push_back(j);
+    }
+    const int G = (int)go.size();
+    if (G == 0) return MCRAT_HIP_OK;
+    // launch 2: everything else
+    const size_t o_scr = align_up(sizeof(RebinPoolList) * (size_t)G, 256);
+    if ((rc = ensure_aos(c, o_scr + scratch))) return rc;
+    b = static_cast<char *>(c->aos_buf);
+    HIPCHK(c, hipMemcpyAsync(b, go.data(), sizeof(RebinPoolList) * (size_t)G, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, launch_rebin_pool(c->ph, reinterpret_cast<RebinPoolList *>(b), G, b + o_scr, c->stream));
+    HIPCHK(c, hipMemcpyAsync(go.data(), b, sizeof(RebinPoolList) * (size_t)G, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int g = 0; g < G; ++g) {
+        const int j = go_j[(size_t)g];
+        mcrat_hip_ctx *v = c->views[ids[(size_t)j]];
+        const RebinPoolList &l = go[(size_t)g];
+        const int B = l.ax.total_bins;
+        drop_graph(v);
+        if (l.status == 1) { v->last_error = "rebinning: a photon maps to an invalid bin index (the reference exits)"; res[(size_t)j].rc = MCRAT_HIP_EREFUSED; continue; }
+        if (l.status == 2) {
+            v->last_error = "rebinning: fewer null slots than rebinned photons (the reference exits with \"Adding to the photon list has failed\")";
+            res[(size_t)j].rc = MCRAT_HIP_EREFUSED;
+            continue;
+        }
+        if (l.status != 0) { c->last_error = "rebinning: the pool kernel left a list without a status"; return MCRAT_HIP_EHIP; }
+        if ((long long)l.n - (long long)l.n_null + (B - l.empty_bins) < B) {                          // :676-681
+            v->last_error = "rebinning: fewer photons in the list than bins after the rebinning";
+            res[(size_t)j].rc = MCRAT_HIP_EREFUSED;
+            continue;
+        }
+        res[(size_t)j].empty_bins = l.empty_bins;
+        res[(size_t)j].scatt_cyclosynch_num_ph = B - l.empty_bins;                                    // :689-690
+        res[(size_t)j].num_cyclosynch_ph_emit = B + range[(size_t)j].synch - l.empty_bins;
+    }
     return MCRAT_HIP_OK;
 }
 
@@ -3131,6 +3232,10 @@ static int pool_emit_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs
         mcrat_hip_ctx *v = c->views[r];
         int n = e.n_emit, nbad = (int)bad[(size_t)e.group];
         double w = e.weight_out;
+        if (nbad > 0) {       // (as mcrat_hip_emit_cyclosynch_pool: inject.hip, qags_planck ran out of intervals)
+            c->last_error = "cyclo-synchrotron emission: the photon-density integral of " + std::to_string(nbad) + " cell(s) did not converge within the device's interval limit";
+            return MCRAT_HIP_EREFUSED;
+        }
         switch (e.error) {
         case 0:
             v->ph.n = c->h_desc[r].len;                                                           // the list may have grown inside its window
@@ -3154,6 +3259,22 @@ static int pool_emit_cyclosynch(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs
         counts[r].pool_weight = w;
         counts[r].integrals_not_converged = nbad;
         emit_base[(size_t)r] = n;
+    }
+    return MCRAT_HIP_OK;
+}
+
+// the rebinning of the pool's lists `ids`: all at once (pool_rebin_lists), or -- MCRAT_HIP_POOL_REBIN_EACH=1, the round-2 path kept for the A/B and
+// the equality test -- list by list through the views
+static int pool_rebin(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, int max_photons, const std::vector<int> &ids, std::vector<PoolRebinResult> &res)
+{
+    const char *e = getenv("MCRAT_HIP_POOL_REBIN_EACH");
+    if (!(e && atoi(e) != 0)) return pool_rebin_lists(c, cs, max_photons, ids, res);
+    res.assign(ids.size(), PoolRebinResult{MCRAT_HIP_OK, 0, 0, 0});
+    for (size_t j = 0; j < ids.size(); ++j) {
+        mcrat_hip_ctx *v = c->views[ids[j]];
+        const int rc = mcrat_hip_rebin_cyclosynch(v, cs, max_photons, &res[j].empty_bins, &res[j].num_cyclosynch_ph_emit, &res[j].scatt_cyclosynch_num_ph);
+        res[j].rc = rc;
+        if (rc != MCRAT_HIP_OK && rc != MCRAT_HIP_EREFUSED) { c->last_error = v->last_error; return rc; }
     }
     return MCRAT_HIP_OK;
 }
@@ -3243,6 +3364,7 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
         HIPCHK(c, hipMemcpyAsync(c->h_desc, c->d_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all_done = true;
+        std::vector<int> parked;                                                                  // lists waiting for rebinCyclosynchCompPhotons (:797-808)
         for (int r = 0; r < R; ++r) {
             if (!open[(size_t)r]) continue;
             mcrat_hip_ctx *v = c->views[r];
@@ -3252,27 +3374,30 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
                 c->last_error = "a cyclo-synchrotron list outgrew the pool's slots per rank (mcrat_hip_pool_create: allow for the doublings)";
                 return MCRAT_HIP_ENOMEM;
             }
-            if (f.halt == CS_HALT_REBIN) {                                                        // :797-808, on the list's view
-                int empty = 0, emit_total = emit_base[(size_t)r] + f.emitted, scatt = f.scatt_num;
-                rc = mcrat_hip_rebin_cyclosynch(v, &csr[(size_t)r], max_photons, &empty, &emit_total, &scatt);
-                if (rc == MCRAT_HIP_OK) {
+            if (f.halt == CS_HALT_REBIN) parked.push_back(r);
+        }
+        if (!parked.empty()) {                                                                    // all of them in the same two launches
+            std::vector<PoolRebinResult> res;
+            if ((rc = pool_rebin(c, cs, max_photons, parked, res))) return rc;
+            for (size_t j = 0; j < parked.size(); ++j) {
+                const int r = parked[j];
+                CsFrame &f = cf[(size_t)r];
+                if (res[j].rc == MCRAT_HIP_OK) {
                     counts[r].rebins += 1;
-                    emit_base[(size_t)r] = emit_total;
+                    emit_base[(size_t)r] = res[j].num_cyclosynch_ph_emit;
                     f.emitted = 0;
-                    f.scatt_num = scatt;
-                } else if (rc != MCRAT_HIP_EREFUSED) {
-                    c->last_error = v->last_error;
-                    return rc;
+                    f.scatt_num = res[j].scatt_cyclosynch_num_ph;
                 }
                 f.halt = 0;
                 c->h_rstates[r].done = f.saved_done;
                 HIPCHK(c, hipMemcpyAsync(d_cf + r, &f, sizeof f, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(c, hipMemcpyAsync(reinterpret_cast<char *>(c->d_rstates + r) + offsetof(LoopState, done), &c->h_rstates[r].done, sizeof(int),
                                          hipMemcpyHostToDevice, c->stream));
-                HIPCHK(c, hipStreamSynchronize(c->stream));
             }
-            if (c->h_rstates[r].done != LOOP_DONE) all_done = false;
+            HIPCHK(c, hipStreamSynchronize(c->stream));
         }
+        for (int r = 0; r < R; ++r)
+            if (open[(size_t)r] && c->h_rstates[r].done != LOOP_DONE) all_done = false;
         if (all_done) break;
     }
     std::vector<int> absorb((size_t)R, 0);
@@ -3286,16 +3411,23 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
         counts[r].n_comptonized = f.n_comptonized;
         v->pending_applied = false;
         v->rank_current = true;
-        if (lists[r].emit_pool) {                                                                 // :853-878
-            if (counts[r].scatt_cyclosynch_num_ph > max_photons) {
-                int empty = 0;
-                rc = mcrat_hip_rebin_cyclosynch(v, &csr[(size_t)r], max_photons, &empty, &counts[r].num_cyclosynch_ph_emit, &counts[r].scatt_cyclosynch_num_ph);
-                if (rc == MCRAT_HIP_OK) counts[r].rebins += 1;
-                else if (rc != MCRAT_HIP_EREFUSED) { c->last_error = v->last_error; return rc; }
-            }
-            if (counts[r].num_cyclosynch_ph_emit > 0) { absorb[(size_t)r] = 1; any_absorb = true; }
-        }
         if (stats) state_to_stats(c->h_rstates[r], v->ph.n, &stats[r]);
+    }
+    {                                                                                             // :853-878, the lists over max_photons all at once
+        std::vector<int> over;
+        for (int r = 0; r < R; ++r)
+            if (open[(size_t)r] && lists[r].emit_pool && counts[r].scatt_cyclosynch_num_ph > max_photons) over.push_back(r);
+        std::vector<PoolRebinResult> res;
+        if ((rc = pool_rebin(c, cs, max_photons, over, res))) return rc;
+        for (size_t j = 0; j < over.size(); ++j) {
+            if (res[j].rc != MCRAT_HIP_OK) continue;
+            const int r = over[j];
+            counts[r].rebins += 1;
+            counts[r].num_cyclosynch_ph_emit = res[j].num_cyclosynch_ph_emit;
+            counts[r].scatt_cyclosynch_num_ph = res[j].scatt_cyclosynch_num_ph;
+        }
+        for (int r = 0; r < R; ++r)
+            if (open[(size_t)r] && lists[r].emit_pool && counts[r].num_cyclosynch_ph_emit > 0) { absorb[(size_t)r] = 1; any_absorb = true; }
     }
     if (any_absorb) {                                                                             // phAbsCyclosynch of every such list, one launch
         for (int r = 0; r < R; ++r)

@@ -351,9 +351,9 @@ __device__ __forceinline__ double planck_tail(double nu, double temp)
     return (8 * M_PI * nu * nu) / (exp(PL_CONST * nu / (K_B * temp)) - 1) / (C_LIGHT * C_LIGHT * C_LIGHT);
 }
 
-// gsl_integration_qags(blackbody_ph_spect, 10, nu_c, 0, 1e-2, ...) (:1276): QUADPACK's 21-point Gauss-Kronrod rule and QAGS' first-step
-// test, as oracle/oracle_cyclosynch.c restates them; `converged` tells whether QAGS would have returned after this one rule
-__device__ double qk21_planck(double a, double b, double temp, bool &converged)
+// QUADPACK's 21-point Gauss-Kronrod rule (dqk21) on blackbody_ph_spect over [a, b], as oracle/oracle_cyclosynch.c (orc_qk21) restates it: the
+// integral, its error estimate, and the two sums QAGS' tests use
+__device__ double qk21_planck(double a, double b, double temp, double &abserr, double &resabs, double &resasc)
 {
     const double XGK[11] = {0.995657163025808080735527280689003, 0.973906528517171720077964012084452, 0.930157491355708226001207180059508,
                             0.865063366688984510732096688423493, 0.780817726586416897063717578345042, 0.679409568299024406234327365114874,
@@ -391,13 +391,53 @@ __device__ double qk21_planck(double a, double b, double temp, bool &converged)
     rabs *= dhlgth; rasc *= dhlgth;
     if (rasc != 0 && err != 0) { const double s = pow(200 * err / rasc, 1.5); err = (s < 1) ? rasc * s : rasc; }
     if (rabs > 2.2250738585072014e-308 / (50 * 2.220446049250313e-16)) { const double m = 50 * 2.220446049250313e-16 * rabs; if (m > err) err = m; }
-    const double tol = fmax(0.0, 1e-2 * fabs(result));
-    converged = !(err <= 100 * 2.220446049250313e-16 * rabs && err > tol) && ((err <= tol && err != rasc) || err == 0.0);
+    abserr = err; resabs = rabs; resasc = rasc;
     return result;
 }
 
-// mc_cyclosynch.c:1244-1296, one weight: the Poisson count of every cell of the shell; flags[0] counts cells whose integral
-// would have needed more than QAGS' first rule (the oracle then bisects; the device keeps the first rule's value)
+// gsl_integration_qags(blackbody_ph_spect, 10, nu_c, 0, 1e-2, limit 10000, ...) (:1276) as orc_qags restates it: the rule on the whole interval
+// and QAGS' first-step test -- where the integrand is the Rayleigh-Jeans tail (every cell of cfg5) that is all of it -- and otherwise bisection of the
+// interval with the largest error estimate until the sum of the estimates meets the tolerance (no epsilon-algorithm extrapolation: the oracle's
+// documented stand-in for the rest of QAGS, the same intervals in the same order and the same sums here).  The intervals live in the lane's scratch
+// memory: at most QAGS_DEV_INTERVALS of them.  status: 0 met the tolerance, 1 roundoff (GSL_EROUND; the first rule's value stands), 2 ran out of
+// intervals -- the caller counts those cells and the host refuses the emission.
+constexpr int QAGS_DEV_INTERVALS = 64;
+__device__ double qags_planck(double a, double b, double temp, int &status, bool &bisected)
+{
+    const double epsabs = 0.0, epsrel = 1e-2;
+    double err, rabs, rasc;
+    const double res = qk21_planck(a, b, temp, err, rabs, rasc);
+    double tol = fmax(epsabs, epsrel * fabs(res));
+    bisected = false;
+    if (err <= 100 * 2.220446049250313e-16 * rabs && err > tol) { status = 1; return res; }
+    if ((err <= tol && err != rasc) || err == 0.0) { status = 0; return res; }
+    bisected = true;
+    double al[QAGS_DEV_INTERVALS], bl[QAGS_DEV_INTERVALS], rl[QAGS_DEV_INTERVALS], el[QAGS_DEV_INTERVALS];
+    int n = 1;
+    al[0] = a; bl[0] = b; rl[0] = res; el[0] = err;
+    double result = res;
+    status = 2;
+    while (n < QAGS_DEV_INTERVALS) {
+        int worst = 0;
+        for (int k = 1; k < n; k++) if (el[k] > el[worst]) worst = k;
+        const double mid = 0.5 * (al[worst] + bl[worst]);
+        double e1, e2, t1, t2;
+        const double r1 = qk21_planck(al[worst], mid, temp, e1, t1, t2);
+        const double r2 = qk21_planck(mid, bl[worst], temp, e2, t1, t2);
+        al[n] = mid; bl[n] = bl[worst]; rl[n] = r2; el[n] = e2;
+        bl[worst] = mid; rl[worst] = r1; el[worst] = e1;
+        n++;
+        double sr = 0, se = 0;
+        for (int k = 0; k < n; k++) { sr += rl[k]; se += el[k]; }
+        result = sr;
+        tol = fmax(epsabs, epsrel * fabs(sr));
+        if (se <= tol) { status = 0; break; }
+    }
+    return result;
+}
+
+// mc_cyclosynch.c:1244-1296, one weight: the Poisson count of every cell of the shell; flags[0] counts cells whose integral ran out of
+// intervals (qags_planck), flags[1] the cells of the shell, flags[2] the cells whose integral needed more than QAGS' first rule
 __global__ __launch_bounds__(256) void cs_emit_count_kernel(CsEmitParams p, HydroDev hy, HydroCols h, double weight, unsigned long long attempt, RngKey key,
                                                             unsigned *__restrict__ count, unsigned long long *__restrict__ total, unsigned *__restrict__ flags)
 {
@@ -410,9 +450,11 @@ __global__ __launch_bounds__(256) void cs_emit_count_kernel(CsEmitParams p, Hydr
         if (in_emission_slab(p, c)) {
             if (attempt == 0) atomicAdd(flags + 1, 1u);
             const double nu_c = cs_nu_c(p, hy, h, i);
-            bool converged;
-            double ph_dens_calc = qk21_planck(10, nu_c, hy.temp[i], converged);
-            if (!converged) atomicAdd(flags, 1u);
+            int status;
+            bool bisected;
+            double ph_dens_calc = qags_planck(10, nu_c, hy.temp[i], status, bisected);
+            if (status == 2) atomicAdd(flags, 1u);                                                   // out of intervals: the host refuses
+            if (bisected && attempt == 0) atomicAdd(flags + 2, 1u);                                  // (statistics: cells past QAGS' first rule)
             ph_dens_calc *= element_volume(p.dimensions, p.geometry, c) / weight;                    // :1277
             EventStream rng = keyed_stream(key, attempt, (uint32_t)i, RNG_CS_COUNT);
             const long long k = poisson(rng, ph_dens_calc);
@@ -472,12 +514,13 @@ __global__ __launch_bounds__(256) void cs_shell_write_kernel(CsEmitParams p, Hyd
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= hy.M || !flag[i]) return;
     const CellRec c = load_cell(hy, p.dimensions, i);
-    bool converged;
+    int status;
+    bool bisected;
     CsShellCell s;
     s.cell = i; s.pad = 0;
-    s.integral = qk21_planck(10, cs_nu_c(p, hy, h, i), hy.temp[i], converged);                         // :1276
+    s.integral = qags_planck(10, cs_nu_c(p, hy, h, i), hy.temp[i], status, bisected);                  // :1276
     s.volume = element_volume(p.dimensions, p.geometry, c);
-    if (!converged) atomicAdd(not_converged, 1u);
+    if (status == 2) atomicAdd(not_converged, 1u);                                                     // out of intervals: the host refuses
     out[start[i]] = s;
 }
 
@@ -674,13 +717,13 @@ __device__ __forceinline__ void rebin_position(const PhotonDev &ph, int i, int t
     if (three) phi = fmod(atan2(y, x) * (180.0 / M_PI) + 360.0, 360.0);
 }
 
-__global__ __launch_bounds__(256) void rebin_range_kernel(PhotonDev ph, int three, RebinRange *__restrict__ partials)
+// one thread's share of collect_photon_statistics (:273-322): the slots start, start + step, ... of the list
+__device__ __forceinline__ RebinRange rebin_range_thread(const PhotonDev &ph, int three, int start, int step)
 {
-    __shared__ RebinRange s_p[4];
     RebinRange q;
     q.p0_min = 1.7976931348623157e308; q.p0_max = 0; q.theta_min = 1.7976931348623157e308; q.theta_max = 0;
     q.phi_min = 1.7976931348623157e308; q.phi_max = 0; q.valid = 0; q.synch = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < ph.n; i += gridDim.x * 256) {
+    for (int i = start; i < ph.n; i += step) {
         const char type = ph.type[i];
         if (rebin_eligible(type)) {
             const double p0 = ph.p0[i];
@@ -692,6 +735,11 @@ __global__ __launch_bounds__(256) void rebin_range_kernel(PhotonDev ph, int thre
         }
         if (type == 'p') q.synch += 1;
     }
+    return q;
+}
+// ... combined over the workgroup's 256 threads (minima, maxima and integer sums: the order does not matter); thread 0 holds the result
+__device__ __forceinline__ RebinRange rebin_range_block(RebinRange q, RebinRange (&s_p)[4])
+{
     for (int off = 32; off > 0; off >>= 1) {
         q.p0_min = fmin(q.p0_min, __shfl_xor(q.p0_min, off)); q.p0_max = fmax(q.p0_max, __shfl_xor(q.p0_max, off));
         q.theta_min = fmin(q.theta_min, __shfl_xor(q.theta_min, off)); q.theta_max = fmax(q.theta_max, __shfl_xor(q.theta_max, off));
@@ -708,8 +756,15 @@ __global__ __launch_bounds__(256) void rebin_range_kernel(PhotonDev ph, int thre
             q.phi_min = fmin(q.phi_min, o.phi_min); q.phi_max = fmax(q.phi_max, o.phi_max);
             q.valid += o.valid; q.synch += o.synch;
         }
-        partials[blockIdx.x] = q;
     }
+    return q;
+}
+
+__global__ __launch_bounds__(256) void rebin_range_kernel(PhotonDev ph, int three, RebinRange *__restrict__ partials)
+{
+    __shared__ RebinRange s_p[4];
+    const RebinRange q = rebin_range_block(rebin_range_thread(ph, three, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256), s_p);
+    if (threadIdx.x == 0) partials[blockIdx.x] = q;
 }
 
 // gsl_histogram2d_set_ranges_uniform's edges and gsl_histogram2d_find (see oracle/oracle_cyclosynch.c)
@@ -729,28 +784,34 @@ __device__ __forceinline__ int axis_find(double lo, double hi, int n, double x)
     return a;
 }
 
+// the bin of slot i (accumulate_bin_statistics :450-466): -1 not rebinned, -2 outside the histograms (the reference's exit(1))
+__device__ __forceinline__ int rebin_assign_one(const PhotonDev &ph, const RebinAxes &ax, int i)
+{
+    if (!rebin_eligible(ph.type[i])) return -1;
+    int bin;
+    double r, theta, phi;
+    rebin_position(ph, i, ax.three, r, theta, phi);
+    const double le = log10(ph.p0[i]);
+    int idx_x = axis_find(ax.e_lo, ax.e_hi, ax.num_bins, le), idx_y = axis_find(ax.t_lo, ax.t_hi, ax.num_bins_theta, theta), idx_z = 0;
+    if (idx_x < 0 || idx_y < 0) { idx_x = 0; idx_y = 0; }                       // gsl_histogram2d_find: both untouched on a domain error
+    if (ax.three) {
+        const int pz = axis_find(ax.p_lo, ax.p_hi, ax.num_bins_phi, phi);
+        const int ex = axis_find(ax.e_lo, ax.e_hi, ax.num_bins, le), ty = axis_find(ax.t_lo, ax.t_hi, ax.num_bins_theta, theta);
+        if (ex >= 0 && pz >= 0) { idx_x = ex; idx_z = pz; }
+        if (ty >= 0 && pz >= 0) { idx_y = ty; idx_z = pz; }
+    }
+    if (idx_x < 0 || idx_x >= ax.num_bins || idx_y < 0 || idx_y >= ax.num_bins_theta || (ax.three && (idx_z < 0 || idx_z >= ax.num_bins_phi))) bin = -2;
+    else bin = ax.three ? idx_z * ax.num_bins * ax.num_bins_theta + idx_x * ax.num_bins_theta + idx_y : idx_x * ax.num_bins_theta + idx_y;
+    if (bin >= ax.total_bins) bin = -2;
+    return bin;
+}
+
 __global__ __launch_bounds__(256) void rebin_assign_kernel(PhotonDev ph, RebinAxes ax, int *__restrict__ bin_of, unsigned *__restrict__ bin_count)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= ph.n) return;
-    int bin = -1;
-    if (rebin_eligible(ph.type[i])) {                                               // accumulate_bin_statistics :450-466
-        double r, theta, phi;
-        rebin_position(ph, i, ax.three, r, theta, phi);
-        const double le = log10(ph.p0[i]);
-        int idx_x = axis_find(ax.e_lo, ax.e_hi, ax.num_bins, le), idx_y = axis_find(ax.t_lo, ax.t_hi, ax.num_bins_theta, theta), idx_z = 0;
-        if (idx_x < 0 || idx_y < 0) { idx_x = 0; idx_y = 0; }                       // gsl_histogram2d_find: both untouched on a domain error
-        if (ax.three) {
-            const int pz = axis_find(ax.p_lo, ax.p_hi, ax.num_bins_phi, phi);
-            const int ex = axis_find(ax.e_lo, ax.e_hi, ax.num_bins, le), ty = axis_find(ax.t_lo, ax.t_hi, ax.num_bins_theta, theta);
-            if (ex >= 0 && pz >= 0) { idx_x = ex; idx_z = pz; }
-            if (ty >= 0 && pz >= 0) { idx_y = ty; idx_z = pz; }
-        }
-        if (idx_x < 0 || idx_x >= ax.num_bins || idx_y < 0 || idx_y >= ax.num_bins_theta || (ax.three && (idx_z < 0 || idx_z >= ax.num_bins_phi))) bin = -2;
-        else bin = ax.three ? idx_z * ax.num_bins * ax.num_bins_theta + idx_x * ax.num_bins_theta + idx_y : idx_x * ax.num_bins_theta + idx_y;
-        if (bin >= ax.total_bins) bin = -2;
-        atomicAdd(bin_count + (bin >= 0 ? bin : ax.total_bins + 1), 1u);          // [total_bins + 1]: photons outside the histograms
-    }
+    const int bin = rebin_assign_one(ph, ax, i);
+    if (bin != -1) atomicAdd(bin_count + (bin >= 0 ? bin : ax.total_bins + 1), 1u);   // [total_bins + 1]: photons outside the histograms
     bin_of[i] = bin;
 }
 
@@ -763,12 +824,10 @@ __global__ __launch_bounds__(256) void rebin_fill_kernel(PhotonDev ph, const int
     if (b >= 0) members[bin_start[b] + (int)atomicAdd(cursor + b, 1u)] = i;
 }
 
-// create_rebinned_photons :504-607, with accumulate_bin_statistics' sums (:467-497) formed in slot order as the reference forms them
-__global__ __launch_bounds__(256) void rebin_create_kernel(PhotonDev ph, RebinAxes ax, const int *__restrict__ bin_start, int *__restrict__ members,
-                                                           RebinRec *__restrict__ recs, unsigned *__restrict__ empty_bins)
+// create_rebinned_photons :504-607, with accumulate_bin_statistics' sums (:467-497) formed in slot order as the reference forms them: bin b's
+// rebinned photon (valid == 0: the bin is empty)
+__device__ __forceinline__ RebinRec rebin_create_one(const PhotonDev &ph, const RebinAxes &ax, const int *__restrict__ bin_start, int *__restrict__ members, int b)
 {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= ax.total_bins) return;
     const int m0 = bin_start[b], m = bin_start[b + 1] - m0;
     for (int a = 1; a < m; ++a) {                       // the fill is unordered: sort the few members by slot
         const int key = members[m0 + a];
@@ -800,7 +859,7 @@ __global__ __launch_bounds__(256) void rebin_create_kernel(PhotonDev ph, RebinAx
     RebinRec o;
     o.valid = 0; o.pad = 0;
     o.weight = o.p0 = o.p1 = o.p2 = o.p3 = o.r0 = o.r1 = o.r2 = o.s0 = o.s1 = o.s2 = o.s3 = o.num_scatt = 0;
-    if (!(total_weight > 0)) { atomicAdd(empty_bins, 1u); recs[b] = o; return; }
+    if (!(total_weight > 0)) return o;
     const double avg_energy = w_energy / total_weight, avg_phi_dir = w_phi_dir / total_weight, avg_theta_dir = w_theta_dir / total_weight;
     const double avg_r = w_r / total_weight, avg_theta_pos = w_theta / total_weight;
     o.valid = 1;
@@ -817,16 +876,22 @@ __global__ __launch_bounds__(256) void rebin_create_kernel(PhotonDev ph, RebinAx
     o.r2 = avg_r * cos(avg_theta_pos);
     o.s0 = w_s0 / total_weight; o.s1 = w_s1 / total_weight; o.s2 = w_s2 / total_weight; o.s3 = w_s3 / total_weight;
     o.num_scatt = (double)(int)(w_scatt / total_weight + 0.5);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void rebin_create_kernel(PhotonDev ph, RebinAxes ax, const int *__restrict__ bin_start, int *__restrict__ members,
+                                                           RebinRec *__restrict__ recs, unsigned *__restrict__ empty_bins)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= ax.total_bins) return;
+    const RebinRec o = rebin_create_one(ph, ax, bin_start, members, b);
+    if (!o.valid) atomicAdd(empty_bins, 1u);
     recs[b] = o;
 }
 
-__global__ __launch_bounds__(256) void rebin_place_kernel(PhotonDev ph, const RebinRec *__restrict__ recs, int total_bins, const int *__restrict__ null_slots)
+// record o into slot s (addToPhotonList, photons.c:190-199)
+__device__ __forceinline__ void rebin_place_one(const PhotonDev &ph, const RebinRec &o, int s)
 {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= total_bins) return;
-    const RebinRec o = recs[b];
-    if (!o.valid) return;                                // a null rebinned photon is not copied (photons.c:192)
-    const int s = null_slots[b];
     ph.type[s] = 'k';
     ph.weight[s] = o.weight;
     ph.p0[s] = o.p0; ph.p1[s] = o.p1; ph.p2[s] = o.p2; ph.p3[s] = o.p3;
@@ -843,10 +908,18 @@ __global__ __launch_bounds__(256) void rebin_place_kernel(PhotonDev ph, const Re
     ph.flags[s] = (unsigned char)(FLAG_VALID | FLAG_RECALC | (o.weight != 0 ? FLAG_MOVES : 0u));
 }
 
-__global__ __launch_bounds__(256) void rebin_nullify_kernel(PhotonDev ph)
+__global__ __launch_bounds__(256) void rebin_place_kernel(PhotonDev ph, const RebinRec *__restrict__ recs, int total_bins, const int *__restrict__ null_slots)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= ph.n) return;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= total_bins) return;
+    const RebinRec o = recs[b];
+    if (!o.valid) return;                                // a null rebinned photon is not copied (photons.c:192)
+    rebin_place_one(ph, o, null_slots[b]);
+}
+
+// setNullPhoton for a 'k' or 'c' photon (:573-581)
+__device__ __forceinline__ void rebin_nullify_one(const PhotonDev &ph, int i)
+{
     const char type = ph.type[i];
     if (type != 'c' && type != 'k') return;
     ph.type[i] = 'N';
@@ -861,6 +934,117 @@ __global__ __launch_bounds__(256) void rebin_nullify_kernel(PhotonDev ph)
     ph.tau[i] = 0; ph.tau_next[i] = 0;
     ph.u0[i] = 0; ph.u1[i] = 0; ph.u2[i] = 0;
     ph.ntau[i] = -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void rebin_nullify_kernel(PhotonDev ph)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ph.n) return;
+    rebin_nullify_one(ph, i);
+}
+
+// ---- rebinCyclosynchCompPhotons for MANY lists of a rank pool at once (round 3): one workgroup per list, every stage of the per-list kernels
+// above inside one launch -- a parked list costs the frame no launches and no host round trips of its own.  Same per-slot and per-bin
+// functions, so the lists come out bit for bit as from mcrat_hip_rebin_cyclosynch.  Two launches: the ranges (the host then fixes the
+// histograms' axes exactly as it does for one list, mc_cyclosynch.c:324-391), then everything else.
+__global__ __launch_bounds__(256) void rebin_pool_range_kernel(PhotonDev pool, int three, const RebinPoolList *__restrict__ lists, RebinRange *__restrict__ out)
+{
+    __shared__ RebinRange s_p[4];
+    PhotonDev ph = pool;
+    offset_photons(ph, (size_t)lists[blockIdx.x].first);
+    ph.n = lists[blockIdx.x].n;
+    const RebinRange q = rebin_range_block(rebin_range_thread(ph, three, threadIdx.x, 256), s_p);
+    if (threadIdx.x == 0) out[blockIdx.x] = q;
+}
+
+// exclusive prefix sums over the workgroup's 256 threads; returns the thread's offset, *total the sum
+__device__ __forceinline__ unsigned block_exclusive_scan_256(unsigned v, unsigned (&s_w)[4], unsigned *total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+    for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(inc, off); if (lane >= off) inc += o; }
+    __syncthreads();                                     // (s_w may still be read from the previous call)
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    *total = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void rebin_pool_kernel(PhotonDev pool, RebinPoolList *__restrict__ lists, char *__restrict__ scratch)
+{
+    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_empty;
+    RebinPoolList &L = lists[blockIdx.x];
+    PhotonDev ph = pool;
+    offset_photons(ph, (size_t)L.first);
+    ph.n = L.n;
+    const RebinAxes ax = L.ax;
+    const int n = L.n, B = ax.total_bins, tid = threadIdx.x;
+    const int n_al = (n + 63) & ~63, b_al = (B + 2 + 63) & ~63;
+    int *bin_of = reinterpret_cast<int *>(scratch + L.scratch), *members = bin_of + n_al, *null_slots = members + n_al;
+    unsigned *bin_count = reinterpret_cast<unsigned *>(null_slots + n_al), *cursor = bin_count + b_al;      // bin_count[B + 1]: photons outside the histograms
+    int *bin_start = reinterpret_cast<int *>(cursor + b_al);
+    RebinRec *recs = reinterpret_cast<RebinRec *>(bin_start + b_al);
+    if (tid == 0) s_empty = 0;
+    for (int k = tid; k < B + 2; k += 256) { bin_count[k] = 0; cursor[k] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {                                       // accumulate_bin_statistics :450-466
+        const int bin = rebin_assign_one(ph, ax, i);
+        if (bin != -1) atomicAdd(bin_count + (bin >= 0 ? bin : B + 1), 1u);
+        bin_of[i] = bin;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (bin_count[B + 1] != 0) {                                               // the reference exits; the list is left as it was
+        if (tid == 0) L.status = 1;
+        return;
+    }
+    unsigned run = 0;                                                          // bin_start = exclusive prefix sums of bin_count
+    for (int k0 = 0; k0 < B; k0 += 256) {
+        const int k = k0 + tid;
+        unsigned total;
+        const unsigned off = block_exclusive_scan_256(k < B ? bin_count[k] : 0u, s_w, &total);
+        if (k < B) bin_start[k] = (int)(run + off);
+        run += total;
+    }
+    if (tid == 0) bin_start[B] = (int)run;
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int b = bin_of[i];
+        if (b >= 0) members[bin_start[b] + (int)atomicAdd(cursor + b, 1u)] = i;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int b = tid; b < B; b += 256) {                                       // create_rebinned_photons :504-607
+        const RebinRec o = rebin_create_one(ph, ax, bin_start, members, b);
+        if (!o.valid) atomicAdd(&s_empty, 1u);
+        recs[b] = o;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) rebin_nullify_one(ph, i);               // :573-581
+    __threadfence_block();
+    __syncthreads();
+    run = 0;                                                                   // the null slots in ascending order (photons.c:181-189)
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        const bool is_null = i < n && ph.type[i] == 'N';
+        unsigned total;
+        const unsigned off = block_exclusive_scan_256(is_null ? 1u : 0u, s_w, &total);
+        if (is_null) null_slots[run + off] = i;
+        run += total;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) { L.n_null = (int)run; L.empty_bins = (int)s_empty; L.status = ((unsigned)B > run) ? 2 : 0; }
+    if ((unsigned)B > run) return;                                             // "Adding to the photon list has failed": the reference exits
+    for (int b = tid; b < B; b += 256) {                                       // addToPhotonList, photons.c:190-199
+        const RebinRec o = recs[b];
+        if (o.valid) rebin_place_one(ph, o, null_slots[b]);
+    }
 }
 
 }  // namespace
@@ -897,6 +1081,26 @@ hipError_t launch_rebin_create(const PhotonDev &ph, const RebinAxes &ax, const i
 hipError_t launch_rebin_place(const PhotonDev &ph, const RebinRec *recs, int total_bins, const int *null_slots, hipStream_t stream)
 {
     rebin_place_kernel<<<dim3((total_bins + 255) / 256), dim3(256), 0, stream>>>(ph, recs, total_bins, null_slots);
+    return hipGetLastError();
+}
+
+size_t rebin_pool_scratch_bytes(int n, int total_bins)
+{
+    const size_t n_al = ((size_t)n + 63) & ~(size_t)63, b_al = ((size_t)total_bins + 2 + 63) & ~(size_t)63;
+    return (sizeof(int) * (3 * n_al + 3 * b_al) + sizeof(RebinRec) * (size_t)total_bins + 255) & ~(size_t)255;
+}
+
+hipError_t launch_rebin_pool_range(const PhotonDev &pool, int three, const RebinPoolList *lists, int n_lists, RebinRange *out, hipStream_t stream)
+{
+    if (n_lists <= 0) return hipSuccess;
+    rebin_pool_range_kernel<<<dim3(n_lists), dim3(256), 0, stream>>>(pool, three, lists, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rebin_pool(const PhotonDev &pool, RebinPoolList *lists, int n_lists, char *scratch, hipStream_t stream)
+{
+    if (n_lists <= 0) return hipSuccess;
+    rebin_pool_kernel<<<dim3(n_lists), dim3(256), 0, stream>>>(pool, lists, scratch);
     return hipGetLastError();
 }
 

@@ -786,15 +786,10 @@ using EventShared = EventSharedT<EVENT_BLOCK>;
 // (sh.raw[0..n_raw), complete below t_cut unless it overflowed), walk it as photonEvent does, refill from
 // time_to_scatter if it runs out, then the bookkeeping of mcrat.c:782-784 / 837-845 into *st.
 // All BLOCK threads call it; `gmin` is the list's minimum candidate (used when the shortlist is empty).
-struct NoIdleWork { __device__ __forceinline__ void operator()() const {} };
-
-// IDLE: what the threads that take no part in the walk do while it runs (called once, by every thread outside the walking wavefront, before the
-// barrier at which they would otherwise wait for the walk's end): rank_loop_kernel draws the next pass's free-path random numbers there.
-template <int DIMS, int GEOM, bool STOKES, int BLOCK, class PH, class SRC = KeyedSource, class IDLE = NoIdleWork>
+template <int DIMS, int GEOM, bool STOKES, int BLOCK, class PH, class SRC = KeyedSource>
 __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
                                             EventSharedT<BLOCK> &sh, int n_raw, Cand gmin, int base, int n,
-                                            unsigned long long iter, double dt_max, int last_idx, double t_est, const SRC &src = SRC(),
-                                            const IDLE &idle = IDLE())
+                                            unsigned long long iter, double dt_max, int last_idx, double t_est, const SRC &src = SRC())
 {
     const int tid = threadIdx.x;
     int n_list = (n_raw > BLOCK) ? 0 : n_raw;              // overflowed: incomplete, ignore it
@@ -805,7 +800,11 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
         sh.list[rank] = me;
     }
     if (n_list == 0 && tid == 0) sh.list[0] = gmin;
-    __syncthreads();
+    // A shortlist of up to 64 entries is sorted by the first wavefront alone -- the one that walks it: its own LDS writes are in order before
+    // its reads, no workgroup barrier needed, and the other wavefronts are free until the barrier behind the walk (rank_loop_kernel draws the
+    // next pass's random numbers there).  (n_list is the same in every thread: either all pass the barrier or none.)
+    if (n_list > 64) __syncthreads();
+    else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (n_list == 0 && gmin.idx != INT_MAX) n_list = 1;
 
     if (tid == 0) MC_STAMP(st, 1);
@@ -846,8 +845,6 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
 #ifndef MCRAT_NO_WALK_PRIORITY
             __builtin_amdgcn_s_setprio(0);
 #endif
-        } else if (round == 0 && tid >= 64) {
-            idle();
         }
         __syncthreads();
         if (sh.status != EV_NEED_MORE) break;
@@ -1424,11 +1421,16 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if (force) RANK_TICK(1); else RANK_TICK(2);
         // ---- the event half and the bookkeeping
         const bool frame_goes_on = gmin.t < st.remaining_time;          // (else this pass ends the frame, mcrat.c:834: nobody needs further draws)
-        auto idle_work = [&]() { if constexpr (RANK_BLOCK > 64) { if (frame_goes_on) draw_logs(iter + 1, 64, RANK_BLOCK - 64); } };
-        event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n_pass, iter, st.remaining_time, st.last_scattered_index, st.t_est,
-                                                    KeyedSource(), idle_work);
-        if constexpr (RANK_BLOCK == 64) {                        // one wavefront per list: it draws after its walk
-            if (frame_goes_on) draw_logs(iter + 1, 0, 64);
+#ifndef MCRAT_NO_SHADOW_DRAWS
+        constexpr bool SHADOW = RANK_BLOCK > 64;
+#else                                                            // (A/B build: everybody draws after the walk)
+        constexpr bool SHADOW = false;
+#endif
+        // the wavefronts that do not walk draw for the next pass now; they join the others at the barrier behind the walk (event_block)
+        if constexpr (SHADOW) { if (frame_goes_on && tid >= 64) draw_logs(iter + 1, 64, RANK_BLOCK - 64); }
+        event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n_pass, iter, st.remaining_time, st.last_scattered_index, st.t_est);
+        if constexpr (!SHADOW) {                                 // one wavefront per list: it draws after its walk
+            if (frame_goes_on) draw_logs(iter + 1, 0, RANK_BLOCK);
             __syncthreads();
         }
         if (tid == 0) {

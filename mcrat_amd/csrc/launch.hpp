@@ -292,6 +292,18 @@ hipError_t launch_rebin_create(const PhotonDev &ph, const RebinAxes &ax, const i
 hipError_t launch_rebin_place(const PhotonDev &ph, const RebinRec *recs, int total_bins, const int *null_slots, hipStream_t stream);
 // setNullPhoton for every 'k' and 'c' photon (:573-581)
 hipError_t launch_rebin_nullify(const PhotonDev &ph, hipStream_t stream);
+// the rebinning of many lists of a rank pool in two launches, one workgroup per list (inject.hip, rebin_pool_kernel)
+struct RebinPoolList {
+    int first, n;              // the list's window in the pool's slots
+    RebinAxes ax;              // (second launch) the histograms, fixed by the host from the first launch's ranges
+    unsigned long long scratch;   // byte offset of the list's scratch (rebin_pool_scratch_bytes) in the buffer handed to the second launch
+    int status;                // out: 0 rebinned; 1 a photon maps outside the histograms (list untouched); 2 fewer null slots than bins
+    int empty_bins, n_null;    // out
+    int pad;
+};
+size_t rebin_pool_scratch_bytes(int n, int total_bins);
+hipError_t launch_rebin_pool_range(const PhotonDev &pool, int three, const RebinPoolList *lists, int n_lists, RebinRange *out, hipStream_t stream);
+hipError_t launch_rebin_pool(const PhotonDev &pool, RebinPoolList *lists, int n_lists, char *scratch, hipStream_t stream);
 hipError_t grid_build(const GridPlan &p, const CellGeom *geom, const CellGeom2 *geom2, const CellFluid *fluid, const double *fluid_c, int M,
                       unsigned *count, int *start, int *scan_scratch, int *entries, FatCell *cells, BucketDir *dir, long long nb,
                       long long total, hipStream_t stream);

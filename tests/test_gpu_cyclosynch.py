@@ -73,12 +73,13 @@ def test_absorption_matches_the_oracle(hip, oracle, b_field_calc, dims):
         assert np.array_equal(got[f], want[f], equal_nan=got[f].dtype.kind == "f"), f
 
 
-def _oracle_pool(oracle, frame, cfg, aos, null_slots, dens, b_field_calc, seed, maximum_photons, frames=(200, 200)):
+def _oracle_pool(oracle, frame, cfg, aos, null_slots, dens, b_field_calc, seed, maximum_photons, frames=(200, 200), B=(None, None, None), ph_weight=1e40):
     """-> (photons emitted, weight, fallback flag, the list before the emission, the list after it)"""
     L = oracle.lib()
     c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
     H = oracle.OracleHydro(frame)
-    cs = oracle.CS(b_field_calc, 0.5, 0.1, dens.ctypes.data_as(C.POINTER(C.c_double)), None, None, None, frames[0], frames[1], 0.5, 10.0)
+    ptr = lambda a: a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+    cs = oracle.CS(b_field_calc, 0.5, 0.1, ptr(dens), ptr(B[0]), ptr(B[1]), ptr(B[2]), frames[0], frames[1], 0.5, 10.0)
     l = oracle.PhotonList()
     L.orc_list_init(C.byref(l))
     a = aos.copy()
@@ -90,12 +91,44 @@ def _oracle_pool(oracle, frame, cfg, aos, null_slots, dens, b_field_calc, seed, 
     rng = oracle.Rng()
     L.orc_rng_init(C.byref(rng), seed, 0)
     w, fb = C.c_double(), C.c_int()
-    n = L.orc_photonEmitCyclosynch(C.byref(c), C.byref(cs), C.byref(l), 1e12, 1e40, maximum_photons, 0.0, 0.05, C.byref(H.c), C.byref(rng), 0, 0,
+    n = L.orc_photonEmitCyclosynch(C.byref(c), C.byref(cs), C.byref(l), 1e12, ph_weight, maximum_photons, 0.0, 0.05, C.byref(H.c), C.byref(rng), 0, 0,
                                    C.byref(w), C.byref(fb))
     buf = (C.c_char * (l.list_capacity * oracle.PHOTON_DTYPE.itemsize)).from_address(l.photons)
     out = np.frombuffer(buf, dtype=oracle.PHOTON_DTYPE).copy()
     L.orc_list_free(C.byref(l))
     return n, w.value, fb.value, before, out
+
+
+@pytest.mark.parametrize("field", [1e12, 1e14])
+def test_pool_emission_where_qags_goes_past_its_first_rule(hip, oracle, field):
+    """gsl_integration_qags of the Planck photon density up to the cyclotron frequency (mc_cyclosynch.c:1276) in cells whose cyclotron frequency
+    lies far beyond the Planck peak (B_FIELD_CALC == SIMULATION with a magnetar's field: h nu_c / kT of 10^2 and more): the 21-point rule on the
+    whole interval fails QAGS' first-step test, and the device bisects the worst interval exactly as the oracle's orc_qags does (its documented
+    stand-in for the rest of QAGS) -- the same Poisson means, so the same pool photons at the same weight."""
+    frame, ph, cfg = synth.config2(n_photons=600, nzc=8, stokes=1, lumi=1e53)
+    dens = np.ascontiguousarray(frame["dens"])
+    M = frame["num_elements"]
+    B = [np.full(M, field), np.zeros(M), np.zeros(M)]
+    aos = synth.photons_to_aos(ph, hip.PHOTON_DTYPE)
+    # (the weight the search starts from: near the answer -- from far below it the reference's int photon total overflows on the way, :1244-1296)
+    n_ref, w_ref, fb_ref, aos, want = _oracle_pool(oracle, frame, cfg, aos, range(1, 600, 2), dens, 2, 77, 1500, B=B, ph_weight=1e50)
+    assert fb_ref == 1 and n_ref > 0                        # the oracle went past the first rule
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    e.set_hydro(frame)
+    e.set_hydro_extras(dens, *B)
+    e.set_photons_aos(aos)
+    n, w, bad = e.emit_cyclosynch_pool(1e12, 1e50, 1500, 0.0, 0.05, frame["fps"], 77, b_field_calc=2, scatt_frame_number=200, inj_frame_number=200)
+    assert (n, w, bad) == (n_ref, w_ref, 0)
+    got = e.get_photons_aos()
+    assert np.array_equal(got["type"], want["type"]) and np.array_equal(got["weight"], want["weight"])
+    pool = got["type"] == b"p"
+    assert pool.sum() == n
+    for f in ("p0", "r0", "r1", "r2"):
+        scale = np.abs(want["p0"][pool]) if f == "p0" else 1e12
+        assert np.all(np.abs(got[f][pool] - want[f][pool]) <= 1e-11 * scale), f
+    # (a field so strong that every one of the rule's 21 nodes lies beyond the Planck peak's reach integrates to exactly 0 with error 0 -- QAGS, the
+    # oracle and the device all call that converged; the device's 64-interval limit is a safety net this integrand does not reach)
+    e.close()
 
 
 @pytest.mark.parametrize("case", ["null-slots", "full-list-doubles", "no-cell-in-shell"])

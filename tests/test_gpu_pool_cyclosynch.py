@@ -140,6 +140,48 @@ def test_pool_lists_with_the_switch_on_match_the_oracle_list_by_list(hip, oracle
     pool.close()
 
 
+def test_dozens_of_lists_rebinned_in_the_same_frame(hip, oracle, monkeypatch):
+    """mc_cyclosynch.c:610-710 for all parked lists of a frame in two launches (engine.hip, pool_rebin_lists; inject.hip, rebin_pool_kernel):
+    96 lists, of which more than 64 have their rebinning trigger (mcrat.c:797-808) fire in the same frame, come out bit for bit as when every list is rebinned on its own
+    through its view (MCRAT_HIP_POOL_REBIN_EACH=1, the round-2 path), and as the oracle leaves them (three of them checked, 1e-9)."""
+    frame, ph, cfg = synth.config2(n_photons=300, nzc=8, lumi=3e53)
+    dens = np.ascontiguousarray(frame["dens"])
+    R, max_photons, theta_max = 96, 200, 0.05
+    starts = [_start_list(oracle, ph, 7 * r) for r in range(R)]
+    args = [dict(seed=31 + 3 * r, time_now=0.0, remaining_time=8.0 + 0.01 * (r % 7), r_inj=1e12, ph_weight_suggest=1e40, theta_min=0.0, theta_max=theta_max,
+                 emit_pool=1, scatt_frame_number=200, inj_frame_number=200) for r in range(R)]
+    runs = {}
+    for each in ("0", "1"):
+        monkeypatch.setenv("MCRAT_HIP_POOL_REBIN_EACH", each)
+        pool = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
+        pool.set_hydro(frame)
+        pool.set_hydro_extras(dens, None, None, None)
+        pool.pool_create(R, 4800)
+        for r in range(R):
+            pool.pool_rank(r, r).set_photons_aos(starts[r].astype(hip.PHOTON_DTYPE))
+        sts, cnts = pool.pool_scatter_frames_cyclosynch(args, max_photons, frame["fps"], b_field_calc=1, rebin_ang_phi=10.0)
+        runs[each] = (sts, cnts, [pool.pool_rank(r, r).get_photons_aos() for r in range(R)])
+        pool.close()
+    (sa, ca, la), (sb, cb, lb) = runs["0"], runs["1"]
+    assert sum(1 for r in range(R) if ca[r].rebins >= 1) >= 64
+    for r in range(R):
+        assert (sa[r].iterations, sa[r].frame_scatt_cnt) == (sb[r].iterations, sb[r].frame_scatt_cnt), r
+        assert (ca[r].num_cyclosynch_ph_emit, ca[r].scatt_cyclosynch_num_ph, ca[r].frame_abs_cnt, ca[r].rebins) == \
+            (cb[r].num_cyclosynch_ph_emit, cb[r].scatt_cyclosynch_num_ph, cb[r].frame_abs_cnt, cb[r].rebins), r
+        assert la[r].tobytes() == lb[r].tobytes(), r
+    for r in (0, 35, 95):
+        want, st, cnt, t = _oracle_frame(oracle, cfg, frame, dens, [None, None, None], starts[r], args[r]["seed"], r, args[r]["remaining_time"], max_photons,
+                                         theta_max, 1, 1, 10.0)
+        assert (sa[r].iterations, sa[r].frame_scatt_cnt) == (st.iterations, st.frame_scatt_cnt), r
+        assert (ca[r].num_cyclosynch_ph_emit, ca[r].scatt_cyclosynch_num_ph, ca[r].frame_abs_cnt, ca[r].rebins) == \
+            (cnt.num_cyclosynch_ph_emit, cnt.scatt_cyclosynch_num_ph, cnt.frame_abs_cnt, cnt.rebins), r
+        got = la[r]
+        assert len(got) == len(want) and np.array_equal(got["type"], want["type"]) and np.array_equal(got["weight"], want["weight"])
+        for f in ("p0", "r0", "r1", "r2", "s1"):
+            scale = np.maximum(np.abs(want["p0"]), 1e-300) if f == "p0" else (np.maximum(np.abs(want[f]), 1e9) if f.startswith("r") else 1.0)
+            assert np.all(np.abs(got[f] - want[f]) / scale <= 1e-9), (r, f)
+
+
 def test_a_pool_too_small_for_the_doublings_says_so(hip, oracle):
     frame, ph, cfg = synth.config_3d_cartesian(n_photons=300, n=(8, 8, 8))
     pool = hip.Engine(cfg["dimensions"], cfg["geometry"], 1, cyclosynchrotron=1)
