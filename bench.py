@@ -216,7 +216,7 @@ def bench_cfg5(args):
         def __init__(self, lo, hi):
             self.lo, self.hi = lo, hi
             self.ts = torch.cuda.Stream()
-            pool = self.pool = engine.Engine(synth.THREE, synth.SPHERICAL, 1, cyclosynchrotron=1, stream=self.ts.cuda_stream)
+            pool = self.pool = engine.Engine(synth.THREE, synth.SPHERICAL, 1, cyclosynchrotron=1, stream=self.ts.cuda_stream, profile=True)
             self.m_inj, _, _ = pool.ingest(raw, dict(r_inj=r_inj, ph_inj_switch=1, min_r=0, max_r=0, min_theta=0, max_theta=0, fps=fps, **dom), jet)
             pool.pool_create(hi - lo, 4 * max_photons)
             for r in range(lo, hi):
@@ -260,6 +260,7 @@ def bench_cfg5(args):
     import threading
     gate = threading.Barrier(n_pools + 1)
     parts = [None] * n_pools
+    loop_prof = [None] * n_pools
 
     def drive(p):
         for k in range(warmup):
@@ -268,10 +269,13 @@ def bench_cfg5(args):
         gate.wait()
         gate.wait()
         acc = [0] * 7
+        ms0, l0 = pools[p].pool.profile_totals()
         for k in range(steps):
             acc = [a + b for a, b in zip(acc, pools[p].one(SEED + 7 + 1000 * k))]
         pools[p].pool.synchronize()
+        ms1, l1 = pools[p].pool.profile_totals()
         parts[p] = acc
+        loop_prof[p] = (ms1 - ms0, l1 - l0)
     threads = [threading.Thread(target=drive, args=(p,)) for p in range(n_pools)]
     for th in threads:
         th.start()
@@ -285,6 +289,8 @@ def bench_cfg5(args):
     dt = time.perf_counter() - t0
     tot = [sum(x[j] for x in parts) for j in range(7)]
     achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[1] / dt / 1e9
+    loop_ms, loop_launches = max(x[0] for x in loop_prof), sum(x[1] for x in loop_prof)     # (pools side by side: the longest pool's loop time)
+    loop_gbs = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[1] / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
     cpu = None
     if not args.no_cpu_baseline:
         try:
@@ -306,10 +312,13 @@ def bench_cfg5(args):
            "photon_steps_per_s": tot[1] / dt, "scatter_events": tot[0], "loop_passes": tot[2],
            "cyclosynchrotron": {"pool_photons_emitted_per_frame": tot[3] / steps, "photons_absorbed_per_frame": tot[4] / steps, "rebinnings_per_frame": tot[5] / steps,
                                 "list_slots_after_a_frame": tot[6] // steps, "setup_s_ingest_and_injection": setup_inject},
-           "roofline": {"kernel": "rank_loop_kernel + cs_replace_pool_kernel (whole frame)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "note": "110 B x photon-steps over the WALL time of the timed frames (pool emission, rebinning and absorption included), not over "
-                                "one kernel's launches: a lower bound of the loop kernel's own figure"},
+           "roofline": {"kernel": "rank_loop_kernel (CSH build: the hook of mcrat.c:786-808 inside the loop)", "bound": "hbm",
+                        "achieved": loop_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": loop_gbs / HBM_PEAK_GBS, "traffic": None,
+                        "avg_launch_ms": loop_ms / max(1, loop_launches), "launches": int(loop_launches), "loop_ms_per_frame": loop_ms / steps,
+                        "frac_whole_frame": achieved / HBM_PEAK_GBS, "achieved_whole_frame": achieved,
+                        "note": "loop only: 110 B x photon-steps over the summed duration of the loop kernel's launches (HIP events on the pool's stream "
+                                "around every batch of launches; the pools' launches do not overlap here when --pools is 1); frac_whole_frame divides the "
+                                "same bytes by the WALL time of the timed frames -- pool emission, rebinning, absorption and the host's part included"},
            "cpu_baseline": cpu}
     print(json.dumps(out), flush=True)
 
@@ -473,8 +482,12 @@ def main():
             else:
                 e.set_hydro(frame)
             e.pool_create(max(1, hi - lo), int(lens.max()))
+            # the lists as the reference's struct photon records, all of them in one copy and one launch (mcrat_hip_pool_set_photons; list by list
+            # it was 52 small copies per list: 53 339 __amd_rocclr_copyBuffer dispatches in round 2's trace of this command)
             for r in range(lo, hi):
-                e.pool_rank(r - lo, sb + r).set_photons(sub_photons(src, int(offs[r]), int(offs[r + 1])))
+                e.pool_rank(r - lo, sb + r)
+            recs = synth.photons_to_aos(src, engine.PHOTON_DTYPE)
+            e.pool_set_photons(list(range(hi - lo)), [recs[int(offs[r]):int(offs[r + 1])] for r in range(lo, hi)])
             return e
         e = engine.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], device=local_rank, stream=stream,
                           rng_stream=first_stream, iterations_per_sync=per_sync or 500, use_graph=bool(args.graph),

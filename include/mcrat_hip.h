@@ -514,6 +514,10 @@ typedef struct mcrat_hip_rank_summary {
     int    num_output;                           /* photons with weight != 0: what printPhotons writes (mcrat_io.c:137-181) */
     int    list_capacity;                        /* photon_list->list_capacity of this rank (0: no list) */
 } mcrat_hip_rank_summary;
+/* mcrat_hip_config.profile = 1: the summed duration (HIP events on the context's stream) and the number of the loop kernel's launches since
+ * the context was created -- mcrat_hip_run's and mcrat_hip_pool_scatter_frames_cyclosynch's (there: rank_loop_kernel with the hook inside;
+ * emission, rebinning and absorption are NOT in it).  MCRAT_HIP_ESTATE without profile. */
+int mcrat_hip_profile_totals(const mcrat_hip_ctx *ctx, double *loop_kernel_ms, long long *loop_kernel_launches);
 int mcrat_hip_pool_create(mcrat_hip_ctx *pool, int n_ranks, int slots_per_rank);
 int mcrat_hip_pool_rank(mcrat_hip_ctx *pool, int rank, uint32_t rng_stream, mcrat_hip_ctx **view);
 int mcrat_hip_pool_summaries(mcrat_hip_ctx *pool, mcrat_hip_rank_summary *out /* [n_ranks] */);

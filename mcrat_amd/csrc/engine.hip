@@ -43,6 +43,8 @@ struct mcrat_hip_ctx {
     size_t ph_snap_bytes = 0;
     bool have_photons = false;
     void *aos_buf = nullptr;          // device copy of the caller's struct photon records (mcrat_hip_set_photons / get_photons)
+    void *pin_ring[2] = {nullptr, nullptr};   // pinned staging for uploads gathered from many host buffers (mcrat_hip_pool_set_photons)
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
     size_t aos_bytes = 0;
     int step_blocks = 0;
     Cand *partials = nullptr;
@@ -307,6 +309,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
     if (c->ph_buf) (void)hipFree(c->ph_buf);
+    for (int k = 0; k < 2; ++k) { if (c->pin_ring[k]) (void)hipHostFree(c->pin_ring[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     if (c->ph_snap) (void)hipFree(c->ph_snap);
     if (c->aos_buf) (void)hipFree(c->aos_buf);
     if (c->hy_buf) (void)hipFree(c->hy_buf);
@@ -1489,11 +1492,36 @@ extern "C" int mcrat_hip_pool_set_photons(mcrat_hip_ctx *c, int count, const int
     const size_t rec_bytes = sizeof(mcrat_hip_photon) * total, desc_bytes = sizeof(Desc) * (size_t)count;
     int rc = ensure_aos(c, align_up(rec_bytes, 256) + desc_bytes);
     if (rc) return rc;
-    std::vector<mcrat_hip_photon> host(total);
-    for (int j = 0; j < count; ++j)
-        memcpy(host.data() + desc[(size_t)j].first, lists[j].photons, sizeof(mcrat_hip_photon) * (size_t)lists[j].list_capacity);
     char *dev = static_cast<char *>(c->aos_buf);
-    HIPCHK(c, hipMemcpyAsync(dev, host.data(), rec_bytes, hipMemcpyHostToDevice, c->stream));
+    {   // the lists' records, gathered through two pinned pieces: the copy into one overlaps the transfer of the other (a pageable source
+        // of this size moves at 3 GB/s; the caller's lists are wherever readCheckpoint put them)
+        constexpr size_t PIECE = 16u << 20;
+        for (int k = 0; k < 2; ++k) {
+            if (!c->pin_ring[k]) HIPCHK(c, hipHostMalloc(&c->pin_ring[k], PIECE, hipHostMallocDefault));
+            if (!c->pin_ev[k]) HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
+        }
+        size_t done = 0;            // bytes of the concatenated records already on their way
+        int j = 0, k = 0;
+        size_t in_list = 0;         // bytes of list j already taken
+        bool used[2] = {false, false};
+        while (done < rec_bytes) {
+            if (used[k]) HIPCHK(c, hipEventSynchronize(c->pin_ev[k]));
+            char *dst = static_cast<char *>(c->pin_ring[k]);
+            size_t fill = 0;
+            while (fill < PIECE && j < count) {
+                const size_t list_bytes = sizeof(mcrat_hip_photon) * (size_t)lists[j].list_capacity;
+                const size_t take = std::min(PIECE - fill, list_bytes - in_list);
+                memcpy(dst + fill, reinterpret_cast<const char *>(lists[j].photons) + in_list, take);
+                fill += take; in_list += take;
+                if (in_list == list_bytes) { ++j; in_list = 0; }
+            }
+            HIPCHK(c, hipMemcpyAsync(dev + done, dst, fill, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipEventRecord(c->pin_ev[k], c->stream));
+            used[k] = true;
+            done += fill;
+            k ^= 1;
+        }
+    }
     HIPCHK(c, hipMemcpyAsync(dev + align_up(rec_bytes, 256), desc.data(), desc_bytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, launch_pool_aos_to_soa(dev, c->ph, c->rank_stride, dev + align_up(rec_bytes, 256), count, c->stream));
     for (int j = 0; j < count; ++j) {
@@ -2031,6 +2059,15 @@ static int pool_rebin_lists(mcrat_hip_ctx *c, const mcrat_hip_cyclosynch *cs, in
 }
 
 extern "C" int mcrat_hip_num_photon_slots(const mcrat_hip_ctx *c) { return (c && c->have_photons) ? c->ph.n : 0; }
+
+extern "C" int mcrat_hip_profile_totals(const mcrat_hip_ctx *c, double *loop_kernel_ms, long long *loop_kernel_launches)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (!c->cfg.profile) return MCRAT_HIP_ESTATE;
+    if (loop_kernel_ms) *loop_kernel_ms = c->prof_step_ms;
+    if (loop_kernel_launches) *loop_kernel_launches = c->prof_launches;
+    return MCRAT_HIP_OK;
+}
 
 static int flush_pending(mcrat_hip_ctx *c)
 {
@@ -3354,10 +3391,22 @@ extern "C" int mcrat_hip_pool_scatter_frames_cyclosynch(mcrat_hip_ctx *c, const 
     const CsHookArgs *d_args = hook_kernel ? nullptr : static_cast<const CsHookArgs *>(c->d_cs_args);
     const int pairs_per_sync = hook_kernel ? 8 : 2;
     for (;;) {
+        if (c->cfg.profile) {                                    // the loop's launches between events (bench.py: cfg5's loop-only roofline)
+            if ((rc = ensure_events(c, 2))) return rc;
+            HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        }
         for (int k = 0; k < pairs_per_sync; ++k) {
             HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, 1 << 30, c->d_desc, d_cf, d_args, 4096, c->rank_block,
                                        c->stream));
             if (hook_kernel) HIPCHK(c, launch_cs_replace_pool(p, c->hy, c->hcol, c->d_rstates, c->ph, c->rank_stride, R, c->d_desc, d_cf, c->stream));
+        }
+        if (c->cfg.profile) {
+            HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+            HIPCHK(c, hipEventSynchronize(c->ev[1]));
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            c->prof_step_ms += ms;
+            c->prof_launches += pairs_per_sync;
         }
         HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(cf.data(), d_cf, sizeof(CsFrame) * (size_t)R, hipMemcpyDeviceToHost, c->stream));

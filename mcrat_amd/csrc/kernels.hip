@@ -1152,6 +1152,11 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     // and the slot alone, not on what the event before it does: the wavefronts that sit out the event walk (three of four; the walk is one
     // wavefront's, event_block) compute the NEXT pass's while they would otherwise wait at the barrier, into a scratch column (ListCols::draw_log).
     // Phase 1 then reads 8 B per slot instead of running ten Philox rounds per pair and a logarithm per slot: the same bits, a shorter pass.
+#ifndef MCRAT_NO_SHADOW_DRAWS
+    constexpr bool SHADOW = RANK_BLOCK > 64;                 // (a list of one wavefront has nobody in the walk's shadow: it draws in phase 1, as before)
+#else
+    constexpr bool SHADOW = false;                           // (A/B build)
+#endif
     auto draw_logs = [&](unsigned long long it, int first_thread, int n_threads) {
         for (int pair = tid - first_thread; 2 * pair < n_pass; pair += n_threads) {
             const Philox4 blk = keyed_block(rk.seed, it, (uint32_t)pair, RNG_FREEPATH, rk.stream);
@@ -1160,8 +1165,10 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             if (2 * pair + 1 < n) ph.draw_log(i + 1) = log(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32)));
         }
     };
-    draw_logs(st.iteration, 0, EVENT_BLOCK);                 // the first pass of this launch: nobody has drawn for it
-    __syncthreads();
+    if constexpr (SHADOW) {
+        draw_logs(st.iteration, 0, EVENT_BLOCK);             // the first pass of this launch: nobody has drawn for it
+        __syncthreads();
+    }
     RANK_TICK(0);
 
     // the advance the last pass left pending (LoopState::seg), applied to every moving slot but the one the event advanced itself
@@ -1281,9 +1288,18 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         else phys::hydro_coords<DIMS, GEOM>(r0[k], r1[k], r2[k], a0[k], a1[k], a2[k]);
                         dom[k] = phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);      // mclib.c:492-505
                     }
-                    uint64_t bits[NS];                                                // the bit pattern of log(u+) of the slot's draw (draw_logs)
+                    uint64_t bits[NS];                                                // the bit pattern of log(u+) of the slot's draw
+                    if constexpr (SHADOW) {                                           // drawn in the previous walk's shadow (draw_logs)
 #pragma unroll
-                    for (int k = 0; k < NS; ++k) bits[k] = (uint64_t)__double_as_longlong(ph.draw_log(base + il[k]));
+                        for (int k = 0; k < NS; ++k) bits[k] = (uint64_t)__double_as_longlong(ph.draw_log(base + il[k]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < PAIRS; ++j) {
+                            const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)(pair + j * EVENT_BLOCK), RNG_FREEPATH, rk.stream);
+                            bits[2 * j] = (uint64_t)__double_as_longlong(log(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32))));
+                            bits[2 * j + 1] = (uint64_t)__double_as_longlong(log(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))));
+                        }
+                    }
                     // decisions, slot by slot
                     int qd[NS], code[NS];
                     bool settled[NS];
@@ -1421,18 +1437,10 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if (force) RANK_TICK(1); else RANK_TICK(2);
         // ---- the event half and the bookkeeping
         const bool frame_goes_on = gmin.t < st.remaining_time;          // (else this pass ends the frame, mcrat.c:834: nobody needs further draws)
-#ifndef MCRAT_NO_SHADOW_DRAWS
-        constexpr bool SHADOW = RANK_BLOCK > 64;
-#else                                                            // (A/B build: everybody draws after the walk)
-        constexpr bool SHADOW = false;
-#endif
         // the wavefronts that do not walk draw for the next pass now; they join the others at the barrier behind the walk (event_block)
         if constexpr (SHADOW) { if (frame_goes_on && tid >= 64) draw_logs(iter + 1, 64, RANK_BLOCK - 64); }
+        (void)frame_goes_on;
         event_block<DIMS, GEOM, STOKES, RANK_BLOCK>(ph, hy, &st, rk, sh, s_sln, gmin, base, n_pass, iter, st.remaining_time, st.last_scattered_index, st.t_est);
-        if constexpr (!SHADOW) {                                 // one wavefront per list: it draws after its walk
-            if (frame_goes_on) draw_logs(iter + 1, 0, RANK_BLOCK);
-            __syncthreads();
-        }
         if (tid == 0) {
             st.force_relocate = 0;
             // cyclo-synchrotron lists: if photonEvent reported a pool photon (it becomes a comptonised one and is replaced, mcrat.c:786-795)
@@ -1473,8 +1481,10 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                     if (tid == 0) const_cast<RankDesc *>(lay.desc)[rank].len = n;
                 }
                 settle_pass_limit();                         // (the new photon's slot, fresh null slots)
-                draw_logs(st.iteration, 0, EVENT_BLOCK);     // (the pass limit may have grown: the next pass's draws for every pair)
-                __syncthreads();
+                if constexpr (SHADOW) {
+                    draw_logs(st.iteration, 0, EVENT_BLOCK); // (the pass limit may have grown: the next pass's draws for every pair)
+                    __syncthreads();
+                }
             }
         }
         RANK_TICK(3);
@@ -2829,20 +2839,26 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                 kernel_global<<<dim3(n_ranks), dim3(threads), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
             }
         };
-        if (block == 512 && fuse && !TABLE_MODE && kc.geometry != GEOM_SPHERICAL) {
-            if constexpr (GV != GEOM_SPHERICAL) {
+        // The fused pass exists where engine.hip's choose_rank_block can ask for it: DIRECT optical depths, not in spherical geometry (there it
+        // measured slower), 256 or 512 threads.  Everything else has the queue form only -- a third of the instantiations less than building all.
+        if constexpr (!TABLE_MODE && GV != GEOM_SPHERICAL) {
+            if (fuse && block == 512) {
                 if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 512, true>, rank_loop_kernel<DV, GV, true, false, 512, true>, 512);
                 else launch(rank_loop_kernel<DV, GV, false, true, 512, true>, rank_loop_kernel<DV, GV, false, false, 512, true>, 512);
+                return;
             }
-        } else if (block == 512) {
+            if (fuse && block != 128) {
+                if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256, true>, rank_loop_kernel<DV, GV, true, false, 256, true>, 256);
+                else launch(rank_loop_kernel<DV, GV, false, true, 256, true>, rank_loop_kernel<DV, GV, false, false, 256, true>, 256);
+                return;
+            }
+        }
+        if (block == 512) {
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 512, false>, rank_loop_kernel<DV, GV, true, false, 512, false>, 512);
             else launch(rank_loop_kernel<DV, GV, false, true, 512, false>, rank_loop_kernel<DV, GV, false, false, 512, false>, 512);
         } else if (block == 128) {                 // (no fused build at 128 threads: it measured no gain on thin frames, round 2, and was 36 instantiations)
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, RANK_SMALL, false>, rank_loop_kernel<DV, GV, true, false, RANK_SMALL, false>, RANK_SMALL);
             else launch(rank_loop_kernel<DV, GV, false, true, RANK_SMALL, false>, rank_loop_kernel<DV, GV, false, false, RANK_SMALL, false>, RANK_SMALL);
-        } else if (fuse && !TABLE_MODE) {
-            if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256, true>, rank_loop_kernel<DV, GV, true, false, 256, true>, 256);
-            else launch(rank_loop_kernel<DV, GV, false, true, 256, true>, rank_loop_kernel<DV, GV, false, false, 256, true>, 256);
         } else {
             if (kc.stokes) launch(rank_loop_kernel<DV, GV, true, true, 256, false>, rank_loop_kernel<DV, GV, true, false, 256, false>, 256);
             else launch(rank_loop_kernel<DV, GV, false, true, 256, false>, rank_loop_kernel<DV, GV, false, false, 256, false>, 256);

@@ -218,6 +218,7 @@ SYMBOLS = {
     "mcrat_hip_num_photon_slots": (C.c_int, [_ctx]),
     "mcrat_hip_pool_inject_photons": (C.c_int, [_ctx, C.c_double, C.POINTER(PoolInjectList)]),
     "mcrat_hip_pool_set_photons": (C.c_int, [_ctx, C.c_int, _ip, C.c_void_p]),
+    "mcrat_hip_profile_totals": (C.c_int, [_ctx, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "mcrat_hip_outbox_create": (C.c_int, [_ctx, C.POINTER(C.c_void_p)]),
     "mcrat_hip_outbox_destroy": (None, [C.c_void_p]),
     "mcrat_hip_outbox_post": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
@@ -648,6 +649,12 @@ class Engine:
         self._check(self.lib.mcrat_hip_get_output(self.ctx, C.byref(o)), "get_output")
         assert o.count == m
         return out
+
+    def profile_totals(self):
+        """(summed ms, launches) of the loop kernel since the context was created (profile=True contexts)"""
+        ms, n = C.c_double(), C.c_longlong()
+        self._check(self.lib.mcrat_hip_profile_totals(self.ctx, C.byref(ms), C.byref(n)), "profile_totals")
+        return ms.value, n.value
 
     def outbox_create(self):
         """mcrat_hip_outbox_create: a staging area (device + pinned host) for the frame's records and output columns"""
