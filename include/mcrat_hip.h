@@ -614,6 +614,9 @@ int mcrat_hip_shared_clock_buffers(mcrat_hip_ctx *ctx, void **send, void **recv)
  *                                          spinning its own budget;
  *   mcrat_hip_shared_clock_reset_exchange  after such a failure: clears this rank's give-up word, round number and stamps.  Every rank calls
  *                                          it, then the ranks synchronise (any barrier), then begin_frame as usual.
+ * Since round 3 the push runs at the end of the propose kernel and the wait at the head of the resolve kernel (two launches less per round); the
+ * three exchange calls then only check the state and return, so a host loop written as propose / exchange / resolve stays as it is.  The peers
+ * must therefore be set before the first propose.  MCRAT_HIP_SC_FOLD=0 (environment, read at attach) keeps push and wait as kernels of their own.
  * All on the context's stream and without per-round arguments (the round number lives on the device, the wait kernel copies the round's
  * proposals to the fixed place resolve reads), so propose / exchange / resolve capture into a hipGraph like the collective.  Every rank must run the same
  * number of rounds (rounds after the frame's end are no-ops but still exchange), as with the all-gather. */

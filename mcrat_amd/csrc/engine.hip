@@ -125,6 +125,7 @@ struct mcrat_hip_ctx {
     ScProposal *sc_send = nullptr, *sc_recv = nullptr;
     // device-initiated exchange (mcrat_hip_shared_clock_attach_device): fine-grained receive buffer (2 x world proposals) and stamps
     bool sc_device = false, sc_peers_set = false;
+    bool sc_fold = true;              // device exchange: push and wait run inside the propose and resolve kernels (MCRAT_HIP_SC_FOLD=0: as launches of their own)
     unsigned long long *sc_flags = nullptr;
     ScProposal *sc_gather = nullptr;   // the round's proposals of all ranks, copied out of the receive buffer's current half: what resolve reads
     ScPeers sc_peers{};
@@ -3607,6 +3608,8 @@ extern "C" int mcrat_hip_shared_clock_attach_device(mcrat_hip_ctx *c, int world,
     HIPCHK(c, hipMemset(c->sc_flags, 0, flag_bytes));
     HIPCHK(c, hipDeviceSynchronize());
     c->sc_device = true;
+    c->sc_fold = true;
+    if (const char *e = getenv("MCRAT_HIP_SC_FOLD")) c->sc_fold = atoi(e) != 0;
     return MCRAT_HIP_OK;
 }
 
@@ -3635,10 +3638,30 @@ extern "C" int mcrat_hip_shared_clock_set_peers(mcrat_hip_ctx *c, void *const *p
     return MCRAT_HIP_OK;
 }
 
+static int sc_wait_spins()
+{
+    int spins = 4000000;                                             // a few seconds: ranks enter a frame together (a barrier on the host)
+    if (const char *e = getenv("MCRAT_HIP_SC_WAIT_SPINS")) spins = atoi(e) > 0 ? atoi(e) : spins;
+    return spins;
+}
+
+// the exchange inside the round's own kernels (launch.hpp, ScFold), when the GPUs do it themselves
+static ScFold sc_fold_of(const mcrat_hip_ctx *c)
+{
+    ScFold f{};
+    f.on = (c->sc_device && c->sc_peers_set && c->sc_fold) ? 1 : 0;
+    if (f.on) {
+        f.world = c->sc_world; f.rank = c->sc_rank; f.max_spins = sc_wait_spins();
+        f.peers = c->sc_peers; f.my_flags = c->sc_flags; f.recv = c->sc_recv; f.gathered = c->sc_gather;
+    }
+    return f;
+}
+
 extern "C" int mcrat_hip_shared_clock_exchange_push(mcrat_hip_ctx *c)
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->sc_device || !c->sc_peers_set || !c->frame_open) return MCRAT_HIP_ESTATE;
+    if (c->sc_fold) return MCRAT_HIP_OK;                              // (the propose kernel has pushed)
     HIPCHK(c, launch_sc_push(c->sc_send, c->sc_peers, c->sc_flags, c->sc_world, c->sc_rank, c->stream));
     return MCRAT_HIP_OK;
 }
@@ -3647,9 +3670,8 @@ extern "C" int mcrat_hip_shared_clock_exchange_wait(mcrat_hip_ctx *c)
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (!c->sc_device || !c->sc_peers_set || !c->frame_open) return MCRAT_HIP_ESTATE;
-    int spins = 4000000;                                             // a few seconds: ranks enter a frame together (a barrier on the host)
-    if (const char *e = getenv("MCRAT_HIP_SC_WAIT_SPINS")) spins = atoi(e) > 0 ? atoi(e) : spins;
-    HIPCHK(c, launch_sc_wait(c->sc_flags, c->sc_recv, c->sc_gather, c->sc_world, spins, c->d_state, c->stream));
+    if (c->sc_fold) return MCRAT_HIP_OK;                              // (the resolve kernel will wait)
+    HIPCHK(c, launch_sc_wait(c->sc_flags, c->sc_recv, c->sc_gather, c->sc_world, sc_wait_spins(), c->d_state, c->stream));
     return MCRAT_HIP_OK;
 }
 
@@ -3685,8 +3707,9 @@ extern "C" int mcrat_hip_shared_clock_propose(mcrat_hip_ctx *c)
 {
     if (!c) return MCRAT_HIP_EINVAL;
     if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
+    if (c->sc_device && !c->sc_peers_set && c->sc_fold) { c->last_error = "shared clock: the peers' buffers are not set (mcrat_hip_shared_clock_set_peers)"; return MCRAT_HIP_ESTATE; }
     HIPCHK(c, launch_sc_propose(c->kc, c->find_switch != 0, c->ph, c->hy, c->d_state, c->d_sc, c->key, c->partials, c->step_blocks,
-                                c->shortlist, c->sc_send, c->stream));
+                                c->shortlist, c->sc_send, sc_fold_of(c), c->stream));
     c->find_switch = 0;
     return MCRAT_HIP_OK;
 }
@@ -3696,7 +3719,7 @@ extern "C" int mcrat_hip_shared_clock_resolve(mcrat_hip_ctx *c)
     if (!c) return MCRAT_HIP_EINVAL;
     if (c->sc_world <= 0 || !c->frame_open) return MCRAT_HIP_ESTATE;
     const ScProposal *all = c->sc_device ? c->sc_gather : c->sc_recv;                   // device exchange: the wait kernel has copied the round out
-    HIPCHK(c, launch_sc_resolve(c->kc, c->ph, c->hy, c->d_state, c->d_sc, c->key, all, c->sc_world, c->stream));
+    HIPCHK(c, launch_sc_resolve(c->kc, c->ph, c->hy, c->d_state, c->d_sc, c->key, all, c->sc_world, sc_fold_of(c), c->stream));
     return MCRAT_HIP_OK;
 }
 

@@ -20,6 +20,7 @@
 #include <type_traits>
 #include "device_types.hpp"
 #include "launch.hpp"
+#include "sc_exchange.hpp"
 #include "physics.hpp"
 #include "photon_cols.hpp"
 #include "rng.hpp"
@@ -1050,6 +1051,9 @@ constexpr int rank_lds_bytes_per_slot(int block) { return block == 256 ? 7 * (in
 #ifndef RANK_WAVES_PER_SIMD
 #define RANK_WAVES_PER_SIMD 2
 #endif
+#ifndef RANK_NS_FUSED
+#define RANK_NS_FUSED 2        // slots a thread takes through a fused (lock-step) trip: 2; 4 (one trip per pass for 1000-photon lists) spills, DESIGN.md section 4
+#endif
 #ifndef RANK_FUSE_DEN
 #define RANK_FUSE_DEN 2      // a pass takes the fused form when more than 1/RANK_FUSE_DEN of the slots changed cell in the previous one
 #endif
@@ -1307,26 +1311,30 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
 #pragma unroll
                     for (int k = 0; k < NS; ++k) { settled[k] = false; tl[k] = 0; qd[k] = 0; code[k] = -1; }
                     if constexpr (FUSED && !TABLE_MODE) {
-                        static_assert(NS == 2, "the fused form takes one slot pair per trip");
-                        bool cand[2], same[2] = {false, false};
+                        bool cand[NS], same[NS], todo[NS];
+                        bool any_todo = false;
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
+                        for (int k = 0; k < NS; ++k) {
+                            same[k] = false;
                             cand[k] = live[k] && (fl[k] & FLAG_VALID) && dom[k] && cell[k] != -1;
                             if (cand[k]) code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]);
+                            todo[k] = cand[k];
+                            any_todo = any_todo || cand[k];
                         }
-                        bool todo[2] = {cand[0], cand[1]};
-                        if (todo[0] || todo[1]) {
-                            const int slot[2] = {base + il[0], base + il[1]};
-                            const LockstepProbe probe = {cell, force, same};
-                            double tt[2];
-                            relocate_lockstep<DIMS, GEOM, 2, true>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, !force, tt, relocated, &probe);
+                        if (any_todo) {
+                            int slot[NS];
 #pragma unroll
-                            for (int k = 0; k < 2; ++k)
+                            for (int k = 0; k < NS; ++k) slot[k] = base + il[k];
+                            const LockstepProbe probe = {cell, force, same};
+                            double tt[NS];
+                            relocate_lockstep<DIMS, GEOM, NS, true>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, bits, fl, !force, tt, relocated, &probe);
+#pragma unroll
+                            for (int k = 0; k < NS; ++k)
                                 if (cand[k] && !todo[k] && !same[k]) { settled[k] = true; tl[k] = tt[k]; n_rel += 1; }
                         }
                         bool any = false;
 #pragma unroll
-                        for (int k = 0; k < 2; ++k) {
+                        for (int k = 0; k < NS; ++k) {
                             if (!cand[k]) continue;
                             bool stays = same[k];
                             if (todo[k]) {                                            // no hint settles this slot: the test on its cached cell
@@ -1338,7 +1346,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                         }
                         if (any) {                                                    // the draws of the slots that stay in their cells
 #pragma unroll
-                            for (int k = 0; k < 2; ++k) tf[k] = free_time_from_log(ntau[k], __longlong_as_double((long long)bits[k]));
+                            for (int k = 0; k < NS; ++k) tf[k] = free_time_from_log(ntau[k], __longlong_as_double((long long)bits[k]));
                         }
                     } else {
 #pragma unroll
@@ -1395,7 +1403,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                 }
             };
             if constexpr (FUSE && !TABLE_MODE) {
-                if (fused) phase1(std::integral_constant<int, 2>{}, std::true_type{});
+                if (fused) phase1(std::integral_constant<int, RANK_NS_FUSED>{}, std::true_type{});
                 else phase1(std::integral_constant<int, RANK_NS_QUEUE>{}, std::false_type{});
             } else {
                 phase1(std::integral_constant<int, RANK_NS_QUEUE>{}, std::false_type{});
@@ -2354,9 +2362,8 @@ __global__ __launch_bounds__(STEP_BLOCK) void sc_midpass_kernel(PhotonDev ph, co
 
 // this GPU's earliest candidates of the round, with their data, into `out`
 template <bool STOKES>
-__global__ __launch_bounds__(EVENT_BLOCK) void sc_propose_kernel(PhotonDev ph, LoopState *st, const ScState *__restrict__ sc, RngKey key,
-                                                                 const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl,
-                                                                 ScProposal *__restrict__ out)
+__device__ __forceinline__ void sc_propose_body(const PhotonDev &ph, LoopState *st, const ScState *__restrict__ sc, const RngKey &key,
+                                                const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl, ScProposal *__restrict__ out)
 {
     static_assert(EVENT_BLOCK == SHORTLIST_CAP, "one thread per shortlist entry");
     __shared__ Cand s_raw[SHORTLIST_CAP];
@@ -2429,17 +2436,34 @@ __global__ __launch_bounds__(EVENT_BLOCK) void sc_propose_kernel(PhotonDev ph, L
     }
 }
 
+template <bool STOKES>
+__global__ __launch_bounds__(EVENT_BLOCK) void sc_propose_kernel(PhotonDev ph, LoopState *st, const ScState *__restrict__ sc, RngKey key,
+                                                                 const Cand *__restrict__ block_min, int n_blocks, Shortlist *sl,
+                                                                 ScProposal *__restrict__ out, ScFold fold)
+{
+    sc_propose_body<STOKES>(ph, st, sc, key, block_min, n_blocks, sl, out);
+    if (fold.on) {                                                  // the exchange's push, in line (a finished or parked frame still stamps its rounds)
+        __threadfence();
+        __syncthreads();
+        sc_push_body(out, fold.peers, fold.my_flags, fold.world, fold.rank);
+    }
+}
+
 // every GPU: merge the gathered proposals, walk the chain as photonEvent does (mclib.c:1128-1339), store the
 // scatter if the photon is ours, and do the bookkeeping of mcrat.c:782-784 / 837-845 -- identically everywhere
 template <int DIMS, int GEOM, bool STOKES>
 __global__ __launch_bounds__(EVENT_BLOCK) void sc_resolve_kernel(PhotonDev ph, HydroDev hy, LoopState *st, ScState *sc, RngKey key,
-                                                                 const ScProposal *__restrict__ all, int world)
+                                                                 const ScProposal *all, int world, ScFold fold)
 {
     __shared__ ScRecord s_rec[SC_MAX_WORLD * SC_K];
     __shared__ int s_order[SC_MAX_WORLD * SC_K];
     __shared__ int s_off[SC_MAX_WORLD + 1];
     __shared__ double s_seg[MAX_SEG];
+    __shared__ int s_failed;
     const int tid = threadIdx.x;
+    if (fold.on) {                                                  // the exchange's wait, in line: the round's proposals into `all` (= fold.gathered)
+        if (!sc_wait_body(fold.my_flags, fold.recv, fold.gathered, fold.world, fold.max_spins, st, &s_failed)) return;
+    }
     const int done = st->done;
     if (done == LOOP_DONE || done == LOOP_SC_GAVE_UP) return;
     if (tid == 0) {
@@ -2879,23 +2903,23 @@ hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const 
 }
 
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream)
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream)
 {
     hipError_t e = MCRAT_TU_NS::launch_step(kc, force_relocate, ph, hy, st, key, block_min, blocks, sl, stream);
     if (e != hipSuccess) return e;
     sc_midpass_kernel<<<dim3(blocks), dim3(STEP_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, sl);
-    if (kc.stokes) sc_propose_kernel<true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, blocks, sl, out);
-    else sc_propose_kernel<false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, blocks, sl, out);
+    if (kc.stokes) sc_propose_kernel<true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, blocks, sl, out, fold);
+    else sc_propose_kernel<false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, st, sc, key, block_min, blocks, sl, out, fold);
     return hipGetLastError();
 }
 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream)
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream)
 {
     return dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
-        if (kc.stokes) sc_resolve_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, sc, key, all, world);
-        else sc_resolve_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, sc, key, all, world);
+        if (kc.stokes) sc_resolve_kernel<DV, GV, true><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, sc, key, all, world, fold);
+        else sc_resolve_kernel<DV, GV, false><<<dim3(1), dim3(EVENT_BLOCK), 0, stream>>>(ph, hy, st, sc, key, all, world, fold);
     });
 }
 

@@ -43,6 +43,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
 // flag[r] = rank r's stamps (SC_MAX_WORLD words, one per sender, + a word counting waits that gave up + the rank's own round number)
 struct ScPeers { ScProposal *recv[SC_MAX_WORLD]; unsigned long long *flag[SC_MAX_WORLD]; };
 constexpr int SC_GAVE_UP_WORD = SC_MAX_WORLD, SC_ROUND_WORD = SC_MAX_WORLD + 1, SC_FLAG_WORDS = SC_MAX_WORLD + 2;
+// the same exchange folded into the round's own kernels (on != 0): sc_propose_kernel pushes its proposal when it has written it, sc_resolve_kernel
+// waits for the round's stamps before it reads `gathered` -- two launches less per round than push and wait as kernels of their own
+struct ScFold { int on, world, rank, max_spins; ScPeers peers; unsigned long long *my_flags; const ScProposal *recv; ScProposal *gathered; };
 hipError_t launch_sc_push(const ScProposal *send, const ScPeers &peers, unsigned long long *my_flags, int world, int rank, hipStream_t stream);
 hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins, LoopState *st, hipStream_t stream);
 // FAST mode: every photon through the whole frame on its own clock (kernels.hip, fast_frame_kernel); the counters add up over launches
@@ -54,10 +57,10 @@ hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const 
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 // one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 // ... and, after the host has all-gathered the proposals into `all`, the replicated walk of photonEvent
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream);
 // apply the pending advance (end of run / before photons are read back) and clear it
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream);
 hipError_t launch_k2e(const double *temp, double *k2e, int M, hipStream_t stream);

@@ -18,9 +18,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 int step_grid_blocks(int n_pad);
@@ -42,9 +42,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_direct_d1
@@ -60,9 +60,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_direct_d2
@@ -78,9 +78,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_table_d0
@@ -96,9 +96,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_table_d1
@@ -114,9 +114,9 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
                             int block, hipStream_t stream);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream);
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream);
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream);
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 }  // namespace tau_table_d2
@@ -163,15 +163,15 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
 }
 
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
-                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, hipStream_t stream)
+                             ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream)
 {
-    MCRAT_ROUTE(launch_sc_propose, kc, force_relocate, ph, hy, st, sc, key, block_min, blocks, sl, out, stream);
+    MCRAT_ROUTE(launch_sc_propose, kc, force_relocate, ph, hy, st, sc, key, block_min, blocks, sl, out, fold, stream);
 }
 
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
-                             const ScProposal *all, int world, hipStream_t stream)
+                             const ScProposal *all, int world, const ScFold &fold, hipStream_t stream)
 {
-    MCRAT_ROUTE(launch_sc_resolve, kc, ph, hy, st, sc, key, all, world, stream);
+    MCRAT_ROUTE(launch_sc_resolve, kc, ph, hy, st, sc, key, all, world, fold, stream);
 }
 
 hipError_t launch_flush(const PhotonDev &ph, LoopState *st, int blocks, hipStream_t stream) { return tau_direct_d0::launch_flush(ph, st, blocks, stream); }

@@ -6,6 +6,7 @@
 #include "../../include/mcrat_hip.h"
 #include "device_types.hpp"
 #include "launch.hpp"
+#include "sc_exchange.hpp"
 
 namespace mcrat {
 
@@ -441,59 +442,15 @@ hipError_t launch_cs_absorb(const CsParams &p, const PhotonDev &ph, const double
 // are no-ops), so the photons stay at the last pass every rank completed.  mcrat_hip_shared_clock_reset_exchange clears the state.
 __global__ __launch_bounds__(256) void sc_push_kernel(const ScProposal *__restrict__ send, ScPeers peers, unsigned long long *my_flags, int world, int rank)
 {
-    constexpr int WORDS = (int)(sizeof(ScProposal) / sizeof(unsigned long long));
-    static_assert(sizeof(ScProposal) % sizeof(unsigned long long) == 0, "proposal copied by 8-byte words");
-    if (my_flags[SC_GAVE_UP_WORD] != 0ull) return;
-    // the round number lives on the device (my_flags[SC_ROUND_WORD], touched by this rank's kernels only, in stream order): the launches
-    // carry no per-round argument and can be replayed from a hipGraph
-    const unsigned long long round = my_flags[SC_ROUND_WORD] + 1ull;
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(send);
-    for (int k = threadIdx.x; k < WORDS * world; k += 256) {
-        const int peer = k / WORDS, w = k - peer * WORDS;
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(peers.recv[peer] + (size_t)(round & 1ull) * (size_t)world + (size_t)rank);
-        __hip_atomic_store(dst + w, src[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
-    __syncthreads();
-    if ((int)threadIdx.x < world) __hip_atomic_store(peers.flag[threadIdx.x] + rank, round, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x == 0) my_flags[SC_ROUND_WORD] = round;
+    sc_push_body(send, peers, my_flags, world, rank);
 }
 
-// waits for the round's stamps of all ranks, then copies the round's half of the receive buffer into `gathered`, which is what
-// sc_resolve_kernel reads (a fixed address: no per-round argument there either).  If a stamp does not come within max_spins the wait gives up:
-// nothing is copied (a stale half of the buffer must never be resolved) and the loop is parked.
+// (if a stamp does not come within max_spins the wait gives up: nothing is copied -- a stale half of the buffer must never be resolved -- and the loop is parked)
 __global__ __launch_bounds__(256) void sc_wait_kernel(unsigned long long *my_flags, const ScProposal *recv, ScProposal *gathered, int world, int max_spins,
                                                       LoopState *st)
 {
-    constexpr int WORDS = (int)(sizeof(ScProposal) / sizeof(unsigned long long));
     __shared__ int s_failed;
-    if (my_flags[SC_GAVE_UP_WORD] != 0ull) return;                  // dead since an earlier round: not another budget of spins
-    if (threadIdx.x == 0) s_failed = 0;
-    __syncthreads();
-    const unsigned long long round = my_flags[SC_ROUND_WORD];
-    const int r = threadIdx.x;
-    if (r < world) {
-        int spins = 0;
-        while (__hip_atomic_load(my_flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < round) {
-            if (++spins > max_spins) {                              // a peer that never arrives must not hang the GPU: say so and stop
-                s_failed = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(16);
-        }
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (s_failed) {
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(my_flags + SC_GAVE_UP_WORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (st->done != LOOP_DONE) st->done = LOOP_SC_GAVE_UP;
-        }
-        return;
-    }
-    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(recv + (size_t)(round & 1ull) * (size_t)world);
-    unsigned long long *dst = reinterpret_cast<unsigned long long *>(gathered);
-    for (int k = threadIdx.x; k < WORDS * world; k += 256) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    (void)sc_wait_body(my_flags, recv, gathered, world, max_spins, st, &s_failed);
 }
 
 hipError_t launch_sc_push(const ScProposal *send, const ScPeers &peers, unsigned long long *my_flags, int world, int rank, hipStream_t stream)
