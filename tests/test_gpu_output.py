@@ -94,6 +94,42 @@ def test_checkpoint_streamed_from_the_device_equals_the_one_written_from_host_re
     e.close()
 
 
+def test_checkpoint_with_the_cyclosynchrotron_switch_converts_the_resident_list(hip, tmp_path):
+    """saveCheckpoint converts 'k' photons with weight != 0 to 'c' IN the list (mcrat_io.c:896-900), so the next frame's phAbsCyclosynch and the PT
+    column see the converted types: mcrat_host_save_checkpoint(..., ctx, ..., cyclosynchrotron_switch = 1) does it on the device list, and the file
+    holds the converted records -- the same as converting host records and writing those"""
+    from mcrat_amd.host import build_host
+    host = C.CDLL(build_host.build())
+    host.mcrat_host_save_checkpoint.restype = C.c_int
+    host.mcrat_host_save_checkpoint.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p, C.POINTER(PhotonList), C.c_int,
+                                                C.c_int, C.c_int, C.c_int, C.c_int]
+    frame, ph, cfg = synth.config2(n_photons=3000, nzc=8, stokes=1, lumi=1e53)
+    aos = synth.photons_to_aos(ph, hip.PHOTON_DTYPE)
+    aos["type"][::3] = b"k"
+    aos["weight"][::6] = 0.0                                     # a 'k' photon with weight 0 stays 'k'
+    aos["type"][1::7] = b"p"
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    e.set_hydro(frame)
+    e.set_photons_aos(aos)
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    assert host.mcrat_host_save_checkpoint((str(tmp_path / "a") + "/").encode(), 200, 203, 257, 51.4, e.ctx, None, 3000, 3000, 0, 4, 1) == 0
+    got = e.get_photons_aos()
+    want = aos.copy()
+    conv = (want["type"] == b"k") & (want["weight"] != 0)
+    assert conv.sum() > 400 and ((want["type"] == b"k") & (want["weight"] == 0)).sum() > 100
+    want["type"][conv] = b"c"
+    assert np.array_equal(got["type"], want["type"])             # the resident list has changed
+    l = PhotonList(aos.ctypes.data, None, 3000, 0, 3000)          # the host path converts its records in place too
+    assert host.mcrat_host_save_checkpoint((str(tmp_path / "b") + "/").encode(), 200, 203, 257, 51.4, None, C.byref(l), 3000, 3000, 0, 4, 1) == 0
+    assert np.array_equal(aos["type"], want["type"])
+    a, b = (tmp_path / "a" / "mc_chkpt_0.dat").read_bytes(), (tmp_path / "b" / "mc_chkpt_0.dat").read_bytes()
+    head = 4 + 1 + 12 + 8 + 4
+    ra, rb = np.frombuffer(a[head:], dtype=hip.PHOTON_DTYPE), np.frombuffer(b[head:], dtype=hip.PHOTON_DTYPE)
+    assert np.array_equal(ra["type"], want["type"]) and np.array_equal(rb["type"], want["type"])
+    e.close()
+
+
 def test_hdf5_frame_datasets_like_printPhotons(hip, tmp_path):
     from mcrat_amd.host import build_host
     path = build_host.build_h5()

@@ -448,3 +448,21 @@ def test_pool_set_photons_equals_set_photons_list_by_list(hip):
     assert got_stats.frame_scatt_cnt >= want_stats.frame_scatt_cnt      # (the extra list scatters too)
     one.close()
     many.close()
+
+
+def test_profile_totals_count_the_loop_kernels_launches(hip):
+    """mcrat_hip_profile_totals: the summed duration and number of the loop kernel's launches of a profile = 1 context (bench.py's loop-only roofline)"""
+    frame, ph, cfg = synth.config2(n_photons=4000, nzc=8, lumi=1e53)
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=1000, profile=True)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    assert e.profile_totals() == (0.0, 0)
+    e.begin_frame(5, 0.0, 1.0 / frame["fps"])
+    st = e.run(0)
+    ms, launches = e.profile_totals()
+    assert launches >= 1 and 0 < ms < 1e4 and st.step_kernel_launches == launches and abs(st.step_kernel_ms - ms) < 1e-9
+    e.close()
+    plain = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    with pytest.raises(hip.McratHipError):
+        plain.profile_totals()
+    plain.close()
