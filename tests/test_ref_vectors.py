@@ -65,6 +65,16 @@ def test_oracle_replays_mcrats_stream_onto_mcrats_photons(oracle, case):
     assert oracle.photon_loop.tape_pos == want["tape"].size          # MCRaT consumed exactly as many uniforms
     assert tn == pytest.approx(float(want["clock"][0]), rel=1e-12)
     _hold(P.aos, want)
+    if "reductions" in want.files:                                   # G10: phMinMax, phScattStats, averagePhotonEnergy on the end state
+        import ctypes as C
+        L = oracle.lib()
+        L.orc_averagePhotonEnergy.restype = C.c_double
+        mm = [C.c_double() for _ in range(4)]
+        L.orc_phMinMax(C.byref(P.c), *[C.byref(x) for x in mm])
+        mx, mn, avg, ravg = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+        L.orc_phScattStats(C.byref(P.c), C.byref(mx), C.byref(mn), C.byref(avg), C.byref(ravg))
+        got = [x.value for x in mm] + [avg.value, ravg.value, L.orc_averagePhotonEnergy(C.byref(P.c))]
+        assert np.allclose(got, want["reductions"], rtol=1e-9, atol=0) and [mx.value, mn.value] == list(want["scatt_max_min"])
 
 
 @pytest.mark.gpu
@@ -119,3 +129,130 @@ def test_the_fixture_chain_works_with_the_oracle_standing_in_for_the_reference(o
     st2, tn2, _, _ = oracle.photon_loop(c, P2, H, seed=0, time_now=t0, remaining_time=1.0 / frame["fps"], max_iterations=int(want["stats"][0]), tape=want["tape"])
     assert oracle.photon_loop.tape_pos == want["tape"].size and tn2 == float(want["clock"][0])
     _hold(P2.aos, want)
+
+
+# ------------------------------------------------------------------ function-level vectors (G1-G7 of SURVEY.md section 8c; tools/ref_harness/harness_funcs.c)
+def _oracle_functions(oracle, dims, geom, stokes, tape, scatter_at=None, kns_at=None):
+    """What harness_funcs.c computes with MCRaT's functions, computed with the oracle's: the draws come from `tape` -- each scatter / Klein-Nishina
+    case from the position the reference had reached (scatter_at / kns_at), or one after the other when the oracle stands in for the reference"""
+    import ctypes as C
+    L = oracle.lib()
+    d = mi.function_inputs()
+    n = d["boost_beta"].shape[0]
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    c = oracle.make_config(dims, geom, stokes)
+    out = {"switches": np.array([dims, geom, stokes], dtype=np.int64)}
+    L.orc_kleinNishinaCrossSection.restype = C.c_double
+    L.orc_findPhi.restype = C.c_double
+    out["kn_sigma"] = np.array([L.orc_kleinNishinaCrossSection(C.c_double(float(e))) for e in d["kn_eps"]])
+    bp, be = np.zeros((n, 4)), np.zeros((n, 4))
+    so, xx, xy, xphi, mo = d["stokes_in"].copy(), np.zeros((n, 3)), np.zeros((n, 3)), np.zeros(n), d["stokes_in"].copy()
+    for i in range(n):
+        b, q = np.ascontiguousarray(d["boost_beta"][i]), np.ascontiguousarray(d["boost_p"][i])
+        L.orc_lorentzBoost(dp(b), dp(q), dp(bp[i]), b"p")
+        L.orc_lorentzBoost(dp(b), dp(q), dp(be[i]), b"e")
+        v, k, kb = (np.ascontiguousarray(d[key][i]) for key in ("stokes_v", "stokes_k", "stokes_kb"))
+        L.orc_stokesRotation(dp(v), dp(k), dp(kb), dp(so[i]))
+        xv, xr = np.ascontiguousarray(d["xy_v"][i]), np.ascontiguousarray(d["xy_ref"][i])
+        x2, y2 = np.zeros(3), np.zeros(3)
+        L.orc_findXY(dp(xv), dp(xr), dp(xx[i]), dp(xy[i]))
+        L.orc_findXY(dp(xv), dp(v), dp(x2), dp(y2))
+        xphi[i] = L.orc_findPhi(dp(xx[i]), dp(xy[i]), dp(x2), dp(y2))
+        L.orc_mullerMatrixRotation(C.c_double(float(d["muller_theta"][i])), dp(mo[i]))
+    out.update(boost_out_photon=bp, boost_out_electron=be, stokes_out=so, xy_x=xx, xy_y=xy, xy_phi=xphi, muller_out=mo)
+    t = np.ascontiguousarray(tape, dtype=np.float64)
+    r = oracle.Rng()
+    L.orc_rng_init_tape.argtypes = [C.POINTER(oracle.Rng), C.POINTER(C.c_double), C.c_int64]
+    L.orc_rng_init_tape(C.byref(r), dp(t), int(t.size))
+    el, po, sso = np.zeros((n, 4)), d["scatter_ph_in"].copy(), d["scatter_stokes_in"].copy()
+    ok, at = np.zeros(n, dtype=np.int32), np.zeros(n + 1, dtype=np.int64)
+    for i in range(n):
+        if scatter_at is not None:
+            r.tape_pos = int(scatter_at[i])
+        at[i] = r.tape_pos
+        L.orc_singleThermalElectron(dp(el[i]), C.c_double(float(d["scatter_temp"][i])), dp(po[i]), C.byref(r))
+        ok[i] = L.orc_singleScatter(C.byref(c), dp(el[i].copy()), dp(po[i]), dp(sso[i]), C.byref(r))
+    at[n] = r.tape_pos
+    out.update(scatter_electron=el, scatter_ph_out=po, scatter_stokes_out=sso, scatter_occurred=ok, scatter_tape_at=at)
+    th, ph = np.zeros(n), np.zeros(n)
+    kok, kat = np.zeros(n, dtype=np.int32), np.zeros(n + 1, dtype=np.int64)
+    for i in range(n):
+        if kns_at is not None:
+            r.tape_pos = int(kns_at[i])
+        kat[i] = r.tape_pos
+        a, b = C.c_double(), C.c_double()
+        kok[i] = L.orc_kleinNishinaScatter(C.byref(c), C.byref(a), C.byref(b), C.c_double(float(d["kns_p0"][i])), C.c_double(float(d["kns_q"][i])),
+                                           C.c_double(float(d["kns_u"][i])), C.byref(r))
+        th[i], ph[i] = a.value, b.value
+    kat[n] = r.tape_pos
+    assert not r.tape_error
+    out.update(kns_theta=th, kns_phi=ph, kns_ok=kok, kns_tape_at=kat)
+    co = np.zeros((n, 3))
+    for i in range(n):
+        L.orc_mcratCoordinateToHydroCoordinate(C.byref(c), dp(co[i]), *[C.c_double(float(x)) for x in d["coord_xyz"][i]])
+    out["coord_out"] = co
+    out["tape"] = t[:int(kat[n])].copy()
+    return out
+
+
+def _functions_hold(got, want):
+    for k in ("scatter_occurred", "kns_ok", "scatter_tape_at", "kns_tape_at"):
+        assert np.array_equal(got[k], want[k]), k                      # the same decisions from the same number of draws
+    for k in ("kn_sigma", "boost_out_photon", "boost_out_electron", "stokes_out", "xy_x", "xy_y", "xy_phi", "muller_out", "scatter_electron",
+              "scatter_ph_out", "scatter_stokes_out", "kns_theta", "kns_phi", "coord_out"):
+        a, b = np.asarray(got[k], float), np.asarray(want[k], float)
+        scale = np.maximum(np.abs(b), 1e-3 * np.max(np.abs(b), axis=-1, keepdims=True) if b.ndim > 1 else 1e-300)
+        assert np.all((np.abs(a - b) <= 1e-9 * np.maximum(scale, 1e-300)) | (np.isnan(a) & np.isnan(b))), k
+
+
+@pytest.mark.parametrize("case", list(mi.CASES))
+def test_oracle_functions_equal_mcrats_functions(oracle, case):
+    """G1-G7: MCRaT's own kleinNishinaCrossSection, lorentzBoost, findXY / findPhi / mullerMatrixRotation / stokesRotation, singleThermalElectron +
+    singleScatter, kleinNishinaScatter and mcratCoordinateToHydroCoordinate against the oracle's restatements, the random draws replayed case by case"""
+    p = os.path.join(HERE, "golden", "ref_functions_%s.npz" % case)
+    if not os.path.exists(p):
+        pytest.skip("no %s: run tools/ref_harness against an MCRaT checkout with GSL (tools/ref_harness/README.md)" % os.path.basename(p))
+    want = np.load(p)
+    dims, geom, stokes = (int(x) for x in want["switches"])
+    got = _oracle_functions(oracle, dims, geom, stokes, want["tape"], want["scatter_tape_at"], want["kns_tape_at"])
+    _functions_hold(got, want)
+
+
+def test_the_function_fixture_chain_works_with_the_oracle_standing_in(oracle, tmp_path):
+    """(runs everywhere) functions.in -> harness_funcs' output format -> to_npz.py -> the check above, with the ORACLE writing functions_<case>.out in
+    MCRaT's place: keeps the maintainer's tooling from rotting, says nothing about parity with MCRaT"""
+    import struct
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools", "ref_harness"))
+    spec2 = importlib.util.spec_from_file_location("to_npz", os.path.join(ROOT, "tools", "ref_harness", "to_npz.py"))
+    tz = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(tz)
+    mi.write_functions(str(tmp_path))
+    with open(os.path.join(str(tmp_path), "functions.in"), "rb") as f:
+        magic, nk, n = struct.unpack("<3i", f.read(12))
+        eps = np.frombuffer(f.read(8 * nk), dtype="<f8")
+    d = mi.function_inputs()
+    assert magic == mi.FUNCS_MAGIC and np.array_equal(eps, d["kn_eps"]) and n == d["boost_beta"].shape[0]
+    tape = np.random.default_rng(3).random(400000)
+    tape[11::501] = 0.0
+    ref = _oracle_functions(oracle, synth.TWO, synth.CYLINDRICAL, 1, tape)
+    assert ref["scatter_occurred"].sum() > n // 2 and ref["kns_ok"].sum() > n // 4
+    path = os.path.join(str(tmp_path), "functions_cfg2_stokes.out")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<6i", mi.FUNCS_MAGIC, synth.TWO, synth.CYLINDRICAL, 1, nk, n))
+        for k in ("kn_sigma", "boost_out_photon", "boost_out_electron", "stokes_out", "xy_x", "xy_y", "xy_phi", "muller_out", "scatter_electron",
+                  "scatter_ph_out", "scatter_stokes_out"):
+            f.write(np.ascontiguousarray(ref[k], dtype="<f8").tobytes())
+        f.write(ref["scatter_occurred"].astype("<i4").tobytes())
+        f.write(ref["scatter_tape_at"].astype("<i8").tobytes())
+        f.write(np.ascontiguousarray(ref["kns_theta"], dtype="<f8").tobytes())
+        f.write(np.ascontiguousarray(ref["kns_phi"], dtype="<f8").tobytes())
+        f.write(ref["kns_ok"].astype("<i4").tobytes())
+        f.write(ref["kns_tape_at"].astype("<i8").tobytes())
+        f.write(np.ascontiguousarray(ref["coord_out"], dtype="<f8").tobytes())
+        f.write(struct.pack("<q", ref["tape"].size))
+        f.write(np.ascontiguousarray(ref["tape"], dtype="<f8").tobytes())
+    want = tz.read_functions(path)
+    assert list(want["switches"]) == [synth.TWO, synth.CYLINDRICAL, 1]
+    got = _oracle_functions(oracle, synth.TWO, synth.CYLINDRICAL, 1, want["tape"], want["scatter_tape_at"], want["kns_tape_at"])
+    _functions_hold(got, want)

@@ -11,7 +11,8 @@
  *               then int32 nearest_block_index, recalc_properties, type
  * <case>.out:
  *   int32  magic, N, passes_done, frame_scatt_cnt, num_photons_find_new_element, last ph_scatt_index;  double time_now, remaining_time
- *   per photon as above;  int64 tape_n;  double[tape_n]
+ *   per photon as above;  int64 tape_n;  double[tape_n];  double min_r, max_r, min_theta, max_theta (phMinMax), avg_scatt, avg_r (phScattStats),
+ *   avg_energy (averagePhotonEnergy);  int32 max_scatt, min_scatt
  */
 #include "mcrat.h"
 #include "tape_rng.h"
@@ -122,6 +123,15 @@ int main(int argc, char **argv)
     const long long nt = (long long)n_tape;
     wr(&nt, sizeof nt, 1, out);
     wr(tape, sizeof(double), n_tape, out);
+    {   /* G10: the per-frame reductions main() logs (Src/mcrat.c:704,881; Src/mclib.h:25-29) on the end state */
+        double red[7] = {0, 0, 0, 0, 0, 0, 0};
+        int mm[2] = {0, 0};
+        phMinMax(&photon_list, &red[0], &red[1], &red[2], &red[3], fPtr);
+        phScattStats(&photon_list, &mm[0], &mm[1], &red[4], &red[5], fPtr);
+        red[6] = averagePhotonEnergy(&photon_list);
+        wr(red, sizeof(double), 7, out);
+        wr(mm, sizeof(int), 2, out);
+    }
     fclose(out);
     fprintf(stderr, "harness: %d passes, %d scatterings, %lld uniforms recorded, time_now %.17g\n", done, frame_scatt_cnt, nt, time_now);
     tape_recorder_free(rng);

@@ -45,8 +45,58 @@ def write_case(name, outdir):
     print("wrote", os.path.join(outdir, name + ".in"), "(%d cells, %d photons, %d passes)" % (M, N, passes))
 
 
+FUNCS_MAGIC = 0x4D435246
+# the order functions.in holds them in (harness_funcs.c): name -> columns per case (0: one value per case; kn_eps has its own length)
+FUNCTION_INPUTS = (("boost_beta", 3), ("boost_p", 4), ("stokes_v", 3), ("stokes_k", 3), ("stokes_kb", 3), ("stokes_in", 4), ("xy_v", 3), ("xy_ref", 3),
+                   ("muller_theta", 0), ("scatter_temp", 0), ("scatter_ph_in", 4), ("scatter_stokes_in", 4), ("kns_p0", 0), ("kns_q", 0), ("kns_u", 0),
+                   ("coord_xyz", 3))
+
+
+def function_inputs(n=256):
+    """the function-level cases G1-G7 of SURVEY.md section 8c, from a seed: what harness_funcs.c feeds MCRaT's own functions"""
+    rng = np.random.default_rng(20251226)
+    m_el_c = synth.M_EL * synth.C_LIGHT
+    d = {"kn_eps": np.concatenate([np.logspace(-6, 3, 73), [1e-3, np.nextafter(1e-3, 0)]])}
+    beta = rng.normal(size=(n, 3))
+    beta *= (rng.uniform(0, 1, n) ** 0.25 * 0.99995 / np.linalg.norm(beta, axis=1))[:, None]
+    beta[0] = 0.0                                                  # no boost
+    beta[1] = np.array([0, 0, np.sqrt(1 - 1e-4)])                  # gamma = 100
+    p = rng.normal(size=(n, 4)) * 1e-18
+    p[:, 0] = np.linalg.norm(p[:, 1:], axis=1)
+    d.update(boost_beta=beta, boost_p=p)
+    d.update(stokes_v=rng.normal(size=(n, 3)) * 0.4, stokes_k=rng.normal(size=(n, 3)), stokes_kb=rng.normal(size=(n, 3)),
+             stokes_in=np.concatenate([np.ones((n, 1)), rng.uniform(-0.5, 0.5, (n, 3))], axis=1))
+    xy_v, xy_ref = rng.normal(size=(n, 3)), rng.normal(size=(n, 3))
+    xy_ref[:8] = xy_v[:8] * (1 + 1e-9 * rng.normal(size=(8, 1))) + 1e-7 * rng.normal(size=(8, 3))     # near-parallel vectors
+    d.update(xy_v=xy_v, xy_ref=xy_ref, muller_theta=rng.uniform(-np.pi, np.pi, n))
+    temps = np.array([1e5, 5e6, 1e7, 3e7, 1e9])
+    dirs = rng.normal(size=(n, 3))
+    dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    e = 10 ** rng.uniform(-4, 0.5, n) * m_el_c
+    d.update(scatter_temp=temps[np.arange(n) % 5], scatter_ph_in=np.concatenate([e[:, None], e[:, None] * dirs], axis=1),
+             scatter_stokes_in=np.concatenate([np.ones((n, 1)), rng.uniform(-0.4, 0.4, (n, 2)), np.zeros((n, 1))], axis=1))
+    qu = np.array([(0.0, 0.0), (1.0, 0.0), (0.3, -0.4)])
+    d.update(kns_p0=np.array([1e-4, 1e-2, 1.0, 10.0])[np.arange(n) % 4] * m_el_c, kns_q=qu[(np.arange(n) // 4) % 3, 0], kns_u=qu[(np.arange(n) // 4) % 3, 1])
+    xyz = rng.normal(size=(n, 3)) * 1e12
+    xyz[:, 2] = np.abs(xyz[:, 2])
+    d.update(coord_xyz=xyz)
+    return {k: np.ascontiguousarray(v, dtype="<f8") for k, v in d.items()}
+
+
+def write_functions(outdir, n=256):
+    d = function_inputs(n)
+    with open(os.path.join(outdir, "functions.in"), "wb") as f:
+        f.write(struct.pack("<3i", FUNCS_MAGIC, d["kn_eps"].size, n))
+        f.write(d["kn_eps"].tobytes())
+        for k, cols in FUNCTION_INPUTS:
+            assert d[k].shape == ((n, cols) if cols else (n,)), k
+            f.write(d[k].tobytes())
+    print("wrote", os.path.join(outdir, "functions.in"), "(%d + %d cases)" % (d["kn_eps"].size, n))
+
+
 if __name__ == "__main__":
     out = sys.argv[1]
     os.makedirs(out, exist_ok=True)
     for c in CASES:
         write_case(c, out)
+    write_functions(out)
