@@ -157,7 +157,7 @@ typedef struct mcrat_hip_frame_stats {
     double step_kernel_ms;                   /* profile=1: summed duration of step-kernel launches */
     long long step_kernel_launches;
     double event_kernel_ms;                  /* profile=1: summed duration of event-kernel launches */
-    long long table_misses;                  /* TAU_CALCULATION == TABLE: cross-section lookups outside the table (clamped) */
+    long long table_misses;                  /* TAU_CALCULATION == TABLE: lookups outside the table that were clamped (see mcrat_hip_set_hot_cross_section) */
 } mcrat_hip_frame_stats;
 
 typedef struct mcrat_hip_ctx mcrat_hip_ctx;
@@ -401,8 +401,12 @@ int mcrat_hip_inject_photons(mcrat_hip_ctx *ctx, double r_inj, double ph_weight,
  * thermal_table[N_PH_E + 1][N_T + 1] (hot_x_section.c; log10 of the cross section over sigma_T, photon-energy index
  * first), the four bounds are LOG_PH_E_MIN/MAX and LOG_T_MIN/MAX of hot_x_section.h:2-10.  Creating the table
  * (createHotCrossSection, GSL Monte-Carlo integration) stays host-side work of MCRaT; mcrat_host_read_hot_cross_section
- * (mcrat_amd/host) reads the file MCRaT writes.  A lookup outside the table is clamped to its edge and counted in
- * mcrat_hip_frame_stats.table_misses (the reference re-integrates such a cross section on the spot). */
+ * (mcrat_amd/host) reads the file MCRaT writes.  A lookup outside the table gets what the reference's fallback returns where that is closed-form
+ * (interpolateThermalHotCrossSection -> calculateTotalThermalCrossSection, hot_x_section.c:563-599,324-356): below LOG_T_MIN -- every cell colder
+ * than 5.9e5 K with the reference's bounds -- the Klein-Nishina cross section of the photon's comoving energy, or 1 when that is below LOG_PH_E_MIN
+ * too (:337-340).  The remaining cases (a photon energy beyond the table at a tabulated temperature, or a temperature above LOG_T_MAX) are a
+ * 500 000-sample Monte-Carlo integral drawn from the run's generator in the reference; the loop clamps those to the table's edge and counts them in
+ * mcrat_hip_frame_stats.table_misses. */
 int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *ctx, const double *thermal_table, int n_ph_e, int n_t,
                                     double log_ph_e_min, double log_ph_e_max, double log_t_min, double log_t_max);
 

@@ -351,6 +351,15 @@ __device__ __forceinline__ int table_cell(double x0, double dx, int n_cells, dou
     return i;
 }
 
+// kleinNishinaCrossSection (mcrat_scattering.c:597-623) with the reference's own divisions: 2e6-sized terms cancel to O(1) at the 1e-3 seam, so where the
+// value enters an optical depth (below) it is computed in the reference's operation order (kn_cross_section's reciprocals are for the acceptance test)
+__device__ __forceinline__ double kn_cross_section_ieee(double e)
+{
+    if (e >= 1e-3)
+        return (3. / 4.) * (2. / (e * e) + (1. / (2. * e) - (1. + e) / (e * e * e)) * log(1. + 2. * e) + (1. + e) / ((1. + 2. * e) * (1. + 2. * e)));
+    return (1. - 2. * e);
+}
+
 __device__ __forceinline__ double thermal_cross_section(const HydroDev &h, double photon_comv_e, double fluid_temp, bool count = true)
 {
     if (!h.hot_table) return 1.0;
@@ -363,7 +372,15 @@ __device__ __forceinline__ double thermal_cross_section(const HydroDev &h, doubl
     if (x > x_hi) { x = x_hi; out = true; }
     if (!(y >= h.hot_t0)) { y = h.hot_t0; out = true; }
     if (y > y_hi) { y = y_hi; out = true; }
-    if (out && count) atomicAdd(h.table_misses, 1);
+    if (out) {
+        // Outside the table the reference computes the cross section directly (interpolateThermalHotCrossSection's fallback, hot_x_section.c:563-599 ->
+        // calculateTotalThermalCrossSection, :324-356): cold plasma below the table -- every cell under 5.9e5 K with the reference's LOG_T_MIN = -4 -- is
+        // 1 for a photon below the table too and the Klein-Nishina cross section otherwise (:337-340); only the remaining cases (a photon energy
+        // beyond the table at a tabulated temperature) are its 500 000-sample Monte-Carlo integral, which the loop does not run: clamped and counted.
+        const double theta_min = pow(10.0, h.hot_t0), e_min = pow(10.0, h.hot_e0);
+        if (theta < theta_min) return (normalized_photon_comv_e < e_min) ? 1.0 : kn_cross_section_ieee(normalized_photon_comv_e);
+        if (count) atomicAdd(h.table_misses, 1);
+    }
     const int xi = table_cell(h.hot_e0, h.hot_de, h.hot_n_ph_e, x);
     const int yi = table_cell(h.hot_t0, h.hot_dt, h.hot_n_t, y);
     const double xmin = h.hot_e0 + xi * h.hot_de, xmax = h.hot_e0 + (xi + 1) * h.hot_de;

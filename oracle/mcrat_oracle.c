@@ -712,7 +712,14 @@ double orc_getThermalCrossSection(const orc_config *c, double photon_comv_e, dou
     if (x > x_hi) { x = x_hi; out = 1; }
     if (!(y >= c->log_t_min)) { y = c->log_t_min; out = 1; }
     if (y > y_hi) { y = y_hi; out = 1; }
-    if (out) { g_table_misses += 1; if (miss) *miss += 1; }
+    if (out) {
+        /* interpolateThermalHotCrossSection's fallback (hot_x_section.c:563-599): calculateTotalThermalCrossSection (:324-356) -- cold plasma below the
+         * table is 1 / the Klein-Nishina cross section (:337-340); its Monte-Carlo integral for the remaining cases is not restated: clamped, counted */
+        const double theta_min = pow(10.0, c->log_t_min), e_min = pow(10.0, c->log_ph_e_min);
+        if (theta < theta_min) return (normalized_photon_comv_e < e_min) ? 1.0 : orc_kleinNishinaCrossSection(normalized_photon_comv_e);
+        g_table_misses += 1;
+        if (miss) *miss += 1;
+    }
     const int xi = bisect_cell(c->log_ph_e_min, dx, c->n_ph_e, x);
     const int yi = bisect_cell(c->log_t_min, dy, c->n_t, y);
     const double xmin = c->log_ph_e_min + xi * dx, xmax = c->log_ph_e_min + (xi + 1) * dx;

@@ -574,6 +574,50 @@ def test_table_lookups_outside_the_table_are_clamped_and_counted(hip, oracle):
     _compare(out, P.aos)
 
 
+def test_table_lookups_in_cold_plasma_are_the_klein_nishina_cross_section(hip, oracle):
+    """cells colder than the table's lowest temperature (5.9e5 K with the reference's LOG_T_MIN): calculateTotalThermalCrossSection returns the
+    Klein-Nishina cross section of the photon's comoving energy there (hot_x_section.c:337-340) -- engine and oracle do the same, nothing is clamped"""
+    tab = _hot_table()
+    frame, ph, cfg = synth.config1(n_photons=300, n0=16, n1=16)
+    frame = dict(frame, temp=np.full_like(frame["temp"], 2.0e5))
+    c = oracle.make_config(cfg["dimensions"], cfg["geometry"], cfg["stokes"], hot_table=tab)
+    e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], tau_calculation=hip.TAU_TABLE)
+    e.set_hot_cross_section(tab)
+    e.set_hydro(frame)
+    e.set_photons(ph)
+    e.begin_frame(9, 0.0, 0.2)
+    st = e.run(150)
+    out = e.get_photons()
+    P = oracle.OraclePhotons(synth.photons_to_aos(ph, oracle.PHOTON_DTYPE))
+    H = oracle.OracleHydro(frame)
+    rst, _, _, _ = oracle.photon_loop(c, P, H, seed=9, time_now=0.0, remaining_time=0.2, max_iterations=150)
+    assert st.table_misses == rst.table_misses == 0 and st.frame_scatt_cnt == rst.frame_scatt_cnt > 20
+    # 1e-6 here, not 1e-9: the reference's formula takes log(1. + 2. * e) of a photon energy e ~ 1e-3 and multiplies it by (1 + e)/e^3 ~ 1e9
+    # (mcrat_scattering.c:610-615) -- the rounding of 1 + 2e alone is worth 2e-7 of the result, so two comoving energies that agree to 1e-10 (the
+    # engine's and the oracle's do) give cross sections that agree to 1e-7.  Integers (cells, scattering counts, which photon when) are still exact.
+    _compare(out, P.aos, rtol=1e-6)
+    # ... and it IS the Klein-Nishina factor: tau = n sigma_T sigma_KN(e') (1 - beta cos), so tau / tau_DIRECT = sigma_KN(e')
+    d = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    d.set_hydro(frame)
+    d.set_photons(ph)
+    d.begin_frame(9, 0.0, 0.2)
+    d.run(1)
+    t = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], tau_calculation=hip.TAU_TABLE)
+    t.set_hot_cross_section(tab)
+    t.set_hydro(frame)
+    t.set_photons(ph)
+    t.begin_frame(9, 0.0, 0.2)
+    t.run(1)
+    a, b = d.get_photons(), t.get_photons()
+    ok = (np.asarray(a["nearest_block_index"]) >= 0) & (np.asarray(a["num_scatt"]) == np.asarray(ph["num_scatt"]))
+    L = oracle.lib()
+    L.orc_kleinNishinaCrossSection.restype = C.c_double
+    kn = np.array([L.orc_kleinNishinaCrossSection(C.c_double(float(x) / (synth.M_EL * synth.C_LIGHT))) for x in np.asarray(a["comv_p0"])[ok]])
+    assert ok.sum() > 200 and np.allclose(np.asarray(b["total_optical_depth"])[ok] / np.asarray(a["total_optical_depth"])[ok], kn, rtol=1e-6)
+    for x in (e, d, t):
+        x.close()
+
+
 def test_table_mode_needs_its_table(hip):
     frame, ph, cfg = synth.config1(n_photons=100, n0=8, n1=8)
     e = hip.Engine(cfg["dimensions"], cfg["geometry"], 0, tau_calculation=hip.TAU_TABLE)

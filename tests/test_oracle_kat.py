@@ -685,6 +685,15 @@ def test_hot_cross_section_interpolation(oracle):
     got = L.orc_getThermalCrossSection(C.byref(c2), 1e-14 * ME * CL, 1e7, C.byref(m))
     edge = L.orc_getThermalCrossSection(C.byref(c2), 1e-12 * ME * CL, 1e7, None)
     assert m.value == 1 and L.orc_table_misses() == 1 and got == pytest.approx(edge, rel=1e-12)
+    # cold plasma below the table: what calculateTotalThermalCrossSection returns there (hot_x_section.c:337-340), not counted as a miss
+    L.orc_kleinNishinaCrossSection.restype = C.c_double
+    L.orc_reset_table_misses()
+    m = C.c_int(0)
+    for e_norm in (1e-6, 0.3, 40.0):
+        got = L.orc_getThermalCrossSection(C.byref(c2), e_norm * ME * CL, 1e5, C.byref(m))        # theta = 1.7e-5 < 1e-4
+        assert got == L.orc_kleinNishinaCrossSection(C.c_double(e_norm))
+    assert L.orc_getThermalCrossSection(C.byref(c2), 1e-13 * ME * CL, 1e5, C.byref(m)) == 1.0    # the photon below the table too
+    assert m.value == 0 and L.orc_table_misses() == 0
     # DIRECT
     d = oracle.make_config(0, 2, 0)
     assert L.orc_getThermalCrossSection(C.byref(d), 1e-20, 1e7, None) == 1.0
