@@ -676,7 +676,9 @@ class Engine:
             records = np.frombuffer(C.string_at(rec, PHOTON_DTYPE.itemsize * n.value), dtype=PHOTON_DTYPE) if n.value else np.zeros(0, dtype=PHOTON_DTYPE)
         m = o.count
         cols = {f: np.ctypeslib.as_array(getattr(o, f), shape=(m,)).copy() if m else np.empty(0) for f in OUTPUT_COLUMNS}
-        cols["type"] = np.frombuffer(C.string_at(C.cast(o.type, C.c_void_p), m), dtype="S1").copy() if m else np.empty(0, dtype="S1")
+        # (the raw pointer: reading a c_char_p member gives a Python bytes COPY that ends at the first NUL, not the address)
+        type_ptr = C.c_void_p.from_buffer(o, OutputColumns.type.offset).value
+        cols["type"] = np.frombuffer(C.string_at(type_ptr, m), dtype="S1").copy() if m else np.empty(0, dtype="S1")
         return records, cols
 
     def outbox_destroy(self, box):
