@@ -459,7 +459,7 @@ int mcrat_hip_propagate_frame(mcrat_hip_ctx *ctx, double *time_now, double remai
  * the exact mode within Monte-Carlo error (tests/test_gpu_fast_mode.py), single photons do not.  fast_windows is how often
  * per frame a photon's cell and optical depth are refreshed besides after its own scatterings; the reference refreshes them whenever
  * any photon of the rank scatters, i.e. -- for its ranks of about 1000 photons -- as often as the frame has scatterings per 1000 photons.
- * fast_windows <= 0 follows that: the scatterings per 1000 photons of the context's previous FAST frame, between 8 and 128 (32 for the
+ * fast_windows <= 0 follows that: the scatterings per 1000 photons of the context's previous FAST frame, between 8 and 2048 (32 for the
  * first frame); a fixed 8 is biased by about a per cent in frames with tens of scatterings per photon.  Works on a single list, virtual ranks or a rank pool alike (the lists do not matter to it);
  * refuses cyclo-synchrotron contexts and an attached shared clock.  stats: iterations = passes of the longest-running workgroup,
  * photon_steps = free-path draws, frame_scatt_cnt, kn_rejections, num_photons_find_new_element, not_found. */

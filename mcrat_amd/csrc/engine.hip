@@ -2975,7 +2975,9 @@ static void fast_cadence_learn(mcrat_hip_ctx *c, unsigned long long scatterings,
 {
     if (photons <= 0) return;
     const double per_thousand = 1000.0 * (double)scatterings / (double)photons;
-    c->fast_auto_windows = per_thousand < 8.0 ? 8 : (per_thousand > 128.0 ? 128 : (int)(per_thousand + 0.5));
+    // (the upper end: at 7 300 scatterings per thousand photons and frame 128 windows still count 0.14 % too many scatterings, 512 0.05 %, 2048 none --
+    // tools/fast_cadence_gate.py, 1.9e7 events -- and 2048 windows are still faster than the exact loop there)
+    c->fast_auto_windows = per_thousand < 8.0 ? 8 : (per_thousand > 2048.0 ? 2048 : (int)(per_thousand + 0.5));
 }
 
 // MCRAT_HIP_MODE_FAST for the lists of a rank pool, one launch: list r (open[r] != 0) runs its frame of remaining_time[r] with its own seed

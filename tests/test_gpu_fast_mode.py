@@ -243,3 +243,32 @@ def test_fast_mode_in_the_other_builds_of_the_kernels(hip, case):
         z = (me[k][0] - mf[k][0]) / max(1e-300, np.hypot(me[k][1], mf[k][1]))
         assert abs(z) < 4.5, (case, k, me[k], mf[k], z)
     assert st_f.not_found == st_e.not_found == 0 or abs(st_f.not_found - st_e.not_found) <= 0.2 * max(st_e.not_found, 50)
+
+
+def test_learnt_cadence_matches_the_exact_loop_on_a_dense_run_of_ten_million_events(hip):
+    """fast_windows = 0: the context refreshes a photon's cell and optical depth as often per frame as a 1000-photon rank of the exact loop would have
+    (the scatterings of the frame before per thousand photons, 8 ... 2048).  Three frames of the L = 1e54 jet, 1.9e7 scatterings: the mean number of
+    scatterings per photon agrees with the exact loop's within 4 sigma of their Monte-Carlo errors -- and the gate is not vacuous: 8 fixed windows
+    (round 2's default) miss it by more than twenty sigma."""
+    n, frames = 1000000, 3
+    frame, ph, cfg = synth.config2(n_photons=n, lumi=1e54)
+    dt = 1.0 / frame["fps"]
+    mean, err, events = {}, {}, {}
+    for mode, windows in (("exact", None), ("auto", 0), ("fixed-8", 8)):
+        e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], virtual_rank_photons=1000 if mode == "exact" else 0)
+        e.set_hydro(frame)
+        e.set_photons(ph)
+        t, ev = 0.0, 0
+        for f in range(frames):
+            if mode == "exact":
+                t, st = e.propagate_frame(t, (f + 1) * dt - t, 1000 + f)
+            else:
+                t, st = e.propagate_frame_fast(t, (f + 1) * dt - t, 1000 + f, windows)
+            ev += st.frame_scatt_cnt
+        ns = np.asarray(e.get_photons()["num_scatt"]) - np.asarray(ph["num_scatt"])
+        e.close()
+        mean[mode], err[mode], events[mode] = float(ns.mean()), float(ns.std() / np.sqrt(n)), ev
+    assert events["exact"] > 1e7
+    sigma = np.hypot(err["exact"], err["auto"])
+    assert abs(mean["auto"] - mean["exact"]) < 4 * sigma, (mean, err)
+    assert abs(mean["fixed-8"] - mean["exact"]) > 10 * sigma, (mean, err)
