@@ -394,7 +394,7 @@ def main():
                                                         "cfg2 / cfg3 (measured on cfg2: 0.95 ms per frame with one, 0.70 with two, 0.65 with three, 1.0 with four: HIP has "
                                                         "four hardware queues), 1 for cfg5 (measured: slower with two)")
     ap.add_argument("--share-hydro", type=int, default=1, help="the pools read one staged copy of the hydro frame (mcrat_hip_share_hydro)")
-    ap.add_argument("--fast-windows", type=int, default=8, help="FAST mode beside the exact headline: refreshes per frame (0: skip)")
+    ap.add_argument("--fast-windows", type=int, default=0, help="FAST mode beside the exact headline: refreshes per frame (0: the context learns them from the frame before, the unbiased default; < 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--shared-clock-rounds", type=int, default=300,
                     help="also time this many rounds of the one-list-over-all-GPUs mode (0: skip)")
@@ -712,7 +712,7 @@ def main():
     # FAST mode beside the exact headline, never instead of it (mcrat_hip_propagate_frame_mode): the same photons and
     # frame, every photon on its own clock.  Statistically equivalent to the exact loop (tests/test_gpu_fast_mode.py), not sequence-equivalent.
     fast = None
-    if args.mode == "ranks" and args.other_mode and args.fast_windows > 0:
+    if args.mode == "ranks" and args.other_mode and args.fast_windows >= 0:
         try:
             def run_fast(e, k, seed0):
                 ev = ps = 0
@@ -738,10 +738,11 @@ def main():
                 dist.all_reduce(cc, op=dist.ReduceOp.SUM)
                 dt_f, ev_f, ps_f = float(tt.item()), float(cc[0].item()), float(cc[1].item())
             fast = {"mode": "FAST", "note": "the headline's photons and frame with MCRAT_HIP_MODE_FAST: one lane per photon through the whole frame on its "
-                                            "own clock, per-photon keyed random numbers, cell and optical depth refreshed %d times per frame and after each own "
+                                            "own clock, per-photon keyed random numbers, cell and optical depth refreshed %s per frame and after each own "
                                             "scattering; statistically (not sequence-) equivalent to the exact loop: scatterings per photon, spectrum, Q/U agree "
                                             "within Monte-Carlo error (tests/test_gpu_fast_mode.py).  Reported beside the exact headline, not instead of it"
-                                            % args.fast_windows,
+                                            % (("%d times" % args.fast_windows) if args.fast_windows > 0 else
+                                               "as often as the frame before had scatterings per 1000 photons (8 ... 2048)"),
                     "windows": args.fast_windows, "value": ev_f / dt_f, "unit": "scatter-events/s", "n_gpus": world, "steps": steps,
                     "ms_per_step": dt_f * 1e3 / steps, "photon_steps_per_s": ps_f / dt_f, "scatter_events": ev_f}
             if rank == 0 and world == 1 and args.config == "cfg2":
