@@ -33,7 +33,7 @@ names = ["entry->walk (merge block minima, sort shortlist)", "walk start->candid
          "thermal electron", "singleScatter", "boost back + stores", "bookkeeping"]
 d = np.diff(a, axis=1)
 ok = (d >= 0).all(axis=1) & (a[:, 1:] > 0).all(axis=1)
-print("passes with a plain accept on the first candidate: %d of %d; s_memtime ticks (100 MHz -> x10 ns)" % (ok.sum(), len(a)))
+print("passes with a plain accept on the first candidate: %d of %d; s_memtime shader-clock ticks" % (ok.sum(), len(a)))
 for j, nme in enumerate(names):
-    print("  %-55s median %8.0f ticks = %6.2f us" % (nme, np.median(d[ok, j]), np.median(d[ok, j]) * 0.01))
-print("  %-55s median %8.0f ticks = %6.2f us" % ("total entry->end", np.median(a[ok, 7] - a[ok, 0]), np.median(a[ok, 7] - a[ok, 0]) * 0.01))
+    print("  %-55s median %8.0f ticks = %6.2f us" % (nme, np.median(d[ok, j]), np.median(d[ok, j]) / 2280.0))
+print("  %-55s median %8.0f ticks = %6.2f us" % ("total entry->end", np.median(a[ok, 7] - a[ok, 0]), np.median(a[ok, 7] - a[ok, 0]) / 2280.0))
