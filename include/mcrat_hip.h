@@ -569,6 +569,33 @@ int mcrat_hip_pool_set_photons(mcrat_hip_ctx *pool, int count, const int *rank_o
 int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *pool, const int *open, const uint64_t *seeds, const double *time_now, const double *remaining_time);
 int mcrat_hip_pool_frame_stats(mcrat_hip_ctx *pool, mcrat_hip_frame_stats *out /* [n_ranks] */);
 int mcrat_hip_pool_layout(const mcrat_hip_ctx *pool, int *n_ranks, int *slots_per_rank);
+/* The frame queue: every list of the pool through SEVERAL hydro frames in ONE launch.  The reference's ranks are asynchronous processes, each in its
+ * own frame loop (Src/mcrat.c:457-479, :566-934: nothing makes rank A wait for rank B at the end of a hydro frame); one launch per hydro frame does,
+ * and a third of such a launch is the tail of its last lists.  Here the loop kernel's workgroups are persistent and take
+ * (frame, list) items in frame-major order: a list that is through frame f starts f + 1 while others are still in f.  Every list runs exactly the
+ * frames mcrat_hip_pool_begin_frames + mcrat_hip_run would have given it one at a time -- the same seeds, clocks, passes, photons, bit for bit.
+ * All arrays are [n_frames * n_ranks], frame-major (item f * n_ranks + r); a list's open frames must be consecutive (a rank joins at its injection
+ * frame and stays, mcrat.c:566-700).  chain_clock: a list's clock carries over from its previous frame of the call -- time_now = where that frame ended,
+ * remaining_time = frame_end - time_now (mcrat.c:757 with frame_end = (scatt_frame + increment_scatt_frame) / fps) -- and time_now / remaining_time
+ * are used for its first frame only; else every frame takes its own time_now and remaining_time.  restore_each_frame: every frame starts from
+ * the lists as mcrat_hip_snapshot_photons saved them (benchmarks: the same work every frame).  hydro: NULL, or [n_frames] contexts holding the
+ * staged hydro frame of frame f (mcrat_hip_set_hydro / mcrat_hip_ingest_* on them; NULL entry: the pool's own frame) -- a real run stages frame f + 1
+ * for the slab the photons can reach from frame f (phMinMax widened by c / fps) before the launch.  stats: [n_frames * n_ranks], what
+ * mcrat_hip_pool_frame_stats would have reported after each frame (lists that sat a frame out: zeros).  Not with the cyclo-synchrotron switch (its
+ * hook needs the host between passes).  Afterwards the pool is as after the last frame's mcrat_hip_run. */
+typedef struct mcrat_hip_frame_plan {
+    int n_frames;
+    int chain_clock;
+    int restore_each_frame;
+    int reserved;
+    const int      *open;
+    const uint64_t *seeds;
+    const double   *time_now;
+    const double   *remaining_time;
+    const double   *frame_end;            /* chain_clock only */
+    mcrat_hip_ctx *const *hydro;          /* NULL: every frame through the pool's own staged frame */
+} mcrat_hip_frame_plan;
+int mcrat_hip_pool_run_frames(mcrat_hip_ctx *pool, const mcrat_hip_frame_plan *plan, mcrat_hip_frame_stats *stats /* [n_frames * n_ranks] */);
 
 /* function-granular A/B entry points (one kernel each, for parity tests against the
  * reference functions): the findContainingHydroCell + calcMeanFreePath half of an

@@ -98,7 +98,6 @@ struct mcrat_hip_ctx {
     long long tape_n = 0;
     long long *d_tape_cursor = nullptr;   // {cursor, error word} in one 16-byte block
     int fast_auto_windows = 32;       // FAST mode with fast_windows <= 0: the refresh cadence, from what the last FAST frame looked like (fast_cadence)
-    bool rank_pipe = false;           // ... or rank_pipe_kernel (the passes pipelined; lists of up to 1024 slots, DIRECT optical depths)
     bool rank_block_fixed = false;
     double rank_passes_per_list = 0;  // of the last completed frame
     LoopState *d_rstates = nullptr;
@@ -115,6 +114,8 @@ struct mcrat_hip_ctx {
     std::vector<int> snap_lens;       // the lists' lengths when mcrat_hip_snapshot_photons was taken
     RankDesc *d_desc = nullptr;
     RankDesc *h_desc = nullptr;       // pinned
+    void *d_fq = nullptr, *h_fq = nullptr;   // the frame queue's block (mcrat_hip_pool_run_frames): ticket, frames_done, order, items, records; pinned mirror
+    size_t fq_bytes = 0;
     mcrat_hip_ctx *parent = nullptr;  // this context is the view of list view_rank of `parent`
     int view_rank = -1;
     uint32_t view_stream = 0;
@@ -309,6 +310,8 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->d_desc) (void)hipFree(c->d_desc);
     if (c->h_desc) (void)hipHostFree(c->h_desc);
+    if (c->d_fq) (void)hipFree(c->d_fq);
+    if (c->h_fq) (void)hipHostFree(c->h_fq);
     if (c->ph_buf) (void)hipFree(c->ph_buf);
     for (int k = 0; k < 2; ++k) { if (c->pin_ring[k]) (void)hipHostFree(c->pin_ring[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     if (c->ph_snap) (void)hipFree(c->ph_snap);
@@ -2747,22 +2750,12 @@ static int ensure_events(mcrat_hip_ctx *c, size_t n);
 // are too long to keep in LDS, or the frames are optically thin: a thin frame is a dozen passes in which half the photons
 // change cell, i.e. slow-path throughput per list, and there 256 threads per list do better.  The engine cannot know the
 // optical depth before it has run a frame; it looks at the previous one (passes per list).
-// rank_pipe_kernel (kernels.hip; builds with -DMCRAT_RANK_PIPE=1 only -- it measured slower): the event's completion and the next pass
-// overlap.  256-thread lists only; launch_rank_loop falls back to rank_loop_kernel for lists it cannot hold (longer than 1024 slots,
-// TAU_CALCULATION == TABLE) and in builds without it.  MCRAT_HIP_RANK_PIPE=1 asks for it.
-static void choose_rank_pipe(mcrat_hip_ctx *c)
-{
-    c->rank_pipe = false;
-    if (const char *e = getenv("MCRAT_HIP_RANK_PIPE")) c->rank_pipe = atoi(e) != 0 && c->rank_block == 256;
-}
-
 static void choose_rank_block(mcrat_hip_ctx *c)
 {
     if (const char *e = getenv("MCRAT_HIP_RANK_BLOCK")) {
         c->rank_block = (atoi(e) == 128) ? 128 : (atoi(e) == 512 ? 512 : 256);
         c->rank_fuse = c->rank_passes_per_list < 48.0;
         if (const char *f = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = atoi(f) != 0;
-        choose_rank_pipe(c);
         return;
     }
     int cus = 256, dev = 0;
@@ -2782,7 +2775,6 @@ static void choose_rank_block(mcrat_hip_ctx *c)
     // benchmark frames run 2 % faster without it -- cfg3 at 1e7 photons 8.62 -> 8.43 ms; the cylindrical Stokes frame 1.07 -> 0.94 ms with it)
     c->rank_fuse = c->rank_passes_per_list < 48.0 && c->kc.geometry != GEOM_SPHERICAL;
     if (const char *e = getenv("MCRAT_HIP_RANK_FUSE")) c->rank_fuse = atoi(e) != 0;
-    choose_rank_pipe(c);
 }
 
 // rank pool: what the kernel needs to know about every list, from its view
@@ -2816,7 +2808,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
         HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, c->n_ranks, c->rank_stride, longest, c->is_pool ? c->d_desc : nullptr, nullptr, nullptr, batch,
-                                   c->rank_block + (c->rank_fuse ? 1000 : 0) + (c->rank_pipe ? 2000 : 0), c->stream));
+                                   c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
         if (c->cfg.profile) {
             HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
             HIPCHK(c, hipEventSynchronize(c->ev[1]));
@@ -2848,6 +2840,188 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
         if (done && c->n_ranks > 0) c->rank_passes_per_list = (double)it_sum / c->n_ranks;
     }
     if (stats) { stats->step_kernel_ms = c->prof_step_ms; stats->step_kernel_launches = c->prof_launches; stats->table_misses = read_table_misses(c); }
+    return MCRAT_HIP_OK;
+}
+
+// The frame queue (launch.hpp, FrameQueueDev; kernels.hip, rank_loop_kernel): the pool's lists through several hydro frames in one launch.
+extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame_plan *p, mcrat_hip_frame_stats *stats)
+{
+    if (!c || !p || !stats || p->n_frames <= 0 || !p->open || !p->seeds || !p->time_now || !p->remaining_time) return MCRAT_HIP_EINVAL;
+    if (p->chain_clock && !p->frame_end) return MCRAT_HIP_EINVAL;
+    if (!c->is_pool) return MCRAT_HIP_ESTATE;
+    if (!c->have_hydro) return MCRAT_HIP_ESTATE;
+    if (c->cfg.cyclosynchrotron_switch) { c->last_error = "CYCLOSYNCHROTRON_SWITCH is on: its hook needs the host between passes, one frame per call (mcrat_hip_pool_scatter_frames_cyclosynch)"; return MCRAT_HIP_ESTATE; }
+    if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && !c->d_hot_table) {
+        c->last_error = "TAU_CALCULATION == TABLE needs mcrat_hip_set_hot_cross_section first";
+        return MCRAT_HIP_ESTATE;
+    }
+    if (p->hydro)
+        for (int f = 0; f < p->n_frames; ++f)
+            if (p->hydro[f] && p->hydro[f] != c) { c->last_error = "pool_run_frames: frames staged on other contexts are not built yet"; return MCRAT_HIP_EINVAL; }
+    const int R = c->n_ranks, F = p->n_frames;
+    const size_t N = (size_t)R * (size_t)F;
+    if (N > 0x7fffffffull) return MCRAT_HIP_EINVAL;
+    // the lists that take part, each in one run of consecutive frames
+    std::vector<int> first((size_t)R, -1), last((size_t)R, -1);
+    for (int r = 0; r < R; ++r) {
+        for (int f = 0; f < F; ++f) {
+            if (!p->open[(size_t)f * R + r]) continue;
+            if (first[r] < 0) first[r] = f;
+            else if (last[r] != f - 1) { c->last_error = "pool_run_frames: a list's open frames must be consecutive"; return MCRAT_HIP_EINVAL; }
+            last[r] = f;
+        }
+        const mcrat_hip_ctx *v = c->views[(size_t)r];
+        if (first[r] >= 0 && (!v || !v->have_photons)) { c->last_error = "pool_run_frames: a list that does not exist was asked to open a frame"; return MCRAT_HIP_ESTATE; }
+    }
+    if (p->restore_each_frame) {
+        if (!c->ph_snap || c->ph_snap_bytes < c->ph_bytes) { c->last_error = "pool_run_frames: restore_each_frame without a snapshot (mcrat_hip_snapshot_photons)"; return MCRAT_HIP_ESTATE; }
+        for (int r = 0; r < R; ++r)
+            if (first[r] >= 0 && ((size_t)r >= c->snap_lens.size() || c->snap_lens[(size_t)r] != c->views[(size_t)r]->ph.n)) {
+                c->last_error = "pool_run_frames: a list has changed length since the snapshot";
+                return MCRAT_HIP_ESTATE;
+            }
+    }
+    for (int r = 0; r < R; ++r) {
+        const mcrat_hip_ctx *v = c->views[(size_t)r];
+        RankDesc d{};
+        if (first[r] >= 0) { d.len = v->ph.n; d.stream = v->key.stream; d.seed = p->seeds[(size_t)first[r] * R + r]; }
+        c->h_desc[r] = d;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    // the queue's block: [ticket | frames_done R | order N | items N] (uploaded per launch) then the records (read back)
+    const size_t off_done = 64 * FRAME_QUEUE_XCDS, off_order = align_up(off_done + sizeof(unsigned) * (size_t)R, 64), off_items = align_up(off_order + sizeof(int) * N, 64);
+    const size_t off_rec = align_up(off_items + sizeof(FrameItem) * N, 256), bytes = off_rec + sizeof(LoopState) * N;
+    if (c->fq_bytes < bytes) {
+        if (c->d_fq) { HIPCHK(c, hipFree(c->d_fq)); c->d_fq = nullptr; }
+        if (c->h_fq) { HIPCHK(c, hipHostFree(c->h_fq)); c->h_fq = nullptr; }
+        c->fq_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->d_fq, bytes));
+        HIPCHK(c, hipHostMalloc(&c->h_fq, bytes, hipHostMallocDefault));
+        c->fq_bytes = bytes;
+    }
+    char *hb = static_cast<char *>(c->h_fq), *db = static_cast<char *>(c->d_fq);
+    unsigned *h_done = reinterpret_cast<unsigned *>(hb + off_done);
+    int *h_order = reinterpret_cast<int *>(hb + off_order);
+    FrameItem *h_items = reinterpret_cast<FrameItem *>(hb + off_items);
+    LoopState *h_rec = reinterpret_cast<LoopState *>(hb + off_rec);
+    memset(hb, 0, off_rec);
+    for (size_t t = 0; t < N; ++t) {
+        FrameItem &it = h_items[t];
+        it.seed = p->seeds[t]; it.time_now = p->time_now[t]; it.remaining_time = p->remaining_time[t];
+        it.frame_end = p->frame_end ? p->frame_end[t] : 0.0;
+        it.open = p->open[t] ? 1 : 0;
+        it.hydro = 0;
+    }
+    HIPCHK(c, hipMemsetAsync(db + off_rec, 0, sizeof(LoopState) * N, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
+    if (!c->rank_block_fixed) { choose_rank_block(c); c->rank_block_fixed = true; }
+    FrameQueueDev fq{};
+    fq.n_frames = F; fq.restore = p->restore_each_frame ? 1 : 0; fq.chain_clock = p->chain_clock ? 1 : 0;
+    fq.ticket = reinterpret_cast<unsigned *>(db); fq.frames_done = reinterpret_cast<unsigned *>(db + off_done);
+    fq.order = reinterpret_cast<const int *>(db + off_order); fq.items = reinterpret_cast<const FrameItem *>(db + off_items);
+    fq.records = reinterpret_cast<LoopState *>(db + off_rec);
+    fq.snap_delta = p->restore_each_frame ? (long long)(static_cast<char *>(c->ph_snap) - static_cast<char *>(c->ph_buf)) : 0;
+    long long per_frame_cap = 32768;             // passes one list may take per frame and launch (run_ranks' bound on a launch's duration)
+    if (const char *e = getenv("MCRAT_HIP_RANK_LAUNCH_CAP")) per_frame_cap = atoll(e) > 0 ? atoll(e) : per_frame_cap;
+    const int longest = longest_rank_list(c);
+    c->prof_step_ms = 0; c->prof_launches = 0;
+    int xcd_of_class[FRAME_QUEUE_XCDS];                      // which XCD's queue the lists r % 8 == k are in (identity unless an XCD turned out to start no workgroups)
+    for (int x = 0; x < FRAME_QUEUE_XCDS; ++x) xcd_of_class[x] = x;
+    std::vector<unsigned> tickets((size_t)FRAME_QUEUE_XCDS * FRAME_TICKET_STRIDE);
+    for (int attempt = 0;; ++attempt) {
+        // the open items in the order they are taken: per XCD (list r belongs to XCD r % 8: a list never changes L2) frame-major; one workgroup per item,
+        // and as the hardware deals workgroups round-robin over the XCDs, eight times the longest XCD's list of them
+        int n_open = 0, longest_xcd = 0;
+        for (int x = 0; x < FRAME_QUEUE_XCDS; ++x) {
+            fq.order_off[x] = n_open;
+            for (size_t t = 0; t < N; ++t)
+                if (h_items[t].open && xcd_of_class[(int)(t % (size_t)R) % FRAME_QUEUE_XCDS] == x) h_order[n_open++] = (int)t;
+            longest_xcd = std::max(longest_xcd, n_open - fq.order_off[x]);
+        }
+        fq.order_off[FRAME_QUEUE_XCDS] = n_open;
+        const int n_groups = FRAME_QUEUE_XCDS * longest_xcd;
+        HIPCHK(c, hipMemcpyAsync(db, hb, off_rec, hipMemcpyHostToDevice, c->stream));
+        if (c->cfg.profile) {
+            int rc = ensure_events(c, 2);
+            if (rc) return rc;
+            HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+        }
+        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, longest, c->d_desc, nullptr, nullptr, per_frame_cap,
+                                   c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream, &fq, n_groups));
+        if (c->cfg.profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        HIPCHK(c, hipMemcpyAsync(tickets.data(), db, sizeof(unsigned) * tickets.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_done, db + off_done, sizeof(unsigned) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h_rec, db + off_rec, sizeof(LoopState) * N, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->cfg.profile) {
+            float ms = 0;
+            HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
+            c->prof_step_ms += ms;
+            c->prof_launches += 1;
+        }
+        bool all = true;
+        for (int r = 0; r < R; ++r) {
+            if (h_done[r] & FRAME_STALLED) h_done[r] &= ~FRAME_STALLED;            // (the frame that ran into the pass limit = the frames before it are through)
+            all = all && (first[r] < 0 || (int)h_done[r] == last[r] + 1);
+        }
+        if (all) break;
+        {   // a device whose workgroups report fewer XCDs than eight (another partition mode): the queues nobody drew from move to XCDs that exist
+            int alive[FRAME_QUEUE_XCDS], n_alive = 0;
+            for (int x = 0; x < FRAME_QUEUE_XCDS; ++x)
+                if (tickets[(size_t)x * FRAME_TICKET_STRIDE] > 0) alive[n_alive++] = x;
+            if (n_alive == 0) { c->last_error = "pool_run_frames: no workgroup drew an item"; return MCRAT_HIP_EHIP; }
+            for (int k = 0; k < FRAME_QUEUE_XCDS; ++k)
+                if (tickets[(size_t)xcd_of_class[k] * FRAME_TICKET_STRIDE] == 0) xcd_of_class[k] = alive[k % n_alive];
+        }
+        if (attempt >= 1 << 16) { c->last_error = "pool_run_frames: lists that make no progress"; return MCRAT_HIP_EHIP; }
+        // Lists whose frame ran into the launch's pass limit (and their later frames, whose workgroups gave up): their finished frames leave the queue, the
+        // frame in progress goes on from its LoopState (open = 2), the rest as planned -- with the clock the host now knows.
+        memset(hb, 0, off_done);                                                   // ticket
+        for (int r = 0; r < R; ++r) {
+            if (first[r] < 0) continue;
+            const int nf = std::max((int)h_done[r], first[r]);                     // the first frame that is not complete
+            for (int f = first[r]; f <= last[r]; ++f) {
+                FrameItem &it = h_items[(size_t)f * R + r];
+                if (f < nf) { it.open = 0; continue; }
+                if (f > nf) continue;
+                const LoopState &rec = h_rec[(size_t)f * R + r];
+                if (rec.iterations > 0 && !rec.done) it.open = 2;
+                else if (p->chain_clock && f > first[r]) {                         // (its previous frame has left the queue: the clock it would have read there)
+                    it.time_now = h_rec[(size_t)(f - 1) * R + r].time_now;
+                    it.remaining_time = it.frame_end - it.time_now;
+                }
+            }
+        }
+    }
+    for (size_t t = 0; t < N; ++t) {
+        const int r = (int)(t % (size_t)R);
+        if (p->open[t]) state_to_stats(h_rec[t], c->views[(size_t)r]->ph.n, &stats[t]);
+        else memset(&stats[t], 0, sizeof stats[t]);
+    }
+    // the pool as after the last frame's mcrat_hip_run
+    long long it_sum = 0;
+    int lists = 0;
+    for (int r = 0; r < R; ++r) {
+        if (first[r] < 0) continue;
+        mcrat_hip_ctx *v = c->views[(size_t)r];
+        const size_t t = (size_t)last[r] * R + r;
+        if (v->graph_exec && v->key.seed != p->seeds[t]) drop_graph(v);
+        v->key.seed = p->seeds[t];
+        v->find_switch = 1;
+        v->pending_applied = false;
+        v->rank_current = true;
+        v->frame_open = true;
+        v->prof_step_ms = v->prof_event_ms = 0;
+        v->prof_launches = 0;
+        c->h_rstates[r] = h_rec[t];
+        it_sum += h_rec[t].iterations;
+        lists += 1;
+    }
+    if (lists > 0) c->rank_passes_per_list = (double)it_sum / lists;
+    c->frame_open = true;
+    c->rank_block_fixed = false;
+    stats[0].step_kernel_ms = c->prof_step_ms;               // (profile = 1: the launch's duration, on the first item)
+    stats[0].step_kernel_launches = c->prof_launches;
     return MCRAT_HIP_OK;
 }
 

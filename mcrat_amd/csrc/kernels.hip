@@ -16,7 +16,9 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 #include "device_types.hpp"
 #include "launch.hpp"
@@ -249,7 +251,7 @@ __device__ __forceinline__ double fast_one(const PH &ph, const HydroDev &hy, int
                 }
             }
         }
-        if (queue == 1) bucket = phys::grid_bucket(hy.grid, a0, a1, a2);        // where the slow path will search
+        if (queue == 1) bucket = phys::grid_bucket_of<DIMS>(hy.grid, a0, a1, a2);        // where the slow path will search
         if (queue) return INFINITY;
         if (MC_DIAG(DIAG_SKIP_SAMPLE)) return 1e-3 + (double)i * 1e-12 + (double)(bits & 1) * 0.0 + ntau * 0.0;
         return sample_free_time(ntau, bits);
@@ -263,7 +265,7 @@ __device__ __forceinline__ double fast_one(const PH &ph, const HydroDev &hy, int
 // rounds: {photon columns, bucket range} then {bucket entries | the cell's fluid record}.
 // `bits` is the slot's free-path draw of this pass: phase 1 has computed the pair's Philox block anyway (one block serves two
 // slots) and hands the 64 bits over -- for queued slots through the slot's time_to_scatter entry, which this function overwrites.
-// (LOGS: `bits` is not the draw but the bit pattern of log(u) of the draw -- rank_pipe_kernel computes the logarithms of a pass ahead of time)
+// (LOGS: `bits` is not the draw but the bit pattern of log(u) of the draw -- rank_loop_kernel's waves that sit out the event walk compute a pass's logarithms ahead of time)
 __device__ __forceinline__ double free_time_from_log(double ntau, double log_u) { return div_by_c(ntau * log_u); }   // = sample_free_time, its log at hand
 
 template <int DIMS, int GEOM, bool LOGS = false, class PH>
@@ -348,7 +350,7 @@ __device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int
 // Takes a slot only when the bucket's hint settles it (one 96-B entry, the cell provably the only one that holds the point:
 // find_in_bucket); todo[k] stays set for the others -- list walks, points outside every cell -- and the caller falls back to slow_one.
 // (DIRECT optical depths only: the TABLE build keeps slow_one.)
-// `probe` (rank_pipe_kernel's optically thin passes): the caller has NOT tested the slots against their cached cells -- the entry the hint
+// `probe` (rank_loop_kernel's fused passes): the caller has NOT tested the slots against their cached cells -- the entry the hint
 // names settles that too.  A point well inside the hinted cell is in no other cell (device_types.hpp, BucketDir), so if that cell is the
 // cached one the slot has stayed (checkInBlock, geometry.c:394, would have said so) and nothing is stored for it (probe->same[k] set), and
 // if it is another one the slot has left its cell (mclib.c:507,528).  This saves every slot the 32-B gather of its cached cell's geometry.
@@ -380,13 +382,13 @@ __device__ __forceinline__ void relocate_lockstep(const PH &ph, const HydroDev &
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const unsigned hint = (d[k].hints >> (4 * ((code[k] >> GRID_CODE_OCT_SHIFT) & 7))) & 15u;
-        take[k] = take[k] && d[k].n > 0 && (code[k] & GRID_CODE_HINT_OK) && hint != GRID_NO_HINT;
+        take[k] = take[k] & (d[k].n > 0) & ((code[k] & GRID_CODE_HINT_OK) != 0) & (hint != GRID_NO_HINT);
         f[k] = g.cells[take[k] ? d[k].e0 + (int)hint : 0];
     }
     double comv[K][4], tau[K], ntau[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        take[k] = take[k] && phys::well_in_fat_cell<DIMS>(f[k], a0[k], a1[k], a2[k]);
+        take[k] = take[k] & phys::well_in_fat_cell<DIMS>(f[k], a0[k], a1[k], a2[k]);
         double cphi, sphi;
         phys::relocation_azimuth<DIMS, GEOM>(r0[k], r1[k], a0[k], cphi, sphi);  // photon azimuth, mclib.c:549-552
         double beta[3];
@@ -397,6 +399,11 @@ __device__ __forceinline__ void relocate_lockstep(const PH &ph, const HydroDev &
         ntau[k] = -phys::rcp_nr(tau[k]);
         t[k] = LOGS ? free_time_from_log(ntau[k], __longlong_as_double((long long)bits[k])) : sample_free_time(ntau[k], bits[k]);
     }
+    // (the K chains above are meant to run side by side: without this the compiler sinks each slot's arithmetic into that slot's `take` branch
+    // below and the chains run one after the other)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+        asm volatile("" : "+v"(comv[k][0]), "+v"(comv[k][1]), "+v"(comv[k][2]), "+v"(comv[k][3]), "+v"(tau[k]), "+v"(ntau[k]), "+v"(t[k]));
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         if (!take[k]) continue;
@@ -1037,6 +1044,7 @@ struct RankLayout {
     const RankDesc *desc;
     CsFrame *cs;          // CYCLOSYNCHROTRON_SWITCH on: per list, where a pass the hook of mcrat.c:786-808 must look at parks the list
     const CsHookArgs *hook;   // ... or, when given (and the kernel built with CSH), what the hook needs to run right there, inside the loop
+    FrameQueueDev fq;     // n_frames > 0: persistent workgroups take (frame, list) items from a ticket (launch.hpp)
 };
 
 // Four lists per CU.  Measured by varying the number of lists on a dense jet: a workgroup alone on its CU needs 25 us per
@@ -1073,13 +1081,41 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's r and -1/tau columns when it fits (lds_slots >= n)
     __shared__ LoopState st;
     __shared__ EventSharedT<RANK_BLOCK> sh;
-    __shared__ int s_qn, s_sln, s_nrel, s_hook, s_len;
+    __shared__ int s_qn, s_sln, s_nrel, s_hook, s_len, s_item;
     __shared__ int s_qb[RANK_QCAP];
     // the slow-path queue shares memory with the event walk's sorted list: the queue is empty before the list is written
     static_assert(sizeof(sh.list) >= sizeof(int) * RANK_QCAP, "queue fits into the sorted-list storage");
     int *const s_q = reinterpret_cast<int *>(sh.list);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int rank = blockIdx.x;
+#ifdef MCRAT_NO_FRAME_QUEUE
+    const bool queued = false;                               // (A/B build: what carrying the queue costs a launch that does not use it)
+#else
+    const bool queued = lay.fq.n_frames > 0;
+#endif
+    // One list through one frame: the whole loop of mcrat.c:761-851.  Without a queue the workgroup does this once, for list blockIdx.x, from the
+    // LoopState begin_frame left in states[]; with one (launch.hpp, FrameQueueDev) for one (frame, list) item after the other, each from the item's seed and clock.
+    // every column of one list copied between the live lists and a buffer laid out like them (the snapshot; a frame's capture): slot i of a column
+    // at byte offset +from is read, +to written.  All 24 double columns of a slot are loaded before the first is stored: a workgroup's copy is
+    // a handful of memory round trips, not one per column and 256 slots.
+    auto copy_list_columns = [&](const PhotonDev &g, int base, int n, long long from, long long to) {
+        for (int il = tid; il < n; il += RANK_BLOCK) {
+            const size_t i = (size_t)base + il;
+            double v[N_DOUBLE_COLS];
+#pragma unroll
+            for (int k = 0; k < N_DOUBLE_COLS; ++k)
+                v[k] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(g.r0 + (size_t)k * g.col_stride + i) + from);
+            const int ci = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(g.idx + i) + from);
+            const unsigned char cf = *reinterpret_cast<const unsigned char *>(reinterpret_cast<const char *>(g.flags + i) + from);
+            const char ct = *(reinterpret_cast<const char *>(g.type + i) + from);
+#pragma unroll
+            for (int k = 0; k < N_DOUBLE_COLS; ++k)
+                *reinterpret_cast<double *>(reinterpret_cast<char *>(g.r0 + (size_t)k * g.col_stride + i) + to) = v[k];
+            *reinterpret_cast<int *>(reinterpret_cast<char *>(g.idx + i) + to) = ci;
+            *reinterpret_cast<unsigned char *>(reinterpret_cast<char *>(g.flags + i) + to) = cf;
+            *(reinterpret_cast<char *>(g.type + i) + to) = ct;
+        }
+    };
+    auto list_frame = [&](const int rank, const int item) __attribute__((always_inline)) {
     const int base = rank * lay.stride;
     int n = min(lay.stride, lay.n_total - base);
     RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
@@ -1089,14 +1125,41 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         rk.seed = d.seed;
         rk.stream = d.stream;
     }
+    if (item >= 0) rk.seed = lay.fq.items[item].seed;
+    // (open == 2: the frame was begun by an earlier launch that ran into its pass limit -- the list goes on from its LoopState, as without a queue)
+    const bool fresh = item >= 0 && lay.fq.items[item].open == 1;
     // a pool list's *scattered_ph_index is list-local between launches (its view reads it like a context of its own)
     const int idx_shift = lay.desc ? base : 0;
-    if (tid == 0) {
+    if (fresh) {                                             // a new frame (cf. init_states_multi_kernel, staging.hip; mcrat.c:754-758)
+        static_assert(sizeof(LoopState) / sizeof(int) <= 64, "one wavefront clears the state");
+        if (tid < (int)(sizeof(LoopState) / sizeof(int))) reinterpret_cast<int *>(&st)[tid] = 0;
+        __syncthreads();
+        if (tid == 0) {
+            double t_now = lay.fq.items[item].time_now, rem = lay.fq.items[item].remaining_time;
+            if (lay.fq.chain_clock && item >= lay.n_ranks && lay.fq.items[item - lay.n_ranks].open) {
+                t_now = states[rank].time_now;               // the clock its previous frame of this launch ended on
+                rem = lay.fq.items[item].frame_end - t_now;
+            }
+            st.remaining_time = rem;
+            st.time_now = t_now;
+            st.done = !(rem > 0);
+            st.skip_idx = -1;
+            st.last_scattered_index = -1;
+            st.force_relocate = 1;                           // mcrat.c:756
+        }
+    } else if (tid == 0) {
         st = states[rank];
         if (st.last_scattered_index >= 0) st.last_scattered_index += idx_shift;
     }
     __syncthreads();
-    if (st.done || n <= 0) return;
+    if (st.done || n <= 0) {
+        if (item >= 0 && tid == 0) { states[rank] = st; lay.fq.records[item] = st; }
+        return;
+    }
+    if (fresh && lay.fq.restore) {                           // the frame starts from the snapshot of the list (mcrat_hip_restore_photons, for this list)
+        copy_list_columns(gph, base, n, lay.fq.snap_delta, 0);
+        __syncthreads();
+    }
     // Cyclo-synchrotron lists double when they run out of null slots (photons.c:112-121), so half of a list can be null slots behind the
     // last photon.  A null slot takes no part in a pass -- no cell, never the earliest candidate, time_to_scatter = 1e12/c every time
     // (mclib.c:620,684) -- so the passes of this launch run over the slots up to the last one that is NOT such a settled null slot (a fresh
@@ -1316,8 +1379,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
 #pragma unroll
                         for (int k = 0; k < NS; ++k) {
                             same[k] = false;
-                            cand[k] = live[k] && (fl[k] & FLAG_VALID) && dom[k] && cell[k] != -1;
-                            if (cand[k]) code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]);
+                            cand[k] = live[k] & ((fl[k] & FLAG_VALID) != 0) & dom[k] & (cell[k] != -1);
+                            if (cand[k]) code[k] = phys::grid_bucket_of<DIMS>(hy.grid, a0[k], a1[k], a2[k]);
                             todo[k] = cand[k];
                             any_todo = any_todo || cand[k];
                         }
@@ -1351,14 +1414,14 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
                     } else {
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
-                        inb[k] = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) && (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
-                        if constexpr (DIMS == DIM_THREE) inb[k] = inb[k] && (2 * fabs(a2[k] - cg2[k].c2) - cg2[k].s2 <= 0);
+                        inb[k] = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) & (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
+                        if constexpr (DIMS == DIM_THREE) inb[k] = inb[k] & (2 * fabs(a2[k] - cg2[k].c2) - cg2[k].s2 <= 0);
                         if (MC_DIAG(DIAG_SKIP_INCELL)) inb[k] = true;
                         qd[k] = 0; code[k] = -1;
                         if (!live[k] || !(fl[k] & FLAG_VALID) || !(dom[k] && cell[k] != -1)) continue;
                         if (force || !inb[k]) qd[k] = 1;                              // mclib.c:507,528
                         else if ((fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;   // mclib.c:668
-                        if (qd[k] == 1) { code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]); n_rel += 1; }
+                        if (qd[k] == 1) { code[k] = phys::grid_bucket_of<DIMS>(hy.grid, a0[k], a1[k], a2[k]); n_rel += 1; }
                     }
 #pragma unroll
                     for (int k = 0; k < NS; ++k) {
@@ -1530,582 +1593,69 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             st.nseg = 0; st.skip_idx = -1;
             if (st.last_scattered_index >= 0) st.last_scattered_index -= idx_shift;
             states[rank] = st;
+            if (item >= 0) lay.fq.records[item] = st;
+        }
+        // the list as this frame leaves it, for the frame's outputs (printPhotons, saveCheckpoint: mcrat.c:881-906), before its next frame moves it on
+        if (item >= 0 && lay.fq.capture_delta != 0 && item / lay.n_ranks < lay.fq.n_frames - 1 && st.done == LOOP_DONE) {
+            __syncthreads();
+            copy_list_columns(gph, base, n, 0, lay.fq.capture_delta + (long long)(item / lay.n_ranks) * lay.fq.capture_stride);
         }
     }
-}
+    };   // list_frame
 
-// ------------------------------------------------------------------ virtual ranks, the passes pipelined (round 3; -DMCRAT_RANK_PIPE=1 only)
-// MEASURED SLOWER than rank_loop_kernel and therefore not part of the product build ("the passes pipelined"): a list's
-// pass took 29.5 us against 26.0 us (1025 lists of 976 photons, cfg2, lives of the lists on the 100 MHz clock, tools/diag_pipe.py).  What the
-// walk's completion hides is less than what phase 1 loses by running on three wavefronts in three rounds of 64 slot pairs instead of on four
-// in two, and u0-2 coming from L2 instead of LDS puts one more memory latency into every round.  Kept for the next attempt (it is parity-green
-// against the oracle, tests/test_gpu_pool.py with MCRAT_HIP_RANK_PIPE=1 on such a build); the rest of this comment is the design.
-#if defined(MCRAT_RANK_PIPE) && MCRAT_RANK_PIPE
-// rank_loop_kernel runs a list's passes strictly one after the other: phase 1 (every slot: pending advance, in-cell test, re-location, free
-// path), the leftovers, the minimum, the sort -- then ONE wavefront walks the event (photonEvent, mclib.c:1107-1356) while the other three
-// wait at a barrier: a quarter of a list's frame.  Nothing in the next pass depends on what the scattered photon looks like afterwards: the
-// other slots need the pass's time segments (mclib.c:1138,1332) and which slot to leave alone, and both are known the moment the
-// Klein-Nishina test accepts a candidate (kleinNishinaScatter, mcrat_scattering.c:509-523) -- the sampling of the angles, the Compton shift,
-// Fano's matrix and the boosts back cannot fail.  So the walk is cut there (scatter_decide / scatter_finish):
-//   wavefront 0           walks the sorted candidates as far as an accepted test, publishes {segments, scattered slot, pass number, shortlist
-//                         threshold} (PipeNext) and meets the others at barrier A; then completes the scattering, stores it, takes the
-//                         scattered slot through ITS phase 1 of the next pass, and joins the others
-//   wavefronts 1-3        meanwhile compute the next pass's Philox blocks and log(u) for every slot (the key {pass + 1, slot} does not depend
-//                         on the event) into LDS; after barrier A they run phase 1 of the next pass for every other slot, 64 slot pairs at a
-//                         time from a shared counter
-// so a pass costs {decision half of the walk} + {phase 1 without its draws, on three to four wavefronts} + {minimum, sort}, instead of the
-// sum of everything.  The arithmetic of every slot and of the event is that of rank_loop_kernel / step_kernel + event_kernel -- the same
-// device functions in the same order -- so a list's photons are bit for bit what those kernels give (tests/test_gpu_parity.py,
-// tests/test_gpu_pool.py run both).
-// LDS per list: r, -1/tau, cell, flags (37 B per slot) and the logarithms (8 B); u0-2 are read from L2 once per pass (no dependent
-// chain hangs on them).  Lists of up to 1024 slots, two per CU.  Not for cyclo-synchrotron lists (their hook needs the pass complete) or
-// TAU_CALCULATION == TABLE (rank_loop_kernel keeps those).
-constexpr unsigned LIST_MASK_PIPE = colbit(COL_R0) | colbit(COL_R1) | colbit(COL_R2) | colbit(COL_NTAU) | COLBIT_IDX | COLBIT_FLAGS;
-constexpr int PIPE_BLOCK = 256;
-constexpr int PIPE_QCAP = 512;           // leftovers of a pass: slots the bucket hints do not settle, slots whose tau alone is stale, and in
-                                         // passes in which few slots change cell (dense frames) those that do
-constexpr int rank_pipe_lds_bytes_per_slot() { return (int)ListCols<LIST_MASK_PIPE>::lds_bytes_per_slot + (int)sizeof(double); }
-
-struct alignas(16) PipeNext {            // what the walk of pass k tells phase 1 of pass k + 1
-    double seg[MAX_SEG];                 // the pass's advance segments (mclib.c:1138,1332), applied to every moving slot but `skip`
-    double t_cut;                        // shortlist threshold of pass k + 1
-    unsigned long long iter;             // its number (the RNG counter)
-    int nseg, skip;                      // skip: the scattered slot, advanced by the event itself (-1: none)
-    int go;                              // 0: the frame (or this launch's share of passes) is over
-    int force;                           // pass k + 1 is the forced re-location pass of a new frame (mcrat.c:756)
-    int thin;                            // most slots changed cell in the last pass: pass k + 1 looks every slot up in the grid first (LockstepProbe)
-    int pad;
-};
-
-// the K smallest (t, i) of a wavefront's lanes -> out[0..TOPK) (ascending); every lane returns with the same out
-__device__ __forceinline__ void wave_topk(TopK &mine, Cand (&out)[TOPK])
-{
-#pragma unroll
-    for (int r = 0; r < TOPK; ++r) {
-        double ht = mine.t[0];
-        int hi = mine.i[0];
-        wave_min_pair(ht, hi);
-        if (mine.i[0] == hi && mine.t[0] == ht) mine.pop();
-        out[r].t = ht; out[r].idx = hi; out[r].pad = 0;
-    }
-}
-
-template <int DIMS, int GEOM, bool STOKES>
-__global__ __launch_bounds__(PIPE_BLOCK, RANK_WAVES_PER_SIMD) void rank_pipe_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
-                                                                                RankLayout lay, long long max_passes, int lds_slots)
-{
-    static_assert(!TABLE_MODE, "DIRECT optical depths (relocate_lockstep)");
-    constexpr int BLOCK = PIPE_BLOCK;
-    extern __shared__ __align__(16) unsigned char s_dyn[];
-    __shared__ LoopState st;
-    __shared__ PipeNext nx;
-    __shared__ Cand s_raw[BLOCK], s_list[BLOCK];           // shortlist of the pass being built / sorted shortlist of the pass being walked
-    __shared__ double s_wt[BLOCK / 64];
-    __shared__ int s_wi[BLOCK / 64];
-    __shared__ int s_q[PIPE_QCAP], s_qb[PIPE_QCAP];
-    __shared__ int s_qn, s_sln, s_chunk, s_nrel;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rank = blockIdx.x;
-    const int base = rank * lay.stride;
-    int n = min(lay.stride, lay.n_total - base);
-    RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
-    if (lay.desc) {
-        const RankDesc d = lay.desc[rank];
-        n = min(n, d.len);
-        rk.seed = d.seed;
-        rk.stream = d.stream;
-    }
-    const int idx_shift = lay.desc ? base : 0;             // a pool list's *scattered_ph_index is list-local between launches
-    if (tid == 0) {
-        st = states[rank];
-        if (st.last_scattered_index >= 0) st.last_scattered_index += idx_shift;
-    }
-    __syncthreads();
-    if (st.done || n <= 0) return;
-
-    using Cols = ListCols<LIST_MASK_PIPE>;
-    const Cols ph(gph, s_dyn, lds_slots, base);
-    double *const s_lg = reinterpret_cast<double *>(s_dyn + (size_t)lds_slots * Cols::lds_bytes_per_slot);   // log(u) of the pass's draws, per slot
-    for (int il = tid; il < n; il += BLOCK) {
-        const int i = base + il;
-        ph.r0(i) = ph.template gcol<COL_R0>(i); ph.r1(i) = ph.template gcol<COL_R1>(i); ph.r2(i) = ph.template gcol<COL_R2>(i);
-        ph.ntau(i) = ph.template gcol<COL_NTAU>(i);
-        ph.idx(i) = ph.g_idx_at(i); ph.flags(i) = ph.g_flags_at(i);
-    }
-    if (tid == 0) {
-        nx.nseg = st.nseg; nx.skip = st.skip_idx; nx.iter = st.iteration; nx.t_cut = st.t_cut; nx.go = 1; nx.force = st.force_relocate;
-        nx.thin = 1; nx.pad = 0;                             // (the first pass of a launch: a new frame's forced pass, or unknown)
-        for (int k = 0; k < MAX_SEG; ++k) nx.seg[k] = st.seg[k];
-        s_qn = 0; s_sln = 0; s_chunk = 0; s_nrel = 0;
-    }
-    __syncthreads();
-
-#ifdef MCRAT_DIAG
-    // shader-clock sums per list (diagnostic build): set A (g_diag bit 512 clear), by the walker's lane 0: [0] leftovers + minimum + sort, [1] decision half
-    // of the walk, [2] its wait at barrier A, [3] completion + the scattered slot, [4] its share of phase 1, [5] its wait at barrier B; by lane 0 of
-    // wavefront 1: [6] the draws, [7] its phase 1.  Set B (bit 512 set), lane 0 of wavefront 1 inside phase1_pair: [0] loads + advance, [1] cell record +
-    // coordinates + decisions, [2] re-location, [3] stores + shortlist, [4] pairs taken
-    __shared__ long long s_dg[8];
-    if (tid < 8) s_dg[tid] = 0;
-    long long dg_t = 0;
-    const bool dg_inner = (g_diag & 512) != 0;
-    const bool dg_clock = (g_diag & 1024) != 0;          // set C: [0] start and [1] end of the list on the 100 MHz clock, [2] its length in shader-clock ticks
-    const long long dg_real0 = (long long)__builtin_amdgcn_s_memrealtime(), dg_tick0 = (long long)__builtin_amdgcn_s_memtime();
-#define PIPE_T0() do { if (!dg_clock) { __builtin_amdgcn_sched_barrier(0); dg_t = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define PIPE_TICK(cond, k) do { if (!dg_clock) { __builtin_amdgcn_sched_barrier(0); const long long n_ = (long long)__builtin_amdgcn_s_memtime(); if (cond) s_dg[k] += n_ - dg_t; dg_t = n_; __builtin_amdgcn_sched_barrier(0); } } while (0)
-#define PIPE_TICK_W(cond, k) do { __builtin_amdgcn_s_waitcnt(0); PIPE_TICK(cond, k); } while (0)
-#else
-#define PIPE_T0() do { } while (0)
-#define PIPE_TICK(cond, k) do { } while (0)
-#define PIPE_TICK_W(cond, k) do { } while (0)
-#endif
-    const int npairs = (n + 1) >> 1;
-    // log(u) of every slot's draw of pass `iter` (mclib.c:675): one Philox block per slot pair, as the draw order prescribes (rng.hpp)
-    auto precompute = [&](unsigned long long iter, int first, int step) {
-        for (int pair = first; pair < npairs; pair += step) {
-            const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)pair, RNG_FREEPATH, rk.stream);
-            const uint64_t b0 = (uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32), b1 = (uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32);
-            s_lg[2 * pair] = log(bits_to_uniform_pos(b0));
-            if (2 * pair + 1 < n) s_lg[2 * pair + 1] = log(bits_to_uniform_pos(b1));
-        }
-    };
-    MinCand best;
-    int relocated = 0, not_found = 0, n_rel = 0;
-    auto shortlist_lds = [&](double t, int i) {
-        const int pos = atomicAdd(&s_sln, 1);
-        if (pos < BLOCK) { s_raw[pos].t = t; s_raw[pos].idx = i; s_raw[pos].pad = 0; }
-    };
-    // phase 1 of the pass nx describes, for the slot pair `pair` of this lane: the arithmetic of rank_loop_kernel's fused form (fast_one /
-    // relocate_lockstep per slot), the draw's logarithm from LDS; the scattered slot of the previous pass (nx.skip) is left to the walker
-    auto phase1_pair = [&](int pair) {
-        const int nseg = nx.nseg, skip = nx.skip;
-        const bool force = nx.force != 0;
-        const double t_cut = nx.t_cut;
-#ifdef MCRAT_DIAG
-        const bool dgi = dg_inner && tid == 64;
-        if (dgi) { PIPE_T0(); s_dg[4] += 1; }
-#endif
-        int il[2] = {2 * pair, 2 * pair + 1};
-        bool live[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) { live[k] = il[k] < n && base + il[k] != skip; if (il[k] >= n) il[k] = 0; }
-        double r0[2], r1[2], r2[2], ntau[2], lg[2];
-        int cell[2];
-        unsigned fl[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = base + il[k];
-            r0[k] = ph.r0(i); r1[k] = ph.r1(i); r2[k] = ph.r2(i);
-            ntau[k] = ph.ntau(i); cell[k] = ph.idx(i); fl[k] = ph.flags(i);
-            lg[k] = s_lg[il[k]];
-        }
-        if (nseg > 0) {                                      // pending updatePhotonPosition, mclib.c:1067-1095
-            double u0[2], u1[2], u2[2];
-            bool mv[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = base + il[k];
-                u0[k] = ph.u0(i); u1[k] = ph.u1(i); u2[k] = ph.u2(i);
-                mv[k] = live[k] && (fl[k] & FLAG_MOVES);
-            }
-            for (int sg = 0; sg < nseg; ++sg) {
-                const double t = nx.seg[sg];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const double n0 = r0[k] + u0[k] * t, n1 = r1[k] + u1[k] * t, n2 = r2[k] + u2[k] * t;
-                    r0[k] = mv[k] ? n0 : r0[k]; r1[k] = mv[k] ? n1 : r1[k]; r2[k] = mv[k] ? n2 : r2[k];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                if (mv[k]) { const int i = base + il[k]; ph.r0(i) = r0[k]; ph.r1(i) = r1[k]; ph.r2(i) = r2[k]; }
-        }
-#ifdef MCRAT_DIAG
-        if (dg_inner) PIPE_TICK_W(dgi, 0);
-#endif
-        double a0[2], a1[2], a2[2];
-        bool dom[2], cand[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            phys::hydro_coords<DIMS, GEOM>(r0[k], r1[k], r2[k], a0[k], a1[k], a2[k]);
-            dom[k] = phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);           // mclib.c:492-505
-            cand[k] = live[k] && (fl[k] & FLAG_VALID) && dom[k] && cell[k] != -1;
-        }
-        int qd[2] = {0, 0}, code[2] = {-1, -1};
-        bool settled[2] = {false, false};
-        double tl[2] = {0, 0};
-        const uint64_t lb[2] = {(uint64_t)__double_as_longlong(lg[0]), (uint64_t)__double_as_longlong(lg[1])};
-        const int slot[2] = {base + il[0], base + il[1]};
-        if (nx.thin) {
-            // most slots change cell between two events here (or this is a frame's forced pass): every slot is looked up in the grid first, and
-            // the entry its bucket's hint names says both whether it has left its cached cell and where it is (LockstepProbe) -- the gather of
-            // the cached cell's geometry is spent only on the few slots no hint settles
-            bool todo[2] = {cand[0], cand[1]}, same[2] = {false, false};
-#pragma unroll
-            for (int k = 0; k < 2; ++k) if (cand[k]) code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]);
-#ifdef MCRAT_DIAG
-            if (dg_inner) PIPE_TICK_W(dgi, 1);
-#endif
-            if (todo[0] || todo[1]) {
-                const LockstepProbe probe = {cell, force, same};
-                double tt[2];
-                relocate_lockstep<DIMS, GEOM, 2, true>(ph, hy, slot, todo, r0, r1, a0, a1, a2, code, lb, fl, !force, tt, relocated, &probe);
-#pragma unroll
-                for (int k = 0; k < 2; ++k)
-                    if (cand[k] && !todo[k] && !same[k]) { settled[k] = true; tl[k] = tt[k]; n_rel += 1; }
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (!cand[k]) continue;
-                bool stays = same[k];
-                if (todo[k]) {                                                     // no hint settles this slot: the test on its cached cell
-                    stays = !force && phys::check_in_block<DIMS>(hy, cell[k], a0[k], a1[k], a2[k]);   // mclib.c:507,528
-                    if (!stays) { qd[k] = 1; n_rel += 1; }
-                }
-                if (stays && (fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;          // mclib.c:668
-            }
-        } else {
-            CellGeom cg[2];
-            CellGeom2 cg2[2];
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int cc = cell[k] < 0 ? 0 : cell[k];
-                cg[k] = hy.geom[cc];                                              // geometry.c:394-417 operands
-                if constexpr (DIMS == DIM_THREE) cg2[k] = hy.geom2[cc];
-            }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                bool inb = (2 * fabs(a0[k] - cg[k].c0) - cg[k].s0 <= 0) && (2 * fabs(a1[k] - cg[k].c1) - cg[k].s1 <= 0);
-                if constexpr (DIMS == DIM_THREE) inb = inb && (2 * fabs(a2[k] - cg2[k].c2) - cg2[k].s2 <= 0);
-                if (!cand[k]) continue;
-                if (force || !inb) qd[k] = 1;                                      // mclib.c:507,528
-                else if ((fl[k] & FLAG_RECALC) && !(fl[k] & FLAG_TAU_FRESH)) qd[k] = 2;   // mclib.c:668
-                if (qd[k] == 1) { code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]); n_rel += 1; }
-            }
-#ifdef MCRAT_DIAG
-            if (dg_inner) PIPE_TICK_W(dgi, 1);
-#endif
-            // (the few slots that changed cell go to the leftover queue: after the pass's barrier they are re-located with dense lanes)
-        }
-#ifdef MCRAT_DIAG
-        if (dg_inner) PIPE_TICK_W(dgi, 2);
-#endif
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (!live[k]) continue;
-            const int i = base + il[k];
-            double t;
-            if (!(fl[k] & FLAG_VALID)) { ph.tts(i) = INFINITY; continue; }
-            if (settled[k]) {                                                  // re-located in lockstep above; everything is stored
-                best.offer(tl[k], i);
-                if (tl[k] < t_cut) shortlist_lds(tl[k], i);
-                continue;
-            }
-            if (dom[k] && cell[k] != -1) {
-                const int q = qd[k];
-                if (!q && (fl[k] & FLAG_RECALC)) {                             // mclib.c:668, tau of the new momentum is at hand
-                    ph.flags(i) = (unsigned char)(fl[k] & ~(FLAG_RECALC | FLAG_TAU_FRESH));
-                    ph.tau(i) = ph.tau_next(i);
-                }
-                if (q) {
-                    const int e = atomicAdd(&s_qn, 1);
-                    if (e < PIPE_QCAP) {
-                        s_q[e] = il[k] | (q == 2 ? Q_RECALC_ONLY : 0);
-                        s_qb[e] = code[k];
-                        continue;
-                    }
-                    t = slow_one<DIMS, GEOM, true>(ph, hy, i, q == 1, code[k], !force, (uint64_t)__double_as_longlong(lg[k]), relocated, not_found);   // queue full: in line
-                } else {
-                    t = free_time_from_log(ntau[k], lg[k]);                    // mclib.c:675-687
-                    ph.tts(i) = t;
-                }
-            } else {
-                if (cell[k] != -1) ph.idx(i) = -1;                             // mclib.c:592
-                t = 1e12 / C_LIGHT;                                            // mclib.c:620,684
-                ph.tts(i) = t;
-            }
-            best.offer(t, i);
-            if (t < t_cut) shortlist_lds(t, i);
-        }
-#ifdef MCRAT_DIAG
-        if (dg_inner) PIPE_TICK_W(dgi, 3);
-#endif
-    };
-    // 64 slot pairs at a time from a counter the wavefronts share (the walker joins when it has finished its scattering)
-    auto phase1_work = [&]() {
-        for (;;) {
-            int c = 0;
-            if (lane == 0) c = atomicAdd(&s_chunk, 1);
-            c = __builtin_amdgcn_readfirstlane(c);
-            if (c * 64 >= npairs) break;
-            const int pair = c * 64 + lane;
-            if (pair < npairs) phase1_pair(pair);
-        }
-        // how many slots changed cell: the next pass's form (PipeNext::thin)
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) n_rel += __shfl_xor(n_rel, off, 64);
-        if (lane == 0 && n_rel) atomicAdd(&s_nrel, n_rel);
-        n_rel = 0;
-    };
-
-    // ---- the first pass of this launch: nothing to overlap it with
-    precompute(nx.iter, tid, BLOCK);
-    best.init();
-    __syncthreads();
-    phase1_work();
-
-    PIPE_T0();
-    for (long long pass = 0;; ++pass) {
-        PIPE_TICK(!dg_inner && tid == 64, 7);
-        PIPE_TICK(!dg_inner && tid == 0, 4);
-        __syncthreads();                                     // barrier B: phase 1 of the pass is done (and the scattering of the one before stored)
-        PIPE_TICK(!dg_inner && tid == 0, 5);
-        // ---- what is left of the pass: counters, the slots the hints did not settle, the minimum, the sorted shortlist
-        if (relocated) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.n_relocated), (unsigned long long)relocated); relocated = 0; }
-        if (not_found) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.not_found), (unsigned long long)not_found); not_found = 0; }
-        const int nrel_prev = s_nrel;                        // slots that changed cell in the pass just done
-        const int qn = min(s_qn, PIPE_QCAP);
-        if (qn > 0) {
-            const bool force = nx.force != 0;
-            const double t_cut = nx.t_cut;
-            for (int e = tid; e < qn; e += BLOCK) {
-                const int il = s_q[e] & ~Q_RECALC_ONLY;
-                const int i = base + il;
-                const double t = slow_one<DIMS, GEOM, true>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, (uint64_t)__double_as_longlong(s_lg[il]), relocated, not_found);
-                best.offer(t, i);
-                if (t < t_cut) shortlist_lds(t, i);
-            }
-            if (relocated) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.n_relocated), (unsigned long long)relocated); relocated = 0; }
-            if (not_found) { atomicAdd(reinterpret_cast<unsigned long long *>(&st.not_found), (unsigned long long)not_found); not_found = 0; }
-        }
-        wave_min_pair_dpp(best.t, best.i);
-        if (lane == 0) { s_wt[wave] = best.t; s_wi[wave] = best.i; }
-        __syncthreads();
-        const int n_raw = s_sln;
-        int n_list = (n_raw > BLOCK) ? 0 : n_raw;            // overflowed: incomplete, ignore it
-        if (tid < n_list) {                                  // rank sort (equal (t, idx) pairs cannot occur)
-            const Cand me = s_raw[tid];
-            int rk_ = 0;
-            for (int j = 0; j < n_list; ++j) rk_ += cand_less(s_raw[j].t, s_raw[j].idx, me.t, me.idx) ? 1 : 0;
-            s_list[rk_] = me;
-        }
-        MinCand g;
-        g.init();
-#pragma unroll
-        for (int wv = 0; wv < BLOCK / 64; ++wv) g.offer(s_wt[wv], s_wi[wv]);
-        if (n_list == 0 && tid == 0) { s_list[0].t = g.t; s_list[0].idx = g.i; s_list[0].pad = 0; }
-        if (n_list == 0 && g.i != INT_MAX) n_list = 1;
-        const unsigned long long iter = nx.iter;             // the pass whose event is walked now
-        __syncthreads();
-        PIPE_TICK(!dg_inner && tid == 0, 0);
-        if (tid == 64) PIPE_T0();
-
-        if (wave == 0) {
-            // ---- the walk of photonEvent (mclib.c:1128-1339; cf. event_block / try_candidate) as far as a decision
-            __builtin_amdgcn_s_setprio(3);
-            const double dt_max = st.remaining_time, t_est = st.t_est;
-            const double t_first = (n_list > 0) ? s_list[0].t : INFINITY;
-            double old_scatt_time = 0, dt = 0;
-            int w_nseg = 0, skip = -1, last_idx = st.last_scattered_index;
-            long long rej = 0, rescans = 0;
-            bool first = true, called = false, decided = false, scattered = false;
-            // the scattering in flight between barrier A and its completion
-            EventMid mid;
-            double p[4], pc[4], sv[4] = {1, 0, 0, 0}, r[3];
-            unsigned cand_flags = 0;
-            double scatt_time_acc = 0;
-            Cand cur[TOPK];
-            const Cand *list = s_list;
-            int nl = n_list;
-            const int max_rounds = n / TOPK + 3;
-            for (int round = 0; round < max_rounds && !decided; ++round) {
-                if (nl == 0) {                               // every slot was tried (or there is none): mclib.c:1128 loop ends
-                    dt = (round == 0) ? dt_max : old_scatt_time;
-                    decided = true;
-                    break;
-                }
-                for (int c = 0; c < nl && !decided; ++c) {
-                    const double scatt_time = list[c].t;
-                    const int i = list[c].idx;
-                    const bool in_frame = scatt_time < dt_max;
-                    if (!(first && !in_frame)) last_idx = i;
-                    if (first) called = in_frame;
-                    first = false;
-                    if (!in_frame) {                         // mclib.c:1327-1335
-                        const double this_seg = dt_max - old_scatt_time;
-                        if (w_nseg < MAX_SEG) nx.seg[w_nseg++] = this_seg;
-                        else nx.seg[MAX_SEG - 1] += this_seg;
-                        dt = dt_max;
-                        decided = true;
-                        break;
-                    }
-                    const double this_seg = scatt_time - old_scatt_time;   // mclib.c:1138
-                    if (w_nseg < MAX_SEG) nx.seg[w_nseg++] = this_seg;
-                    else nx.seg[MAX_SEG - 1] += this_seg;
-                    old_scatt_time = scatt_time;
-                    const int cell = ph.idx(i);
-                    p[0] = ph.p0(i); p[1] = ph.p1(i); p[2] = ph.p2(i); p[3] = ph.p3(i);
-                    r[0] = ph.r0(i); r[1] = ph.r1(i); r[2] = ph.r2(i);
-                    pc[0] = ph.c0(i); pc[1] = ph.c1(i); pc[2] = ph.c2(i); pc[3] = ph.c3(i);
-                    cand_flags = ph.flags(i);
-                    const double u0 = ph.u0(i), u1 = ph.u1(i), u2 = ph.u2(i);
-                    sv[0] = 1; sv[1] = 0; sv[2] = 0; sv[3] = 0;
-                    if constexpr (STOKES) { sv[0] = ph.s0(i); sv[1] = ph.s1(i); sv[2] = ph.s2(i); sv[3] = ph.s3(i); }
-                    if (cell == -1) continue;                // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
-                    if (cand_flags & FLAG_MOVES) {           // the candidate's own position after mclib.c:1138
-                        for (int k = 0; k < w_nseg; ++k) {
-                            r[0] += u0 * nx.seg[k];
-                            r[1] += u1 * nx.seg[k];
-                            r[2] += u2 * nx.seg[k];
-                        }
-                    }
-                    if (!scatter_decide<DIMS, GEOM, STOKES, WAVE_WALK>(hy, &st, rk, iter, (uint32_t)(i - base), cell, r, p, pc, sv, mid)) {
-                        rej += 1;
-                        continue;
-                    }
-                    skip = i;
-                    dt = scatt_time;
-                    scatt_time_acc = scatt_time;
-                    scattered = true;
-                    decided = true;
-                }
-                if (!decided) {                              // the list is used up: the next TOPK candidates from time_to_scatter
-                    const double lt = list[nl - 1].t;
-                    const int li = list[nl - 1].idx;
-                    rescans += 1;
-                    TopK more;
-                    more.init();
-                    for (int i = base + lane; i < base + n; i += 64) {
-                        double t = ph.tts(i);
-                        if (t != t) t = INFINITY;
-                        if (cand_less(lt, li, t, i)) more.insert(t, i);
-                    }
-                    wave_topk(more, cur);
-                    list = cur;
-                    nl = 0;
-                    for (int c = 0; c < TOPK; ++c) nl += (cur[c].idx != INT_MAX) ? 1 : 0;
-                }
-            }
-            (void)scatt_time_acc;
-            // ---- the pass is decided: tell the others, then complete it
-            const double rem = dt_max - dt;
-            const bool frame_done = !(rem > 0);
-            const bool go = !frame_done && (pass + 1 < max_passes);
-            double est = t_est;
-            if (t_first < INFINITY) est = (t_est > 0) ? 0.875 * t_est + 0.125 * t_first : t_first;   // shortlist threshold: ~8 expected entries (speed only)
-            if (lane == 0) {
-                nx.nseg = w_nseg; nx.skip = skip; nx.iter = iter + 1; nx.go = go ? 1 : 0; nx.force = 0;
-                nx.thin = (3 * nrel_prev > n) ? 1 : 0;
-                if (t_first < INFINITY) nx.t_cut = 8.0 * est;
-                s_qn = 0; s_sln = 0; s_chunk = 0; s_nrel = 0;
-            }
-            PIPE_TICK(!dg_inner && tid == 0, 1);
-            __syncthreads();                                 // barrier A
-            PIPE_TICK(!dg_inner && tid == 0, 2);
-            if (scattered) {
-                double tau_new;
-                scatter_finish<DIMS, GEOM, STOKES, WAVE_WALK>(hy, &st, mid, p, pc, sv, tau_new);
-                commit_scatter<STOKES>(ph, skip, p, pc, sv, r, tau_new, cand_flags);
-            }
-            if (lane == 0) {                                 // mcrat.c:782-784 / 837-845
-                if (scattered) { st.frame_scatt_cnt += 1; st.last_scattered_temp = mid.fluid_temp; }   // mclib.c:1318
-                st.time_now += dt;
-                st.remaining_time = rem;
-                st.last_time_step = dt;
-                st.iteration = iter + 1;
-                st.iterations += 1;
-                st.done = frame_done;
-                st.nseg = go ? 0 : w_nseg;                   // (go: phase 1 of the next pass, already under way, applies them)
-                for (int k = 0; k < MAX_SEG; ++k) st.seg[k] = (!go && k < w_nseg) ? nx.seg[k] : 0.0;
-                st.skip_idx = go ? -1 : skip;
-                st.last_scattered_index = last_idx;
-                st.kn_rejections += rej;
-                st.photon_event_called = called ? 1 : 0;
-                st.rescans += rescans;
-                st.force_relocate = 0;
-                if (t_first < INFINITY) { st.t_est = est; st.t_cut = 8.0 * est; }
-            }
-            __builtin_amdgcn_s_setprio(0);
-            best.init();
-            if (go && scattered) {
-                // the scattered slot's own phase 1 of the next pass: it has not moved since the event (mclib.c:1332 skips nothing, the event
-                // advanced it), its tau is fresh if it is still in its cell.  Every lane of the wavefront the same values; lane 0 counts.
-                const int i = skip;
-                const unsigned fl = ph.flags(i);
-                const int cell = ph.idx(i);
-                const double lgi = s_lg[i - base];
-                double a0, a1, a2, t;
-                phys::hydro_coords<DIMS, GEOM>(r[0], r[1], r[2], a0, a1, a2);
-                int rel1 = 0, nf1 = 0;
-                if (phys::in_domain<DIMS>(hy, a0, a1, a2) && cell != -1) {
-                    if (!phys::check_in_block<DIMS>(hy, cell, a0, a1, a2)) {
-                        const int code = phys::grid_bucket(hy.grid, a0, a1, a2);
-                        t = slow_one<DIMS, GEOM, true>(ph, hy, i, true, code, true, (uint64_t)__double_as_longlong(lgi), rel1, nf1);
-                    } else {
-                        ph.flags(i) = (unsigned char)(fl & ~(FLAG_RECALC | FLAG_TAU_FRESH));   // mclib.c:668: tau of the new momentum is at hand
-                        ph.tau(i) = ph.tau_next(i);
-                        t = free_time_from_log(ph.ntau(i), lgi);
-                        ph.tts(i) = t;
-                    }
-                } else {
-                    if (cell != -1) ph.idx(i) = -1;                                 // mclib.c:592
-                    t = 1e12 / C_LIGHT;
-                    ph.tts(i) = t;
-                }
-                if (lane == 0) {
-                    relocated += rel1; not_found += nf1;
-                    best.offer(t, i);
-                    if (t < nx.t_cut) shortlist_lds(t, i);
-                }
-            }
-            PIPE_TICK(!dg_inner && tid == 0, 3);
-        } else {
-            precompute(iter + 1, tid - 64, BLOCK - 64);      // the next pass's draws, while the walk decides
-            PIPE_TICK(!dg_inner && tid == 64, 6);
-            __syncthreads();                                 // barrier A
-            if (tid == 64) PIPE_T0();
-            best.init();
-        }
-        if (!nx.go) break;
-        phase1_work();
-    }
-    __syncthreads();
-
-    // leave the photons current: apply the advance still pending (cf. flush_kernel), write the LDS columns back
-    {
-        const int nseg = st.nseg, skip = st.skip_idx;
-        for (int il = tid; il < n; il += BLOCK) {
-            const int i = base + il;
-            double r0 = ph.r0(i), r1 = ph.r1(i), r2 = ph.r2(i);
-            const unsigned fl = ph.flags(i);
-            if (nseg > 0 && (fl & FLAG_MOVES) && i != skip) {
-                const double u0 = ph.u0(i), u1 = ph.u1(i), u2 = ph.u2(i);
-                for (int sg = 0; sg < nseg; ++sg) {
-                    const double t = st.seg[sg];
-                    r0 += u0 * t; r1 += u1 * t; r2 += u2 * t;
-                }
-            }
-            ph.template gcol<COL_R0>(i) = r0; ph.template gcol<COL_R1>(i) = r1; ph.template gcol<COL_R2>(i) = r2;
-            ph.template gcol<COL_NTAU>(i) = ph.ntau(i);
-            ph.g_idx_at(i) = ph.idx(i); ph.g_flags_at(i) = (unsigned char)fl;
-        }
-#ifdef MCRAT_DIAG
-        __syncthreads();
-        if (tid == 0) for (int k = 0; k < 8; ++k) st.stamps[k] = s_dg[k];
-        if (tid == 0 && dg_clock) {
-            st.stamps[0] = dg_real0; st.stamps[1] = (long long)__builtin_amdgcn_s_memrealtime();
-            st.stamps[2] = (long long)__builtin_amdgcn_s_memtime() - dg_tick0;
-        }
-#endif
+    // ---- which list, which frame
+    int rank = blockIdx.x, item = -1;
+    if (queued) {
+        // The k-th workgroup to START takes the k-th open item (frame-major): whatever order the hardware starts workgroups in, the workgroup of a
+        // list's previous frame has started before this one, runs without waiting for anything later, and so always gets through -- waiting for it
+        // cannot deadlock.  (It is rare: with more lists than the device holds at once a list's previous frame ended long before its next item is drawn.)
+        // The lists are dealt out to the XCDs (list r belongs to XCD r % 8) and a workgroup takes items of the XCD it runs on (HW_REG_XCC_ID), so a
+        // list never changes XCD: what its previous frame stored is in the L2 this workgroup reads through, and the hand-over costs no write-back
+        // of that L2 (an agent-scope release per item cost the queue 9 % on the benchmark frame), only the invalidation of this CU's L1.  Should the
+        // hardware start fewer workgroups on an XCD than it has items, those items stay undone and the host launches again for them.
         if (tid == 0) {
-            st.nseg = 0; st.skip_idx = -1;
-            if (st.last_scattered_index >= 0) st.last_scattered_index -= idx_shift;
-            states[rank] = st;
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= (unsigned)(FRAME_QUEUE_XCDS - 1);
+            const unsigned k = atomicAdd(lay.fq.ticket + xcc * FRAME_TICKET_STRIDE, 1u);
+            int it = k < (unsigned)(lay.fq.order_off[xcc + 1] - lay.fq.order_off[xcc]) ? lay.fq.order[lay.fq.order_off[xcc] + (int)k] : -1;
+            const int f = it / lay.n_ranks, r = it - f * lay.n_ranks;
+            if (it >= 0 && f > 0 && lay.fq.items[it - lay.n_ranks].open) {
+                unsigned d = 0;
+                long long spins = 0;
+                for (;;) {
+                    d = __hip_atomic_load(&lay.fq.frames_done[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (d >= (unsigned)f || spins >= (1ll << 22)) break;      // (through, or stalled: the flag bit makes it large; bounded: ~4 s)
+                    __builtin_amdgcn_s_sleep(32);
+                    spins += 1;
+                }
+                if (d != (unsigned)f) it = -1;                                 // its previous frame ran into the launch's pass limit: the host goes on from there
+                // Hand-over of a list between workgroups of one XCD (another CU's L1 sees nothing of a workgroup's stores by itself; MI355X_MICROARCH.md,
+                // inter-workgroup visibility): the one that ends a frame drains every wave's stores into the XCD's L2 and passes its barrier before ONE
+                // lane's agent-scope store of frames_done; the one that takes the list on makes ONE agent-scope acquire (this CU's L1 invalidated) after
+                // it has seen frames_done, in front of the barrier that lets its other waves go.
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            s_item = it;
+        }
+        __syncthreads();
+        item = __builtin_amdgcn_readfirstlane(s_item);
+        if (item < 0) return;
+        rank = item % lay.n_ranks;
+    }
+    list_frame(rank, item);
+    if (queued) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned frame = (unsigned)(item / lay.n_ranks);
+            // (a frame that ran into the launch's pass limit is not through: FRAME_STALLED | frame tells the list's later items to give up)
+            __hip_atomic_store(&lay.fq.frames_done[rank], st.done == LOOP_DONE ? frame + 1u : (FRAME_STALLED | frame), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
 
-#endif   // MCRAT_RANK_PIPE
 
 // ------------------------------------------------------------------ FAST mode (SURVEY.md section 7, 8b `mode`)
 // Within a frozen hydro frame the photons are mutually independent and exponential free paths are memoryless, so the frame can be run
@@ -2203,7 +1753,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
                 const bool inside = (cell[k] != -1) && phys::in_domain<DIMS>(hy, a0[k], a1[k], a2[k]);
                 if (pass == 0 && inside && queue[k] != 1) {                 // find_nearest_grid_switch = 1 on a new frame (mcrat.c:756)
                     queue[k] = 1;
-                    code[k] = phys::grid_bucket(hy.grid, a0[k], a1[k], a2[k]);
+                    code[k] = phys::grid_bucket_of<DIMS>(hy.grid, a0[k], a1[k], a2[k]);
                 }
                 if (!inside) cell[k] = -1;                                  // (fast_one has stored it, mclib.c:592)
             }
@@ -2803,31 +2353,17 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
 #endif
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream)
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open)
 {
-    const bool pipe = block >= 2000;               // block: 128 or 256 threads per list, + 1000 for the build with the fused pass, + 2000 for rank_pipe_kernel
-    if (pipe) block -= 2000;
+    // block: 64, 128, 256 or 512 threads per list, + 1000 for the build with the fused pass
     const bool fuse = block >= 1000;
     if (fuse) block -= 1000;
-    RankLayout lay = {n_ranks, rank_stride, ph.n, desc, cs, hook};
-    (void)pipe;
-#if defined(MCRAT_RANK_PIPE) && MCRAT_RANK_PIPE
-    if constexpr (!TABLE_MODE) {
-        if (pipe && !cs && longest_list <= 1024 && !getenv("MCRAT_HIP_NO_LDS_LISTS")) {      // the pipelined passes: lists that fit its LDS form
-            const int lds_slots = (longest_list + 15) & ~15;
-            const size_t dyn = (size_t)lds_slots * rank_pipe_lds_bytes_per_slot();
-            return dispatch(kc, [&](auto D, auto G) {
-                constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
-                auto go = [&](auto kernel) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-                    kernel<<<dim3(n_ranks), dim3(PIPE_BLOCK), dyn, stream>>>(ph, hy, states, key, lay, max_passes, lds_slots);
-                };
-                if (kc.stokes) go(rank_pipe_kernel<DV, GV, true>);
-                else go(rank_pipe_kernel<DV, GV, false>);
-            });
-        }
+    RankLayout lay = {n_ranks, rank_stride, ph.n, desc, cs, hook, FrameQueueDev{}};
+    const bool queued = fq && fq->n_frames > 0;
+    if (queued) {
+        if (cs || n_open <= 0) return hipErrorInvalidValue;   // (cyclo-synchrotron lists go to the host between passes: one frame per launch)
+        lay.fq = *fq;
     }
-#endif
     if (cs && hook && desc) {                      // cyclo-synchrotron lists with the hook inside the loop: columns in HBM/L2, no fused pass
         return dispatch(kc, [&](auto D, auto G) {
             constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
@@ -2854,13 +2390,14 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
         // static + dynamic LDS may exceed the 64 KiB default: the kernel must be told, and if the runtime refuses
         // the list simply stays in global memory (lds_slots = 0)
+        const int grid = queued ? n_open : n_ranks;          // a queue launch: one workgroup per open (frame, list) item
         auto launch = [&](auto kernel, auto kernel_global, int threads) {
             if (lds_slots > 0 &&
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) {
-                kernel<<<dim3(n_ranks), dim3(threads), dyn, stream>>>(ph, hy, states, key, lay, max_passes, lds_slots);
+                kernel<<<dim3(grid), dim3(threads), dyn, stream>>>(ph, hy, states, key, lay, max_passes, lds_slots);
             } else {
                 (void)hipGetLastError();
-                kernel_global<<<dim3(n_ranks), dim3(threads), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
+                kernel_global<<<dim3(grid), dim3(threads), 0, stream>>>(ph, hy, states, key, lay, max_passes, 0);
             }
         };
         // The fused pass exists where engine.hip's choose_rank_block can ask for it: DIRECT optical depths, not in spherical geometry (there it

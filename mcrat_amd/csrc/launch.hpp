@@ -36,9 +36,41 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
 // [r * rank_stride, ...) -- rank_stride of them, or desc[r].len with the list's own seed and stream (rank pool); longest_list sizes the LDS copy
 // hook: (device memory) what the cyclo-synchrotron hook needs -- then lists with `cs` run it inside the loop instead of parking for
 // cs_replace_pool_kernel after every pass it has to look at
+// The frame queue (round 4): ONE launch takes every list through SEVERAL hydro frames.  The reference's ranks are asynchronous processes, each in
+// its own frame loop (mcrat.c:457-479, :566-934); a launch per hydro frame makes them wait for each other at every frame's end.  A queue launch has
+// one workgroup per (frame, list) item, and the k-th workgroup to start on an XCD takes the k-th open item of that XCD's lists in frame-major order
+// (`order`, `ticket`): a list that is through frame f starts f + 1 as soon as a workgroup slot frees up, while other lists are still in f.  The item of a list whose previous
+// frame is still running waits for it (frames_done; the earlier item's workgroup started earlier and depends on nothing later, so this cannot
+// deadlock).  Every list sees exactly the frames it would have seen one launch at a time: the same seeds, clocks, passes and photons
+// (tests/test_gpu_frame_queue.py).
+struct FrameItem {                   // list r in frame f: item f * n_ranks + r
+    unsigned long long seed;         // the list's seed of this frame (gsl_rng_get, mcrat.c:701)
+    double time_now;                 // its clock at the start of the frame ...
+    double remaining_time;           // ... and the time left in it (mcrat.c:757), unless the clock is chained (below)
+    double frame_end;                // (scatt_frame + increment_scatt_frame) / fps: a chained list gets frame_end - its own time_now, the host's expression
+    int open;                        // the list takes part in this frame (a rank joins at its injection frame, mcrat.c:566-700)
+    int hydro;                       // which staged hydro frame of the launch it propagates through
+};
+struct FrameQueueDev {
+    int n_frames;                    // 0: no queue -- one workgroup per list, one frame, as before
+    int restore;                     // every frame starts from the context's snapshot (mcrat_hip_snapshot_photons; benchmarks: the same work every frame)
+    int chain_clock;                 // a list's clock carries over from its previous frame of this launch (time_now of the LoopState it left)
+    int pad;
+    unsigned *ticket;                // [FRAME_QUEUE_XCDS * FRAME_TICKET_STRIDE] per XCD: workgroups that have started there
+    const int *order;                // [open items] per XCD (order_off[x] .. order_off[x + 1]) its lists' items in the order they are taken: frame-major
+    int order_off[9];
+    unsigned *frames_done;           // [n_ranks] f + 1 once item (f, r) is complete; FRAME_STALLED | f: frame f ran into the launch's pass limit
+    const FrameItem *items;          // [n_frames * n_ranks]
+    LoopState *records;              // [n_frames * n_ranks] the LoopState every frame ended with
+    long long snap_delta;            // bytes from a column of the live lists to its copy in the snapshot (restore)
+    long long capture_delta, capture_stride;   // != 0: at the end of frame f < n_frames - 1 the list's columns are copied to live + capture_delta + f * capture_stride
+};
+constexpr unsigned FRAME_STALLED = 0x80000000u;
+constexpr int FRAME_QUEUE_XCDS = 8, FRAME_TICKET_STRIDE = 16;     // (a ticket per XCD, each on a 64-B line of its own)
+// `fq` (n_frames > 0, n_open items in fq->order) makes it a queue launch: one workgroup per open item
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, struct CsFrame *cs, const struct CsHookArgs *hook,
-                            long long max_passes, int block, hipStream_t stream);
+                            long long max_passes, int block, hipStream_t stream, const FrameQueueDev *fq = nullptr, int n_open = 0);
 // shared clock with a device-initiated exchange (staging.hip): recv[r] = rank r's receive buffer (2 x world proposals, by round parity),
 // flag[r] = rank r's stamps (SC_MAX_WORLD words, one per sender, + a word counting waits that gave up + the rank's own round number)
 struct ScPeers { ScProposal *recv[SC_MAX_WORLD]; unsigned long long *flag[SC_MAX_WORLD]; };

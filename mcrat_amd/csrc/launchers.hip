@@ -16,7 +16,7 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
                             Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream);
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -40,7 +40,7 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
                             Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream);
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -58,7 +58,7 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
                             Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream);
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -76,7 +76,7 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
                             Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream);
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -94,7 +94,7 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
                             Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream);
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -112,7 +112,7 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
                             Cand *block_min, int n_blocks, Shortlist *sl, hipStream_t stream);
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream);
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open);
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,
                              ScState *sc, RngKey key, Cand *block_min, int blocks, Shortlist *sl, ScProposal *out, const ScFold &fold, hipStream_t stream);
 hipError_t launch_sc_resolve(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *st, ScState *sc, RngKey key,
@@ -157,9 +157,9 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
 
 hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, LoopState *states, RngKey key,
                             int n_ranks, int rank_stride, int longest_list, const RankDesc *desc, CsFrame *cs, const CsHookArgs *hook, long long max_passes,
-                            int block, hipStream_t stream)
+                            int block, hipStream_t stream, const FrameQueueDev *fq, int n_open)
 {
-    MCRAT_ROUTE(launch_rank_loop, kc, ph, hy, states, key, n_ranks, rank_stride, longest_list, desc, cs, hook, max_passes, block, stream);
+    MCRAT_ROUTE(launch_rank_loop, kc, ph, hy, states, key, n_ranks, rank_stride, longest_list, desc, cs, hook, max_passes, block, stream, fq, n_open);
 }
 
 hipError_t launch_sc_propose(const KernelConfig &kc, bool force_relocate, const PhotonDev &ph, const HydroDev &hy, LoopState *st,

@@ -85,8 +85,8 @@ __device__ __forceinline__ void hydro_coords(double x, double y, double z, doubl
 template <int DIMS>
 __device__ __forceinline__ bool in_domain(const HydroDev &h, double a0, double a1, double a2)
 {
-    bool in = (a1 < h.dom1[1]) && (a1 > h.dom1[0]) && (a0 < h.dom0[1]) && (a0 > h.dom0[0]);
-    if constexpr (DIMS == DIM_THREE) in = (a2 < h.dom2[1]) && (a2 > h.dom2[0]) && in;
+    bool in = (a1 < h.dom1[1]) & (a1 > h.dom1[0]) & (a0 < h.dom0[1]) & (a0 > h.dom0[0]);      // (`&`: no branch between the comparisons)
+    if constexpr (DIMS == DIM_THREE) in = (a2 < h.dom2[1]) & (a2 > h.dom2[0]) & in;
     return in;
 }
 
@@ -95,10 +95,10 @@ template <int DIMS>
 __device__ __forceinline__ bool check_in_block(const HydroDev &h, int cell, double a0, double a1, double a2)
 {
     const CellGeom g = h.geom[cell];
-    bool in = (2 * fabs(a0 - g.c0) - g.s0 <= 0) && (2 * fabs(a1 - g.c1) - g.s1 <= 0);
+    bool in = (2 * fabs(a0 - g.c0) - g.s0 <= 0) & (2 * fabs(a1 - g.c1) - g.s1 <= 0);
     if constexpr (DIMS == DIM_THREE) {
         const CellGeom2 g2 = h.geom2[cell];
-        in = in && (2 * fabs(a2 - g2.c2) - g2.s2 <= 0);
+        in = in & (2 * fabs(a2 - g2.c2) - g2.s2 <= 0);
     }
     return in;
 }
@@ -106,28 +106,42 @@ __device__ __forceinline__ bool check_in_block(const HydroDev &h, int cell, doub
 // bucket of the cell-lookup grid that holds a point (engine.hip, build_grid), as a code: bucket index, the octant
 // of the bucket the point lies in, and whether it lies far enough (1e-6 bucket widths) from the octant's faces for
 // the bucket's hint to be used (device_types.hpp, BucketDir).  -1: the coordinates are NaN.
-__device__ __forceinline__ int grid_bucket(const GridDev &g, double a0, double a1, double a2)
+// Written without a divergent branch (round 4): the tests of an axis are combined with `&`, the clamp is a max / min, a NaN is remembered
+// and turns the code into -1 at the end -- as a chain of `&&`, ternaries and an early return this function compiled to a dozen
+// exec-mask regions per axis, 190 instructions per point of which 14 were arithmetic (tools/isa_blocks.py on the fused pass of
+// rank_loop_kernel).  The logarithmic axes are a wave-uniform branch.  Same values as before, point by point.
+template <int NAXES>
+__device__ __forceinline__ int grid_bucket_axes(const GridDev &g, double a0, double a1, double a2)
 {
     const double a[3] = {a0, a1, a2};
     int b[3] = {0, 0, 0};
     int oct = 0;
-    bool ok = true;
+    bool ok = true, nan = false;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        if (k < g.naxes) {
-            double u = g.logmap[k] ? log(a[k]) : a[k];
-            const double x = (u - g.org[k]) * g.inv[k];
-            double f = floor(x);
-            if (!(f == f)) return -1;
-            const double fr = x - f;
-            const double d0 = fr, d1 = fabs(fr - 0.5), d2 = 1.0 - fr;
-            ok = ok && (f >= 0.0) && (f <= (double)(g.dim[k] - 1)) && (d0 > 1e-6) && (d1 > 1e-6) && (d2 > 1e-6);
-            oct |= (fr >= 0.5 ? 1 : 0) << k;
-            int bi = (f < 0.0) ? 0 : ((f > (double)(g.dim[k] - 1)) ? g.dim[k] - 1 : (int)f);
-            b[k] = bi;
-        }
+    for (int k = 0; k < NAXES; ++k) {
+        double u = a[k];
+        if (g.logmap[k]) u = log(a[k]);
+        const double x = (u - g.org[k]) * g.inv[k];
+        const double f = floor(x);
+        const double fr = x - f;
+        const double hi = (double)(g.dim[k] - 1);
+        nan = nan | !(f == f);
+        ok = ok & (f >= 0.0) & (f <= hi) & (fr > 1e-6) & (fabs(fr - 0.5) > 1e-6) & (1.0 - fr > 1e-6);
+        oct |= (fr >= 0.5 ? 1 : 0) << k;
+        b[k] = (int)fmin(fmax(f, 0.0), hi);                  // (f NaN: 0, and the code is -1 anyway)
     }
-    return ((b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0]) | (oct << GRID_CODE_OCT_SHIFT) | (ok ? GRID_CODE_HINT_OK : 0);
+    const int code = ((b[2] * g.dim[1] + b[1]) * g.dim[0] + b[0]) | (oct << GRID_CODE_OCT_SHIFT) | (ok ? GRID_CODE_HINT_OK : 0);
+    return nan ? -1 : code;
+}
+__device__ __forceinline__ int grid_bucket(const GridDev &g, double a0, double a1, double a2)
+{
+    return g.naxes == 3 ? grid_bucket_axes<3>(g, a0, a1, a2) : grid_bucket_axes<2>(g, a0, a1, a2);
+}
+// ... for callers that know DIMENSIONS at compile time (the grid has three axes in 3-D, two otherwise: engine.hip, stage_hydro)
+template <int DIMS>
+__device__ __forceinline__ int grid_bucket_of(const GridDev &g, double a0, double a1, double a2)
+{
+    return grid_bucket_axes<DIMS == DIM_THREE ? 3 : 2>(g, a0, a1, a2);
 }
 
 template <int DIMS>
@@ -143,8 +157,8 @@ __device__ __forceinline__ bool in_fat_cell(const FatCell &f, double a0, double 
 template <int DIMS>
 __device__ __forceinline__ bool well_in_fat_cell(const FatCell &f, double a0, double a1, double a2)
 {
-    bool in = (2 * fabs(a0 - f.c0) - f.s0 < -1e-8 * f.s0) && (2 * fabs(a1 - f.c1) - f.s1 < -1e-8 * f.s1);
-    if constexpr (DIMS == DIM_THREE) in = in && (2 * fabs(a2 - f.c2) - f.s2 < -1e-8 * f.s2);
+    bool in = (2 * fabs(a0 - f.c0) - f.s0 < -1e-8 * f.s0) & (2 * fabs(a1 - f.c1) - f.s1 < -1e-8 * f.s1);
+    if constexpr (DIMS == DIM_THREE) in = in & (2 * fabs(a2 - f.c2) - f.s2 < -1e-8 * f.s2);
     return in;
 }
 
@@ -202,7 +216,7 @@ template <int DIMS>
 __device__ __forceinline__ int find_containing_block(const HydroDev &h, double a0, double a1, double a2)
 {
     FatCell hit;
-    return find_in_bucket<DIMS>(h.grid, grid_bucket(h.grid, a0, a1, a2), a0, a1, a2, hit);
+    return find_in_bucket<DIMS>(h.grid, grid_bucket_of<DIMS>(h.grid, a0, a1, a2), a0, a1, a2, hit);
 }
 
 // geometry.c:189-253 on a staged record (see cell_beta below)

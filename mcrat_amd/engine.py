@@ -87,6 +87,13 @@ class FrameStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class FramePlan(C.Structure):
+    """mcrat_hip_frame_plan: several hydro frames of every list of a pool in one launch (the frame queue)"""
+    _fields_ = [("n_frames", C.c_int), ("chain_clock", C.c_int), ("restore_each_frame", C.c_int), ("reserved", C.c_int),
+                ("open", C.POINTER(C.c_int)), ("seeds", C.POINTER(C.c_uint64)), ("time_now", _dp), ("remaining_time", _dp), ("frame_end", _dp),
+                ("hydro", C.POINTER(C.c_void_p))]
+
+
 class Slab(C.Structure):
     """mcrat_hip_slab: the selecting arguments of getHydroData (mcrat_io.h:26) + fps and the hydro domains"""
     _fields_ = [("r_inj", C.c_double), ("ph_inj_switch", C.c_int), ("min_r", C.c_double), ("max_r", C.c_double),
@@ -242,6 +249,7 @@ SYMBOLS = {
     "mcrat_hip_pool_begin_frames": (C.c_int, [_ctx, _ip, C.POINTER(C.c_uint64), _dp, _dp]),
     "mcrat_hip_pool_frame_stats": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_pool_layout": (C.c_int, [_ctx, _ip, _ip]),
+    "mcrat_hip_pool_run_frames": (C.c_int, [_ctx, C.POINTER(FramePlan), C.POINTER(FrameStats)]),
     "mcrat_hip_step_locate_sample": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_step_event": (C.c_int, [_ctx, C.POINTER(FrameStats)]),
     "mcrat_hip_update_photon_position": (C.c_int, [_ctx, C.c_double]),
@@ -772,6 +780,32 @@ class Engine:
         st = (FrameStats * R)()
         self._check(self.lib.mcrat_hip_pool_propagate_frames_fast(self.ctx, o, sd, t, rem, int(windows), st), "pool_propagate_frames_fast")
         return list(st)
+
+    def frame_plan(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False):
+        """a mcrat_hip_frame_plan from [n_frames][n_ranks] arrays -> (plan, stats array, the arrays the plan points into)"""
+        R = self.n_pool_ranks
+        o = np.ascontiguousarray(open_, dtype=np.int32).reshape(-1, R)
+        F = o.shape[0]
+        sd = np.ascontiguousarray(seeds, dtype=np.uint64).reshape(F, R)
+        t = np.ascontiguousarray(time_now, dtype=np.float64).reshape(F, R)
+        rem = np.ascontiguousarray(remaining_time, dtype=np.float64).reshape(F, R)
+        fe = None if frame_end is None else np.ascontiguousarray(frame_end, dtype=np.float64).reshape(F, R)
+        plan = FramePlan(F, int(bool(chain_clock)), int(bool(restore_each_frame)), 0, o.ctypes.data_as(C.POINTER(C.c_int)),
+                         sd.ctypes.data_as(C.POINTER(C.c_uint64)), t.ctypes.data_as(_dp), rem.ctypes.data_as(_dp),
+                         fe.ctypes.data_as(_dp) if fe is not None else None, None)
+        return plan, (FrameStats * (F * R))(), (o, sd, t, rem, fe)
+
+    def pool_run_plan(self, plan, stats):
+        """mcrat_hip_pool_run_frames on a prepared plan; stats (frame_plan's array) receives item f * n_ranks + r"""
+        self._check(self.lib.mcrat_hip_pool_run_frames(self.ctx, C.byref(plan), stats), "pool_run_frames")
+
+    def pool_run_frames(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False):
+        """mcrat_hip_pool_run_frames: the arrays are [n_frames][n_ranks]; every open list through its frames in ONE launch (the frame queue:
+        a list that is through frame f starts f + 1 while others are still in f) -> FrameStats [n_frames][n_ranks]"""
+        plan, st, keep = self.frame_plan(open_, seeds, time_now, remaining_time, frame_end, chain_clock, restore_each_frame)
+        self.pool_run_plan(plan, st)
+        R, F = self.n_pool_ranks, plan.n_frames
+        return [[st[f * R + r] for r in range(R)] for f in range(F)]
 
     def snapshot_photons(self):
         self._check(self.lib.mcrat_hip_snapshot_photons(self.ctx), "snapshot_photons")

@@ -1,0 +1,160 @@
+"""The frame queue (mcrat_hip_pool_run_frames): every list of a rank pool through SEVERAL hydro frames in one launch, a list that is
+through frame f starting f + 1 while others are still in f -- the reference's ranks are asynchronous processes, each in its own frame
+loop (Src/mcrat.c:457-479, :566-934).  What a list sees must not depend on that: its photons, clocks and counters are bit for bit those of
+mcrat_hip_pool_begin_frames / begin_frame + mcrat_hip_run one frame at a time (which tests/test_gpu_pool.py holds against the oracle).
+Through the C ABI."""
+import numpy as np
+import pytest
+
+from mcrat_amd import synth
+from tests.test_gpu_parity import FLOAT_FIELDS, INT_FIELDS
+from tests.test_gpu_pool import _lists
+
+pytestmark = pytest.mark.gpu
+
+STAT_FIELDS = ("iterations", "photon_steps", "frame_scatt_cnt", "num_photons_find_new_element", "not_found", "kn_rejections", "rescans",
+               "last_scattered_index", "last_scattered_temp", "last_time_step", "remaining_time", "time_now")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from mcrat_amd import engine
+    engine.load_library()
+    return engine
+
+
+def _pool(hip, frame, cfg, subs, streams, window):
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(frame)
+    pool.pool_create(len(subs), window)
+    recs = [synth.photons_to_aos(s, hip.PHOTON_DTYPE) for s in subs]
+    for r in range(len(subs)):
+        pool.pool_rank(r, streams[r])
+    pool.pool_set_photons(list(range(len(subs))), recs)
+    return pool
+
+
+def _same_photons(a, b, what):
+    for k in FLOAT_FIELDS + INT_FIELDS:
+        assert np.array_equal(a[k], b[k], equal_nan=True), (what, k)
+
+
+def _setup(hip, lens, lumi=1e54, nzc=8, stokes=1):
+    frame, ph, cfg = synth.config2(n_photons=sum(lens), nzc=nzc, stokes=stokes, lumi=lumi)
+    subs = _lists(ph, lens)
+    R = len(lens)
+    streams = [5 + 3 * r for r in range(R)]
+    return frame, cfg, subs, streams
+
+
+def _run_both(hip, lens, F, open_, restore, window, lumi=1e54, monkeypatch=None, cap=None):
+    frame, cfg, subs, streams = _setup(hip, lens, lumi=lumi)
+    R = len(lens)
+    fps = frame["fps"]
+    seeds = np.array([[1000 + 17 * r + 1000003 * f for r in range(R)] for f in range(F)], dtype=np.uint64)
+
+    ref = _pool(hip, frame, cfg, subs, streams, window)
+    if restore:
+        ref.snapshot_photons()
+    t_now = [0.0] * R
+    want = []
+    for f in range(F):
+        if restore:
+            ref.restore_photons()
+        for r in range(R):
+            if open_[f][r]:
+                t0 = 0.0 if restore else t_now[r]
+                rem = 1.0 / fps if restore else (f + 1) / fps - t0
+                ref.views[r].begin_frame(int(seeds[f][r]), t0, rem)
+        ref.run(0)
+        row = []
+        for r in range(R):
+            if not open_[f][r]:
+                row.append(None)
+                continue
+            st = ref.views[r].frame_statistics()
+            t_now[r] = st.time_now
+            row.append({k: getattr(st, k) for k in STAT_FIELDS})
+        want.append(row)
+
+    q = _pool(hip, frame, cfg, subs, streams, window)
+    if restore:
+        q.snapshot_photons()
+    if cap is not None:
+        monkeypatch.setenv("MCRAT_HIP_RANK_LAUNCH_CAP", str(cap))
+    t_first = np.zeros((F, R))
+    rem_first = np.array([[(1.0 / fps if restore else (f + 1) / fps) for r in range(R)] for f in range(F)])
+    frame_end = np.array([[(f + 1) / fps for r in range(R)] for f in range(F)])
+    got = q.pool_run_frames(open_, seeds, t_first, rem_first, frame_end=None if restore else frame_end, chain_clock=not restore,
+                            restore_each_frame=restore)
+    if cap is not None:
+        monkeypatch.delenv("MCRAT_HIP_RANK_LAUNCH_CAP")
+    for f in range(F):
+        for r in range(R):
+            if not open_[f][r]:
+                assert got[f][r].iterations == 0
+                continue
+            for k in STAT_FIELDS:
+                a, b = getattr(got[f][r], k), want[f][r][k]
+                assert a == b or (a != a and b != b), (f, r, k, a, b)
+    for r in range(R):
+        if any(open_[f][r] for f in range(F)):
+            _same_photons(q.views[r].get_photons(), ref.views[r].get_photons(), r)
+            st = q.views[r].frame_statistics()             # the view is where the last frame left it
+            last = max(f for f in range(F) if open_[f][r])
+            assert st.time_now == want[last][r]["time_now"] and st.frame_scatt_cnt == want[last][r]["frame_scatt_cnt"]
+    events = sum(w["frame_scatt_cnt"] for row in want for w in row if w)
+    assert events > 0
+    ref.close()
+    q.close()
+    return want
+
+
+def test_chained_frames_equal_one_launch_per_frame(hip):
+    """ragged lists, three frames with the clock carried from frame to frame; one list joins at frame 1 (its injection frame)"""
+    lens = [137, 1000, 512, 999, 64, 700, 1024, 333, 420]
+    F, R = 3, len(lens)
+    open_ = np.ones((F, R), dtype=np.int32)
+    open_[0][4] = 0
+    _run_both(hip, lens, F, open_, restore=False, window=1100)
+
+
+def test_restored_frames_equal_restore_plus_launch(hip):
+    """the benchmark's shape: every frame from the snapshot with its own seeds"""
+    lens = [400, 1000, 512, 976, 1016, 935]
+    F, R = 4, len(lens)
+    open_ = np.ones((F, R), dtype=np.int32)
+    _run_both(hip, lens, F, open_, restore=True, window=1024)
+
+
+def test_more_lists_than_the_device_holds(hip):
+    """700 short lists over three frames: items are drawn from the ticket by whichever workgroup is free, in frame-major order"""
+    lens = [48 + (7 * r) % 33 for r in range(700)]
+    F, R = 3, len(lens)
+    open_ = np.ones((F, R), dtype=np.int32)
+    _run_both(hip, lens, F, open_, restore=False, window=96, lumi=1e55)
+
+
+def test_a_pass_limit_per_launch_only_costs_launches(hip, monkeypatch):
+    """lists whose frame does not finish within the launch's pass limit go on in the next launch, frame by frame, with the same results"""
+    lens = [300, 800, 512, 64]
+    F, R = 3, len(lens)
+    open_ = np.ones((F, R), dtype=np.int32)
+    _run_both(hip, lens, F, open_, restore=False, window=1024, monkeypatch=monkeypatch, cap=7)
+
+
+def test_refusals(hip):
+    frame, cfg, subs, streams = _setup(hip, [100, 100])
+    q = _pool(hip, frame, cfg, subs, streams, 128)
+    F, R = 3, 2
+    seeds = np.ones((F, R), dtype=np.uint64)
+    z = np.zeros((F, R))
+    rem = np.full((F, R), 0.2)
+    gap = np.array([[1, 1], [0, 1], [1, 1]], dtype=np.int32)          # a list's frames must be consecutive
+    with pytest.raises(hip.McratHipError):
+        q.pool_run_frames(gap, seeds, z, rem)
+    with pytest.raises(hip.McratHipError):                             # restore without a snapshot
+        q.pool_run_frames(np.ones((F, R), dtype=np.int32), seeds, z, rem, restore_each_frame=True)
+    with pytest.raises(hip.McratHipError):                             # a chained clock needs the frames' ends
+        q.pool_run_frames(np.ones((F, R), dtype=np.int32), seeds, z, rem, chain_clock=True)
+    q.close()
