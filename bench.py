@@ -24,6 +24,7 @@ the CPU baseline (oracle/ = faithful C restatement of the reference, one host co
 """
 
 import argparse
+import ctypes as C
 import glob
 import json
 import os
@@ -249,7 +250,7 @@ def bench_cfg5(args):
             stride = max(1, R_ // 64)
             slots = sum(int(pool.lib.mcrat_hip_num_photon_slots(pool.pool_rank(r, self.lo + r).ctx)) for r in range(0, R_, stride)) * stride
             return (sum(x.frame_scatt_cnt for x in st), sum(x.photon_steps for x in st), sum(x.iterations for x in st), sum(x.num_cyclosynch_ph_emit for x in cn),
-                    sum(x.frame_abs_cnt for x in cn), sum(x.rebins for x in cn), slots)
+                    sum(x.frame_abs_cnt for x in cn), sum(x.rebins for x in cn), slots, sum(x.slot_steps for x in st))
     t0 = time.perf_counter()
     pools = [Pool((p * R) // n_pools, ((p + 1) * R) // n_pools) for p in range(n_pools)]
     setup_inject = time.perf_counter() - t0
@@ -268,7 +269,7 @@ def bench_cfg5(args):
         pools[p].pool.synchronize()
         gate.wait()
         gate.wait()
-        acc = [0] * 7
+        acc = [0] * 8
         ms0, l0 = pools[p].pool.profile_totals()
         for k in range(steps):
             acc = [a + b for a, b in zip(acc, pools[p].one(SEED + 7 + 1000 * k))]
@@ -287,10 +288,15 @@ def bench_cfg5(args):
         th.join()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tot = [sum(x[j] for x in parts) for j in range(7)]
-    achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[1] / dt / 1e9
+    tot = [sum(x[j] for x in parts) for j in range(8)]
+    # The roofline counts the slots actually taken through a pass (tot[7], mcrat_hip_frame_stats.slot_steps): a list that has doubled
+    # (photons.c:112-121) is half settled null slots behind its last photon, which rank_loop_kernel's passes leave out (no cell, never a candidate,
+    # time_to_scatter = 1e12/c every time) although the reference's loops walk them (mclib.c:620,684) -- iterations x list_capacity (tot[1], the
+    # reference's definition of a photon-step) would credit 110 B to slots that move no byte.  Both are reported.
+    achieved = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[7] / dt / 1e9
     loop_ms, loop_launches = max(x[0] for x in loop_prof), sum(x[1] for x in loop_prof)     # (pools side by side: the longest pool's loop time)
-    loop_gbs = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[1] / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
+    loop_gbs = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[7] / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
+    loop_gbs_ref_def = ALGORITHMIC_BYTES_PER_PHOTON_STEP * tot[1] / (loop_ms * 1e-3) / 1e9 if loop_ms > 0 else 0.0
     cpu = None
     if not args.no_cpu_baseline:
         try:
@@ -306,17 +312,22 @@ def bench_cfg5(args):
                                   "slab), B_FIELD_CALC == SIMULATION, cyclo-synchrotron emission and absorption, Compton+KN, Stokes on; %d injected photons "
                                   "as %d adopted ranks (lists of %d-%d photons that grow with their pool photons) in %d rank pool(s), each on its own HIP stream "
                                   "with a host thread; step = one scatter frame (mcrat.c:706-878: pool emission, loop with replacement of scattered pool "
-                                  "photons, rebinning, absorption) for all lists, from resident snapshots"
-                                  % (cells_read, m_cells, n, R, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2, n_pools),
+                                  "photons, rebinning where a list is due -- %s in this run --, absorption) for all lists, from resident snapshots"
+                                  % (cells_read, m_cells, n, R, args.rank_photons * 3 // 4, args.rank_photons * 3 // 2, n_pools,
+                                     ("%.1f lists per frame" % (tot[5] / steps)) if tot[5] else "none"),
                       "mode": "ranks", "photons_per_gpu": n, "cells": int(m_cells), "parallelism": "independent photon shards x1"},
-           "photon_steps_per_s": tot[1] / dt, "scatter_events": tot[0], "loop_passes": tot[2],
+           "photon_steps_per_s": tot[1] / dt, "slot_steps_per_s": tot[7] / dt, "photon_steps_reference_definition": tot[1], "slot_steps_taken_through_a_pass": tot[7],
+           "scatter_events": tot[0], "loop_passes": tot[2],
            "cyclosynchrotron": {"pool_photons_emitted_per_frame": tot[3] / steps, "photons_absorbed_per_frame": tot[4] / steps, "rebinnings_per_frame": tot[5] / steps,
                                 "list_slots_after_a_frame": tot[6] // steps, "setup_s_ingest_and_injection": setup_inject},
            "roofline": {"kernel": "rank_loop_kernel (CSH build: the hook of mcrat.c:786-808 inside the loop)", "bound": "hbm",
                         "achieved": loop_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": loop_gbs / HBM_PEAK_GBS, "traffic": None,
                         "avg_launch_ms": loop_ms / max(1, loop_launches), "launches": int(loop_launches), "loop_ms_per_frame": loop_ms / steps,
                         "frac_whole_frame": achieved / HBM_PEAK_GBS, "achieved_whole_frame": achieved,
-                        "note": "loop only: 110 B x photon-steps over the summed duration of the loop kernel's launches (HIP events on the pool's stream "
+                        "frac_reference_photon_step_definition": loop_gbs_ref_def / HBM_PEAK_GBS,
+                        "note": "110 B x the slots actually taken through a pass (slot_steps; frac_reference_photon_step_definition prices iterations x "
+                                "list_capacity instead, which counts the settled null slots of doubled lists that the kernel skips: about twice the figure, and "
+                                "not bytes that move).  Loop only: over the summed duration of the loop kernel's launches (HIP events on the pool's stream "
                                 "around every batch of launches; the pools' launches do not overlap here when --pools is 1); frac_whole_frame divides the "
                                 "same bytes by the WALL time of the timed frames -- pool emission, rebinning, absorption and the host's part included"},
            "cpu_baseline": cpu}
@@ -393,6 +404,10 @@ def main():
     ap.add_argument("--pools", type=int, default=0, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to; 0: 3 for "
                                                         "cfg2 / cfg3 (measured on cfg2: 0.95 ms per frame with one, 0.70 with two, 0.65 with three, 1.0 with four: HIP has "
                                                         "four hardware queues), 1 for cfg5 (measured: slower with two)")
+    ap.add_argument("--launch-shape", choices=("queue", "pools"), default="queue",
+                    help="ranks mode: 'queue' = ONE rank pool and ONE launch for all timed frames (mcrat_hip_pool_run_frames: a list that is through frame f "
+                         "starts f + 1 while others are still in f; measured 0.51 ms per frame against 0.53 with three pools); 'pools' = round 3's shape, "
+                         "--pools rank pools on their own streams with a host thread each, one launch per pool and frame")
     ap.add_argument("--share-hydro", type=int, default=1, help="the pools read one staged copy of the hydro frame (mcrat_hip_share_hydro)")
     ap.add_argument("--fast-windows", type=int, default=0, help="FAST mode beside the exact headline: refreshes per frame (0: the context learns them from the frame before, the unbiased default; < 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -548,12 +563,48 @@ def main():
             e.close()
         return sum(x[0] for x in tot), sum(x[1] for x in tot), sum(x[2] for x in tot), dt
 
+    def run_queued(l0, l1, k_frames, k_warm, photons=None, stream_base=None, layout=None):
+        """the lists [l0, l1) as ONE rank pool, all k_frames frames in ONE launch (the frame queue): every frame of a list starts from the resident
+        snapshot with the frame's seed, exactly the frames run_ranks gives it one launch at a time -> (events, photon_steps, passes, seconds, launch_ms)"""
+        e = make_engine("ranks", profile=True, photons=photons, lists=(l0, l1), stream_base=stream_base, layout=layout)
+        e.snapshot_photons()
+        R = l1 - l0
+
+        def plan(k, seed0):
+            seeds = np.repeat(np.arange(seed0, seed0 + k, dtype=np.uint64)[:, None], R, axis=1)
+            return e.frame_plan(np.ones((k, R), dtype=np.int32), seeds, np.zeros((k, R)), np.full((k, R), remaining), restore_each_frame=True)
+        # (a plan of the timed call's size in which no list opens a frame: the queue's device and pinned buffers get their size outside the timed region)
+        pr, sr, keep_r = e.frame_plan(np.zeros((k_frames, R), dtype=np.int32), np.zeros((k_frames, R), dtype=np.uint64), np.zeros((k_frames, R)),
+                                      np.full((k_frames, R), remaining), restore_each_frame=True)
+        e.pool_run_plan(pr, sr)
+        if k_warm > 0:
+            pw, sw, keep_w = plan(k_warm, SEED + 1000)
+            e.pool_run_plan(pw, sw)
+        pt, st, keep_t = plan(k_frames, SEED)
+        e.synchronize()
+        sync()
+        t0 = time.perf_counter()
+        e.pool_run_plan(pt, st)
+        e.synchronize()
+        sync()
+        dt = time.perf_counter() - t0
+        a = np.frombuffer(st, dtype=np.dtype([("it", "<i8"), ("ps", "<i8"), ("sc", "<i8"), ("rest", "V%d" % (C.sizeof(engine.FrameStats) - 24))]))
+        launch_ms = st[0].step_kernel_ms / max(1, st[0].step_kernel_launches)
+        e.close()
+        return int(a["sc"].sum()), int(a["ps"].sum()), int(a["it"].sum()), dt, launch_ms
+
     def measure_ranks(k_frames, k_warm, with_roofline):
         # The adopted ranks never wait for each other (the reference's MPI ranks are asynchronous processes), so they need not share one
         # launch either: --pools P deals the lists out to P rank pools, each on its own HIP stream and driven by its own host thread
         # (as P processes sharing the GPU would be).  A step is still one hydro frame for ALL lists; what changes is that a pool whose last
         # lists are finishing no longer leaves the rest of the device idle -- the other pools' next frames fill it.
-        ev, ps, it, dt = run_pooled(0, n_lists, k_frames, k_warm)
+        # --launch-shape queue (round 4): the same independence taken further -- ONE pool, ONE launch for all k_frames frames, a workgroup per
+        # (frame, list) item: a list that is through frame f starts f + 1 as soon as a workgroup slot is free (mcrat_hip_pool_run_frames).
+        queue_launch_ms = None
+        if args.launch_shape == "queue":
+            ev, ps, it, dt, queue_launch_ms = run_queued(0, n_lists, k_frames, k_warm)
+        else:
+            ev, ps, it, dt = run_pooled(0, n_lists, k_frames, k_warm)
         nr = n_lists
         roof = None
         if with_roofline:
@@ -577,16 +628,33 @@ def main():
             traffic, src = committed_traffic("*_rank_loop_kernel_pmc.json") if full else (None, None)
             # ... and the same bytes over the WALL time of the timed region (the headline's launch shape: the pools' launches overlap)
             headline_gbs = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps / dt / 1e9
-            roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "frac_kernel_alone": achieved / HBM_PEAK_GBS,
-                    "frac_headline": headline_gbs / HBM_PEAK_GBS, "achieved_headline": headline_gbs,
-                    "traffic": traffic, "traffic_source": src,
-                    "bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches),
-                    "note": "latency-bound persistent kernel (one workgroup walks one list's whole frame; the forced "
-                            "re-location pass of the new frame is inside the launch), measured on ONE pool holding all lists -- one "
-                            "launch per frame, alone on the device (with --pools > 1 the headline's launches overlap each other, "
-                            "which is the point, and have no duration of their own); the HBM-bound kernel of this path is "
-                            "step_kernel, see other_mode.roofline"}
+            if queue_launch_ms:
+                # the headline IS one launch of rank_loop_kernel (all timed frames): its duration between HIP events on the pool's stream
+                q_bytes = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps
+                q_gbs = q_bytes / (queue_launch_ms * 1e-3) / 1e9
+                roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": q_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": q_gbs / HBM_PEAK_GBS, "frac_headline": headline_gbs / HBM_PEAK_GBS, "achieved_headline": headline_gbs,
+                        "frac_one_frame_per_launch": achieved / HBM_PEAK_GBS,
+                        "traffic": (traffic * k_frames) if traffic else None, "traffic_source": src,
+                        "bytes_per_launch": q_bytes, "avg_launch_ms": queue_launch_ms, "launches": 1, "frames_per_launch": k_frames,
+                        "one_frame_launch": {"bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches)},
+                        "note": "the timed region is ONE launch of rank_loop_kernel for all %d frames (frame queue: a workgroup per (frame, list) item); "
+                                "frac = 110 B x the photon-steps of that launch / its duration between HIP events on the pool's stream / 8 TB/s; frac_headline "
+                                "= the same bytes over the wall time of the timed region; frac_one_frame_per_launch = round 3's figure, one launch per frame "
+                                "alone on the device (its last lists' tail inside); traffic = the committed per-frame PMC figure x frames.  A latency-bound "
+                                "kernel (one workgroup walks one list's whole frame); the HBM-bound kernel of this path is step_kernel, see other_mode.roofline"
+                                % k_frames}
+            else:
+                roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "frac_kernel_alone": achieved / HBM_PEAK_GBS,
+                        "frac_headline": headline_gbs / HBM_PEAK_GBS, "achieved_headline": headline_gbs,
+                        "traffic": traffic, "traffic_source": src,
+                        "bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches),
+                        "note": "latency-bound persistent kernel (one workgroup walks one list's whole frame; the forced "
+                                "re-location pass of the new frame is inside the launch), measured on ONE pool holding all lists -- one "
+                                "launch per frame, alone on the device (with --pools > 1 the headline's launches overlap each other, "
+                                "which is the point, and have no duration of their own); the HBM-bound kernel of this path is "
+                                "step_kernel, see other_mode.roofline"}
         return dict(events=ev, photon_steps=ps, passes=it, seconds=dt, ranks=nr, roofline=roof)
 
     def measure_strong(k_frames, k_warm):
@@ -600,7 +668,10 @@ def main():
         else:
             _, common, _ = synth.config2(n_photons=args.photons, seed=SEED, nzc=args.nzc, stokes=args.stokes)
         lo, hi = sharding.shard_bounds(n_lists, world, rank)
-        ev, ps, it, dt = run_pooled(lo, hi, k_frames, k_warm, photons=common, stream_base=0)
+        if args.launch_shape == "queue":
+            ev, ps, it, dt, _ = run_queued(lo, hi, k_frames, k_warm, photons=common, stream_base=0)
+        else:
+            ev, ps, it, dt = run_pooled(lo, hi, k_frames, k_warm, photons=common, stream_base=0)
         return ev, ps, dt, hi - lo
 
     def measure_list(k_steps, k_warm, prof_steps):
@@ -1056,11 +1127,14 @@ def main():
 
     if rank == 0:
         if args.mode == "ranks":
-            pools = max(1, min(int(args.pools) if args.pools > 0 else 3, n_lists))
+            pools = 1 if args.launch_shape == "queue" else max(1, min(int(args.pools) if args.pools > 0 else 3, n_lists))
             shape = ("%d adopted ranks with lists of %d-%d photons (independent lists, own clock and RNG stream each: the reference's MPI "
                      "ranks; one workgroup per list) in %s; step = one hydro frame (1/fps = %.2f s) for all lists, every pool restarted from "
                      "its resident snapshot"
                      % (main_res.get("ranks", 0), int(lens.min()), int(lens.max()),
+                        ("one rank pool and ONE launch of the loop kernel for all %d timed frames (frame queue, mcrat_hip_pool_run_frames: a workgroup per "
+                         "(frame, list) item; a list that is through frame f starts f + 1 while others are still in f -- the reference's ranks are "
+                         "asynchronous across hydro frames, mcrat.c:457-479,566-934)" % steps) if args.launch_shape == "queue" else
                         "one rank pool, all lists in one launch" if pools == 1 else
                         "%d rank pools on %d HIP streams with a host thread each (the ranks are asynchronous in the reference too: a pool whose "
                         "last lists are finishing no longer leaves the device idle), one launch per pool and frame" % (pools, pools), remaining))

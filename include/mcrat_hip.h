@@ -158,6 +158,10 @@ typedef struct mcrat_hip_frame_stats {
     long long step_kernel_launches;
     double event_kernel_ms;                  /* profile=1: summed duration of event-kernel launches */
     long long table_misses;                  /* TAU_CALCULATION == TABLE: lookups outside the table that were clamped (see mcrat_hip_set_hot_cross_section) */
+    long long slot_steps;                    /* slots actually taken through a pass, summed over the passes: = photon_steps, except that a
+                                                cyclo-synchrotron list's settled null slots behind its last photon (the half a doubled list consists of,
+                                                Src/photons.c:112-121) take no part in a pass here although the reference walks them (Src/mclib.c:620,684) --
+                                                the figure a roofline is computed from */
 } mcrat_hip_frame_stats;
 
 typedef struct mcrat_hip_ctx mcrat_hip_ctx;

@@ -199,7 +199,11 @@ struct alignas(256) LoopState {
     double t_est;                        // running estimate of the smallest free time per iteration
     int force_relocate;                  // virtual-rank mode: the next pass is the forced re-location pass of a new frame
     int photon_event_called;             // this pass took the photonEvent branch of mcrat.c:777 (the cyclo-synchrotron hook of :786 looks at it)
-    long long stamps[8];                 // diagnostic build only (-DMCRAT_DIAG): s_memtime at points of the event walk
+    union {
+        long long stamps[8];             // diagnostic build only (-DMCRAT_DIAG): s_memtime at points of the event walk
+        long long slot_steps;            // product build: slots actually taken through a pass, summed over the passes (a cyclo-synchrotron list's settled
+                                         // null slots behind its last photon are not: rank_loop_kernel, n_pass); iterations x list_capacity otherwise
+    };
 };
 
 // Candidates of one iteration.  Every slot whose free time is below LoopState::t_cut is appended here

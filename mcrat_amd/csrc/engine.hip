@@ -2345,6 +2345,7 @@ static void fill_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
     const LoopState &h = *c->h_state;
     s->iterations = h.iterations;
     s->photon_steps = h.iterations * (long long)c->ph.n;
+    s->slot_steps = h.slot_steps;
     s->frame_scatt_cnt = h.frame_scatt_cnt;
     s->num_photons_find_new_element = h.n_relocated;
     s->not_found = h.not_found;
@@ -2366,6 +2367,7 @@ static void state_to_stats(const LoopState &h, long long slots, mcrat_hip_frame_
     memset(s, 0, sizeof *s);
     s->iterations = h.iterations;
     s->photon_steps = h.iterations * slots;
+    s->slot_steps = h.slot_steps;
     s->frame_scatt_cnt = h.frame_scatt_cnt;
     s->num_photons_find_new_element = h.n_relocated;
     s->not_found = h.not_found;
@@ -2401,7 +2403,7 @@ static void fill_rank_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
     memset(&acc, 0, sizeof acc);
     for (int r = 0; r < c->n_ranks; ++r) {
         state_to_stats(c->h_rstates[r], rank_slots(c, r), &t);
-        acc.iterations += t.iterations; acc.photon_steps += t.photon_steps; acc.frame_scatt_cnt += t.frame_scatt_cnt;
+        acc.iterations += t.iterations; acc.photon_steps += t.photon_steps; acc.slot_steps += t.slot_steps; acc.frame_scatt_cnt += t.frame_scatt_cnt;
         acc.num_photons_find_new_element += t.num_photons_find_new_element; acc.not_found += t.not_found;
         acc.kn_rejections += t.kn_rejections; acc.rescans += t.rescans;
         if (r == 0 || t.remaining_time > acc.remaining_time) {
@@ -2925,7 +2927,11 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     if (const char *e = getenv("MCRAT_HIP_RANK_LAUNCH_CAP")) per_frame_cap = atoll(e) > 0 ? atoll(e) : per_frame_cap;
     const int longest = longest_rank_list(c);
     c->prof_step_ms = 0; c->prof_launches = 0;
-    int xcd_of_class[FRAME_QUEUE_XCDS];                      // which XCD's queue the lists r % 8 == k are in (identity unless an XCD turned out to start no workgroups)
+    // Which XCD a list belongs to: list r to XCD r % 8, where one launch per frame puts it too.  (Measured against contiguous eighths of the lists --
+    // neighbouring lists hold photons of neighbouring cells, so an XCD's L2 would have an eighth of the cells to hold: 0.567 against 0.52 ms per frame
+    // on the benchmark frame, the eighths differ in optical depth and the launch ends with the slowest XCD.)
+    auto list_class = [&](int r) { return r % FRAME_QUEUE_XCDS; };
+    int xcd_of_class[FRAME_QUEUE_XCDS];                      // which XCD's queue the lists of class k are in (identity unless an XCD turned out to start no workgroups)
     for (int x = 0; x < FRAME_QUEUE_XCDS; ++x) xcd_of_class[x] = x;
     std::vector<unsigned> tickets((size_t)FRAME_QUEUE_XCDS * FRAME_TICKET_STRIDE);
     for (int attempt = 0;; ++attempt) {
@@ -2935,11 +2941,12 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         for (int x = 0; x < FRAME_QUEUE_XCDS; ++x) {
             fq.order_off[x] = n_open;
             for (size_t t = 0; t < N; ++t)
-                if (h_items[t].open && xcd_of_class[(int)(t % (size_t)R) % FRAME_QUEUE_XCDS] == x) h_order[n_open++] = (int)t;
+                if (h_items[t].open && xcd_of_class[list_class((int)(t % (size_t)R))] == x) h_order[n_open++] = (int)t;
             longest_xcd = std::max(longest_xcd, n_open - fq.order_off[x]);
         }
         fq.order_off[FRAME_QUEUE_XCDS] = n_open;
         const int n_groups = FRAME_QUEUE_XCDS * longest_xcd;
+        if (n_groups == 0) break;                            // (no list opens a frame: the call has only sized the queue's buffers)
         HIPCHK(c, hipMemcpyAsync(db, hb, off_rec, hipMemcpyHostToDevice, c->stream));
         if (c->cfg.profile) {
             int rc = ensure_events(c, 2);
@@ -3017,8 +3024,7 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         it_sum += h_rec[t].iterations;
         lists += 1;
     }
-    if (lists > 0) c->rank_passes_per_list = (double)it_sum / lists;
-    c->frame_open = true;
+    if (lists > 0) { c->rank_passes_per_list = (double)it_sum / lists; c->frame_open = true; }
     c->rank_block_fixed = false;
     stats[0].step_kernel_ms = c->prof_step_ms;               // (profile = 1: the launch's duration, on the first item)
     stats[0].step_kernel_launches = c->prof_launches;
@@ -3127,6 +3133,7 @@ static void fast_stats(const FastCounts &fc, double time_now, mcrat_hip_frame_st
     memset(stats, 0, sizeof *stats);
     stats->iterations = (long long)fc.passes;
     stats->photon_steps = (long long)fc.photon_steps;
+    stats->slot_steps = (long long)fc.photon_steps;
     stats->frame_scatt_cnt = (long long)fc.scatterings;
     stats->kn_rejections = (long long)fc.kn_rejections;
     stats->num_photons_find_new_element = (long long)fc.relocated;

@@ -192,7 +192,7 @@ __device__ __forceinline__ double div_by_c(double x)
 __device__ __forceinline__ double sample_free_time(double ntau /* -1.0 / tau */, uint64_t bits)
 {
     const double rnd = bits_to_uniform_pos(bits);
-    const double mfp = ntau * log(rnd);
+    const double mfp = ntau * phys::log_unit(rnd);
     return div_by_c(mfp);
 }
 
@@ -719,10 +719,33 @@ __device__ __forceinline__ void commit_scatter(const PH &ph, int i, const double
     ph.flags(i) = (unsigned char)(cand_flags | FLAG_RECALC | FLAG_TAU_FRESH);
 }
 
+// what the walk needs from a candidate's slot: one round of independent loads (this wavefront's latency is its list's)
+struct CandCols {
+    int idx;                     // the slot these columns belong to (-1: none loaded)
+    int cell;
+    unsigned flags;
+    double p[4], r[3], pc[4], u[3], s[4];
+};
+template <bool STOKES, class PH>
+__device__ __forceinline__ void load_candidate(const PH &ph, int i, CandCols &c)
+{
+    c.idx = i;
+    c.cell = ph.idx(i);
+    c.p[0] = ph.p0(i); c.p[1] = ph.p1(i); c.p[2] = ph.p2(i); c.p[3] = ph.p3(i);
+    c.r[0] = ph.r0(i); c.r[1] = ph.r1(i); c.r[2] = ph.r2(i);
+    c.pc[0] = ph.c0(i); c.pc[1] = ph.c1(i); c.pc[2] = ph.c2(i); c.pc[3] = ph.c3(i);
+    c.flags = ph.flags(i);
+    c.u[0] = ph.u0(i); c.u[1] = ph.u1(i); c.u[2] = ph.u2(i);
+    c.s[0] = 1; c.s[1] = 0; c.s[2] = 0; c.s[3] = 0;
+    if constexpr (STOKES) { c.s[0] = ph.s0(i); c.s[1] = ph.s1(i); c.s[2] = ph.s2(i); c.s[3] = ph.s3(i); }
+}
+
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
+// `cc`: the slot's columns, loaded by the caller (event_block: the head candidate's before the shortlist is sorted, so that they arrive meanwhile)
 template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class PH, class SRC = KeyedSource>
 __device__ __forceinline__ int try_candidate(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
-                                             unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base, const SRC &src = SRC())
+                                             unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base, const SRC &src,
+                                             const CandCols &cc)
 {
     // *scattered_ph_index (mclib.c:1341) is the last candidate photonEvent looked at; main() does not call
     // photonEvent at all when even the first free time exceeds the frame (mcrat.c:777,834)
@@ -741,15 +764,13 @@ __device__ __forceinline__ int try_candidate(const PH &ph, const HydroDev &hy, L
     if (w.nseg < MAX_SEG) w.seg[w.nseg++] = this_seg;
     else w.seg[MAX_SEG - 1] += this_seg;
     w.old_scatt_time = scatt_time;
-    // one round of independent loads for everything the candidate needs (this lane's latency is the kernel's)
-    const int cell = ph.idx(i);
-    double p[4] = {ph.p0(i), ph.p1(i), ph.p2(i), ph.p3(i)};
-    double r[3] = {ph.r0(i), ph.r1(i), ph.r2(i)};
-    double pc[4] = {ph.c0(i), ph.c1(i), ph.c2(i), ph.c3(i)};
-    const unsigned cand_flags = ph.flags(i);
-    const double u0 = ph.u0(i), u1 = ph.u1(i), u2 = ph.u2(i);
-    double s[4] = {1, 0, 0, 0};
-    if constexpr (STOKES) { s[0] = ph.s0(i); s[1] = ph.s1(i); s[2] = ph.s2(i); s[3] = ph.s3(i); }
+    const int cell = cc.cell;
+    double p[4] = {cc.p[0], cc.p[1], cc.p[2], cc.p[3]};
+    double r[3] = {cc.r[0], cc.r[1], cc.r[2]};
+    double pc[4] = {cc.pc[0], cc.pc[1], cc.pc[2], cc.pc[3]};
+    const unsigned cand_flags = cc.flags;
+    const double u0 = cc.u[0], u1 = cc.u[1], u2 = cc.u[2];
+    double s[4] = {cc.s[0], cc.s[1], cc.s[2], cc.s[3]};
     if (cell == -1) return EV_RUNNING;                     // cannot scatter (documented deviation: mclib.c:1146-1148 would index [-1])
 
     if (cand_flags & FLAG_MOVES) {                         // the candidate's own position after mclib.c:1138
@@ -801,7 +822,34 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
 {
     const int tid = threadIdx.x;
     int n_list = (n_raw > BLOCK) ? 0 : n_raw;              // overflowed: incomplete, ignore it
-    if (tid < n_list) {                                    // rank sort (equal (t, idx) pairs cannot occur)
+    // The head of the sorted list is the list's minimum, which the caller already has: the walking wavefront asks for that slot's columns now, and
+    // they arrive while the shortlist is being sorted -- one dependent gather round trip (a fifth of the walk, tools/diag_event.py) off the walk.
+    CandCols head;
+    head.idx = -1;
+    if ((WAVE_WALK ? tid < 64 : tid == 0) && gmin.idx != INT_MAX) load_candidate<STOKES>(ph, gmin.idx, head);
+    constexpr int SORT_IN_REGISTERS = 16;                  // (twice the shortlist's expected length: t_cut aims at eight entries)
+    if (n_list <= SORT_IN_REGISTERS) {
+        // rank sort of a short shortlist in the walking wavefront's registers (equal (t, idx) pairs cannot occur): lane l holds entry l, every entry is
+        // broadcast with v_readlane -- straight-line code without an LDS round trip per comparison, and without a loop, at whose head the compiler
+        // would wait for the head candidate's columns asked for above
+        if (tid < 64) {
+            int lane_ = tid;                               // (opaque to the compiler: the address of sh.raw[tid], hoisted out of the pass loop, was kept in a
+            asm volatile("" : "+v"(lane_));                // spilled register -- and its scratch reload waits for every load in flight, the head's included)
+            Cand me;
+            me.t = INFINITY; me.idx = INT_MAX; me.pad = 0;
+            if (lane_ < n_list) me = sh.raw[lane_];
+            const int t_lo = (int)(unsigned)(__double_as_longlong(me.t) & 0xffffffffll), t_hi = (int)(unsigned)((unsigned long long)__double_as_longlong(me.t) >> 32);
+            int rank = 0;
+#pragma unroll
+            for (int j = 0; j < SORT_IN_REGISTERS; ++j) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(t_lo, j), hi = (unsigned)__builtin_amdgcn_readlane(t_hi, j);
+                const double tj = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+                const int ij = __builtin_amdgcn_readlane(me.idx, j);
+                rank += cand_less(tj, ij, me.t, me.idx) ? 1 : 0;
+            }
+            if (lane_ < n_list) sh.list[rank] = me;
+        }
+    } else if (tid < n_list) {                             // ... of a long one through LDS
         const Cand me = sh.raw[tid];
         int rank = 0;
         for (int j = 0; j < n_list; ++j) rank += cand_less(sh.raw[j].t, sh.raw[j].idx, me.t, me.idx) ? 1 : 0;
@@ -841,7 +889,8 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
                 status = EV_DONE;
             }
             for (int c = 0; c < n_list && status == EV_NEED_MORE; ++c) {
-                if (try_candidate<DIMS, GEOM, STOKES, WAVE_WALK>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base, src) == EV_DONE)
+                if (head.idx != list[c].idx) load_candidate<STOKES>(ph, list[c].idx, head);      // (the head of the first round is at hand)
+                if (try_candidate<DIMS, GEOM, STOKES, WAVE_WALK>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base, src, head) == EV_DONE)
                     status = EV_DONE;
             }
             if (status == EV_NEED_MORE) {
@@ -880,6 +929,9 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
         st->last_time_step = w.dt;
         st->iteration = iter + 1;
         st->iterations += 1;
+#ifndef MCRAT_DIAG
+        st->slot_steps += n;
+#endif
         st->done = !(rem > 0);
         st->nseg = w.nseg;
         for (int s = 0; s < MAX_SEG; ++s) st->seg[s] = (s < w.nseg) ? w.seg[s] : 0.0;
@@ -1003,7 +1055,7 @@ __global__ __launch_bounds__(TAPE_BLOCK) void tape_draw_kernel(PhotonDev ph, con
         if (valid) {
             double t = ph.tts[i];                                          // slots without a cell: 1e12 / c, stored by step_kernel (mclib.c:620,684)
             if (located) {
-                t = div_by_c(ph.ntau[i] * log(s_u[rank]));                 // mclib.c:675-687
+                t = div_by_c(ph.ntau[i] * phys::log_unit(s_u[rank]));                 // mclib.c:675-687
                 ph.tts[i] = t;
             }
             best.offer(t, i);
@@ -1228,8 +1280,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         for (int pair = tid - first_thread; 2 * pair < n_pass; pair += n_threads) {
             const Philox4 blk = keyed_block(rk.seed, it, (uint32_t)pair, RNG_FREEPATH, rk.stream);
             const int i = base + 2 * pair;
-            ph.draw_log(i) = log(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32)));
-            if (2 * pair + 1 < n) ph.draw_log(i + 1) = log(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32)));
+            ph.draw_log(i) = phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32)));
+            if (2 * pair + 1 < n) ph.draw_log(i + 1) = phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32)));
         }
     };
     if constexpr (SHADOW) {
@@ -1363,8 +1415,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
 #pragma unroll
                         for (int j = 0; j < PAIRS; ++j) {
                             const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)(pair + j * EVENT_BLOCK), RNG_FREEPATH, rk.stream);
-                            bits[2 * j] = (uint64_t)__double_as_longlong(log(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32))));
-                            bits[2 * j + 1] = (uint64_t)__double_as_longlong(log(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))));
+                            bits[2 * j] = (uint64_t)__double_as_longlong(phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32))));
+                            bits[2 * j + 1] = (uint64_t)__double_as_longlong(phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))));
                         }
                     }
                     // decisions, slot by slot
@@ -2116,6 +2168,9 @@ __global__ __launch_bounds__(EVENT_BLOCK) void sc_resolve_kernel(PhotonDev ph, H
         st->last_time_step = dt;
         st->iteration = iter + 1;
         st->iterations += 1;
+#ifndef MCRAT_DIAG
+        st->slot_steps += ph.n;
+#endif
         st->done = !(rem > 0) ? LOOP_DONE : 0;
         st->skip_idx = skip;
         if (t_first < INFINITY) {

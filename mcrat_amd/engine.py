@@ -81,7 +81,7 @@ class FrameStats(C.Structure):
                 ("last_scattered_index", C.c_int), ("last_scattered_temp", C.c_double),
                 ("last_time_step", C.c_double), ("remaining_time", C.c_double), ("time_now", C.c_double),
                 ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_longlong), ("event_kernel_ms", C.c_double),
-                ("table_misses", C.c_longlong)]
+                ("table_misses", C.c_longlong), ("slot_steps", C.c_longlong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
