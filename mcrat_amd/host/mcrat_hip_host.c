@@ -542,7 +542,7 @@ static void *checkpoint_slice(void *p)
 {
     out_slice *sl = (out_slice *)p;
     out_job *j = sl->job;
-    for (int r = sl->first; r < j->n_ranks && j->rc == 0; r += sl->step) {
+    for (int r = sl->first; r < j->n_ranks && __atomic_load_n(&j->rc, __ATOMIC_RELAXED) == 0; r += sl->step) {
         const out_rank_meta *k = &j->meta[r];
         if (!k->active) continue;
         mcrat_hip_photon_list l;
@@ -552,7 +552,7 @@ static void *checkpoint_slice(void *p)
         if (k->fPtr) fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: Making checkpoint file\n", k->angle_id, k->deg_lo, k->deg_hi);
         if (mcrat_host_save_checkpoint(k->mc_dir, k->frame, k->frm2, j->F, k->time_now, NULL, &l, l.list_capacity, j->last_frm, k->angle_id, k->angle_procs, 0) != 0) {
             if (k->fPtr) fprintf(k->fPtr, "There is an issue with opening and saving the chkpt file therefore MCRaT is not saving data to the checkpoint or mc_proc files to prevent corruption of those data.\n");
-            j->rc = 1;
+            __atomic_store_n(&j->rc, 1, __ATOMIC_RELAXED);                 /* (several helper threads may get here) */
         }
     }
     return NULL;
@@ -571,8 +571,13 @@ static int write_frame_files(out_job *j)
             if (!sl[t].started && (t + 1 < T || j->print_photons)) checkpoint_slice(&sl[t]);     /* no thread to be had: here */
         }
         if (!j->print_photons) checkpoint_slice(&sl[T - 1]);                                   /* (the last slice on this thread when it has nothing else to do) */
+        /* Every checkpoint of the frame before the first mc_proc dataset of the frame, as in the reference (mcrat.c:902-915: saveCheckpoint, and
+         * printPhotons only if it succeeded -- "not saving data ... to prevent corruption"): were a rank's datasets appended while another rank's
+         * checkpoint fails, a restart from the older checkpoints would append frame F to that rank's file a second time. */
+        for (int t = 0; t < T; t++)
+            if (sl[t].started) { pthread_join(sl[t].thread, NULL); sl[t].started = 0; }
     }
-    if (j->print_photons) {
+    if (j->print_photons && __atomic_load_n(&j->rc, __ATOMIC_RELAXED) == 0) {
         size_t first = 0;
         for (int r = 0; r < j->n_ranks && j->rc == 0; r++) {
             const out_rank_meta *k = &j->meta[r];

@@ -101,6 +101,15 @@ int mcrat_host_read_checkpoint(const char *dir, mcrat_hip_photon_list *list, int
 int mcrat_host_print_photons(mcrat_hip_ctx *ctx, int frame, const char *dir, int angle_rank, int comv_switch, int stokes_switch,
                              int save_type, FILE *fPtr);
 int mcrat_host_h5_read(const char *file, const char *group, const char *name, int is_char, void *data, int cap, int *n);
+/* HDF5's default build is not thread-safe, and mcrat_host_run_ranks with asynchronous output has its writer thread in print_photons (frame F)
+ * while the calling thread is in get_hydro (frame F + 1) -- with several pools per process, several of each.  Every function of
+ * libmcrat_hip_host_h5 that enters HDF5 (mcrat_host_print_photons, _print_photon_arrays, _h5_read, _read_flash, _read_chombo) therefore takes ONE
+ * process-wide recursive lock.  A caller whose own get_hydro / print_photons callbacks call HDF5 directly must bracket those calls with
+ * mcrat_host_h5_lock() / mcrat_host_h5_unlock() (or run with sync_output = 1 and one pool per process).  mcrat_host_h5_threadsafe(): what
+ * H5is_library_threadsafe says about the library this build links. */
+void mcrat_host_h5_lock(void);
+void mcrat_host_h5_unlock(void);
+int  mcrat_host_h5_threadsafe(void);
 /* the HDF5 half alone, on arrays the caller holds (cols->count photons, NULL columns skipped): what mcrat_host_run_ranks calls per rank
  * with slices of ONE mcrat_hip_get_output of the whole pool */
 int mcrat_host_print_photon_arrays(const mcrat_hip_output_columns *cols, int frame, const char *dir, int angle_rank, FILE *fPtr);
@@ -244,7 +253,10 @@ typedef struct mcrat_host_pool_config {
      * own) when they are written, i.e. possibly after the next frame's first lines.  An error of the writer ends the run at the next frame.
      * sync_output = 1: the reference's order -- the loop waits for the files (records staged in pieces of 2^20 slots: the choice for pools whose
      * records do not fit pinned memory twice).  output_threads: threads that share the ranks' checkpoint files (0: 4); printPhotons is always
-     * called from one thread, one rank after the other. */
+     * called from one thread, one rank after the other, and only after every checkpoint of the frame has been written (the reference's order,
+     * mcrat.c:902-915: a failed checkpoint means no mc_proc data of that frame for any rank).  CONCURRENCY: with sync_output = 0 the caller's
+     * print_photons (writer thread, frame F) and get_hydro (calling thread, frame F + 1) run at the same time; the library's own HDF5 functions
+     * serialise on one lock, callbacks that use HDF5 themselves take mcrat_host_h5_lock (above). */
     int    sync_output, output_threads;
     /* out */
     long long hydro_frames_read;         /* get_hydro calls */

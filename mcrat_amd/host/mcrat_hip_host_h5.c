@@ -7,8 +7,39 @@
 #include "mcrat_hip_host.h"
 
 #include <hdf5.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* ONE lock around everything in this file that enters the HDF5 library.  HDF5's default build is not thread-safe (H5is_library_threadsafe), and
+ * mcrat_host_run_ranks' writer thread calls print_photons for frame F while the calling thread reads frame F + 1 (get_hydro -> mcrat_host_read_flash /
+ * mcrat_host_read_chombo) -- with two pools per process two writers and two readers: four threads in a library that keeps global ID tables.  The lock
+ * is recursive (mcrat_host_print_photons -> mcrat_host_print_photon_arrays) and exported: a caller whose own get_hydro / print_photons callbacks
+ * call HDF5 directly brackets those calls with mcrat_host_h5_lock / _unlock. */
+static pthread_mutex_t g_h5_mutex;
+static pthread_once_t g_h5_once = PTHREAD_ONCE_INIT;
+static void h5_mutex_init(void)
+{
+    pthread_mutexattr_t a;
+    pthread_mutexattr_init(&a);
+    pthread_mutexattr_settype(&a, PTHREAD_MUTEX_RECURSIVE);
+    pthread_mutex_init(&g_h5_mutex, &a);
+    pthread_mutexattr_destroy(&a);
+}
+void mcrat_host_h5_lock(void)
+{
+    pthread_once(&g_h5_once, h5_mutex_init);
+    pthread_mutex_lock(&g_h5_mutex);
+}
+void mcrat_host_h5_unlock(void) { pthread_mutex_unlock(&g_h5_mutex); }
+int mcrat_host_h5_threadsafe(void)
+{
+    hbool_t ts = 0;
+    mcrat_host_h5_lock();
+    const herr_t e = H5is_library_threadsafe(&ts);
+    mcrat_host_h5_unlock();
+    return (e >= 0 && ts) ? 1 : 0;
+}
 
 /* one dataset of the frame's group: created chunked and unlimited on first use (:252-262), otherwise extended by `n` and
  * written at the old end (:402-424) */
@@ -55,10 +86,11 @@ int mcrat_host_print_photon_arrays(const mcrat_hip_output_columns *cols, int fra
     char file[2000], group[64];
     snprintf(file, sizeof file, "%s%s%d%s", dir, "mc_proc_", angle_rank, ".h5");
     snprintf(group, sizeof group, "%d", frame);
+    mcrat_host_h5_lock();
     H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
     hid_t f = H5Fcreate(file, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT);           /* :199-206 */
     if (f < 0) f = H5Fopen(file, H5F_ACC_RDWR, H5P_DEFAULT);
-    if (f < 0) return MCRAT_HIP_EINVAL;
+    if (f < 0) { mcrat_host_h5_unlock(); return MCRAT_HIP_EINVAL; }
     hid_t g = (H5Lexists(f, group, H5P_DEFAULT) > 0) ? H5Gopen2(f, group, H5P_DEFAULT) : H5Gcreate2(f, group, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
     int bad = g < 0;
     static const char *names[17] = {"P0", "P1", "P2", "P3", "COMV_P0", "COMV_P1", "COMV_P2", "COMV_P3", "R0", "R1", "R2",
@@ -70,6 +102,7 @@ int mcrat_host_print_photon_arrays(const mcrat_hip_output_columns *cols, int fra
     if (!bad && cols->type) bad = put(g, "PT", H5T_NATIVE_CHAR, cols->type, (hsize_t)n) != 0;
     if (g >= 0) H5Gclose(g);
     H5Fclose(f);
+    mcrat_host_h5_unlock();
     return bad ? MCRAT_HIP_EINVAL : MCRAT_HIP_OK;
 }
 
@@ -108,9 +141,10 @@ int mcrat_host_print_photons(mcrat_hip_ctx *ctx, int frame, const char *dir, int
 int mcrat_host_h5_read(const char *file, const char *group, const char *name, int is_char, void *data, int cap, int *n)
 {
     if (!file || !group || !name || !n) return MCRAT_HIP_EINVAL;
+    mcrat_host_h5_lock();
     H5Eset_auto2(H5E_DEFAULT, NULL, NULL);
     hid_t f = H5Fopen(file, H5F_ACC_RDONLY, H5P_DEFAULT);
-    if (f < 0) return MCRAT_HIP_EINVAL;
+    if (f < 0) { mcrat_host_h5_unlock(); return MCRAT_HIP_EINVAL; }
     int rc = MCRAT_HIP_EINVAL;
     hid_t g = H5Gopen2(f, group, H5P_DEFAULT);
     if (g >= 0) {
@@ -129,6 +163,7 @@ int mcrat_host_h5_read(const char *file, const char *group, const char *name, in
         H5Gclose(g);
     }
     H5Fclose(f);
+    mcrat_host_h5_unlock();
     return rc;
 }
 
@@ -169,7 +204,7 @@ void mcrat_host_free_flash(mcrat_host_flash *f)
     memset(f, 0, sizeof *f);
 }
 
-int mcrat_host_read_flash(const char *file, double l_scale, double d_scale, double p_scale, mcrat_host_flash *out)
+static int read_flash_locked(const char *file, double l_scale, double d_scale, double p_scale, mcrat_host_flash *out)
 {
     if (!file || !out) return -2;
     memset(out, 0, sizeof *out);
@@ -216,7 +251,7 @@ static int attr_read(hid_t obj, const char *name, hid_t type, void *out)
     return st < 0 ? -1 : 0;
 }
 
-int mcrat_host_read_chombo(const char *file, int three_dimensional, double l_scale, double d_scale, double p_scale, mcrat_host_chombo *out)
+static int read_chombo_locked(const char *file, int three_dimensional, double l_scale, double d_scale, double p_scale, mcrat_host_chombo *out)
 {
     if (!file || !out) return -2;
     memset(out, 0, sizeof *out);
@@ -307,5 +342,22 @@ done:
     H5Tclose(box_t);
     H5Fclose(f);
     if (rc) mcrat_host_free_chombo(out);
+    return rc;
+}
+
+/* (the public readers: the same under the library-wide HDF5 lock, see the top of this file) */
+int mcrat_host_read_flash(const char *file, double l_scale, double d_scale, double p_scale, mcrat_host_flash *out)
+{
+    mcrat_host_h5_lock();
+    const int rc = read_flash_locked(file, l_scale, d_scale, p_scale, out);
+    mcrat_host_h5_unlock();
+    return rc;
+}
+
+int mcrat_host_read_chombo(const char *file, int three_dimensional, double l_scale, double d_scale, double p_scale, mcrat_host_chombo *out)
+{
+    mcrat_host_h5_lock();
+    const int rc = read_chombo_locked(file, three_dimensional, l_scale, d_scale, p_scale, out);
+    mcrat_host_h5_unlock();
     return rc;
 }

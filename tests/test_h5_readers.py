@@ -132,3 +132,70 @@ def test_pluto_chombo_file(h5, oracle, tmp_path, three):
     assert h5.mcrat_host_read_chombo(b"/nonexistent", int(three), 1.0, 1.0, 1.0, C.byref(hc)) == -1
     if not three:                       # a 2-D file has no lo_k / hi_k members and no domBeg3: it cannot be read as 3-D
         assert h5.mcrat_host_read_chombo(path, 1, 1.0, 1.0, 1.0, C.byref(hc)) == -2
+
+
+def test_writers_and_readers_in_several_threads(h5, tmp_path):
+    """mcrat_host_run_ranks' asynchronous output has print_photons (writer thread, frame F) and get_hydro -> mcrat_host_read_flash (calling thread,
+    frame F + 1) in HDF5 at the same time, two of each with two pools per process; the default HDF5 build is not thread-safe, so the library
+    serialises its own HDF5 entry points on one lock (mcrat_hip_host_h5.c).  Four threads hammer them here on real files; every call must succeed
+    and every file must hold what was written (without the lock this crashes or corrupts HDF5's ID tables within a few hundred calls)."""
+    import threading
+    e = h5.engine
+    raw = synth.flash_raw_blocks(2e9, 8, 16, 8, 1e12 - 1.6e10, seed=3)
+    keep = []
+
+    def ptr(a, dtype=np.float64, ctype=C.c_double):
+        arr = np.ascontiguousarray(a, dtype=dtype)
+        keep.append(arr)
+        return arr.ctypes.data_as(C.POINTER(ctype))
+    n = len(raw["node_type"])
+    b = e.FlashBlocks(n, 3, 2, ptr(raw["coordinates"]), ptr(raw["block_size"]), ptr(raw["node_type"], np.int32, C.c_int), ptr(raw["velx"]),
+                      ptr(raw["vely"]), ptr(raw["dens"]), ptr(raw["pres"]), 1.0, 1.0, 1.0)
+    flash = str(tmp_path / "frame_0001").encode()
+    assert h5.writer.fixture_write_flash(flash, C.byref(b)) == 0
+    h5.mcrat_host_print_photon_arrays.restype = C.c_int
+    h5.mcrat_host_print_photon_arrays.argtypes = [C.POINTER(e.OutputColumns), C.c_int, C.c_char_p, C.c_int, C.c_void_p]
+    h5.mcrat_host_h5_read.restype = C.c_int
+    h5.mcrat_host_h5_read.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    h5.mcrat_host_h5_threadsafe.restype = C.c_int
+    assert h5.mcrat_host_h5_threadsafe() in (0, 1)
+    h5.mcrat_host_h5_lock()                                 # the lock is recursive and exported for callers' own HDF5 calls
+    h5.mcrat_host_h5_lock()
+    h5.mcrat_host_h5_unlock()
+    h5.mcrat_host_h5_unlock()
+    frames, m = 40, 257
+    errors = []
+
+    def writer(rank):
+        rng = np.random.default_rng(rank)
+        for f in range(frames):
+            cols = e.OutputColumns()
+            cols.count = m
+            arrs = {}
+            for k, name in enumerate(e.OUTPUT_COLUMNS):
+                arrs[name] = np.full(m, 1000.0 * rank + f + 0.001 * k) + rng.random(m) * 0.0
+                setattr(cols, name, arrs[name].ctypes.data_as(C.POINTER(C.c_double)))
+            cols.type = None
+            rc = h5.mcrat_host_print_photon_arrays(C.byref(cols), f, (str(tmp_path) + "/").encode(), rank, None)
+            if rc:
+                errors.append(("print", rank, f, rc))
+
+    def reader(k):
+        for f in range(frames):
+            hf = h5.HostFlash()
+            rc = h5.mcrat_host_read_flash(flash, 1.0, 1.0, 1.0, C.byref(hf))
+            if rc or hf.blocks.n_blocks != n or not np.array_equal(np.ctypeslib.as_array(hf.blocks.dens, shape=(n, 1, 8, 8)), raw["dens"]):
+                errors.append(("read", k, f, rc))
+            h5.mcrat_host_free_flash(C.byref(hf))
+    threads = [threading.Thread(target=writer, args=(r,)) for r in (0, 1)] + [threading.Thread(target=reader, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+    for rank in (0, 1):
+        for f in (0, frames - 1):
+            out = np.zeros(m)
+            got = C.c_int(0)
+            assert h5.mcrat_host_h5_read((str(tmp_path) + "/mc_proc_%d.h5" % rank).encode(), str(f).encode(), b"P0", 0, out.ctypes.data, m, C.byref(got)) == 0
+            assert got.value == m and np.all(out == 1000.0 * rank + f)
