@@ -463,7 +463,9 @@ int mcrat_hip_propagate_frame(mcrat_hip_ctx *ctx, double *time_now, double remai
  * the exact mode within Monte-Carlo error (tests/test_gpu_fast_mode.py), single photons do not.  fast_windows is how often
  * per frame a photon's cell and optical depth are refreshed besides after its own scatterings; the reference refreshes them whenever
  * any photon of the rank scatters, i.e. -- for its ranks of about 1000 photons -- as often as the frame has scatterings per 1000 photons.
- * fast_windows <= 0 follows that: the scatterings per 1000 photons of the context's previous FAST frame, between 8 and 2048 (32 for the
+ * fast_windows <= 0 follows that: the scatterings per 1000 photons of the LIST's previous FAST frame (a pool's list: kept on its view, so that a
+ * list's photons do not depend on which other lists share the pool; mcrat_hip_fast_cadence reads and sets it -- a driver that restarts a run hands
+ * the value back, or the restarted list begins at 32 again), between 8 and 2048 (32 for the
  * first frame); a fixed 8 is biased by about a per cent in frames with tens of scatterings per photon.  Works on a single list, virtual ranks or a rank pool alike (the lists do not matter to it);
  * refuses cyclo-synchrotron contexts and an attached shared clock.  stats: iterations = passes of the longest-running workgroup,
  * photon_steps = free-path draws, frame_scatt_cnt, kn_rejections, num_photons_find_new_element, not_found. */
@@ -478,6 +480,8 @@ int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *ctx, double *time_now, double 
  * for every list that holds photons with one seed and one frame time. */
 int mcrat_hip_pool_propagate_frames_fast(mcrat_hip_ctx *pool, const int *open, const uint64_t *seeds, const double *time_now,
                                          const double *remaining_time, int fast_windows, mcrat_hip_frame_stats *stats);
+/* the learnt refresh cadence of a list (a context holding one list, or a view of a pool): returns it; set_windows > 0 sets it first (clamped to 8..2048) */
+int mcrat_hip_fast_cadence(mcrat_hip_ctx *ctx, int set_windows);
 
 /* the same loop in pieces, for bounded runs (benchmarks, tests, progress logging):
  * begin_frame resets the per-frame state; each run executes at most max_iterations

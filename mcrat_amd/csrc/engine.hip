@@ -3147,11 +3147,14 @@ static void fast_stats(const FastCounts &fc, double time_now, mcrat_hip_frame_st
 // path whenever ANY photon of its rank scatters -- N_events(rank, frame) times per frame, for the reference's ranks of about 1000 photons that
 // is the frame's scatterings per 1000 photons.  A fixed 8 is right for thin frames and biased by a per cent in dense ones (the Lundman run's first
 // frames: 68.0 scatterings per photon against the exact mode's 67.3; 128 windows give 67.3).  So the cadence follows the frame: the scatterings per
-// 1000 photons the context's LAST fast frame counted, between 8 and 128 (beyond which the run above no longer changes), 32 before any frame has run.
+// 1000 photons the LIST's last fast frame counted (fast_cadence_learn below), between 8 and 2048, 32 before any frame has run.
 static int fast_cadence(const mcrat_hip_ctx *c, int fast_windows)
 {
     return fast_windows > 0 ? fast_windows : c->fast_auto_windows;
 }
+// The cadence is a property of the LIST (kept on its context -- a pool's list: on its view): what a 10^3-photon rank of the exact mode would have
+// refreshed in the frame this list has just seen -- its own scatterings per thousand of its own photons, between 8 and 2048 windows.  A list's
+// photons therefore do not depend on which other lists share its pool, and mcrat_hip_fast_cadence carries the value over a restart.
 static void fast_cadence_learn(mcrat_hip_ctx *c, unsigned long long scatterings, long long photons)
 {
     if (photons <= 0) return;
@@ -3159,6 +3162,13 @@ static void fast_cadence_learn(mcrat_hip_ctx *c, unsigned long long scatterings,
     // (the upper end: at 7 300 scatterings per thousand photons and frame 128 windows still count 0.14 % too many scatterings, 512 0.05 %, 2048 none --
     // tools/fast_cadence_gate.py, 1.9e7 events -- and 2048 windows are still faster than the exact loop there)
     c->fast_auto_windows = per_thousand < 8.0 ? 8 : (per_thousand > 2048.0 ? 2048 : (int)(per_thousand + 0.5));
+}
+
+extern "C" int mcrat_hip_fast_cadence(mcrat_hip_ctx *c, int set_windows)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (set_windows > 0) c->fast_auto_windows = set_windows < 8 ? 8 : (set_windows > 2048 ? 2048 : set_windows);
+    return c->fast_auto_windows;
 }
 
 // MCRAT_HIP_MODE_FAST for the lists of a rank pool, one launch: list r (open[r] != 0) runs its frame of remaining_time[r] with its own seed
@@ -3181,15 +3191,20 @@ extern "C" int mcrat_hip_pool_propagate_frames_fast(mcrat_hip_ctx *c, const int 
         c->h_desc[r].len = v->ph.n; c->h_desc[r].stream = v->key.stream; c->h_desc[r].seed = seeds[r];
         rem[(size_t)r] = remaining_time[r] > 0 ? remaining_time[r] : 0.0;
     }
-    const size_t bytes = (sizeof(FastCounts) + sizeof(double)) * (size_t)R;
+    std::vector<int> win((size_t)R, 8);                      // every list its own cadence (fast_cadence_learn): as its view run alone would have
+    for (int r = 0; r < R; ++r)
+        if (open[r]) win[(size_t)r] = fast_cadence(c->views[r], fast_windows);
+    const size_t bytes = (sizeof(FastCounts) + sizeof(double) + sizeof(int)) * (size_t)R;
     if ((rc = ensure_aos(c, bytes + 64))) return rc;
     FastCounts *d_cnt = static_cast<FastCounts *>(c->aos_buf);
     double *d_rem = reinterpret_cast<double *>(d_cnt + R);
+    int *d_win = reinterpret_cast<int *>(d_rem + R);
     HIPCHK(c, hipMemsetAsync(d_cnt, 0, sizeof(FastCounts) * (size_t)R, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_rem, rem.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_win, win.data(), sizeof(int) * (size_t)R, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
-    const FastLists lists{c->rank_stride, c->d_desc, d_rem};
-    HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, c->key, 0.0, fast_cadence(c, fast_windows), 1 << 22, d_cnt, lists, c->stream));
+    const FastLists lists{c->rank_stride, c->d_desc, d_rem, d_win};
+    HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, c->key, 0.0, 8, 1 << 22, d_cnt, lists, c->stream));
     std::vector<FastCounts> cnt((size_t)R);
     HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, sizeof(FastCounts) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -3202,9 +3217,10 @@ extern "C" int mcrat_hip_pool_propagate_frames_fast(mcrat_hip_ctx *c, const int 
         v->frame_open = false; v->pending_applied = false; v->rank_current = true;
         unfinished += cnt[(size_t)r].unfinished;
         scatterings += cnt[(size_t)r].scatterings; photons += v->ph.n;
+        if (rem[(size_t)r] > 0) fast_cadence_learn(v, cnt[(size_t)r].scatterings, v->ph.n);
         if (stats) fast_stats(cnt[(size_t)r], time_now[r] + rem[(size_t)r], &stats[r]);
     }
-    fast_cadence_learn(c, scatterings, photons);
+    (void)scatterings; (void)photons;
     if (unfinished) { c->last_error = "FAST mode: photons left with frame time after 2^22 passes (an optical depth of infinity?)"; return MCRAT_HIP_ESTATE; }
     return MCRAT_HIP_OK;
 }
@@ -3251,7 +3267,7 @@ extern "C" int mcrat_hip_propagate_frame_mode(mcrat_hip_ctx *c, double *time_now
     FastCounts fc{};
     if (remaining_time > 0) {
         HIPCHK(c, launch_fast_frame(c->kc, c->ph, c->hy, key, remaining_time, fast_cadence(c, fast_windows), 1 << 22,
-                                    static_cast<FastCounts *>(c->d_fast), FastLists{0, nullptr, nullptr}, c->stream));
+                                    static_cast<FastCounts *>(c->d_fast), FastLists{0, nullptr, nullptr, nullptr}, c->stream));
         HIPCHK(c, hipMemcpyAsync(&fc, c->d_fast, sizeof fc, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -1753,6 +1753,7 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
         first = r * lists.stride;
         len = d.len;
         remaining_time = lists.remaining_time[r];
+        if (lists.windows) windows = lists.windows[r];                // the list's own refresh cadence (what IT looked like last frame, not the pool)
         if (len <= 0 || !(remaining_time > 0)) return;
         key.seed = d.seed; key.stream = d.stream; key.slot_base = 0;
         counts += r;

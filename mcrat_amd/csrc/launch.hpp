@@ -84,7 +84,7 @@ hipError_t launch_sc_wait(unsigned long long *my_flags, const ScProposal *recv, 
 struct FastCounts { unsigned long long photon_steps, scatterings, kn_rejections, relocated, not_found, unfinished, passes; };
 // desc != nullptr: the photons are the lists of a rank pool (list r in slots [r * stride, r * stride + desc[r].len), stride a multiple of 256);
 // every list then has its own seed and stream (desc), its own frame time and its own counters (counts[r]); lists with len 0 or no time stand still
-struct FastLists { int stride; const RankDesc *desc; const double *remaining_time; };
+struct FastLists { int stride; const RankDesc *desc; const double *remaining_time; const int *windows; };   // windows: per list (nullptr: the launch's)
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,
                              int max_passes, FastCounts *counts, const FastLists &lists, hipStream_t stream);
 // one list over several GPUs with one clock: {step, midpass re-read, proposal of this GPU's earliest candidates} ...

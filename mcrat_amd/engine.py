@@ -234,6 +234,7 @@ SYMBOLS = {
     "mcrat_hip_share_hydro": (C.c_int, [_ctx, _ctx]),
     "mcrat_hip_propagate_frame": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.POINTER(FrameStats)]),
     "mcrat_hip_propagate_frame_mode": (C.c_int, [_ctx, _dp, C.c_double, C.c_uint64, C.c_int, C.c_int, C.POINTER(FrameStats)]),
+    "mcrat_hip_fast_cadence": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_pool_propagate_frames_fast": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_uint64), _dp, _dp, C.c_int, C.POINTER(FrameStats)]),
     "mcrat_hip_begin_frame": (C.c_int, [_ctx, C.c_uint64, C.c_double, C.c_double]),
     "mcrat_hip_run": (C.c_int, [_ctx, C.c_longlong, C.POINTER(FrameStats)]),
@@ -769,6 +770,10 @@ class Engine:
         self._check(self.lib.mcrat_hip_propagate_frame_mode(self.ctx, C.byref(tn), float(remaining_time), int(seed), MODE_FAST, int(windows),
                                                             C.byref(st)), "propagate_frame_mode")
         return tn.value, st
+
+    def fast_cadence(self, set_windows=0):
+        """the list's learnt FAST refresh cadence (windows per frame); set_windows > 0 sets it (a restarted run hands the value back)"""
+        return int(self.lib.mcrat_hip_fast_cadence(self.ctx, int(set_windows)))
 
     def pool_propagate_frames_fast(self, open_, seeds, time_now, remaining_time, windows=0):
         """FAST mode for the lists of the pool, each with its own seed and frame time -> per-list FrameStats"""

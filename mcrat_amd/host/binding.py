@@ -21,9 +21,10 @@ class HostRank(C.Structure):
                 ("ph_weight_suggest", C.c_double), ("framestart", C.c_int), ("frm2", C.c_int),
                 ("rng_seed", C.c_uint64), ("rng_stream", C.c_uint32), ("fPtr", C.c_void_p),
                 ("restrt", C.c_char), ("scatt_framestart", C.c_int), ("time_now_start", C.c_double), ("restart_list", C.POINTER(engine.PhotonList)),
+                ("fast_cadence_start", C.c_int),
                 ("view", C.c_void_p), ("frame", C.c_int), ("scatt_frame", C.c_int), ("time_now", C.c_double),
                 ("num_photons", C.c_int), ("ph_weight", C.c_double), ("seeds_drawn", C.c_longlong),
-                ("frame_scatt_cnt_total", C.c_longlong), ("scatt_cyclosynch_num_ph", C.c_int), ("first_scatt_frame", C.c_int),
+                ("frame_scatt_cnt_total", C.c_longlong), ("fast_cadence", C.c_int), ("scatt_cyclosynch_num_ph", C.c_int), ("first_scatt_frame", C.c_int),
                 ("cyclosynch_emitted_total", C.c_longlong), ("cyclosynch_absorbed_total", C.c_longlong), ("state", C.c_int)]
 
 

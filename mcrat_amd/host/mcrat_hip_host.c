@@ -744,6 +744,7 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     for (int r = 0; r < n_ranks && rc == 0; r++) {
         mcrat_host_rank *k = &ranks[r];
         rc = mcrat_hip_pool_rank(pool, r, k->rng_stream, &k->view);
+        if (rc == 0 && k->fast_cadence_start > 0) (void)mcrat_hip_fast_cadence(k->view, k->fast_cadence_start);
         k->frame = k->framestart;
         k->state = 0;
         k->seeds_drawn = 0;
@@ -882,6 +883,8 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
             }
             if (!cfg->cyclosynchrotron_switch && cfg->mode == MCRAT_HIP_MODE_FAST) {
                 if ((rc = mcrat_hip_pool_propagate_frames_fast(pool, open, seeds, t_now, t_rem, cfg->fast_windows, stats))) break;
+                for (int r = 0; r < n_ranks; r++)
+                    if (open[r] && ranks[r].view) ranks[r].fast_cadence = mcrat_hip_fast_cadence(ranks[r].view, 0);
             } else if (!cfg->cyclosynchrotron_switch) {
                 if ((rc = mcrat_hip_pool_begin_frames(pool, open, seeds, t_now, t_rem))) break;  /* every list's begin_frame, one launch */
                 mcrat_hip_frame_stats tot;

@@ -192,6 +192,9 @@ typedef struct mcrat_host_rank {
     int      scatt_framestart;
     double   time_now_start;
     const mcrat_hip_photon_list *restart_list;
+    int      fast_cadence_start;         /* MCRAT_HIP_MODE_FAST with fast_windows <= 0: the list's learnt refresh cadence when the run was interrupted
+                                            (fast_cadence below, as the previous run left it) -- handed back so that a restarted run goes on as the
+                                            uninterrupted one would have; 0: none known (a fresh list starts at 32 windows) */
     /* progress (driver-owned; zero it before the first call) */
     mcrat_hip_ctx *view;
     int      frame, scatt_frame;         /* the loop variables of mcrat.c:609,:664 */
@@ -200,6 +203,7 @@ typedef struct mcrat_host_rank {
     double   ph_weight;                  /* the adjusted weight of the injection */
     long long seeds_drawn;
     long long frame_scatt_cnt_total;     /* scatterings over all frames (for callers' accounting) */
+    int      fast_cadence;               /* FAST mode: the list's learnt refresh cadence after its last frame (mcrat_hip_fast_cadence) */
     int      scatt_cyclosynch_num_ph;    /* main()'s counter of comptonised photons, carried over the scatter frames of an injection (mcrat.c:873,921) */
     int      first_scatt_frame;          /* scatt_framestart of the running batch: no pool emission in that frame (mcrat.c:707) */
     long long cyclosynch_emitted_total, cyclosynch_absorbed_total;

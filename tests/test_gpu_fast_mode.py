@@ -272,3 +272,47 @@ def test_learnt_cadence_matches_the_exact_loop_on_a_dense_run_of_ten_million_eve
     sigma = np.hypot(err["exact"], err["auto"])
     assert abs(mean["auto"] - mean["exact"]) < 4 * sigma, (mean, err)
     assert abs(mean["fixed-8"] - mean["exact"]) > 10 * sigma, (mean, err)
+
+
+def test_the_learnt_cadence_belongs_to_the_list_not_to_the_pool(hip):
+    """fast_windows <= 0 learns the refresh cadence from the frame before -- of THAT list: a dense list sharing a pool with a thin one must run its second
+    frame exactly as it does alone in a context of its own (round 3 learnt one number from the summed scatterings of all adopted ranks: a rank's
+    photons then depended on which other ranks the process had adopted), and a restarted run that hands the value back (mcrat_hip_fast_cadence)
+    goes on as the uninterrupted one."""
+    dense, ph_d, cfg = synth.config2(n_photons=6_000, nzc=16, stokes=0, lumi=1e53)
+    rem = 1.0 / dense["fps"]
+    # the photons as list 0 of a pool whose list 1 holds photons that hardly scatter on the same frame (far outside the jet's core)
+    pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    pool.set_hydro(dense)
+    pool.pool_create(2, 6_144)
+    v0, v1 = pool.pool_rank(0, 11), pool.pool_rank(1, 12)
+    v0.set_photons(ph_d)
+    quiet = {k: (a.copy() if isinstance(a, np.ndarray) else a) for k, a in ph_d.items()}
+    quiet["r0"] = quiet["r0"] + 2e11                           # moved off the axis, beyond the jet's opening angle: far fewer scatterings per photon
+    v1.set_photons(quiet)
+    s1 = pool.pool_propagate_frames_fast([1, 1], [5, 6], [0.0, 0.0], [rem, rem])
+    c0, c1 = v0.fast_cadence(), v1.fast_cadence()
+    assert c0 == min(2048, max(8, int(1000.0 * s1[0].frame_scatt_cnt / 6000 + 0.5)))
+    assert c1 == min(2048, max(8, int(1000.0 * s1[1].frame_scatt_cnt / 6000 + 0.5))) and c0 != c1
+    pool.pool_propagate_frames_fast([1, 1], [7, 8], [rem, rem], [rem, rem])
+    own = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=11)
+    own.set_hydro(dense)
+    own.set_photons(ph_d)
+    own.propagate_frame_fast(0.0, rem, 5)
+    assert own.fast_cadence() == c0
+    mid = own.get_photons()
+    own.propagate_frame_fast(rem, rem, 7)
+    a, b = own.get_photons(), v0.get_photons()
+    for k in a:
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    # "restart": a fresh context, the interrupted run's photons and its cadence
+    again = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=11)
+    again.set_hydro(dense)
+    again.set_photons(mid)
+    assert again.fast_cadence() == 32 and again.fast_cadence(c0) == c0
+    again.propagate_frame_fast(rem, rem, 7)
+    c = again.get_photons()
+    for k in a:
+        assert np.array_equal(a[k], c[k], equal_nan=True), k
+    for e in (pool, own, again):
+        e.close()
