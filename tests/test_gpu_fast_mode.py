@@ -304,7 +304,7 @@ def test_the_learnt_cadence_belongs_to_the_list_not_to_the_pool(hip):
     own.propagate_frame_fast(rem, rem, 7)
     a, b = own.get_photons(), v0.get_photons()
     for k in a:
-        assert np.array_equal(a[k], b[k], equal_nan=True), k
+        assert np.array_equal(a[k], b[k]), k
     # "restart": a fresh context, the interrupted run's photons and its cadence
     again = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], rng_stream=11)
     again.set_hydro(dense)
@@ -313,6 +313,6 @@ def test_the_learnt_cadence_belongs_to_the_list_not_to_the_pool(hip):
     again.propagate_frame_fast(rem, rem, 7)
     c = again.get_photons()
     for k in a:
-        assert np.array_equal(a[k], c[k], equal_nan=True), k
+        assert np.array_equal(a[k], c[k]), k
     for e in (pool, own, again):
         e.close()

@@ -211,3 +211,68 @@ def test_cfg3_at_its_full_ten_million_photons_as_a_rank_pool(hip):
     _, stf = pool.propagate_frame_fast(2.0, rem, 77)
     assert abs(stf.frame_scatt_cnt - st.frame_scatt_cnt) < 6 * np.sqrt(st.frame_scatt_cnt) + 1e-3 * st.frame_scatt_cnt
     pool.close()
+
+
+def test_cfg4_share_of_one_gpu_as_a_rank_pool_and_through_the_frame_queue(hip):
+    """BASELINE.json configs[3] (10^8 photons on 8 GPUs, the cfg2 frame replicated) is 1.25e7 photons per GPU: ~12 800 adopted ranks on the 1 048 576-cell
+    cylindrical frame.  One GPU's share at full size: the invariants of this file on a sample of lists, the per-list counters adding up, and the
+    frame queue (two frames of every list in ONE launch, mcrat_hip_pool_run_frames) bit-identical to one launch per frame."""
+    n = 12_500_000
+    frame, ph, cfg = synth.config2(n_photons=n)
+    assert frame["num_elements"] == 1048576 and len(ph["p0"]) == n
+    rem = 1.0 / frame["fps"]
+    per = 976
+    n_lists = int(round(n / per))
+    rng = np.random.default_rng(4)
+    lens = np.full(n_lists, per) + rng.integers(-40, 41, n_lists)
+    lens[-1] += n - int(lens.sum())
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    assert offs[-1] == n and lens.min() > 0 and n_lists > 12_000
+    recs = synth.photons_to_aos(ph, hip.PHOTON_DTYPE)
+
+    def make():
+        pool = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+        pool.set_hydro(frame)
+        pool.pool_create(n_lists, int(lens.max()))
+        for r in range(n_lists):
+            pool.pool_rank(r, 5000 + r)
+        pool.pool_set_photons(list(range(n_lists)), [recs[offs[r]:offs[r + 1]] for r in range(n_lists)])
+        return pool
+    pool = make()
+    seeds = np.array([[77 + 13 * r for r in range(n_lists)], [900_001 + 7 * r for r in range(n_lists)]], dtype=np.uint64)
+    # frame by frame, every list its own seed and the clock carried on
+    totals = []
+    t_now = np.zeros(n_lists)
+    for f in range(2):
+        t_rem = (f + 1) / frame["fps"] - t_now
+        o, sd, t, rm = (np.ones(n_lists, dtype=np.int32), seeds[f], t_now.copy(), t_rem.copy())
+        pool._check(pool.lib.mcrat_hip_pool_begin_frames(pool.ctx, o.ctypes.data_as(hip.C.POINTER(hip.C.c_int)), sd.ctypes.data_as(hip.C.POINTER(hip.C.c_uint64)),
+                                                        t.ctypes.data_as(hip.C.POINTER(hip.C.c_double)), rm.ctypes.data_as(hip.C.POINTER(hip.C.c_double))), "pool_begin_frames")
+        st = pool.run(0)
+        assert st.remaining_time == 0.0 and st.not_found == 0
+        totals.append((st.iterations, st.frame_scatt_cnt, st.num_photons_find_new_element))
+        per_list = (hip.FrameStats * n_lists)()
+        pool._check(pool.lib.mcrat_hip_pool_frame_stats(pool.ctx, per_list), "pool_frame_stats")
+        t_now = np.array([s.time_now for s in per_list])
+        assert sum(s.frame_scatt_cnt for s in per_list) == st.frame_scatt_cnt
+    assert totals[0][1] > 60_000
+    sample = list(range(0, n_lists, max(1, n_lists // 300)))
+    got = {r: pool.views[r].get_photons() for r in sample}
+    for r, o in got.items():
+        lo, hi = offs[r], offs[r + 1]
+        assert np.array_equal(o["weight"], ph["weight"][lo:hi]) and np.array_equal(o["type"], ph["type"][lo:hi])
+        nrm = np.sqrt(o["p1"] ** 2 + o["p2"] ** 2 + o["p3"] ** 2)
+        assert np.isfinite(o["p0"]).all() and np.allclose(nrm, o["p0"], rtol=1e-12, atol=0)
+        assert (o["num_scatt"] >= ph["num_scatt"][lo:hi]).all()
+    pool.close()
+    # the same two frames of every list in ONE launch
+    q = make()
+    frame_end = np.array([[(f + 1) / frame["fps"]] * n_lists for f in range(2)])
+    stq = q.pool_run_frames(np.ones((2, n_lists), dtype=np.int32), seeds, np.zeros((2, n_lists)), frame_end.copy(), frame_end=frame_end, chain_clock=True)
+    for f in range(2):
+        assert (sum(s.iterations for s in stq[f]), sum(s.frame_scatt_cnt for s in stq[f]), sum(s.num_photons_find_new_element for s in stq[f])) == totals[f]
+    for r in sample:
+        o = q.views[r].get_photons()
+        for k in ("p0", "p1", "p2", "p3", "r0", "r1", "r2", "comv_p0", "num_scatt", "nearest_block_index"):
+            assert np.array_equal(o[k], got[r][k], equal_nan=True), (r, k)
+    q.close()

@@ -52,14 +52,11 @@ for sub, want, bytes_note in (("pmc_ranks", "rank_loop_kernel", "ranks"), ("pmc_
     k = max(ks, key=lambda q: sum(acc[q]["FETCH_SIZE"]) / len(acc[q]["FETCH_SIZE"]) * len(acc[q]["FETCH_SIZE"]))
     fetch_kb = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
     write_kb = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
-    if want == "step_kernel":
-        rd = 2 * fetch_kb * 1024
-        corr = ("gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read stream, so read bytes = 2 x FETCH_SIZE x 1024; "
-                "WRITE_SIZE is exact (MI355X_MICROARCH.md, HBM section)")
-    else:
-        rd = fetch_kb * 1024
-        corr = ("this kernel loads 8 B per lane and gathers 16-96 B records (not the 16 B/lane wide streams for which MI355X_MICROARCH.md "
-                "prescribes doubling FETCH_SIZE); that width is uncalibrated, so FETCH_SIZE is taken as counted: a lower bound on read bytes")
+    # profiles/r04_fetch_calibration.txt (tools/fetch_calibration.hip): on gfx950 FETCH_SIZE x 1024 is half the bytes of the 128-B lines a kernel
+    # touches, for 8-B and 16-B coalesced streams and for 16-B and 128-B gathers alike -- one factor for every kernel
+    rd = 2 * fetch_kb * 1024
+    corr = ("gfx950: FETCH_SIZE tallies the 128-B fabric requests at 64 B; read bytes = 2 x FETCH_SIZE x 1024 for every access width of this kernel "
+            "(calibrated against known byte counts: profiles/r04_fetch_calibration.txt); WRITE_SIZE as counted")
     wr = write_kb * 1024
     out[want] = {"kernel": k, "FETCH_SIZE_KB_mean": fetch_kb, "WRITE_SIZE_KB_mean": write_kb, "launches_counted": len(acc[k]["FETCH_SIZE"]),
                  "correction": corr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
@@ -68,7 +65,7 @@ for sub, want, bytes_note in (("pmc_ranks", "rank_loop_kernel", "ranks"), ("pmc_
         out[want]["algorithmic_bytes_per_launch"] = 110000000
     json.dump(out[want], open(os.path.join(dst, "%s_%s_pmc.json" % (tag, want)), "w"), indent=1)
 open(os.path.join(dst, "%s_pmc_summary.txt" % tag), "w").write("\n".join(lines) + "\n")
-for sub, name in (("kt_default", "%s_kernel_stats.csv" % tag), ("kt_list", "%s_list_kernel_stats.csv" % tag),
+for sub, name in (("kt_default", "%s_kernel_stats.csv" % tag), ("kt_oneframe", "%s_kernel_stats_one_frame_per_launch.csv" % tag), ("kt_list", "%s_list_kernel_stats.csv" % tag),
                   ("kt_ingest", "%s_ingest_kernel_stats.csv" % tag), ("kt_cfg3", "%s_cfg3_kernel_stats.csv" % tag),
                   ("kt_cfg5", "%s_cfg5_kernel_stats.csv" % tag), ("kt_pools3", "%s_kernel_stats_pools3.csv" % tag)):
     f = stats_file(sub)
@@ -84,8 +81,11 @@ if os.path.exists(b) and os.path.getsize(b) > 0:
 u = os.path.join(src, "pools3_union.json")
 if os.path.exists(u):
     shutil.copy(u, os.path.join(dst, "%s_pools3_union.json" % tag))
-for name in ("bench_cfg3", "bench_cfg5", "kt_cfg5", "kt_default", "kt_pools3"):
+u = os.path.join(src, "queue_dispatches.csv")
+if os.path.exists(u):
+    shutil.copy(u, os.path.join(dst, "%s_queue_dispatches.csv" % tag))
+for name in ("bench_cfg3", "bench_cfg5", "kt_cfg5", "kt_default", "kt_pools3", "kt_oneframe"):
     b = os.path.join(src, name + ".json")
     if os.path.exists(b) and os.path.getsize(b) > 0:
-        shutil.copy(b, os.path.join(dst, "%s_%s.json" % (tag, name.replace("kt_cfg5", "bench_cfg5_traced").replace("kt_default", "bench_traced").replace("kt_pools3", "bench_traced_pools3"))))
+        shutil.copy(b, os.path.join(dst, "%s_%s.json" % (tag, name.replace("kt_cfg5", "bench_cfg5_traced").replace("kt_default", "bench_traced").replace("kt_pools3", "bench_traced_pools3").replace("kt_oneframe", "bench_traced_one_frame_per_launch"))))
 print(json.dumps({k: v["traffic_bytes_per_launch"] for k, v in out.items()}))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Everything profiles/ holds for a round, in one GPU call:  tools/profile_round.sh  (run through gpurun), then
-# `python tools/pmc_to_json.py gpurun_out/round profiles r03` here to turn the merged output into the committed files.
+# `python tools/pmc_to_json.py gpurun_out/round profiles r04` here to turn the merged output into the committed files.
 # PMC passes are separate runs with --kernel-trace only (never with --sys-trace & co); the program follows `--` directly.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
@@ -10,10 +10,14 @@ mkdir -p $out
 if [[ $part == *a* ]]; then
 echo "== bench, no profiler"
 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "exit=$?"
-echo "== kernel trace of the default bench command"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_default -- python3 bench.py --pools 1 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_default.json 2> $out/kt_default.err; echo "exit=$?"
+echo "== kernel trace of the default bench command (frame queue: the timed region is ONE launch of rank_loop_kernel; the per-dispatch trace of that kernel is kept)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_default -- python3 bench.py --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_default.json 2> $out/kt_default.err; echo "exit=$?"
+python3 tools/queue_dispatches.py $out/kt_default rank_loop_kernel $out/queue_dispatches.csv
+find $out/kt_default -name "*kernel_trace.csv" -delete
+echo "== kernel trace, one launch per frame on one pool (round 3's kernel-alone figure)"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_oneframe -- python3 bench.py --launch-shape pools --pools 1 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_oneframe.json 2> $out/kt_oneframe.err; echo "exit=$?"
 echo "== kernel trace of the HEADLINE's launch shape: three pools on three streams (the per-dispatch trace is kept until the union of the overlapping launches is taken)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_pools3 -- python3 bench.py --pools 3 --steps 20 --warmup 5 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_pools3.json 2> $out/kt_pools3.err; echo "exit=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_pools3 -- python3 bench.py --launch-shape pools --pools 3 --steps 20 --warmup 5 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_pools3.json 2> $out/kt_pools3.err; echo "exit=$?"
 python3 tools/union_busy.py $out/kt_pools3 rank_loop_kernel 20 5 3 $out/pools3_union.json
 find $out/kt_pools3 -name "*kernel_trace.csv" -delete
 echo "== kernel trace, list mode (eager launches so that every kernel is a trace record)"
@@ -26,7 +30,7 @@ shrink() {   # keep the counter rows of the loop's kernels only (the staging cop
 for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"; do
   i=$((i+1))
   echo "== pmc pass $i ($ctrs), ranks mode"
-  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_ranks/p$i -- python3 bench.py --pools 1 --steps 5 --warmup 1 --other-mode 0 --host-driver 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/pmc_ranks_p$i.json 2> $out/pmc_ranks_p$i.err; echo "exit=$?"
+  rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d $out/pmc_ranks/p$i -- python3 bench.py --launch-shape pools --pools 1 --steps 5 --warmup 1 --other-mode 0 --host-driver 0 --no-cpu-baseline --shared-clock-rounds 0 > $out/pmc_ranks_p$i.json 2> $out/pmc_ranks_p$i.err; echo "exit=$?"
   echo "== pmc pass $i ($ctrs), list mode"
   shrink $out/pmc_ranks/p$i
   if [ $i -le 3 ]; then
