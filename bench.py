@@ -629,13 +629,21 @@ def main():
             # ... and the same bytes over the WALL time of the timed region (the headline's launch shape: the pools' launches overlap)
             headline_gbs = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps / dt / 1e9
             if queue_launch_ms:
-                # the headline IS one launch of rank_loop_kernel (all timed frames): its duration between HIP events on the pool's stream
+                # the headline IS one launch of rank_loop_kernel (all timed frames): its duration between HIP events on the pool's stream.
+                # traffic: the committed PMC passes over such a launch (tools/pmc_queue.sh), per frame x the frames of this one
+                q_traffic, q_src = None, None
+                qf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rank_loop_queue_pmc.json")))
+                if qf and full:
+                    with open(qf[-1]) as f:
+                        q_traffic, q_src = json.load(f).get("traffic_bytes_per_frame", 0) * k_frames, os.path.basename(qf[-1])
+                elif traffic:
+                    q_traffic, q_src = traffic * k_frames, src
                 q_bytes = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps
                 q_gbs = q_bytes / (queue_launch_ms * 1e-3) / 1e9
                 roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": q_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": q_gbs / HBM_PEAK_GBS, "frac_headline": headline_gbs / HBM_PEAK_GBS, "achieved_headline": headline_gbs,
                         "frac_one_frame_per_launch": achieved / HBM_PEAK_GBS,
-                        "traffic": (traffic * k_frames) if traffic else None, "traffic_source": src,
+                        "traffic": q_traffic, "traffic_source": q_src,
                         "bytes_per_launch": q_bytes, "avg_launch_ms": queue_launch_ms, "launches": 1, "frames_per_launch": k_frames,
                         "one_frame_launch": {"bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches)},
                         "note": "the timed region is ONE launch of rank_loop_kernel for all %d frames (frame queue: a workgroup per (frame, list) item); "

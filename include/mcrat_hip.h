@@ -678,7 +678,12 @@ int mcrat_hip_shared_clock_finish(mcrat_hip_ctx *ctx, mcrat_hip_frame_stats *sta
  *   per pass, one gsl_rng_uniform_pos for every slot with a cell (nearest_block_index != -1), in ascending slot order   (Src/mclib.c:646-675)
  *   then photonEvent's draws for each candidate it tries, in its call order                       (Src/electron.c:81,196,217-233; Src/mcrat_scattering.c:519-574)
  * gsl_rng_uniform_pos skips zeros, gsl_ran_gaussian (polar method) takes as many pairs as it needs: as GSL publishes them.  The photons after a frame
- * can then be held against MCRaT's own, photon for photon ("Pinning parity with your GSL").  A validation mode: one list per context
+ * can then be held against MCRaT's own, photon for photon ("Pinning parity with your GSL").  STATUS: the tape path is validated against
+ * this repository's CPU restatement of MCRaT only (tests/test_gpu_tape.py: engine == oracle on the same tape, zeros on the tape included) -- no tape
+ * recorded from MCRaT itself exists yet (the reference needs GSL, which the development image lacks; tools/ref_harness has not been compiled
+ * against it).  The product build's arithmetic differs from the reference's IEEE sequence in the last place or two (reciprocals and roots by
+ * v_rcp / v_rsq + Newton steps, physics.hpp), so a comparison decided within a few ulp can fall the other way than MCRaT's; a maintainer who wants
+ * correctly rounded operands under every decision builds the kernels with -DMCRAT_IEEE_ARITH=1 (slower; physics.hpp).  A validation mode: one list per context
  * (refused on rank pools, virtual ranks, the shared clock and with the cyclo-synchrotron switch), the free-path draws of a pass taken by one
  * workgroup.  uniforms == NULL or n == 0 returns to the keyed source.  While a tape is set the seed of begin_frame / propagate_frame is ignored and
  * the tape is read on across frames (MCRaT's reseeding is part of the recorded stream).

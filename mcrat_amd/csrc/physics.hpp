@@ -26,6 +26,18 @@ constexpr int REJECTION_CAP = 1 << 22;   // every rejection loop is bounded so t
 // and folds the divisions the reference repeats (p/|p| thrice in zeroNorm, six by beta^2 in lorentzBoost) into one reciprocal.
 // The values are the reference's real numbers rounded differently in the last place or two; the gates are the oracle's
 // (integers exact, doubles 1e-9 over trajectories, tests/).
+// -DMCRAT_IEEE_ARITH=1 (a variant build, tools/variant_build.py ieee -DMCRAT_IEEE_ARITH=1; not the product): the three helpers below and log_unit
+// become the IEEE division, square root and the math library's logarithm the reference's C compiles to -- for a maintainer who compares photon for
+// photon with MCRaT on a recorded tape (tools/ref_harness) and wants every decision taken on correctly rounded operands.  What stays in either build
+// is algebra, not approximation: the boost as p + (kf (b.p) - g p0) b, the optical depth on per-cell operands -- the same real numbers as the
+// reference's expressions, rounded in a different order (a few ulp).  tests/test_gpu_tape.py passes on both builds; the product's gate is the oracle's
+// 1e-9 over trajectories (north_star: 1e-5), and a comparison decided within a few ulp -- a Klein-Nishina acceptance, two free times, a point on a
+// cell face -- can fall the other way than MCRaT's: that photon's trajectory then differs from there on while the statistics do not.
+#if defined(MCRAT_IEEE_ARITH) && MCRAT_IEEE_ARITH
+__device__ __forceinline__ double rcp_nr(double x) { return 1.0 / x; }
+__device__ __forceinline__ double rsqrt_nr(double x) { return 1.0 / sqrt(x); }
+__device__ __forceinline__ double sqrt_nr(double x) { return sqrt(x); }
+#else
 __device__ __forceinline__ double rcp_nr(double x)
 {
     const double r0 = __builtin_amdgcn_rcp(x);
@@ -51,6 +63,7 @@ __device__ __forceinline__ double sqrt_nr(double x)
     const double y = x * rsqrt_nr(x);
     return (x == 0.0) ? 0.0 : y;
 }
+#endif
 
 // ln(u) for the free-path draws: 0 < u < 1, a normal double (rng.hpp, bits_to_uniform_pos: u >= 2^-53; a tape's uniforms alike).  Every located
 // slot draws one per pass (mclib.c:675-680), which makes the logarithm a fifth of the loop's instructions; the math library's handles
@@ -60,6 +73,9 @@ __device__ __forceinline__ double sqrt_nr(double x)
 // 4e-16 on a free path (the gates are the oracle's, which calls the C library's log: integers exact, doubles 1e-9 over trajectories).
 __device__ __forceinline__ double log_unit(double u)
 {
+#if defined(MCRAT_IEEE_ARITH) && MCRAT_IEEE_ARITH
+    return log(u);
+#endif
     constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
     constexpr double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01, LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
                      LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01, LG7 = 1.479819860511658591e-01;
