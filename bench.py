@@ -589,7 +589,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         a = np.frombuffer(st, dtype=np.dtype([("it", "<i8"), ("ps", "<i8"), ("sc", "<i8"), ("rest", "V%d" % (C.sizeof(engine.FrameStats) - 24))]))
-        launch_ms = st[0].step_kernel_ms / max(1, st[0].step_kernel_launches)
+        launch_ms = (st[0].step_kernel_ms, int(st[0].step_kernel_launches))      # summed duration and number of the loop kernel's launches in the timed call
         e.close()
         return int(a["sc"].sum()), int(a["ps"].sum()), int(a["it"].sum()), dt, launch_ms
 
@@ -635,19 +635,25 @@ def main():
                 qf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rank_loop_queue_pmc.json")))
                 if qf and full:
                     with open(qf[-1]) as f:
-                        q_traffic, q_src = json.load(f).get("traffic_bytes_per_frame", 0) * k_frames, os.path.basename(qf[-1])
+                        q_traffic, q_src = json.load(f).get("traffic_bytes_per_frame", 0) * (k_frames // q_launches), os.path.basename(qf[-1])
                 elif traffic:
-                    q_traffic, q_src = traffic * k_frames, src
-                q_bytes = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps
+                    q_traffic, q_src = traffic * (k_frames // q_launches), src
+                # (a launch form without a queue build -- 128- or 512-thread lists, columns in HBM/L2: cfg3's 10 246 lists -- runs the plan one launch
+                # per frame inside the same call: q_launches > 1, and the figures are per launch)
+                q_total_ms, q_launches = queue_launch_ms
+                q_launches = max(1, q_launches)
+                q_bytes = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps / q_launches
+                queue_launch_ms = q_total_ms / q_launches
                 q_gbs = q_bytes / (queue_launch_ms * 1e-3) / 1e9
                 roof = {"kernel": "rank_loop_kernel", "bound": "hbm", "achieved": q_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": q_gbs / HBM_PEAK_GBS, "frac_headline": headline_gbs / HBM_PEAK_GBS, "achieved_headline": headline_gbs,
                         "frac_one_frame_per_launch": achieved / HBM_PEAK_GBS,
                         "traffic": q_traffic, "traffic_source": q_src,
-                        "bytes_per_launch": q_bytes, "avg_launch_ms": queue_launch_ms, "launches": 1, "frames_per_launch": k_frames,
+                        "bytes_per_launch": q_bytes, "avg_launch_ms": queue_launch_ms, "launches": q_launches, "frames_per_launch": k_frames // q_launches,
                         "one_frame_launch": {"bytes_per_launch": bytes_per_launch, "avg_launch_ms": launch_ms, "launches": int(launches)},
-                        "note": "the timed region is ONE launch of rank_loop_kernel for all %d frames (frame queue: a workgroup per (frame, list) item); "
-                                "frac = 110 B x the photon-steps of that launch / its duration between HIP events on the pool's stream / 8 TB/s; frac_headline "
+                        "note": "the timed region is ONE call for all %d frames: one launch of rank_loop_kernel (frame queue: a workgroup per (frame, list) item) "
+                                "where the launch form has a queue build, else one launch per frame (`launches`); "
+                                "frac = 110 B x the photon-steps of a launch / its duration between HIP events on the pool's stream / 8 TB/s; frac_headline "
                                 "= the same bytes over the wall time of the timed region; frac_one_frame_per_launch = round 3's figure, one launch per frame "
                                 "alone on the device (its last lists' tail inside); traffic = the committed per-frame PMC figure x frames.  A latency-bound "
                                 "kernel (one workgroup walks one list's whole frame); the HBM-bound kernel of this path is step_kernel, see other_mode.roofline"
@@ -1140,9 +1146,10 @@ def main():
                      "ranks; one workgroup per list) in %s; step = one hydro frame (1/fps = %.2f s) for all lists, every pool restarted from "
                      "its resident snapshot"
                      % (main_res.get("ranks", 0), int(lens.min()), int(lens.max()),
-                        ("one rank pool and ONE launch of the loop kernel for all %d timed frames (frame queue, mcrat_hip_pool_run_frames: a workgroup per "
-                         "(frame, list) item; a list that is through frame f starts f + 1 while others are still in f -- the reference's ranks are "
-                         "asynchronous across hydro frames, mcrat.c:457-479,566-934)" % steps) if args.launch_shape == "queue" else
+                        ("one rank pool and ONE call for all %d timed frames (mcrat_hip_pool_run_frames; roofline.launches says how many launches it "
+                         "took: one -- the frame queue, a workgroup per (frame, list) item, a list that is through frame f starts f + 1 while others are "
+                         "still in f, as the reference's ranks are asynchronous across hydro frames, mcrat.c:457-479,566-934 -- where the launch form has a "
+                         "queue build (256-thread lists in LDS), else one per frame)" % steps) if args.launch_shape == "queue" else
                         "one rank pool, all lists in one launch" if pools == 1 else
                         "%d rank pools on %d HIP streams with a host thread each (the ranks are asynchronous in the reference too: a pool whose "
                         "last lists are finishing no longer leaves the device idle), one launch per pool and frame" % (pools, pools), remaining))

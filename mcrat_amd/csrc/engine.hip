@@ -2934,7 +2934,8 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     int xcd_of_class[FRAME_QUEUE_XCDS];                      // which XCD's queue the lists of class k are in (identity unless an XCD turned out to start no workgroups)
     for (int x = 0; x < FRAME_QUEUE_XCDS; ++x) xcd_of_class[x] = x;
     std::vector<unsigned> tickets((size_t)FRAME_QUEUE_XCDS * FRAME_TICKET_STRIDE);
-    for (int attempt = 0;; ++attempt) {
+    bool one_by_one = getenv("MCRAT_HIP_NO_FRAME_QUEUE") && atoi(getenv("MCRAT_HIP_NO_FRAME_QUEUE")) != 0;      // (A/B: the plan frame by frame)
+    for (int attempt = 0; !one_by_one; ++attempt) {
         // the open items in the order they are taken: per XCD (list r belongs to XCD r % 8: a list never changes L2) frame-major; one workgroup per item,
         // and as the hardware deals workgroups round-robin over the XCDs, eight times the longest XCD's list of them
         int n_open = 0, longest_xcd = 0;
@@ -2953,8 +2954,12 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
             if (rc) return rc;
             HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
         }
-        HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, longest, c->d_desc, nullptr, nullptr, per_frame_cap,
-                                   c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream, &fq, n_groups));
+        {
+            const hipError_t le = launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, longest, c->d_desc, nullptr, nullptr, per_frame_cap,
+                                                   c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream, &fq, n_groups);
+            if (le == hipErrorNotSupported && attempt == 0) { one_by_one = true; break; }      // no queue build of this launch form (kernels.hip)
+            HIPCHK(c, le);
+        }
         if (c->cfg.profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
         HIPCHK(c, hipMemcpyAsync(tickets.data(), db, sizeof(unsigned) * tickets.size(), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(h_done, db + off_done, sizeof(unsigned) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
@@ -2998,6 +3003,63 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
                     it.remaining_time = it.frame_end - it.time_now;
                 }
             }
+        }
+    }
+    if (one_by_one) {
+        // The plan one launch per frame: launch forms without a queue build (128- and 512-thread lists, lists whose columns stay in HBM/L2) -- the same
+        // frames, seeds and clocks, so the same photons; what is lost is only that a list need not wait for the others at a frame's end.
+        std::vector<double> t_now((size_t)R, 0.0), t_rem((size_t)R, 0.0);
+        std::vector<int> op((size_t)R, 0);
+        const size_t sb = (sizeof(int) + 2 * sizeof(double)) * (size_t)R;
+        int rc = ensure_aos(c, sb + 64);
+        if (rc) return rc;
+        double *d_t = static_cast<double *>(c->aos_buf), *d_rem = d_t + R;
+        int *d_open = reinterpret_cast<int *>(d_rem + R);
+        const long long snap = p->restore_each_frame ? (long long)(static_cast<char *>(c->ph_snap) - static_cast<char *>(c->ph_buf)) : 0;
+        for (int f = 0; f < F; ++f) {
+            bool any = false, all_lists = true;                               // (every list that exists takes part: the whole pool is restored in one copy)
+            for (int r = 0; r < R; ++r)
+                if (c->views[(size_t)r] && c->views[(size_t)r]->have_photons && !h_items[(size_t)f * R + r].open) all_lists = false;
+            if (p->restore_each_frame && all_lists) HIPCHK(c, hipMemcpyAsync(c->ph_buf, c->ph_snap, c->ph_bytes, hipMemcpyDeviceToDevice, c->stream));
+            for (int r = 0; r < R; ++r) {
+                const size_t t = (size_t)f * R + r;
+                op[(size_t)r] = h_items[t].open ? 1 : 0;
+                if (!op[(size_t)r]) { c->h_desc[r].len = 0; continue; }
+                any = true;
+                const mcrat_hip_ctx *v = c->views[(size_t)r];
+                c->h_desc[r].len = v->ph.n; c->h_desc[r].stream = v->key.stream; c->h_desc[r].seed = h_items[t].seed;
+                t_now[(size_t)r] = h_items[t].time_now; t_rem[(size_t)r] = h_items[t].remaining_time;
+                if (p->chain_clock && f > first[r]) { t_now[(size_t)r] = h_rec[t - R].time_now; t_rem[(size_t)r] = h_items[t].frame_end - t_now[(size_t)r]; }
+                if (p->restore_each_frame && !all_lists) {                    // the list's window of every column back from the snapshot
+                    const size_t b0 = (size_t)r * (size_t)c->rank_stride, len = (size_t)v->ph.n;
+                    char *col0 = reinterpret_cast<char *>(c->ph.r0 + b0);
+                    HIPCHK(c, hipMemcpy2DAsync(col0, sizeof(double) * c->ph.col_stride, col0 + snap, sizeof(double) * c->ph.col_stride, sizeof(double) * len,
+                                               24, hipMemcpyDeviceToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(c->ph.idx + b0, reinterpret_cast<char *>(c->ph.idx + b0) + snap, sizeof(int) * len, hipMemcpyDeviceToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(c->ph.flags + b0, reinterpret_cast<char *>(c->ph.flags + b0) + snap, len, hipMemcpyDeviceToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(c->ph.type + b0, reinterpret_cast<char *>(c->ph.type + b0) + snap, len, hipMemcpyDeviceToDevice, c->stream));
+                }
+            }
+            if (!any) continue;
+            HIPCHK(c, hipMemcpyAsync(d_t, t_now.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_rem, t_rem.data(), sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(d_open, op.data(), sizeof(int) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, launch_init_states_multi(c->d_rstates, R, d_open, d_t, d_rem, c->stream));
+            for (;;) {
+                if (c->cfg.profile) { rc = ensure_events(c, 2); if (rc) return rc; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
+                HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, longest, c->d_desc, nullptr, nullptr, per_frame_cap,
+                                           c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
+                if (c->cfg.profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                if (c->cfg.profile) { float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1])); c->prof_step_ms += ms; c->prof_launches += 1; }
+                bool done = true;
+                for (int r = 0; r < R && done; ++r) done = !op[(size_t)r] || c->h_rstates[r].done != 0;
+                if (done) break;
+            }
+            for (int r = 0; r < R; ++r)
+                if (op[(size_t)r]) h_rec[(size_t)f * R + r] = c->h_rstates[r];
         }
     }
     for (size_t t = 0; t < N; ++t) {

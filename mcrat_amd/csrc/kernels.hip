@@ -741,11 +741,9 @@ __device__ __forceinline__ void load_candidate(const PH &ph, int i, CandCols &c)
 }
 
 // one candidate (scatt_time, i) of the walk.  Returns EV_DONE when the iteration is decided.
-// `cc`: the slot's columns, loaded by the caller (event_block: the head candidate's before the shortlist is sorted, so that they arrive meanwhile)
 template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class PH, class SRC = KeyedSource>
 __device__ __forceinline__ int try_candidate(const PH &ph, const HydroDev &hy, LoopState *st, const RngKey &key,
-                                             unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base, const SRC &src,
-                                             const CandCols &cc)
+                                             unsigned long long iter, EventWalk &w, double scatt_time, int i, int slot_base, const SRC &src = SRC())
 {
     // *scattered_ph_index (mclib.c:1341) is the last candidate photonEvent looked at; main() does not call
     // photonEvent at all when even the first free time exceeds the frame (mcrat.c:777,834)
@@ -764,6 +762,9 @@ __device__ __forceinline__ int try_candidate(const PH &ph, const HydroDev &hy, L
     if (w.nseg < MAX_SEG) w.seg[w.nseg++] = this_seg;
     else w.seg[MAX_SEG - 1] += this_seg;
     w.old_scatt_time = scatt_time;
+    // one round of independent loads for everything the candidate needs (this wavefront's latency is its list's)
+    CandCols cc;
+    load_candidate<STOKES>(ph, i, cc);
     const int cell = cc.cell;
     double p[4] = {cc.p[0], cc.p[1], cc.p[2], cc.p[3]};
     double r[3] = {cc.r[0], cc.r[1], cc.r[2]};
@@ -822,34 +823,7 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
 {
     const int tid = threadIdx.x;
     int n_list = (n_raw > BLOCK) ? 0 : n_raw;              // overflowed: incomplete, ignore it
-    // The head of the sorted list is the list's minimum, which the caller already has: the walking wavefront asks for that slot's columns now, and
-    // they arrive while the shortlist is being sorted -- one dependent gather round trip (a fifth of the walk, tools/diag_event.py) off the walk.
-    CandCols head;
-    head.idx = -1;
-    if ((WAVE_WALK ? tid < 64 : tid == 0) && gmin.idx != INT_MAX) load_candidate<STOKES>(ph, gmin.idx, head);
-    constexpr int SORT_IN_REGISTERS = 16;                  // (twice the shortlist's expected length: t_cut aims at eight entries)
-    if (n_list <= SORT_IN_REGISTERS) {
-        // rank sort of a short shortlist in the walking wavefront's registers (equal (t, idx) pairs cannot occur): lane l holds entry l, every entry is
-        // broadcast with v_readlane -- straight-line code without an LDS round trip per comparison, and without a loop, at whose head the compiler
-        // would wait for the head candidate's columns asked for above
-        if (tid < 64) {
-            int lane_ = tid;                               // (opaque to the compiler: the address of sh.raw[tid], hoisted out of the pass loop, was kept in a
-            asm volatile("" : "+v"(lane_));                // spilled register -- and its scratch reload waits for every load in flight, the head's included)
-            Cand me;
-            me.t = INFINITY; me.idx = INT_MAX; me.pad = 0;
-            if (lane_ < n_list) me = sh.raw[lane_];
-            const int t_lo = (int)(unsigned)(__double_as_longlong(me.t) & 0xffffffffll), t_hi = (int)(unsigned)((unsigned long long)__double_as_longlong(me.t) >> 32);
-            int rank = 0;
-#pragma unroll
-            for (int j = 0; j < SORT_IN_REGISTERS; ++j) {
-                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(t_lo, j), hi = (unsigned)__builtin_amdgcn_readlane(t_hi, j);
-                const double tj = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-                const int ij = __builtin_amdgcn_readlane(me.idx, j);
-                rank += cand_less(tj, ij, me.t, me.idx) ? 1 : 0;
-            }
-            if (lane_ < n_list) sh.list[rank] = me;
-        }
-    } else if (tid < n_list) {                             // ... of a long one through LDS
+    if (tid < n_list) {                                    // rank sort (equal (t, idx) pairs cannot occur)
         const Cand me = sh.raw[tid];
         int rank = 0;
         for (int j = 0; j < n_list; ++j) rank += cand_less(sh.raw[j].t, sh.raw[j].idx, me.t, me.idx) ? 1 : 0;
@@ -889,8 +863,7 @@ __device__ __forceinline__ void event_block(const PH &ph, const HydroDev &hy, Lo
                 status = EV_DONE;
             }
             for (int c = 0; c < n_list && status == EV_NEED_MORE; ++c) {
-                if (head.idx != list[c].idx) load_candidate<STOKES>(ph, list[c].idx, head);      // (the head of the first round is at hand)
-                if (try_candidate<DIMS, GEOM, STOKES, WAVE_WALK>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base, src, head) == EV_DONE)
+                if (try_candidate<DIMS, GEOM, STOKES, WAVE_WALK>(ph, hy, st, key, iter, w, list[c].t, list[c].idx, base, src) == EV_DONE)
                     status = EV_DONE;
             }
             if (status == EV_NEED_MORE) {
@@ -1089,6 +1062,31 @@ __global__ __launch_bounds__(TAPE_BLOCK) void tape_draw_kernel(PhotonDev ph, con
 // launch's seed and the streams key.stream + rank.  desc != nullptr (rank pool, mcrat_hip_pool_*): rank r owns the slots
 // [r * stride, r * stride + desc[r].len) -- the reference's ranks hold Poisson-sized lists (mclib.c:87-136) -- and has its own
 // seed and stream, as every MPI rank has its own generator (mcrat.c:99-103,701).
+// Every column of one list copied between the live lists and a buffer laid out like them (the snapshot; a frame's capture): slot i of a column at byte
+// offset +from is read, +to written.  All 24 double columns of a slot are loaded before the first is stored: a workgroup's copy is a handful of memory
+// round trips, not one per column and 256 slots.  NOT inlined into rank_loop_kernel: called once per (frame, list) item, and its registers must not
+// count against the loop's.
+__device__ __attribute__((noinline)) void copy_list_columns(double *r0, unsigned col_stride, int *idx, unsigned char *flags, char *type, int base, int n,
+                                                            long long from, long long to, int tid, int block)
+{
+    for (int il = tid; il < n; il += block) {
+        const size_t i = (size_t)base + il;
+        double v[N_DOUBLE_COLS];
+#pragma unroll
+        for (int k = 0; k < N_DOUBLE_COLS; ++k)
+            v[k] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(r0 + (size_t)k * col_stride + i) + from);
+        const int ci = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(idx + i) + from);
+        const unsigned char cf = *reinterpret_cast<const unsigned char *>(reinterpret_cast<const char *>(flags + i) + from);
+        const char ct = *(reinterpret_cast<const char *>(type + i) + from);
+#pragma unroll
+        for (int k = 0; k < N_DOUBLE_COLS; ++k)
+            *reinterpret_cast<double *>(reinterpret_cast<char *>(r0 + (size_t)k * col_stride + i) + to) = v[k];
+        *reinterpret_cast<int *>(reinterpret_cast<char *>(idx + i) + to) = ci;
+        *reinterpret_cast<unsigned char *>(reinterpret_cast<char *>(flags + i) + to) = cf;
+        *(reinterpret_cast<char *>(type + i) + to) = ct;
+    }
+}
+
 struct RankLayout {
     int n_ranks;
     int stride;           // slots reserved per rank
@@ -1120,7 +1118,10 @@ constexpr int rank_lds_bytes_per_slot(int block) { return block == 256 ? 7 * (in
 
 // FUSE: the kernel also holds the fused form of a pass (below).  It pays in optically thin frames and costs dense ones code they never
 // run (instruction cache, registers), so it is a build of its own and engine.hip picks per frame, as it picks the workgroup size.
-template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK, bool FUSE, bool CSH = false>
+// QUEUE: the build that can take (frame, list) items from the frame queue (launch.hpp, FrameQueueDev).  A build of its own because carrying the
+// queue's paths costs a build that does not use them 25 spilled doubles per lane (measured: the 2-D spherical Stokes build 128 -> 328 B of scratch, cfg3's
+// frame 6.0 -> 8.2 ms), and instantiated only for the 256-thread lists with their columns in LDS; every other launch form runs a plan frame by frame.
+template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK, bool FUSE, bool CSH = false, bool QUEUE = false>
 __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
@@ -1139,34 +1140,11 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     static_assert(sizeof(sh.list) >= sizeof(int) * RANK_QCAP, "queue fits into the sorted-list storage");
     int *const s_q = reinterpret_cast<int *>(sh.list);
     const int tid = threadIdx.x, lane = tid & 63;
-#ifdef MCRAT_NO_FRAME_QUEUE
-    const bool queued = false;                               // (A/B build: what carrying the queue costs a launch that does not use it)
-#else
-    const bool queued = lay.fq.n_frames > 0;
-#endif
+    const bool queued = QUEUE ? lay.fq.n_frames > 0 : false;
     // One list through one frame: the whole loop of mcrat.c:761-851.  Without a queue the workgroup does this once, for list blockIdx.x, from the
     // LoopState begin_frame left in states[]; with one (launch.hpp, FrameQueueDev) for one (frame, list) item after the other, each from the item's seed and clock.
-    // every column of one list copied between the live lists and a buffer laid out like them (the snapshot; a frame's capture): slot i of a column
-    // at byte offset +from is read, +to written.  All 24 double columns of a slot are loaded before the first is stored: a workgroup's copy is
-    // a handful of memory round trips, not one per column and 256 slots.
-    auto copy_list_columns = [&](const PhotonDev &g, int base, int n, long long from, long long to) {
-        for (int il = tid; il < n; il += RANK_BLOCK) {
-            const size_t i = (size_t)base + il;
-            double v[N_DOUBLE_COLS];
-#pragma unroll
-            for (int k = 0; k < N_DOUBLE_COLS; ++k)
-                v[k] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(g.r0 + (size_t)k * g.col_stride + i) + from);
-            const int ci = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(g.idx + i) + from);
-            const unsigned char cf = *reinterpret_cast<const unsigned char *>(reinterpret_cast<const char *>(g.flags + i) + from);
-            const char ct = *(reinterpret_cast<const char *>(g.type + i) + from);
-#pragma unroll
-            for (int k = 0; k < N_DOUBLE_COLS; ++k)
-                *reinterpret_cast<double *>(reinterpret_cast<char *>(g.r0 + (size_t)k * g.col_stride + i) + to) = v[k];
-            *reinterpret_cast<int *>(reinterpret_cast<char *>(g.idx + i) + to) = ci;
-            *reinterpret_cast<unsigned char *>(reinterpret_cast<char *>(g.flags + i) + to) = cf;
-            *(reinterpret_cast<char *>(g.type + i) + to) = ct;
-        }
-    };
+    // (the copies of a list between the live columns and the snapshot / a frame's capture: copy_list_columns, a function of its own -- inlined,
+    // its 48 registers of columns in flight sat on top of the loop's hoisted per-thread invariants and cost every build 25 spilled doubles)
     auto list_frame = [&](const int rank, const int item) __attribute__((always_inline)) {
     const int base = rank * lay.stride;
     int n = min(lay.stride, lay.n_total - base);
@@ -1209,7 +1187,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         return;
     }
     if (fresh && lay.fq.restore) {                           // the frame starts from the snapshot of the list (mcrat_hip_restore_photons, for this list)
-        copy_list_columns(gph, base, n, lay.fq.snap_delta, 0);
+        copy_list_columns(gph.r0, gph.col_stride, gph.idx, gph.flags, gph.type, base, n, lay.fq.snap_delta, 0, tid, RANK_BLOCK);
         __syncthreads();
     }
     // Cyclo-synchrotron lists double when they run out of null slots (photons.c:112-121), so half of a list can be null slots behind the
@@ -1650,7 +1628,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         // the list as this frame leaves it, for the frame's outputs (printPhotons, saveCheckpoint: mcrat.c:881-906), before its next frame moves it on
         if (item >= 0 && lay.fq.capture_delta != 0 && item / lay.n_ranks < lay.fq.n_frames - 1 && st.done == LOOP_DONE) {
             __syncthreads();
-            copy_list_columns(gph, base, n, 0, lay.fq.capture_delta + (long long)(item / lay.n_ranks) * lay.fq.capture_stride);
+            copy_list_columns(gph.r0, gph.col_stride, gph.idx, gph.flags, gph.type, base, n, 0, lay.fq.capture_delta + (long long)(item / lay.n_ranks) * lay.fq.capture_stride, tid, RANK_BLOCK);
         }
     }
     };   // list_frame
@@ -2442,11 +2420,32 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
     const int lds_limit = (block == 128) ? 1024 : (block == 512 ? 4096 : 1088);
     if (!getenv("MCRAT_HIP_NO_LDS_LISTS") && longest_list <= lds_limit) lds_slots = (longest_list + 15) & ~15;
     size_t dyn = (size_t)lds_slots * rank_lds_bytes_per_slot(block == 128 ? 128 : (block == 512 ? 512 : 256));
-    return dispatch(kc, [&](auto D, auto G) {
+    bool queue_launched = false;
+    const hipError_t launched = dispatch(kc, [&](auto D, auto G) {
         constexpr int DV = decltype(D)::value, GV = decltype(G)::value;
         // static + dynamic LDS may exceed the 64 KiB default: the kernel must be told, and if the runtime refuses
         // the list simply stays in global memory (lds_slots = 0)
         const int grid = queued ? n_open : n_ranks;          // a queue launch: one workgroup per open (frame, list) item
+        if (queued) {
+            // the queue builds: 256-thread lists with their columns in LDS, with or without the fused pass; anything else is refused and the caller
+            // runs the plan frame by frame (engine.hip, mcrat_hip_pool_run_frames)
+            if (block != 256 || lds_slots <= 0) return;
+            auto launch_q = [&](auto kernel) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { (void)hipGetLastError(); return; }
+                kernel<<<dim3(grid), dim3(256), dyn, stream>>>(ph, hy, states, key, lay, max_passes, lds_slots);
+                queue_launched = true;
+            };
+            if constexpr (!TABLE_MODE && GV != GEOM_SPHERICAL) {
+                if (fuse) {
+                    if (kc.stokes) launch_q(rank_loop_kernel<DV, GV, true, true, 256, true, false, true>);
+                    else launch_q(rank_loop_kernel<DV, GV, false, true, 256, true, false, true>);
+                    return;
+                }
+            }
+            if (kc.stokes) launch_q(rank_loop_kernel<DV, GV, true, true, 256, false, false, true>);
+            else launch_q(rank_loop_kernel<DV, GV, false, true, 256, false, false, true>);
+            return;
+        }
         auto launch = [&](auto kernel, auto kernel_global, int threads) {
             if (lds_slots > 0 &&
                 hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) {
@@ -2481,6 +2480,8 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
             else launch(rank_loop_kernel<DV, GV, false, true, 256, false>, rank_loop_kernel<DV, GV, false, false, 256, false>, 256);
         }
     });
+    if (queued && !queue_launched && launched == hipSuccess) return hipErrorNotSupported;      // no queue build of this launch form: frame by frame then
+    return launched;
 }
 
 hipError_t launch_fast_frame(const KernelConfig &kc, const PhotonDev &ph, const HydroDev &hy, RngKey key, double remaining_time, int windows,

@@ -110,8 +110,17 @@ def _run_both(hip, lens, F, open_, restore, window, lumi=1e54, monkeypatch=None,
     return want
 
 
-def test_chained_frames_equal_one_launch_per_frame(hip):
-    """ragged lists, three frames with the clock carried from frame to frame; one list joins at frame 1 (its injection frame)"""
+FORMS = {"queue": {}, "frame-by-frame": {"MCRAT_HIP_NO_FRAME_QUEUE": "1"}, "128-thread-lists": {"MCRAT_HIP_RANK_BLOCK": "128"},
+         "columns-in-hbm": {"MCRAT_HIP_NO_LDS_LISTS": "1"}}
+
+
+@pytest.mark.parametrize("form", list(FORMS))
+def test_chained_frames_equal_one_launch_per_frame(hip, monkeypatch, form):
+    """ragged lists, three frames with the clock carried from frame to frame; one list joins at frame 1 (its injection frame).  The queue builds of
+    the kernel exist for 256-thread lists with their columns in LDS (kernels.hip); every other launch form runs the plan one launch per frame inside
+    the same call -- the same photons either way"""
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
     lens = [137, 1000, 512, 999, 64, 700, 1024, 333, 420]
     F, R = 3, len(lens)
     open_ = np.ones((F, R), dtype=np.int32)
@@ -119,8 +128,11 @@ def test_chained_frames_equal_one_launch_per_frame(hip):
     _run_both(hip, lens, F, open_, restore=False, window=1100)
 
 
-def test_restored_frames_equal_restore_plus_launch(hip):
+@pytest.mark.parametrize("form", list(FORMS))
+def test_restored_frames_equal_restore_plus_launch(hip, monkeypatch, form):
     """the benchmark's shape: every frame from the snapshot with its own seeds"""
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
     lens = [400, 1000, 512, 976, 1016, 935]
     F, R = 4, len(lens)
     open_ = np.ones((F, R), dtype=np.int32)
