@@ -404,10 +404,12 @@ def main():
     ap.add_argument("--pools", type=int, default=0, help="ranks mode: rank pools (HIP streams, host threads) the lists are dealt out to; 0: 3 for "
                                                         "cfg2 / cfg3 (measured on cfg2: 0.95 ms per frame with one, 0.70 with two, 0.65 with three, 1.0 with four: HIP has "
                                                         "four hardware queues), 1 for cfg5 (measured: slower with two)")
-    ap.add_argument("--launch-shape", choices=("queue", "pools"), default="queue",
+    ap.add_argument("--launch-shape", choices=("queue", "pools"), default=None,
                     help="ranks mode: 'queue' = ONE rank pool and ONE launch for all timed frames (mcrat_hip_pool_run_frames: a list that is through frame f "
                          "starts f + 1 while others are still in f; measured 0.51 ms per frame against 0.53 with three pools); 'pools' = round 3's shape, "
-                         "--pools rank pools on their own streams with a host thread each, one launch per pool and frame")
+                         "--pools rank pools on their own streams with a host thread each, one launch per pool and frame.  Default: queue for cfg2 "
+                         "(the headline), pools for cfg3 -- its 10 246 lists run as 128-thread lists, a launch form without a queue build, so the "
+                         "queue's call would run the frames one launch each on one pool (7.0 ms per frame against 6.6 with three pools)")
     ap.add_argument("--share-hydro", type=int, default=1, help="the pools read one staged copy of the hydro frame (mcrat_hip_share_hydro)")
     ap.add_argument("--fast-windows", type=int, default=0, help="FAST mode beside the exact headline: refreshes per frame (0: the context learns them from the frame before, the unbiased default; < 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -424,6 +426,8 @@ def main():
         raise SystemExit("--photons must be even")
     if args.config == "cfg3":
         args.stokes = 1
+    if args.launch_shape is None:
+        args.launch_shape = "pools" if args.config == "cfg3" else "queue"
 
     import torch
     from mcrat_amd import engine, synth
@@ -631,6 +635,10 @@ def main():
             if queue_launch_ms:
                 # the headline IS one launch of rank_loop_kernel (all timed frames): its duration between HIP events on the pool's stream.
                 # traffic: the committed PMC passes over such a launch (tools/pmc_queue.sh), per frame x the frames of this one
+                # (a launch form without a queue build -- 128- or 512-thread lists, columns in HBM/L2: cfg3's 10 246 lists -- runs the plan one launch
+                # per frame inside the same call: q_launches > 1, and the figures are per launch)
+                q_total_ms, q_launches = queue_launch_ms
+                q_launches = max(1, q_launches)
                 q_traffic, q_src = None, None
                 qf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rank_loop_queue_pmc.json")))
                 if qf and full:
@@ -638,10 +646,6 @@ def main():
                         q_traffic, q_src = json.load(f).get("traffic_bytes_per_frame", 0) * (k_frames // q_launches), os.path.basename(qf[-1])
                 elif traffic:
                     q_traffic, q_src = traffic * (k_frames // q_launches), src
-                # (a launch form without a queue build -- 128- or 512-thread lists, columns in HBM/L2: cfg3's 10 246 lists -- runs the plan one launch
-                # per frame inside the same call: q_launches > 1, and the figures are per launch)
-                q_total_ms, q_launches = queue_launch_ms
-                q_launches = max(1, q_launches)
                 q_bytes = ALGORITHMIC_BYTES_PER_PHOTON_STEP * ps / q_launches
                 queue_launch_ms = q_total_ms / q_launches
                 q_gbs = q_bytes / (queue_launch_ms * 1e-3) / 1e9
