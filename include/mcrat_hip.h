@@ -587,8 +587,10 @@ int mcrat_hip_pool_layout(const mcrat_hip_ctx *pool, int *n_ranks, int *slots_pe
  * remaining_time = frame_end - time_now (mcrat.c:757 with frame_end = (scatt_frame + increment_scatt_frame) / fps) -- and time_now / remaining_time
  * are used for its first frame only; else every frame takes its own time_now and remaining_time.  restore_each_frame: every frame starts from
  * the lists as mcrat_hip_snapshot_photons saved them (benchmarks: the same work every frame).  hydro: NULL, or [n_frames] contexts holding the
- * staged hydro frame of frame f (mcrat_hip_set_hydro / mcrat_hip_ingest_* on them; NULL entry: the pool's own frame) -- a real run stages frame f + 1
- * for the slab the photons can reach from frame f (phMinMax widened by c / fps) before the launch.  stats: [n_frames * n_ranks], what
+ * staged hydro frame of frame f (mcrat_hip_set_hydro / mcrat_hip_ingest_* on them, same device and switches as the pool; NULL entry: the pool's own
+ * frame; the contexts keep their frames staged while the call runs) -- a real run stages frame f + 1 for the slab the photons can reach from frame
+ * f (phMinMax widened by c / fps) before the launch: a list in frame f + 1 then finds its photons in the cells of THAT frame, exactly as after
+ * mcrat_hip_share_hydro(pool, hydro[f + 1]) + one launch per frame.  stats: [n_frames * n_ranks], what
  * mcrat_hip_pool_frame_stats would have reported after each frame (lists that sat a frame out: zeros).  Not with the cyclo-synchrotron switch (its
  * hook needs the host between passes).  Afterwards the pool is as after the last frame's mcrat_hip_run. */
 typedef struct mcrat_hip_frame_plan {

@@ -62,13 +62,19 @@ def build(force=False, resource_log=None, extra_flags=(), lib=None, objdir=None)
         deps = [os.path.join(CSRC, d) for d in DEPS[src]]
         fresh = (not force and not resource_log and os.path.exists(obj) and
                  all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in deps))
+        # stderr to a file, not a pipe: the resource remarks of one kernels TU are megabytes, and a full pipe would stall that TU until its turn below
+        errf = None if fresh else open(obj + ".log", "w+")
         procs.append((src, obj, None if fresh else subprocess.Popen([hipcc()] + cflags + [os.path.join(CSRC, src), "-o", obj],
-                                                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+                                                                    stdout=subprocess.DEVNULL, stderr=errf, text=True), errf))
     log, failed = [], False
-    for src, obj, p in procs:
+    for src, obj, p, errf in procs:
         if p is None:
             continue
-        _, err = p.communicate()
+        p.wait()
+        errf.seek(0)
+        err = errf.read()
+        errf.close()
+        os.remove(obj + ".log")
         log.append(err)
         if p.returncode != 0:
             sys.stderr.write(err)
@@ -78,7 +84,7 @@ def build(force=False, resource_log=None, extra_flags=(), lib=None, objdir=None)
             f.write("".join(log))
     if failed:
         raise RuntimeError("hipcc failed building libmcrat_hip.so")
-    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, obj, _ in procs] + ["-o", lib],
+    r = subprocess.run([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [obj for _, obj, _, _ in procs] + ["-o", lib],
                        capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr)

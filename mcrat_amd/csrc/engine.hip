@@ -2857,9 +2857,26 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         c->last_error = "TAU_CALCULATION == TABLE needs mcrat_hip_set_hot_cross_section first";
         return MCRAT_HIP_ESTATE;
     }
+    // the staged hydro frames of the plan: index 0 the pool's own, then every other context named in plan->hydro (it keeps its frame staged while the
+    // call runs; same switches as the pool -- its HydroDev is handed to the pool's kernels as it is)
+    std::vector<HydroDev> hyv(1, c->hy);
+    std::vector<const mcrat_hip_ctx *> hy_ctx(1, c);
+    std::vector<int> hy_of_frame((size_t)p->n_frames, 0);
     if (p->hydro)
-        for (int f = 0; f < p->n_frames; ++f)
-            if (p->hydro[f] && p->hydro[f] != c) { c->last_error = "pool_run_frames: frames staged on other contexts are not built yet"; return MCRAT_HIP_EINVAL; }
+        for (int f = 0; f < p->n_frames; ++f) {
+            const mcrat_hip_ctx *o = p->hydro[f];
+            if (!o || o == c) continue;
+            if (!o->have_hydro) { c->last_error = "pool_run_frames: a context named in plan->hydro holds no staged frame"; return MCRAT_HIP_ESTATE; }
+            if (o->kc.dimensions != c->kc.dimensions || o->kc.geometry != c->kc.geometry || o->kc.table != c->kc.table || o->cfg.device != c->cfg.device) {
+                c->last_error = "pool_run_frames: a frame staged on a context with other switches (DIMENSIONS, GEOMETRY, TAU_CALCULATION) or on another device";
+                return MCRAT_HIP_EINVAL;
+            }
+            if (c->kc.table && !o->hy.hot_table) { c->last_error = "pool_run_frames: TAU_CALCULATION == TABLE and a frame's context has no cross-section table"; return MCRAT_HIP_ESTATE; }
+            size_t k = 1;
+            while (k < hy_ctx.size() && hy_ctx[k] != o) ++k;
+            if (k == hy_ctx.size()) { hy_ctx.push_back(o); hyv.push_back(o->hy); }
+            hy_of_frame[(size_t)f] = (int)k;
+        }
     const int R = c->n_ranks, F = p->n_frames;
     const size_t N = (size_t)R * (size_t)F;
     if (N > 0x7fffffffull) return MCRAT_HIP_EINVAL;
@@ -2892,7 +2909,8 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     HIPCHK(c, hipMemcpyAsync(c->d_desc, c->h_desc, sizeof(RankDesc) * (size_t)R, hipMemcpyHostToDevice, c->stream));
     // the queue's block: [ticket | frames_done R | order N | items N] (uploaded per launch) then the records (read back)
     const size_t off_done = 64 * FRAME_QUEUE_XCDS, off_order = align_up(off_done + sizeof(unsigned) * (size_t)R, 64), off_items = align_up(off_order + sizeof(int) * N, 64);
-    const size_t off_rec = align_up(off_items + sizeof(FrameItem) * N, 256), bytes = off_rec + sizeof(LoopState) * N;
+    const size_t off_hy = align_up(off_items + sizeof(FrameItem) * N, 256);
+    const size_t off_rec = align_up(off_hy + sizeof(HydroDev) * hyv.size(), 256), bytes = off_rec + sizeof(LoopState) * N;
     if (c->fq_bytes < bytes) {
         if (c->d_fq) { HIPCHK(c, hipFree(c->d_fq)); c->d_fq = nullptr; }
         if (c->h_fq) { HIPCHK(c, hipHostFree(c->h_fq)); c->h_fq = nullptr; }
@@ -2912,8 +2930,9 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         it.seed = p->seeds[t]; it.time_now = p->time_now[t]; it.remaining_time = p->remaining_time[t];
         it.frame_end = p->frame_end ? p->frame_end[t] : 0.0;
         it.open = p->open[t] ? 1 : 0;
-        it.hydro = 0;
+        it.hydro = hy_of_frame[t / (size_t)R];
     }
+    memcpy(hb + off_hy, hyv.data(), sizeof(HydroDev) * hyv.size());
     HIPCHK(c, hipMemsetAsync(db + off_rec, 0, sizeof(LoopState) * N, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
     if (!c->rank_block_fixed) { choose_rank_block(c); c->rank_block_fixed = true; }
@@ -2922,6 +2941,7 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     fq.ticket = reinterpret_cast<unsigned *>(db); fq.frames_done = reinterpret_cast<unsigned *>(db + off_done);
     fq.order = reinterpret_cast<const int *>(db + off_order); fq.items = reinterpret_cast<const FrameItem *>(db + off_items);
     fq.records = reinterpret_cast<LoopState *>(db + off_rec);
+    fq.hydro = reinterpret_cast<const HydroDev *>(db + off_hy);
     fq.snap_delta = p->restore_each_frame ? (long long)(static_cast<char *>(c->ph_snap) - static_cast<char *>(c->ph_buf)) : 0;
     long long per_frame_cap = 32768;             // passes one list may take per frame and launch (run_ranks' bound on a launch's duration)
     if (const char *e = getenv("MCRAT_HIP_RANK_LAUNCH_CAP")) per_frame_cap = atoll(e) > 0 ? atoll(e) : per_frame_cap;
@@ -3048,8 +3068,8 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
             HIPCHK(c, launch_init_states_multi(c->d_rstates, R, d_open, d_t, d_rem, c->stream));
             for (;;) {
                 if (c->cfg.profile) { rc = ensure_events(c, 2); if (rc) return rc; HIPCHK(c, hipEventRecord(c->ev[0], c->stream)); }
-                HIPCHK(c, launch_rank_loop(c->kc, c->ph, c->hy, c->d_rstates, c->key, R, c->rank_stride, longest, c->d_desc, nullptr, nullptr, per_frame_cap,
-                                           c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
+                HIPCHK(c, launch_rank_loop(c->kc, c->ph, hyv[(size_t)hy_of_frame[(size_t)f]], c->d_rstates, c->key, R, c->rank_stride, longest, c->d_desc, nullptr, nullptr,
+                                           per_frame_cap, c->rank_block + (c->rank_fuse ? 1000 : 0), c->stream));
                 if (c->cfg.profile) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
                 HIPCHK(c, hipMemcpyAsync(c->h_rstates, c->d_rstates, sizeof(LoopState) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -20,12 +20,6 @@ namespace {
 
 constexpr uint32_t RNG_HOT_TABLE = 4u;
 
-// singleMaxwellJuttner, electron.c:538-561, with its normalisation hoisted (it depends on theta only)
-__device__ __forceinline__ double mj_normalisation(double theta)
-{
-    return (theta > 1.e-2) ? phys::bessel_k2_scaled(1. / theta) : sqrt(M_PI * theta / 2.);      // K_2(1/theta) e^(1/theta)
-}
-
 __global__ __launch_bounds__(HOT_TABLE_SUBSTREAMS) void hot_table_kernel(HotTableParams p, double *__restrict__ table)
 {
     __shared__ double s_w[HOT_TABLE_SUBSTREAMS / 64];
@@ -34,31 +28,20 @@ __global__ __launch_bounds__(HOT_TABLE_SUBSTREAMS) void hot_table_kernel(HotTabl
     const double dt = (p.log_t_max - p.log_t_min) / p.n_t, dph_e = (p.log_ph_e_max - p.log_ph_e_min) / p.n_ph_e;   // hot_x_section.c:85
     const double ph_comv = pow(10., p.log_ph_e_min + i * dph_e);
     const double theta = pow(10., p.log_t_min + j * dt);
-    // hot_x_section.c:334-335: gamma in [1, 1 + 12 theta], mu in [-1, 1]
-    const double g_lo = 1, g_w = (1. + 12 * theta) - 1, mu_lo = -1, mu_w = 1 - (-1.);
-    const double norm = mj_normalisation(theta);
+    const double norm = phys::mj_normalisation(theta);
 
     const Philox4 b = keyed_block(p.seed, (unsigned long long)entry, (uint32_t)threadIdx.x, RNG_HOT_TABLE, 0u);
     EventStream rng;
     rng.state = (uint64_t)b.w[0] | ((uint64_t)b.w[1] << 32);
-    double sum = 0;
-    for (long long k = threadIdx.x; k < p.calls; k += HOT_TABLE_SUBSTREAMS) {
-        const double gamma = g_lo + rng.uniform_pos() * g_w;          // gsl_monte_plain: x = xl + uniform_pos * (xu - xl)
-        const double mu = mu_lo + rng.uniform_pos() * mu_w;
-        // thermalCrossSectionIntegrand :359-368 = singleMaxwellJuttner * boostedCrossSection :370-400
-        const double mj = ((gamma * sqrt(gamma * gamma - 1.) / (theta * norm)) * exp(-(gamma - 1.) / theta));
-        const double beta = sqrt(gamma * gamma - 1.) / gamma;
-        const double norm_ph_e = ph_comv * gamma * (1. - mu * beta);
-        sum += mj * (phys::kn_cross_section(norm_ph_e) * (1. - mu * beta));
-    }
+    // the integrand and the sample loop: physics.hpp (shared with the loop's look-ups off the table)
+    double sum = phys::hot_substream_sum(ph_comv, theta, norm, rng, threadIdx.x, p.calls, HOT_TABLE_SUBSTREAMS);
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
         double total = 0;
         for (int w = 0; w < HOT_TABLE_SUBSTREAMS / 64; ++w) total += s_w[w];
-        const double result = (g_w * mu_w) * (total / (double)p.calls);       // volume x mean
-        table[entry] = log10(0.5 * result);                                    // :355, :96
+        table[entry] = log10(phys::hot_integral_of_total(total, theta, p.calls));     // volume x mean, :355, :96
     }
 }
 

@@ -1122,7 +1122,7 @@ constexpr int rank_lds_bytes_per_slot(int block) { return block == 256 ? 7 * (in
 // queue's paths costs a build that does not use them 25 spilled doubles per lane (measured: the 2-D spherical Stokes build 128 -> 328 B of scratch, cfg3's
 // frame 6.0 -> 8.2 ms), and instantiated only for the 256-thread lists with their columns in LDS; every other launch form runs a plan frame by frame.
 template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK, bool FUSE, bool CSH = false, bool QUEUE = false>
-__global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy, LoopState *states, RngKey key,
+__global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy_arg, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
     constexpr int EVENT_BLOCK = RANK_BLOCK;                    // (shadows the event kernel's block size inside this kernel)
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     // LoopState begin_frame left in states[]; with one (launch.hpp, FrameQueueDev) for one (frame, list) item after the other, each from the item's seed and clock.
     // (the copies of a list between the live columns and the snapshot / a frame's capture: copy_list_columns, a function of its own -- inlined,
     // its 48 registers of columns in flight sat on top of the loop's hoisted per-thread invariants and cost every build 25 spilled doubles)
-    auto list_frame = [&](const int rank, const int item) __attribute__((always_inline)) {
+    auto list_frame = [&](const int rank, const int item, const HydroDev &hy) __attribute__((always_inline)) {
     const int base = rank * lay.stride;
     int n = min(lay.stride, lay.n_total - base);
     RngKey rk = {key.seed, key.stream + (uint32_t)rank, 0u};
@@ -1674,7 +1674,17 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         if (item < 0) return;
         rank = item % lay.n_ranks;
     }
-    list_frame(rank, item);
+    if constexpr (QUEUE) {
+        // the hydro frame of THIS item: a queue launch may take its lists through several staged frames (FrameQueueDev::hydro; a real run stages frame
+        // f + 1 for the slab the photons can reach from frame f before the launch).  The array is read through the constant address space, so that
+        // its members arrive by scalar loads like a kernel argument's.
+        typedef const HydroDev __attribute__((address_space(4))) *ConstHydro;
+        ConstHydro frames = (ConstHydro)lay.fq.hydro;
+        const int h = __builtin_amdgcn_readfirstlane(lay.fq.items[item].hydro);
+        list_frame(rank, item, *(const HydroDev *)(frames + h));
+    } else {
+        list_frame(rank, item, hy_arg);
+    }
     if (queued) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

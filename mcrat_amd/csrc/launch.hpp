@@ -61,6 +61,7 @@ struct FrameQueueDev {
     int order_off[9];
     unsigned *frames_done;           // [n_ranks] f + 1 once item (f, r) is complete; FRAME_STALLED | f: frame f ran into the launch's pass limit
     const FrameItem *items;          // [n_frames * n_ranks]
+    const HydroDev *hydro;           // [n_hydro] the staged hydro frames of the launch (FrameItem::hydro indexes it); read through the constant address space
     LoopState *records;              // [n_frames * n_ranks] the LoopState every frame ended with
     long long snap_delta;            // bytes from a column of the live lists to its copy in the snapshot (restore)
     long long capture_delta, capture_stride;   // != 0: at the end of frame f < n_frames - 1 the list's columns are copied to live + capture_delta + f * capture_stride

@@ -400,8 +400,8 @@ __device__ __forceinline__ double optical_depth_staged(const double fluid_beta[3
 // getCrossSection / getThermalCrossSection, optical_depth.c:117-149: 1 in DIRECT; in TABLE
 // 10^interp(log10(h nu'/m_e c^2), log10(kT/m_e c^2)) with GSL's bilinear interp2d scheme on the uniform grid of
 // hot_x_section.c:461-502 (cell with x_i <= x < x_{i+1}, last cell closed).  Outside the table the reference
-// re-integrates the cross section by Monte Carlo (hot_x_section.c:563-599); here the arguments are clamped to the
-// table's edge and the lookup is counted (HydroDev::table_misses), as in the oracle.
+// integrates the cross section afresh (interpolateThermalHotCrossSection's GSL_EDOM branch, hot_x_section.c:563-599 ->
+// calculateTotalThermalCrossSection, :324-356): table_fallback_* below.
 __device__ __forceinline__ int table_cell(double x0, double dx, int n_cells, double x)
 {
     int i = (int)floor((x - x0) / dx);
@@ -421,26 +421,25 @@ __device__ __forceinline__ double kn_cross_section_ieee(double e)
     return (1. - 2. * e);
 }
 
-__device__ __forceinline__ double thermal_cross_section(const HydroDev &h, double photon_comv_e, double fluid_temp, bool count = true)
+// The look-up proper.  false: `norm` is the cross section (DIRECT: 1; the table's interpolant; or, for plasma colder than the table, 1 / the
+// Klein-Nishina cross section of the photon, hot_x_section.c:337-340).  true: (eps, theta) lies outside the table at a temperature the table
+// covers or above it -- the reference integrates (table_fallback_* below); eps = h nu'/m_e c^2 and theta = kT/m_e c^2 are handed back.
+__device__ __forceinline__ bool thermal_cross_section_lookup(const HydroDev &h, double photon_comv_e, double fluid_temp, double &norm, double &eps, double &theta_out)
 {
-    if (!h.hot_table) return 1.0;
+    norm = 1.0;
+    if (!h.hot_table) return false;
     const double normalized_photon_comv_e = photon_comv_e / (M_EL * C_LIGHT);
     const double theta = K_B * fluid_temp / (M_EL * C_LIGHT * C_LIGHT);
-    double x = log10(normalized_photon_comv_e), y = log10(theta);
+    const double x = log10(normalized_photon_comv_e), y = log10(theta);
     const double x_hi = h.hot_e0 + h.hot_n_ph_e * h.hot_de, y_hi = h.hot_t0 + h.hot_n_t * h.hot_dt;
-    bool out = false;
-    if (!(x >= h.hot_e0)) { x = h.hot_e0; out = true; }
-    if (x > x_hi) { x = x_hi; out = true; }
-    if (!(y >= h.hot_t0)) { y = h.hot_t0; out = true; }
-    if (y > y_hi) { y = y_hi; out = true; }
+    const bool out = !(x >= h.hot_e0) | (x > x_hi) | !(y >= h.hot_t0) | (y > y_hi);           // gsl_spline2d_eval_e: GSL_EDOM
     if (out) {
-        // Outside the table the reference computes the cross section directly (interpolateThermalHotCrossSection's fallback, hot_x_section.c:563-599 ->
-        // calculateTotalThermalCrossSection, :324-356): cold plasma below the table -- every cell under 5.9e5 K with the reference's LOG_T_MIN = -4 -- is
-        // 1 for a photon below the table too and the Klein-Nishina cross section otherwise (:337-340); only the remaining cases (a photon energy
-        // beyond the table at a tabulated temperature) are its 500 000-sample Monte-Carlo integral, which the loop does not run: clamped and counted.
-        const double theta_min = pow(10.0, h.hot_t0), e_min = pow(10.0, h.hot_e0);
-        if (theta < theta_min) return (normalized_photon_comv_e < e_min) ? 1.0 : kn_cross_section_ieee(normalized_photon_comv_e);
-        if (count) atomicAdd(h.table_misses, 1);
+        const double theta_min = pow(10.0, h.hot_t0), e_min = pow(10.0, h.hot_e0);               // :337-340
+        if (theta < theta_min) { norm = (normalized_photon_comv_e < e_min) ? 1.0 : kn_cross_section_ieee(normalized_photon_comv_e); return false; }
+        // :584-588: the integral is taken at 10^x, 10^y (the arguments went through log10 on their way in)
+        eps = pow(10.0, x);
+        theta_out = pow(10.0, y);
+        return true;
     }
     const int xi = table_cell(h.hot_e0, h.hot_de, h.hot_n_ph_e, x);
     const int yi = table_cell(h.hot_t0, h.hot_dt, h.hot_n_t, y);
@@ -451,7 +450,8 @@ __device__ __forceinline__ double thermal_cross_section(const HydroDev &h, doubl
     const double zmaxmin = h.hot_table[(xi + 1) * ny + yi], zmaxmax = h.hot_table[(xi + 1) * ny + yi + 1];
     const double t = (x - xmin) / (xmax - xmin), u = (y - ymin) / (ymax - ymin);
     const double z = (1. - t) * (1. - u) * zminmin + t * (1. - u) * zmaxmin + (1. - t) * u * zminmax + t * u * zmaxmax;
-    return pow(10.0, z);
+    norm = pow(10.0, z);
+    return false;
 }
 
 // ---------------------------------------------------------------- Stokes helpers
@@ -836,6 +836,88 @@ __device__ __forceinline__ double bessel_k2_scaled(double x)
         if (e + 2.0 * t < -80.0) break;
     }
     return sum * h;
+}
+
+// ---------------------------------------------------------------- the hot cross section's integral (hot_x_section.c:324-400)
+// 0.5 * int_1^{1+12 theta} dgamma int_-1^1 dmu f_MJ(gamma; theta) sigma_KN(eps gamma (1 - mu beta)) / sigma_T (1 - mu beta) as the reference's plain
+// Monte-Carlo rule (gsl_monte_plain_integrate: volume x mean of the integrand at uniformly drawn points).  The samples are dealt to
+// HOT_TABLE_SUBSTREAMS = 256 substreams, sample k to substream k % 256, each with its own keyed generator drawing x0 then x1 per sample (the
+// reference's draw order); the 256 partial sums are added in substream order.  hot_table.hip builds the table from these pieces (one workgroup
+// per entry); the loop uses them where a look-up falls off the table (table_fallback_lane / _wave).
+
+// singleMaxwellJuttner's normalisation, electron.c:538-561 (it depends on theta only)
+__device__ __forceinline__ double mj_normalisation(double theta)
+{
+    return (theta > 1.e-2) ? bessel_k2_scaled(1. / theta) : sqrt(M_PI * theta / 2.);      // K_2(1/theta) e^(1/theta)
+}
+
+// the samples first, first + stride, ... < calls of one substream
+__device__ __forceinline__ double hot_substream_sum(double ph_comv, double theta, double mj_norm, EventStream rng, long long first, long long calls, int stride)
+{
+    // hot_x_section.c:334-335: gamma in [1, 1 + 12 theta], mu in [-1, 1]
+    const double g_lo = 1, g_w = (1. + 12 * theta) - 1, mu_lo = -1, mu_w = 1 - (-1.);
+    double sum = 0;
+    for (long long k = first; k < calls; k += stride) {
+        const double gamma = g_lo + rng.uniform_pos() * g_w;          // gsl_monte_plain: x = xl + uniform_pos * (xu - xl)
+        const double mu = mu_lo + rng.uniform_pos() * mu_w;
+        // thermalCrossSectionIntegrand :359-368 = singleMaxwellJuttner * boostedCrossSection :370-400
+        const double mj = ((gamma * sqrt(gamma * gamma - 1.) / (theta * mj_norm)) * exp(-(gamma - 1.) / theta));
+        const double beta = sqrt(gamma * gamma - 1.) / gamma;
+        const double norm_ph_e = ph_comv * gamma * (1. - mu * beta);
+        sum += mj * (kn_cross_section(norm_ph_e) * (1. - mu * beta));
+    }
+    return sum;
+}
+
+// volume x mean, then the 0.5 of :355
+__device__ __forceinline__ double hot_integral_of_total(double total, double theta, long long calls)
+{
+    const double g_w = (1. + 12 * theta) - 1, mu_w = 1 - (-1.);
+    return 0.5 * ((g_w * mu_w) * (total / (double)calls));
+}
+
+// A look-up off the table inside the loop.  The reference takes 2 x 500 000 numbers from the rank's generator at that point; here substream s of
+// the integral for (pass, slot) is the keyed stream {iteration = pass | (s + 1) << 48, word2 = slot, purpose = TABLE_FALLBACK, the list's stream}:
+// the value depends on the pass, the slot and (eps, theta) only, not on who computes it -- one lane on its own (a slot that missed somewhere in a
+// divergent stretch of a kernel: 500 000 integrand evaluations in one lane, a fifth of a second) or a whole wavefront (64 substreams at a time;
+// rank_loop_kernel brings its misses to one: a few milliseconds).  What comes back is what getThermalCrossSection returns for it:
+// 10^log10(integral) (hot_x_section.c:588, optical_depth.c:143).
+constexpr uint32_t RNG_TABLE_FALLBACK = 9u;
+constexpr int TABLE_FALLBACK_SUBSTREAMS = 256;
+
+__device__ __forceinline__ EventStream table_fallback_stream(uint64_t seed, uint64_t pass, uint32_t slot, uint32_t stream, int s)
+{
+    const Philox4 b = keyed_block(seed, pass | ((uint64_t)(s + 1) << 48), slot, RNG_TABLE_FALLBACK, stream);
+    EventStream rng;
+    rng.state = (uint64_t)b.w[0] | ((uint64_t)b.w[1] << 32);
+    return rng;
+}
+
+__device__ __noinline__ inline double table_fallback_lane(double eps, double theta, uint64_t seed, uint64_t pass, uint32_t slot, uint32_t stream, int calls)
+{
+    const double mj_norm = mj_normalisation(theta);
+    double total = 0;
+    for (int s = 0; s < TABLE_FALLBACK_SUBSTREAMS && s < calls; ++s)
+        total += hot_substream_sum(eps, theta, mj_norm, table_fallback_stream(seed, pass, slot, stream, s), s, calls, TABLE_FALLBACK_SUBSTREAMS);
+    return pow(10.0, log10(hot_integral_of_total(total, theta, calls)));
+}
+
+// the same number from a full wavefront: every lane passes the same arguments, lane l takes the substreams l, l + 64, l + 128, l + 192
+__device__ __noinline__ inline double table_fallback_wave(double eps, double theta, uint64_t seed, uint64_t pass, uint32_t slot, uint32_t stream, int calls)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    const double mj_norm = mj_normalisation(theta);
+    double part[TABLE_FALLBACK_SUBSTREAMS / 64];
+#pragma unroll
+    for (int g = 0; g < TABLE_FALLBACK_SUBSTREAMS / 64; ++g) {
+        const int s = 64 * g + lane;
+        part[g] = s < calls ? hot_substream_sum(eps, theta, mj_norm, table_fallback_stream(seed, pass, slot, stream, s), s, calls, TABLE_FALLBACK_SUBSTREAMS) : 0.0;
+    }
+    double total = 0;
+#pragma unroll
+    for (int g = 0; g < TABLE_FALLBACK_SUBSTREAMS / 64; ++g)
+        for (int l = 0; l < 64; ++l) total += __shfl(part[g], l, 64);      // substream order
+    return pow(10.0, log10(hot_integral_of_total(total, theta, calls)));
 }
 
 }  // namespace phys

@@ -786,8 +786,9 @@ class Engine:
         self._check(self.lib.mcrat_hip_pool_propagate_frames_fast(self.ctx, o, sd, t, rem, int(windows), st), "pool_propagate_frames_fast")
         return list(st)
 
-    def frame_plan(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False):
-        """a mcrat_hip_frame_plan from [n_frames][n_ranks] arrays -> (plan, stats array, the arrays the plan points into)"""
+    def frame_plan(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False, hydro=None):
+        """a mcrat_hip_frame_plan from [n_frames][n_ranks] arrays -> (plan, stats array, the arrays the plan points into);
+        hydro: per frame None (the pool's own staged frame) or an Engine holding that frame's staged hydro frame"""
         R = self.n_pool_ranks
         o = np.ascontiguousarray(open_, dtype=np.int32).reshape(-1, R)
         F = o.shape[0]
@@ -798,16 +799,20 @@ class Engine:
         plan = FramePlan(F, int(bool(chain_clock)), int(bool(restore_each_frame)), 0, o.ctypes.data_as(C.POINTER(C.c_int)),
                          sd.ctypes.data_as(C.POINTER(C.c_uint64)), t.ctypes.data_as(_dp), rem.ctypes.data_as(_dp),
                          fe.ctypes.data_as(_dp) if fe is not None else None, None)
-        return plan, (FrameStats * (F * R))(), (o, sd, t, rem, fe)
+        hy = None
+        if hydro is not None:
+            hy = (C.c_void_p * F)(*[(h.ctx if h is not None else None) for h in hydro])
+            plan.hydro = C.cast(hy, C.POINTER(C.c_void_p))
+        return plan, (FrameStats * (F * R))(), (o, sd, t, rem, fe, hy, hydro)
 
     def pool_run_plan(self, plan, stats):
         """mcrat_hip_pool_run_frames on a prepared plan; stats (frame_plan's array) receives item f * n_ranks + r"""
         self._check(self.lib.mcrat_hip_pool_run_frames(self.ctx, C.byref(plan), stats), "pool_run_frames")
 
-    def pool_run_frames(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False):
+    def pool_run_frames(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False, hydro=None):
         """mcrat_hip_pool_run_frames: the arrays are [n_frames][n_ranks]; every open list through its frames in ONE launch (the frame queue:
         a list that is through frame f starts f + 1 while others are still in f) -> FrameStats [n_frames][n_ranks]"""
-        plan, st, keep = self.frame_plan(open_, seeds, time_now, remaining_time, frame_end, chain_clock, restore_each_frame)
+        plan, st, keep = self.frame_plan(open_, seeds, time_now, remaining_time, frame_end, chain_clock, restore_each_frame, hydro)
         self.pool_run_plan(plan, st)
         R, F = self.n_pool_ranks, plan.n_frames
         return [[st[f * R + r] for r in range(R)] for f in range(F)]

@@ -170,3 +170,90 @@ def test_refusals(hip):
     with pytest.raises(hip.McratHipError):                             # a chained clock needs the frames' ends
         q.pool_run_frames(np.ones((F, R), dtype=np.int32), seeds, z, rem, chain_clock=True)
     q.close()
+
+
+def _evolved(frame, k):
+    """a later hydro frame of the same mesh: denser, cooler, the flow turned a little (gamma kept consistent with the velocity)"""
+    out = dict(frame)
+    s = 1.0 - 0.04 * k
+    out["v0"] = frame["v0"] * s + 0.01 * k * frame["v1"]
+    out["v1"] = frame["v1"] * s
+    g = 1.0 / np.sqrt(1.0 - (out["v0"] ** 2 + out["v1"] ** 2))
+    out["gamma"] = g
+    out["dens"] = frame["dens"] * (1.0 + 0.5 * k)
+    out["dens_lab"] = out["dens"] * g
+    out["temp"] = frame["temp"] * (1.0 - 0.1 * k)
+    out["pres"] = frame["pres"] * (1.0 - 0.1 * k) ** 4
+    return out
+
+
+@pytest.mark.parametrize("form", ["queue", "frame-by-frame"])
+def test_every_frame_of_a_plan_in_its_own_hydro_frame(hip, monkeypatch, form):
+    """mcrat.c:566-934: a rank reads hydro frame f, runs its photons to the frame's end, reads f + 1.  A plan names the context each frame's hydro
+    data is staged on; a list that is through frame f goes on in frame f + 1's cells inside the same launch, while others are still in f.  Three
+    frames on three contexts (the pool's own first) against mcrat_hip_share_hydro + one launch per frame"""
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    lens = [137, 1000, 512, 999, 64, 700, 1024, 333, 420]
+    frame, cfg, subs, streams = _setup(hip, lens)
+    F, R = 3, len(lens)
+    fps = frame["fps"]
+    frames = [frame, _evolved(frame, 1), _evolved(frame, 2)]
+    holders = []
+    for f in (1, 2):
+        h = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+        h.set_hydro(frames[f])
+        holders.append(h)
+    seeds = np.array([[77 + 13 * r + 1000003 * f for r in range(R)] for f in range(F)], dtype=np.uint64)
+    open_ = np.ones((F, R), dtype=np.int32)
+    open_[0][2] = 0                                                     # joins at frame 1
+
+    ref = _pool(hip, frame, cfg, subs, streams, 1100)
+    t_now = [0.0] * R
+    want = []
+    for f in range(F):
+        if f:
+            ref.share_hydro(holders[f - 1])
+        for r in range(R):
+            if open_[f][r]:
+                ref.views[r].begin_frame(int(seeds[f][r]), t_now[r], (f + 1) / fps - t_now[r])
+        ref.run(0)
+        row = []
+        for r in range(R):
+            st = ref.views[r].frame_statistics() if open_[f][r] else None
+            if st is not None:
+                t_now[r] = st.time_now
+            row.append(st and {k: getattr(st, k) for k in STAT_FIELDS})
+        want.append(row)
+    # the frames differ where it matters: a list's second frame in the first frame's cells is another trajectory
+    same = _pool(hip, frame, cfg, subs, streams, 1100)
+    frame_end = np.array([[(f + 1) / fps for r in range(R)] for f in range(F)])
+    rem = frame_end.copy()
+    same.pool_run_frames(open_, seeds, np.zeros((F, R)), rem, frame_end=frame_end, chain_clock=True)
+    assert any(not np.array_equal(same.views[r].get_photons()["p0"], ref.views[r].get_photons()["p0"]) for r in range(R))
+    same.close()
+
+    q = _pool(hip, frame, cfg, subs, streams, 1100)
+    got = q.pool_run_frames(open_, seeds, np.zeros((F, R)), rem, frame_end=frame_end, chain_clock=True, hydro=[None, holders[0], holders[1]])
+    for f in range(F):
+        for r in range(R):
+            if not open_[f][r]:
+                continue
+            for k in STAT_FIELDS:
+                a, b = getattr(got[f][r], k), want[f][r][k]
+                assert a == b or (a != a and b != b), (f, r, k, a, b)
+    for r in range(R):
+        _same_photons(q.views[r].get_photons(), ref.views[r].get_photons(), r)
+    assert sum(w["frame_scatt_cnt"] for row in want for w in row if w) > 0
+
+    # a context without a staged frame, or built with other switches, is refused
+    empty = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"])
+    with pytest.raises(hip.McratHipError):
+        q.pool_run_frames(open_, seeds, np.zeros((F, R)), rem, frame_end=frame_end, chain_clock=True, hydro=[None, empty, None])
+    other = hip.Engine(synth.TWO, synth.CARTESIAN, cfg["stokes"])
+    f1, _, _ = synth.config1(n_photons=10, n0=16, n1=16, stokes=cfg["stokes"])
+    other.set_hydro(f1)
+    with pytest.raises(hip.McratHipError):
+        q.pool_run_frames(open_, seeds, np.zeros((F, R)), rem, frame_end=frame_end, chain_clock=True, hydro=[None, other, None])
+    for e in (empty, other, q, ref) + tuple(holders):
+        e.close()
