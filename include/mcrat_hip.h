@@ -157,7 +157,7 @@ typedef struct mcrat_hip_frame_stats {
     double step_kernel_ms;                   /* profile=1: summed duration of step-kernel launches */
     long long step_kernel_launches;
     double event_kernel_ms;                  /* profile=1: summed duration of event-kernel launches */
-    long long table_misses;                  /* TAU_CALCULATION == TABLE: lookups outside the table that were clamped (see mcrat_hip_set_hot_cross_section) */
+    long long table_fallbacks;                  /* TAU_CALCULATION == TABLE: look-ups off the table whose cross section was integrated afresh (mcrat_hip_set_hot_cross_section) */
     long long slot_steps;                    /* slots actually taken through a pass, summed over the passes: = photon_steps, except that a
                                                 cyclo-synchrotron list's settled null slots behind its last photon (the half a doubled list consists of,
                                                 Src/photons.c:112-121) take no part in a pass here although the reference walks them (Src/mclib.c:620,684) --
@@ -408,11 +408,17 @@ int mcrat_hip_inject_photons(mcrat_hip_ctx *ctx, double r_inj, double ph_weight,
  * (mcrat_amd/host) reads the file MCRaT writes.  A lookup outside the table gets what the reference's fallback returns where that is closed-form
  * (interpolateThermalHotCrossSection -> calculateTotalThermalCrossSection, hot_x_section.c:563-599,324-356): below LOG_T_MIN -- every cell colder
  * than 5.9e5 K with the reference's bounds -- the Klein-Nishina cross section of the photon's comoving energy, or 1 when that is below LOG_PH_E_MIN
- * too (:337-340).  The remaining cases (a photon energy beyond the table at a tabulated temperature, or a temperature above LOG_T_MAX) are a
- * 500 000-sample Monte-Carlo integral drawn from the run's generator in the reference; the loop clamps those to the table's edge and counts them in
- * mcrat_hip_frame_stats.table_misses. */
+ * too (:337-340).  The remaining cases (a photon energy beyond the table at a tabulated temperature, or a temperature above LOG_T_MAX) are the
+ * reference's Monte-Carlo integral of the cross section at that (energy, temperature) -- calculateTotalThermalCrossSection's 500 000 samples, here
+ * from the keyed source: the integral of (pass, slot) has its own 256 substreams, so its value does not depend on which kernel or how many lanes
+ * compute it (one wavefront per look-up in the rank pool's loop: milliseconds; one lane in list, shared-clock and FAST mode: a fifth of a second --
+ * like the reference, which reports every such look-up on stderr, the loop treats them as rare).  mcrat_hip_frame_stats.table_fallbacks counts them. */
 int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *ctx, const double *thermal_table, int n_ph_e, int n_t,
                                     double log_ph_e_min, double log_ph_e_max, double log_t_min, double log_t_max);
+
+/* `calls` of that integral (hot_x_section.c:348: 500 000, the default); calls <= 0 only asks.  Returns the value in force (a pool's lists follow
+ * their pool).  For tests, and for runs that would rather take a coarser integral than wait. */
+int mcrat_hip_table_fallback_calls(mcrat_hip_ctx *ctx, int calls);
 
 /* createHotCrossSection (hot_x_section.c:82-133) on the device: fills thermal_table[(n_ph_e + 1) * (n_t + 1)] (photon-energy
  * index first, log10 of the cross section over sigma_T) with the Monte-Carlo integrals of calculateTotalThermalCrossSection

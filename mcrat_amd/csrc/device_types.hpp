@@ -168,7 +168,7 @@ struct HydroDev {
     const double *hot_table;
     int hot_n_ph_e, hot_n_t;
     double hot_e0, hot_de, hot_t0, hot_dt;
-    int *table_misses;           // lookups outside the tabulated range that were integrated afresh (physics.hpp: table_fallback_*)
+    int *table_fallbacks;           // lookups outside the tabulated range that were integrated afresh (physics.hpp: table_fallback_*)
     int hot_fallback_calls;      // samples of that integral (500 000, hot_x_section.c:348)
 };
 

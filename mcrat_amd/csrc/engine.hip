@@ -73,8 +73,9 @@ struct mcrat_hip_ctx {
     // TAU_CALCULATION == TABLE
     double *d_hot_table = nullptr;
     int hot_n_ph_e = 0, hot_n_t = 0;
+    int hot_fallback_calls = 500000;   // hot_x_section.c:348
     double hot_grid[4] = {0, 0, 0, 0};          // log10 photon energy min/max, log10 theta min/max
-    int *d_table_misses = nullptr;
+    int *d_table_fallbacks = nullptr;
 
     // loop
     LoopState *d_state = nullptr;
@@ -231,8 +232,8 @@ extern "C" int mcrat_hip_init(mcrat_hip_ctx **out, const mcrat_hip_config *cfg)
         c->own_stream = true;
     }
     if (hipMalloc((void **)&c->d_state, sizeof(LoopState)) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
-    if (hipMalloc((void **)&c->d_table_misses, sizeof(int)) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
-    if (hipMemset(c->d_table_misses, 0, sizeof(int)) != hipSuccess) return fail(MCRAT_HIP_ENODEV);
+    if (hipMalloc((void **)&c->d_table_fallbacks, sizeof(int)) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
+    if (hipMemset(c->d_table_fallbacks, 0, sizeof(int)) != hipSuccess) return fail(MCRAT_HIP_ENODEV);
     if (hipHostMalloc((void **)&c->h_state, sizeof(LoopState), hipHostMallocDefault) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
     if (hipMalloc((void **)&c->d_red, sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS) != hipSuccess) return fail(MCRAT_HIP_ENOMEM);
     if (hipHostMalloc((void **)&c->h_red, sizeof(ReducePartial) * mcrat_hip_ctx::RED_BLOCKS, hipHostMallocDefault) != hipSuccess)
@@ -330,7 +331,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->d_hot_table) (void)hipFree(c->d_hot_table);
     if (c->d_tape) (void)hipFree(c->d_tape);
     if (c->d_tape_cursor) (void)hipFree(c->d_tape_cursor);
-    if (c->d_table_misses) (void)hipFree(c->d_table_misses);
+    if (c->d_table_fallbacks) (void)hipFree(c->d_table_fallbacks);
     if (c->d_sc) (void)hipFree(c->d_sc);
     if (c->sc_own_send && c->sc_send) (void)hipFree(c->sc_send);
     if (c->sc_own_recv && c->sc_recv) (void)hipFree(c->sc_recv);
@@ -594,7 +595,20 @@ static void apply_hot_table(mcrat_hip_ctx *c)
     // the grid steps as hot_x_section.c:464 forms them
     hy.hot_de = table ? (c->hot_grid[1] - c->hot_grid[0]) / c->hot_n_ph_e : 0.0;
     hy.hot_dt = table ? (c->hot_grid[3] - c->hot_grid[2]) / c->hot_n_t : 0.0;
-    hy.table_misses = c->d_table_misses;
+    hy.table_fallbacks = c->d_table_fallbacks;
+    hy.hot_fallback_calls = c->hot_fallback_calls;
+}
+
+extern "C" int mcrat_hip_table_fallback_calls(mcrat_hip_ctx *c, int calls)
+{
+    if (!c) return MCRAT_HIP_EINVAL;
+    if (calls > 0) {
+        c->hot_fallback_calls = calls;
+        apply_hot_table(c);
+        drop_graph(c);
+        sync_views(c);
+    }
+    return c->hot_fallback_calls;
 }
 
 extern "C" int mcrat_hip_set_hot_cross_section(mcrat_hip_ctx *c, const double *thermal_table, int n_ph_e, int n_t,
@@ -632,6 +646,7 @@ static void sync_views(mcrat_hip_ctx *c)
         v->hcol = c->hcol; v->hcol_buf = c->hcol_buf; v->hcol_M = c->hcol_M;
         v->have_hydro = c->have_hydro;
         v->d_hot_table = c->d_hot_table; v->hot_n_ph_e = c->hot_n_ph_e; v->hot_n_t = c->hot_n_t;
+        v->hot_fallback_calls = c->hot_fallback_calls;
         for (int k = 0; k < 4; ++k) v->hot_grid[k] = c->hot_grid[k];
         drop_graph(v);
     }
@@ -2331,11 +2346,11 @@ extern "C" int mcrat_hip_outbox_wait(mcrat_hip_outbox *b, const mcrat_hip_photon
 }
 
 // ---------------------------------------------------------------------------------------------- the loop
-static long long read_table_misses(mcrat_hip_ctx *c)
+static long long read_table_fallbacks(mcrat_hip_ctx *c)
 {
     int m = 0;
-    if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && c->d_table_misses &&
-        hipMemcpy(&m, c->d_table_misses, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) m = -1;
+    if (c->cfg.tau_calculation == MCRAT_HIP_TAU_TABLE && c->d_table_fallbacks &&
+        hipMemcpy(&m, c->d_table_fallbacks, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) m = -1;
     return m;
 }
 
@@ -2359,7 +2374,7 @@ static void fill_stats(mcrat_hip_ctx *c, mcrat_hip_frame_stats *s)
     s->step_kernel_ms = c->prof_step_ms;
     s->step_kernel_launches = c->prof_launches;
     s->event_kernel_ms = c->prof_event_ms;
-    s->table_misses = read_table_misses(c);
+    s->table_fallbacks = read_table_fallbacks(c);
 }
 
 static void state_to_stats(const LoopState &h, long long slots, mcrat_hip_frame_stats *s)
@@ -2500,7 +2515,7 @@ extern "C" int mcrat_hip_pool_rank(mcrat_hip_ctx *c, int rank, uint32_t rng_stre
         v->d_state = c->d_rstates + rank;         // windows into the pool's blocks; nothing here is owned by the view
         v->h_state = c->h_rstates + rank;
         v->d_red = c->d_red; v->h_red = c->h_red;
-        v->d_table_misses = c->d_table_misses;
+        v->d_table_fallbacks = c->d_table_fallbacks;
         c->views[rank] = v;
         sync_views(c);
     }
@@ -2545,7 +2560,7 @@ extern "C" int mcrat_hip_pool_begin_frames(mcrat_hip_ctx *c, const int *open, co
     HIPCHK(c, hipMemcpyAsync(d_t, time_now, sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_rem, remaining_time, sizeof(double) * (size_t)R, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_open, op.data(), sizeof(int) * (size_t)R, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_table_fallbacks, 0, sizeof(int), c->stream));
     HIPCHK(c, launch_init_states_multi(c->d_rstates, R, d_open, d_t, d_rem, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));        // the arrays above are the caller's and `op`
     for (int r = 0; r < R; ++r) {
@@ -2630,7 +2645,7 @@ extern "C" int mcrat_hip_begin_frame(mcrat_hip_ctx *c, uint64_t seed, double tim
         return MCRAT_HIP_ESTATE;
     }
     // everything below is ordered on the context's stream behind whatever the previous frame left there: no wait
-    HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_table_fallbacks, 0, sizeof(int), c->stream));
     LoopState h;
     memset(&h, 0, sizeof h);
     h.remaining_time = remaining_time;
@@ -2841,7 +2856,7 @@ static int run_ranks(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame
         for (int r = 0; r < c->n_ranks; ++r) { it_sum += c->h_rstates[r].iterations; done = done && c->h_rstates[r].done; }
         if (done && c->n_ranks > 0) c->rank_passes_per_list = (double)it_sum / c->n_ranks;
     }
-    if (stats) { stats->step_kernel_ms = c->prof_step_ms; stats->step_kernel_launches = c->prof_launches; stats->table_misses = read_table_misses(c); }
+    if (stats) { stats->step_kernel_ms = c->prof_step_ms; stats->step_kernel_launches = c->prof_launches; stats->table_fallbacks = read_table_fallbacks(c); }
     return MCRAT_HIP_OK;
 }
 
@@ -2934,7 +2949,7 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     }
     memcpy(hb + off_hy, hyv.data(), sizeof(HydroDev) * hyv.size());
     HIPCHK(c, hipMemsetAsync(db + off_rec, 0, sizeof(LoopState) * N, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_table_misses, 0, sizeof(int), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_table_fallbacks, 0, sizeof(int), c->stream));
     if (!c->rank_block_fixed) { choose_rank_block(c); c->rank_block_fixed = true; }
     FrameQueueDev fq{};
     fq.n_frames = F; fq.restore = p->restore_each_frame ? 1 : 0; fq.chain_clock = p->chain_clock ? 1 : 0;

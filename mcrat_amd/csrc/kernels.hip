@@ -222,6 +222,7 @@ __device__ __forceinline__ void shortlist_push(Shortlist *sl, double t, int i)
 }
 
 constexpr int Q_RECALC_ONLY = (int)0x80000000;   // queue entry flag: the slot is still in its cell, only tau is stale
+constexpr int Q_DEFERRED = 0x40000000;           // rank_loop_kernel, TABLE: the slot's look-up fell off the table; a wavefront integrates it after the queue
 
 // streaming half of an iteration for one slot.  Returns the free time, or sets `queue` (0: no, 1: re-locate,
 // 2: recalc tau only) when the slot must go through the slow path; the time returned then is a placeholder.
@@ -268,9 +269,24 @@ __device__ __forceinline__ double fast_one(const PH &ph, const HydroDev &hy, int
 // (LOGS: `bits` is not the draw but the bit pattern of log(u) of the draw -- rank_loop_kernel's waves that sit out the event walk compute a pass's logarithms ahead of time)
 __device__ __forceinline__ double free_time_from_log(double ntau, double log_u) { return div_by_c(ntau * log_u); }   // = sample_free_time, its log at hand
 
+// TAU_CALCULATION == TABLE: what a look-up that falls off the table needs to integrate the cross section afresh (physics.hpp: table_fallback_*;
+// hot_x_section.c:563-599) -- the key of the integral's substreams (the pass the reference would evaluate it in, the slot's global index) and who
+// integrates: this lane on its own (mode 0), or the caller, who brings the slot to a whole wavefront (mode 1: slow_one hands (eps, theta) back and
+// leaves the slot as it was; mode 2: slow_one is told the integral)
+struct TableSite {
+    uint64_t seed, pass;
+    uint32_t stream, slot_base;
+    int first;                   // the index (as slow_one sees it) of the list's slot 0
+    int mode;
+    bool deferred;
+    double norm, eps, theta;
+    __device__ __forceinline__ TableSite(const RngKey &key, unsigned long long iter, int first_ = 0, int mode_ = 0)
+        : seed(key.seed), pass(iter), stream(key.stream), slot_base(key.slot_base), first(first_), mode(mode_), deferred(false), norm(1), eps(0), theta(0) {}
+};
+
 template <int DIMS, int GEOM, bool LOGS = false, class PH>
 __device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int i, bool relocate, int bucket, bool count_it,
-                                           uint64_t bits, int &relocated, int &not_found)
+                                           uint64_t bits, int &relocated, int &not_found, TableSite &ts)
 {
     const double r0 = ph.r0(i), r1 = ph.r1(i), r2 = ph.r2(i);
     const double p0 = ph.p0(i), p1 = ph.p1(i), p2 = ph.p2(i), p3 = ph.p3(i);
@@ -323,7 +339,17 @@ __device__ __forceinline__ double slow_one(const PH &ph, const HydroDev &hy, int
             double norm = 1.0;
             if constexpr (TABLE_MODE) {                                          // TAU_CALCULATION == TABLE, optical_depth.c:58
                 if (!new_cell) comv0 = ph.c0(i);
-                norm = phys::thermal_cross_section(hy, comv0, hy.temp[cell]);
+                if (ts.mode == 2) {
+                    norm = ts.norm;
+                } else if (phys::thermal_cross_section_lookup(hy, comv0, hy.temp[cell], norm, ts.eps, ts.theta)) {   // off the table: hot_x_section.c:563-599
+                    if (ts.mode == 1) {
+                        ts.deferred = true;                                      // (idx and comv_p stored above are what the second visit stores again)
+                        if (new_cell && count_it) relocated -= 1;
+                        return 0.0;
+                    }
+                    norm = phys::table_fallback_lane(ts.eps, ts.theta, ts.seed, ts.pass, ts.slot_base + (uint32_t)(i - ts.first), ts.stream, hy.hot_fallback_calls);
+                    atomicAdd(hy.table_fallbacks, 1);
+                }
             }
             const double tau = phys::optical_depth_staged(beta, fw, fnsig, p1, p2, p3, norm);
             ntau = -phys::rcp_nr(tau);
@@ -478,6 +504,7 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
     MinCand best;
     best.init();
     int relocated = 0, not_found = 0;
+    TableSite ts(key, iter);                     // TABLE: a look-up off the table is integrated by the lane that meets it (list mode has no wavefront to spare)
     const int nchunks = ph.n_pad / (2 * STEP_BLOCK);
     if (threadIdx.x == 0) s_qn = 0;
     for (int e = threadIdx.x; e < STEP_QCAP; e += STEP_BLOCK) s_q[e] = -1;   // -1: hole left by a wave that overflowed
@@ -526,8 +553,8 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
                     if (q1 && !todo[1]) { T.y = tt[1]; q1 = 0; }
                 }
             }
-            if (q0) T.x = slow_one<DIMS, GEOM>(pc, hy, i0, true, b0, false, bits0, relocated, not_found);
-            if (q1) T.y = slow_one<DIMS, GEOM>(pc, hy, i0 + 1, true, b1, false, bits1, relocated, not_found);
+            if (q0) T.x = slow_one<DIMS, GEOM>(pc, hy, i0, true, b0, false, bits0, relocated, not_found, ts);
+            if (q1) T.y = slow_one<DIMS, GEOM>(pc, hy, i0 + 1, true, b1, false, bits1, relocated, not_found, ts);
             q0 = q1 = 0;
         } else {
             // ballot-compact the slots that need the slow path into the workgroup's LDS queue (one LDS atomic
@@ -543,8 +570,8 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
                     if (q0) { const int e = base + __popcll(m0 & below); s_q[e] = i0 | (q0 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b0; }
                     if (q1) { const int e = base + c0 + __popcll(m1 & below); s_q[e] = (i0 + 1) | (q1 == 2 ? Q_RECALC_ONLY : 0); s_qb[e] = b1; }
                 } else {
-                    if (q0) { T.x = slow_one<DIMS, GEOM>(pc, hy, i0, q0 == 1, b0, true, bits0, relocated, not_found); q0 = 0; }
-                    if (q1) { T.y = slow_one<DIMS, GEOM>(pc, hy, i0 + 1, q1 == 1, b1, true, bits1, relocated, not_found); q1 = 0; }
+                    if (q0) { T.x = slow_one<DIMS, GEOM>(pc, hy, i0, q0 == 1, b0, true, bits0, relocated, not_found, ts); q0 = 0; }
+                    if (q1) { T.y = slow_one<DIMS, GEOM>(pc, hy, i0 + 1, q1 == 1, b1, true, bits1, relocated, not_found, ts); q1 = 0; }
                 }
             }
         }
@@ -571,7 +598,7 @@ __global__ __launch_bounds__(STEP_BLOCK, STEP_WAVES_PER_SIMD) void step_kernel(P
             if (entry == -1) continue;
             const int i = entry & ~Q_RECALC_ONLY;
             const uint64_t bits = (uint64_t)__double_as_longlong(ph.tts[i]);
-            const double t = slow_one<DIMS, GEOM>(pc, hy, i, !(entry & Q_RECALC_ONLY), s_qb[e], true, bits, relocated, not_found);
+            const double t = slow_one<DIMS, GEOM>(pc, hy, i, !(entry & Q_RECALC_ONLY), s_qb[e], true, bits, relocated, not_found, ts);
             best.offer(t, i);
             if (t < t_cut) shortlist_push(sl, t, i);
         }
@@ -670,8 +697,8 @@ __device__ __forceinline__ bool scatter_decide(const HydroDev &hy, LoopState *st
 }
 
 template <int DIMS, int GEOM, bool STOKES, bool WAVE = false, class SRC = KeyedSource>
-__device__ __forceinline__ void scatter_finish(const HydroDev &hy, LoopState *st, EventMidT<typename SRC::Stream> &m, double p[4], double pc[4], double s[4],
-                                               double &tau_new, const SRC &src = SRC())
+__device__ __forceinline__ void scatter_finish(const HydroDev &hy, LoopState *st, const RngKey &key, unsigned long long iter, uint32_t rng_slot,
+                                               EventMidT<typename SRC::Stream> &m, double p[4], double pc[4], double s[4], double &tau_new, const SRC &src = SRC())
 {
     phys::single_scatter_finish<STOKES>(m.sm, pc, s, m.rng);           // the rest of mclib.c:1245
     src.close(m.rng);
@@ -683,7 +710,18 @@ __device__ __forceinline__ void scatter_finish(const HydroDev &hy, LoopState *st
     // cached cell (calcMeanFreePath, mclib.c:668-673: same position, same cell record, the new momentum) is computed
     // here while everything is in registers; the next pass still runs its in-cell test and re-locates if it fails.
     double norm = 1.0;
-    if constexpr (TABLE_MODE) norm = phys::thermal_cross_section(hy, pc[0], m.fluid_temp, !WAVE || (threadIdx.x & 63) == 0);   // optical_depth.c:58
+    if constexpr (TABLE_MODE) {                                        // optical_depth.c:58
+        double eps, theta;
+        if (phys::thermal_cross_section_lookup(hy, pc[0], m.fluid_temp, norm, eps, theta)) {
+            // off the table (hot_x_section.c:563-599).  The reference meets this look-up in the NEXT pass's calcMeanFreePath: the integral is keyed with
+            // that pass, so that a slot which has left its cell by then -- and is looked up again there -- is the only difference to it
+            const int calls = hy.hot_fallback_calls;
+            const bool whole_wave = WAVE && __ballot(1) == ~0ull;     // (the walk's wavefront: the same values in all lanes)
+            norm = whole_wave ? phys::table_fallback_wave(eps, theta, key.seed, iter + 1, rng_slot, key.stream, calls)
+                              : phys::table_fallback_lane(eps, theta, key.seed, iter + 1, rng_slot, key.stream, calls);
+            if (!WAVE || (threadIdx.x & 63) == 0) atomicAdd(hy.table_fallbacks, 1);
+        }
+    }
     tau_new = phys::optical_depth_staged(m.beta, m.w, m.nsig, p[1], p[2], p[3], norm);
 }
 
@@ -696,7 +734,7 @@ __device__ __forceinline__ bool scatter_core(const HydroDev &hy, LoopState *st, 
     const bool ok = scatter_decide<DIMS, GEOM, STOKES, WAVE, SRC>(hy, st, key, iter, rng_slot, cell, r, p, pc, s, m, src);
     fluid_temp = m.fluid_temp;
     if (!ok) return false;
-    scatter_finish<DIMS, GEOM, STOKES, WAVE, SRC>(hy, st, m, p, pc, s, tau_new, src);
+    scatter_finish<DIMS, GEOM, STOKES, WAVE, SRC>(hy, st, key, iter, rng_slot, m, p, pc, s, tau_new, src);
     return true;
 }
 
@@ -1134,7 +1172,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     extern __shared__ __align__(16) unsigned char s_dyn[];     // the list's r and -1/tau columns when it fits (lds_slots >= n)
     __shared__ LoopState st;
     __shared__ EventSharedT<RANK_BLOCK> sh;
-    __shared__ int s_qn, s_sln, s_nrel, s_hook, s_len, s_item;
+    __shared__ int s_qn, s_sln, s_nrel, s_hook, s_len, s_item, s_ndefer;
     __shared__ int s_qb[RANK_QCAP];
     // the slow-path queue shares memory with the event walk's sorted list: the queue is empty before the list is written
     static_assert(sizeof(sh.list) >= sizeof(int) * RANK_QCAP, "queue fits into the sorted-list storage");
@@ -1298,7 +1336,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         // instead of queueing them: no hand-over through LDS, and the chains of its slots overlap.  Where few do (dense frames), the
         // queue keeps the lanes of the slow path dense.  Same arithmetic either way.
         const bool fused = FUSE && !TABLE_MODE && (force || RANK_FUSE_DEN * prev_rel > n_pass);
-        if (tid == 0) { s_qn = 0; s_sln = 0; s_nrel = 0; }
+        if (tid == 0) { s_qn = 0; s_sln = 0; s_nrel = 0; s_ndefer = 0; }
         __syncthreads();
         int n_rel = 0;
 
@@ -1316,7 +1354,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             const int c1 = min(n_pass, c0 + RANK_QCAP);
             if (c0 > 0) {
                 __syncthreads();                             // the previous chunk's queue has been worked off
-                if (tid == 0) s_qn = 0;
+                if (tid == 0) { s_qn = 0; s_ndefer = 0; }
                 __syncthreads();
             }
             // Queue form: two slot pairs per thread per trip, every stage written over all four slots before the next stage: with
@@ -1514,13 +1552,46 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             if (!force) RANK_TICK(7);
             // ---- phase 2: the queued slots, dense
             const int qn = s_qn;
-            for (int e = tid; e < qn; e += EVENT_BLOCK) {
-                const int il = s_q[e] & ~Q_RECALC_ONLY;
-                const int i = base + il;
-                const uint64_t qbits = (uint64_t)__double_as_longlong(ph.tts(i));
-                const double t = slow_one<DIMS, GEOM, true>(ph, hy, i, !(s_q[e] & Q_RECALC_ONLY), s_qb[e], !force, qbits, relocated, not_found);
-                best.offer(t, i);
-                if (t < t_cut) shortlist_lds(t, i);
+            TableSite ts(rk, iter, base, TABLE_MODE ? 1 : 0);
+            // TAU_CALCULATION == TABLE has a second round: a slot whose look-up fell off the table (hot_x_section.c:563-599: the reference integrates
+            // the cross section afresh, 500 000 samples) left the first round as it came, (eps, theta) parked in its tau / -1/tau entries; now a
+            // wavefront per such slot integrates (physics.hpp: table_fallback_wave) and its lane 0 takes the slot through slow_one with the value
+#pragma nounroll
+            for (int round = 0; round < (TABLE_MODE ? 2 : 1); ++round) {
+                if (round == 1) {
+                    __syncthreads();
+                    if (!s_ndefer) break;
+                }
+                const int e_step = round == 0 ? EVENT_BLOCK : EVENT_BLOCK / 64;
+                for (int e = round == 0 ? tid : (tid >> 6); e < qn; e += e_step) {
+                    const int q = s_q[e];
+                    const int i = base + (q & ~(Q_RECALC_ONLY | Q_DEFERRED));
+                    if constexpr (TABLE_MODE) {
+                        if (round == 1) {
+                            if (!(q & Q_DEFERRED)) continue;                              // (the same for all lanes of the wavefront)
+                            const double norm = phys::table_fallback_wave(ph.tau(i), ph.ntau(i), ts.seed, ts.pass, ts.slot_base + (uint32_t)(i - base), ts.stream,
+                                                                          hy.hot_fallback_calls);
+                            if (lane != 0) continue;
+                            atomicAdd(hy.table_fallbacks, 1);
+                            ts.mode = 2;
+                            ts.norm = norm;
+                        }
+                    }
+                    const uint64_t qbits = (uint64_t)__double_as_longlong(ph.tts(i));
+                    const double t = slow_one<DIMS, GEOM, true>(ph, hy, i, !(q & Q_RECALC_ONLY), s_qb[e], !force, qbits, relocated, not_found, ts);
+                    if constexpr (TABLE_MODE) {
+                        if (ts.deferred) {
+                            ts.deferred = false;
+                            ph.tau(i) = ts.eps;
+                            ph.ntau(i) = ts.theta;
+                            s_q[e] = q | Q_DEFERRED;
+                            s_ndefer = 1;
+                            continue;
+                        }
+                    }
+                    best.offer(t, i);
+                    if (t < t_cut) shortlist_lds(t, i);
+                }
             }
         }
         wave_min_pair_dpp(best.t, best.i);
@@ -1813,7 +1884,9 @@ __global__ __launch_bounds__(FAST_BLOCK, 2) void fast_frame_kernel(PhotonDev ph,
                 if (!act[k]) continue;
                 const int i = slot[k];
                 if (queue[k]) {
-                    t[k] = slow_one<DIMS, GEOM>(pcols, hy, i, queue[k] == 1, code[k], true, bits[k], relocated, not_found);
+                    TableSite ts(key, (unsigned long long)pass);
+                    ts.slot_base = rng_first;
+                    t[k] = slow_one<DIMS, GEOM>(pcols, hy, i, queue[k] == 1, code[k], true, bits[k], relocated, not_found, ts);
                     cell[k] = ph.idx[i];
                 }
                 steps += 1;

@@ -81,7 +81,7 @@ class FrameStats(C.Structure):
                 ("last_scattered_index", C.c_int), ("last_scattered_temp", C.c_double),
                 ("last_time_step", C.c_double), ("remaining_time", C.c_double), ("time_now", C.c_double),
                 ("step_kernel_ms", C.c_double), ("step_kernel_launches", C.c_longlong), ("event_kernel_ms", C.c_double),
-                ("table_misses", C.c_longlong), ("slot_steps", C.c_longlong)]
+                ("table_fallbacks", C.c_longlong), ("slot_steps", C.c_longlong)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -214,6 +214,7 @@ SYMBOLS = {
     "mcrat_hip_inject_photons": (C.c_int, [_ctx, C.c_double, C.c_double, C.c_int, C.c_int, C.c_char, C.c_double, C.c_double, C.c_double,
                                            C.c_uint64, _ip, _dp]),
     "mcrat_hip_set_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
+    "mcrat_hip_table_fallback_calls": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_create_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
                                                      C.c_uint64]),
     "mcrat_hip_set_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
@@ -446,6 +447,10 @@ class Engine:
         self._check(self.lib.mcrat_hip_set_hot_cross_section(self.ctx, t.ctypes.data_as(_dp), t.shape[0] - 1, t.shape[1] - 1,
                                                              float(grid[0]), float(grid[1]), float(grid[2]), float(grid[3])),
                     "set_hot_cross_section")
+
+    def table_fallback_calls(self, calls=0):
+        """samples of the integral a look-up off the table takes (hot_x_section.c:348: 500000); calls > 0 sets it"""
+        return int(self.lib.mcrat_hip_table_fallback_calls(self.ctx, int(calls)))
 
     def create_hot_cross_section(self, n_ph_e=220, n_t=80, grid=(-12.0, 6.0, -4.0, 4.0), calls=500000, seed=1):
         """createHotCrossSection (hot_x_section.c:82-133) on the device -> (n_ph_e + 1, n_t + 1) array of log10(sigma / sigma_T)"""

@@ -629,9 +629,9 @@ int orc_singleScatter(const orc_config *c, double el_comov[4], double ph_comov[4
  * GSL is not in this image; its published bilinear scheme (interp2d/bilinear.c of GSL 2.x: cell found by bisection
  * with x[i] <= x < x[i+1], the last cell closed; t = (x-x_i)/(x_{i+1}-x_i), u likewise;
  * z = (1-t)(1-u) z00 + t(1-u) z10 + (1-t)u z01 + t u z11) is restated here.
- * Deviation: outside the tabulated range GSL reports GSL_EDOM and the reference integrates the cross section
- * afresh with gsl_monte_plain (hot_x_section.c:563-599, consuming random numbers); here the arguments are clamped
- * to the table's edge and the event is counted (table_misses). */
+ * Outside the tabulated range GSL reports GSL_EDOM and the reference integrates the cross section afresh with
+ * gsl_monte_plain (hot_x_section.c:563-599 -> :324-356, 2 x 500 000 numbers from the rank's generator): orc_tableFallbackCrossSection
+ * below, from the keyed source (the look-up is counted in table_fallbacks). */
 /* electron.c:538-561 */
 double orc_singleMaxwellJuttner(double gamma, double theta)
 {
@@ -683,9 +683,41 @@ void orc_createHotCrossSection(double *thermal_table, int n_ph_e, int n_t, doubl
         }
 }
 
-static long long g_table_misses = 0;
-long long orc_table_misses(void) { return g_table_misses; }
-void orc_reset_table_misses(void) { g_table_misses = 0; }
+/* interpolateThermalHotCrossSection's GSL_EDOM branch inside the loop (hot_x_section.c:563-599): calculateTotalThermalCrossSection (:324-356) at
+ * (eps, theta) with the plain Monte-Carlo rule of orc_calculateTotalThermalCrossSection above, its 256 substreams keyed
+ * {iteration = pass | (s + 1) << 48, word2 = slot, purpose = 9, the list's stream} -- the engine's physics.hpp:table_fallback_* -- and returned as
+ * getThermalCrossSection returns it: 10^log10(integral) (:588, optical_depth.c:143).  (The normalisation of singleMaxwellJuttner depends on theta
+ * only and is taken once.) */
+double orc_tableFallbackCrossSection(const orc_config *c, double eps, double theta, const orc_rng *rng, uint32_t slot)
+{
+    const long long calls = c->fallback_calls > 0 ? c->fallback_calls : 500000;              /* :348 */
+    const double xl[2] = {1, -1}, xu[2] = {1. + 12 * theta, 1};
+    double normalization;
+    if (theta > 1.e-2) normalization = orc_bessel_K2(1. / theta) * exp(1. / theta);
+    else normalization = sqrt(M_PI * theta / 2.);
+    orc_rng r;
+    orc_rng_init(&r, rng ? rng->seed : 0, rng ? rng->stream : 0);
+    const uint64_t pass = rng ? rng->iteration : 0;
+    double total = 0;
+    for (int s = 0; s < 256 && s < calls; s++) {
+        orc_rng_set_iteration(&r, pass | ((uint64_t)(s + 1) << 48));
+        orc_rng_stream_begin(&r, slot, 9u);
+        double sum = 0;
+        for (long long k = s; k < calls; k += 256) {
+            const double gamma = xl[0] + orc_rng_uniform_pos(&r) * (xu[0] - xl[0]);
+            const double mu = xl[1] + orc_rng_uniform_pos(&r) * (xu[1] - xl[1]);
+            const double mj = ((gamma * sqrt(gamma * gamma - 1.) / (theta * normalization)) * exp(-(gamma - 1.) / theta));   /* electron.c:560 */
+            sum += mj * orc_boostedCrossSection(eps, mu, gamma);
+        }
+        total += sum;
+    }
+    const double result = 0.5 * (((xu[0] - xl[0]) * (xu[1] - xl[1])) * (total / (double)calls));
+    return pow(10.0, log10(result));
+}
+
+static long long g_table_fallbacks = 0;
+long long orc_table_fallbacks(void) { return g_table_fallbacks; }
+void orc_reset_table_fallbacks(void) { g_table_fallbacks = 0; }
 
 static int bisect_cell(double x0, double dx, int n_cells, double x)
 {
@@ -700,25 +732,27 @@ static int bisect_cell(double x0, double dx, int n_cells, double x)
 
 double orc_getThermalCrossSection(const orc_config *c, double photon_comv_e, double fluid_temp, int *miss)
 {
+    return orc_getThermalCrossSection_keyed(c, photon_comv_e, fluid_temp, NULL, 0, miss);
+}
+
+/* rng: the list's generator in the pass the look-up happens in, slot: the photon's index -- the key of the integral a look-up off the table takes */
+double orc_getThermalCrossSection_keyed(const orc_config *c, double photon_comv_e, double fluid_temp, const orc_rng *rng, uint32_t slot, int *miss)
+{
     if (c->tau_calculation != ORC_TAU_TABLE) return 1;                         /* optical_depth.c:125-127,147 */
     const double normalized_photon_comv_e = photon_comv_e / (ORC_M_EL * ORC_C_LIGHT);     /* :139 */
     const double theta = ORC_K_B * fluid_temp / (ORC_M_EL * ORC_C_LIGHT * ORC_C_LIGHT);   /* calcDimlessTheta, mc_cyclosynch.c:48-52 */
-    double x = log10(normalized_photon_comv_e), y = log10(theta);
+    const double x = log10(normalized_photon_comv_e), y = log10(theta);
     const double dx = (c->log_ph_e_max - c->log_ph_e_min) / c->n_ph_e;        /* hot_x_section.c:464 */
     const double dy = (c->log_t_max - c->log_t_min) / c->n_t;
     const double x_hi = c->log_ph_e_min + c->n_ph_e * dx, y_hi = c->log_t_min + c->n_t * dy;
-    int out = 0;
-    if (!(x >= c->log_ph_e_min)) { x = c->log_ph_e_min; out = 1; }
-    if (x > x_hi) { x = x_hi; out = 1; }
-    if (!(y >= c->log_t_min)) { y = c->log_t_min; out = 1; }
-    if (y > y_hi) { y = y_hi; out = 1; }
-    if (out) {
+    if (!(x >= c->log_ph_e_min) || x > x_hi || !(y >= c->log_t_min) || y > y_hi) {          /* gsl_spline2d_eval_e: GSL_EDOM */
         /* interpolateThermalHotCrossSection's fallback (hot_x_section.c:563-599): calculateTotalThermalCrossSection (:324-356) -- cold plasma below the
-         * table is 1 / the Klein-Nishina cross section (:337-340); its Monte-Carlo integral for the remaining cases is not restated: clamped, counted */
+         * table is 1 / the Klein-Nishina cross section (:337-340); else its Monte-Carlo integral at 10^x, 10^y (:584-588) */
         const double theta_min = pow(10.0, c->log_t_min), e_min = pow(10.0, c->log_ph_e_min);
         if (theta < theta_min) return (normalized_photon_comv_e < e_min) ? 1.0 : orc_kleinNishinaCrossSection(normalized_photon_comv_e);
-        g_table_misses += 1;
+        g_table_fallbacks += 1;
         if (miss) *miss += 1;
+        return orc_tableFallbackCrossSection(c, pow(10.0, x), pow(10.0, y), rng, slot);
     }
     const int xi = bisect_cell(c->log_ph_e_min, dx, c->n_ph_e, x);
     const int yi = bisect_cell(c->log_t_min, dy, c->n_t, y);
@@ -735,6 +769,11 @@ double orc_getThermalCrossSection(const orc_config *c, double photon_comv_e, dou
 /* optical_depth.c:7-59 (getCrossSection :117-130: 1 in DIRECT, the table in TABLE) */
 void orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hydro *h)
 {
+    orc_calculateOpticalDepth_keyed(c, ph, h, NULL, 0);
+}
+
+void orc_calculateOpticalDepth_keyed(const orc_config *c, orc_photon *ph, const orc_hydro *h, const orc_rng *rng, uint32_t slot)
+{
     int idx = ph->nearest_block_index;
     double fluid_beta[3];
     double ph_phi = atan2(ph->r1, ph->r0);
@@ -747,13 +786,20 @@ void orc_calculateOpticalDepth(const orc_config *c, orc_photon *ph, const orc_hy
     double beta = sqrt(1.0 - 1.0 / (h->gamma[idx] * h->gamma[idx]));
     double fluid_factor = (1.0 - beta * n_cosangle);
     double thermal_n_dens_lab = h->dens_lab[idx] / ORC_M_P;
-    double norm_cross_section = orc_getThermalCrossSection(c, ph->comv_p0, h->temp[idx], NULL);   /* :58 */
+    double norm_cross_section = orc_getThermalCrossSection_keyed(c, ph->comv_p0, h->temp[idx], rng, slot, NULL);   /* :58 */
     ph->total_optical_depth = (thermal_n_dens_lab) * (ORC_THOM_X_SECT * norm_cross_section) * fluid_factor;
 }
 
 /* mclib.c:436-615 */
 int orc_findContainingHydroCell(const orc_config *c, orc_photon_list *l, const orc_hydro *h,
                                 int find_nearest_block_switch, orc_stats *st)
+{
+    return orc_findContainingHydroCell_keyed(c, l, h, find_nearest_block_switch, st, NULL);
+}
+
+/* (the reference's takes gsl_rng *rand for the look-ups off the table, mclib.c:436; `rng` here keys them) */
+int orc_findContainingHydroCell_keyed(const orc_config *c, orc_photon_list *l, const orc_hydro *h,
+                                      int find_nearest_block_switch, orc_stats *st, const orc_rng *rng)
 {
     int n_new = 0;
     for (int i = 0; i < l->list_capacity; i++) {
@@ -785,7 +831,7 @@ int orc_findContainingHydroCell(const orc_config *c, orc_photon_list *l, const o
                     ph->comv_p1 = ph_p_comv[1];
                     ph->comv_p2 = ph_p_comv[2];
                     ph->comv_p3 = ph_p_comv[3];
-                    orc_calculateOpticalDepth(c, ph, h);
+                    orc_calculateOpticalDepth_keyed(c, ph, h, rng, (uint32_t)i);
                     if (ph->recalc_properties == 1) ph->recalc_properties = 0;
                     n_new += 1;
                 } else if (st) {
@@ -854,7 +900,7 @@ void orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hyd
         double mfp;
         if (ph->nearest_block_index != -1) {
             if (ph->recalc_properties == 1) {
-                orc_calculateOpticalDepth(c, ph, h);
+                orc_calculateOpticalDepth_keyed(c, ph, h, rng, (uint32_t)i);
                 ph->recalc_properties = 0;
             }
             double rnd = orc_rng_freepath_draw(rng, (uint32_t)i);
@@ -1003,10 +1049,10 @@ void orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro *h
 {
     long long it = 0;
     double time_step = 0;
-    const long long misses0 = g_table_misses;
+    const long long misses0 = g_table_fallbacks;
     while (*remaining_time > 0 && (max_iterations <= 0 || it < max_iterations)) {
         orc_rng_set_iteration(rng, iteration_base + (uint64_t)it);
-        st->num_photons_find_new_element += orc_findContainingHydroCell(c, l, h, *find_nearest_grid_switch, st);
+        st->num_photons_find_new_element += orc_findContainingHydroCell_keyed(c, l, h, *find_nearest_grid_switch, st, rng);
         orc_calcMeanFreePath(c, l, h, rng);
         *find_nearest_grid_switch = 0;
 
@@ -1028,7 +1074,7 @@ void orc_photon_loop(const orc_config *c, orc_photon_list *l, const orc_hydro *h
     st->last_time_step = time_step;
     st->remaining_time = *remaining_time;
     st->time_now = *time_now;
-    st->table_misses += g_table_misses - misses0;
+    st->table_fallbacks += g_table_fallbacks - misses0;
 }
 
 /* ------------------------------------------------------------------ */

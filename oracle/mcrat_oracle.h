@@ -114,6 +114,7 @@ typedef struct orc_config {
      * author would remove: the cell search goes through an exact bucket grid (orc_grid_attach) and only the prefix of
      * the sorted order that photonEvent consumes is produced (bench.py "cpu_optimised"). */
     int optimised;
+    int fallback_calls; /* TABLE: samples of the integral a look-up off the table takes (0: the reference's 500 000, hot_x_section.c:348) */
 } orc_config;
 /* builds (and replaces) the bucket grid for `h`; used by orc_findContainingBlock when c->optimised and the frame matches */
 void orc_grid_attach(const orc_config *c, const orc_hydro *h);
@@ -131,7 +132,7 @@ typedef struct orc_stats {
     double last_time_step;
     double remaining_time;
     double time_now;
-    long long table_misses;          /* TABLE: lookups outside the tabulated range (clamped; see orc_getThermalCrossSection) */
+    long long table_fallbacks;          /* TABLE: look-ups off the table, integrated afresh (orc_tableFallbackCrossSection) */
 } orc_stats;
 
 /* ---- photonInjection ------------------------------------ */
@@ -183,8 +184,13 @@ double orc_boostedCrossSection(double norm_ph_comv, double mu, double gamma);   
 double orc_calculateTotalThermalCrossSection(double ph_comv, double theta, long long calls, uint64_t seed, int entry); /* :324 */
 void   orc_createHotCrossSection(double *thermal_table, int n_ph_e, int n_t, double log_ph_e_min, double log_ph_e_max,
                                  double log_t_min, double log_t_max, long long calls, uint64_t seed);  /* :82-107 */
-long long orc_table_misses(void);   /* lookups outside the table since orc_reset_table_misses() */
-void   orc_reset_table_misses(void);
+double orc_tableFallbackCrossSection(const orc_config *c, double eps, double theta, const orc_rng *rng, uint32_t slot); /* hot_x_section.c:563-599 */
+double orc_getThermalCrossSection_keyed(const orc_config *c, double photon_comv_e, double fluid_temp, const orc_rng *rng, uint32_t slot, int *miss);
+void   orc_calculateOpticalDepth_keyed(const orc_config *c, orc_photon *ph, const orc_hydro *h, const orc_rng *rng, uint32_t slot);
+int    orc_findContainingHydroCell_keyed(const orc_config *c, orc_photon_list *l, const orc_hydro *h, int find_nearest_block_switch, orc_stats *st,
+                                         const orc_rng *rng);
+long long orc_table_fallbacks(void);   /* look-ups off the table (integrated afresh) since orc_reset_table_fallbacks() */
+void   orc_reset_table_fallbacks(void);
 int    orc_findContainingHydroCell(const orc_config *c, orc_photon_list *l, const orc_hydro *h,
                                    int find_nearest_block_switch, orc_stats *st);                /* mclib.c:436 */
 void   orc_calcMeanFreePath(const orc_config *c, orc_photon_list *l, const orc_hydro *h, orc_rng *rng); /* mclib.c:617 */

@@ -600,7 +600,7 @@ void orc_scatter_frame_cs(const orc_config *c, orc_cs *cs, orc_photon_list *l, c
     double time_step = 0;
     while (remaining_time > 0 && (max_iterations <= 0 || it < max_iterations) && !cnt->error) {   /* :761-851 */
         orc_rng_set_iteration(rng, (uint64_t)it);
-        st->num_photons_find_new_element += orc_findContainingHydroCell(c, l, h, find_nearest_grid_switch, st);
+        st->num_photons_find_new_element += orc_findContainingHydroCell_keyed(c, l, h, find_nearest_grid_switch, st, rng);
         orc_calcMeanFreePath(c, l, h, rng);
         find_nearest_grid_switch = 0;
         if (l->photons[l->sorted_indexes[0]].time_to_scatter < remaining_time) {

@@ -60,7 +60,7 @@ class Config(C.Structure):
     _fields_ = [("dimensions", C.c_int), ("geometry", C.c_int), ("stokes_switch", C.c_int), ("tau_calculation", C.c_int),
                 ("hot_table", C.POINTER(C.c_double)), ("n_ph_e", C.c_int), ("n_t", C.c_int),
                 ("log_ph_e_min", C.c_double), ("log_ph_e_max", C.c_double), ("log_t_min", C.c_double), ("log_t_max", C.c_double),
-                ("optimised", C.c_int)]
+                ("optimised", C.c_int), ("fallback_calls", C.c_int)]
 
 
 class Stats(C.Structure):
@@ -68,7 +68,7 @@ class Stats(C.Structure):
                 ("frame_scatt_cnt", C.c_longlong), ("num_photons_find_new_element", C.c_longlong),
                 ("not_found", C.c_longlong), ("kn_rejections", C.c_longlong), ("event_draws", C.c_longlong),
                 ("last_scattered_index", C.c_int), ("last_time_step", C.c_double),
-                ("remaining_time", C.c_double), ("time_now", C.c_double), ("table_misses", C.c_longlong)]
+                ("remaining_time", C.c_double), ("time_now", C.c_double), ("table_fallbacks", C.c_longlong)]
 
 
 FRAME_FIELDS = ("r0", "r1", "r2", "r0_size", "r1_size", "r2_size", "v0", "v1", "v2", "dens", "dens_lab", "pres", "temp", "gamma", "r", "theta")
@@ -229,8 +229,8 @@ def lib():
             "orc_saveCheckpoint_convert": (i, [lp]),
             "orc_scatter_frame_cs": (None, [cfgp, C.POINTER(CS), lp, hp, rp, _dp, d, d, d, i, d, d, i, C.c_longlong, sp, C.POINTER(CSCounts)]),
             "orc_rebinCyclosynchCompPhotons": (i, [cfgp, C.POINTER(CS), lp, C.POINTER(i), C.POINTER(i), i]),
-            "orc_table_misses": (C.c_longlong, []),
-            "orc_reset_table_misses": (None, []),
+            "orc_table_fallbacks": (C.c_longlong, []),
+            "orc_reset_table_fallbacks": (None, []),
             "orc_findContainingHydroCell": (i, [cfgp, lp, hp, i, sp]),
             "orc_calcMeanFreePath": (None, [cfgp, lp, hp, rp]),
             "orc_updatePhotonPosition": (None, [lp, d]),
@@ -302,11 +302,12 @@ class OraclePhotons:
         self.c.list_capacity = n
 
 
-def make_config(dimensions, geometry, stokes, hot_table=None, grid=None, optimised=False):
+def make_config(dimensions, geometry, stokes, hot_table=None, grid=None, optimised=False, fallback_calls=0):
     """hot_table: (N_PH_E + 1, N_T + 1) array of log10(sigma / sigma_T) -> TAU_CALCULATION == TABLE on the grid
     (log_ph_e_min, log_ph_e_max, log_t_min, log_t_max), default the reference's (hot_x_section.h:2-10)."""
     c = Config(int(dimensions), int(geometry), int(bool(stokes)), 1)
     c.optimised = int(bool(optimised))           # same results with an exact cell-search grid (orc_grid_attach) and a prefix sort
+    c.fallback_calls = int(fallback_calls)       # samples of a look-up off the table (0: 500 000, hot_x_section.c:348)
     if hot_table is not None:
         import numpy as np
         t = np.ascontiguousarray(hot_table, dtype=np.float64)

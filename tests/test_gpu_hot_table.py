@@ -64,6 +64,6 @@ def test_reference_size_table_in_a_second_with_the_right_limits(hip, oracle):
     e.set_photons(ph)
     e.begin_frame(4, 0.0, 0.2)
     st = e.run(200)
-    assert st.frame_scatt_cnt > 20 and st.table_misses == 0
+    assert st.frame_scatt_cnt > 20 and st.table_fallbacks == 0
     e.close()
     print("hot cross-section table, 221 x 81 x 500000 samples: %.3f s" % dt)

@@ -679,21 +679,48 @@ def test_hot_cross_section_interpolation(oracle):
         e, T = 10.0 ** x[a, b] * ME * CL, 10.0 ** y[a, b] * ME * CL * CL / KB
         got = L.orc_getThermalCrossSection(C.byref(c2), e * (1 + 1e-13), T * (1 + 1e-13), None)
         assert np.log10(got) == pytest.approx(tab2[a, b], abs=1e-11)
-    # outside: clamped and counted
-    L.orc_reset_table_misses()
-    m = C.c_int(0)
-    got = L.orc_getThermalCrossSection(C.byref(c2), 1e-14 * ME * CL, 1e7, C.byref(m))
-    edge = L.orc_getThermalCrossSection(C.byref(c2), 1e-12 * ME * CL, 1e7, None)
-    assert m.value == 1 and L.orc_table_misses() == 1 and got == pytest.approx(edge, rel=1e-12)
+    # outside at a tabulated temperature: the cross section is integrated afresh (hot_x_section.c:563-599 -> :324-356) and the look-up counted.
+    # Against a Gauss-Legendre quadrature of the same integrand (electron.c:538-561, hot_x_section.c:370-400), within the Monte-Carlo error of
+    # 500 000 samples; and in the Thomson limit the integral is the normalisation of the electron distribution, 1
+    L.orc_reset_table_fallbacks()
+    L.orc_singleMaxwellJuttner.restype = C.c_double
+    L.orc_boostedCrossSection.restype = C.c_double
+    for e_norm, T in ((1e-14, 1e7), (3e6, 3e9), (1e-13, 2e10)):
+        m = C.c_int(0)
+        got = L.orc_getThermalCrossSection(C.byref(c2), e_norm * ME * CL, T, C.byref(m))
+        theta = KB * T / (ME * CL * CL)
+        gx, gw = np.polynomial.legendre.leggauss(96)
+        gam = 1 + (gx + 1) * 6 * theta
+        quad = 0.0
+        for g, wg in zip(gam, gw * 6 * theta):
+            f = L.orc_singleMaxwellJuttner(C.c_double(g), C.c_double(theta))
+            quad += wg * f * sum(wm * L.orc_boostedCrossSection(C.c_double(e_norm), C.c_double(mu), C.c_double(g)) for mu, wm in zip(gx, gw))
+        assert m.value == 1 and got == pytest.approx(0.5 * quad, rel=1e-2), (e_norm, T, got, 0.5 * quad)
+        if e_norm < 1e-10:
+            assert got == pytest.approx(1.0, rel=1e-2)
+    assert L.orc_table_fallbacks() == 3
+    # the integral belongs to (pass, slot, list): the same key gives the same number, another slot another sample of it
+    L.orc_getThermalCrossSection_keyed.restype = C.c_double
+    L.orc_getThermalCrossSection_keyed.argtypes = [C.POINTER(oracle.Config), C.c_double, C.c_double, C.POINTER(oracle.Rng), C.c_uint32, C.POINTER(C.c_int)]
+    c3 = oracle.make_config(0, 2, 0, hot_table=tab2, fallback_calls=20000)
+    r = oracle.Rng()
+    L.orc_rng_init(C.byref(r), 77, 3)
+    L.orc_rng_set_iteration(C.byref(r), 12)
+    a = L.orc_getThermalCrossSection_keyed(C.byref(c3), 1e-14 * ME * CL, 1e9, C.byref(r), 5, None)
+    b = L.orc_getThermalCrossSection_keyed(C.byref(c3), 1e-14 * ME * CL, 1e9, C.byref(r), 5, None)
+    d = L.orc_getThermalCrossSection_keyed(C.byref(c3), 1e-14 * ME * CL, 1e9, C.byref(r), 6, None)
+    L.orc_rng_set_iteration(C.byref(r), 13)
+    e2 = L.orc_getThermalCrossSection_keyed(C.byref(c3), 1e-14 * ME * CL, 1e9, C.byref(r), 5, None)
+    assert a == b and a != d and a != e2 and d == pytest.approx(a, rel=0.1) and e2 == pytest.approx(a, rel=0.1)
     # cold plasma below the table: what calculateTotalThermalCrossSection returns there (hot_x_section.c:337-340), not counted as a miss
     L.orc_kleinNishinaCrossSection.restype = C.c_double
-    L.orc_reset_table_misses()
+    L.orc_reset_table_fallbacks()
     m = C.c_int(0)
     for e_norm in (1e-6, 0.3, 40.0):
         got = L.orc_getThermalCrossSection(C.byref(c2), e_norm * ME * CL, 1e5, C.byref(m))        # theta = 1.7e-5 < 1e-4
         assert got == L.orc_kleinNishinaCrossSection(C.c_double(e_norm))
     assert L.orc_getThermalCrossSection(C.byref(c2), 1e-13 * ME * CL, 1e5, C.byref(m)) == 1.0    # the photon below the table too
-    assert m.value == 0 and L.orc_table_misses() == 0
+    assert m.value == 0 and L.orc_table_fallbacks() == 0
     # DIRECT
     d = oracle.make_config(0, 2, 0)
     assert L.orc_getThermalCrossSection(C.byref(d), 1e-20, 1e7, None) == 1.0
