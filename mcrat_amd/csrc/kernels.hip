@@ -192,7 +192,7 @@ __device__ __forceinline__ double div_by_c(double x)
 __device__ __forceinline__ double sample_free_time(double ntau /* -1.0 / tau */, uint64_t bits)
 {
     const double rnd = bits_to_uniform_pos(bits);
-    const double mfp = ntau * phys::log_unit(rnd);
+    const double mfp = ntau * log(rnd);
     return div_by_c(mfp);
 }
 
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(TAPE_BLOCK) void tape_draw_kernel(PhotonDev ph, con
         if (valid) {
             double t = ph.tts[i];                                          // slots without a cell: 1e12 / c, stored by step_kernel (mclib.c:620,684)
             if (located) {
-                t = div_by_c(ph.ntau[i] * phys::log_unit(s_u[rank]));                 // mclib.c:675-687
+                t = div_by_c(ph.ntau[i] * log(s_u[rank]));                 // mclib.c:675-687
                 ph.tts[i] = t;
             }
             best.offer(t, i);
@@ -1160,6 +1160,8 @@ constexpr int rank_lds_bytes_per_slot(int block) { return block == 256 ? 7 * (in
 // queue's paths costs a build that does not use them 25 spilled doubles per lane (measured: the 2-D spherical Stokes build 128 -> 328 B of scratch, cfg3's
 // frame 6.0 -> 8.2 ms), and instantiated only for the 256-thread lists with their columns in LDS; every other launch form runs a plan frame by frame.
 template <int DIMS, int GEOM, bool STOKES, bool RESIDENT, int RANK_BLOCK, bool FUSE, bool CSH = false, bool QUEUE = false>
+// (one wavefront per SIMD for the small-list builds -- up to 512 registers, spills to AGPRs, no scratch -- measured slower: cfg5's 64-thread lists
+// frac 0.394 -> 0.365, cfg3's 128-thread lists 0.32 -> 0.21: the second wavefront hides more latency than the scratch traffic costs)
 __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_kernel(PhotonDev gph, HydroDev hy_arg, LoopState *states, RngKey key,
                                                                 RankLayout lay, long long max_passes, int lds_slots)
 {
@@ -1296,8 +1298,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         for (int pair = tid - first_thread; 2 * pair < n_pass; pair += n_threads) {
             const Philox4 blk = keyed_block(rk.seed, it, (uint32_t)pair, RNG_FREEPATH, rk.stream);
             const int i = base + 2 * pair;
-            ph.draw_log(i) = phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32)));
-            if (2 * pair + 1 < n) ph.draw_log(i + 1) = phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32)));
+            ph.draw_log(i) = log(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32)));
+            if (2 * pair + 1 < n) ph.draw_log(i + 1) = log(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32)));
         }
     };
     if constexpr (SHADOW) {
@@ -1431,8 +1433,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
 #pragma unroll
                         for (int j = 0; j < PAIRS; ++j) {
                             const Philox4 blk = keyed_block(rk.seed, iter, (uint32_t)(pair + j * EVENT_BLOCK), RNG_FREEPATH, rk.stream);
-                            bits[2 * j] = (uint64_t)__double_as_longlong(phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32))));
-                            bits[2 * j + 1] = (uint64_t)__double_as_longlong(phys::log_unit(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))));
+                            bits[2 * j] = (uint64_t)__double_as_longlong(log(bits_to_uniform_pos((uint64_t)blk.w[0] | ((uint64_t)blk.w[1] << 32))));
+                            bits[2 * j + 1] = (uint64_t)__double_as_longlong(log(bits_to_uniform_pos((uint64_t)blk.w[2] | ((uint64_t)blk.w[3] << 32))));
                         }
                     }
                     // decisions, slot by slot

@@ -26,8 +26,8 @@ constexpr int REJECTION_CAP = 1 << 22;   // every rejection loop is bounded so t
 // and folds the divisions the reference repeats (p/|p| thrice in zeroNorm, six by beta^2 in lorentzBoost) into one reciprocal.
 // The values are the reference's real numbers rounded differently in the last place or two; the gates are the oracle's
 // (integers exact, doubles 1e-9 over trajectories, tests/).
-// -DMCRAT_IEEE_ARITH=1 (a variant build, tools/variant_build.py ieee -DMCRAT_IEEE_ARITH=1; not the product): the three helpers below and log_unit
-// become the IEEE division, square root and the math library's logarithm the reference's C compiles to -- for a maintainer who compares photon for
+// -DMCRAT_IEEE_ARITH=1 (a variant build, tools/variant_build.py ieee -DMCRAT_IEEE_ARITH=1; not the product): the three helpers below
+// become the IEEE division and square root the reference's C compiles to (the logarithm of the free-path draws is the math library's in every build) -- for a maintainer who compares photon for
 // photon with MCRaT on a recorded tape (tools/ref_harness) and wants every decision taken on correctly rounded operands.  What stays in either build
 // is algebra, not approximation: the boost as p + (kf (b.p) - g p0) b, the optical depth on per-cell operands -- the same real numbers as the
 // reference's expressions, rounded in a different order (a few ulp).  tests/test_gpu_tape.py passes on both builds; the product's gate is the oracle's
@@ -65,39 +65,6 @@ __device__ __forceinline__ double sqrt_nr(double x)
 }
 #endif
 
-// ln(u) for the free-path draws: 0 < u < 1, a normal double (rng.hpp, bits_to_uniform_pos: u >= 2^-53; a tape's uniforms alike).  Every located
-// slot draws one per pass (mclib.c:675-680), which makes the logarithm a fifth of the loop's instructions; the math library's handles
-// zero, negative, infinite and subnormal arguments and keeps the result under one ulp with double-double arithmetic -- 76 instructions.  This is the
-// classical reduction (u = 2^k m, sqrt(1/2) <= m < sqrt(2); f = m - 1; s = f / (2 + f); ln m = f - (f^2/2 - s (f^2/2 + R(s^2))) with the minimax
-// polynomial R of degree 14 in s that fdlibm's log documents) on the arguments that can occur here: 36 instructions, within 2 ulp of ln(u) -- a relative
-// 4e-16 on a free path (the gates are the oracle's, which calls the C library's log: integers exact, doubles 1e-9 over trajectories).
-__device__ __forceinline__ double log_unit(double u)
-{
-#if defined(MCRAT_IEEE_ARITH) && MCRAT_IEEE_ARITH
-    return log(u);
-#endif
-    constexpr double LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
-    constexpr double LG1 = 6.666666666666735130e-01, LG2 = 3.999999999940941908e-01, LG3 = 2.857142874366239149e-01, LG4 = 2.222219843214978396e-01,
-                     LG5 = 1.818357216161805012e-01, LG6 = 1.531383769920937332e-01, LG7 = 1.479819860511658591e-01;
-    double m = __builtin_amdgcn_frexp_mant(u);              // [1/2, 1)
-    int k = __builtin_amdgcn_frexp_exp(u);
-    const bool low = m < 0.70710678118654752440;
-    m = low ? m + m : m;
-    k = low ? k - 1 : k;
-    const double f = m - 1.0;
-    const double d = 2.0 + f;                                // in [1.7, 2.42): the reciprocal needs no guard
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    const double s = f * r;
-    const double z = s * s, w = z * z;
-    const double t1 = w * fma(w, fma(w, LG6, LG4), LG2);
-    const double t2 = z * fma(w, fma(w, fma(w, LG7, LG5), LG3), LG1);
-    const double R = t2 + t1;
-    const double hfsq = 0.5 * f * f;
-    const double dk = (double)k;
-    return fma(dk, LN2_HI, -((hfsq - fma(s, hfsq + R, dk * LN2_LO)) - f));
-}
 
 // ---------------------------------------------------------------- geometry
 // geometry.c:15-64

@@ -30,18 +30,22 @@ def main():
     procs = []
     for tu in tus:
         obj = os.path.join(objdir, os.path.splitext(tu)[0] + ".o")
+        errf = open(obj + ".log", "w+")                 # (a file, not a pipe: the remarks of one TU fill a pipe and the TUs would compile one after the other)
         procs.append((obj, subprocess.Popen([build.hipcc()] + cflags + ["-Rpass-analysis=kernel-resource-usage", os.path.join(build.CSRC, tu), "-o", obj],
-                                            stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+                                            stdout=subprocess.DEVNULL, stderr=errf, text=True), errf))
     errs = []
-    for obj, p in procs:
-        _, err = p.communicate()
+    for obj, p, errf in procs:
+        p.wait()
+        errf.seek(0)
+        err = errf.read()
+        errf.close()
         errs.append(err)
         if p.returncode != 0:
             sys.stderr.write(err)
             raise SystemExit("hipcc failed")
     open(log, "w").write("".join(errs))
-    built = {os.path.basename(o) for o, _ in procs}
-    objs = [o for o, _ in procs]
+    built = {os.path.basename(o) for o, _, _ in procs}
+    objs = [o for o, _, _ in procs]
     for src in build.SOURCES:
         o = os.path.splitext(src)[0] + ".o"
         if o not in built:
@@ -52,7 +56,6 @@ def main():
         sys.stderr.write(r.stderr)
         raise SystemExit("link failed")
     print(lib)
-    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), log])
 
 
 if __name__ == "__main__":
