@@ -16,7 +16,15 @@ LIB = os.path.join(HERE, "libmcrat_hip.so")
 KERNEL_TUS = ["kernels%s_d%d.hip" % (m, d) for m in ("", "_table") for d in (0, 1, 2)]   # kernels.hip per TAU_CALCULATION x DIMENSIONS
 SOURCES = KERNEL_TUS + ["launchers.hip", "grid_build.hip", "staging.hip", "inject.hip", "ingest.hip", "hot_table.hip", "functions.hip", "engine.hip"]
 HEADERS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", "cs_device.hpp", os.path.join("..", "..", "include", "mcrat_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden"]
+# -amdgpu-prealloc-sgpr-spill-vgprs: the loop kernels sit at 256 VGPRs with hundreds of scalar registers spilled to lanes of vector registers; with the
+#   compiler's default (those vector registers chosen after everything else is allocated) single instantiations wrote a wrong Stokes V -- another
+#   instantiation after every larger edit (round 3: 3-D spherical; round 4: 3-D polar; without the shadow draws: 3-D spherical again), every time cured
+#   by keeping the spilled scalars elsewhere (profiles/r04_s3_corruption_probe.txt).  Reserving the lane-spill registers up front costs nothing
+#   measurable (headline 0.493 vs 0.493 ms per frame, cfg5 the same, cfg3 3 %) and tests/test_gpu_instantiations.py is green in all 36 tuples x forms.
+# --offload-compress: the device code of ~420 instantiations of the loop kernel is 53 MB; compressed in the bundle 8 MB (the HIP runtime unpacks it
+#   when the library is loaded).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-fvisibility=hidden",
+         "-mllvm", "-amdgpu-prealloc-sgpr-spill-vgprs=1", "--offload-compress"]
 OBJDIR = os.path.join(HERE, "_obj")
 _KERNEL_DEPS = ["kernels.hip", "device_types.hpp", "launch.hpp", "physics.hpp", "rng.hpp", "cs_device.hpp"]
 DEPS = {"launchers.hip": ["launchers.hip", "device_types.hpp", "launch.hpp"],
