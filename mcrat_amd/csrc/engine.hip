@@ -5,6 +5,7 @@
 // There is no CPU compute path in this file: if HIP is unavailable every entry point fails.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -2895,15 +2896,23 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     const int R = c->n_ranks, F = p->n_frames;
     const size_t N = (size_t)R * (size_t)F;
     if (N > 0x7fffffffull) return MCRAT_HIP_EINVAL;
+    // MCRAT_HIP_QUEUE_TIMING=1: where the call's host time goes, on stderr (development aid)
+    static const bool timing = getenv("MCRAT_HIP_QUEUE_TIMING") && atoi(getenv("MCRAT_HIP_QUEUE_TIMING")) != 0;
+    auto clock_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double tq0 = clock_us();
+    double tq_filled = 0, tq_launched = 0, tq_synced = 0, tq_a = 0, tq_b = 0, tq_c = 0;
     // the lists that take part, each in one run of consecutive frames
     std::vector<int> first((size_t)R, -1), last((size_t)R, -1);
-    for (int r = 0; r < R; ++r) {
-        for (int f = 0; f < F; ++f) {
-            if (!p->open[(size_t)f * R + r]) continue;
+    for (int f = 0; f < F; ++f) {
+        const int *open_f = p->open + (size_t)f * R;
+        for (int r = 0; r < R; ++r) {
+            if (!open_f[r]) continue;
             if (first[r] < 0) first[r] = f;
             else if (last[r] != f - 1) { c->last_error = "pool_run_frames: a list's open frames must be consecutive"; return MCRAT_HIP_EINVAL; }
             last[r] = f;
         }
+    }
+    for (int r = 0; r < R; ++r) {
         const mcrat_hip_ctx *v = c->views[(size_t)r];
         if (first[r] >= 0 && (!v || !v->have_photons)) { c->last_error = "pool_run_frames: a list that does not exist was asked to open a frame"; return MCRAT_HIP_ESTATE; }
     }
@@ -2934,6 +2943,7 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         HIPCHK(c, hipHostMalloc(&c->h_fq, bytes, hipHostMallocDefault));
         c->fq_bytes = bytes;
     }
+    tq_a = clock_us();
     char *hb = static_cast<char *>(c->h_fq), *db = static_cast<char *>(c->d_fq);
     unsigned *h_done = reinterpret_cast<unsigned *>(hb + off_done);
     int *h_order = reinterpret_cast<int *>(hb + off_order);
@@ -2948,9 +2958,11 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         it.hydro = hy_of_frame[t / (size_t)R];
     }
     memcpy(hb + off_hy, hyv.data(), sizeof(HydroDev) * hyv.size());
+    tq_b = clock_us();
     HIPCHK(c, hipMemsetAsync(db + off_rec, 0, sizeof(LoopState) * N, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_table_fallbacks, 0, sizeof(int), c->stream));
     if (!c->rank_block_fixed) { choose_rank_block(c); c->rank_block_fixed = true; }
+    tq_c = clock_us();
     FrameQueueDev fq{};
     fq.n_frames = F; fq.restore = p->restore_each_frame ? 1 : 0; fq.chain_clock = p->chain_clock ? 1 : 0;
     fq.ticket = reinterpret_cast<unsigned *>(db); fq.frames_done = reinterpret_cast<unsigned *>(db + off_done);
@@ -2974,15 +2986,24 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         // the open items in the order they are taken: per XCD (list r belongs to XCD r % 8: a list never changes L2) frame-major; one workgroup per item,
         // and as the hardware deals workgroups round-robin over the XCDs, eight times the longest XCD's list of them
         int n_open = 0, longest_xcd = 0;
-        for (int x = 0; x < FRAME_QUEUE_XCDS; ++x) {
-            fq.order_off[x] = n_open;
-            for (size_t t = 0; t < N; ++t)
-                if (h_items[t].open && xcd_of_class[list_class((int)(t % (size_t)R))] == x) h_order[n_open++] = (int)t;
-            longest_xcd = std::max(longest_xcd, n_open - fq.order_off[x]);
+        {
+            int count[FRAME_QUEUE_XCDS] = {0}, fill[FRAME_QUEUE_XCDS];
+            for (int f = 0; f < F; ++f)
+                for (int r = 0; r < R; ++r)
+                    if (h_items[(size_t)f * R + r].open) count[xcd_of_class[list_class(r)]] += 1;
+            for (int x = 0; x < FRAME_QUEUE_XCDS; ++x) {
+                fq.order_off[x] = fill[x] = n_open;
+                n_open += count[x];
+                longest_xcd = std::max(longest_xcd, count[x]);
+            }
+            for (int f = 0; f < F; ++f)                      // frame-major within an XCD's queue
+                for (int r = 0; r < R; ++r)
+                    if (h_items[(size_t)f * R + r].open) h_order[fill[xcd_of_class[list_class(r)]]++] = f * R + r;
         }
         fq.order_off[FRAME_QUEUE_XCDS] = n_open;
         const int n_groups = FRAME_QUEUE_XCDS * longest_xcd;
         if (n_groups == 0) break;                            // (no list opens a frame: the call has only sized the queue's buffers)
+        tq_filled = clock_us();
         HIPCHK(c, hipMemcpyAsync(db, hb, off_rec, hipMemcpyHostToDevice, c->stream));
         if (c->cfg.profile) {
             int rc = ensure_events(c, 2);
@@ -2999,7 +3020,9 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         HIPCHK(c, hipMemcpyAsync(tickets.data(), db, sizeof(unsigned) * tickets.size(), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(h_done, db + off_done, sizeof(unsigned) * (size_t)R, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(h_rec, db + off_rec, sizeof(LoopState) * N, hipMemcpyDeviceToHost, c->stream));
+        tq_launched = clock_us();
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        tq_synced = clock_us();
         if (c->cfg.profile) {
             float ms = 0;
             HIPCHK(c, hipEventElapsedTime(&ms, c->ev[0], c->ev[1]));
@@ -3125,6 +3148,9 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     c->rank_block_fixed = false;
     stats[0].step_kernel_ms = c->prof_step_ms;               // (profile = 1: the launch's duration, on the first item)
     stats[0].step_kernel_launches = c->prof_launches;
+    if (timing)
+        fprintf(stderr, "pool_run_frames: %d frames x %d lists: plan -> queue %.0f us (checks %.0f, items %.0f, memsets + block choice %.0f, order %.0f), upload + launch calls %.0f us, waiting for the device %.0f us (kernel %.0f us), records -> stats %.0f us\n",
+                F, R, tq_filled - tq0, tq_a - tq0, tq_b - tq_a, tq_c - tq_b, tq_filled - tq_c, tq_launched - tq_filled, tq_synced - tq_launched, 1e3 * c->prof_step_ms, clock_us() - tq_synced);
     return MCRAT_HIP_OK;
 }
 
