@@ -603,7 +603,7 @@ typedef struct mcrat_hip_frame_plan {
     int n_frames;
     int chain_clock;
     int restore_each_frame;
-    int reserved;
+    int capture_frames;                   /* 1: the lists as every frame but the last leaves them are kept for mcrat_hip_pool_select_frame */
     const int      *open;
     const uint64_t *seeds;
     const double   *time_now;
@@ -612,6 +612,14 @@ typedef struct mcrat_hip_frame_plan {
     mcrat_hip_ctx *const *hydro;          /* NULL: every frame through the pool's own staged frame */
 } mcrat_hip_frame_plan;
 int mcrat_hip_pool_run_frames(mcrat_hip_ctx *pool, const mcrat_hip_frame_plan *plan, mcrat_hip_frame_stats *stats /* [n_frames * n_ranks] */);
+
+/* The outputs of the frames of a plan (phScattStats, saveCheckpoint, printPhotons: mcrat.c:881-915 need every list as ITS frame left it, and in a
+ * queue launch a list is moved on by its next frame at once).  With plan.capture_frames = 1 each list is copied aside at the end of every frame but
+ * the last (the lists that were open in it; one copy of the pool per such frame in HBM); mcrat_hip_pool_select_frame(pool, f) then makes the pool's
+ * read entry points -- mcrat_hip_pool_summaries, mcrat_hip_outbox_post, mcrat_hip_get_photons_range, mcrat_hip_get_output -- look at frame f's copy,
+ * until mcrat_hip_pool_select_frame(pool, -1) (the live lists = the last frame).  While a frame is selected mcrat_hip_run and
+ * mcrat_hip_pool_run_frames refuse.  The captures are valid until the next mcrat_hip_pool_run_frames. */
+int mcrat_hip_pool_select_frame(mcrat_hip_ctx *pool, int frame);
 
 /* function-granular A/B entry points (one kernel each, for parity tests against the
  * reference functions): the findContainingHydroCell + calcMeanFreePath half of an

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mcrat_hip.h"
@@ -41,6 +42,11 @@ struct mcrat_hip_ctx {
     void *ph_buf = nullptr;
     size_t ph_bytes = 0;
     void *ph_snap = nullptr;          // mcrat_hip_snapshot_photons
+    void *ph_cap = nullptr;           // mcrat_hip_pool_run_frames with capture_frames: the lists as frames 0 .. n_frames - 2 left them, ph_bytes each
+    size_t ph_cap_bytes = 0;
+    int cap_frames = 0;               // how many of them the last plan filled
+    int selected_frame = -1;          // mcrat_hip_pool_select_frame: the read entry points look at that capture (c->ph shifted), -1: the live lists
+    PhotonDev ph_live{};
     size_t ph_snap_bytes = 0;
     bool have_photons = false;
     void *aos_buf = nullptr;          // device copy of the caller's struct photon records (mcrat_hip_set_photons / get_photons)
@@ -317,6 +323,7 @@ extern "C" void mcrat_hip_destroy(mcrat_hip_ctx *c)
     if (c->ph_buf) (void)hipFree(c->ph_buf);
     for (int k = 0; k < 2; ++k) { if (c->pin_ring[k]) (void)hipHostFree(c->pin_ring[k]); if (c->pin_ev[k]) (void)hipEventDestroy(c->pin_ev[k]); }
     if (c->ph_snap) (void)hipFree(c->ph_snap);
+    if (c->ph_cap) (void)hipFree(c->ph_cap);
     if (c->aos_buf) (void)hipFree(c->aos_buf);
     if (c->hy_buf) (void)hipFree(c->hy_buf);
     if (c->grid_buf) (void)hipFree(c->grid_buf);
@@ -2866,6 +2873,7 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
 {
     if (!c || !p || !stats || p->n_frames <= 0 || !p->open || !p->seeds || !p->time_now || !p->remaining_time) return MCRAT_HIP_EINVAL;
     if (p->chain_clock && !p->frame_end) return MCRAT_HIP_EINVAL;
+    if (c->selected_frame >= 0) { c->last_error = "a captured frame is selected (mcrat_hip_pool_select_frame(pool, -1) first)"; return MCRAT_HIP_ESTATE; }
     if (!c->is_pool) return MCRAT_HIP_ESTATE;
     if (!c->have_hydro) return MCRAT_HIP_ESTATE;
     if (c->cfg.cyclosynchrotron_switch) { c->last_error = "CYCLOSYNCHROTRON_SWITCH is on: its hook needs the host between passes, one frame per call (mcrat_hip_pool_scatter_frames_cyclosynch)"; return MCRAT_HIP_ESTATE; }
@@ -2970,6 +2978,18 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     fq.records = reinterpret_cast<LoopState *>(db + off_rec);
     fq.hydro = reinterpret_cast<const HydroDev *>(db + off_hy);
     fq.snap_delta = p->restore_each_frame ? (long long)(static_cast<char *>(c->ph_snap) - static_cast<char *>(c->ph_buf)) : 0;
+    c->cap_frames = 0;
+    if (p->capture_frames && F > 1) {                        // the lists as every frame but the last leaves them (the frame's outputs: mcrat.c:881-915)
+        const size_t need = c->ph_bytes * (size_t)(F - 1);
+        if (c->ph_cap_bytes < need) {
+            if (c->ph_cap) { HIPCHK(c, hipFree(c->ph_cap)); c->ph_cap = nullptr; c->ph_cap_bytes = 0; }
+            HIPCHK(c, hipMalloc(&c->ph_cap, need));
+            c->ph_cap_bytes = need;
+        }
+        fq.capture_delta = (long long)(static_cast<char *>(c->ph_cap) - static_cast<char *>(c->ph_buf));
+        fq.capture_stride = (long long)c->ph_bytes;
+        c->cap_frames = F - 1;
+    }
     long long per_frame_cap = 32768;             // passes one list may take per frame and launch (run_ranks' bound on a launch's duration)
     if (const char *e = getenv("MCRAT_HIP_RANK_LAUNCH_CAP")) per_frame_cap = atoll(e) > 0 ? atoll(e) : per_frame_cap;
     const int longest = longest_rank_list(c);
@@ -3118,6 +3138,8 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
             }
             for (int r = 0; r < R; ++r)
                 if (op[(size_t)r]) h_rec[(size_t)f * R + r] = c->h_rstates[r];
+            if (c->cap_frames > 0 && f < F - 1)               // the pool as frame f leaves it
+                HIPCHK(c, hipMemcpyAsync(static_cast<char *>(c->ph_cap) + (size_t)f * c->ph_bytes, c->ph_buf, c->ph_bytes, hipMemcpyDeviceToDevice, c->stream));
         }
     }
     for (size_t t = 0; t < N; ++t) {
@@ -3154,9 +3176,29 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
     return MCRAT_HIP_OK;
 }
 
+// The pool's read entry points (mcrat_hip_pool_summaries, mcrat_hip_outbox_post, mcrat_hip_get_photons_range, mcrat_hip_get_output) on the lists as
+// frame `frame` of the last plan left them: the captures are laid out like the live lists, so the pool's column pointers are simply moved over.
+extern "C" int mcrat_hip_pool_select_frame(mcrat_hip_ctx *c, int frame)
+{
+    if (!c || !c->is_pool) return MCRAT_HIP_EINVAL;
+    if (c->selected_frame >= 0) { c->ph = c->ph_live; c->selected_frame = -1; }
+    if (frame < 0) return MCRAT_HIP_OK;
+    if (frame >= c->cap_frames || !c->ph_cap) { c->last_error = "pool_select_frame: no capture of that frame (mcrat_hip_frame_plan.capture_frames; the last frame is the live lists)"; return MCRAT_HIP_ESTATE; }
+    c->ph_live = c->ph;
+    const long long delta = (static_cast<char *>(c->ph_cap) - static_cast<char *>(c->ph_buf)) + (long long)frame * (long long)c->ph_bytes;
+    auto move = [&](auto *&ptr) { ptr = reinterpret_cast<std::remove_reference_t<decltype(ptr)>>(reinterpret_cast<char *>(ptr) + delta); };
+    PhotonDev &q = c->ph;
+    move(q.r0); move(q.r1); move(q.r2); move(q.p0); move(q.p1); move(q.p2); move(q.p3); move(q.c0); move(q.c1); move(q.c2); move(q.c3);
+    move(q.s0); move(q.s1); move(q.s2); move(q.s3); move(q.num_scatt); move(q.weight); move(q.tau); move(q.tts); move(q.u0); move(q.u1); move(q.u2);
+    move(q.ntau); move(q.tau_next); move(q.idx); move(q.flags); move(q.type);
+    c->selected_frame = frame;
+    return MCRAT_HIP_OK;
+}
+
 extern "C" int mcrat_hip_run(mcrat_hip_ctx *c, long long max_iterations, mcrat_hip_frame_stats *stats)
 {
     if (!c) return MCRAT_HIP_EINVAL;
+    if (c->selected_frame >= 0) { c->last_error = "a captured frame is selected (mcrat_hip_pool_select_frame(pool, -1) first)"; return MCRAT_HIP_ESTATE; }
     if (c->is_pool) {                              // every list whose view has opened a frame (or the pool's own begin_frame: all)
         if (!c->have_hydro) return MCRAT_HIP_ESTATE;
         if (c->cfg.cyclosynchrotron_switch) { c->last_error = "CYCLOSYNCHROTRON_SWITCH is on: run the views one by one (mcrat_hip_scatter_frame_cyclosynch)"; return MCRAT_HIP_ESTATE; }

@@ -89,7 +89,7 @@ class FrameStats(C.Structure):
 
 class FramePlan(C.Structure):
     """mcrat_hip_frame_plan: several hydro frames of every list of a pool in one launch (the frame queue)"""
-    _fields_ = [("n_frames", C.c_int), ("chain_clock", C.c_int), ("restore_each_frame", C.c_int), ("reserved", C.c_int),
+    _fields_ = [("n_frames", C.c_int), ("chain_clock", C.c_int), ("restore_each_frame", C.c_int), ("capture_frames", C.c_int),
                 ("open", C.POINTER(C.c_int)), ("seeds", C.POINTER(C.c_uint64)), ("time_now", _dp), ("remaining_time", _dp), ("frame_end", _dp),
                 ("hydro", C.POINTER(C.c_void_p))]
 
@@ -215,6 +215,7 @@ SYMBOLS = {
                                            C.c_uint64, _ip, _dp]),
     "mcrat_hip_set_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double]),
     "mcrat_hip_table_fallback_calls": (C.c_int, [_ctx, C.c_int]),
+    "mcrat_hip_pool_select_frame": (C.c_int, [_ctx, C.c_int]),
     "mcrat_hip_create_hot_cross_section": (C.c_int, [_ctx, _dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong,
                                                      C.c_uint64]),
     "mcrat_hip_set_photons": (C.c_int, [_ctx, C.POINTER(PhotonList)]),
@@ -791,7 +792,7 @@ class Engine:
         self._check(self.lib.mcrat_hip_pool_propagate_frames_fast(self.ctx, o, sd, t, rem, int(windows), st), "pool_propagate_frames_fast")
         return list(st)
 
-    def frame_plan(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False, hydro=None):
+    def frame_plan(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False, hydro=None, capture=False):
         """a mcrat_hip_frame_plan from [n_frames][n_ranks] arrays -> (plan, stats array, the arrays the plan points into);
         hydro: per frame None (the pool's own staged frame) or an Engine holding that frame's staged hydro frame"""
         R = self.n_pool_ranks
@@ -801,7 +802,7 @@ class Engine:
         t = np.ascontiguousarray(time_now, dtype=np.float64).reshape(F, R)
         rem = np.ascontiguousarray(remaining_time, dtype=np.float64).reshape(F, R)
         fe = None if frame_end is None else np.ascontiguousarray(frame_end, dtype=np.float64).reshape(F, R)
-        plan = FramePlan(F, int(bool(chain_clock)), int(bool(restore_each_frame)), 0, o.ctypes.data_as(C.POINTER(C.c_int)),
+        plan = FramePlan(F, int(bool(chain_clock)), int(bool(restore_each_frame)), int(bool(capture)), o.ctypes.data_as(C.POINTER(C.c_int)),
                          sd.ctypes.data_as(C.POINTER(C.c_uint64)), t.ctypes.data_as(_dp), rem.ctypes.data_as(_dp),
                          fe.ctypes.data_as(_dp) if fe is not None else None, None)
         hy = None
@@ -814,13 +815,18 @@ class Engine:
         """mcrat_hip_pool_run_frames on a prepared plan; stats (frame_plan's array) receives item f * n_ranks + r"""
         self._check(self.lib.mcrat_hip_pool_run_frames(self.ctx, C.byref(plan), stats), "pool_run_frames")
 
-    def pool_run_frames(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False, hydro=None):
+    def pool_run_frames(self, open_, seeds, time_now, remaining_time, frame_end=None, chain_clock=False, restore_each_frame=False, hydro=None, capture=False):
         """mcrat_hip_pool_run_frames: the arrays are [n_frames][n_ranks]; every open list through its frames in ONE launch (the frame queue:
         a list that is through frame f starts f + 1 while others are still in f) -> FrameStats [n_frames][n_ranks]"""
-        plan, st, keep = self.frame_plan(open_, seeds, time_now, remaining_time, frame_end, chain_clock, restore_each_frame, hydro)
+        plan, st, keep = self.frame_plan(open_, seeds, time_now, remaining_time, frame_end, chain_clock, restore_each_frame, hydro, capture)
         self.pool_run_plan(plan, st)
         R, F = self.n_pool_ranks, plan.n_frames
         return [[st[f * R + r] for r in range(R)] for f in range(F)]
+
+    def pool_select_frame(self, frame):
+        """the pool's read calls (pool_summaries, get_photons_range, get_output, outbox) on the lists as frame `frame` of the last plan with
+        capture=True left them; -1: the live lists again"""
+        self._check(self.lib.mcrat_hip_pool_select_frame(self.ctx, int(frame)), "pool_select_frame")
 
     def snapshot_photons(self):
         self._check(self.lib.mcrat_hip_snapshot_photons(self.ctx), "snapshot_photons")

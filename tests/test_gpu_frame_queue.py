@@ -257,3 +257,49 @@ def test_every_frame_of_a_plan_in_its_own_hydro_frame(hip, monkeypatch, form):
         q.pool_run_frames(open_, seeds, np.zeros((F, R)), rem, frame_end=frame_end, chain_clock=True, hydro=[None, other, None])
     for e in (empty, other, q, ref) + tuple(holders):
         e.close()
+
+
+@pytest.mark.parametrize("form", ["queue", "frame-by-frame", "128-thread-lists"])
+def test_captured_frames_are_the_lists_as_each_frame_left_them(hip, monkeypatch, form):
+    """mcrat.c:881-915: phScattStats, saveCheckpoint and printPhotons of frame f need every list as frame f left it -- in a queue launch its next frame
+    moves it on at once.  plan.capture_frames keeps a copy per frame; mcrat_hip_pool_select_frame points the pool's read calls at it.  Against the pool
+    read after each frame of a frame-by-frame run: records and per-list summaries, bit for bit"""
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
+    lens = [137, 1000, 512, 999, 64, 700, 1024, 333, 420]
+    frame, cfg, subs, streams = _setup(hip, lens)
+    F, R, window = 3, len(lens), 1100
+    fps = frame["fps"]
+    seeds = np.array([[31 + 7 * r + 1000003 * f for r in range(R)] for f in range(F)], dtype=np.uint64)
+    open_ = np.ones((F, R), dtype=np.int32)
+    ref = _pool(hip, frame, cfg, subs, streams, window)
+    t_now = [0.0] * R
+    want = []
+    for f in range(F):
+        for r in range(R):
+            ref.views[r].begin_frame(int(seeds[f][r]), t_now[r], (f + 1) / fps - t_now[r])
+        ref.run(0)
+        for r in range(R):
+            t_now[r] = ref.views[r].frame_statistics().time_now
+        want.append((ref.get_photons_range(0, R * window).copy(), ref.pool_summaries()))
+    q = _pool(hip, frame, cfg, subs, streams, window)
+    frame_end = np.array([[(f + 1) / fps for r in range(R)] for f in range(F)])
+    q.pool_run_frames(open_, seeds, np.zeros((F, R)), frame_end.copy(), frame_end=frame_end, chain_clock=True, capture=True)
+    for f in range(F):
+        q.pool_select_frame(f if f < F - 1 else -1)
+        if f < F - 1:
+            with pytest.raises(hip.McratHipError):                                  # nothing runs while a capture is selected
+                q.run(0)
+        got, summ = q.get_photons_range(0, R * window), q.pool_summaries()
+        for r in range(R):
+            a, b = got[r * window:r * window + lens[r]], want[f][0][r * window:r * window + lens[r]]
+            for name in a.dtype.names:                                              # (field by field: the records' padding bytes are not data)
+                assert np.array_equal(a[name], b[name], equal_nan=a[name].dtype.kind == "f"), (f, r, name)
+            for k in ("min_r", "max_r", "min_theta", "max_theta", "avg_r", "avg_scatt", "max_scatt", "min_scatt", "num_output", "list_capacity"):
+                x, y = getattr(summ[r], k), getattr(want[f][1][r], k)
+                assert x == y or (x != x and y != y), (f, r, k, x, y)
+    q.pool_select_frame(-1)
+    with pytest.raises(hip.McratHipError):
+        q.pool_select_frame(F - 1)                                                  # the last frame is the live lists
+    ref.close()
+    q.close()
