@@ -39,8 +39,8 @@ class PoolConfig(C.Structure):
                 ("get_hydro", GET_HYDRO), ("user", C.c_void_p), ("write_checkpoints", C.c_int),
                 ("print_photons", C.c_void_p), ("comv_switch", C.c_int), ("stokes_switch", C.c_int), ("save_type", C.c_int),
                 ("max_frames", C.c_int), ("cyclosynchrotron_switch", C.c_int), ("cs", engine.Cyclosynch), ("mode", C.c_int), ("fast_windows", C.c_int),
-                ("sync_output", C.c_int), ("output_threads", C.c_int),
-                ("hydro_frames_read", C.c_longlong), ("launches", C.c_longlong),
+                ("sync_output", C.c_int), ("output_threads", C.c_int), ("stage_ctx", C.c_void_p),
+                ("hydro_frames_read", C.c_longlong), ("launches", C.c_longlong), ("two_frame_launches", C.c_longlong),
                 ("ms_propagate", C.c_double), ("ms_hydro", C.c_double), ("ms_output", C.c_double),
                 ("ms_output_writer", C.c_double), ("ms_output_blocked", C.c_double)]
 

@@ -709,16 +709,26 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
     double *t_now = (double *)calloc((size_t)n_ranks, sizeof(double)), *t_rem = (double *)calloc((size_t)n_ranks, sizeof(double));
     mcrat_hip_pool_cs_list *cs_lists = (mcrat_hip_pool_cs_list *)calloc((size_t)n_ranks, sizeof *cs_lists);
     mcrat_hip_cyclosynch_counts *cs_counts = (mcrat_hip_cyclosynch_counts *)calloc((size_t)n_ranks, sizeof *cs_counts);
+    /* two hydro frames per launch (cfg->stage_ctx): the plan's arrays [2 * n_ranks] and what the second frame left for the next turn of the loop */
+    mcrat_hip_frame_stats *stats2 = (mcrat_hip_frame_stats *)calloc((size_t)n_ranks * 2, sizeof *stats2);
+    int *open2 = (int *)calloc((size_t)n_ranks * 2, sizeof(int));
+    uint64_t *seeds2 = (uint64_t *)calloc((size_t)n_ranks * 2, sizeof(uint64_t));
+    double *t_now2 = (double *)calloc((size_t)n_ranks * 2, sizeof(double)), *t_rem2 = (double *)calloc((size_t)n_ranks * 2, sizeof(double));
+    double *t_end2 = (double *)calloc((size_t)n_ranks * 2, sizeof(double));
+    int second_pending = 0;              /* this turn's frame was propagated by the previous turn's launch */
     mcrat_hip_photon *rec_buf = NULL;
     double *out_buf = NULL;
     char *out_type = NULL;
     size_t out_cap = 0;
     int stride = 0;
-    if (!summ || !stats || !open || !inj || !seeds || !t_now || !t_rem || !cs_lists || !cs_counts || mcrat_hip_pool_layout(pool, NULL, &stride) != 0) {
+    if (!summ || !stats || !open || !inj || !seeds || !t_now || !t_rem || !cs_lists || !cs_counts || !stats2 || !open2 || !seeds2 || !t_now2 || !t_rem2 || !t_end2 ||
+        mcrat_hip_pool_layout(pool, NULL, &stride) != 0) {
         free(summ); free(stats); free(open); free(inj); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
+        free(stats2); free(open2); free(seeds2); free(t_now2); free(t_rem2); free(t_end2);
         return MCRAT_HIP_ENOMEM;
     }
     cfg->hydro_frames_read = cfg->launches = 0;
+    cfg->two_frame_launches = 0;
     cfg->ms_propagate = cfg->ms_hydro = cfg->ms_output = 0;
     cfg->ms_output_writer = cfg->ms_output_blocked = 0;
     /* the writer of the frames' files (asynchronous output): two outboxes, two jobs */
@@ -841,6 +851,8 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 n_active += ranks[r].state == 1;
             }
             if (!n_active) continue;
+            /* (second_pending: this frame was propagated by the previous turn's launch, in the frame staged on cfg->stage_ctx -- nothing to read) */
+            if (!second_pending) {
             /* phMinMax of every list (mcrat.c:704) -> the slab all of them fit in -> getHydroData once (:721) */
             if ((rc = mcrat_hip_pool_summaries(pool, summ))) break;
             slab.ph_inj_switch = 0;
@@ -866,6 +878,36 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                 cfg->hydro_frames_read += 1;
                 if (rc) break;
             }
+            }
+            /* Two hydro frames in one launch (cfg->stage_ctx; EXACT mode): frame F + 1 staged beside frame F for everything the photons can reach from
+             * where they are (phMinMax widened by c / fps: nobody outruns light), every list through both frames in one call of
+             * mcrat_hip_pool_run_frames -- a list that is through frame F goes on in F + 1 while others are still in F, as the reference's ranks do in
+             * their own frame loops (mcrat.c:566-934).  Only when no rank joins at F + 1 (injection and restart sit between two frames), and the
+             * frames' outputs are taken from what each frame left (capture_frames, mcrat_hip_pool_select_frame). */
+            int two = 0;
+            if (!second_pending && cfg->stage_ctx && !cfg->cyclosynchrotron_switch && cfg->mode == MCRAT_HIP_MODE_EXACT && F + 1 <= cfg->last_frm &&
+                !(cfg->max_frames > 0 && frames_done + 2 > cfg->max_frames)) {
+                two = 1;
+                for (int r = 0; r < n_ranks; r++) {
+                    if (ranks[r].state == 0 && ranks[r].frame == F + 1) two = 0;                  /* injects at F + 1 */
+                    if (ranks[r].state == 4 && ranks[r].scatt_frame == F + 1) two = 0;            /* a restarted rank picks up at F + 1 */
+                    if (ranks[r].state == 2 || ranks[r].state == 3) continue;
+                }
+            }
+            if (two) {
+                mcrat_hip_slab next = slab;
+                const double reach = MCRAT_C_LIGHT / cfg->fps;
+                next.min_r = slab.min_r - reach > 0 ? slab.min_r - reach : 0;
+                next.max_r = slab.max_r + reach;
+                const double dth = next.min_r > 0 ? reach / next.min_r : M_PI;
+                next.min_theta = slab.min_theta - dth > 0 ? slab.min_theta - dth : 0;
+                next.max_theta = slab.max_theta + dth < M_PI ? slab.max_theta + dth : M_PI;
+                const double t0 = wall_ms();
+                rc = cfg->get_hydro(cfg->user, cfg->stage_ctx, F + 1, &next);
+                cfg->ms_hydro += wall_ms() - t0;
+                cfg->hydro_frames_read += 1;
+                if (rc) break;
+            }
             const double t_prop = wall_ms();
             for (int r = 0; r < n_ranks; r++) {
                 mcrat_host_rank *k = &ranks[r];
@@ -876,12 +918,36 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                             k->frame, k->frm2);
                     fprintf(k->fPtr, ">> Proc %d with angles %0.1lf-%0.1lf: propagating and scattering %d photons\n", k->angle_id, RANK_DEG(k), k->num_photons);
                 }
+                if (second_pending) continue;                                                    /* (its seed was drawn with the launch) */
                 /* the rank's per-frame seed (gsl_rng_set(rng, gsl_rng_get(rng)), :701) and its own clock (:758) */
                 seeds[r] = mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++);
                 t_now[r] = k->time_now;
                 t_rem[r] = ((F + 1) / cfg->fps) - k->time_now;
             }
-            if (!cfg->cyclosynchrotron_switch && cfg->mode == MCRAT_HIP_MODE_FAST) {
+            int captured = 0;
+            if (second_pending) {
+                for (int r = 0; r < n_ranks; r++) stats[r] = stats2[n_ranks + r];
+            } else if (two) {
+                for (int r = 0; r < n_ranks; r++) {
+                    mcrat_host_rank *k = &ranks[r];
+                    open2[r] = open2[n_ranks + r] = open[r];
+                    seeds2[r] = seeds[r];
+                    seeds2[n_ranks + r] = open[r] ? mcrat_host_rank_seed(k->rng_seed, k->seeds_drawn++) : 0;     /* frame F + 1's seed: the rank's next */
+                    t_now2[r] = t_now[r]; t_rem2[r] = t_rem[r];
+                    t_now2[n_ranks + r] = t_rem2[n_ranks + r] = 0;                                            /* (the clock is carried: chain_clock) */
+                    t_end2[r] = (F + 1) / cfg->fps; t_end2[n_ranks + r] = (F + 2) / cfg->fps;
+                }
+                mcrat_hip_ctx *frames[2] = {NULL, cfg->stage_ctx};
+                mcrat_hip_frame_plan plan;
+                memset(&plan, 0, sizeof plan);
+                plan.n_frames = 2; plan.chain_clock = 1; plan.capture_frames = 1;
+                plan.open = open2; plan.seeds = seeds2; plan.time_now = t_now2; plan.remaining_time = t_rem2; plan.frame_end = t_end2; plan.hydro = frames;
+                if ((rc = mcrat_hip_pool_run_frames(pool, &plan, stats2))) break;
+                for (int r = 0; r < n_ranks; r++) stats[r] = stats2[r];
+                if ((rc = mcrat_hip_pool_select_frame(pool, 0))) break;                          /* frame F's outputs: the lists as frame F left them */
+                captured = 1;
+                cfg->two_frame_launches += 1;
+            } else if (!cfg->cyclosynchrotron_switch && cfg->mode == MCRAT_HIP_MODE_FAST) {
                 if ((rc = mcrat_hip_pool_propagate_frames_fast(pool, open, seeds, t_now, t_rem, cfg->fast_windows, stats))) break;
                 for (int r = 0; r < n_ranks; r++)
                     if (open[r] && ranks[r].view) ranks[r].fast_cadence = mcrat_hip_fast_cadence(ranks[r].view, 0);
@@ -914,7 +980,7 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                     if (ranks[r].fPtr) fprintf(ranks[r].fPtr, "The number of cyclosynchrotron photons absorbed in this frame is: %d\n", cs_counts[r].frame_abs_cnt);
                 }
             }
-            cfg->launches += 1;
+            if (!second_pending) cfg->launches += 1;
             if ((rc = mcrat_hip_pool_summaries(pool, summ))) break;                               /* phScattStats, :881 */
             cfg->ms_propagate += wall_ms() - t_prop;
             const double t_out = wall_ms();
@@ -1029,6 +1095,8 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
                     if (rc) break;
                 }
             }
+            if (captured && (rc = mcrat_hip_pool_select_frame(pool, -1))) break;                 /* back to the live lists (= what frame F + 1 left) */
+            second_pending = captured;
             for (int r = 0; r < n_ranks; r++)
                 if (ranks[r].state == 1) ranks[r].scatt_frame = F + 1;
             cfg->ms_output += wall_ms() - t_out;
@@ -1067,6 +1135,7 @@ int mcrat_host_run_ranks(mcrat_hip_ctx *pool, mcrat_host_rank *ranks, int n_rank
             if (k->fPtr) { fprintf(k->fPtr, "Process %d has completed the MC calculation.\n", k->angle_id); fflush(k->fPtr); }
         }
     free(summ); free(stats); free(open); free(inj); free(seeds); free(t_now); free(t_rem); free(cs_lists); free(cs_counts);
+    free(stats2); free(open2); free(seeds2); free(t_now2); free(t_rem2); free(t_end2);
     free(rec_buf); free(out_buf); free(out_type);
     return rc;
 }

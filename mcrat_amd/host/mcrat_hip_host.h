@@ -262,9 +262,16 @@ typedef struct mcrat_host_pool_config {
      * print_photons (writer thread, frame F) and get_hydro (calling thread, frame F + 1) run at the same time; the library's own HDF5 functions
      * serialise on one lock, callbacks that use HDF5 themselves take mcrat_host_h5_lock (above). */
     int    sync_output, output_threads;
+    /* Optional: a second context (the pool's switches and device) for the NEXT hydro frame.  With it, in EXACT mode without the cyclo-synchrotron switch,
+     * the driver stages frame F + 1 beside frame F (get_hydro is called with this context and a slab widened by c / fps) and takes every list
+     * through both frames in one launch (mcrat_hip_pool_run_frames: a list that is through F goes on in F + 1 at once) whenever no rank joins at
+     * F + 1; each frame's checkpoint and mc_proc data are written from the lists as that frame left them.  Files and logs are those of the
+     * one-frame-per-launch run (tests/test_gpu_rank_pool_host.py). */
+    mcrat_hip_ctx *stage_ctx;
     /* out */
     long long hydro_frames_read;         /* get_hydro calls */
-    long long launches;                  /* mcrat_hip_run calls */
+    long long launches;                  /* mcrat_hip_run / mcrat_hip_pool_run_frames calls */
+    long long two_frame_launches;        /* of which took two hydro frames */
     double ms_propagate, ms_hydro, ms_output;   /* wall time of the calling thread in the loop, in the reader callback, in checkpoint + printPhotons
                                                  * (asynchronous output: posting the outbox, waiting for a free one, the final drain) */
     double ms_output_writer;                    /* asynchronous output: what the writer thread spent on the frames' files (copy wait + writing) ... */

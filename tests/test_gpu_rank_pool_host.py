@@ -256,3 +256,100 @@ def test_restarted_rank_continues_from_its_checkpoint(hip, tmp_path):
     libc = C.CDLL(None)
     for l in lists:
         libc.free(C.c_void_p(l.photons))
+
+
+@pytest.mark.parametrize("sync_output", [0, 1], ids=["writer-thread", "sync-output"])
+def test_two_hydro_frames_per_launch_write_the_files_of_one_frame_per_launch(hip, tmp_path, sync_output):
+    """mcrat_host_pool_config.stage_ctx: frame F + 1 staged on a second context for what the photons can reach from frame F, every list through both
+    frames in ONE launch (a list that is through F goes on in F + 1 while others are still in F: mcrat.c:566-934, the ranks' own frame loops), each
+    frame's files written from the lists as that frame left them.  Four ranks of two injection radii that all join at frame 0 and run to frame 5:
+    launches (0,1) (2,3) (4,5).  Against the same run one frame per launch: every mc_proc dataset and every checkpoint record equal (but for
+    nearest_block_index, which numbers the cells of whatever slab was read -- here a wider one), the same scattering counts in the logs."""
+    from mcrat_amd.host import binding as B
+    host, h5 = B.host(), B.host_h5()
+    raw = synth.pluto_raw_grid(synth.TWO, synth.SPHERICAL, (1e11, 0.0), (4e12, 0.6), (384, 96), seed=31, log_axis0=True)
+    jet = hip.Engine.outflow(3, lumi=2e53, theta_j=0.1)
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    R, LASTF = 4, 5
+
+    def run(tag, staged):
+        ranks = (B.HostRank * R)()
+        dirs, logs = [], []
+        for r, k in enumerate(ranks):
+            k.myid, k.angle_id, k.angle_procs = r, r, R
+            k.theta_jmin_thread, k.theta_jmax_thread, k.ph_weight_suggest = 0.02 * (r % 2), 0.02 * (r % 2) + 0.05, 1e50
+            k.inj_radius = 1e12 if r < 2 else 1.2e12
+            k.framestart, k.frm2, k.rng_seed, k.rng_stream = 0, 0, 4242, r
+            d = str(tmp_path / ("%s_%d" % (tag, r))) + "/"
+            os.makedirs(d)
+            k.mc_dir = d.encode()
+            k.fPtr = libc.fopen((d + "mc_output_%d.log" % r).encode(), b"a")
+            dirs.append(d)
+            logs.append(k.fPtr)
+        pool = hip.Engine(synth.TWO, synth.SPHERICAL, 1)
+        stage = hip.Engine(synth.TWO, synth.SPHERICAL, 1) if staged else None
+        reads = []
+
+        def reader(user, ctx, frame, slab):
+            s = _slab_dict(slab.contents)
+            on_stage = staged and ctx == stage.ctx.value
+            reads.append((frame, s["ph_inj_switch"], bool(on_stage), s["min_r"], s["max_r"]))
+            (stage if on_stage else pool).ingest(raw, s, jet)
+            return 0
+        cfg = B.PoolConfig()
+        cfg.fps, cfg.last_frm = FPS, LASTF
+        for k, v in DOM.items():
+            getattr(cfg, k)[0], getattr(cfg, k)[1] = v
+        cfg.spect, cfg.min_photons, cfg.max_photons = b"b", 300, 900
+        cfg.get_hydro = B.GET_HYDRO(reader)
+        cfg.write_checkpoints = 1
+        if h5 is not None:
+            cfg.print_photons = C.cast(h5.mcrat_host_print_photon_arrays, C.c_void_p).value
+        cfg.comv_switch, cfg.stokes_switch, cfg.save_type = 1, 1, 1
+        cfg.mode, cfg.sync_output, cfg.output_threads = hip.MODE_EXACT, sync_output, 2
+        if staged:
+            cfg.stage_ctx = stage.ctx.value
+        assert host.mcrat_host_run_ranks(pool.ctx, ranks, R, C.byref(cfg)) == 0
+        for f in logs:
+            libc.fclose(f)
+        out = dict(dirs=dirs, reads=reads, launches=cfg.launches, two=cfg.two_frame_launches, scatt=[k.frame_scatt_cnt_total for k in ranks],
+                   t=[k.time_now for k in ranks], n=[k.num_photons for k in ranks])
+        pool.close()
+        if stage is not None:
+            stage.close()
+        return out
+    one = run("one", False)
+    two = run("two", True)
+    assert one["launches"] == 6 and one["two"] == 0 and two["launches"] == 3 and two["two"] == 3
+    assert [(f, st) for f, inj, st, lo, hi in two["reads"] if not inj] == [(0, False), (1, True), (2, False), (3, True), (4, False), (5, True)]
+    reach = 2.99792458e10 / FPS
+    for (f, inj, st, lo, hi), (f0, inj0, st0, lo0, hi0) in zip([x for x in two["reads"] if not x[1]][0::2], [x for x in two["reads"] if not x[1]][1::2]):
+        assert lo0 == pytest.approx(max(lo - reach, 0)) and hi0 == pytest.approx(hi + reach) and f0 == f + 1
+    assert one["scatt"] == two["scatt"] and sum(one["scatt"]) > 200 and one["t"] == two["t"] and one["n"] == two["n"]
+    head = 4 + 1 + 4 + 4
+    for r in range(R):
+        a, b = one["dirs"][r], two["dirs"][r]
+        for name in ("mc_chkpt_%d.dat_old" % r,):
+            x, y = open(a + name, "rb").read(), open(b + name, "rb").read()
+            assert x[:head] == y[:head] and len(x) == len(y)
+            ra, rb = np.frombuffer(x[head:], dtype=hip.PHOTON_DTYPE), np.frombuffer(y[head:], dtype=hip.PHOTON_DTYPE)
+            for col in ra.dtype.names:
+                if col != "nearest_block_index":
+                    assert np.array_equal(ra[col], rb[col], equal_nan=ra[col].dtype.kind == "f"), (r, col)
+        la, lb = open(a + "mc_output_%d.log" % r).read(), open(b + "mc_output_%d.log" % r).read()
+        pick = lambda t: [l for l in t.splitlines() if "scatterings in this frame" in l or "Working on" in l or "propagating" in l]
+        assert pick(la) == pick(lb) and len(pick(la)) == 3 * (LASTF + 1) + 1          # (+ the injection frame's own "Working on Frame")
+        if h5 is not None:
+            for F in range(LASTF + 1):
+                for name, is_char in (("P0", 0), ("P3", 0), ("R0", 0), ("R2", 0), ("COMV_P0", 0), ("S1", 0), ("S3", 0), ("NS", 0), ("PW", 0), ("PT", 1)):
+                    got = []
+                    for path in (a, b):
+                        n = C.c_int()
+                        buf = np.empty(one["n"][r], dtype="S1" if is_char else np.float64)
+                        assert h5.mcrat_host_h5_read((path + "mc_proc_%d.h5" % r).encode(), str(F).encode(), name.encode(), is_char, buf.ctypes.data,
+                                                     one["n"][r], C.byref(n)) == 0
+                        got.append(buf[:n.value].copy())
+                    assert len(got[0]) == len(got[1]) > 0 and np.array_equal(got[0], got[1]), (r, F, name)
