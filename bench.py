@@ -967,12 +967,17 @@ def main():
                        "through %d hydro frames of the cfg2 mesh read as a FLASH checkpoint (host buffers -> mcrat_hip_ingest_flash, once per frame "
                        "for all ranks); photons resident throughout.  ms per hydro frame, by what is written per rank and frame" % (R, frames),
                "ranks": R, "hydro_frames": frames}
-        for label, chk, hdf in (("no_output", 0, 0), ("checkpoints", 1, 0), ("checkpoints_and_hdf5", 1, 1)):
+        # (no_output_two_frames_per_launch: the same with mcrat_host_pool_config.stage_ctx -- frame F + 1 staged on a second context, two hydro frames per
+        # launch, each frame's statistics from the captured lists; four frames = two launches)
+        for label, chk, hdf in (("no_output", 0, 0), ("no_output_two_frames_per_launch", 0, 0), ("checkpoints", 1, 0), ("checkpoints_and_hdf5", 1, 1)):
             if hdf and h5 is None:
                 continue
+            staged = label.endswith("two_frames_per_launch")
+            frames = 4 if staged else 3
             tmp = tempfile.mkdtemp(prefix="mcrat_bench_")
             try:
                 pool = engine.Engine(synth.TWO, synth.CYLINDRICAL, 0, device=local_rank, stream=stream)
+                stage = engine.Engine(synth.TWO, synth.CYLINDRICAL, 0, device=local_rank, stream=stream) if staged else None
                 ranks = (B.HostRank * R)()
                 for r, k in enumerate(ranks):
                     k.myid, k.angle_id, k.angle_procs = r, r, R
@@ -985,9 +990,9 @@ def main():
                 pc.r1_domain[0], pc.r1_domain[1] = frame["r1_domain"]
                 pc.spect, pc.min_photons, pc.max_photons = b"b", 500, 1000
 
-                def reader(user, ctx, f, slab, pool=pool):
+                def reader(user, ctx, f, slab, pool=pool, stage=stage):
                     sl = slab.contents
-                    pool.ingest(raw, dict(r_inj=sl.r_inj, ph_inj_switch=sl.ph_inj_switch, min_r=sl.min_r, max_r=sl.max_r, min_theta=sl.min_theta,
+                    (stage if (stage is not None and ctx == stage.ctx.value) else pool).ingest(raw, dict(r_inj=sl.r_inj, ph_inj_switch=sl.ph_inj_switch, min_r=sl.min_r, max_r=sl.max_r, min_theta=sl.min_theta,
                                           max_theta=sl.max_theta, fps=sl.fps, r0_domain=tuple(sl.r0_domain), r1_domain=tuple(sl.r1_domain),
                                           r2_domain=tuple(sl.r2_domain)), jet)
                     return 0
@@ -996,6 +1001,8 @@ def main():
                 if hdf:
                     pc.print_photons = C.cast(h5.mcrat_host_print_photon_arrays, C.c_void_p).value
                 pc.comv_switch, pc.stokes_switch, pc.save_type = 1, 0, 0
+                if staged:
+                    pc.stage_ctx = stage.ctx.value
                 t0 = time.perf_counter()
                 rc = host.mcrat_host_run_ranks(pool.ctx, ranks, R, C.byref(pc))
                 wall = time.perf_counter() - t0
@@ -1007,6 +1014,11 @@ def main():
                               "ms_per_frame": {"propagate_and_statistics": pc.ms_propagate / frames, "output": pc.ms_output / frames,
                                                "hydro_reader_and_ingest": pc.ms_hydro / pc.hydro_frames_read},
                               "scatter_events_per_s_inclusive": events / ((pc.ms_propagate + pc.ms_output + pc.ms_hydro) * 1e-3)}
+                if staged:
+                    res[label]["hydro_frames"] = frames
+                    res[label]["launches"] = int(pc.launches)
+                    res[label]["two_frame_launches"] = int(pc.two_frame_launches)
+                    stage.close()
                 if chk or hdf:
                     # the writer thread (mcrat_hip_outbox_*): what it spent on the frames' files, how much of that the loop waited for, the rest
                     # was hidden behind the loop; and what the file system alone takes for as many files of the same size (same C, same box)
