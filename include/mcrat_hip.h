@@ -615,7 +615,7 @@ int mcrat_hip_pool_run_frames(mcrat_hip_ctx *pool, const mcrat_hip_frame_plan *p
 
 /* The outputs of the frames of a plan (phScattStats, saveCheckpoint, printPhotons: mcrat.c:881-915 need every list as ITS frame left it, and in a
  * queue launch a list is moved on by its next frame at once).  With plan.capture_frames = 1 each list is copied aside at the end of every frame but
- * the last (the lists that were open in it; one copy of the pool per such frame in HBM); mcrat_hip_pool_select_frame(pool, f) then makes the pool's
+ * the last (the lists that were open in it -- every other slot of a capture reads as an empty one, weight 0; one copy of the pool per such frame in HBM); mcrat_hip_pool_select_frame(pool, f) then makes the pool's
  * read entry points -- mcrat_hip_pool_summaries, mcrat_hip_outbox_post, mcrat_hip_get_photons_range, mcrat_hip_get_output -- look at frame f's copy,
  * until mcrat_hip_pool_select_frame(pool, -1) (the live lists = the last frame).  While a frame is selected mcrat_hip_run and
  * mcrat_hip_pool_run_frames refuse.  The captures are valid until the next mcrat_hip_pool_run_frames. */

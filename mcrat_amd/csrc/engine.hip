@@ -2989,6 +2989,11 @@ extern "C" int mcrat_hip_pool_run_frames(mcrat_hip_ctx *c, const mcrat_hip_frame
         fq.capture_delta = (long long)(static_cast<char *>(c->ph_cap) - static_cast<char *>(c->ph_buf));
         fq.capture_stride = (long long)c->ph_bytes;
         c->cap_frames = F - 1;
+        // a capture holds the slots [0, list_capacity) of the lists that were open in its frame; every other slot must read as the empty slot it is in
+        // the live lists (printPhotons' compaction keeps weight != 0 over the whole pool): the weight column starts from zero
+        for (int f = 0; f < F - 1; ++f)
+            HIPCHK(c, hipMemsetAsync(reinterpret_cast<char *>(c->ph.weight) + fq.capture_delta + (long long)f * fq.capture_stride, 0,
+                                     sizeof(double) * (size_t)c->ph.n, c->stream));
     }
     long long per_frame_cap = 32768;             // passes one list may take per frame and launch (run_ranks' bound on a launch's duration)
     if (const char *e = getenv("MCRAT_HIP_RANK_LAUNCH_CAP")) per_frame_cap = atoll(e) > 0 ? atoll(e) : per_frame_cap;

@@ -352,4 +352,6 @@ def test_two_hydro_frames_per_launch_write_the_files_of_one_frame_per_launch(hip
                         assert h5.mcrat_host_h5_read((path + "mc_proc_%d.h5" % r).encode(), str(F).encode(), name.encode(), is_char, buf.ctypes.data,
                                                      one["n"][r], C.byref(n)) == 0
                         got.append(buf[:n.value].copy())
-                    assert len(got[0]) == len(got[1]) > 0 and np.array_equal(got[0], got[1]), (r, F, name)
+                    bad = np.nonzero(got[0] != got[1])[0] if len(got[0]) == len(got[1]) else None
+                    assert len(got[0]) == len(got[1]) > 0 and np.array_equal(got[0], got[1]), (r, F, name, len(got[0]), len(got[1]), one["n"][r],
+                                                                                                 None if bad is None else (len(bad), bad[:5], bad[-5:]))
