@@ -258,12 +258,14 @@ def test_restarted_rank_continues_from_its_checkpoint(hip, tmp_path):
         libc.free(C.c_void_p(l.photons))
 
 
+@pytest.mark.parametrize("late", [0, 1], ids=["all-join-at-0", "two-join-at-1"])
 @pytest.mark.parametrize("sync_output", [0, 1], ids=["writer-thread", "sync-output"])
-def test_two_hydro_frames_per_launch_write_the_files_of_one_frame_per_launch(hip, tmp_path, sync_output):
+def test_two_hydro_frames_per_launch_write_the_files_of_one_frame_per_launch(hip, tmp_path, sync_output, late):
     """mcrat_host_pool_config.stage_ctx: frame F + 1 staged on a second context for what the photons can reach from frame F, every list through both
     frames in ONE launch (a list that is through F goes on in F + 1 while others are still in F: mcrat.c:566-934, the ranks' own frame loops), each
     frame's files written from the lists as that frame left them.  Four ranks of two injection radii that all join at frame 0 and run to frame 5:
-    launches (0,1) (2,3) (4,5).  Against the same run one frame per launch: every mc_proc dataset and every checkpoint record equal (but for
+    launches (0,1) (2,3) (4,5); with two of them joining at frame 1: (0) alone -- a rank joins at 1 --, then (1,2) (3,4) and (5).  Against the same run
+    one frame per launch: every mc_proc dataset and every checkpoint record equal (but for
     nearest_block_index, which numbers the cells of whatever slab was read -- here a wider one), the same scattering counts in the logs."""
     from mcrat_amd.host import binding as B
     host, h5 = B.host(), B.host_h5()
@@ -282,7 +284,8 @@ def test_two_hydro_frames_per_launch_write_the_files_of_one_frame_per_launch(hip
             k.myid, k.angle_id, k.angle_procs = r, r, R
             k.theta_jmin_thread, k.theta_jmax_thread, k.ph_weight_suggest = 0.02 * (r % 2), 0.02 * (r % 2) + 0.05, 1e50
             k.inj_radius = 1e12 if r < 2 else 1.2e12
-            k.framestart, k.frm2, k.rng_seed, k.rng_stream = 0, 0, 4242, r
+            k.framestart = k.frm2 = late * (r % 2)
+            k.rng_seed, k.rng_stream = 4242, r
             d = str(tmp_path / ("%s_%d" % (tag, r))) + "/"
             os.makedirs(d)
             k.mc_dir = d.encode()
@@ -323,11 +326,19 @@ def test_two_hydro_frames_per_launch_write_the_files_of_one_frame_per_launch(hip
         return out
     one = run("one", False)
     two = run("two", True)
-    assert one["launches"] == 6 and one["two"] == 0 and two["launches"] == 3 and two["two"] == 3
-    assert [(f, st) for f, inj, st, lo, hi in two["reads"] if not inj] == [(0, False), (1, True), (2, False), (3, True), (4, False), (5, True)]
+    assert one["launches"] == 6 and one["two"] == 0
+    staged_reads = [(f, st) for f, inj, st, lo, hi in two["reads"] if not inj]
+    if late:
+        assert two["launches"] == 4 and two["two"] == 2
+        assert staged_reads == [(0, False), (1, False), (2, True), (3, False), (4, True), (5, False)]
+    else:
+        assert two["launches"] == 3 and two["two"] == 3
+        assert staged_reads == [(0, False), (1, True), (2, False), (3, True), (4, False), (5, True)]
     reach = 2.99792458e10 / FPS
-    for (f, inj, st, lo, hi), (f0, inj0, st0, lo0, hi0) in zip([x for x in two["reads"] if not x[1]][0::2], [x for x in two["reads"] if not x[1]][1::2]):
-        assert lo0 == pytest.approx(max(lo - reach, 0)) and hi0 == pytest.approx(hi + reach) and f0 == f + 1
+    plain = [x for x in two["reads"] if not x[1]]
+    for a_, b_ in zip(plain, plain[1:]):
+        if b_[2]:                                                                   # a staged read: the pool's slab of the frame before, widened
+            assert b_[3] == pytest.approx(max(a_[3] - reach, 0)) and b_[4] == pytest.approx(a_[4] + reach) and b_[0] == a_[0] + 1 and not a_[2]
     assert one["scatt"] == two["scatt"] and sum(one["scatt"]) > 200 and one["t"] == two["t"] and one["n"] == two["n"]
     head = 4 + 1 + 4 + 4
     for r in range(R):
@@ -341,9 +352,9 @@ def test_two_hydro_frames_per_launch_write_the_files_of_one_frame_per_launch(hip
                     assert np.array_equal(ra[col], rb[col], equal_nan=ra[col].dtype.kind == "f"), (r, col)
         la, lb = open(a + "mc_output_%d.log" % r).read(), open(b + "mc_output_%d.log" % r).read()
         pick = lambda t: [l for l in t.splitlines() if "scatterings in this frame" in l or "Working on" in l or "propagating" in l]
-        assert pick(la) == pick(lb) and len(pick(la)) == 3 * (LASTF + 1) + 1          # (+ the injection frame's own "Working on Frame")
+        assert pick(la) == pick(lb) and len(pick(la)) == 3 * (LASTF + 1 - late * (r % 2)) + 1     # (+ the injection frame's own "Working on Frame")
         if h5 is not None:
-            for F in range(LASTF + 1):
+            for F in range(late * (r % 2), LASTF + 1):
                 for name, is_char in (("P0", 0), ("P3", 0), ("R0", 0), ("R2", 0), ("COMV_P0", 0), ("S1", 0), ("S3", 0), ("NS", 0), ("PW", 0), ("PT", 1)):
                     got = []
                     for path in (a, b):
