@@ -312,3 +312,53 @@ def test_captured_frames_are_the_lists_as_each_frame_left_them(hip, monkeypatch,
         q.pool_select_frame(F - 1)                                                  # the last frame is the live lists
     ref.close()
     q.close()
+
+
+def test_a_plan_with_staged_frames_in_table_mode(hip):
+    """TAU_CALCULATION == TABLE: the cross-section table travels with each staged frame's context (its HydroDev carries the table); a context without
+    one is refused"""
+    from tests.test_gpu_pool import _hot_table
+    tab = _hot_table()
+    lens = [300, 700, 512]
+    frame, cfg, subs, streams = _setup(hip, lens)
+    F, R = 2, len(lens)
+    fps = frame["fps"]
+    later = _evolved(frame, 1)
+
+    def pool_of(fr):
+        e = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], tau_calculation=hip.TAU_TABLE)
+        e.set_hot_cross_section(tab)
+        e.set_hydro(fr)
+        return e
+
+    def filled():
+        e = pool_of(frame)
+        e.pool_create(R, 768)
+        for r in range(R):
+            e.pool_rank(r, streams[r])
+        e.pool_set_photons(list(range(R)), [synth.photons_to_aos(s, hip.PHOTON_DTYPE) for s in subs])
+        return e
+    holder = pool_of(later)
+    seeds = np.array([[5 + r + 1000003 * f for r in range(R)] for f in range(F)], dtype=np.uint64)
+    open_ = np.ones((F, R), dtype=np.int32)
+    frame_end = np.array([[(f + 1) / fps for r in range(R)] for f in range(F)])
+    ref = filled()
+    t_now = [0.0] * R
+    for f in range(F):
+        if f:
+            ref.share_hydro(holder)
+        for r in range(R):
+            ref.views[r].begin_frame(int(seeds[f][r]), t_now[r], (f + 1) / fps - t_now[r])
+        ref.run(0)
+        t_now = [ref.views[r].frame_statistics().time_now for r in range(R)]
+    q = filled()
+    got = q.pool_run_frames(open_, seeds, np.zeros((F, R)), frame_end.copy(), frame_end=frame_end, chain_clock=True, hydro=[None, holder])
+    assert sum(got[f][r].frame_scatt_cnt for f in range(F) for r in range(R)) > 0
+    for r in range(R):
+        _same_photons(q.views[r].get_photons(), ref.views[r].get_photons(), r)
+    bare = hip.Engine(cfg["dimensions"], cfg["geometry"], cfg["stokes"], tau_calculation=hip.TAU_TABLE)
+    bare.set_hydro(later)                                                           # no table on this one
+    with pytest.raises(hip.McratHipError):
+        q.pool_run_frames(open_, seeds, np.zeros((F, R)), frame_end.copy(), frame_end=frame_end, chain_clock=True, hydro=[None, bare])
+    for e in (bare, q, ref, holder):
+        e.close()
