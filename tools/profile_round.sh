@@ -11,7 +11,8 @@ if [[ $part == *a* ]]; then
 echo "== bench, no profiler"
 python3 bench.py > $out/bench.json 2> $out/bench.err; echo "exit=$?"
 echo "== kernel trace of the default bench command (frame queue: the timed region is ONE launch of rank_loop_kernel; the per-dispatch trace of that kernel is kept)"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_default -- python3 bench.py --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_default.json 2> $out/kt_default.err; echo "exit=$?"
+# (--warmup 20: the warm-up is then a 20-frame launch like the timed one, so the --stats average of the queue kernel IS the duration of such a launch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_default -- python3 bench.py --steps 20 --warmup 20 --no-cpu-baseline --host-driver 0 --other-mode 0 --shared-clock-rounds 0 > $out/kt_default.json 2> $out/kt_default.err; echo "exit=$?"
 python3 tools/queue_dispatches.py $out/kt_default rank_loop_kernel $out/queue_dispatches.csv
 find $out/kt_default -name "*kernel_trace.csv" -delete
 echo "== kernel trace, one launch per frame on one pool (round 3's kernel-alone figure)"
