@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     // the slow-path queue shares memory with the event walk's sorted list: the queue is empty before the list is written
     static_assert(sizeof(sh.list) >= sizeof(int) * RANK_QCAP, "queue fits into the sorted-list storage");
     int *const s_q = reinterpret_cast<int *>(sh.list);
-    const int tid = threadIdx.x, lane = tid & 63;
+    int tid = threadIdx.x, lane = tid & 63;                   // (not const: the queue builds launder them between two items, see the loop below)
     const bool queued = QUEUE ? lay.fq.n_frames > 0 : false;
     // One list through one frame: the whole loop of mcrat.c:761-851.  Without a queue the workgroup does this once, for list blockIdx.x, from the
     // LoopState begin_frame left in states[]; with one (launch.hpp, FrameQueueDev) for one (frame, list) item after the other, each from the item's seed and clock.
@@ -1707,6 +1707,12 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
     };   // list_frame
 
     // ---- which list, which frame
+    // A queue launch's workgroups are persistent: one takes item after item from its XCD's queue until that is empty -- a workgroup per item left 13 %
+    // of the wave slots empty between a workgroup's end and its successor's start (SQ_WAVE_CYCLES of the launch against 2048 slots x its duration).
+    // The loop must not let the compiler carry per-thread values from one item to the next (hoisted out of the loop they live through the whole
+    // body: the first persistent form of this kernel paid 37 spilled registers for that): the thread index is laundered at the top of every turn.
+    for (;;) {
+    if constexpr (QUEUE) { asm volatile("" : "+v"(tid)); lane = tid & 63; }
     int rank = blockIdx.x, item = -1;
     if (queued) {
         // The k-th workgroup to START takes the k-th open item (frame-major): whatever order the hardware starts workgroups in, the workgroup of a
@@ -1721,7 +1727,7 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             xcc &= (unsigned)(FRAME_QUEUE_XCDS - 1);
             const unsigned k = atomicAdd(lay.fq.ticket + xcc * FRAME_TICKET_STRIDE, 1u);
-            int it = k < (unsigned)(lay.fq.order_off[xcc + 1] - lay.fq.order_off[xcc]) ? lay.fq.order[lay.fq.order_off[xcc] + (int)k] : -1;
+            int it = k < (unsigned)(lay.fq.order_off[xcc + 1] - lay.fq.order_off[xcc]) ? lay.fq.order[lay.fq.order_off[xcc] + (int)k] : -2;   // -2: the queue is empty
             const int f = it / lay.n_ranks, r = it - f * lay.n_ranks;
             if (it >= 0 && f > 0 && lay.fq.items[it - lay.n_ranks].open) {
                 unsigned d = 0;
@@ -1744,7 +1750,8 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
         }
         __syncthreads();
         item = __builtin_amdgcn_readfirstlane(s_item);
-        if (item < 0) return;
+        if (item == -2) return;                                // the queue is empty
+        if (item < 0) { __syncthreads(); continue; }           // (its list's previous frame stalled: the host goes on from there; on to the next item)
         rank = item % lay.n_ranks;
     }
     if constexpr (QUEUE) {
@@ -1766,6 +1773,9 @@ __global__ __launch_bounds__(RANK_BLOCK, RANK_WAVES_PER_SIMD) void rank_loop_ker
             // (a frame that ran into the launch's pass limit is not through: FRAME_STALLED | frame tells the list's later items to give up)
             __hip_atomic_store(&lay.fq.frames_done[rank], st.done == LOOP_DONE ? frame + 1u : (FRAME_STALLED | frame), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    if (!(QUEUE && queued)) break;
+    __syncthreads();
     }
 }
 
@@ -2517,6 +2527,14 @@ hipError_t launch_rank_loop(const KernelConfig &kc, const PhotonDev &ph, const H
             if (block != 256 || lds_slots <= 0) return;
             auto launch_q = [&](auto kernel) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { (void)hipGetLastError(); return; }
+                // persistent workgroups: as many as the device holds at once (they are dealt to the XCDs round-robin, an eighth each); more would only
+                // start, find their queue empty and leave
+                int per_cu = 0, cus = 256, dev = 0, grid = n_open;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kernel), 256, dyn) == hipSuccess && per_cu > 0 &&
+                    hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+                    grid = std::min(n_open, per_cu * cus);
+                else
+                    (void)hipGetLastError();
                 kernel<<<dim3(grid), dim3(256), dyn, stream>>>(ph, hy, states, key, lay, max_passes, lds_slots);
                 queue_launched = true;
             };
