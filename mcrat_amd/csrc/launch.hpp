@@ -38,10 +38,10 @@ hipError_t launch_tape_pass(const KernelConfig &kc, const PhotonDev &ph, const H
 // cs_replace_pool_kernel after every pass it has to look at
 // The frame queue (round 4): ONE launch takes every list through SEVERAL hydro frames.  The reference's ranks are asynchronous processes, each in
 // its own frame loop (mcrat.c:457-479, :566-934); a launch per hydro frame makes them wait for each other at every frame's end.  A queue launch has
-// one workgroup per (frame, list) item, and the k-th workgroup to start on an XCD takes the k-th open item of that XCD's lists in frame-major order
-// (`order`, `ticket`): a list that is through frame f starts f + 1 as soon as a workgroup slot frees up, while other lists are still in f.  The item of a list whose previous
-// frame is still running waits for it (frames_done; the earlier item's workgroup started earlier and depends on nothing later, so this cannot
-// deadlock).  Every list sees exactly the frames it would have seen one launch at a time: the same seeds, clocks, passes and photons
+// as many persistent workgroups as the device holds; each draws (frame, list) items from the queue of the XCD it runs on until that is empty, the k-th
+// draw on an XCD getting the k-th open item of that XCD's lists in frame-major order (`order`, `ticket`): a list that is through frame f starts f + 1 as
+// soon as a workgroup is free, while other lists are still in f.  The item of a list whose previous frame is still running waits for it (frames_done;
+// that item was drawn earlier, by a workgroup that is running and depends on nothing later, so this cannot deadlock).  Every list sees exactly the frames it would have seen one launch at a time: the same seeds, clocks, passes and photons
 // (tests/test_gpu_frame_queue.py).
 struct FrameItem {                   // list r in frame f: item f * n_ranks + r
     unsigned long long seed;         // the list's seed of this frame (gsl_rng_get, mcrat.c:701)

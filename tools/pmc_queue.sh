@@ -2,10 +2,12 @@
 # PMC passes over the frame-queue launch of rank_loop_kernel (tools/queue_bench.py: cfg2, 1e6 photons as 1025 lists, K frames in one launch):
 #   tools/pmc_queue.sh [frames]      (through gpurun; the table goes to gpurun_out/pmcq/summary.txt)
 # Counters in their own runs with --kernel-trace only; the program follows `--` directly.  Of the dispatches of rank_loop_kernel the one with the
-# largest grid is the K-frame queue launch (one workgroup per (frame, list) item); the one-frame launches of the same run are listed beside it.
+# 512-workgroup grid is the K-frame queue launch (persistent workgroups, as many as the device holds; warm-up and timed call alike); the one-frame
+# launches of the same run (1025 workgroups) are listed beside it.
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 K=${1:-20}
+export QUEUE_BENCH_WARM_FRAMES=$K     # (the queue kernel's two launches -- warm-up and timed -- are then the same work: persistent workgroups, one grid)
 rm -rf gpurun_out/pmcq && mkdir -p gpurun_out/pmcq
 i=0
 for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \

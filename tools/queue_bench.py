@@ -87,7 +87,9 @@ def main():
         a = np.frombuffer(st, dtype=np.dtype([(n_, "<i8") for n_ in ("it", "ps", "sc")] + [("rest", "V%d" % (C.sizeof(engine.FrameStats) - 24))]))
         return int(a["sc"].sum()), int(a["ps"].sum()), dt
     try:
-        queue(2, SEED + 1000)
+        # (QUEUE_BENCH_WARM_FRAMES: the warm-up call's frames -- tools/pmc_queue.sh asks for as many as the timed call, so that the two launches of the
+        # queue kernel, which have the same grid since the workgroups are persistent, are the same work and the counters' mean is one launch's)
+        queue(int(os.environ.get("QUEUE_BENCH_WARM_FRAMES", "2")), SEED + 1000)
         ev_c, ps_c, dt = queue(K, SEED)
         out["queue_1pool_ms"] = dt / K * 1e3
         out["queue_frac"] = 110.0 * ps_c / dt / 8e12
